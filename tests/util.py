@@ -1,0 +1,41 @@
+"""Shared helpers for the test-suite (golden loading, tolerance reports)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    d = {k: z[k] for k in z.files if k != "meta"}
+    meta = json.loads(bytes(z["meta"]).decode())
+    return d, meta
+
+
+def batch_inputs(d, torch_=True):
+    b = {k[3:]: d[k] for k in d if k.startswith("in_")}
+    b["num_graphs"] = int(len(b["num_nodes_per_graph"]))
+    if torch_:
+        b = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in b.items()}
+    return b
+
+
+def rel_err(a, ref):
+    """max |a-ref| / max|ref|  (per-tensor scale; the tolerance form of SURVEY.md 7.2)."""
+    a = np.asarray(a, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    scale = max(np.abs(ref).max(), 1e-30) if ref.size else 1.0
+    return float(np.abs(a - ref).max() / scale) if ref.size else 0.0
+
+
+def assert_close(a, ref, rtol, what=""):
+    a = np.asarray(a)
+    ref = np.asarray(ref)
+    assert a.shape == ref.shape, f"{what}: shape {a.shape} vs {ref.shape}"
+    e = rel_err(a, ref)
+    assert e <= rtol, f"{what}: max|d|/max|ref| = {e:.3e} > {rtol:.1e}"
+    return e
