@@ -1,0 +1,212 @@
+/* tsdiff_hip.h -- C ABI of libtsdiff_hip.so: the MI355X (gfx950) implementation of the
+ * TSDiff score-network denoising hot path.
+ *
+ * Every entry point replaces one Python-level operation of the reference
+ * (seonghann/tsdiff, paths relative to the reference root) and is what a
+ * ctypes / cffi binding on the reference side would bind:
+ *
+ *   tsd_topology_*      models/common.py:115-202   _extend_ts_graph_order (pos-independent part)
+ *   tsd_geometry_build  models/common.py:205-223,328-384 + models/epsnet/condensenc.py:117-154
+ *                       + models/geometry.py:18-19 (radius graph, union, types, edge_length)
+ *   tsd_node_embed      models/epsnet/condensenc.py:193-198
+ *   tsd_edge_embed      models/epsnet/condensenc.py:156-176, models/encoder/edge.py:58-68
+ *   tsd_cfconv_layer    models/encoder/schnet.py:88-107 (filter MLP + message + scatter-add, fused)
+ *   tsd_cfconv_aggregate models/encoder/schnet.py:102,106 (MessagePassing aggr="add" alone)
+ *   tsd_node_update     models/encoder/schnet.py:103,123-127,223-224 (lin2, ssp, lin, residual, next lin1)
+ *   tsd_pair_output     models/common.py:226-229 + models/epsnet/condensenc.py:236-237
+ *   tsd_eq_transform*   models/geometry.py:22-30
+ *   tsd_sampler_step    models/sampler.py:208-251 (clip_norm, LD/DDPM update, NaN flag, center_pos)
+ *   tsd_score_forward   models/epsnet/condensenc.py:178-239 + models/sampler.py:58-116 (M checkpoints)
+ *   tsd_sampler_run     models/sampler.py:187-254 (the 5000-step loop, device resident, hipGraph replay)
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in _host;
+ *   - the library never allocates or frees device memory: outputs and scratch are caller
+ *     allocated (torch's caching allocator on the Python side);
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), performs no
+ *     host synchronisation and returns 0 on success or a negative TSD_ERR_* code;
+ *     tsd_last_error() returns a thread-local message for the last failure;
+ *   - floating point is fp32 end to end (fp32 MFMA, exact-f32 FMA chains); indices at this
+ *     boundary are int32 except where the reference surface hands over int64 tensors
+ *     (bond_index, bond_type, atom_type, r_feat, p_feat);
+ *   - hidden size H must be 64, 128 or 256 (reference config: 256).
+ */
+#ifndef TSDIFF_HIP_H
+#define TSDIFF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSD_OK 0
+#define TSD_ERR_INVALID (-1)     /* bad argument (shape, hidden size, null pointer) */
+#define TSD_ERR_HIP (-2)         /* a HIP runtime call failed; see tsd_last_error() */
+#define TSD_ERR_UNSUPPORTED (-3) /* e.g. a graph with more than TSD_MAX_GRAPH_NODES atoms */
+#define TSD_ERR_NAN (-4)         /* reported through status words, mapped to FloatingPointError */
+
+#define TSD_EDGE_TILE 32         /* edges per workgroup tile of every per-edge kernel */
+#define TSD_NODE_TILE 32         /* nodes per workgroup tile of the per-node kernels */
+#define TSD_MAX_GRAPH_NODES 255  /* two u8 hop matrices of n*n must fit in the 160 KiB LDS */
+#define TSD_NUM_BOND_TYPES 22    /* len(rdkit BondType.names), reference utils/chem.py:21 */
+
+/* status word bits (device int32 written by kernels, read by the caller when it chooses) */
+#define TSD_STATUS_NAN 1           /* NaN in positions after an update (sampler.py:248-250) */
+#define TSD_STATUS_BAD_BOND 2      /* bond across graphs / self loop / index out of range */
+#define TSD_STATUS_ASYMMETRIC 4    /* bond list is not symmetric (A0 contract: both directions) */
+
+typedef struct tsd_model_cfg {
+    int32_t hidden;          /* config.hidden_dim == config.encoder.hidden_dim */
+    int32_t num_convs;       /* config.encoder.num_convs */
+    int32_t feat_dim;        /* config.feat_dim */
+    int32_t edge_order;      /* config.edge_order (encoder graph) */
+    int32_t pred_edge_order; /* config.pred_edge_order (output graph) */
+    float edge_cutoff;       /* config.edge_cutoff (radius graph) */
+    float conv_cutoff;       /* config.encoder.cutoff (CFConv mask C) */
+} tsd_model_cfg;
+
+/* One extended-graph edge list in device memory (capacity = num_pairs entries).
+ * Sorted row-major by (src, dst) exactly like the reference's edge_index. */
+typedef struct tsd_edges {
+    int32_t* count;    /* [1]   number of edges E */
+    int32_t* row_ptr;  /* [N+1] CSR over src */
+    int32_t* src;      /* [cap] edge_index[0] */
+    int32_t* dst;      /* [cap] edge_index[1] */
+    float* dist;       /* [cap] edge_length */
+    uint8_t* type_r;   /* [cap] edge type in the reactant graph (0, 1..21, 22+hop-1) */
+    uint8_t* type_p;   /* [cap] same for the product graph */
+    int32_t* pair_id;  /* [cap] index of the edge's ordered pair in the topology */
+} tsd_edges;
+
+const char* tsd_version(void);
+const char* tsd_last_error(void);
+
+/* ---- weights ---------------------------------------------------------------------------
+ * `raw` is the reference state_dict flattened, each tensor row-major [out,in], in this order:
+ *   edge_encoder.bond_emb.weight, edge_encoder.mlp.layers.0.{weight,bias}, .1.{weight,bias},
+ *   atom_embedding.weight, atom_feat_embedding.weight,
+ *   for l in 0..L-1: encoder.interactions.l.conv.lin1.weight, conv.lin2.{weight,bias},
+ *                    conv.nn.0.{weight,bias}, conv.nn.2.{weight,bias}, lin.{weight,bias},
+ *   grad_dist_mlp.layers.{0,1,2}.{weight,bias}, edge_cat.0.{weight,bias}, edge_cat.2.{weight,bias}
+ * `packed` receives the MFMA-friendly layout ([k/4][out][k%4] for every dense matrix). */
+size_t tsd_raw_weight_floats(const tsd_model_cfg* cfg);
+size_t tsd_packed_weight_floats(const tsd_model_cfg* cfg);
+int tsd_pack_weights(const tsd_model_cfg* cfg, const float* raw, float* packed, void* stream);
+
+/* ---- topology (once per batch; pos independent) -------------------------------------------
+ * graph_ptr [G+1]: node offsets; pair_base [G+1]: prefix sums of n_g*(n_g-1).
+ * Outputs: node_graph [N], pair_ptr [N+1], pair_code [P] (u16: bondR | bondP<<5 | hopR<<10 | hopP<<13),
+ * status [1] (TSD_STATUS_* bits OR-ed in). max_order = max(edge_order, pred_edge_order) <= 7. */
+int tsd_topology_build(int32_t num_nodes, int32_t num_graphs, int32_t num_pairs, int64_t num_bonds,
+                       const int32_t* graph_ptr, const int32_t* pair_base,
+                       const int64_t* bond_index /* [2,num_bonds] */, const int64_t* bond_type,
+                       int32_t max_order, int32_t max_graph_nodes_host,
+                       int32_t* node_graph, int32_t* pair_ptr, uint16_t* pair_code,
+                       int32_t* status, void* stream);
+
+/* ---- geometry (every step) ---------------------------------------------------------------
+ * Builds the order-`edge_order` (enc) and order-`pred_edge_order` (out) edge lists of `pos`.
+ * scratch: int32 [2*(N+1) + 2*P]. out2enc [P]: enc edge index of every out edge.
+ * pair2out [P]: out edge index of every ordered pair, -1 when the pair is not an out edge. */
+size_t tsd_geometry_scratch_ints(int32_t num_nodes, int32_t num_pairs);
+int tsd_geometry_build(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_graphs, int32_t num_pairs,
+                       const float* pos, const int32_t* graph_ptr, const int32_t* node_graph,
+                       const int32_t* pair_ptr, const uint16_t* pair_code,
+                       tsd_edges enc, tsd_edges out, int32_t* out2enc, int32_t* pair2out,
+                       int32_t* scratch, void* stream);
+
+/* ---- network pieces (one checkpoint each; `w` = packed weights of that checkpoint) --------- */
+int tsd_node_embed(const tsd_model_cfg* cfg, const float* w, int32_t num_nodes,
+                   const int64_t* atom_type, const int64_t* r_feat, const int64_t* p_feat,
+                   float* z /* [N,H] */, void* stream);
+
+int tsd_edge_embed(const tsd_model_cfg* cfg, const float* w, int32_t capacity, tsd_edges edges,
+                   float* edge_attr /* [cap,H] */, void* stream);
+
+/* x1 = lin1_layer(h) for layer 0 (no bias). */
+int tsd_node_lin1(const tsd_model_cfg* cfg, const float* w, int32_t layer, int32_t num_nodes,
+                  const float* h, float* x1, void* stream);
+
+/* Fused CFConv message pass of `layer`: W = nn(edge_attr) * C; agg[i] = sum_{e in row i} x1[dst e] * W_e.
+ * Complete rows go to agg [N,H]; rows cut by a tile boundary go to part [ceil(cap/32),2,H]
+ * (deterministic two-level reduction, finished by tsd_node_update). */
+int tsd_cfconv_layer(const tsd_model_cfg* cfg, const float* w, int32_t layer, int32_t capacity,
+                     tsd_edges enc, const float* edge_attr, const float* x1,
+                     float* agg, float* part, void* stream);
+
+/* The scatter-add alone with a materialised filter W [E,H] (T5; HBM-bound, config C5):
+ * out[i] = sum_{e: row_ptr[i] <= e < row_ptr[i+1]} x1[dst[e]] * W[e]. */
+int tsd_cfconv_aggregate(int32_t hidden, int32_t num_nodes, const int32_t* row_ptr, const int32_t* dst,
+                         const float* W, const float* x1, float* out, void* stream);
+
+/* h += lin(ssp(lin2(agg) )); if next_layer >= 0 also x1 = lin1_{next_layer}(h). */
+int tsd_node_update(const tsd_model_cfg* cfg, const float* w, int32_t layer, int32_t next_layer,
+                    int32_t num_nodes, const int32_t* enc_row_ptr, const float* agg, const float* part,
+                    float* h, float* x1, void* stream);
+
+int tsd_pair_output(const tsd_model_cfg* cfg, const float* w, int32_t capacity, tsd_edges out,
+                    const float* h, const float* edge_attr_out, float* edge_inv /* [cap] */, void* stream);
+
+/* ---- distance score -> Cartesian score -------------------------------------------------- */
+/* generic (any edge list, int64 like the reference surface); fp32 atomics. score must be zeroed. */
+int tsd_eq_transform(int32_t num_nodes, int64_t num_edges, const float* score_d, const float* pos,
+                     const int64_t* edge_index /* [2,E] */, const float* edge_length,
+                     float* score_pos /* [N,3] */, void* stream);
+
+/* ---- whole forward for M checkpoints ---------------------------------------------------- */
+typedef struct tsd_batch {
+    int32_t num_nodes, num_graphs, num_pairs, num_models;
+    const int32_t* graph_ptr;   /* [G+1] */
+    const int32_t* node_graph;  /* [N] */
+    const int32_t* pair_ptr;    /* [N+1] */
+    const uint16_t* pair_code;  /* [P] */
+    const float* weights;       /* [M, packed_floats] */
+    const float* z;             /* [M, N, H] node embeddings (tsd_node_embed), pos independent */
+    tsd_edges enc, out;
+    int32_t* out2enc;           /* [P] */
+    int32_t* pair2out;          /* [P] */
+    int32_t* geo_scratch;       /* tsd_geometry_scratch_ints */
+    float* workspace;           /* tsd_forward_workspace_floats */
+    float* edge_inv;            /* [M, P] per-checkpoint output */
+} tsd_batch;
+
+size_t tsd_forward_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs,
+                                    int32_t num_models);
+/* geometry + M forwards; edge_inv[m] valid for the first *out.count entries. */
+int tsd_score_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* pos, void* stream);
+
+/* mean over checkpoints in the reference's order: ((e0+e1)+...)/M -> edge_inv_mean [P] */
+int tsd_ensemble_mean(int32_t num_models, int32_t num_pairs, const int32_t* count,
+                      const float* edge_inv, float* edge_inv_mean, void* stream);
+
+/* eq_transform on the library's own out-edge list (deterministic, no atomics):
+ * score[i] = sum_{e in row i} u_e s_e + sum_{e in row i} u_e s_{(dst e, i)}. */
+int tsd_eq_transform_rows(int32_t num_nodes, const float* pos, const int32_t* pair_ptr,
+                          const int32_t* graph_ptr, const int32_t* node_graph,
+                          tsd_edges out, const int32_t* pair2out, const float* score_d,
+                          float* score_pos, void* stream);
+
+/* ---- sampler ------------------------------------------------------------------------- */
+/* per-step coefficients, computed by the host exactly as the reference's fp32 tensor ops do:
+ * LD   (kind 0): c[0]=step_size, c[1]=sigma_i, c[2]=sqrt(2*step_size)
+ * DDPM (kind 1): c[0]=sqrt(at), c[1]=sqrt(1/at), c[2]=sqrt(1/at-1), c[3]=sqrt(atm1)*beta_t,
+ *                c[4]=sqrt(1-beta_t)*(1-atm1), c[5]=1-at, c[6]=mask*exp(0.5*log(beta_t)), c[7]=sqrt(atm1) */
+#define TSD_STEP_COEFS 8
+int tsd_sampler_step(int32_t kind, int32_t num_nodes, int32_t num_graphs, const int32_t* graph_ptr,
+                     const float* score_pos, const float* noise, const float* coefs /* [8] device */,
+                     float clip, float clip_pos /* <0: none */, float* pos, int32_t* status, void* stream);
+
+/* The device-resident sampling loop: n_steps x (geometry, M forwards, mean, eq_transform,
+ * update, centre).  coefs [n_steps,8], noises [n_steps,N,3]; traj [n_steps,N,3] or NULL.
+ * use_graph != 0 captures one step into a hipGraph and replays it. */
+int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t kind, int32_t n_steps,
+                    const float* coefs, const float* noises, float clip, float clip_pos,
+                    float* pos, float* traj, float* scratch /* [P + 3N] */, int32_t* status,
+                    int32_t use_graph, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSDIFF_HIP_H */

@@ -1,0 +1,86 @@
+"""CPU: the C-ABI library loads and exports every symbol include/tsdiff_hip.h declares; host-side
+logic that needs no GPU (config mapping, state_dict key compatibility, error mapping)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from tests.util import ROOT
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "tsdiff_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(tsd_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from tsdiff_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _lib.load()
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/tsdiff_hip.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in tsdiff_amd/_lib.py"
+    assert set(_lib.SIGNATURES) == set(names)
+    assert b"gfx950" in lib.tsd_version()
+
+
+def test_weight_sizes_match_reference_parameter_count():
+    from tsdiff_amd import _lib, engine, synth
+    lib = _lib.load()
+    cfg = engine.make_cfg(synth.DEFAULT_MODEL_CONFIG)
+    # 2 770 305 trainable fp32 parameters in the reference model
+    assert lib.tsd_raw_weight_floats(C.byref(cfg)) == 2770305
+    assert lib.tsd_packed_weight_floats(C.byref(cfg)) >= 2770305
+    bad = engine.make_cfg(synth.DEFAULT_MODEL_CONFIG)
+    bad.hidden = 100
+    assert lib.tsd_raw_weight_floats(C.byref(bad)) == 0
+    assert b"unsupported" in lib.tsd_last_error()
+
+
+def test_state_dict_keys_match_reference():
+    """keys / shapes recorded from the reference model, including aliases"""
+    from tsdiff_amd import synth
+    from tsdiff_amd.epsnet import get_model
+    from tsdiff_amd.utils import AttrDict
+    model = get_model(AttrDict(synth.DEFAULT_MODEL_CONFIG))
+    sd = model.state_dict()
+    shapes = synth.param_shapes(synth.DEFAULT_MODEL_CONFIG)
+    for k, (shape, _) in shapes.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+    assert tuple(sd["betas"].shape) == (5000,) and tuple(sd["alphas"].shape) == (5000,)
+    for alias in ("model_embedding.0.weight", "model_embedding.1.weight", "model.0.bond_emb.weight",
+                  "model.0.mlp.layers.1.bias", "model.1.interactions.6.conv.nn.2.weight",
+                  "model.2.layers.2.weight"):
+        assert alias in sd, alias
+    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    assert n_train == 2770305
+    with pytest.raises(NotImplementedError):
+        get_model(AttrDict({**synth.DEFAULT_MODEL_CONFIG, "network": "nope"}))
+
+
+def test_product_path_has_no_cpu_fallback():
+    from tsdiff_amd import _lib, synth
+    from tsdiff_amd.epsnet import get_model
+    from tsdiff_amd.utils import AttrDict
+    model = get_model(AttrDict(synth.small_model_config(64, 2)))
+    b = synth.wb97xd3_like_batch(2, seed=0)
+    t = {k: torch.from_numpy(v) for k, v in b.items() if hasattr(v, "shape")}
+    with pytest.raises(_lib.TsdError):
+        model(t["atom_type"], t["r_feat"], t["p_feat"], t["pos"], t["bond_index"], t["bond_type"], t["batch"],
+              torch.zeros(2, dtype=torch.long))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "tsdiff_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert "oracle" not in src.replace("# checker", ""), f"{f} mentions the oracle"

@@ -1,0 +1,156 @@
+"""ctypes binding of libtsdiff_hip.so (include/tsdiff_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, an exception is
+raised.  Build it with `python __graft_entry__.py` (or `make -C tsdiff_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtsdiff_hip.so")
+
+TSD_OK = 0
+TSD_ERR_INVALID = -1
+TSD_ERR_HIP = -2
+TSD_ERR_UNSUPPORTED = -3
+TSD_ERR_NAN = -4
+
+EDGE_TILE = 32
+MAX_GRAPH_NODES = 255
+STEP_COEFS = 8
+STATUS_NAN = 1
+STATUS_BAD_BOND = 2
+STATUS_ASYMMETRIC = 4
+
+c_i32p = C.POINTER(C.c_int32)
+c_f32p = C.POINTER(C.c_float)
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [
+        ("hidden", C.c_int32),
+        ("num_convs", C.c_int32),
+        ("feat_dim", C.c_int32),
+        ("edge_order", C.c_int32),
+        ("pred_edge_order", C.c_int32),
+        ("edge_cutoff", C.c_float),
+        ("conv_cutoff", C.c_float),
+    ]
+
+
+class Edges(C.Structure):
+    _fields_ = [
+        ("count", C.c_void_p),
+        ("row_ptr", C.c_void_p),
+        ("src", C.c_void_p),
+        ("dst", C.c_void_p),
+        ("dist", C.c_void_p),
+        ("type_r", C.c_void_p),
+        ("type_p", C.c_void_p),
+        ("pair_id", C.c_void_p),
+    ]
+
+
+class Batch(C.Structure):
+    _fields_ = [
+        ("num_nodes", C.c_int32),
+        ("num_graphs", C.c_int32),
+        ("num_pairs", C.c_int32),
+        ("num_models", C.c_int32),
+        ("graph_ptr", C.c_void_p),
+        ("node_graph", C.c_void_p),
+        ("pair_ptr", C.c_void_p),
+        ("pair_code", C.c_void_p),
+        ("weights", C.c_void_p),
+        ("z", C.c_void_p),
+        ("enc", Edges),
+        ("out", Edges),
+        ("out2enc", C.c_void_p),
+        ("pair2out", C.c_void_p),
+        ("geo_scratch", C.c_void_p),
+        ("workspace", C.c_void_p),
+        ("edge_inv", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/tsdiff_hip.h
+_P = C.c_void_p
+_CFG = C.POINTER(ModelCfg)
+SIGNATURES = {
+    "tsd_version": (C.c_char_p, []),
+    "tsd_last_error": (C.c_char_p, []),
+    "tsd_raw_weight_floats": (C.c_size_t, [_CFG]),
+    "tsd_packed_weight_floats": (C.c_size_t, [_CFG]),
+    "tsd_pack_weights": (C.c_int, [_CFG, _P, _P, _P]),
+    "tsd_topology_build": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, _P, _P, _P, _P, C.c_int32,
+                                     C.c_int32, _P, _P, _P, _P, _P]),
+    "tsd_geometry_scratch_ints": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "tsd_geometry_build": (C.c_int, [_CFG, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, Edges, Edges,
+                                     _P, _P, _P, _P]),
+    "tsd_node_embed": (C.c_int, [_CFG, _P, C.c_int32, _P, _P, _P, _P, _P]),
+    "tsd_edge_embed": (C.c_int, [_CFG, _P, C.c_int32, Edges, _P, _P]),
+    "tsd_node_lin1": (C.c_int, [_CFG, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "tsd_cfconv_layer": (C.c_int, [_CFG, _P, C.c_int32, C.c_int32, Edges, _P, _P, _P, _P, _P]),
+    "tsd_cfconv_aggregate": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "tsd_node_update": (C.c_int, [_CFG, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "tsd_pair_output": (C.c_int, [_CFG, _P, C.c_int32, Edges, _P, _P, _P, _P]),
+    "tsd_eq_transform": (C.c_int, [C.c_int32, C.c_int64, _P, _P, _P, _P, _P, _P]),
+    "tsd_forward_workspace_floats": (C.c_size_t, [_CFG, C.c_int32, C.c_int32, C.c_int32]),
+    "tsd_score_forward": (C.c_int, [_CFG, C.POINTER(Batch), _P, _P]),
+    "tsd_ensemble_mean": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "tsd_eq_transform_rows": (C.c_int, [C.c_int32, _P, _P, _P, _P, Edges, _P, _P, _P, _P]),
+    "tsd_sampler_step": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_float, C.c_float, _P,
+                                   _P, _P]),
+    "tsd_sampler_run": (C.c_int, [_CFG, C.POINTER(Batch), C.c_int32, C.c_int32, _P, _P, C.c_float, C.c_float,
+                                  _P, _P, _P, _P, C.c_int32, _P]),
+}
+
+_lib = None
+
+
+class TsdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TsdError(
+            f"{LIB_PATH} not found: the HIP extension is not built (run `python __graft_entry__.py` "
+            "or `make -C tsdiff_amd/csrc`). There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale -> loud
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code):
+    """Map a TSD_* return code to the reference's error conventions."""
+    if code == TSD_OK:
+        return
+    msg = load().tsd_last_error().decode(errors="replace")
+    if code == TSD_ERR_INVALID:
+        raise ValueError(msg)
+    if code == TSD_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if code == TSD_ERR_NAN:
+        raise FloatingPointError(msg)
+    raise TsdError(msg)
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None) as c_void_p"""
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,329 @@
+// api.hip -- the extern "C" surface of libtsdiff_hip.so (declared in include/tsdiff_hip.h) and the
+// orchestration of one score-network forward / one sampling step / the device-resident loop.
+#include <stdarg.h>
+
+#include "common.hpp"
+
+namespace tsd {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return TSD_OK;
+    set_error("HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
+    return TSD_ERR_HIP;
+}
+
+// launchers implemented in the kernel translation units
+int launch_edge_embed(const tsd_model_cfg&, const float*, int, tsd_edges, float*, hipStream_t);
+int launch_cfconv_layer(const tsd_model_cfg&, const float*, int, int, tsd_edges, const float*, const float*,
+                        float*, float*, hipStream_t);
+int launch_node_update(const tsd_model_cfg&, const float*, int, int, int, const int32_t*, const float*,
+                       const float*, float*, float*, hipStream_t);
+int launch_node_lin1(const tsd_model_cfg&, const float*, int, int, const float*, float*, hipStream_t);
+int launch_pair_output(const tsd_model_cfg&, const float*, int, tsd_edges, const float*, const float*, float*,
+                       hipStream_t);
+size_t raw_weight_floats(const tsd_model_cfg&);
+int launch_pack_weights(const tsd_model_cfg&, const float*, float*, hipStream_t);
+int launch_topology(int, int, int, int64_t, const int32_t*, const int32_t*, const int64_t*, const int64_t*, int,
+                    int, int32_t*, int32_t*, uint16_t*, int32_t*, hipStream_t);
+size_t geometry_scratch_ints(int, int);
+int launch_geometry(const tsd_model_cfg&, int, int, int, const float*, const int32_t*, const int32_t*,
+                    const int32_t*, const uint16_t*, tsd_edges, tsd_edges, int32_t*, int32_t*, int32_t*,
+                    hipStream_t);
+int launch_node_embed(const tsd_model_cfg&, const float*, int, const int64_t*, const int64_t*, const int64_t*,
+                      float*, hipStream_t);
+int launch_cfconv_aggregate(int, int, const int32_t*, const int32_t*, const float*, const float*, float*,
+                            hipStream_t);
+int launch_eq_transform_atomic(int, int64_t, const float*, const float*, const int64_t*, const float*, float*,
+                               hipStream_t);
+int launch_eq_transform_rows(int, const float*, const int32_t*, const int32_t*, const int32_t*, tsd_edges,
+                             const int32_t*, const float*, float*, hipStream_t);
+int launch_ensemble_mean(int, int, const int32_t*, const float*, float*, hipStream_t);
+int launch_sampler_step(int, int, int, const int32_t*, const float*, const float*, const float*, float, float,
+                        float*, float*, int32_t*, const int32_t*, hipStream_t);
+int launch_advance(int32_t*, hipStream_t);
+
+static int check_cfg(const tsd_model_cfg* c) {
+    TSD_REQUIRE(c != nullptr, "cfg is null");
+    TSD_REQUIRE(hidden_supported(c->hidden), "hidden=%d unsupported (64/128/256)", c->hidden);
+    TSD_REQUIRE(c->num_convs >= 1 && c->num_convs <= 64, "num_convs=%d out of range", c->num_convs);
+    TSD_REQUIRE(c->feat_dim >= 1, "feat_dim=%d", c->feat_dim);
+    TSD_REQUIRE(c->edge_order >= 1 && c->edge_order <= 7 && c->pred_edge_order >= 1 && c->pred_edge_order <= 7,
+                "edge orders (%d,%d) outside 1..7", c->edge_order, c->pred_edge_order);
+    return TSD_OK;
+}
+
+struct Workspace {
+    float *ea_enc, *ea_out, *h, *x1, *agg, *part;
+    size_t total;
+};
+
+static Workspace carve(const tsd_model_cfg& c, int N, int P, float* base) {
+    Workspace w;
+    const size_t H = c.hidden;
+    size_t o = 0;
+    auto take = [&](size_t n) { float* p = base ? base + o : nullptr; o += (n + 63) & ~size_t(63); return p; };
+    w.ea_enc = take((size_t)P * H);
+    w.ea_out = (c.edge_order != c.pred_edge_order) ? take((size_t)P * H) : w.ea_enc;
+    w.h = take((size_t)N * H);
+    w.x1 = take((size_t)N * H);
+    w.agg = take((size_t)N * H);
+    w.part = take((size_t)((P + TSD_EDGE_TILE - 1) / TSD_EDGE_TILE) * 2 * H);
+    w.total = o;
+    return w;
+}
+
+static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float* pos, hipStream_t st) {
+    const int N = b.num_nodes, G = b.num_graphs, P = b.num_pairs, M = b.num_models;
+    const size_t H = c.hidden;
+    int r;
+    if ((r = launch_geometry(c, N, G, P, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, b.enc, b.out,
+                             b.out2enc, b.pair2out, b.geo_scratch, st)))
+        return r;
+    const Workspace w = carve(c, N, P, b.workspace);
+    const size_t wfloats = weight_layout(c).total;
+    const bool same = c.edge_order == c.pred_edge_order;
+    for (int m = 0; m < M; ++m) {
+        const float* W = b.weights + (size_t)m * wfloats;
+        if ((r = launch_edge_embed(c, W, P, b.enc, w.ea_enc, st))) return r;
+        TSD_HIP(hipMemcpyAsync(w.h, b.z + (size_t)m * N * H, (size_t)N * H * sizeof(float),
+                               hipMemcpyDeviceToDevice, st));
+        if ((r = launch_node_lin1(c, W, 0, N, w.h, w.x1, st))) return r;
+        for (int l = 0; l < c.num_convs; ++l) {
+            if ((r = launch_cfconv_layer(c, W, l, P, b.enc, w.ea_enc, w.x1, w.agg, w.part, st))) return r;
+            if ((r = launch_node_update(c, W, l, (l + 1 < c.num_convs) ? l + 1 : -1, N, b.enc.row_ptr, w.agg,
+                                        w.part, w.h, w.x1, st)))
+                return r;
+        }
+        if (!same) {
+            if ((r = launch_edge_embed(c, W, P, b.out, w.ea_out, st))) return r;
+        }
+        if ((r = launch_pair_output(c, W, P, b.out, w.h, w.ea_out, b.edge_inv + (size_t)m * P, st))) return r;
+    }
+    return TSD_OK;
+}
+
+static int step_impl(const tsd_model_cfg& c, const tsd_batch& b, int kind, const float* coefs,
+                     const float* noises, float clip, float clip_pos, float* pos, float* traj, float* scratch,
+                     int32_t* status, const int32_t* step_ctr, hipStream_t st) {
+    int r;
+    float* mean = scratch;
+    float* score = scratch + (((size_t)b.num_pairs + 63) & ~size_t(63));
+    if ((r = forward_impl(c, b, pos, st))) return r;
+    if ((r = launch_ensemble_mean(b.num_models, b.num_pairs, b.out.count, b.edge_inv, mean, st))) return r;
+    if ((r = launch_eq_transform_rows(b.num_nodes, pos, b.pair_ptr, b.graph_ptr, b.node_graph, b.out, b.pair2out,
+                                      mean, score, st)))
+        return r;
+    return launch_sampler_step(kind, b.num_nodes, b.num_graphs, b.graph_ptr, score, noises, coefs, clip, clip_pos,
+                               pos, traj, status, step_ctr, st);
+}
+
+}  // namespace tsd
+
+using namespace tsd;
+
+extern "C" {
+
+const char* tsd_version(void) { return "tsdiff_hip 0.1 (gfx950, fp32 MFMA)"; }
+const char* tsd_last_error(void) { return g_err; }
+
+size_t tsd_raw_weight_floats(const tsd_model_cfg* cfg) {
+    if (check_cfg(cfg)) return 0;
+    return raw_weight_floats(*cfg);
+}
+size_t tsd_packed_weight_floats(const tsd_model_cfg* cfg) {
+    if (check_cfg(cfg)) return 0;
+    return weight_layout(*cfg).total;
+}
+int tsd_pack_weights(const tsd_model_cfg* cfg, const float* raw, float* packed, void* stream) {
+    int r = check_cfg(cfg);
+    if (r) return r;
+    TSD_REQUIRE(raw && packed, "null weight pointer");
+    return launch_pack_weights(*cfg, raw, packed, (hipStream_t)stream);
+}
+
+int tsd_topology_build(int32_t num_nodes, int32_t num_graphs, int32_t num_pairs, int64_t num_bonds,
+                       const int32_t* graph_ptr, const int32_t* pair_base, const int64_t* bond_index,
+                       const int64_t* bond_type, int32_t max_order, int32_t max_graph_nodes_host,
+                       int32_t* node_graph, int32_t* pair_ptr, uint16_t* pair_code, int32_t* status,
+                       void* stream) {
+    TSD_REQUIRE(num_nodes >= 0 && num_graphs >= 0 && num_pairs >= 0 && num_bonds >= 0, "negative size");
+    TSD_REQUIRE(graph_ptr && pair_base && node_graph && pair_ptr && status, "null pointer");
+    TSD_REQUIRE(num_pairs == 0 || pair_code, "null pair_code");
+    TSD_REQUIRE(num_bonds == 0 || (bond_index && bond_type), "null bond arrays");
+    return launch_topology(num_nodes, num_graphs, num_pairs, num_bonds, graph_ptr, pair_base, bond_index,
+                           bond_type, max_order, max_graph_nodes_host, node_graph, pair_ptr, pair_code, status,
+                           (hipStream_t)stream);
+}
+
+size_t tsd_geometry_scratch_ints(int32_t num_nodes, int32_t num_pairs) {
+    return geometry_scratch_ints(num_nodes, num_pairs);
+}
+
+int tsd_geometry_build(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_graphs, int32_t num_pairs,
+                       const float* pos, const int32_t* graph_ptr, const int32_t* node_graph,
+                       const int32_t* pair_ptr, const uint16_t* pair_code, tsd_edges enc, tsd_edges out,
+                       int32_t* out2enc, int32_t* pair2out, int32_t* scratch, void* stream) {
+    int r = check_cfg(cfg);
+    if (r) return r;
+    TSD_REQUIRE(pos && graph_ptr && node_graph && pair_ptr && scratch, "null pointer");
+    TSD_REQUIRE(enc.count && enc.row_ptr && out.count && out.row_ptr, "null edge list");
+    return launch_geometry(*cfg, num_nodes, num_graphs, num_pairs, pos, graph_ptr, node_graph, pair_ptr,
+                           pair_code, enc, out, out2enc, pair2out, scratch, (hipStream_t)stream);
+}
+
+int tsd_node_embed(const tsd_model_cfg* cfg, const float* w, int32_t num_nodes, const int64_t* atom_type,
+                   const int64_t* r_feat, const int64_t* p_feat, float* z, void* stream) {
+    int r = check_cfg(cfg);
+    if (r) return r;
+    return launch_node_embed(*cfg, w, num_nodes, atom_type, r_feat, p_feat, z, (hipStream_t)stream);
+}
+
+int tsd_edge_embed(const tsd_model_cfg* cfg, const float* w, int32_t capacity, tsd_edges edges,
+                   float* edge_attr, void* stream) {
+    int r = check_cfg(cfg);
+    if (r) return r;
+    return launch_edge_embed(*cfg, w, capacity, edges, edge_attr, (hipStream_t)stream);
+}
+
+int tsd_node_lin1(const tsd_model_cfg* cfg, const float* w, int32_t layer, int32_t num_nodes, const float* h,
+                  float* x1, void* stream) {
+    int r = check_cfg(cfg);
+    if (r) return r;
+    TSD_REQUIRE(layer >= 0 && layer < cfg->num_convs, "layer %d out of range", layer);
+    return launch_node_lin1(*cfg, w, layer, num_nodes, h, x1, (hipStream_t)stream);
+}
+
+int tsd_cfconv_layer(const tsd_model_cfg* cfg, const float* w, int32_t layer, int32_t capacity, tsd_edges enc,
+                     const float* edge_attr, const float* x1, float* agg, float* part, void* stream) {
+    int r = check_cfg(cfg);
+    if (r) return r;
+    TSD_REQUIRE(layer >= 0 && layer < cfg->num_convs, "layer %d out of range", layer);
+    return launch_cfconv_layer(*cfg, w, layer, capacity, enc, edge_attr, x1, agg, part, (hipStream_t)stream);
+}
+
+int tsd_cfconv_aggregate(int32_t hidden, int32_t num_nodes, const int32_t* row_ptr, const int32_t* dst,
+                         const float* W, const float* x1, float* out, void* stream) {
+    TSD_REQUIRE(row_ptr && dst && W && x1 && out, "null pointer");
+    return launch_cfconv_aggregate(hidden, num_nodes, row_ptr, dst, W, x1, out, (hipStream_t)stream);
+}
+
+int tsd_node_update(const tsd_model_cfg* cfg, const float* w, int32_t layer, int32_t next_layer,
+                    int32_t num_nodes, const int32_t* enc_row_ptr, const float* agg, const float* part,
+                    float* h, float* x1, void* stream) {
+    int r = check_cfg(cfg);
+    if (r) return r;
+    TSD_REQUIRE(layer >= 0 && layer < cfg->num_convs && next_layer < cfg->num_convs, "layer out of range");
+    return launch_node_update(*cfg, w, layer, next_layer, num_nodes, enc_row_ptr, agg, part, h, x1,
+                              (hipStream_t)stream);
+}
+
+int tsd_pair_output(const tsd_model_cfg* cfg, const float* w, int32_t capacity, tsd_edges out, const float* h,
+                    const float* edge_attr_out, float* edge_inv, void* stream) {
+    int r = check_cfg(cfg);
+    if (r) return r;
+    return launch_pair_output(*cfg, w, capacity, out, h, edge_attr_out, edge_inv, (hipStream_t)stream);
+}
+
+int tsd_eq_transform(int32_t num_nodes, int64_t num_edges, const float* score_d, const float* pos,
+                     const int64_t* edge_index, const float* edge_length, float* score_pos, void* stream) {
+    TSD_REQUIRE(num_edges == 0 || (score_d && pos && edge_index && edge_length && score_pos), "null pointer");
+    return launch_eq_transform_atomic(num_nodes, num_edges, score_d, pos, edge_index, edge_length, score_pos,
+                                      (hipStream_t)stream);
+}
+
+size_t tsd_forward_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs,
+                                    int32_t num_models) {
+    (void)num_models;  // checkpoints run back to back on one stream and share the activations
+    if (check_cfg(cfg)) return 0;
+    return carve(*cfg, num_nodes, num_pairs, nullptr).total;
+}
+
+int tsd_score_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* pos, void* stream) {
+    int r = check_cfg(cfg);
+    if (r) return r;
+    TSD_REQUIRE(batch && pos, "null pointer");
+    TSD_REQUIRE(batch->num_models >= 1, "num_models=%d", batch->num_models);
+    return forward_impl(*cfg, *batch, pos, (hipStream_t)stream);
+}
+
+int tsd_ensemble_mean(int32_t num_models, int32_t num_pairs, const int32_t* count, const float* edge_inv,
+                      float* edge_inv_mean, void* stream) {
+    return launch_ensemble_mean(num_models, num_pairs, count, edge_inv, edge_inv_mean, (hipStream_t)stream);
+}
+
+int tsd_eq_transform_rows(int32_t num_nodes, const float* pos, const int32_t* pair_ptr,
+                          const int32_t* graph_ptr, const int32_t* node_graph, tsd_edges out,
+                          const int32_t* pair2out, const float* score_d, float* score_pos, void* stream) {
+    return launch_eq_transform_rows(num_nodes, pos, pair_ptr, graph_ptr, node_graph, out, pair2out, score_d,
+                                    score_pos, (hipStream_t)stream);
+}
+
+int tsd_sampler_step(int32_t kind, int32_t num_nodes, int32_t num_graphs, const int32_t* graph_ptr,
+                     const float* score_pos, const float* noise, const float* coefs, float clip, float clip_pos,
+                     float* pos, int32_t* status, void* stream) {
+    TSD_REQUIRE(kind == 0 || kind == 1, "kind=%d (0 = ld, 1 = ddpm)", kind);
+    return launch_sampler_step(kind, num_nodes, num_graphs, graph_ptr, score_pos, noise, coefs, clip, clip_pos,
+                               pos, nullptr, status, nullptr, (hipStream_t)stream);
+}
+
+int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t kind, int32_t n_steps,
+                    const float* coefs, const float* noises, float clip, float clip_pos, float* pos, float* traj,
+                    float* scratch, int32_t* status, int32_t use_graph, void* stream) {
+    int r = check_cfg(cfg);
+    if (r) return r;
+    TSD_REQUIRE(batch && coefs && noises && pos && scratch && status, "null pointer");
+    TSD_REQUIRE(kind == 0 || kind == 1, "kind=%d (0 = ld, 1 = ddpm)", kind);
+    TSD_REQUIRE(n_steps >= 0, "n_steps=%d", n_steps);
+    hipStream_t st = (hipStream_t)stream;
+    if (n_steps == 0) return TSD_OK;
+    int32_t* step_ctr = status + 1;  // status[1]: device-side step counter (offsets into coefs/noises/traj)
+    TSD_HIP(hipMemsetAsync(step_ctr, 0, sizeof(int32_t), st));
+    // step 0 runs eagerly (also performs every one-time function-attribute set-up outside capture)
+    if ((r = step_impl(*cfg, *batch, kind, coefs, noises, clip, clip_pos, pos, traj, scratch, status, step_ctr, st)))
+        return r;
+    if ((r = launch_advance(step_ctr, st))) return r;
+    if (n_steps == 1) return TSD_OK;
+    if (!use_graph) {
+        for (int k = 1; k < n_steps; ++k) {
+            if ((r = step_impl(*cfg, *batch, kind, coefs, noises, clip, clip_pos, pos, traj, scratch, status,
+                               step_ctr, st)))
+                return r;
+            if ((r = launch_advance(step_ctr, st))) return r;
+        }
+        return TSD_OK;
+    }
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    TSD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    r = step_impl(*cfg, *batch, kind, coefs, noises, clip, clip_pos, pos, traj, scratch, status, step_ctr, st);
+    if (!r) r = launch_advance(step_ctr, st);
+    hipError_t ce = hipStreamEndCapture(st, &graph);
+    if (r) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return r;
+    }
+    TSD_HIP(ce);
+    hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (ie != hipSuccess) {
+        (void)hipGraphDestroy(graph);
+        return check_hip(ie, "hipGraphInstantiate");
+    }
+    for (int k = 1; k < n_steps && r == TSD_OK; ++k) r = check_hip(hipGraphLaunch(exec, st), "hipGraphLaunch");
+    // the exec object must outlive its launches: wait for the stream before destroying it
+    hipError_t se = hipStreamSynchronize(st);
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    if (r) return r;
+    return check_hip(se, "hipStreamSynchronize");
+}
+
+}  // extern "C"

@@ -1,0 +1,306 @@
+// kernels_misc.hip -- the HBM/latency-bound kernels around the MFMA chain:
+// node embedding, stand-alone CFConv aggregation (T5), eq_transform, ensemble mean, sampler update.
+#include "common.hpp"
+
+namespace tsd {
+
+// ---------------------------------------------------------------------------------------------
+// A2: z = [Emb[atom] + Wf r_feat , Wf p_feat - Wf r_feat]      reference condensenc.py:193-198
+// ---------------------------------------------------------------------------------------------
+__global__ void node_embed_kernel(int N, int H, int F, const float* __restrict__ atom_emb,
+                                  const float* __restrict__ wf, const int64_t* __restrict__ atom_type,
+                                  const int64_t* __restrict__ r_feat, const int64_t* __restrict__ p_feat,
+                                  float* __restrict__ z) {
+    const int half = H / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * half) return;
+    const int i = idx / half, c = idx % half;
+    int a = (int)atom_type[i];
+    a = a < 0 ? 0 : (a > 99 ? 99 : a);
+    float fr = 0.0f, fp = 0.0f;
+    for (int k = 0; k < F; ++k) {
+        const float w = wf[c * F + k];
+        fr = fmaf((float)r_feat[(size_t)i * F + k], w, fr);
+        fp = fmaf((float)p_feat[(size_t)i * F + k], w, fp);
+    }
+    z[(size_t)i * H + c] = atom_emb[a * half + c] + fr;
+    z[(size_t)i * H + half + c] = fp - fr;
+}
+
+int launch_node_embed(const tsd_model_cfg& c, const float* W, int N, const int64_t* atom_type,
+                      const int64_t* r_feat, const int64_t* p_feat, float* z, hipStream_t st) {
+    const WeightLayout L = weight_layout(c);
+    const int n = N * (c.hidden / 2);
+    if (n == 0) return TSD_OK;
+    hipLaunchKernelGGL(node_embed_kernel, dim3((n + 255) / 256), dim3(256), 0, st, N, c.hidden, c.feat_dim,
+                       W + L.atom_emb, W + L.atom_feat, atom_type, r_feat, p_feat, z);
+    TSD_LAUNCH_CHECK("node_embed");
+    return TSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// T5 alone: out[i] = sum_{e in row i} x1[dst[e]] * W[e]          reference schnet.py:102,106
+// HBM-bound: W is streamed once (4H bytes/edge), x1 rows come from L2/MALL, one wave per row,
+// each lane owns H/64 consecutive channels, edges in order (bit-identical to a sequential
+// scatter_add: product rounded, then added).
+// ---------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(256) void cfconv_aggregate_kernel(int N, const int32_t* __restrict__ row_ptr,
+                                                               const int32_t* __restrict__ dst,
+                                                               const float* __restrict__ W,
+                                                               const float* __restrict__ x1,
+                                                               float* __restrict__ out) {
+    constexpr int V = H / 64;  // floats per lane: 4 (H=256), 2, 1
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= N) return;
+    const int e0 = row_ptr[i], e1 = row_ptr[i + 1];
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.0f;
+    constexpr int U = 4;
+    int e = e0;
+    for (; e + U <= e1; e += U) {
+        float w[U][V], x[U][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = dst[e + u];
+            const float* wp = W + (size_t)(e + u) * H + lane * V;
+            const float* xp = x1 + (size_t)j * H + lane * V;
+            if (V == 4) {
+                const f32x4 wv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp));
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xp);
+#pragma unroll
+                for (int v = 0; v < V; ++v) { w[u][v] = wv[v]; x[u][v] = xv[v]; }
+            } else {
+#pragma unroll
+                for (int v = 0; v < V; ++v) { w[u][v] = wp[v]; x[u][v] = xp[v]; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int v = 0; v < V; ++v) acc[v] = __fadd_rn(acc[v], __fmul_rn(x[u][v], w[u][v]));
+    }
+    for (; e < e1; ++e) {
+        const int j = dst[e];
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+            acc[v] = __fadd_rn(acc[v], __fmul_rn(x1[(size_t)j * H + lane * V + v], W[(size_t)e * H + lane * V + v]));
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) out[(size_t)i * H + lane * V + v] = acc[v];
+}
+
+int launch_cfconv_aggregate(int H, int N, const int32_t* row_ptr, const int32_t* dst, const float* W,
+                            const float* x1, float* out, hipStream_t st) {
+    if (N == 0) return TSD_OK;
+    const int blocks = (N + 3) / 4;
+    switch (H) {
+        case 64: hipLaunchKernelGGL(cfconv_aggregate_kernel<64>, dim3(blocks), dim3(256), 0, st, N, row_ptr, dst, W, x1, out); break;
+        case 128: hipLaunchKernelGGL(cfconv_aggregate_kernel<128>, dim3(blocks), dim3(256), 0, st, N, row_ptr, dst, W, x1, out); break;
+        case 256: hipLaunchKernelGGL(cfconv_aggregate_kernel<256>, dim3(blocks), dim3(256), 0, st, N, row_ptr, dst, W, x1, out); break;
+        default: set_error("hidden=%d unsupported (64/128/256)", H); return TSD_ERR_INVALID;
+    }
+    TSD_LAUNCH_CHECK("cfconv_aggregate");
+    return TSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// eq_transform                                                   reference models/geometry.py:22-30
+// ---------------------------------------------------------------------------------------------
+__global__ void eq_transform_atomic_kernel(int64_t E, const float* __restrict__ sd, const float* __restrict__ pos,
+                                           const int64_t* __restrict__ ei, const float* __restrict__ len,
+                                           float* __restrict__ score) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const int64_t i = ei[e], j = ei[E + e];
+    const float inv = 1.0f / len[e], s = sd[e];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float v = __fmul_rn(__fmul_rn(inv, pos[3 * i + k] - pos[3 * j + k]), s);
+        atomicAdd(score + 3 * i + k, v);
+        atomicAdd(score + 3 * j + k, -v);
+    }
+}
+
+int launch_eq_transform_atomic(int N, int64_t E, const float* sd, const float* pos, const int64_t* ei,
+                               const float* len, float* score, hipStream_t st) {
+    (void)N;
+    if (E == 0) return TSD_OK;
+    hipLaunchKernelGGL(eq_transform_atomic_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, E, sd, pos,
+                       ei, len, score);
+    TSD_LAUNCH_CHECK("eq_transform_atomic");
+    return TSD_OK;
+}
+
+// deterministic form on the library's own out-edge list: one thread per node walks its row.
+// first term: edges (i,j) of row i in order; second term: edges (j,i), j ascending == same order,
+// -dd_dr(j,i) == dd_dr(i,j) exactly, score_d looked up through pair2out.
+__global__ void eq_transform_rows_kernel(int N, const float* __restrict__ pos, const int32_t* __restrict__ pair_ptr,
+                                         const int32_t* __restrict__ graph_ptr,
+                                         const int32_t* __restrict__ node_graph, tsd_edges out,
+                                         const int32_t* __restrict__ pair2out, const float* __restrict__ sd,
+                                         float* __restrict__ score) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int lo = graph_ptr[node_graph[i]];
+    const int il = i - lo;
+    const float px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
+    float ax = 0.f, ay = 0.f, az = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
+    const int e1 = out.row_ptr[i + 1];
+    for (int e = out.row_ptr[i]; e < e1; ++e) {
+        const int j = out.dst[e];
+        const int jl = j - lo;
+        const float inv = 1.0f / out.dist[e];
+        const float ux = __fmul_rn(inv, px - pos[3 * j]), uy = __fmul_rn(inv, py - pos[3 * j + 1]),
+                    uz = __fmul_rn(inv, pz - pos[3 * j + 2]);
+        const float s1 = sd[e];
+        const int et = pair2out[pair_ptr[j] + il - (il > jl ? 1 : 0)];
+        const float s2 = et >= 0 ? sd[et] : 0.0f;
+        ax = __fadd_rn(ax, __fmul_rn(ux, s1));
+        ay = __fadd_rn(ay, __fmul_rn(uy, s1));
+        az = __fadd_rn(az, __fmul_rn(uz, s1));
+        bx = __fadd_rn(bx, __fmul_rn(ux, s2));
+        by = __fadd_rn(by, __fmul_rn(uy, s2));
+        bz = __fadd_rn(bz, __fmul_rn(uz, s2));
+    }
+    score[3 * i] = ax + bx;
+    score[3 * i + 1] = ay + by;
+    score[3 * i + 2] = az + bz;
+}
+
+int launch_eq_transform_rows(int N, const float* pos, const int32_t* pair_ptr, const int32_t* graph_ptr,
+                             const int32_t* node_graph, tsd_edges out, const int32_t* pair2out,
+                             const float* sd, float* score, hipStream_t st) {
+    if (N == 0) return TSD_OK;
+    hipLaunchKernelGGL(eq_transform_rows_kernel, dim3((N + 127) / 128), dim3(128), 0, st, N, pos, pair_ptr,
+                       graph_ptr, node_graph, out, pair2out, sd, score);
+    TSD_LAUNCH_CHECK("eq_transform_rows");
+    return TSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ensemble mean, reference sampler.py:96-111: edge_inv += out[0] (in order), then /= M
+// ---------------------------------------------------------------------------------------------
+__global__ void ensemble_mean_kernel(int M, int P, const int32_t* __restrict__ count,
+                                     const float* __restrict__ inv, float* __restrict__ mean) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= *count) return;
+    float s = inv[e];
+    for (int m = 1; m < M; ++m) s = __fadd_rn(s, inv[(size_t)m * P + e]);
+    mean[e] = s / (float)M;
+}
+
+int launch_ensemble_mean(int M, int P, const int32_t* count, const float* inv, float* mean, hipStream_t st) {
+    if (P == 0) return TSD_OK;
+    hipLaunchKernelGGL(ensemble_mean_kernel, dim3((P + 255) / 256), dim3(256), 0, st, M, P, count, inv, mean);
+    TSD_LAUNCH_CHECK("ensemble_mean");
+    return TSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// sampler update: clip_norm, LD / DDPM step, NaN flag, centre per graph, optional clamp
+// reference models/sampler.py:208-253, 260-268.  One wave per graph.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sampler_step_kernel(int kind, const int32_t* __restrict__ graph_ptr,
+                                                          const float* __restrict__ score,
+                                                          const float* __restrict__ noise,
+                                                          const float* __restrict__ coefs, float clip,
+                                                          float clip_pos, float* __restrict__ pos,
+                                                          float* __restrict__ traj, int32_t* __restrict__ status,
+                                                          const int32_t* __restrict__ step_ctr, int N) {
+    if (step_ctr) {  // device-resident loop: this step's slices of the per-step tables
+        const size_t k = (size_t)*step_ctr;
+        coefs += k * TSD_STEP_COEFS;
+        noise += k * 3 * (size_t)N;
+        if (traj) traj += k * 3 * (size_t)N;
+    }
+    const int g = blockIdx.x;
+    const int lo = graph_ptr[g], hi = graph_ptr[g + 1];
+    const int lane = threadIdx.x;
+    float c[TSD_STEP_COEFS];
+#pragma unroll
+    for (int k = 0; k < TSD_STEP_COEFS; ++k) c[k] = coefs[k];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    bool bad = false;
+    for (int i = lo + lane; i < hi; i += 64) {
+        float v[3], p[3], nz[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            v[k] = score[3 * i + k];
+            p[k] = pos[3 * i + k];
+            nz[k] = noise[3 * i + k];
+        }
+        // clip_norm (sampler.py:265-268)
+        const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(v[0], v[0]), __fmul_rn(v[1], v[1])), __fmul_rn(v[2], v[2])));
+        const float denom = norm > clip ? clip / norm : 1.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float eps = __fmul_rn(v[k], denom);
+            float nx;
+            if (kind == 0) {  // LD, sampler.py:238-244
+                nx = __fadd_rn(__fadd_rn(p[k], __fmul_rn(c[0], eps) / c[1]), __fmul_rn(nz[k], c[2]));
+            } else {  // DDPM, sampler.py:215-236
+                const float e = -eps;
+                const float pos_C = __fmul_rn(c[0], p[k]);
+                const float pos0 = __fsub_rn(__fmul_rn(c[1], pos_C), __fmul_rn(c[2], e));
+                const float mean = __fadd_rn(__fmul_rn(c[3], pos0), __fmul_rn(c[4], pos_C)) / c[5];
+                nx = __fadd_rn(mean, __fmul_rn(c[6], nz[k])) / c[7];
+            }
+            bad |= (nx != nx);
+            p[k] = nx;
+        }
+        pos[3 * i] = p[0];
+        pos[3 * i + 1] = p[1];
+        pos[3 * i + 2] = p[2];
+        sx += p[0];
+        sy += p[1];
+        sz += p[2];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        sx += __shfl_xor(sx, off);
+        sy += __shfl_xor(sy, off);
+        sz += __shfl_xor(sz, off);
+    }
+    if (__ballot(bad) != 0ull && lane == 0) atomicOr(status, TSD_STATUS_NAN);
+    const float cnt = (float)max(hi - lo, 1);
+    const float mx = sx / cnt, my = sy / cnt, mz = sz / cnt;
+    for (int i = lo + lane; i < hi; i += 64) {  // center_pos (sampler.py:260-262); same lane wrote these
+        float x = pos[3 * i] - mx, y = pos[3 * i + 1] - my, z = pos[3 * i + 2] - mz;
+        if (clip_pos >= 0.0f) {
+            x = fminf(fmaxf(x, -clip_pos), clip_pos);
+            y = fminf(fmaxf(y, -clip_pos), clip_pos);
+            z = fminf(fmaxf(z, -clip_pos), clip_pos);
+        }
+        pos[3 * i] = x;
+        pos[3 * i + 1] = y;
+        pos[3 * i + 2] = z;
+        if (traj) {
+            traj[3 * i] = x;
+            traj[3 * i + 1] = y;
+            traj[3 * i + 2] = z;
+        }
+    }
+}
+
+int launch_sampler_step(int kind, int N, int G, const int32_t* graph_ptr, const float* score, const float* noise,
+                        const float* coefs, float clip, float clip_pos, float* pos, float* traj,
+                        int32_t* status, const int32_t* step_ctr, hipStream_t st) {
+    if (G == 0) return TSD_OK;
+    hipLaunchKernelGGL(sampler_step_kernel, dim3(G), dim3(64), 0, st, kind, graph_ptr, score, noise, coefs, clip,
+                       clip_pos, pos, traj, status, step_ctr, N);
+    TSD_LAUNCH_CHECK("sampler_step");
+    return TSD_OK;
+}
+
+__global__ void advance_kernel(int32_t* ctr) { *ctr += 1; }
+
+int launch_advance(int32_t* ctr, hipStream_t st) {
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, ctr);
+    TSD_LAUNCH_CHECK("advance");
+    return TSD_OK;
+}
+
+}  // namespace tsd

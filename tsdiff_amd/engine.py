@@ -1,0 +1,267 @@
+"""Host-side plumbing between torch device tensors and the C ABI (include/tsdiff_hip.h).
+
+torch is used for device memory (caching allocator), streams and dtype conversion only; every
+computation of the path runs in libtsdiff_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Batch, Edges, ModelCfg, check, ptr, stream_ptr
+
+# order of the flattened reference state_dict expected by tsd_pack_weights (include/tsdiff_hip.h)
+
+
+def raw_param_names(num_convs):
+    names = [
+        "edge_encoder.bond_emb.weight",
+        "edge_encoder.mlp.layers.0.weight", "edge_encoder.mlp.layers.0.bias",
+        "edge_encoder.mlp.layers.1.weight", "edge_encoder.mlp.layers.1.bias",
+        "atom_embedding.weight", "atom_feat_embedding.weight",
+    ]
+    for l in range(num_convs):
+        p = f"encoder.interactions.{l}."
+        names += [p + "conv.lin1.weight", p + "conv.lin2.weight", p + "conv.lin2.bias",
+                  p + "conv.nn.0.weight", p + "conv.nn.0.bias", p + "conv.nn.2.weight", p + "conv.nn.2.bias",
+                  p + "lin.weight", p + "lin.bias"]
+    names += [f"grad_dist_mlp.layers.{i}.{k}" for i in range(3) for k in ("weight", "bias")]
+    names += ["edge_cat.0.weight", "edge_cat.0.bias", "edge_cat.2.weight", "edge_cat.2.bias"]
+    return names
+
+
+def cfg_get(cfg, key, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+def make_cfg(model_config):
+    """tsd_model_cfg from the reference's `config.model` (EasyDict / dict / attribute object)."""
+    enc = cfg_get(model_config, "encoder")
+    H = int(cfg_get(model_config, "hidden_dim"))
+    if int(cfg_get(enc, "hidden_dim")) != H:
+        raise ValueError("condensenc needs encoder.hidden_dim == hidden_dim")
+    if cfg_get(enc, "name", "schnet") != "schnet":
+        raise NotImplementedError("Unknown/unsupported encoder: %s" % cfg_get(enc, "name"))
+    if bool(cfg_get(enc, "smooth_conv", False)):
+        raise NotImplementedError("encoder.smooth_conv=True is not on the shipped path")
+    if cfg_get(model_config, "edge_encoder", "mlp") != "mlp":
+        raise NotImplementedError("Unknown/unsupported edge encoder: %s" % cfg_get(model_config, "edge_encoder"))
+    for k in ("mlp_act", "edge_cat_act"):
+        if cfg_get(model_config, k, "swish") != "swish":
+            raise NotImplementedError(f"{k}={cfg_get(model_config, k)}: only swish is built")
+    return ModelCfg(
+        hidden=H,
+        num_convs=int(cfg_get(enc, "num_convs")),
+        feat_dim=int(cfg_get(model_config, "feat_dim")),
+        edge_order=int(cfg_get(model_config, "edge_order")),
+        pred_edge_order=int(cfg_get(model_config, "pred_edge_order")),
+        edge_cutoff=float(cfg_get(model_config, "edge_cutoff")),
+        conv_cutoff=float(cfg_get(enc, "cutoff")),
+    )
+
+
+def pack_weights(cfg, named_tensors, device):
+    """named_tensors: name -> tensor (reference state_dict names).  Returns packed fp32 device arena."""
+    lib = _lib.load()
+    names = raw_param_names(cfg.num_convs)
+    raw = torch.cat([named_tensors[n].detach().to(device=device, dtype=torch.float32).reshape(-1) for n in names])
+    n_raw = lib.tsd_raw_weight_floats(C.byref(cfg))
+    if raw.numel() != n_raw:
+        raise ValueError(f"state_dict has {raw.numel()} weights, config needs {n_raw}")
+    packed = torch.zeros(lib.tsd_packed_weight_floats(C.byref(cfg)), dtype=torch.float32, device=device)
+    check(lib.tsd_pack_weights(C.byref(cfg), ptr(raw), ptr(packed), stream_ptr()))
+    return packed
+
+
+class EdgeList:
+    """device buffers of one extended-graph edge list (capacity = num_pairs)"""
+
+    def __init__(self, N, P, device):
+        i32 = dict(dtype=torch.int32, device=device)
+        self.count = torch.zeros(1, **i32)
+        self.row_ptr = torch.zeros(N + 1, **i32)
+        self.src = torch.zeros(max(P, 1), **i32)
+        self.dst = torch.zeros(max(P, 1), **i32)
+        self.dist = torch.zeros(max(P, 1), dtype=torch.float32, device=device)
+        self.type_r = torch.zeros(max(P, 1), dtype=torch.uint8, device=device)
+        self.type_p = torch.zeros(max(P, 1), dtype=torch.uint8, device=device)
+        self.pair_id = torch.zeros(max(P, 1), **i32)
+
+    def struct(self):
+        return Edges(*[C.c_void_p(t.data_ptr()) for t in (
+            self.count, self.row_ptr, self.src, self.dst, self.dist, self.type_r, self.type_p, self.pair_id)])
+
+    def num_edges(self):
+        return int(self.count.item())  # host sync
+
+
+class DeviceBatch:
+    """Everything pos-independent about one batch of reaction graphs, resident in HBM:
+    topology (k-hop pair codes), edge-list buffers, per-checkpoint node embeddings, workspace.
+
+    Built once per batch (the reference recomputes all of it 5000 x M times)."""
+
+    def __init__(self, cfg, atom_type, r_feat, p_feat, bond_index, bond_type, batch=None,
+                 num_nodes_per_graph=None):
+        lib = _lib.load()
+        dev = atom_type.device
+        if dev.type != "cuda":
+            raise _lib.TsdError("tsdiff_amd runs on the GPU only (inputs must be cuda tensors); "
+                                "there is no CPU fallback")
+        self.cfg = cfg
+        self.device = dev
+        N = int(atom_type.shape[0])
+        if num_nodes_per_graph is None:
+            if batch is None:
+                raise ValueError("need `batch` or `num_nodes_per_graph`")
+            nn_host = torch.bincount(batch).cpu().numpy().astype(np.int64) if N else np.zeros(0, np.int64)
+        else:
+            nn_host = (num_nodes_per_graph.detach().cpu().numpy() if torch.is_tensor(num_nodes_per_graph)
+                       else np.asarray(num_nodes_per_graph)).astype(np.int64)
+        if int(nn_host.sum()) != N:
+            raise ValueError("num_nodes_per_graph does not sum to the number of atoms")
+        G = int(nn_host.shape[0])
+        graph_ptr = np.zeros(G + 1, np.int64)
+        np.cumsum(nn_host, out=graph_ptr[1:])
+        pair_base = np.zeros(G + 1, np.int64)
+        np.cumsum(nn_host * (nn_host - 1), out=pair_base[1:])
+        P = int(pair_base[-1])
+        if P >= 2 ** 31 or N >= 2 ** 31:
+            raise NotImplementedError("batch too large for int32 indexing")
+        self.N, self.G, self.P = N, G, P
+        self.max_n = int(nn_host.max()) if G else 0
+        self.num_nodes_per_graph_host = nn_host
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.graph_ptr = torch.from_numpy(graph_ptr.astype(np.int32)).to(dev)
+        self.pair_base = torch.from_numpy(pair_base.astype(np.int32)).to(dev)
+        self.node_graph = torch.zeros(max(N, 1), **i32)
+        self.pair_ptr = torch.zeros(N + 1, **i32)
+        self.pair_code = torch.zeros(max(P, 1), dtype=torch.int16, device=dev)
+        self.status = torch.zeros(4, **i32)
+        self.atom_type = atom_type.to(torch.int64).contiguous()
+        self.r_feat = r_feat.to(torch.int64).contiguous()
+        self.p_feat = p_feat.to(torch.int64).contiguous()
+        bond_index = bond_index.to(torch.int64).contiguous()
+        bond_type = bond_type.to(torch.int64).contiguous()
+        nb = int(bond_type.shape[0])
+        max_order = max(cfg.edge_order, cfg.pred_edge_order)
+        check(lib.tsd_topology_build(N, G, P, nb, ptr(self.graph_ptr), ptr(self.pair_base), ptr(bond_index),
+                                     ptr(bond_type), max_order, self.max_n, ptr(self.node_graph),
+                                     ptr(self.pair_ptr), ptr(self.pair_code), ptr(self.status), stream_ptr()))
+        st = int(self.status[0].item())  # one sync per batch
+        if st & _lib.STATUS_BAD_BOND:
+            raise ValueError("bond_index/bond_type: self loop, bond across graphs or value out of range")
+        if st & _lib.STATUS_ASYMMETRIC:
+            raise ValueError("bond list must contain both directions of every bond with equal types "
+                             "(reference utils/datasets.py:491-507)")
+        self.enc = EdgeList(N, P, dev)
+        self.out = EdgeList(N, P, dev)
+        self.out2enc = torch.zeros(max(P, 1), **i32)
+        self.pair2out = torch.zeros(max(P, 1), **i32)
+        self.geo_scratch = torch.zeros(lib.tsd_geometry_scratch_ints(N, P), **i32)
+        self.workspace = None
+        self.edge_inv = None
+        self.z = None
+        self._z_key = None
+        self.scratch = torch.zeros(((P + 63) // 64) * 64 + 3 * N + 64, dtype=torch.float32, device=dev)
+
+    # ---- per-checkpoint state ----------------------------------------------------------------
+    def bind_models(self, packed_list, key):
+        """packed_list: list of M packed weight arenas (same config). Computes z per checkpoint."""
+        lib = _lib.load()
+        if self._z_key == key:
+            return
+        M = len(packed_list)
+        H = self.cfg.hidden
+        self.weights = torch.stack(packed_list) if M > 1 else packed_list[0].reshape(1, -1)
+        self.z = torch.empty(M, max(self.N, 1), H, dtype=torch.float32, device=self.device)
+        for m in range(M):
+            check(lib.tsd_node_embed(C.byref(self.cfg), ptr(self.weights[m]), self.N, ptr(self.atom_type),
+                                     ptr(self.r_feat), ptr(self.p_feat), ptr(self.z[m]), stream_ptr()))
+        nws = lib.tsd_forward_workspace_floats(C.byref(self.cfg), self.N, self.P, M)
+        if self.workspace is None or self.workspace.numel() < nws:
+            self.workspace = torch.empty(max(nws, 1), dtype=torch.float32, device=self.device)
+        self.edge_inv = torch.zeros(M, max(self.P, 1), dtype=torch.float32, device=self.device)
+        self.M = M
+        self._z_key = key
+
+    def struct(self):
+        return Batch(
+            num_nodes=self.N, num_graphs=self.G, num_pairs=self.P, num_models=self.M,
+            graph_ptr=self.graph_ptr.data_ptr(), node_graph=self.node_graph.data_ptr(),
+            pair_ptr=self.pair_ptr.data_ptr(), pair_code=self.pair_code.data_ptr(),
+            weights=self.weights.data_ptr(), z=self.z.data_ptr(),
+            enc=self.enc.struct(), out=self.out.struct(),
+            out2enc=self.out2enc.data_ptr(), pair2out=self.pair2out.data_ptr(),
+            geo_scratch=self.geo_scratch.data_ptr(), workspace=self.workspace.data_ptr(),
+            edge_inv=self.edge_inv.data_ptr())
+
+    # ---- ops -------------------------------------------------------------------------------
+    def geometry(self, pos):
+        lib = _lib.load()
+        pos = pos.to(torch.float32).contiguous()
+        check(lib.tsd_geometry_build(C.byref(self.cfg), self.N, self.G, self.P, ptr(pos), ptr(self.graph_ptr),
+                                     ptr(self.node_graph), ptr(self.pair_ptr), ptr(self.pair_code),
+                                     self.enc.struct(), self.out.struct(), ptr(self.out2enc),
+                                     ptr(self.pair2out), ptr(self.geo_scratch), stream_ptr()))
+
+    def forward(self, pos):
+        """geometry + M forwards; results stay on the device (self.edge_inv[m, :E_out])."""
+        lib = _lib.load()
+        pos = pos.to(torch.float32).contiguous()
+        b = self.struct()
+        check(lib.tsd_score_forward(C.byref(self.cfg), C.byref(b), ptr(pos), stream_ptr()))
+        return pos
+
+    def ensemble_mean(self):
+        lib = _lib.load()
+        mean = self.scratch[: max(self.P, 1)]
+        check(lib.tsd_ensemble_mean(self.M, self.P, ptr(self.out.count), ptr(self.edge_inv), ptr(mean),
+                                    stream_ptr()))
+        return mean
+
+    def eq_transform_rows(self, pos, score_d):
+        lib = _lib.load()
+        score = torch.empty(self.N, 3, dtype=torch.float32, device=self.device)
+        check(lib.tsd_eq_transform_rows(self.N, ptr(pos), ptr(self.pair_ptr), ptr(self.graph_ptr),
+                                        ptr(self.node_graph), self.out.struct(), ptr(self.pair2out),
+                                        ptr(score_d), ptr(score), stream_ptr()))
+        return score
+
+    def edges_to_torch(self, which="out"):
+        """(edge_index (2,E) int64, edge_length (E,1), type_r, type_p) -- syncs to read E."""
+        el = self.out if which == "out" else self.enc
+        E = el.num_edges()
+        ei = torch.stack([el.src[:E], el.dst[:E]]).to(torch.int64)
+        return ei, el.dist[:E].clone().unsqueeze(-1), el.type_r[:E].to(torch.int64), el.type_p[:E].to(torch.int64)
+
+    def sampler_run(self, kind, pos, coefs, noises, clip, clip_pos, want_traj, use_graph=True):
+        lib = _lib.load()
+        n_steps = int(coefs.shape[0])
+        traj = (torch.empty(n_steps, self.N, 3, dtype=torch.float32, device=self.device) if want_traj else None)
+        self.status.zero_()
+        b = self.struct()
+        check(lib.tsd_sampler_run(C.byref(self.cfg), C.byref(b), kind, n_steps, ptr(coefs), ptr(noises),
+                                  float(clip), float(-1.0 if clip_pos is None else clip_pos), ptr(pos),
+                                  ptr(traj), ptr(self.scratch), ptr(self.status), int(bool(use_graph)),
+                                  stream_ptr()))
+        return traj
+
+
+def eq_transform(score_d, pos, edge_index, edge_length):
+    """reference models/geometry.py:22-30 on arbitrary (device) edge lists."""
+    lib = _lib.load()
+    if pos.device.type != "cuda":
+        raise _lib.TsdError("tsdiff_amd.eq_transform needs cuda tensors (no CPU fallback)")
+    N = int(pos.shape[0])
+    E = int(edge_index.shape[1])
+    score = torch.zeros(N, 3, dtype=torch.float32, device=pos.device)
+    sd = score_d.detach().to(torch.float32).contiguous().view(-1)
+    ln = edge_length.detach().to(torch.float32).contiguous().view(-1)
+    ei = edge_index.to(torch.int64).contiguous()
+    p = pos.detach().to(torch.float32).contiguous()
+    check(lib.tsd_eq_transform(N, E, ptr(sd), ptr(p), ptr(ei), ptr(ln), ptr(score), stream_ptr()))
+    return score

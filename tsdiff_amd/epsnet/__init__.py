@@ -1,0 +1,11 @@
+"""Mirror of the reference registry `models/epsnet/__init__.py:1-15`."""
+
+
+def get_model(config):
+    network = config["network"] if isinstance(config, dict) else config.network
+    if network == "condensenc":
+        from .condensenc import CondenseEncoderEpsNetwork
+        return CondenseEncoderEpsNetwork(config)
+    # `dualenc` is the GeoDiff legacy network that the shipped train.py / sampler.py cannot drive
+    # (SURVEY.md section 0); `dualenc_general` imports a file that does not exist in the reference.
+    raise NotImplementedError("Unknown network: %s" % network)

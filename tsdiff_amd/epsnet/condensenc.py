@@ -1,0 +1,193 @@
+"""Drop-in for the reference `models/epsnet/condensenc.py::CondenseEncoderEpsNetwork`.
+
+Same constructor config, same `state_dict` keys (including the aliased `model.*` /
+`model_embedding.*` entries, reference condensenc.py:81-89), same `forward` / `get_loss`
+signatures and return conventions (condensenc.py:241-328) -- but every computation runs in
+libtsdiff_hip.so on the MI355X.  The `nn.Module` children below only HOLD parameters under the
+reference's names; their own `forward` is never used.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import engine
+
+NUM_BOND_TYPES = 22  # reference utils/chem.py:21
+
+
+def get_beta_schedule(beta_schedule, *, beta_start, beta_end, num_diffusion_timesteps):
+    """reference condensenc.py:13-43 (host side, fp64 numpy, once per model)."""
+    T = num_diffusion_timesteps
+    if beta_schedule == "quad":
+        betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, T, dtype=np.float64) ** 2
+    elif beta_schedule == "linear":
+        betas = np.linspace(beta_start, beta_end, T, dtype=np.float64)
+    elif beta_schedule == "const":
+        betas = beta_end * np.ones(T, dtype=np.float64)
+    elif beta_schedule == "jsd":
+        betas = 1.0 / np.linspace(T, 1, T, dtype=np.float64)
+    elif beta_schedule == "sigmoid":
+        x = np.linspace(-6, 6, T)
+        betas = 1 / (np.exp(-x) + 1) * (beta_end - beta_start) + beta_start
+    else:
+        raise NotImplementedError(beta_schedule)
+    assert betas.shape == (T,)
+    return betas
+
+
+class _Swish(nn.Module):  # parameter-free placeholder so Sequential indices match (edge_cat.{0,2})
+    pass
+
+
+class _MLP(nn.Module):
+    """parameter container with the reference's `layers.{i}.{weight,bias}` names (common.py:46-90)"""
+
+    def __init__(self, input_dim, hidden_dims):
+        super().__init__()
+        dims = [input_dim] + list(hidden_dims)
+        self.layers = nn.ModuleList(nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1))
+
+
+class _MLPEdgeEncoder(nn.Module):  # reference models/encoder/edge.py:44-56
+    def __init__(self, hidden_dim):
+        super().__init__()
+        self.hidden_dim = hidden_dim
+        self.bond_emb = nn.Embedding(100, embedding_dim=hidden_dim)
+        self.mlp = _MLP(1, [hidden_dim, hidden_dim])
+
+    @property
+    def out_channels(self):
+        return self.hidden_dim
+
+
+class _CFConv(nn.Module):  # reference models/encoder/schnet.py:74-86
+    def __init__(self, in_channels, out_channels, num_filters, edge_channels):
+        super().__init__()
+        self.lin1 = nn.Linear(in_channels, num_filters, bias=False)
+        self.lin2 = nn.Linear(num_filters, out_channels)
+        self.nn = nn.Sequential(nn.Linear(edge_channels, num_filters), _Swish(), nn.Linear(num_filters, num_filters))
+        torch.nn.init.xavier_uniform_(self.lin1.weight)
+        torch.nn.init.xavier_uniform_(self.lin2.weight)
+        self.lin2.bias.data.fill_(0)
+
+
+class _InteractionBlock(nn.Module):  # reference schnet.py:110-121
+    def __init__(self, hidden, edge_channels, num_filters):
+        super().__init__()
+        self.conv = _CFConv(hidden, hidden, num_filters, edge_channels)
+        self.lin = nn.Linear(hidden, hidden)
+
+
+class _SchNetEncoder(nn.Module):  # reference schnet.py:131-171
+    def __init__(self, hidden, num_convs):
+        super().__init__()
+        self.interactions = nn.ModuleList(_InteractionBlock(hidden, hidden, hidden) for _ in range(num_convs))
+
+
+class CondenseEncoderEpsNetwork(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self._cfg = engine.make_cfg(config)
+        H = self._cfg.hidden
+        assert H % 2 == 0
+        self.edge_encoder = _MLPEdgeEncoder(H)
+        self.atom_embedding = nn.Embedding(100, H // 2)
+        self.atom_feat_embedding = nn.Linear(self._cfg.feat_dim, H // 2, bias=False)
+        self.encoder = _SchNetEncoder(H, self._cfg.num_convs)
+        self.grad_dist_mlp = _MLP(2 * H, [H, H // 2, 1])
+        self.model_embedding = nn.ModuleList([self.atom_embedding, self.atom_feat_embedding])
+        self.model = nn.ModuleList([self.edge_encoder, self.encoder, self.grad_dist_mlp])
+
+        betas = get_beta_schedule(
+            beta_schedule=engine.cfg_get(config, "beta_schedule"),
+            beta_start=engine.cfg_get(config, "beta_start"),
+            beta_end=engine.cfg_get(config, "beta_end"),
+            num_diffusion_timesteps=engine.cfg_get(config, "num_diffusion_timesteps"),
+        )
+        betas = torch.from_numpy(betas).float()
+        self.betas = nn.Parameter(betas, requires_grad=False)
+        self.alphas = nn.Parameter((1.0 - betas).cumprod(dim=0), requires_grad=False)
+        self.num_timesteps = self.betas.size(0)
+        self.num_bond_types = NUM_BOND_TYPES
+        self.edge_cat = nn.Sequential(nn.Linear(2 * H, H), _Swish(), nn.Linear(H, H))
+
+        self._packed = None
+        self._packed_key = None
+        self._batches = []  # small cache of DeviceBatch objects keyed on the input tensors
+
+    # ------------------------------------------------------------------------------------------
+    def _weight_tensors(self):
+        sd = dict(self.named_parameters())
+        return {n: sd[n] for n in engine.raw_param_names(self._cfg.num_convs)}
+
+    def packed_weights(self):
+        """MFMA-packed fp32 arena in HBM, rebuilt when any parameter changed (version counters)."""
+        wt = self._weight_tensors()
+        dev = next(iter(wt.values())).device
+        key = (str(dev),) + tuple((p.data_ptr(), p._version) for p in wt.values())
+        if self._packed is None or self._packed_key != key:
+            self._packed = engine.pack_weights(self._cfg, wt, dev)
+            self._packed_key = key
+        return self._packed
+
+    def device_batch(self, atom_type, r_feat, p_feat, bond_index, bond_type, batch, num_nodes_per_graph=None):
+        ts = (atom_type, r_feat, p_feat, bond_index, bond_type, batch)
+        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in ts)
+        for k, db in self._batches:
+            if k == key:
+                return db
+        db = engine.DeviceBatch(self._cfg, atom_type, r_feat, p_feat, bond_index, bond_type, batch,
+                                num_nodes_per_graph)
+        self._batches = [(key, db)] + self._batches[:1]
+        return db
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, atom_type, r_feat, p_feat, pos, bond_index, bond_type, batch, time_step,
+                return_edges=True, **kwargs):
+        """reference condensenc.py:241-265; `time_step` and **kwargs are ignored there too."""
+        db = self.device_batch(atom_type, r_feat, p_feat, bond_index, bond_type, batch)
+        packed = self.packed_weights()
+        db.bind_models([packed], key=("single", id(self), self._packed_key))
+        db.forward(pos)
+        E = db.out.num_edges()  # the one host sync (the reference's nonzero() syncs as well)
+        edge_inv = db.edge_inv[0, :E].clone().unsqueeze(-1)
+        if not return_edges:
+            return edge_inv
+        edge_index, edge_length, _, _ = db.edges_to_torch("out")
+        return edge_inv, edge_index, edge_length
+
+    def get_loss(self, atom_type, r_feat, p_feat, pos, bond_index, bond_type, batch, num_nodes_per_graph,
+                 num_graphs, anneal_power=2.0, extend_order=True, extend_radius=True,
+                 _time_step=None, _pos_noise=None):
+        """reference condensenc.py:267-328.  Forward value only in this round: the backward kernels
+        are the first 'next' row of SURVEY.md 8(f); the returned tensor carries no grad_fn.
+        `_time_step` / `_pos_noise` inject the random draws (parity tests)."""
+        node2graph = batch
+        dev = pos.device
+        t0 = engine.cfg_get(self.config, "t0", 0)
+        t1 = engine.cfg_get(self.config, "t1", self.num_timesteps)
+        if _time_step is None:
+            sz = num_graphs // 2 + 1
+            half_1 = torch.randint(t0, t1, size=(sz,), device=dev)
+            half_2 = t0 + t1 - 1 - half_1
+            time_step = torch.cat([half_1, half_2], dim=0)[:num_graphs]
+        else:
+            time_step = _time_step
+        a = self.alphas.index_select(0, time_step)
+        a_pos = a.index_select(0, node2graph).unsqueeze(-1)
+        pos_noise = torch.randn(size=pos.size(), device=dev) if _pos_noise is None else _pos_noise
+        pos_perturbed = pos + pos_noise * (1.0 - a_pos).sqrt() / a_pos.sqrt()
+
+        edge_inv, edge_index, edge_length = self(atom_type, r_feat, p_feat, pos_perturbed, bond_index,
+                                                 bond_type, batch, time_step, return_edges=True)
+        db = self.device_batch(atom_type, r_feat, p_feat, bond_index, bond_type, batch)
+        node_eq = db.eq_transform_rows(pos_perturbed.contiguous(), edge_inv.contiguous().view(-1))
+
+        edge2graph = node2graph.index_select(0, edge_index[0])
+        a_edge = a.index_select(0, edge2graph).unsqueeze(-1)
+        d_gt = (pos[edge_index[0]] - pos[edge_index[1]]).norm(dim=-1).unsqueeze(-1)
+        d_target = (d_gt - edge_length) / (1.0 - a_edge).sqrt() * a_edge.sqrt()
+        pos_target = db.eq_transform_rows(pos_perturbed.contiguous(), d_target.contiguous().view(-1))
+        loss = (node_eq - pos_target) ** 2
+        return torch.sum(loss, dim=-1, keepdim=True)

@@ -1,0 +1,136 @@
+"""Drop-in for the reference `models/sampler.py::EnsembleSampler`.
+
+`forward` keeps the reference contract (mean of edge_inv over the checkpoints, reference
+sampler.py:58-116).  `dynamic_sampling` keeps the reference signature and return value
+(sampler.py:118-257) but the 5000-step loop never leaves the GPU: topology and node embeddings
+are built once per batch, each step is {geometry, M forwards, mean, eq_transform, update, centre}
+in HIP kernels replayed from a hipGraph, the NaN test is a sticky device flag read once at the
+end, and the trajectory is copied to the host once.
+"""
+import torch
+from torch import nn
+
+from . import _lib, engine
+from .epsnet.condensenc import get_beta_schedule  # noqa: F401  (reference sampler.py:11-43 duplicates it)
+
+
+class EnsembleSampler(nn.Module):
+    def __init__(self, models):
+        super().__init__()
+        self.models = models  # plain list like the reference (models are moved individually)
+        self.config = models[0].config
+        self.alphas = models[0].alphas
+        self.betas = models[0].betas
+        self.num_timesteps = models[0].num_timesteps
+
+    # ------------------------------------------------------------------------------------------
+    def _bound_batch(self, atom_type, r_feat, p_feat, bond_index, bond_type, batch, num_graphs=None):
+        m0 = self.models[0]
+        db = m0.device_batch(atom_type, r_feat, p_feat, bond_index, bond_type, batch)
+        if num_graphs is not None and int(num_graphs) != db.G:
+            raise ValueError(f"num_graphs={num_graphs} but batch holds {db.G} graphs")
+        packed = [m.packed_weights() for m in self.models]
+        key = ("ens",) + tuple((id(m), m._packed_key) for m in self.models)
+        db.bind_models(packed, key=key)
+        return db
+
+    def forward(self, atom_type, r_feat, p_feat, pos, bond_index, bond_type, batch, time_step,
+                return_edges=True, **kwargs):
+        db = self._bound_batch(atom_type, r_feat, p_feat, bond_index, bond_type, batch)
+        db.forward(pos)
+        mean = db.ensemble_mean()
+        E = db.out.num_edges()
+        edge_inv = mean[:E].clone().unsqueeze(-1)
+        if not return_edges:
+            return edge_inv
+        edge_index, edge_length, _, _ = db.edges_to_torch("out")
+        return edge_inv, edge_index, edge_length
+
+    # ------------------------------------------------------------------------------------------
+    def step_coefficients(self, seq, seq_next, sampling_type, step_lr):
+        """(n_steps, 8) fp32 table, one row per iteration in execution order, evaluated with the same
+        fp32 tensor expressions as the reference loop body (sampler.py:215-244)."""
+        dev = self.alphas.device
+        sigmas = (1.0 - self.alphas).sqrt() / self.alphas.sqrt()
+        rows = []
+        if sampling_type == "ld":
+            for i in reversed(seq):
+                step_size = step_lr * (sigmas[i] / 0.01) ** 2
+                rows.append(torch.stack([step_size, sigmas[i], torch.sqrt(step_size * 2)]
+                                        + [torch.zeros((), device=dev)] * 5))
+        elif sampling_type == "ddpm":
+            beta = torch.cat([torch.zeros(1, device=dev), self.betas], dim=0)
+            acp = (1 - beta).cumprod(dim=0)
+            for i, j in zip(reversed(seq), reversed(seq_next)):
+                at, atm1 = acp[i + 1], acp[j + 1]
+                beta_t = 1 - at / atm1
+                mask = 1.0 - float(i == 0)
+                rows.append(torch.stack([
+                    at.sqrt(), (1.0 / at).sqrt(), (1.0 / at - 1).sqrt(), atm1.sqrt() * beta_t,
+                    (1 - beta_t).sqrt() * (1 - atm1), 1.0 - at, mask * torch.exp(0.5 * beta_t.log()),
+                    atm1.sqrt()]))
+        else:
+            raise NotImplementedError(sampling_type)
+        return torch.stack(rows).to(torch.float32).contiguous()
+
+    def dynamic_sampling(self, atom_type, r_feat, p_feat, pos_init, bond_index, bond_type, batch, num_graphs,
+                         extend_order, extend_radius=True, n_steps=100, step_lr=0.0000010, clip=1000,
+                         clip_pos=None, denoise_from_time_t=None, noise_from_time_t=None, **kwargs):
+        """Same arguments as the reference.  Extra keyword-only knobs (all optional):
+        noises=(n_steps,N,3) tensor to inject the Gaussian draws, return_traj=False to skip the
+        trajectory, use_graph=False to launch eagerly instead of replaying a hipGraph."""
+        sampling_type = kwargs.get("sampling_type", "ddpm")
+        noises = kwargs.get("noises", None)
+        return_traj = kwargs.get("return_traj", True)
+        use_graph = kwargs.get("use_graph", True)
+        dev = pos_init.device
+        sigmas = (1.0 - self.alphas).sqrt() / self.alphas.sqrt()
+        with torch.no_grad():
+            if noise_from_time_t is not None:  # sampler.py:149-166
+                assert denoise_from_time_t >= n_steps
+                assert denoise_from_time_t >= noise_from_time_t
+                assert noise_from_time_t >= 0
+                seq = range(denoise_from_time_t - n_steps, denoise_from_time_t)
+                noise = torch.randn(pos_init.size(), device=dev)
+                alpha_t = self.alphas[denoise_from_time_t - 1]
+                alpha_s = self.alphas[noise_from_time_t - 1] if noise_from_time_t != 0 else 1
+                sigma = ((1.0 - (alpha_t / alpha_s)) / alpha_t).sqrt()
+                pos = pos_init + noise * sigma
+            elif denoise_from_time_t is not None:  # sampler.py:168-177
+                assert denoise_from_time_t >= n_steps
+                seq = range(denoise_from_time_t - n_steps, denoise_from_time_t)
+                pos = pos_init
+            else:  # sampler.py:179-182
+                seq = range(self.num_timesteps - n_steps, self.num_timesteps)
+                pos = pos_init * sigmas[-1]
+            seq = list(seq)
+            seq_next = [-1] + seq[:-1]
+            pos = pos.to(torch.float32).contiguous().clone()
+            N = pos.shape[0]
+
+            db = self._bound_batch(atom_type, r_feat, p_feat, bond_index, bond_type, batch, num_graphs)
+            coefs = self.step_coefficients(seq, seq_next, sampling_type, step_lr).to(dev)
+            if noises is None:
+                noises = torch.randn(len(seq), N, 3, dtype=torch.float32, device=dev)
+            noises = noises.to(device=dev, dtype=torch.float32).contiguous()
+            kind = 0 if sampling_type == "ld" else 1
+            traj = db.sampler_run(kind, pos, coefs, noises, clip, clip_pos, return_traj, use_graph)
+            status = int(db.status[0].item())  # the single host sync of the loop
+            if status & _lib.STATUS_NAN:
+                print("NaN detected. Please restart.")
+                raise FloatingPointError()
+            pos_traj = list(traj.cpu().unbind(0)) if return_traj else []
+        return pos, pos_traj
+
+
+def center_pos(pos, batch):  # reference sampler.py:260-262 (plumbing form; the loop uses the kernel)
+    G = int(batch.max().item()) + 1 if batch.numel() else 0
+    s = torch.zeros(G, pos.shape[1], dtype=pos.dtype, device=pos.device).index_add_(0, batch, pos)
+    cnt = torch.zeros(G, dtype=pos.dtype, device=pos.device).index_add_(0, batch, torch.ones_like(batch, dtype=pos.dtype))
+    return pos - (s / cnt.clamp(min=1).unsqueeze(-1))[batch]
+
+
+def clip_norm(vec, limit, p=2):  # reference sampler.py:265-268
+    norm = torch.norm(vec, dim=-1, p=2, keepdim=True)
+    denom = torch.where(norm > limit, limit / norm, torch.ones_like(norm))
+    return vec * denom
