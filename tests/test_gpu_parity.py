@@ -300,4 +300,7 @@ def test_full_size_properties(dev):
     r = to_dev({k: torch.from_numpy(v) for k, v in rep.items() if isinstance(v, np.ndarray)}, dev)
     inv, rei, _ = run_forward(model, {**r, "num_graphs": 5}, dev)
     per = inv.view(5, -1)
-    assert all(torch.equal(per[0], per[k]) for k in range(1, 5))
+    # (not bitwise: a row cut by a 32-edge tile boundary is summed as two partials, and where the
+    #  cuts fall depends on the replica's offset in the batch)
+    scale = float(per.abs().max())
+    assert all(float((per[0] - per[k]).abs().max()) <= 2e-6 * scale for k in range(1, 5))

@@ -76,6 +76,16 @@ def pack_weights(cfg, named_tensors, device):
     return packed
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 class EdgeList:
     """device buffers of one extended-graph edge list (capacity = num_pairs)"""
 
@@ -244,10 +254,19 @@ class DeviceBatch:
         traj = (torch.empty(n_steps, self.N, 3, dtype=torch.float32, device=self.device) if want_traj else None)
         self.status.zero_()
         b = self.struct()
-        check(lib.tsd_sampler_run(C.byref(self.cfg), C.byref(b), kind, n_steps, ptr(coefs), ptr(noises),
-                                  float(clip), float(-1.0 if clip_pos is None else clip_pos), ptr(pos),
-                                  ptr(traj), ptr(self.scratch), ptr(self.status), int(bool(use_graph)),
-                                  stream_ptr()))
+        cur = torch.cuda.current_stream(self.device)
+        # hipStreamBeginCapture is illegal on the legacy default stream: run the loop on a side stream
+        side = _side_stream(self.device) if (use_graph and cur.cuda_stream == 0) else None
+        run_on = side if side is not None else cur
+        if side is not None:
+            side.wait_stream(cur)
+        with torch.cuda.stream(run_on):
+            check(lib.tsd_sampler_run(C.byref(self.cfg), C.byref(b), kind, n_steps, ptr(coefs), ptr(noises),
+                                      float(clip), float(-1.0 if clip_pos is None else clip_pos), ptr(pos),
+                                      ptr(traj), ptr(self.scratch), ptr(self.status), int(bool(use_graph)),
+                                      C.c_void_p(run_on.cuda_stream)))
+        if side is not None:
+            cur.wait_stream(side)
         return traj
 
 
