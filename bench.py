@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py -- LD sampling throughput of the TSDiff score-network hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 500 --warmup 50
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one Langevin-dynamics iteration of the reference loop (models/sampler.py:187-254) over
+one batch: device-side graph build, one score-network forward per checkpoint, ensemble mean,
+eq_transform, clip, update, NaN flag, centring.  Workload at every N (weak scaling): BASELINE.json
+configs[1] -- a wb97xd3-like batch of 100 reaction graphs (8..23 atoms, synthetic: the real
+test_data.pkl and the trained checkpoints are LFS blobs absent from the reference tree), the full
+H=256 / 7-block condensenc network with closed-form synthetic weights, fp32, one checkpoint.
+Inputs are resident in HBM before the timed region; graphs shard across ranks with no data-path
+collective (each rank samples its own 100 graphs).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (fused CFConv layer, fp32-MFMA-bound) timed live with events
+  cpu_baseline -- the CPU oracle (our restatement of the reference, kind "port") on the host cores
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md:41
+PEAK_HBM_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--graphs", type=int, default=100, help="graphs per GPU (BASELINE configs[1]: 100)")
+    ap.add_argument("--models", type=int, default=1, help="ensemble size M (configs[2] uses 8)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=20)
+    ap.add_argument("--cpu-threads", type=int, default=32)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=dev)  # RCCL; used for the barrier / max only
+
+    from tsdiff_amd import _lib, synth
+    from tsdiff_amd.epsnet import get_model
+    from tsdiff_amd.sampler import EnsembleSampler
+    from tsdiff_amd.utils import AttrDict
+
+    lib = _lib.load()  # raises if the HIP extension is missing: no fallback
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    models = []
+    for m in range(args.models):
+        model = get_model(AttrDict(cfg))
+        sd = synth.synth_state_dict(cfg, seed=m)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        models.append(model.to(dev))
+    sampler = EnsembleSampler(models)
+
+    b = synth.wb97xd3_like_batch(args.graphs, seed=1000 + rank)
+    g = {k: torch.from_numpy(v).to(dev) for k, v in b.items() if isinstance(v, np.ndarray)}
+    N = int(g["pos"].shape[0])
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    # compact start geometry (every intra-molecular pair within the 10 A cutoff -- the regime the last
+    # ~4000 of the 5000 steps of a real run are in); the timed steps are the LAST K of the schedule
+    pos_init = torch.randn(N, 3, device=dev, generator=gen) * 1.5
+
+    def run(n_steps, pos0):
+        noises = torch.randn(n_steps, N, 3, device=dev, generator=gen)
+        return sampler.dynamic_sampling(
+            g["atom_type"], g["r_feat"], g["p_feat"], pos0, g["bond_index"], g["bond_type"], g["batch"],
+            args.graphs, extend_order=True, n_steps=n_steps, step_lr=1e-7, clip=1000, sampling_type="ld",
+            denoise_from_time_t=n_steps, noises=noises, return_traj=False, use_graph=not args.no_graph)
+
+    # warm-up: builds topology, packs weights, W untimed steps
+    if args.warmup > 0:
+        run(args.warmup, pos_init)
+    # inputs of the timed region are generated before it starts
+    noises = torch.randn(args.steps, N, 3, device=dev, generator=gen)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pos, _ = sampler.dynamic_sampling(
+        g["atom_type"], g["r_feat"], g["p_feat"], pos_init, g["bond_index"], g["bond_type"], g["batch"],
+        args.graphs, extend_order=True, n_steps=args.steps, step_lr=1e-7, clip=1000, sampling_type="ld",
+        denoise_from_time_t=args.steps, noises=noises, return_traj=False, use_graph=not args.no_graph)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(pos).all()
+
+    tot_atoms = torch.tensor([float(N)], device=dev)
+    tmax = torch.tensor([dt], device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot_atoms, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    atoms = float(tot_atoms.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    db = sampler._bound_batch(g["atom_type"], g["r_feat"], g["p_feat"], g["bond_index"], g["bond_type"], g["batch"])
+    E_enc, E_out = db.enc.num_edges(), db.out.num_edges()
+    H, L = cfg["hidden_dim"], cfg["encoder"]["num_convs"]
+
+    # ---- roofline of the dominant kernel: fused CFConv layer (filter MLP + message + segmented sum)
+    x1 = torch.randn(N, H, device=dev)
+    ea = torch.randn(max(db.P, 1), H, device=dev)
+    agg = torch.zeros(N, H, device=dev)
+    part = torch.zeros(((db.P + 31) // 32) * 2, H, device=dev)
+    reps = 50
+
+    def launch_cfconv():
+        _lib.check(lib.tsd_cfconv_layer(C.byref(db.cfg), _lib.ptr(db.weights[0]), 3, db.P, db.enc.struct(),
+                                        _lib.ptr(ea), _lib.ptr(x1), _lib.ptr(agg), _lib.ptr(part),
+                                        _lib.stream_ptr()))
+    for _ in range(5):
+        launch_cfconv()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        launch_cfconv()
+    ev1.record()
+    torch.cuda.synchronize()
+    k_ms = ev0.elapsed_time(ev1) / reps
+    flops = E_enc * (4.0 * H * H + 2.0 * H)  # two [E,H]x[H,H] GEMMs + modulate + accumulate
+    ach = flops / (k_ms * 1e-3) / 1e12
+    roofline = {"kernel": "cfconv_layer_kernel<256>", "bound": "mfma", "achieved": round(ach, 2),
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                "traffic": None, "avg_launch_us": round(k_ms * 1e3, 2), "edges": E_enc,
+                "flop_per_edge": 4 * H * H + 2 * H}
+
+    # whole-forward arithmetic rate (SURVEY.md 8a FLOP model), for orientation
+    F = (E_enc * (131584 + 393216 + L * 262144 + L * 512) + E_out * (131584 + 393216 + 327936 + 256)
+         + N * (L * 393216 + 13000)) * args.models
+    step_s = dt / args.steps
+    fwd_tflops = F / step_s / 1e12
+
+    # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import tsdiff_oracle as O  # checker / baseline only
+        # torch-CPU scales poorly past a few dozen threads on these op sizes (256 threads measured 35 s
+        # per forward on the GPU box): use at most 32 and report the count actually used.
+        nthreads = max(1, min(os.cpu_count() or 1, args.cpu_threads))
+        torch.set_num_threads(nthreads)
+        t = {k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}
+        sds = [O.to_torch_state(synth.synth_state_dict(cfg, seed=m)) for m in range(args.models)]
+        pos_c = pos_init.cpu()
+        nz = torch.randn(args.cpu_steps + 1, N, 3)
+
+        def cpu_run(S):
+            c0 = time.perf_counter()
+            O.sample(sds, cfg, t["atom_type"], t["r_feat"], t["p_feat"], pos_c / 12.1685, t["bond_index"],
+                     t["bond_type"], t["batch"], b["num_nodes_per_graph"], nz, S)
+            return time.perf_counter() - c0
+        t1 = cpu_run(1)  # warm-up + cost estimate
+        S = int(max(2, min(args.cpu_steps, 20.0 / max(t1, 1e-3))))  # ~20 s of CPU work at most
+        cdt = cpu_run(S)
+        cpu = {"value": round(N * S / cdt, 1), "unit": "atoms*steps/s", "cores": nthreads,
+               "kind": "port", "fwd_per_s": round(S * args.models / cdt, 3),
+               "sample": f"{S} LD steps of the same {args.graphs}-graph batch (N={N}), torch-CPU oracle, "
+                         f"{nthreads} of {os.cpu_count()} host cores"}
+
+    out = {
+        "metric": "score-net fwd/sec & atoms·steps/sec, LD sampling on wb97xd3 batch=100",
+        "value": round(atoms * args.steps / dt, 1),
+        "unit": "atoms*steps/s",
+        "fwd_per_s": round(args.gpus * args.models * args.steps / dt, 2),
+        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: wb97xd3-like batch of 100 graphs, LD sampling, last K steps of the "
+                               "5000-step schedule (step_lr 1e-7, clip 1000)",
+                   "graphs_per_gpu": args.graphs, "atoms_per_gpu": N, "edges_enc": E_enc, "edges_out": E_out,
+                   "checkpoints": args.models, "hidden": H, "num_convs": L, "hipgraph": not args.no_graph,
+                   "parallelism": f"graphs sharded over {args.gpus} GPU(s), no collective"},
+        "forward_tflops": round(fwd_tflops, 2),
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

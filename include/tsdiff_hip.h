@@ -48,7 +48,7 @@ extern "C" {
 #define TSD_ERR_NAN (-4)         /* reported through status words, mapped to FloatingPointError */
 
 #define TSD_EDGE_TILE 32         /* edges per workgroup tile of every per-edge kernel */
-#define TSD_NODE_TILE 32         /* nodes per workgroup tile of the per-node kernels */
+#define TSD_NODE_TILE 16         /* nodes per workgroup tile of the per-node kernels */
 #define TSD_MAX_GRAPH_NODES 255  /* two u8 hop matrices of n*n must fit in the 160 KiB LDS */
 #define TSD_NUM_BOND_TYPES 22    /* len(rdkit BondType.names), reference utils/chem.py:21 */
 

@@ -93,13 +93,19 @@ inline bool hidden_supported(int H) { return H == 64 || H == 128 || H == 256; }
 // ---------------------------------------------------------------------------------------------
 // device math (fp32, no fast-math)
 // ---------------------------------------------------------------------------------------------
+// Activations use the hardware transcendental units (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each).
+// Absolute error of either function is ~1e-7 for every input, the same class as the fp32 rounding of
+// the reference's own softplus(x) - log 2 cancellation; the library versions cost ~100 VALU ops per
+// element, which was 30 % of the fused CFConv kernel (profiles/r01_a_kernel_stats.md).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float swishf(float x) {  // reference utils/activation_functions.py:10-11
-    return x / (1.0f + expf(-x));
+    return x * __builtin_amdgcn_rcpf(1.0f + fast_exp(-x));  // x * sigmoid(x)
 }
 __device__ __forceinline__ float sspf(float x) {  // reference models/encoder/schnet.py:65-71
-    // F.softplus(beta=1, threshold=20) - log(2)
-    float sp = (x > 20.0f) ? x : log1pf(expf(x));
-    return sp - 0.69314718055994530942f;
+    // F.softplus(beta=1, threshold=20) - log(2) = max(x,0) + log1p(exp(-|x|)) - log 2
+    const float t = fast_exp(-fabsf(x));
+    const float l = __builtin_amdgcn_logf(1.0f + t) * 0.69314718055994530942f;
+    return (fmaxf(x, 0.0f) + l) - 0.69314718055994530942f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -114,6 +120,9 @@ __device__ __forceinline__ float sspf(float x) {  // reference models/encoder/sc
 //
 // RB = T/32 row blocks, CB = column blocks (32 wide) owned by this wave starting at col0.
 // ---------------------------------------------------------------------------------------------
+// B is double-buffered in registers in chunks of PF k-blocks: while chunk c is multiplied (PF*4*RB*CB
+// MFMAs = 2048 cycles at RB=1, CB=2), chunk c+1 is in flight from L2 -- one k-block of look-ahead
+// (the first version) exposed the L2 latency every iteration (tools/mfma_probe.hip: 84 -> 93 TFLOP/s).
 template <int RB, int CB, int K>
 __device__ __forceinline__ void gemm_tile(const float* __restrict__ ldsA, int lda,
                                           const float* __restrict__ Bp, int nout, int col0,
@@ -124,31 +133,85 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ ldsA, int ld
     const float* aptr = ldsA + l31 * lda + hi * 4;
     const f32x4* bptr = reinterpret_cast<const f32x4*>(Bp) + (size_t)hi * nout + col0 + l31;
     constexpr int KB = K / 8;
-    f32x4 bcur[CB], bnxt[CB];
+    constexpr int PF = 4;
+    constexpr int NC = KB / PF;
+    static_assert(KB % PF == 0, "K must be a multiple of 32");
+    f32x4 b0[PF][CB], b1[PF][CB];
+    auto loadB = [&](f32x4 (&b)[PF][CB], int chunk) {
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) bcur[cb] = bptr[cb * 32];
-#pragma unroll 2
-    for (int kb = 0; kb < KB; ++kb) {
-        if (kb + 1 < KB) {
+        for (int p = 0; p < PF; ++p)
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) bnxt[cb] = bptr[(size_t)(kb + 1) * 2 * nout + cb * 32];
-        }
-        f32x4 a[RB];
+            for (int cb = 0; cb < CB; ++cb) b[p][cb] = bptr[(size_t)(chunk * PF + p) * 2 * nout + cb * 32];
+    };
+    auto compute = [&](const f32x4 (&b)[PF][CB], int chunk) {
+        f32x4 a[PF][RB];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-            a[rb] = *reinterpret_cast<const f32x4*>(aptr + rb * 32 * lda + kb * 8);
+        for (int p = 0; p < PF; ++p)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+            for (int rb = 0; rb < RB; ++rb)
+                a[p][rb] = *reinterpret_cast<const f32x4*>(aptr + rb * 32 * lda + (chunk * PF + p) * 8);
 #pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
+        for (int p = 0; p < PF; ++p)
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb][s], bcur[cb][s], acc[rb][cb], 0, 0, 0);
-                }
-            }
-        }
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) bcur[cb] = bnxt[cb];
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][rb][s], b[p][cb][s], acc[rb][cb], 0, 0, 0);
+    };
+    loadB(b0, 0);
+    for (int c = 0; c < NC; c += 2) {
+        if (c + 1 < NC) loadB(b1, c + 1);
+        compute(b0, c);
+        if (c + 2 < NC) loadB(b0, c + 2);
+        if (c + 1 < NC) compute(b1, c + 1);
+    }
+}
+
+// 16-row variant on the 16x16x4 f32 MFMA (same rate, half the rows): A lane l holds A[i = l&15][k = l>>4],
+// B lane l holds B[k = l>>4][j = l&15], C/D: col = l&15, row = (l>>4)*4 + r, r in [0,4).
+// k is permuted in groups of 16: step s of k-block kb consumes k = kb*16 + q*4 + s on lane quarter q, so a
+// lane reads one float4 of A and one float4 of B per column block per 4 MFMAs, from the SAME packed
+// weight layout ([k/4][out][k%4]) as the 32-row variant.  CB = 16-wide column blocks of this wave.
+template <int CB, int K>
+__device__ __forceinline__ void gemm_tile16(const float* __restrict__ ldsA, int lda,
+                                            const float* __restrict__ Bp, int nout, int col0,
+                                            f32x4 (&acc)[CB]) {
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4;
+    const int l15 = lane & 15;
+    const float* aptr = ldsA + l15 * lda + q * 4;
+    const f32x4* bptr = reinterpret_cast<const f32x4*>(Bp) + (size_t)q * nout + col0 + l15;
+    constexpr int KB = K / 16;
+    constexpr int PF = 4;
+    constexpr int NC = KB / PF;
+    static_assert(KB % PF == 0, "K must be a multiple of 64");
+    f32x4 b0[PF][CB], b1[PF][CB];
+    auto loadB = [&](f32x4 (&b)[PF][CB], int chunk) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) b[p][cb] = bptr[(size_t)(chunk * PF + p) * 4 * nout + cb * 16];
+    };
+    auto compute = [&](const f32x4 (&b)[PF][CB], int chunk) {
+        f32x4 a[PF];
+#pragma unroll
+        for (int p = 0; p < PF; ++p) a[p] = *reinterpret_cast<const f32x4*>(aptr + (chunk * PF + p) * 16);
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][s], b[p][cb][s], acc[cb], 0, 0, 0);
+    };
+    loadB(b0, 0);
+    for (int c = 0; c < NC; c += 2) {
+        if (c + 1 < NC) loadB(b1, c + 1);
+        compute(b0, c);
+        if (c + 2 < NC) loadB(b0, c + 2);
+        if (c + 1 < NC) compute(b1, c + 1);
     }
 }
 

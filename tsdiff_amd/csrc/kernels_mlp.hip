@@ -8,7 +8,8 @@
 
 namespace tsd {
 
-constexpr int T = TSD_EDGE_TILE;  // 32 rows per tile everywhere in this file
+constexpr int T = TSD_EDGE_TILE;   // 32 edges per tile in the per-edge kernels
+constexpr int TN = TSD_NODE_TILE;  // 16 nodes per tile in the per-node kernels
 
 struct EdgeEmbedW {
     const float *bond_emb, *w0, *b0, *w1, *b1, *cw0, *cb0, *cw1, *cb1;
@@ -218,77 +219,83 @@ __global__ __launch_bounds__(H) void cfconv_layer_kernel(CfconvW w, float conv_c
 //   a = assemble(agg, part); h += lin(ssp(lin2(a))); x1 = lin1_next(h)
 // reference models/encoder/schnet.py:103 (lin2), :123-127 (act, lin), :223-224 (residual),
 // :101 (next layer's lin1).   MODE 0: full update; MODE 1: only x1 = lin1(h) (first layer).
+// N is small (1600 atoms at batch 100): 16-row tiles on the 16x16x4 MFMA and 2H threads (H/32 waves,
+// two per SIMD at H=256, 32 columns each) spread the three dependent GEMMs over 2x the CUs with
+// 2x the waves per CU of the 32-row form (75 -> see profiles/ for the measured time per layer).
 // ---------------------------------------------------------------------------------------------
 template <int H, int MODE>
-__global__ __launch_bounds__(H) void node_update_kernel(NodeW w, int N, const int32_t* __restrict__ row_ptr,
-                                                        const float* __restrict__ agg,
-                                                        const float* __restrict__ part,
-                                                        float* __restrict__ h, float* __restrict__ x1) {
+__global__ __launch_bounds__(2 * H) void node_update_kernel(NodeW w, int N, const int32_t* __restrict__ row_ptr,
+                                                            const float* __restrict__ agg,
+                                                            const float* __restrict__ part,
+                                                            float* __restrict__ h, float* __restrict__ x1) {
     constexpr int LDA = H + 4;
+    constexpr int NT = 2 * H;
+    constexpr int C4 = H / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* buf = smem;
-    int* s_rp0 = reinterpret_cast<int*>(smem + T * LDA);
-    int* s_rp1 = s_rp0 + T;
+    int* s_rp0 = reinterpret_cast<int*>(smem + TN * LDA);
+    int* s_rp1 = s_rp0 + TN;
 
-    const int n0 = blockIdx.x * T;
+    const int n0 = blockIdx.x * TN;
     const int tid = threadIdx.x;
-    const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
-    const int col0 = (tid >> 6) * 64;
-    const int nrows = min(T, N - n0);
-    f32x16 acc[1][2];
+    const int lane = tid & 63, q = lane >> 4, l15 = lane & 15;
+    const int col0 = (tid >> 6) * 32;
+    const int nrows = min(TN, N - n0);
+    f32x4 acc[2];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     if (MODE == 0) {
-        if (tid < T) {
+        if (tid < TN) {
             const bool v = tid < nrows;
             s_rp0[tid] = v ? row_ptr[n0 + tid] : 0;
             s_rp1[tid] = v ? row_ptr[n0 + tid + 1] : 0;
         }
         __syncthreads();
-        const int c = tid;
-        for (int r = 0; r < T; ++r) {
+        for (int idx = tid; idx < TN * C4; idx += NT) {
+            const int r = idx / C4, c4 = idx % C4;
             const int rp0 = s_rp0[r], rp1 = s_rp1[r];
-            float v = 0.0f;
+            f32x4 v = zero4;
             if (rp1 > rp0) {
                 const int t0 = rp0 / T, t1 = (rp1 - 1) / T;
                 if (t0 == t1) {
-                    v = agg[(size_t)(n0 + r) * H + c];
-                } else {
+                    v = *reinterpret_cast<const f32x4*>(agg + (size_t)(n0 + r) * H + c4 * 4);
+                } else {  // row cut by edge-tile boundaries: add the tiles' partial sums in order
                     for (int t = t0; t <= t1; ++t) {
                         const int slot = (t == t0 && rp0 != t0 * T) ? 1 : 0;
-                        v += part[((size_t)t * 2 + slot) * H + c];
+                        v += *reinterpret_cast<const f32x4*>(part + ((size_t)t * 2 + slot) * H + c4 * 4);
                     }
                 }
             }
-            buf[r * LDA + c] = v;
+            *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = v;
         }
         __syncthreads();
 
-        zero_acc(acc);
-        gemm_tile<1, 2, H>(buf, LDA, w.lin2_w, H, col0, acc);
+        acc[0] = zero4; acc[1] = zero4;
+        gemm_tile16<2, H>(buf, LDA, w.lin2_w, H, col0, acc);
         __syncthreads();
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-            const int col = col0 + cb * 32 + l31;
+            const int col = col0 + cb * 16 + l15;
             const float b = w.lin2_b[col];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) buf[acc_row(r, hi) * LDA + col] = sspf(acc[0][cb][r] + b);
+            for (int r = 0; r < 4; ++r) buf[(q * 4 + r) * LDA + col] = sspf(acc[cb][r] + b);
         }
         __syncthreads();
 
-        zero_acc(acc);
-        gemm_tile<1, 2, H>(buf, LDA, w.lin_w, H, col0, acc);
+        acc[0] = zero4; acc[1] = zero4;
+        gemm_tile16<2, H>(buf, LDA, w.lin_w, H, col0, acc);
         __syncthreads();
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-            const int col = col0 + cb * 32 + l31;
+            const int col = col0 + cb * 16 + l15;
             const float b = w.lin_b[col];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = acc_row(r, hi);
+            for (int r = 0; r < 4; ++r) {
+                const int row = q * 4 + r;
                 float hn = 0.0f;
                 if (row < nrows) {
                     const size_t o = (size_t)(n0 + row) * H + col;
-                    hn = h[o] + (acc[0][cb][r] + b);
+                    hn = h[o] + (acc[cb][r] + b);
                     h[o] = hn;
                 }
                 buf[row * LDA + col] = hn;
@@ -297,25 +304,24 @@ __global__ __launch_bounds__(H) void node_update_kernel(NodeW w, int N, const in
         if (w.lin1_next_w == nullptr) return;
         __syncthreads();
     } else {
-        constexpr int C4 = H / 4;
-        for (int idx = tid; idx < T * C4; idx += H) {
+        for (int idx = tid; idx < TN * C4; idx += NT) {
             const int r = idx / C4, c4 = idx % C4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            f32x4 v = zero4;
             if (r < nrows) v = *reinterpret_cast<const f32x4*>(h + (size_t)(n0 + r) * H + c4 * 4);
             *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = v;
         }
         __syncthreads();
     }
 
-    zero_acc(acc);
-    gemm_tile<1, 2, H>(buf, LDA, w.lin1_next_w, H, col0, acc);
+    acc[0] = zero4; acc[1] = zero4;
+    gemm_tile16<2, H>(buf, LDA, w.lin1_next_w, H, col0, acc);
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
-        const int col = col0 + cb * 32 + l31;
+        const int col = col0 + cb * 16 + l15;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = acc_row(r, hi);
-            if (row < nrows) x1[(size_t)(n0 + row) * H + col] = acc[0][cb][r];
+        for (int r = 0; r < 4; ++r) {
+            const int row = q * 4 + r;
+            if (row < nrows) x1[(size_t)(n0 + row) * H + col] = acc[cb][r];
         }
     }
 }
@@ -427,7 +433,7 @@ __global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ d
 // ---------------------------------------------------------------------------------------------
 static inline size_t lds_edge_embed(int H) { return (size_t)(T * (2 * H + 4) + 3 * T) * 4; }
 static inline size_t lds_cfconv(int H) { return (size_t)(T * (H + 4) + 5 * T) * 4; }
-static inline size_t lds_node(int H) { return (size_t)(T * (H + 4) + 2 * T) * 4; }
+static inline size_t lds_node(int H) { return (size_t)(TN * (H + 4) + 2 * TN) * 4; }
 static inline size_t lds_pair(int H) { return (size_t)(T * (2 * H + 4) + (H / 64) * T + 2 * T) * 4; }
 
 template <typename K>
@@ -490,13 +496,13 @@ int launch_node_update(const tsd_model_cfg& c, const float* W, int layer, int ne
     const float* B = W + L.layer0 + (size_t)layer * L.layer_stride;
     const float* Bn = next_layer >= 0 ? W + L.layer0 + (size_t)next_layer * L.layer_stride + L.L_lin1_w : nullptr;
     NodeW w{B + L.L_lin2_w, B + L.L_lin2_b, B + L.L_lin_w, B + L.L_lin_b, Bn};
-    const int tiles = (N + T - 1) / T;
+    const int tiles = (N + TN - 1) / TN;
     if (tiles == 0) return TSD_OK;
     const size_t lds = lds_node(c.hidden);
     TSD_DISPATCH_H(c.hidden, {
         static bool done = false; int r = allow_lds_once(node_update_kernel<HH, 0>, lds, done);
         if (r) return r;
-        hipLaunchKernelGGL((node_update_kernel<HH, 0>), dim3(tiles), dim3(HH), lds, st, w, N, row_ptr, agg, part,
+        hipLaunchKernelGGL((node_update_kernel<HH, 0>), dim3(tiles), dim3(2 * HH), lds, st, w, N, row_ptr, agg, part,
                            h, x1);
     });
     TSD_LAUNCH_CHECK("node_update");
@@ -508,13 +514,13 @@ int launch_node_lin1(const tsd_model_cfg& c, const float* W, int layer, int N, c
     const WeightLayout L = weight_layout(c);
     const float* B = W + L.layer0 + (size_t)layer * L.layer_stride;
     NodeW w{nullptr, nullptr, nullptr, nullptr, B + L.L_lin1_w};
-    const int tiles = (N + T - 1) / T;
+    const int tiles = (N + TN - 1) / TN;
     if (tiles == 0) return TSD_OK;
     const size_t lds = lds_node(c.hidden);
     TSD_DISPATCH_H(c.hidden, {
         static bool done = false; int r = allow_lds_once(node_update_kernel<HH, 1>, lds, done);
         if (r) return r;
-        hipLaunchKernelGGL((node_update_kernel<HH, 1>), dim3(tiles), dim3(HH), lds, st, w, N,
+        hipLaunchKernelGGL((node_update_kernel<HH, 1>), dim3(tiles), dim3(2 * HH), lds, st, w, N,
                            (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr,
                            const_cast<float*>(h), x1);
     });
