@@ -108,13 +108,18 @@ int tsd_topology_build(int32_t num_nodes, int32_t num_graphs, int32_t num_pairs,
 
 /* ---- geometry (every step) ---------------------------------------------------------------
  * Builds the order-`edge_order` (enc) and order-`pred_edge_order` (out) edge lists of `pos`.
- * scratch: int32 [2*(N+1) + 2*P]. out2enc [P]: enc edge index of every out edge.
+ * scratch: int32 [tsd_geometry_scratch_ints].
+ * diff: the out edges whose (edge_length, type_r, type_p) differ from their enc edge (or have none);
+ *       only count, row_ptr, dist, type_r, type_p are written.  Their embeddings are computed on
+ *       their own; every other out edge shares the enc edge's embedding bit for bit.
+ * attr_row [P]: for every out edge the row of the [2P,H] edge-attribute matrix holding its embedding:
+ *       the enc edge index (< P), or P + k for the k-th diff edge.
  * pair2out [P]: out edge index of every ordered pair, -1 when the pair is not an out edge. */
 size_t tsd_geometry_scratch_ints(int32_t num_nodes, int32_t num_pairs);
 int tsd_geometry_build(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_graphs, int32_t num_pairs,
                        const float* pos, const int32_t* graph_ptr, const int32_t* node_graph,
                        const int32_t* pair_ptr, const uint16_t* pair_code,
-                       tsd_edges enc, tsd_edges out, int32_t* out2enc, int32_t* pair2out,
+                       tsd_edges enc, tsd_edges out, tsd_edges diff, int32_t* attr_row, int32_t* pair2out,
                        int32_t* scratch, void* stream);
 
 /* ---- network pieces (one checkpoint each; `w` = packed weights of that checkpoint) --------- */
@@ -146,8 +151,10 @@ int tsd_node_update(const tsd_model_cfg* cfg, const float* w, int32_t layer, int
                     int32_t num_nodes, const int32_t* enc_row_ptr, const float* agg, const float* part,
                     float* h, float* x1, void* stream);
 
+/* edge_attr: edge-attribute matrix, row attr_row[e] belongs to out edge e (attr_row NULL: row e). */
 int tsd_pair_output(const tsd_model_cfg* cfg, const float* w, int32_t capacity, tsd_edges out,
-                    const float* h, const float* edge_attr_out, float* edge_inv /* [cap] */, void* stream);
+                    const float* h, const float* edge_attr, const int32_t* attr_row,
+                    float* edge_inv /* [cap] */, void* stream);
 
 /* ---- distance score -> Cartesian score -------------------------------------------------- */
 /* generic (any edge list, int64 like the reference surface); fp32 atomics. score must be zeroed. */
@@ -164,8 +171,8 @@ typedef struct tsd_batch {
     const uint16_t* pair_code;  /* [P] */
     const float* weights;       /* [M, packed_floats] */
     const float* z;             /* [M, N, H] node embeddings (tsd_node_embed), pos independent */
-    tsd_edges enc, out;
-    int32_t* out2enc;           /* [P] */
+    tsd_edges enc, out, diff;
+    int32_t* attr_row;          /* [P] */
     int32_t* pair2out;          /* [P] */
     int32_t* geo_scratch;       /* tsd_geometry_scratch_ints */
     float* workspace;           /* tsd_forward_workspace_floats */

@@ -65,7 +65,8 @@ class Batch(C.Structure):
         ("z", C.c_void_p),
         ("enc", Edges),
         ("out", Edges),
-        ("out2enc", C.c_void_p),
+        ("diff", Edges),
+        ("attr_row", C.c_void_p),
         ("pair2out", C.c_void_p),
         ("geo_scratch", C.c_void_p),
         ("workspace", C.c_void_p),
@@ -86,14 +87,14 @@ SIGNATURES = {
                                      C.c_int32, _P, _P, _P, _P, _P]),
     "tsd_geometry_scratch_ints": (C.c_size_t, [C.c_int32, C.c_int32]),
     "tsd_geometry_build": (C.c_int, [_CFG, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, Edges, Edges,
-                                     _P, _P, _P, _P]),
+                                     Edges, _P, _P, _P, _P]),
     "tsd_node_embed": (C.c_int, [_CFG, _P, C.c_int32, _P, _P, _P, _P, _P]),
     "tsd_edge_embed": (C.c_int, [_CFG, _P, C.c_int32, Edges, _P, _P]),
     "tsd_node_lin1": (C.c_int, [_CFG, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "tsd_cfconv_layer": (C.c_int, [_CFG, _P, C.c_int32, C.c_int32, Edges, _P, _P, _P, _P, _P]),
     "tsd_cfconv_aggregate": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "tsd_node_update": (C.c_int, [_CFG, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
-    "tsd_pair_output": (C.c_int, [_CFG, _P, C.c_int32, Edges, _P, _P, _P, _P]),
+    "tsd_pair_output": (C.c_int, [_CFG, _P, C.c_int32, Edges, _P, _P, _P, _P, _P]),
     "tsd_eq_transform": (C.c_int, [C.c_int32, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "tsd_forward_workspace_floats": (C.c_size_t, [_CFG, C.c_int32, C.c_int32, C.c_int32]),
     "tsd_score_forward": (C.c_int, [_CFG, C.POINTER(Batch), _P, _P]),

@@ -28,16 +28,16 @@ int launch_cfconv_layer(const tsd_model_cfg&, const float*, int, int, tsd_edges,
 int launch_node_update(const tsd_model_cfg&, const float*, int, int, int, const int32_t*, const float*,
                        const float*, float*, float*, hipStream_t);
 int launch_node_lin1(const tsd_model_cfg&, const float*, int, int, const float*, float*, hipStream_t);
-int launch_pair_output(const tsd_model_cfg&, const float*, int, tsd_edges, const float*, const float*, float*,
-                       hipStream_t);
+int launch_pair_output(const tsd_model_cfg&, const float*, int, tsd_edges, const float*, const float*,
+                       const int32_t*, float*, hipStream_t);
 size_t raw_weight_floats(const tsd_model_cfg&);
 int launch_pack_weights(const tsd_model_cfg&, const float*, float*, hipStream_t);
 int launch_topology(int, int, int, int64_t, const int32_t*, const int32_t*, const int64_t*, const int64_t*, int,
                     int, int32_t*, int32_t*, uint16_t*, int32_t*, hipStream_t);
 size_t geometry_scratch_ints(int, int);
 int launch_geometry(const tsd_model_cfg&, int, int, int, const float*, const int32_t*, const int32_t*,
-                    const int32_t*, const uint16_t*, tsd_edges, tsd_edges, int32_t*, int32_t*, int32_t*,
-                    hipStream_t);
+                    const int32_t*, const uint16_t*, tsd_edges, tsd_edges, tsd_edges, int32_t*, int32_t*,
+                    int32_t*, hipStream_t);
 int launch_node_embed(const tsd_model_cfg&, const float*, int, const int64_t*, const int64_t*, const int64_t*,
                       float*, hipStream_t);
 int launch_cfconv_aggregate(int, int, const int32_t*, const int32_t*, const float*, const float*, float*,
@@ -62,7 +62,7 @@ static int check_cfg(const tsd_model_cfg* c) {
 }
 
 struct Workspace {
-    float *ea_enc, *ea_out, *h, *x1, *agg, *part;
+    float *ea, *h, *x1, *agg, *part;  // ea: [2P,H] rows 0..P-1 enc edges, rows P.. separately embedded out edges
     size_t total;
 };
 
@@ -71,8 +71,7 @@ static Workspace carve(const tsd_model_cfg& c, int N, int P, float* base) {
     const size_t H = c.hidden;
     size_t o = 0;
     auto take = [&](size_t n) { float* p = base ? base + o : nullptr; o += (n + 63) & ~size_t(63); return p; };
-    w.ea_enc = take((size_t)P * H);
-    w.ea_out = (c.edge_order != c.pred_edge_order) ? take((size_t)P * H) : w.ea_enc;
+    w.ea = take((size_t)2 * P * H);
     w.h = take((size_t)N * H);
     w.x1 = take((size_t)N * H);
     w.agg = take((size_t)N * H);
@@ -86,27 +85,27 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     const size_t H = c.hidden;
     int r;
     if ((r = launch_geometry(c, N, G, P, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, b.enc, b.out,
-                             b.out2enc, b.pair2out, b.geo_scratch, st)))
+                             b.diff, b.attr_row, b.pair2out, b.geo_scratch, st)))
         return r;
     const Workspace w = carve(c, N, P, b.workspace);
     const size_t wfloats = weight_layout(c).total;
-    const bool same = c.edge_order == c.pred_edge_order;
     for (int m = 0; m < M; ++m) {
         const float* W = b.weights + (size_t)m * wfloats;
-        if ((r = launch_edge_embed(c, W, P, b.enc, w.ea_enc, st))) return r;
+        if ((r = launch_edge_embed(c, W, P, b.enc, w.ea, st))) return r;
         TSD_HIP(hipMemcpyAsync(w.h, b.z + (size_t)m * N * H, (size_t)N * H * sizeof(float),
                                hipMemcpyDeviceToDevice, st));
         if ((r = launch_node_lin1(c, W, 0, N, w.h, w.x1, st))) return r;
         for (int l = 0; l < c.num_convs; ++l) {
-            if ((r = launch_cfconv_layer(c, W, l, P, b.enc, w.ea_enc, w.x1, w.agg, w.part, st))) return r;
+            if ((r = launch_cfconv_layer(c, W, l, P, b.enc, w.ea, w.x1, w.agg, w.part, st))) return r;
             if ((r = launch_node_update(c, W, l, (l + 1 < c.num_convs) ? l + 1 : -1, N, b.enc.row_ptr, w.agg,
                                         w.part, w.h, w.x1, st)))
                 return r;
         }
-        if (!same) {
-            if ((r = launch_edge_embed(c, W, P, b.out, w.ea_out, st))) return r;
-        }
-        if ((r = launch_pair_output(c, W, P, b.out, w.h, w.ea_out, b.edge_inv + (size_t)m * P, st))) return r;
+        // out edges whose (d, types) differ from their enc edge (only the hop == edge_order pairs when
+        // pred_edge_order < edge_order) are embedded on their own; every other out edge reuses its enc row
+        if ((r = launch_edge_embed(c, W, P, b.diff, w.ea + (size_t)P * H, st))) return r;
+        if ((r = launch_pair_output(c, W, P, b.out, w.h, w.ea, b.attr_row, b.edge_inv + (size_t)m * P, st)))
+            return r;
     }
     return TSD_OK;
 }
@@ -171,13 +170,14 @@ size_t tsd_geometry_scratch_ints(int32_t num_nodes, int32_t num_pairs) {
 int tsd_geometry_build(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_graphs, int32_t num_pairs,
                        const float* pos, const int32_t* graph_ptr, const int32_t* node_graph,
                        const int32_t* pair_ptr, const uint16_t* pair_code, tsd_edges enc, tsd_edges out,
-                       int32_t* out2enc, int32_t* pair2out, int32_t* scratch, void* stream) {
+                       tsd_edges diff, int32_t* attr_row, int32_t* pair2out, int32_t* scratch, void* stream) {
     int r = check_cfg(cfg);
     if (r) return r;
     TSD_REQUIRE(pos && graph_ptr && node_graph && pair_ptr && scratch, "null pointer");
-    TSD_REQUIRE(enc.count && enc.row_ptr && out.count && out.row_ptr, "null edge list");
+    TSD_REQUIRE(enc.count && enc.row_ptr && out.count && out.row_ptr && diff.count && diff.row_ptr && attr_row,
+                "null edge list");
     return launch_geometry(*cfg, num_nodes, num_graphs, num_pairs, pos, graph_ptr, node_graph, pair_ptr,
-                           pair_code, enc, out, out2enc, pair2out, scratch, (hipStream_t)stream);
+                           pair_code, enc, out, diff, attr_row, pair2out, scratch, (hipStream_t)stream);
 }
 
 int tsd_node_embed(const tsd_model_cfg* cfg, const float* w, int32_t num_nodes, const int64_t* atom_type,
@@ -227,10 +227,10 @@ int tsd_node_update(const tsd_model_cfg* cfg, const float* w, int32_t layer, int
 }
 
 int tsd_pair_output(const tsd_model_cfg* cfg, const float* w, int32_t capacity, tsd_edges out, const float* h,
-                    const float* edge_attr_out, float* edge_inv, void* stream) {
+                    const float* edge_attr, const int32_t* attr_row, float* edge_inv, void* stream) {
     int r = check_cfg(cfg);
     if (r) return r;
-    return launch_pair_output(*cfg, w, capacity, out, h, edge_attr_out, edge_inv, (hipStream_t)stream);
+    return launch_pair_output(*cfg, w, capacity, out, h, edge_attr, attr_row, edge_inv, (hipStream_t)stream);
 }
 
 int tsd_eq_transform(int32_t num_nodes, int64_t num_edges, const float* score_d, const float* pos,

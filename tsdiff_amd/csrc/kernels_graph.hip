@@ -164,6 +164,11 @@ struct PairEval {
     float d2, d;
     int tr_enc, tp_enc, tr_out, tp_out;
     bool in_enc, in_out;
+    // an out edge whose (d, type_r, type_p) equal its enc edge's has the SAME edge embedding
+    // (same kernel, same inputs, same weights); only the others are embedded a second time
+    __device__ __forceinline__ bool needs_own_attr() const {
+        return in_out && (!in_enc || tr_enc != tr_out || tp_enc != tp_out);
+    }
 };
 
 __device__ __forceinline__ PairEval eval_pair(const float* __restrict__ pos, int i, int j, int code,
@@ -192,73 +197,88 @@ __global__ __launch_bounds__(256) void pair_count_kernel(int N, const float* __r
                                                          const uint16_t* __restrict__ pair_code,
                                                          int order_enc, int order_out, float cut2,
                                                          int32_t* __restrict__ cnt_enc,
-                                                         int32_t* __restrict__ cnt_out) {
+                                                         int32_t* __restrict__ cnt_out,
+                                                         int32_t* __restrict__ cnt_diff) {
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= N) return;
     const int lo = graph_ptr[node_graph[i]];
     const int il = i - lo;
     const int p0 = pair_ptr[i], np = pair_ptr[i + 1] - p0;
-    int ce = 0, co = 0;
+    int ce = 0, co = 0, cd = 0;
     for (int k0 = 0; k0 < np; k0 += 64) {
         const int k = k0 + lane;
-        bool me = false, mo = false;
+        bool me = false, mo = false, md = false;
         if (k < np) {
             const int j = lo + k + (k >= il ? 1 : 0);
             const PairEval r = eval_pair(pos, i, j, pair_code[p0 + k], order_enc, order_out, cut2);
             me = r.in_enc;
             mo = r.in_out;
+            md = r.needs_own_attr();
         }
         ce += __popcll(__ballot(me));
         co += __popcll(__ballot(mo));
+        cd += __popcll(__ballot(md));
     }
     if (lane == 0) {
         cnt_enc[i] = ce;
         cnt_out[i] = co;
+        cnt_diff[i] = cd;
     }
 }
 
-// exclusive scan of two int arrays of length N (+ total at [N]); single workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void scan2_kernel(int N, const int32_t* __restrict__ a_in,
+// exclusive scan of three int arrays of length N (+ total at [N]); single workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void scan3_kernel(int N, const int32_t* __restrict__ a_in,
                                                      const int32_t* __restrict__ b_in,
+                                                     const int32_t* __restrict__ c_in,
                                                      int32_t* __restrict__ a_out, int32_t* __restrict__ b_out,
-                                                     int32_t* __restrict__ a_total, int32_t* __restrict__ b_total) {
-    __shared__ int sa[1024], sb[1024];
+                                                     int32_t* __restrict__ c_out,
+                                                     int32_t* __restrict__ a_total, int32_t* __restrict__ b_total,
+                                                     int32_t* __restrict__ c_total) {
+    __shared__ int sa[1024], sb[1024], sc[1024];
     const int t = threadIdx.x;
     const int per = (N + 1023) / 1024;
     const int beg = min(N, t * per), end = min(N, beg + per);
-    int xa = 0, xb = 0;
+    int xa = 0, xb = 0, xc = 0;
     for (int i = beg; i < end; ++i) {
         xa += a_in[i];
         xb += b_in[i];
+        xc += c_in[i];
     }
     sa[t] = xa;
     sb[t] = xb;
+    sc[t] = xc;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-        int va = 0, vb = 0;
+        int va = 0, vb = 0, vc = 0;
         if (t >= off) {
             va = sa[t - off];
             vb = sb[t - off];
+            vc = sc[t - off];
         }
         __syncthreads();
         sa[t] += va;
         sb[t] += vb;
+        sc[t] += vc;
         __syncthreads();
     }
-    int ra = sa[t] - xa, rb = sb[t] - xb;  // exclusive prefix of this thread's chunk
+    int ra = sa[t] - xa, rb = sb[t] - xb, rc = sc[t] - xc;  // exclusive prefix of this thread's chunk
     for (int i = beg; i < end; ++i) {
-        const int va = a_in[i], vb = b_in[i];
+        const int va = a_in[i], vb = b_in[i], vc = c_in[i];
         a_out[i] = ra;
         b_out[i] = rb;
+        c_out[i] = rc;
         ra += va;
         rb += vb;
+        rc += vc;
     }
     if (t == 1023) {
         a_out[N] = sa[1023];
         b_out[N] = sb[1023];
+        c_out[N] = sc[1023];
         *a_total = sa[1023];
         *b_total = sb[1023];
+        *c_total = sc[1023];
     }
 }
 
@@ -268,8 +288,8 @@ __global__ __launch_bounds__(256) void pair_fill_kernel(int N, const float* __re
                                                         const int32_t* __restrict__ pair_ptr,
                                                         const uint16_t* __restrict__ pair_code,
                                                         int order_enc, int order_out, float cut2,
-                                                        tsd_edges enc, tsd_edges out,
-                                                        int32_t* __restrict__ out2enc,
+                                                        tsd_edges enc, tsd_edges out, tsd_edges diff,
+                                                        int32_t* __restrict__ attr_row, int P,
                                                         int32_t* __restrict__ pair2out) {
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -277,7 +297,7 @@ __global__ __launch_bounds__(256) void pair_fill_kernel(int N, const float* __re
     const int lo = graph_ptr[node_graph[i]];
     const int il = i - lo;
     const int p0 = pair_ptr[i], np = pair_ptr[i + 1] - p0;
-    int be = enc.row_ptr[i], bo = out.row_ptr[i];
+    int be = enc.row_ptr[i], bo = out.row_ptr[i], bd = diff.row_ptr[i];
     const unsigned long long lower = (1ull << lane) - 1ull;
     for (int k0 = 0; k0 < np; k0 += 64) {
         const int k = k0 + lane;
@@ -288,8 +308,9 @@ __global__ __launch_bounds__(256) void pair_fill_kernel(int N, const float* __re
             j = lo + k + (k >= il ? 1 : 0);
             r = eval_pair(pos, i, j, pair_code[p0 + k], order_enc, order_out, cut2);
         }
-        const unsigned long long me = __ballot(r.in_enc), mo = __ballot(r.in_out);
-        const int ie = be + __popcll(me & lower), io = bo + __popcll(mo & lower);
+        const bool own = (k < np) && r.needs_own_attr();
+        const unsigned long long me = __ballot(r.in_enc), mo = __ballot(r.in_out), md = __ballot(own);
+        const int ie = be + __popcll(me & lower), io = bo + __popcll(mo & lower), id = bd + __popcll(md & lower);
         if (r.in_enc) {
             enc.src[ie] = i;
             enc.dst[ie] = j;
@@ -305,40 +326,46 @@ __global__ __launch_bounds__(256) void pair_fill_kernel(int N, const float* __re
             out.type_r[io] = (uint8_t)r.tr_out;
             out.type_p[io] = (uint8_t)r.tp_out;
             out.pair_id[io] = p0 + k;
-            out2enc[io] = r.in_enc ? ie : -1;
+            attr_row[io] = own ? P + id : ie;  // row of the [2P,H] edge-attribute matrix
+        }
+        if (own) {
+            diff.dist[id] = r.d;
+            diff.type_r[id] = (uint8_t)r.tr_out;
+            diff.type_p[id] = (uint8_t)r.tp_out;
         }
         if (k < np) pair2out[p0 + k] = r.in_out ? io : -1;
         be += __popcll(me);
         bo += __popcll(mo);
+        bd += __popcll(md);
     }
 }
 
 size_t geometry_scratch_ints(int N, int P) {
     (void)P;
-    return (size_t)2 * (N + 1);
+    return (size_t)3 * (N + 1);
 }
 
 int launch_geometry(const tsd_model_cfg& c, int N, int G, int P, const float* pos, const int32_t* graph_ptr,
                     const int32_t* node_graph, const int32_t* pair_ptr, const uint16_t* pair_code,
-                    tsd_edges enc, tsd_edges out, int32_t* out2enc, int32_t* pair2out, int32_t* scratch,
-                    hipStream_t st) {
+                    tsd_edges enc, tsd_edges out, tsd_edges diff, int32_t* attr_row, int32_t* pair2out,
+                    int32_t* scratch, hipStream_t st) {
     (void)G;
-    (void)P;
     int32_t* cnt_enc = scratch;
     int32_t* cnt_out = scratch + (N + 1);
+    int32_t* cnt_diff = scratch + 2 * (N + 1);
     const float cut2 = c.edge_cutoff * c.edge_cutoff;
     const int blocks = (N + 3) / 4;
     if (N > 0) {
         hipLaunchKernelGGL(pair_count_kernel, dim3(blocks), dim3(256), 0, st, N, pos, graph_ptr, node_graph,
-                           pair_ptr, pair_code, c.edge_order, c.pred_edge_order, cut2, cnt_enc, cnt_out);
+                           pair_ptr, pair_code, c.edge_order, c.pred_edge_order, cut2, cnt_enc, cnt_out, cnt_diff);
         TSD_LAUNCH_CHECK("pair_count");
     }
-    hipLaunchKernelGGL(scan2_kernel, dim3(1), dim3(1024), 0, st, N, cnt_enc, cnt_out, enc.row_ptr, out.row_ptr,
-                       enc.count, out.count);
-    TSD_LAUNCH_CHECK("scan2");
+    hipLaunchKernelGGL(scan3_kernel, dim3(1), dim3(1024), 0, st, N, cnt_enc, cnt_out, cnt_diff, enc.row_ptr,
+                       out.row_ptr, diff.row_ptr, enc.count, out.count, diff.count);
+    TSD_LAUNCH_CHECK("scan3");
     if (N > 0) {
         hipLaunchKernelGGL(pair_fill_kernel, dim3(blocks), dim3(256), 0, st, N, pos, graph_ptr, node_graph,
-                           pair_ptr, pair_code, c.edge_order, c.pred_edge_order, cut2, enc, out, out2enc,
+                           pair_ptr, pair_code, c.edge_order, c.pred_edge_order, cut2, enc, out, diff, attr_row, P,
                            pair2out);
         TSD_LAUNCH_CHECK("pair_fill");
     }

@@ -333,6 +333,7 @@ __global__ __launch_bounds__(2 * H) void node_update_kernel(NodeW w, int N, cons
 template <int H>
 __global__ __launch_bounds__(H) void pair_output_kernel(PairW w, tsd_edges e, const float* __restrict__ h,
                                                         const float* __restrict__ edge_attr,
+                                                        const int32_t* __restrict__ attr_row,
                                                         float* __restrict__ edge_inv) {
     constexpr int LDA = 2 * H + 4;
     constexpr int NW = H / 64;
@@ -341,6 +342,7 @@ __global__ __launch_bounds__(H) void pair_output_kernel(PairW w, tsd_edges e, co
     float* s_red = smem + T * LDA;  // [NW][T]
     int* s_src = reinterpret_cast<int*>(s_red + NW * T);
     int* s_dst = s_src + T;
+    int* s_row = s_dst + T;
 
     const int E = *e.count;
     const int e0 = blockIdx.x * T;
@@ -354,6 +356,7 @@ __global__ __launch_bounds__(H) void pair_output_kernel(PairW w, tsd_edges e, co
         const bool v = tid < nrows;
         s_src[tid] = v ? e.src[e0 + tid] : 0;
         s_dst[tid] = v ? e.dst[e0 + tid] : 0;
+        s_row[tid] = v ? (attr_row ? attr_row[e0 + tid] : e0 + tid) : 0;
     }
     __syncthreads();
     {
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(H) void pair_output_kernel(PairW w, tsd_edges e, co
             float a = 0.0f, b = 0.0f;
             if (r < nrows) {
                 a = h[(size_t)s_src[r] * H + c] * h[(size_t)s_dst[r] * H + c];
-                b = edge_attr[(size_t)(e0 + r) * H + c];
+                b = edge_attr[(size_t)s_row[r] * H + c];
             }
             buf[r * LDA + c] = a;
             buf[r * LDA + H + c] = b;
@@ -434,7 +437,7 @@ __global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ d
 static inline size_t lds_edge_embed(int H) { return (size_t)(T * (2 * H + 4) + 3 * T) * 4; }
 static inline size_t lds_cfconv(int H) { return (size_t)(T * (H + 4) + 5 * T) * 4; }
 static inline size_t lds_node(int H) { return (size_t)(TN * (H + 4) + 2 * TN) * 4; }
-static inline size_t lds_pair(int H) { return (size_t)(T * (2 * H + 4) + (H / 64) * T + 2 * T) * 4; }
+static inline size_t lds_pair(int H) { return (size_t)(T * (2 * H + 4) + (H / 64) * T + 3 * T) * 4; }
 
 template <typename K>
 static int allow_lds_once(K kernel, size_t bytes, bool& done) {
@@ -529,7 +532,7 @@ int launch_node_lin1(const tsd_model_cfg& c, const float* W, int layer, int N, c
 }
 
 int launch_pair_output(const tsd_model_cfg& c, const float* W, int capacity, tsd_edges e, const float* h,
-                       const float* edge_attr, float* edge_inv, hipStream_t st) {
+                       const float* edge_attr, const int32_t* attr_row, float* edge_inv, hipStream_t st) {
     const WeightLayout L = weight_layout(c);
     PairW w{W + L.out_w0, W + L.out_b0, W + L.out_w1, W + L.out_b1, W + L.out_w2, W + L.out_b2};
     const int tiles = (capacity + T - 1) / T;
@@ -538,7 +541,7 @@ int launch_pair_output(const tsd_model_cfg& c, const float* W, int capacity, tsd
     TSD_DISPATCH_H(c.hidden, {
         static bool done = false; int r = allow_lds_once(pair_output_kernel<HH>, lds, done);
         if (r) return r;
-        hipLaunchKernelGGL(pair_output_kernel<HH>, dim3(tiles), dim3(HH), lds, st, w, e, h, edge_attr, edge_inv);
+        hipLaunchKernelGGL(pair_output_kernel<HH>, dim3(tiles), dim3(HH), lds, st, w, e, h, edge_attr, attr_row, edge_inv);
     });
     TSD_LAUNCH_CHECK("pair_output");
     return TSD_OK;

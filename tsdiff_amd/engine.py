@@ -169,7 +169,8 @@ class DeviceBatch:
                              "(reference utils/datasets.py:491-507)")
         self.enc = EdgeList(N, P, dev)
         self.out = EdgeList(N, P, dev)
-        self.out2enc = torch.zeros(max(P, 1), **i32)
+        self.diff = EdgeList(N, P, dev)
+        self.attr_row = torch.zeros(max(P, 1), **i32)
         self.pair2out = torch.zeros(max(P, 1), **i32)
         self.geo_scratch = torch.zeros(lib.tsd_geometry_scratch_ints(N, P), **i32)
         self.workspace = None
@@ -204,8 +205,8 @@ class DeviceBatch:
             graph_ptr=self.graph_ptr.data_ptr(), node_graph=self.node_graph.data_ptr(),
             pair_ptr=self.pair_ptr.data_ptr(), pair_code=self.pair_code.data_ptr(),
             weights=self.weights.data_ptr(), z=self.z.data_ptr(),
-            enc=self.enc.struct(), out=self.out.struct(),
-            out2enc=self.out2enc.data_ptr(), pair2out=self.pair2out.data_ptr(),
+            enc=self.enc.struct(), out=self.out.struct(), diff=self.diff.struct(),
+            attr_row=self.attr_row.data_ptr(), pair2out=self.pair2out.data_ptr(),
             geo_scratch=self.geo_scratch.data_ptr(), workspace=self.workspace.data_ptr(),
             edge_inv=self.edge_inv.data_ptr())
 
@@ -215,8 +216,9 @@ class DeviceBatch:
         pos = pos.to(torch.float32).contiguous()
         check(lib.tsd_geometry_build(C.byref(self.cfg), self.N, self.G, self.P, ptr(pos), ptr(self.graph_ptr),
                                      ptr(self.node_graph), ptr(self.pair_ptr), ptr(self.pair_code),
-                                     self.enc.struct(), self.out.struct(), ptr(self.out2enc),
-                                     ptr(self.pair2out), ptr(self.geo_scratch), stream_ptr()))
+                                     self.enc.struct(), self.out.struct(), self.diff.struct(),
+                                     ptr(self.attr_row), ptr(self.pair2out), ptr(self.geo_scratch),
+                                     stream_ptr()))
 
     def forward(self, pos):
         """geometry + M forwards; results stay on the device (self.edge_inv[m, :E_out])."""
