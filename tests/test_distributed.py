@@ -1,0 +1,57 @@
+"""CPU: the N>1 sharding path with world_size-2 gloo (no GPU): shard balance, order-preserving gather."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tsdiff_amd import synth
+from tsdiff_amd.distributed import sample_sharded, shard_bounds
+
+
+def test_shard_bounds_balanced_and_contiguous():
+    rng = np.random.default_rng(0)
+    n = rng.integers(8, 24, size=2400)
+    for world in (1, 2, 4, 8):
+        b = shard_bounds(n, world)
+        assert b[0] == 0 and b[-1] == len(n) and all(b[i] <= b[i + 1] for i in range(world))
+        work = n * (n - 1)
+        per = [work[b[r]:b[r + 1]].sum() for r in range(world)]
+        assert max(per) <= 1.02 * work.sum() / world + work.max()
+    assert shard_bounds([5], 4) == [0, 0, 0, 0, 1] or shard_bounds([5], 4)[-1] == 1
+    assert shard_bounds([], 2) == [0, 0, 0]
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    b = synth.wb97xd3_like_batch(11, seed=4)
+    off = np.concatenate([[0], np.cumsum(b["num_nodes_per_graph"])])
+    graphs = [{"atom_type": torch.from_numpy(b["atom_type"][off[g]:off[g + 1]]),
+               "pos": torch.from_numpy(b["pos"][off[g]:off[g + 1]])} for g in range(11)]
+
+    def fake_sampler(shard, r):  # deterministic function of the graph: shows order is preserved
+        return [g["pos"] * 2.0 + g["atom_type"].float().unsqueeze(-1) for g in shard]
+
+    res = sample_sharded(graphs, fake_sampler)
+    if rank == 0:
+        ok = len(res) == 11 and all(
+            torch.equal(res[g], graphs[g]["pos"] * 2.0 + graphs[g]["atom_type"].float().unsqueeze(-1))
+            for g in range(11))
+        ret["ok"] = bool(ok)
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_sample_sharded_gloo_world2():
+    port = 29500 + (os.getpid() % 500)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+        assert ret.get("ok") is True

@@ -1,0 +1,54 @@
+"""Multi-GPU sampling: independent reaction graphs shard across ranks, one process per GPU.
+
+Graphs never interact on this path (radius graph per `batch`, intra-graph scatters, per-graph
+centring: reference models/common.py:344, models/sampler.py:260-262), so there is NO data-path
+collective: every rank holds all M checkpoints, samples its own contiguous shard, and the
+positions are gathered once at the end (host side, original order) -- the `sampling.py:218-231`
+unbatching step.  torch.distributed ("nccl" = RCCL on ROCm, "gloo" in the CPU tests) is used for
+that final gather only.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(num_nodes_per_graph, world_size):
+    """Contiguous shards balanced by the per-graph work  n*(n-1)  (ordered pairs = edges).
+    Returns `world_size + 1` graph offsets; shard r = graphs[b[r]:b[r+1]]."""
+    n = np.asarray(num_nodes_per_graph, dtype=np.int64)
+    work = np.maximum(n * (n - 1), 1)
+    cum = np.concatenate([[0], np.cumsum(work)])
+    total = cum[-1]
+    bounds = [0]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        k = int(np.searchsorted(cum, target, side="left"))
+        # closest prefix to the target, never moving backwards
+        if k > 0 and abs(cum[k - 1] - target) <= abs(cum[min(k, len(cum) - 1)] - target):
+            k -= 1
+        bounds.append(max(bounds[-1], min(k, len(n))))
+    bounds.append(len(n))
+    return bounds
+
+
+def sample_sharded(graphs, sample_fn, group=None):
+    """graphs: list of per-graph dicts (same list on every rank).  `sample_fn(shard_graphs, rank)`
+    returns one (n_g, 3) position tensor per graph of the shard.  Rank 0 returns the positions of
+    ALL graphs in the original order; other ranks return None."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    nn = [int(g["atom_type"].shape[0]) for g in graphs]
+    b = shard_bounds(nn, world)
+    mine = graphs[b[rank]:b[rank + 1]]
+    out = sample_fn(mine, rank) if mine else []
+    out = [torch.as_tensor(p).detach().cpu() for p in out]
+    assert len(out) == len(mine)
+    if world == 1:
+        return out
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(out, gathered, dst=0, group=group)
+    if rank != 0:
+        return None
+    res = [p for part in gathered for p in part]
+    assert len(res) == len(graphs)
+    return res
