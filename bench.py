@@ -135,36 +135,61 @@ def main():
     E_enc, E_out = db.enc.num_edges(), db.out.num_edges()
     H, L = cfg["hidden_dim"], cfg["encoder"]["num_convs"]
 
-    # ---- roofline of the dominant kernel: fused CFConv layer (filter MLP + message + segmented sum)
-    x1 = torch.randn(N, H, device=dev)
-    ea = torch.randn(max(db.P, 1), H, device=dev)
-    agg = torch.zeros(N, H, device=dev)
-    part = torch.zeros(((db.P + 31) // 32) * 2, H, device=dev)
-    reps = 50
+    # ---- roofline of the dominant kernel: CFConv filter generation (all layers, undirected edge list)
+    PU = db.P // 2
+    Eu = db.enc_u.num_edges()
+    ea = torch.randn(max(PU, 1), H, device=dev)
+    wf = torch.empty(L, max(PU, 1), H, device=dev)
+    reps = 20
 
-    def launch_cfconv():
-        _lib.check(lib.tsd_cfconv_layer(C.byref(db.cfg), _lib.ptr(db.weights[0]), 3, db.P, db.enc.struct(),
-                                        _lib.ptr(ea), _lib.ptr(x1), _lib.ptr(agg), _lib.ptr(part),
-                                        _lib.stream_ptr()))
-    for _ in range(5):
-        launch_cfconv()
+    def launch_filter():
+        _lib.check(lib.tsd_filter_gen(C.byref(db.cfg), _lib.ptr(db.weights[0]), PU, db.enc_u.struct(),
+                                      _lib.ptr(ea), _lib.ptr(wf), _lib.stream_ptr()))
+    for _ in range(3):
+        launch_filter()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     for _ in range(reps):
-        launch_cfconv()
+        launch_filter()
     ev1.record()
     torch.cuda.synchronize()
     k_ms = ev0.elapsed_time(ev1) / reps
-    flops = E_enc * (4.0 * H * H + 2.0 * H)  # two [E,H]x[H,H] GEMMs + modulate + accumulate
+    flops = float(L) * Eu * (4.0 * H * H + H)  # per layer and undirected edge: two HxH GEMMs + the C mask
     ach = flops / (k_ms * 1e-3) / 1e12
-    roofline = {"kernel": "cfconv_layer_kernel<256>", "bound": "mfma", "achieved": round(ach, 2),
+    roofline = {"kernel": "filter_gen_kernel<256>", "bound": "mfma", "achieved": round(ach, 2),
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": None, "avg_launch_us": round(k_ms * 1e3, 2), "edges": E_enc,
-                "flop_per_edge": 4 * H * H + 2 * H}
+                "traffic": None, "avg_launch_us": round(k_ms * 1e3, 2), "undirected_edges": Eu, "layers": L,
+                "flop_per_edge_layer": 4 * H * H + H}
+    # the HBM/L2-bound companion: segmented aggregation with the materialised filter
+    x1 = torch.randn(N, H, device=dev)
+    agg = torch.empty(N, H, device=dev)
+
+    def launch_agg():
+        _lib.check(lib.tsd_cfconv_aggregate(H, N, _lib.ptr(db.enc.row_ptr), _lib.ptr(db.enc.dst),
+                                            _lib.ptr(db.enc.umap), _lib.ptr(wf[0]), _lib.ptr(x1), _lib.ptr(agg),
+                                            _lib.stream_ptr()))
+    for _ in range(3):
+        launch_agg()
+    ev0.record()
+    for _ in range(reps):
+        launch_agg()
+    ev1.record()
+    torch.cuda.synchronize()
+    a_ms = ev0.elapsed_time(ev1) / reps
+    a_bytes = E_enc * (4.0 * H + 4 + 4) + 2.0 * N * 4 * H + 4.0 * (N + 1)  # SURVEY.md 8(d) byte model (+ umap)
+    roofline["aggregate"] = {"kernel": "cfconv_aggregate_kernel<256>", "bound": "hbm",
+                             "achieved": round(a_bytes / (a_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+                             "unit": "GB/s", "avg_launch_us": round(a_ms * 1e3, 2),
+                             "note": "27 MB working set at batch 100: L2/MALL resident, launch-latency bound"}
 
     # whole-forward arithmetic rate (SURVEY.md 8a FLOP model), for orientation
-    F = (E_enc * (131584 + 393216 + L * 262144 + L * 512) + E_out * (131584 + 393216 + 327936 + 256)
-         + N * (L * 393216 + 13000)) * args.models
+    # flops the implemented algorithm executes: per-edge MLPs once per undirected pair (E/2), the out
+    # graph's embedding only for the edges that differ; the reference's formulation is 2x that
+    E_diff = db.diff_u.num_edges()
+    F = ((E_enc // 2) * (131584 + 393216 + L * 262144) + E_enc * L * 512 + E_diff * (131584 + 393216)
+         + (E_out // 2) * (327936 + 256) + N * (L * 393216 + 13000)) * args.models
+    F_ref = (E_enc * (131584 + 393216 + L * 262144 + L * 512) + E_out * (131584 + 393216 + 327936 + 256)
+             + N * (L * 393216 + 13000)) * args.models
     step_s = dt / args.steps
     fwd_tflops = F / step_s / 1e12
 
@@ -209,6 +234,7 @@ def main():
                    "checkpoints": args.models, "hidden": H, "num_convs": L, "hipgraph": not args.no_graph,
                    "parallelism": f"graphs sharded over {args.gpus} GPU(s), no collective"},
         "forward_tflops": round(fwd_tflops, 2),
+        "forward_tflops_reference_formulation": round(F_ref / step_s / 1e12, 2),
         "roofline": roofline,
         "cpu_baseline": cpu,
     }

@@ -78,7 +78,25 @@ typedef struct tsd_edges {
     uint8_t* type_r;   /* [cap] edge type in the reactant graph (0, 1..21, 22+hop-1) */
     uint8_t* type_p;   /* [cap] same for the product graph */
     int32_t* pair_id;  /* [cap] index of the edge's ordered pair in the topology */
+    int32_t* umap;     /* [cap] directed lists only: index of the edge's undirected pair {i,j} in the
+                                matching undirected list (enc -> enc_u, out -> out_u) */
 } tsd_edges;
+
+/* Everything tsd_geometry_build produces for one set of positions.
+ * The extended edge set, edge_length and the types are symmetric under (i,j) <-> (j,i), hence so are
+ * the edge embedding, the CFConv filter W and edge_inv: the per-edge MLPs run once per UNDIRECTED
+ * pair (lists *_u, src < dst, capacity P/2) and the directed lists (reference order, what the
+ * Python surface returns) index into them through `umap`. */
+typedef struct tsd_geometry {
+    tsd_edges enc, out;              /* directed, order edge_order / pred_edge_order */
+    tsd_edges enc_u, out_u, diff_u;  /* undirected; diff_u: out_u edges whose (d, type_r, type_p) differ
+                                        from their enc_u edge (or have none) and need their own embedding */
+    int32_t* attr_row;   /* [P/2] per out_u edge: row of the [P,H] edge-attribute matrix holding its
+                                  embedding: its enc_u index, or P/2 + k for the k-th diff_u edge */
+    int32_t* pair2out;   /* [P] directed out edge index of every ordered pair, -1 if not an edge */
+    int32_t* pair2u;     /* [2P] scratch: undirected enc / out index of every ordered pair with src < dst */
+    int32_t* scratch;    /* [tsd_geometry_scratch_ints] */
+} tsd_geometry;
 
 const char* tsd_version(void);
 const char* tsd_last_error(void);
@@ -107,20 +125,11 @@ int tsd_topology_build(int32_t num_nodes, int32_t num_graphs, int32_t num_pairs,
                        int32_t* status, void* stream);
 
 /* ---- geometry (every step) ---------------------------------------------------------------
- * Builds the order-`edge_order` (enc) and order-`pred_edge_order` (out) edge lists of `pos`.
- * scratch: int32 [tsd_geometry_scratch_ints].
- * diff: the out edges whose (edge_length, type_r, type_p) differ from their enc edge (or have none);
- *       only count, row_ptr, dist, type_r, type_p are written.  Their embeddings are computed on
- *       their own; every other out edge shares the enc edge's embedding bit for bit.
- * attr_row [P]: for every out edge the row of the [2P,H] edge-attribute matrix holding its embedding:
- *       the enc edge index (< P), or P + k for the k-th diff edge.
- * pair2out [P]: out edge index of every ordered pair, -1 when the pair is not an out edge. */
+ * Builds the directed and undirected edge lists of `pos` (see tsd_geometry). No host sync. */
 size_t tsd_geometry_scratch_ints(int32_t num_nodes, int32_t num_pairs);
 int tsd_geometry_build(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_graphs, int32_t num_pairs,
                        const float* pos, const int32_t* graph_ptr, const int32_t* node_graph,
-                       const int32_t* pair_ptr, const uint16_t* pair_code,
-                       tsd_edges enc, tsd_edges out, tsd_edges diff, int32_t* attr_row, int32_t* pair2out,
-                       int32_t* scratch, void* stream);
+                       const int32_t* pair_ptr, const uint16_t* pair_code, tsd_geometry geo, void* stream);
 
 /* ---- network pieces (one checkpoint each; `w` = packed weights of that checkpoint) --------- */
 int tsd_node_embed(const tsd_model_cfg* cfg, const float* w, int32_t num_nodes,
@@ -141,12 +150,21 @@ int tsd_cfconv_layer(const tsd_model_cfg* cfg, const float* w, int32_t layer, in
                      tsd_edges enc, const float* edge_attr, const float* x1,
                      float* agg, float* part, void* stream);
 
-/* The scatter-add alone with a materialised filter W [E,H] (T5; HBM-bound, config C5):
- * out[i] = sum_{e: row_ptr[i] <= e < row_ptr[i+1]} x1[dst[e]] * W[e]. */
-int tsd_cfconv_aggregate(int32_t hidden, int32_t num_nodes, const int32_t* row_ptr, const int32_t* dst,
-                         const float* W, const float* x1, float* out, void* stream);
+/* CFConv filters of ALL layers for an (undirected) edge list in one launch:
+ * Wf[l][e] = nn_l(edge_attr[e]) * (dist[e] <= conv_cutoff)   -> Wf [num_convs, capacity, H]
+ * (reference schnet.py:94-99; the filter does not depend on the node states, so the seven layers'
+ * GEMMs are batched: 7x the tiles of one layer keep all 256 CUs busy at batch-100 sizes). */
+int tsd_filter_gen(const tsd_model_cfg* cfg, const float* w, int32_t capacity, tsd_edges edges,
+                   const float* edge_attr, float* Wf, void* stream);
 
-/* h += lin(ssp(lin2(agg) )); if next_layer >= 0 also x1 = lin1_{next_layer}(h). */
+/* The scatter-add with a materialised filter (T5; HBM/L2-bound):
+ * out[i] = sum_{e: row_ptr[i] <= e < row_ptr[i+1]} x1[dst[e]] * W[umap ? umap[e] : e], edges in order. */
+int tsd_cfconv_aggregate(int32_t hidden, int32_t num_nodes, const int32_t* row_ptr, const int32_t* dst,
+                         const int32_t* umap, const float* W, const float* x1, float* out, void* stream);
+
+/* h += lin(ssp(lin2(agg) )); if next_layer >= 0 also x1 = lin1_{next_layer}(h).
+ * part / enc_row_ptr: only for agg produced by tsd_cfconv_layer (rows cut by tile edges); pass NULL
+ * for a complete agg (tsd_cfconv_aggregate). */
 int tsd_node_update(const tsd_model_cfg* cfg, const float* w, int32_t layer, int32_t next_layer,
                     int32_t num_nodes, const int32_t* enc_row_ptr, const float* agg, const float* part,
                     float* h, float* x1, void* stream);
@@ -171,22 +189,20 @@ typedef struct tsd_batch {
     const uint16_t* pair_code;  /* [P] */
     const float* weights;       /* [M, packed_floats] */
     const float* z;             /* [M, N, H] node embeddings (tsd_node_embed), pos independent */
-    tsd_edges enc, out, diff;
-    int32_t* attr_row;          /* [P] */
-    int32_t* pair2out;          /* [P] */
-    int32_t* geo_scratch;       /* tsd_geometry_scratch_ints */
+    tsd_geometry geo;
     float* workspace;           /* tsd_forward_workspace_floats */
-    float* edge_inv;            /* [M, P] per-checkpoint output */
+    float* edge_inv_u;          /* [M, P/2] per-checkpoint output on the undirected out list */
 } tsd_batch;
 
 size_t tsd_forward_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs,
                                     int32_t num_models);
-/* geometry + M forwards; edge_inv[m] valid for the first *out.count entries. */
+/* geometry + M forwards; edge_inv_u[m] valid for the first *geo.out_u.count entries. */
 int tsd_score_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* pos, void* stream);
 
-/* mean over checkpoints in the reference's order: ((e0+e1)+...)/M -> edge_inv_mean [P] */
-int tsd_ensemble_mean(int32_t num_models, int32_t num_pairs, const int32_t* count,
-                      const float* edge_inv, float* edge_inv_mean, void* stream);
+/* mean over checkpoints in the reference's order, expanded to the directed out list:
+ * edge_inv[e] = ((inv_u[0][u] + inv_u[1][u]) + ...)/M with u = out.umap[e]   -> edge_inv [P] */
+int tsd_ensemble_mean(int32_t num_models, int32_t num_pairs, tsd_edges out,
+                      const float* edge_inv_u /* [M, P/2] */, float* edge_inv, void* stream);
 
 /* eq_transform on the library's own out-edge list (deterministic, no atomics):
  * score[i] = sum_{e in row i} u_e s_e + sum_{e in row i} u_e s_{(dst e, i)}. */
@@ -210,7 +226,7 @@ int tsd_sampler_step(int32_t kind, int32_t num_nodes, int32_t num_graphs, const 
  * use_graph != 0 captures one step into a hipGraph and replays it. */
 int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t kind, int32_t n_steps,
                     const float* coefs, const float* noises, float clip, float clip_pos,
-                    float* pos, float* traj, float* scratch /* [P + 3N] */, int32_t* status,
+                    float* pos, float* traj, float* scratch /* [P + 3N + 128] */, int32_t* status /* [2] */,
                     int32_t use_graph, void* stream);
 
 #ifdef __cplusplus

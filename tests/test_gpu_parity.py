@@ -125,7 +125,7 @@ def test_layer_kernels_vs_oracle(dev):
     Wf = trace["W0"].to(dev).contiguous()
     x1o = trace["x1_0"].to(dev).contiguous()
     out = torch.zeros(N, H, device=dev)
-    _lib.check(lib.tsd_cfconv_aggregate(H, N, _lib.ptr(db.enc.row_ptr), _lib.ptr(db.enc.dst), _lib.ptr(Wf),
+    _lib.check(lib.tsd_cfconv_aggregate(H, N, _lib.ptr(db.enc.row_ptr), _lib.ptr(db.enc.dst), None, _lib.ptr(Wf),
                                         _lib.ptr(x1o), _lib.ptr(out), _lib.stream_ptr()))
     ref = trace["agg0"].numpy()
     got = out.cpu().numpy()
@@ -136,6 +136,23 @@ def test_layer_kernels_vs_oracle(dev):
     for e in range(ei.shape[1]):  # sequential fp32 scatter in edge order
         seq[ei[0][e]] += msg[e]
     assert np.array_equal(got, seq), "segmented reduce is not bit-identical to the sequential order"
+    # production path: filters of all layers on the UNDIRECTED list, consumed through umap
+    PU, L = P // 2, cfg["encoder"]["num_convs"]
+    Eu = db.enc_u.num_edges()
+    assert 2 * Eu == E
+    ea_u = torch.zeros(PU, H, device=dev)
+    _lib.check(lib.tsd_edge_embed(C.byref(db.cfg), _lib.ptr(W), PU, db.enc_u.struct(), _lib.ptr(ea_u),
+                                  _lib.stream_ptr()))
+    um = db.enc.umap[:E].long()
+    assert torch.equal(ea_u[um], ea[:E]), "edge embedding of (i,j) and (j,i) must be bit-identical"
+    Wf_all = torch.full((L, PU, H), float("nan"), device=dev)
+    _lib.check(lib.tsd_filter_gen(C.byref(db.cfg), _lib.ptr(W), PU, db.enc_u.struct(), _lib.ptr(ea_u),
+                                  _lib.ptr(Wf_all), _lib.stream_ptr()))
+    assert_close(Wf_all[0][um].cpu().numpy(), trace["W0"].numpy(), RTOL, "filter W (layer 0)")
+    agg2 = torch.zeros(N, H, device=dev)
+    _lib.check(lib.tsd_cfconv_aggregate(H, N, _lib.ptr(db.enc.row_ptr), _lib.ptr(db.enc.dst), _lib.ptr(db.enc.umap),
+                                        _lib.ptr(Wf_all[0]), _lib.ptr(x1o), _lib.ptr(agg2), _lib.stream_ptr()))
+    assert_close(agg2.cpu().numpy(), trace["agg0"].numpy(), RTOL, "aggregate through umap")
 
 
 def test_forward_vs_oracle_seeded_batch(dev):

@@ -48,6 +48,21 @@ class Edges(C.Structure):
         ("type_r", C.c_void_p),
         ("type_p", C.c_void_p),
         ("pair_id", C.c_void_p),
+        ("umap", C.c_void_p),
+    ]
+
+
+class Geometry(C.Structure):
+    _fields_ = [
+        ("enc", Edges),
+        ("out", Edges),
+        ("enc_u", Edges),
+        ("out_u", Edges),
+        ("diff_u", Edges),
+        ("attr_row", C.c_void_p),
+        ("pair2out", C.c_void_p),
+        ("pair2u", C.c_void_p),
+        ("scratch", C.c_void_p),
     ]
 
 
@@ -63,14 +78,9 @@ class Batch(C.Structure):
         ("pair_code", C.c_void_p),
         ("weights", C.c_void_p),
         ("z", C.c_void_p),
-        ("enc", Edges),
-        ("out", Edges),
-        ("diff", Edges),
-        ("attr_row", C.c_void_p),
-        ("pair2out", C.c_void_p),
-        ("geo_scratch", C.c_void_p),
+        ("geo", Geometry),
         ("workspace", C.c_void_p),
-        ("edge_inv", C.c_void_p),
+        ("edge_inv_u", C.c_void_p),
     ]
 
 
@@ -86,19 +96,19 @@ SIGNATURES = {
     "tsd_topology_build": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, _P, _P, _P, _P, C.c_int32,
                                      C.c_int32, _P, _P, _P, _P, _P]),
     "tsd_geometry_scratch_ints": (C.c_size_t, [C.c_int32, C.c_int32]),
-    "tsd_geometry_build": (C.c_int, [_CFG, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, Edges, Edges,
-                                     Edges, _P, _P, _P, _P]),
+    "tsd_geometry_build": (C.c_int, [_CFG, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, Geometry, _P]),
     "tsd_node_embed": (C.c_int, [_CFG, _P, C.c_int32, _P, _P, _P, _P, _P]),
     "tsd_edge_embed": (C.c_int, [_CFG, _P, C.c_int32, Edges, _P, _P]),
     "tsd_node_lin1": (C.c_int, [_CFG, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "tsd_cfconv_layer": (C.c_int, [_CFG, _P, C.c_int32, C.c_int32, Edges, _P, _P, _P, _P, _P]),
-    "tsd_cfconv_aggregate": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "tsd_filter_gen": (C.c_int, [_CFG, _P, C.c_int32, Edges, _P, _P, _P]),
+    "tsd_cfconv_aggregate": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "tsd_node_update": (C.c_int, [_CFG, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "tsd_pair_output": (C.c_int, [_CFG, _P, C.c_int32, Edges, _P, _P, _P, _P, _P]),
     "tsd_eq_transform": (C.c_int, [C.c_int32, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "tsd_forward_workspace_floats": (C.c_size_t, [_CFG, C.c_int32, C.c_int32, C.c_int32]),
     "tsd_score_forward": (C.c_int, [_CFG, C.POINTER(Batch), _P, _P]),
-    "tsd_ensemble_mean": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "tsd_ensemble_mean": (C.c_int, [C.c_int32, C.c_int32, Edges, _P, _P, _P]),
     "tsd_eq_transform_rows": (C.c_int, [C.c_int32, _P, _P, _P, _P, Edges, _P, _P, _P, _P]),
     "tsd_sampler_step": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_float, C.c_float, _P,
                                    _P, _P]),

@@ -36,17 +36,17 @@ int launch_topology(int, int, int, int64_t, const int32_t*, const int32_t*, cons
                     int, int32_t*, int32_t*, uint16_t*, int32_t*, hipStream_t);
 size_t geometry_scratch_ints(int, int);
 int launch_geometry(const tsd_model_cfg&, int, int, int, const float*, const int32_t*, const int32_t*,
-                    const int32_t*, const uint16_t*, tsd_edges, tsd_edges, tsd_edges, int32_t*, int32_t*,
-                    int32_t*, hipStream_t);
+                    const int32_t*, const uint16_t*, tsd_geometry, hipStream_t);
+int launch_filter_gen(const tsd_model_cfg&, const float*, int, tsd_edges, const float*, float*, hipStream_t);
 int launch_node_embed(const tsd_model_cfg&, const float*, int, const int64_t*, const int64_t*, const int64_t*,
                       float*, hipStream_t);
-int launch_cfconv_aggregate(int, int, const int32_t*, const int32_t*, const float*, const float*, float*,
-                            hipStream_t);
+int launch_cfconv_aggregate(int, int, const int32_t*, const int32_t*, const int32_t*, const float*,
+                            const float*, float*, hipStream_t);
 int launch_eq_transform_atomic(int, int64_t, const float*, const float*, const int64_t*, const float*, float*,
                                hipStream_t);
 int launch_eq_transform_rows(int, const float*, const int32_t*, const int32_t*, const int32_t*, tsd_edges,
                              const int32_t*, const float*, float*, hipStream_t);
-int launch_ensemble_mean(int, int, const int32_t*, const float*, float*, hipStream_t);
+int launch_ensemble_mean(int, int, tsd_edges, const float*, float*, hipStream_t);
 int launch_sampler_step(int, int, int, const int32_t*, const float*, const float*, const float*, float, float,
                         float*, float*, int32_t*, const int32_t*, hipStream_t);
 int launch_advance(int32_t*, hipStream_t);
@@ -62,49 +62,57 @@ static int check_cfg(const tsd_model_cfg* c) {
 }
 
 struct Workspace {
-    float *ea, *h, *x1, *agg, *part;  // ea: [2P,H] rows 0..P-1 enc edges, rows P.. separately embedded out edges
+    float *ea;   // [P, H]: rows 0..P/2-1 enc_u edges, rows P/2.. separately embedded (diff_u) out edges
+    float *wf;   // [L, P/2, H]: CFConv filters of every layer on the undirected enc list
+    float *h, *x1, *agg;
     size_t total;
 };
 
 static Workspace carve(const tsd_model_cfg& c, int N, int P, float* base) {
     Workspace w;
-    const size_t H = c.hidden;
+    const size_t H = c.hidden, PU = (size_t)P / 2;
     size_t o = 0;
     auto take = [&](size_t n) { float* p = base ? base + o : nullptr; o += (n + 63) & ~size_t(63); return p; };
-    w.ea = take((size_t)2 * P * H);
+    w.ea = take(2 * PU * H);
+    w.wf = take((size_t)c.num_convs * PU * H);
     w.h = take((size_t)N * H);
     w.x1 = take((size_t)N * H);
     w.agg = take((size_t)N * H);
-    w.part = take((size_t)((P + TSD_EDGE_TILE - 1) / TSD_EDGE_TILE) * 2 * H);
     w.total = o;
     return w;
 }
 
+// One forward per checkpoint on the current positions.  Every per-edge MLP runs on the UNDIRECTED
+// lists (half the edges of the reference's directed list: edge_attr, W and edge_inv are symmetric);
+// the directed CSR list only drives the aggregation and eq_transform through `umap`.
 static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float* pos, hipStream_t st) {
     const int N = b.num_nodes, G = b.num_graphs, P = b.num_pairs, M = b.num_models;
+    const int PU = P / 2;
     const size_t H = c.hidden;
+    const tsd_geometry& g = b.geo;
     int r;
-    if ((r = launch_geometry(c, N, G, P, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, b.enc, b.out,
-                             b.diff, b.attr_row, b.pair2out, b.geo_scratch, st)))
-        return r;
+    if ((r = launch_geometry(c, N, G, P, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, g, st))) return r;
     const Workspace w = carve(c, N, P, b.workspace);
     const size_t wfloats = weight_layout(c).total;
     for (int m = 0; m < M; ++m) {
         const float* W = b.weights + (size_t)m * wfloats;
-        if ((r = launch_edge_embed(c, W, P, b.enc, w.ea, st))) return r;
+        if ((r = launch_edge_embed(c, W, PU, g.enc_u, w.ea, st))) return r;
+        if ((r = launch_filter_gen(c, W, PU, g.enc_u, w.ea, w.wf, st))) return r;
         TSD_HIP(hipMemcpyAsync(w.h, b.z + (size_t)m * N * H, (size_t)N * H * sizeof(float),
                                hipMemcpyDeviceToDevice, st));
         if ((r = launch_node_lin1(c, W, 0, N, w.h, w.x1, st))) return r;
         for (int l = 0; l < c.num_convs; ++l) {
-            if ((r = launch_cfconv_layer(c, W, l, P, b.enc, w.ea, w.x1, w.agg, w.part, st))) return r;
-            if ((r = launch_node_update(c, W, l, (l + 1 < c.num_convs) ? l + 1 : -1, N, b.enc.row_ptr, w.agg,
-                                        w.part, w.h, w.x1, st)))
+            if ((r = launch_cfconv_aggregate(c.hidden, N, g.enc.row_ptr, g.enc.dst, g.enc.umap,
+                                             w.wf + (size_t)l * PU * H, w.x1, w.agg, st)))
+                return r;
+            if ((r = launch_node_update(c, W, l, (l + 1 < c.num_convs) ? l + 1 : -1, N, nullptr, w.agg, nullptr,
+                                        w.h, w.x1, st)))
                 return r;
         }
         // out edges whose (d, types) differ from their enc edge (only the hop == edge_order pairs when
         // pred_edge_order < edge_order) are embedded on their own; every other out edge reuses its enc row
-        if ((r = launch_edge_embed(c, W, P, b.diff, w.ea + (size_t)P * H, st))) return r;
-        if ((r = launch_pair_output(c, W, P, b.out, w.h, w.ea, b.attr_row, b.edge_inv + (size_t)m * P, st)))
+        if ((r = launch_edge_embed(c, W, PU, g.diff_u, w.ea + (size_t)PU * H, st))) return r;
+        if ((r = launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u + (size_t)m * PU, st)))
             return r;
     }
     return TSD_OK;
@@ -117,9 +125,9 @@ static int step_impl(const tsd_model_cfg& c, const tsd_batch& b, int kind, const
     float* mean = scratch;
     float* score = scratch + (((size_t)b.num_pairs + 63) & ~size_t(63));
     if ((r = forward_impl(c, b, pos, st))) return r;
-    if ((r = launch_ensemble_mean(b.num_models, b.num_pairs, b.out.count, b.edge_inv, mean, st))) return r;
-    if ((r = launch_eq_transform_rows(b.num_nodes, pos, b.pair_ptr, b.graph_ptr, b.node_graph, b.out, b.pair2out,
-                                      mean, score, st)))
+    if ((r = launch_ensemble_mean(b.num_models, b.num_pairs, b.geo.out, b.edge_inv_u, mean, st))) return r;
+    if ((r = launch_eq_transform_rows(b.num_nodes, pos, b.pair_ptr, b.graph_ptr, b.node_graph, b.geo.out,
+                                      b.geo.pair2out, mean, score, st)))
         return r;
     return launch_sampler_step(kind, b.num_nodes, b.num_graphs, b.graph_ptr, score, noises, coefs, clip, clip_pos,
                                pos, traj, status, step_ctr, st);
@@ -169,15 +177,18 @@ size_t tsd_geometry_scratch_ints(int32_t num_nodes, int32_t num_pairs) {
 
 int tsd_geometry_build(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_graphs, int32_t num_pairs,
                        const float* pos, const int32_t* graph_ptr, const int32_t* node_graph,
-                       const int32_t* pair_ptr, const uint16_t* pair_code, tsd_edges enc, tsd_edges out,
-                       tsd_edges diff, int32_t* attr_row, int32_t* pair2out, int32_t* scratch, void* stream) {
+                       const int32_t* pair_ptr, const uint16_t* pair_code, tsd_geometry geo, void* stream) {
     int r = check_cfg(cfg);
     if (r) return r;
-    TSD_REQUIRE(pos && graph_ptr && node_graph && pair_ptr && scratch, "null pointer");
-    TSD_REQUIRE(enc.count && enc.row_ptr && out.count && out.row_ptr && diff.count && diff.row_ptr && attr_row,
+    TSD_REQUIRE(pos && graph_ptr && node_graph && pair_ptr && geo.scratch, "null pointer");
+    TSD_REQUIRE(geo.enc.count && geo.enc.row_ptr && geo.out.count && geo.out.row_ptr && geo.enc_u.count &&
+                    geo.enc_u.row_ptr && geo.out_u.count && geo.out_u.row_ptr && geo.diff_u.count &&
+                    geo.diff_u.row_ptr && geo.attr_row && geo.pair2out && geo.pair2u && geo.enc.umap &&
+                    geo.out.umap,
                 "null edge list");
+    TSD_REQUIRE(num_pairs % 2 == 0, "num_pairs must be sum n(n-1)");
     return launch_geometry(*cfg, num_nodes, num_graphs, num_pairs, pos, graph_ptr, node_graph, pair_ptr,
-                           pair_code, enc, out, diff, attr_row, pair2out, scratch, (hipStream_t)stream);
+                           pair_code, geo, (hipStream_t)stream);
 }
 
 int tsd_node_embed(const tsd_model_cfg* cfg, const float* w, int32_t num_nodes, const int64_t* atom_type,
@@ -210,10 +221,18 @@ int tsd_cfconv_layer(const tsd_model_cfg* cfg, const float* w, int32_t layer, in
     return launch_cfconv_layer(*cfg, w, layer, capacity, enc, edge_attr, x1, agg, part, (hipStream_t)stream);
 }
 
+int tsd_filter_gen(const tsd_model_cfg* cfg, const float* w, int32_t capacity, tsd_edges edges,
+                   const float* edge_attr, float* Wf, void* stream) {
+    int r = check_cfg(cfg);
+    if (r) return r;
+    TSD_REQUIRE(w && edge_attr && Wf && edges.count && edges.dist, "null pointer");
+    return launch_filter_gen(*cfg, w, capacity, edges, edge_attr, Wf, (hipStream_t)stream);
+}
+
 int tsd_cfconv_aggregate(int32_t hidden, int32_t num_nodes, const int32_t* row_ptr, const int32_t* dst,
-                         const float* W, const float* x1, float* out, void* stream) {
+                         const int32_t* umap, const float* W, const float* x1, float* out, void* stream) {
     TSD_REQUIRE(row_ptr && dst && W && x1 && out, "null pointer");
-    return launch_cfconv_aggregate(hidden, num_nodes, row_ptr, dst, W, x1, out, (hipStream_t)stream);
+    return launch_cfconv_aggregate(hidden, num_nodes, row_ptr, dst, umap, W, x1, out, (hipStream_t)stream);
 }
 
 int tsd_node_update(const tsd_model_cfg* cfg, const float* w, int32_t layer, int32_t next_layer,
@@ -255,9 +274,10 @@ int tsd_score_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
     return forward_impl(*cfg, *batch, pos, (hipStream_t)stream);
 }
 
-int tsd_ensemble_mean(int32_t num_models, int32_t num_pairs, const int32_t* count, const float* edge_inv,
-                      float* edge_inv_mean, void* stream) {
-    return launch_ensemble_mean(num_models, num_pairs, count, edge_inv, edge_inv_mean, (hipStream_t)stream);
+int tsd_ensemble_mean(int32_t num_models, int32_t num_pairs, tsd_edges out, const float* edge_inv_u,
+                      float* edge_inv, void* stream) {
+    TSD_REQUIRE(num_models >= 1 && out.count && out.umap && edge_inv_u && edge_inv, "bad argument");
+    return launch_ensemble_mean(num_models, num_pairs, out, edge_inv_u, edge_inv, (hipStream_t)stream);
 }
 
 int tsd_eq_transform_rows(int32_t num_nodes, const float* pos, const int32_t* pair_ptr,

@@ -190,95 +190,85 @@ __device__ __forceinline__ PairEval eval_pair(const float* __restrict__ pos, int
     return r;
 }
 
+// per-row member counts of the five lists: 0 enc, 1 out, 2 enc_u, 3 out_u, 4 diff_u  (u: j > i only)
+constexpr int NLIST = 5;
+
 __global__ __launch_bounds__(256) void pair_count_kernel(int N, const float* __restrict__ pos,
                                                          const int32_t* __restrict__ graph_ptr,
                                                          const int32_t* __restrict__ node_graph,
                                                          const int32_t* __restrict__ pair_ptr,
                                                          const uint16_t* __restrict__ pair_code,
                                                          int order_enc, int order_out, float cut2,
-                                                         int32_t* __restrict__ cnt_enc,
-                                                         int32_t* __restrict__ cnt_out,
-                                                         int32_t* __restrict__ cnt_diff) {
+                                                         int32_t* __restrict__ cnt /* [NLIST][N+1] */) {
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= N) return;
     const int lo = graph_ptr[node_graph[i]];
     const int il = i - lo;
     const int p0 = pair_ptr[i], np = pair_ptr[i + 1] - p0;
-    int ce = 0, co = 0, cd = 0;
+    int c[NLIST] = {0, 0, 0, 0, 0};
     for (int k0 = 0; k0 < np; k0 += 64) {
         const int k = k0 + lane;
-        bool me = false, mo = false, md = false;
+        bool m[NLIST] = {false, false, false, false, false};
         if (k < np) {
             const int j = lo + k + (k >= il ? 1 : 0);
             const PairEval r = eval_pair(pos, i, j, pair_code[p0 + k], order_enc, order_out, cut2);
-            me = r.in_enc;
-            mo = r.in_out;
-            md = r.needs_own_attr();
+            const bool up = j > i;
+            m[0] = r.in_enc;
+            m[1] = r.in_out;
+            m[2] = r.in_enc && up;
+            m[3] = r.in_out && up;
+            m[4] = r.needs_own_attr() && up;
         }
-        ce += __popcll(__ballot(me));
-        co += __popcll(__ballot(mo));
-        cd += __popcll(__ballot(md));
+#pragma unroll
+        for (int q = 0; q < NLIST; ++q) c[q] += __popcll(__ballot(m[q]));
     }
     if (lane == 0) {
-        cnt_enc[i] = ce;
-        cnt_out[i] = co;
-        cnt_diff[i] = cd;
+#pragma unroll
+        for (int q = 0; q < NLIST; ++q) cnt[(size_t)q * (N + 1) + i] = c[q];
     }
 }
 
-// exclusive scan of three int arrays of length N (+ total at [N]); single workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void scan3_kernel(int N, const int32_t* __restrict__ a_in,
-                                                     const int32_t* __restrict__ b_in,
-                                                     const int32_t* __restrict__ c_in,
-                                                     int32_t* __restrict__ a_out, int32_t* __restrict__ b_out,
-                                                     int32_t* __restrict__ c_out,
-                                                     int32_t* __restrict__ a_total, int32_t* __restrict__ b_total,
-                                                     int32_t* __restrict__ c_total) {
-    __shared__ int sa[1024], sb[1024], sc[1024];
+struct ScanOut {
+    int32_t* row_ptr[NLIST];
+    int32_t* total[NLIST];
+};
+
+// exclusive scan of NLIST int arrays of length N (+ total at [N]); single workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void scan_kernel(int N, const int32_t* __restrict__ cnt, ScanOut o) {
+    __shared__ int sm[NLIST][1024];
     const int t = threadIdx.x;
     const int per = (N + 1023) / 1024;
     const int beg = min(N, t * per), end = min(N, beg + per);
-    int xa = 0, xb = 0, xc = 0;
-    for (int i = beg; i < end; ++i) {
-        xa += a_in[i];
-        xb += b_in[i];
-        xc += c_in[i];
+    int x[NLIST];
+#pragma unroll
+    for (int q = 0; q < NLIST; ++q) {
+        int a = 0;
+        for (int i = beg; i < end; ++i) a += cnt[(size_t)q * (N + 1) + i];
+        x[q] = a;
+        sm[q][t] = a;
     }
-    sa[t] = xa;
-    sb[t] = xb;
-    sc[t] = xc;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-        int va = 0, vb = 0, vc = 0;
-        if (t >= off) {
-            va = sa[t - off];
-            vb = sb[t - off];
-            vc = sc[t - off];
+        int v[NLIST];
+#pragma unroll
+        for (int q = 0; q < NLIST; ++q) v[q] = (t >= off) ? sm[q][t - off] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NLIST; ++q) sm[q][t] += v[q];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < NLIST; ++q) {
+        int r = sm[q][t] - x[q];  // exclusive prefix of this thread's chunk
+        for (int i = beg; i < end; ++i) {
+            o.row_ptr[q][i] = r;
+            r += cnt[(size_t)q * (N + 1) + i];
         }
-        __syncthreads();
-        sa[t] += va;
-        sb[t] += vb;
-        sc[t] += vc;
-        __syncthreads();
-    }
-    int ra = sa[t] - xa, rb = sb[t] - xb, rc = sc[t] - xc;  // exclusive prefix of this thread's chunk
-    for (int i = beg; i < end; ++i) {
-        const int va = a_in[i], vb = b_in[i], vc = c_in[i];
-        a_out[i] = ra;
-        b_out[i] = rb;
-        c_out[i] = rc;
-        ra += va;
-        rb += vb;
-        rc += vc;
-    }
-    if (t == 1023) {
-        a_out[N] = sa[1023];
-        b_out[N] = sb[1023];
-        c_out[N] = sc[1023];
-        *a_total = sa[1023];
-        *b_total = sb[1023];
-        *c_total = sc[1023];
+        if (t == 1023) {
+            o.row_ptr[q][N] = sm[q][1023];
+            *o.total[q] = sm[q][1023];
+        }
     }
 }
 
@@ -288,86 +278,152 @@ __global__ __launch_bounds__(256) void pair_fill_kernel(int N, const float* __re
                                                         const int32_t* __restrict__ pair_ptr,
                                                         const uint16_t* __restrict__ pair_code,
                                                         int order_enc, int order_out, float cut2,
-                                                        tsd_edges enc, tsd_edges out, tsd_edges diff,
-                                                        int32_t* __restrict__ attr_row, int P,
-                                                        int32_t* __restrict__ pair2out) {
+                                                        tsd_geometry g, int P) {
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= N) return;
     const int lo = graph_ptr[node_graph[i]];
     const int il = i - lo;
     const int p0 = pair_ptr[i], np = pair_ptr[i + 1] - p0;
-    int be = enc.row_ptr[i], bo = out.row_ptr[i], bd = diff.row_ptr[i];
+    const int PU = P / 2;
+    int base[NLIST] = {g.enc.row_ptr[i], g.out.row_ptr[i], g.enc_u.row_ptr[i], g.out_u.row_ptr[i],
+                       g.diff_u.row_ptr[i]};
     const unsigned long long lower = (1ull << lane) - 1ull;
     for (int k0 = 0; k0 < np; k0 += 64) {
         const int k = k0 + lane;
         PairEval r;
         r.in_enc = r.in_out = false;
         int j = 0;
+        bool up = false;
         if (k < np) {
             j = lo + k + (k >= il ? 1 : 0);
             r = eval_pair(pos, i, j, pair_code[p0 + k], order_enc, order_out, cut2);
+            up = j > i;
         }
-        const bool own = (k < np) && r.needs_own_attr();
-        const unsigned long long me = __ballot(r.in_enc), mo = __ballot(r.in_out), md = __ballot(own);
-        const int ie = be + __popcll(me & lower), io = bo + __popcll(mo & lower), id = bd + __popcll(md & lower);
-        if (r.in_enc) {
-            enc.src[ie] = i;
-            enc.dst[ie] = j;
-            enc.dist[ie] = r.d;
-            enc.type_r[ie] = (uint8_t)r.tr_enc;
-            enc.type_p[ie] = (uint8_t)r.tp_enc;
-            enc.pair_id[ie] = p0 + k;
+        const bool m[NLIST] = {r.in_enc, r.in_out, r.in_enc && up, r.in_out && up,
+                               (k < np) && up && r.needs_own_attr()};
+        int at[NLIST];
+#pragma unroll
+        for (int q = 0; q < NLIST; ++q) {
+            const unsigned long long b = __ballot(m[q]);
+            at[q] = base[q] + __popcll(b & lower);
+            base[q] += __popcll(b);
         }
-        if (r.in_out) {
-            out.src[io] = i;
-            out.dst[io] = j;
-            out.dist[io] = r.d;
-            out.type_r[io] = (uint8_t)r.tr_out;
-            out.type_p[io] = (uint8_t)r.tp_out;
-            out.pair_id[io] = p0 + k;
-            attr_row[io] = own ? P + id : ie;  // row of the [2P,H] edge-attribute matrix
+        if (m[0]) {
+            const int e = at[0];
+            g.enc.src[e] = i;
+            g.enc.dst[e] = j;
+            g.enc.dist[e] = r.d;
+            g.enc.type_r[e] = (uint8_t)r.tr_enc;
+            g.enc.type_p[e] = (uint8_t)r.tp_enc;
+            g.enc.pair_id[e] = p0 + k;
         }
-        if (own) {
-            diff.dist[id] = r.d;
-            diff.type_r[id] = (uint8_t)r.tr_out;
-            diff.type_p[id] = (uint8_t)r.tp_out;
+        if (m[1]) {
+            const int e = at[1];
+            g.out.src[e] = i;
+            g.out.dst[e] = j;
+            g.out.dist[e] = r.d;
+            g.out.type_r[e] = (uint8_t)r.tr_out;
+            g.out.type_p[e] = (uint8_t)r.tp_out;
+            g.out.pair_id[e] = p0 + k;
         }
-        if (k < np) pair2out[p0 + k] = r.in_out ? io : -1;
-        be += __popcll(me);
-        bo += __popcll(mo);
-        bd += __popcll(md);
+        if (m[2]) {
+            const int e = at[2];
+            g.enc_u.src[e] = i;
+            g.enc_u.dst[e] = j;
+            g.enc_u.dist[e] = r.d;
+            g.enc_u.type_r[e] = (uint8_t)r.tr_enc;
+            g.enc_u.type_p[e] = (uint8_t)r.tp_enc;
+            g.enc_u.pair_id[e] = p0 + k;
+        }
+        if (m[3]) {
+            const int e = at[3];
+            g.out_u.src[e] = i;
+            g.out_u.dst[e] = j;
+            g.out_u.dist[e] = r.d;
+            g.out_u.type_r[e] = (uint8_t)r.tr_out;
+            g.out_u.type_p[e] = (uint8_t)r.tp_out;
+            g.out_u.pair_id[e] = p0 + k;
+            g.attr_row[e] = m[4] ? PU + at[4] : at[2];  // own embedding, or the enc_u edge's row
+        }
+        if (m[4]) {
+            const int e = at[4];
+            g.diff_u.dist[e] = r.d;
+            g.diff_u.type_r[e] = (uint8_t)r.tr_out;
+            g.diff_u.type_p[e] = (uint8_t)r.tp_out;
+        }
+        if (k < np) {
+            g.pair2out[p0 + k] = m[1] ? at[1] : -1;
+            if (up) {
+                g.pair2u[p0 + k] = m[2] ? at[2] : -1;
+                g.pair2u[(size_t)P + p0 + k] = m[3] ? at[3] : -1;
+            }
+        }
+    }
+}
+
+// directed edge -> index of its undirected pair (needs every row's fill to be complete: own launch)
+__global__ void edge_umap_kernel(tsd_geometry g, const int32_t* __restrict__ graph_ptr,
+                                 const int32_t* __restrict__ node_graph, const int32_t* __restrict__ pair_ptr,
+                                 int P) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int Ee = *g.enc.count, Eo = *g.out.count;
+    if (e < Ee) {
+        const int i = g.enc.src[e], j = g.enc.dst[e];
+        int p = g.enc.pair_id[e];
+        if (i > j) {
+            const int lo = graph_ptr[node_graph[i]];
+            const int il = i - lo, jl = j - lo;
+            p = pair_ptr[j] + il - (il > jl ? 1 : 0);
+        }
+        g.enc.umap[e] = g.pair2u[p];
+    }
+    if (e < Eo) {
+        const int i = g.out.src[e], j = g.out.dst[e];
+        int p = g.out.pair_id[e];
+        if (i > j) {
+            const int lo = graph_ptr[node_graph[i]];
+            const int il = i - lo, jl = j - lo;
+            p = pair_ptr[j] + il - (il > jl ? 1 : 0);
+        }
+        g.out.umap[e] = g.pair2u[(size_t)P + p];
     }
 }
 
 size_t geometry_scratch_ints(int N, int P) {
     (void)P;
-    return (size_t)3 * (N + 1);
+    return (size_t)NLIST * (N + 1);
 }
 
 int launch_geometry(const tsd_model_cfg& c, int N, int G, int P, const float* pos, const int32_t* graph_ptr,
                     const int32_t* node_graph, const int32_t* pair_ptr, const uint16_t* pair_code,
-                    tsd_edges enc, tsd_edges out, tsd_edges diff, int32_t* attr_row, int32_t* pair2out,
-                    int32_t* scratch, hipStream_t st) {
+                    tsd_geometry g, hipStream_t st) {
     (void)G;
-    int32_t* cnt_enc = scratch;
-    int32_t* cnt_out = scratch + (N + 1);
-    int32_t* cnt_diff = scratch + 2 * (N + 1);
+    int32_t* cnt = g.scratch;
     const float cut2 = c.edge_cutoff * c.edge_cutoff;
     const int blocks = (N + 3) / 4;
     if (N > 0) {
         hipLaunchKernelGGL(pair_count_kernel, dim3(blocks), dim3(256), 0, st, N, pos, graph_ptr, node_graph,
-                           pair_ptr, pair_code, c.edge_order, c.pred_edge_order, cut2, cnt_enc, cnt_out, cnt_diff);
+                           pair_ptr, pair_code, c.edge_order, c.pred_edge_order, cut2, cnt);
         TSD_LAUNCH_CHECK("pair_count");
     }
-    hipLaunchKernelGGL(scan3_kernel, dim3(1), dim3(1024), 0, st, N, cnt_enc, cnt_out, cnt_diff, enc.row_ptr,
-                       out.row_ptr, diff.row_ptr, enc.count, out.count, diff.count);
-    TSD_LAUNCH_CHECK("scan3");
+    ScanOut so;
+    tsd_edges* lists[NLIST] = {&g.enc, &g.out, &g.enc_u, &g.out_u, &g.diff_u};
+    for (int q = 0; q < NLIST; ++q) {
+        so.row_ptr[q] = lists[q]->row_ptr;
+        so.total[q] = lists[q]->count;
+    }
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, N, cnt, so);
+    TSD_LAUNCH_CHECK("scan");
     if (N > 0) {
         hipLaunchKernelGGL(pair_fill_kernel, dim3(blocks), dim3(256), 0, st, N, pos, graph_ptr, node_graph,
-                           pair_ptr, pair_code, c.edge_order, c.pred_edge_order, cut2, enc, out, diff, attr_row, P,
-                           pair2out);
+                           pair_ptr, pair_code, c.edge_order, c.pred_edge_order, cut2, g, P);
         TSD_LAUNCH_CHECK("pair_fill");
+    }
+    if (P > 0) {
+        hipLaunchKernelGGL(edge_umap_kernel, dim3((P + 255) / 256), dim3(256), 0, st, g, graph_ptr, node_graph,
+                           pair_ptr, P);
+        TSD_LAUNCH_CHECK("edge_umap");
     }
     return TSD_OK;
 }

@@ -47,6 +47,7 @@ int launch_node_embed(const tsd_model_cfg& c, const float* W, int N, const int64
 template <int H>
 __global__ __launch_bounds__(256) void cfconv_aggregate_kernel(int N, const int32_t* __restrict__ row_ptr,
                                                                const int32_t* __restrict__ dst,
+                                                               const int32_t* __restrict__ umap,
                                                                const float* __restrict__ W,
                                                                const float* __restrict__ x1,
                                                                float* __restrict__ out) {
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(256) void cfconv_aggregate_kernel(int N, const int3
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int j = dst[e + u];
-            const float* wp = W + (size_t)(e + u) * H + lane * V;
+            const int we = umap ? umap[e + u] : e + u;
+            const float* wp = W + (size_t)we * H + lane * V;
             const float* xp = x1 + (size_t)j * H + lane * V;
             if (V == 4) {
                 const f32x4 wv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp));
@@ -84,22 +86,23 @@ __global__ __launch_bounds__(256) void cfconv_aggregate_kernel(int N, const int3
     }
     for (; e < e1; ++e) {
         const int j = dst[e];
+        const int we = umap ? umap[e] : e;
 #pragma unroll
         for (int v = 0; v < V; ++v)
-            acc[v] = __fadd_rn(acc[v], __fmul_rn(x1[(size_t)j * H + lane * V + v], W[(size_t)e * H + lane * V + v]));
+            acc[v] = __fadd_rn(acc[v], __fmul_rn(x1[(size_t)j * H + lane * V + v], W[(size_t)we * H + lane * V + v]));
     }
 #pragma unroll
     for (int v = 0; v < V; ++v) out[(size_t)i * H + lane * V + v] = acc[v];
 }
 
-int launch_cfconv_aggregate(int H, int N, const int32_t* row_ptr, const int32_t* dst, const float* W,
-                            const float* x1, float* out, hipStream_t st) {
+int launch_cfconv_aggregate(int H, int N, const int32_t* row_ptr, const int32_t* dst, const int32_t* umap,
+                            const float* W, const float* x1, float* out, hipStream_t st) {
     if (N == 0) return TSD_OK;
     const int blocks = (N + 3) / 4;
     switch (H) {
-        case 64: hipLaunchKernelGGL(cfconv_aggregate_kernel<64>, dim3(blocks), dim3(256), 0, st, N, row_ptr, dst, W, x1, out); break;
-        case 128: hipLaunchKernelGGL(cfconv_aggregate_kernel<128>, dim3(blocks), dim3(256), 0, st, N, row_ptr, dst, W, x1, out); break;
-        case 256: hipLaunchKernelGGL(cfconv_aggregate_kernel<256>, dim3(blocks), dim3(256), 0, st, N, row_ptr, dst, W, x1, out); break;
+        case 64: hipLaunchKernelGGL(cfconv_aggregate_kernel<64>, dim3(blocks), dim3(256), 0, st, N, row_ptr, dst, umap, W, x1, out); break;
+        case 128: hipLaunchKernelGGL(cfconv_aggregate_kernel<128>, dim3(blocks), dim3(256), 0, st, N, row_ptr, dst, umap, W, x1, out); break;
+        case 256: hipLaunchKernelGGL(cfconv_aggregate_kernel<256>, dim3(blocks), dim3(256), 0, st, N, row_ptr, dst, umap, W, x1, out); break;
         default: set_error("hidden=%d unsupported (64/128/256)", H); return TSD_ERR_INVALID;
     }
     TSD_LAUNCH_CHECK("cfconv_aggregate");
@@ -183,18 +186,19 @@ int launch_eq_transform_rows(int N, const float* pos, const int32_t* pair_ptr, c
 // ---------------------------------------------------------------------------------------------
 // ensemble mean, reference sampler.py:96-111: edge_inv += out[0] (in order), then /= M
 // ---------------------------------------------------------------------------------------------
-__global__ void ensemble_mean_kernel(int M, int P, const int32_t* __restrict__ count,
-                                     const float* __restrict__ inv, float* __restrict__ mean) {
+__global__ void ensemble_mean_kernel(int M, int PU, tsd_edges out, const float* __restrict__ inv_u,
+                                     float* __restrict__ mean) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= *count) return;
-    float s = inv[e];
-    for (int m = 1; m < M; ++m) s = __fadd_rn(s, inv[(size_t)m * P + e]);
+    if (e >= *out.count) return;
+    const int u = out.umap[e];
+    float s = inv_u[u];
+    for (int m = 1; m < M; ++m) s = __fadd_rn(s, inv_u[(size_t)m * PU + u]);
     mean[e] = s / (float)M;
 }
 
-int launch_ensemble_mean(int M, int P, const int32_t* count, const float* inv, float* mean, hipStream_t st) {
+int launch_ensemble_mean(int M, int P, tsd_edges out, const float* inv_u, float* mean, hipStream_t st) {
     if (P == 0) return TSD_OK;
-    hipLaunchKernelGGL(ensemble_mean_kernel, dim3((P + 255) / 256), dim3(256), 0, st, M, P, count, inv, mean);
+    hipLaunchKernelGGL(ensemble_mean_kernel, dim3((P + 255) / 256), dim3(256), 0, st, M, P / 2, out, inv_u, mean);
     TSD_LAUNCH_CHECK("ensemble_mean");
     return TSD_OK;
 }

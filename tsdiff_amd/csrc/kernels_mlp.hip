@@ -215,6 +215,78 @@ __global__ __launch_bounds__(H) void cfconv_layer_kernel(CfconvW w, float conv_c
 }
 
 // ---------------------------------------------------------------------------------------------
+// CFConv filters of every layer, one launch: Wf[l][e] = nn2_l(ssp(nn0_l(edge_attr[e]))) * C(e)
+// reference models/encoder/schnet.py:94-99.  grid = (edge tiles, layers).  The filter is independent
+// of the node states, so all layers' GEMMs are batched; it is evaluated once per UNDIRECTED pair
+// (edge_attr and C are symmetric) and consumed by tsd_cfconv_aggregate through `umap`.
+// ---------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(H) void filter_gen_kernel(const float* __restrict__ Wl0, size_t layer_stride,
+                                                       size_t o_nn0_w, size_t o_nn0_b, size_t o_nn2_w,
+                                                       size_t o_nn2_b, float conv_cutoff, tsd_edges e,
+                                                       const float* __restrict__ edge_attr,
+                                                       float* __restrict__ Wf, size_t wf_layer_stride) {
+    constexpr int LDA = H + 4;
+    constexpr int C4 = H / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* buf = smem;
+    float* s_c = smem + T * LDA;
+
+    const int E = *e.count;
+    const int e0 = blockIdx.x * T;
+    if (e0 >= E) return;
+    const int layer = blockIdx.y;
+    const float* Wb = Wl0 + (size_t)layer * layer_stride;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int col0 = (tid >> 6) * 64;
+    const int nrows = min(T, E - e0);
+
+    if (tid < T) s_c[tid] = (tid < nrows && e.dist[e0 + tid] <= conv_cutoff) ? 1.0f : 0.0f;  // schnet.py:97-98
+    for (int idx = tid; idx < T * C4; idx += H) {
+        const int r = idx / C4, c4 = idx % C4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < nrows) v = *reinterpret_cast<const f32x4*>(edge_attr + (size_t)(e0 + r) * H + c4 * 4);
+        *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = v;
+    }
+    __syncthreads();
+
+    f32x16 acc[1][2];
+    zero_acc(acc);
+    gemm_tile<1, 2, H>(buf, LDA, Wb + o_nn0_w, H, col0, acc);
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int col = col0 + cb * 32 + l31;
+        const float b = Wb[o_nn0_b + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf[acc_row(r, hi) * LDA + col] = sspf(acc[0][cb][r] + b);
+    }
+    __syncthreads();
+
+    zero_acc(acc);
+    gemm_tile<1, 2, H>(buf, LDA, Wb + o_nn2_w, H, col0, acc);
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int col = col0 + cb * 32 + l31;
+        const float b = Wb[o_nn2_b + col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, hi);
+            buf[row * LDA + col] = (acc[0][cb][r] + b) * s_c[row];  // W = nn(edge_attr) * C
+        }
+    }
+    __syncthreads();
+    float* out = Wf + (size_t)layer * wf_layer_stride;  // whole 1-KiB rows, float4 per lane
+    for (int idx = tid; idx < nrows * C4; idx += H) {
+        const int r = idx / C4, c4 = idx % C4;
+        *reinterpret_cast<f32x4*>(out + (size_t)(e0 + r) * H + c4 * 4) =
+            *reinterpret_cast<const f32x4*>(buf + r * LDA + c4 * 4);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // node side of an interaction block + the next block's lin1:
 //   a = assemble(agg, part); h += lin(ssp(lin2(a))); x1 = lin1_next(h)
 // reference models/encoder/schnet.py:103 (lin2), :123-127 (act, lin), :223-224 (residual),
@@ -247,8 +319,9 @@ __global__ __launch_bounds__(2 * H) void node_update_kernel(NodeW w, int N, cons
     if (MODE == 0) {
         if (tid < TN) {
             const bool v = tid < nrows;
-            s_rp0[tid] = v ? row_ptr[n0 + tid] : 0;
-            s_rp1[tid] = v ? row_ptr[n0 + tid + 1] : 0;
+            // without a row_ptr every row counts as non-empty and complete (tsd_cfconv_aggregate output)
+            s_rp0[tid] = (v && row_ptr) ? row_ptr[n0 + tid] : 0;
+            s_rp1[tid] = v ? (row_ptr ? row_ptr[n0 + tid + 1] : 1) : 0;
         }
         __syncthreads();
         for (int idx = tid; idx < TN * C4; idx += NT) {
@@ -257,7 +330,7 @@ __global__ __launch_bounds__(2 * H) void node_update_kernel(NodeW w, int N, cons
             f32x4 v = zero4;
             if (rp1 > rp0) {
                 const int t0 = rp0 / T, t1 = (rp1 - 1) / T;
-                if (t0 == t1) {
+                if (part == nullptr || t0 == t1) {
                     v = *reinterpret_cast<const f32x4*>(agg + (size_t)(n0 + r) * H + c4 * 4);
                 } else {  // row cut by edge-tile boundaries: add the tiles' partial sums in order
                     for (int t = t0; t <= t1; ++t) {
@@ -489,6 +562,25 @@ int launch_cfconv_layer(const tsd_model_cfg& c, const float* W, int layer, int c
                            edge_attr, x1, agg, part);
     });
     TSD_LAUNCH_CHECK("cfconv_layer");
+    return TSD_OK;
+}
+
+static inline size_t lds_filter(int H) { return (size_t)(T * (H + 4) + T) * 4; }
+
+int launch_filter_gen(const tsd_model_cfg& c, const float* W, int capacity, tsd_edges e, const float* edge_attr,
+                      float* Wf, hipStream_t st) {
+    const WeightLayout L = weight_layout(c);
+    const int tiles = (capacity + T - 1) / T;
+    if (tiles == 0) return TSD_OK;
+    const size_t lds = lds_filter(c.hidden);
+    TSD_DISPATCH_H(c.hidden, {
+        static bool done = false; int r = allow_lds_once(filter_gen_kernel<HH>, lds, done);
+        if (r) return r;
+        hipLaunchKernelGGL(filter_gen_kernel<HH>, dim3(tiles, c.num_convs), dim3(HH), lds, st, W + L.layer0,
+                           L.layer_stride, L.L_nn0_w, L.L_nn0_b, L.L_nn2_w, L.L_nn2_b, c.conv_cutoff, e, edge_attr,
+                           Wf, (size_t)capacity * HH);
+    });
+    TSD_LAUNCH_CHECK("filter_gen");
     return TSD_OK;
 }
 

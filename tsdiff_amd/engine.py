@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import Batch, Edges, ModelCfg, check, ptr, stream_ptr
+from ._lib import Batch, Edges, Geometry, ModelCfg, check, ptr, stream_ptr
 
 # order of the flattened reference state_dict expected by tsd_pack_weights (include/tsdiff_hip.h)
 
@@ -99,10 +99,12 @@ class EdgeList:
         self.type_r = torch.zeros(max(P, 1), dtype=torch.uint8, device=device)
         self.type_p = torch.zeros(max(P, 1), dtype=torch.uint8, device=device)
         self.pair_id = torch.zeros(max(P, 1), **i32)
+        self.umap = torch.zeros(max(P, 1), **i32)
 
     def struct(self):
         return Edges(*[C.c_void_p(t.data_ptr()) for t in (
-            self.count, self.row_ptr, self.src, self.dst, self.dist, self.type_r, self.type_p, self.pair_id)])
+            self.count, self.row_ptr, self.src, self.dst, self.dist, self.type_r, self.type_p, self.pair_id,
+            self.umap)])
 
     def num_edges(self):
         return int(self.count.item())  # host sync
@@ -167,17 +169,20 @@ class DeviceBatch:
         if st & _lib.STATUS_ASYMMETRIC:
             raise ValueError("bond list must contain both directions of every bond with equal types "
                              "(reference utils/datasets.py:491-507)")
-        self.enc = EdgeList(N, P, dev)
+        self.enc = EdgeList(N, P, dev)      # directed lists: the reference's edge_index order
         self.out = EdgeList(N, P, dev)
-        self.diff = EdgeList(N, P, dev)
-        self.attr_row = torch.zeros(max(P, 1), **i32)
+        self.enc_u = EdgeList(N, P // 2, dev)  # undirected (src < dst) lists the per-edge MLPs run on
+        self.out_u = EdgeList(N, P // 2, dev)
+        self.diff_u = EdgeList(N, P // 2, dev)
+        self.attr_row = torch.zeros(max(P // 2, 1), **i32)
         self.pair2out = torch.zeros(max(P, 1), **i32)
+        self.pair2u = torch.zeros(max(2 * P, 1), **i32)
         self.geo_scratch = torch.zeros(lib.tsd_geometry_scratch_ints(N, P), **i32)
         self.workspace = None
         self.edge_inv = None
         self.z = None
         self._z_key = None
-        self.scratch = torch.zeros(((P + 63) // 64) * 64 + 3 * N + 64, dtype=torch.float32, device=dev)
+        self.scratch = torch.zeros(((P + 63) // 64) * 64 + 3 * N + 128, dtype=torch.float32, device=dev)
 
     # ---- per-checkpoint state ----------------------------------------------------------------
     def bind_models(self, packed_list, key):
@@ -195,9 +200,15 @@ class DeviceBatch:
         nws = lib.tsd_forward_workspace_floats(C.byref(self.cfg), self.N, self.P, M)
         if self.workspace is None or self.workspace.numel() < nws:
             self.workspace = torch.empty(max(nws, 1), dtype=torch.float32, device=self.device)
-        self.edge_inv = torch.zeros(M, max(self.P, 1), dtype=torch.float32, device=self.device)
+        self.edge_inv_u = torch.zeros(M, max(self.P // 2, 1), dtype=torch.float32, device=self.device)
         self.M = M
         self._z_key = key
+
+    def geo_struct(self):
+        return Geometry(enc=self.enc.struct(), out=self.out.struct(), enc_u=self.enc_u.struct(),
+                        out_u=self.out_u.struct(), diff_u=self.diff_u.struct(),
+                        attr_row=self.attr_row.data_ptr(), pair2out=self.pair2out.data_ptr(),
+                        pair2u=self.pair2u.data_ptr(), scratch=self.geo_scratch.data_ptr())
 
     def struct(self):
         return Batch(
@@ -205,10 +216,8 @@ class DeviceBatch:
             graph_ptr=self.graph_ptr.data_ptr(), node_graph=self.node_graph.data_ptr(),
             pair_ptr=self.pair_ptr.data_ptr(), pair_code=self.pair_code.data_ptr(),
             weights=self.weights.data_ptr(), z=self.z.data_ptr(),
-            enc=self.enc.struct(), out=self.out.struct(), diff=self.diff.struct(),
-            attr_row=self.attr_row.data_ptr(), pair2out=self.pair2out.data_ptr(),
-            geo_scratch=self.geo_scratch.data_ptr(), workspace=self.workspace.data_ptr(),
-            edge_inv=self.edge_inv.data_ptr())
+            geo=self.geo_struct(), workspace=self.workspace.data_ptr(),
+            edge_inv_u=self.edge_inv_u.data_ptr())
 
     # ---- ops -------------------------------------------------------------------------------
     def geometry(self, pos):
@@ -216,12 +225,10 @@ class DeviceBatch:
         pos = pos.to(torch.float32).contiguous()
         check(lib.tsd_geometry_build(C.byref(self.cfg), self.N, self.G, self.P, ptr(pos), ptr(self.graph_ptr),
                                      ptr(self.node_graph), ptr(self.pair_ptr), ptr(self.pair_code),
-                                     self.enc.struct(), self.out.struct(), self.diff.struct(),
-                                     ptr(self.attr_row), ptr(self.pair2out), ptr(self.geo_scratch),
-                                     stream_ptr()))
+                                     self.geo_struct(), stream_ptr()))
 
     def forward(self, pos):
-        """geometry + M forwards; results stay on the device (self.edge_inv[m, :E_out])."""
+        """geometry + M forwards; results stay on the device (self.edge_inv_u[m, :E_out/2])."""
         lib = _lib.load()
         pos = pos.to(torch.float32).contiguous()
         b = self.struct()
@@ -229,9 +236,10 @@ class DeviceBatch:
         return pos
 
     def ensemble_mean(self):
+        """directed edge_inv (reference order): mean over the checkpoints, expanded through out.umap"""
         lib = _lib.load()
         mean = self.scratch[: max(self.P, 1)]
-        check(lib.tsd_ensemble_mean(self.M, self.P, ptr(self.out.count), ptr(self.edge_inv), ptr(mean),
+        check(lib.tsd_ensemble_mean(self.M, self.P, self.out.struct(), ptr(self.edge_inv_u), ptr(mean),
                                     stream_ptr()))
         return mean
 

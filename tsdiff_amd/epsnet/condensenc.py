@@ -150,8 +150,9 @@ class CondenseEncoderEpsNetwork(nn.Module):
         packed = self.packed_weights()
         db.bind_models([packed], key=("single", id(self), self._packed_key))
         db.forward(pos)
+        mean = db.ensemble_mean()  # M = 1: expands the undirected result to the directed edge order
         E = db.out.num_edges()  # the one host sync (the reference's nonzero() syncs as well)
-        edge_inv = db.edge_inv[0, :E].clone().unsqueeze(-1)
+        edge_inv = mean[:E].clone().unsqueeze(-1)
         if not return_edges:
             return edge_inv
         edge_index, edge_length, _, _ = db.edges_to_torch("out")
