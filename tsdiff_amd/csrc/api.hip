@@ -1,6 +1,7 @@
 // api.hip -- the extern "C" surface of libtsdiff_hip.so (declared in include/tsdiff_hip.h) and the
 // orchestration of one score-network forward / one sampling step / the device-resident loop.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -37,7 +38,12 @@ int launch_topology(int, int, int, int64_t, const int32_t*, const int32_t*, cons
 size_t geometry_scratch_ints(int, int);
 int launch_geometry(const tsd_model_cfg&, int, int, int, const float*, const int32_t*, const int32_t*,
                     const int32_t*, const uint16_t*, tsd_geometry, hipStream_t);
-int launch_filter_gen(const tsd_model_cfg&, const float*, int, tsd_edges, const float*, float*, hipStream_t);
+int launch_filter_gen(const tsd_model_cfg&, const float*, int, tsd_edges, const float*, float*, int, int,
+                      hipStream_t);
+int launch_edge_embed2(const tsd_model_cfg&, const float*, int, tsd_edges, float*, int, tsd_edges, float*,
+                       hipStream_t);
+int launch_layer_combo(const tsd_model_cfg&, const float*, int, int, tsd_edges, const float*, const float*, float*,
+                       float*, int, int, tsd_edges, const float*, float*, hipStream_t);
 int launch_node_embed(const tsd_model_cfg&, const float*, int, const int64_t*, const int64_t*, const int64_t*,
                       float*, hipStream_t);
 int launch_cfconv_aggregate(int, int, const int32_t*, const int32_t*, const int32_t*, const float*,
@@ -64,7 +70,7 @@ static int check_cfg(const tsd_model_cfg* c) {
 struct Workspace {
     float *ea;   // [P, H]: rows 0..P/2-1 enc_u edges, rows P/2.. separately embedded (diff_u) out edges
     float *wf;   // [L, P/2, H]: CFConv filters of every layer on the undirected enc list
-    float *h, *x1, *agg;
+    float *h, *x1, *x1b, *agg;
     size_t total;
 };
 
@@ -77,9 +83,47 @@ static Workspace carve(const tsd_model_cfg& c, int N, int P, float* base) {
     w.wf = take((size_t)c.num_convs * PU * H);
     w.h = take((size_t)N * H);
     w.x1 = take((size_t)N * H);
+    w.x1b = take((size_t)N * H);
     w.agg = take((size_t)N * H);
     w.total = o;
     return w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two-stream forward.  The node-side chain of an interaction block (aggregate -> lin2 -> ssp -> lin ->
+// lin1) is a short dependent sequence on N = 1600 rows that can occupy ~100 of the 256 CUs; the filter
+// GEMMs of the NEXT block do not depend on it.  Stream B (library owned) therefore runs
+// edge_embed -> filter(0) -> filter(1) ... -> edge_embed(diff) while the caller's stream A runs the
+// node chain one block behind, joined by events.  Under stream capture the fork/join becomes two
+// parallel branches of the hipGraph.  TSDIFF_NO_OVERLAP=1 keeps everything on stream A.
+// ---------------------------------------------------------------------------------------------
+struct Overlap {
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, diff = nullptr;
+    hipEvent_t filt[64] = {};
+    bool enabled = false, fused = true, ready = false;
+};
+static Overlap g_ov[16];
+
+static int get_overlap(Overlap** out) {
+    int dev = 0;
+    TSD_HIP(hipGetDevice(&dev));
+    Overlap& o = g_ov[dev & 15];
+    if (!o.ready) {
+        // TSDIFF_FORWARD = fused (default) | streams | serial   (A/B switches; see kernels_combo.hip)
+        const char* env = getenv("TSDIFF_FORWARD");
+        o.fused = !(env && (env[0] == 's'));
+        o.enabled = env && env[0] == 's' && env[1] == 't';
+        if (o.enabled) {
+            TSD_HIP(hipStreamCreateWithFlags(&o.side, hipStreamNonBlocking));
+            TSD_HIP(hipEventCreateWithFlags(&o.fork, hipEventDisableTiming));
+            TSD_HIP(hipEventCreateWithFlags(&o.diff, hipEventDisableTiming));
+            for (int l = 0; l < 64; ++l) TSD_HIP(hipEventCreateWithFlags(&o.filt[l], hipEventDisableTiming));
+        }
+        o.ready = true;
+    }
+    *out = &o;
+    return TSD_OK;
 }
 
 // One forward per checkpoint on the current positions.  Every per-edge MLP runs on the UNDIRECTED
@@ -87,31 +131,72 @@ static Workspace carve(const tsd_model_cfg& c, int N, int P, float* base) {
 // the directed CSR list only drives the aggregation and eq_transform through `umap`.
 static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float* pos, hipStream_t st) {
     const int N = b.num_nodes, G = b.num_graphs, P = b.num_pairs, M = b.num_models;
-    const int PU = P / 2;
+    const int PU = P / 2, L = c.num_convs;
     const size_t H = c.hidden;
     const tsd_geometry& g = b.geo;
     int r;
+    Overlap* ov = nullptr;
+    if ((r = get_overlap(&ov))) return r;
+    const bool two = ov->enabled;
+    hipStream_t sb = two ? ov->side : st;
     if ((r = launch_geometry(c, N, G, P, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, g, st))) return r;
     const Workspace w = carve(c, N, P, b.workspace);
     const size_t wfloats = weight_layout(c).total;
+    if (ov->fused) {
+        // one launch per interaction block: node chain of block l || filter GEMMs of block l+1
+        for (int m = 0; m < M; ++m) {
+            const float* W = b.weights + (size_t)m * wfloats;
+            if ((r = launch_edge_embed2(c, W, PU, g.enc_u, w.ea, PU, g.diff_u, w.ea + (size_t)PU * H, st))) return r;
+            TSD_HIP(hipMemcpyAsync(w.h, b.z + (size_t)m * N * H, (size_t)N * H * sizeof(float),
+                                   hipMemcpyDeviceToDevice, st));
+            float* xa = w.x1;
+            float* xb = w.x1b;
+            if ((r = launch_layer_combo(c, W, -1, N, g.enc, nullptr, nullptr, w.h, xa, 0, PU, g.enc_u, w.ea, w.wf, st)))
+                return r;
+            for (int l = 0; l < L; ++l) {
+                const int fl = (l + 1 < L) ? l + 1 : -1;
+                if ((r = launch_layer_combo(c, W, l, N, g.enc, w.wf + (size_t)l * PU * H, xa, w.h, xb, fl, PU, g.enc_u,
+                                            w.ea, w.wf + (size_t)(l + 1 < L ? l + 1 : 0) * PU * H, st)))
+                    return r;
+                float* t = xa; xa = xb; xb = t;
+            }
+            if ((r = launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u + (size_t)m * PU, st)))
+                return r;
+        }
+        return TSD_OK;
+    }
     for (int m = 0; m < M; ++m) {
         const float* W = b.weights + (size_t)m * wfloats;
-        if ((r = launch_edge_embed(c, W, PU, g.enc_u, w.ea, st))) return r;
-        if ((r = launch_filter_gen(c, W, PU, g.enc_u, w.ea, w.wf, st))) return r;
+        if (two) {  // B starts after everything A has done so far (geometry, previous checkpoint)
+            TSD_HIP(hipEventRecord(ov->fork, st));
+            TSD_HIP(hipStreamWaitEvent(sb, ov->fork, 0));
+        }
+        if ((r = launch_edge_embed(c, W, PU, g.enc_u, w.ea, sb))) return r;
+        if ((r = launch_filter_gen(c, W, PU, g.enc_u, w.ea, w.wf, 0, two ? 1 : L, sb))) return r;
+        if (two) TSD_HIP(hipEventRecord(ov->filt[0], sb));
         TSD_HIP(hipMemcpyAsync(w.h, b.z + (size_t)m * N * H, (size_t)N * H * sizeof(float),
                                hipMemcpyDeviceToDevice, st));
         if ((r = launch_node_lin1(c, W, 0, N, w.h, w.x1, st))) return r;
-        for (int l = 0; l < c.num_convs; ++l) {
+        for (int l = 0; l < L; ++l) {
+            if (two && l + 1 < L) {
+                if ((r = launch_filter_gen(c, W, PU, g.enc_u, w.ea, w.wf, l + 1, 1, sb))) return r;
+                TSD_HIP(hipEventRecord(ov->filt[l + 1], sb));
+            }
+            if (two) TSD_HIP(hipStreamWaitEvent(st, ov->filt[l], 0));
             if ((r = launch_cfconv_aggregate(c.hidden, N, g.enc.row_ptr, g.enc.dst, g.enc.umap,
                                              w.wf + (size_t)l * PU * H, w.x1, w.agg, st)))
                 return r;
-            if ((r = launch_node_update(c, W, l, (l + 1 < c.num_convs) ? l + 1 : -1, N, nullptr, w.agg, nullptr,
-                                        w.h, w.x1, st)))
+            if ((r = launch_node_update(c, W, l, (l + 1 < L) ? l + 1 : -1, N, nullptr, w.agg, nullptr, w.h, w.x1,
+                                        st)))
                 return r;
         }
         // out edges whose (d, types) differ from their enc edge (only the hop == edge_order pairs when
         // pred_edge_order < edge_order) are embedded on their own; every other out edge reuses its enc row
-        if ((r = launch_edge_embed(c, W, PU, g.diff_u, w.ea + (size_t)PU * H, st))) return r;
+        if ((r = launch_edge_embed(c, W, PU, g.diff_u, w.ea + (size_t)PU * H, sb))) return r;
+        if (two) {
+            TSD_HIP(hipEventRecord(ov->diff, sb));
+            TSD_HIP(hipStreamWaitEvent(st, ov->diff, 0));  // join: A is downstream of all of B's work
+        }
         if ((r = launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u + (size_t)m * PU, st)))
             return r;
     }
@@ -226,7 +311,7 @@ int tsd_filter_gen(const tsd_model_cfg* cfg, const float* w, int32_t capacity, t
     int r = check_cfg(cfg);
     if (r) return r;
     TSD_REQUIRE(w && edge_attr && Wf && edges.count && edges.dist, "null pointer");
-    return launch_filter_gen(*cfg, w, capacity, edges, edge_attr, Wf, (hipStream_t)stream);
+    return launch_filter_gen(*cfg, w, capacity, edges, edge_attr, Wf, 0, cfg->num_convs, (hipStream_t)stream);
 }
 
 int tsd_cfconv_aggregate(int32_t hidden, int32_t num_nodes, const int32_t* row_ptr, const int32_t* dst,

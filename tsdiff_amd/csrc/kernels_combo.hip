@@ -1,0 +1,316 @@
+// kernels_combo.hip -- one launch per interaction block: the node-side chain of block l and the filter
+// GEMMs of block l+1 share a grid ("horizontal fusion").
+//
+// At batch-100 sizes the node chain (aggregate -> lin2 -> ssp -> lin -> +h -> next lin1 on N = 1600
+// rows) is a short dependent sequence that can occupy ~100 of the 256 CUs, while the CFConv filters
+// of the NEXT block (reference models/encoder/schnet.py:94-99) do not depend on it.  Two streams joined
+// by events were measured slower under hipGraph replay (1.07 vs 0.92 ms/step) and only 6 % faster
+// eagerly, so the overlap is done inside ONE kernel: workgroups [0, node_tiles) take the node role
+// (they are dispatched first: critical path), the rest take the filter role and fill the idle CUs.
+// Roles never communicate; the kernel boundary orders block l's filter before block l's aggregation.
+//
+// Both roles run with 2H threads = H/32 waves, 32 output columns per wave.
+#include "common.hpp"
+
+namespace tsd {
+
+constexpr int T = TSD_EDGE_TILE;   // 32 edges per filter tile
+constexpr int TN = TSD_NODE_TILE;  // 16 nodes per node tile
+
+struct ComboNode {
+    int mode;  // 0: aggregate + update (+ next lin1), 1: x1_out = lin1(h) only, -1: no node role
+    int N;
+    const int32_t *row_ptr, *dst, *umap;
+    const float* Wf;  // this block's filters on the undirected list [Eu, H]
+    const float* x1_in;
+    float* h;
+    float* x1_out;
+    const float *lin2_w, *lin2_b, *lin_w, *lin_b, *lin1_next_w;
+};
+
+struct ComboFilter {
+    int tiles;  // 0: no filter role
+    const float *nn0_w, *nn0_b, *nn2_w, *nn2_b;
+    float conv_cutoff;
+    tsd_edges e;
+    const float* edge_attr;
+    float* out;  // [Eu, H] of the layer being generated
+};
+
+// -------------------------------------------------------------------------------------------------
+// node role: agg[i] = sum_{e in row i} x1[dst e] * Wf[umap e]  (edge order, product rounded then added:
+// bit-identical to a sequential scatter_add), then the three dense layers of tsd_node_update.
+// reference schnet.py:101-107 (message/aggregate), :103 (lin2), :123-127, :223-224
+// -------------------------------------------------------------------------------------------------
+template <int H>
+__device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* smem) {
+    constexpr int LDA = H + 4;
+    constexpr int NT = 2 * H;
+    constexpr int NW = H / 32;
+    constexpr int RPW = TN / NW;  // rows aggregated per wave
+    constexpr int V = H / 64;     // channels per lane during aggregation
+    constexpr int C4 = H / 4;
+    static_assert(TN % NW == 0, "");
+    float* buf = smem;
+
+    const int n0 = tile * TN;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, l15 = lane & 15;
+    const int col0 = wave * 32;
+    const int nrows = min(TN, a.N - n0);
+    f32x4 acc[2];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    if (a.mode == 0) {
+#pragma unroll 1
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int r = __builtin_amdgcn_readfirstlane(wave * RPW + rr);
+            const int i = n0 + r;
+            float s[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) s[v] = 0.0f;
+            if (i < a.N) {
+                const int e0 = a.row_ptr[i], e1 = a.row_ptr[i + 1];
+                for (int eb = e0; eb < e1; eb += 64) {
+                    const int cnt = min(64, e1 - eb);
+                    int jv = 0, uv = 0;
+                    if (lane < cnt) {  // one coalesced index load per 64 edges, broadcast by readlane
+                        jv = a.dst[eb + lane];
+                        uv = a.umap[eb + lane];
+                    }
+                    int k = 0;
+                    for (; k + 4 <= cnt; k += 4) {
+                        float wv[4][V], xv[4][V];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int j = __builtin_amdgcn_readlane(jv, k + u);
+                            const int we = __builtin_amdgcn_readlane(uv, k + u);
+                            const float* wp = a.Wf + (size_t)we * H + lane * V;
+                            const float* xp = a.x1_in + (size_t)j * H + lane * V;
+                            if (V == 4) {
+                                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp);
+                                const f32x4 x4 = *reinterpret_cast<const f32x4*>(xp);
+#pragma unroll
+                                for (int v = 0; v < V; ++v) { wv[u][v] = w4[v]; xv[u][v] = x4[v]; }
+                            } else {
+#pragma unroll
+                                for (int v = 0; v < V; ++v) { wv[u][v] = wp[v]; xv[u][v] = xp[v]; }
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int v = 0; v < V; ++v) s[v] = __fadd_rn(s[v], __fmul_rn(xv[u][v], wv[u][v]));
+                    }
+                    for (; k < cnt; ++k) {
+                        const int j = __builtin_amdgcn_readlane(jv, k);
+                        const int we = __builtin_amdgcn_readlane(uv, k);
+#pragma unroll
+                        for (int v = 0; v < V; ++v)
+                            s[v] = __fadd_rn(s[v], __fmul_rn(a.x1_in[(size_t)j * H + lane * V + v],
+                                                             a.Wf[(size_t)we * H + lane * V + v]));
+                    }
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < V; ++v) buf[r * LDA + lane * V + v] = s[v];
+        }
+        __syncthreads();
+
+        acc[0] = zero4; acc[1] = zero4;
+        gemm_tile16<2, H>(buf, LDA, a.lin2_w, H, col0, acc);
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int col = col0 + cb * 16 + l15;
+            const float b = a.lin2_b[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) buf[(q * 4 + r) * LDA + col] = sspf(acc[cb][r] + b);
+        }
+        __syncthreads();
+
+        acc[0] = zero4; acc[1] = zero4;
+        gemm_tile16<2, H>(buf, LDA, a.lin_w, H, col0, acc);
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int col = col0 + cb * 16 + l15;
+            const float b = a.lin_b[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = q * 4 + r;
+                float hn = 0.0f;
+                if (row < nrows) {
+                    const size_t o = (size_t)(n0 + row) * H + col;
+                    hn = a.h[o] + (acc[cb][r] + b);
+                    a.h[o] = hn;
+                }
+                buf[row * LDA + col] = hn;
+            }
+        }
+        if (a.lin1_next_w == nullptr) return;
+        __syncthreads();
+    } else {
+        for (int idx = tid; idx < TN * C4; idx += NT) {
+            const int r = idx / C4, c4 = idx % C4;
+            f32x4 v = zero4;
+            if (r < nrows) v = *reinterpret_cast<const f32x4*>(a.h + (size_t)(n0 + r) * H + c4 * 4);
+            *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = v;
+        }
+        __syncthreads();
+    }
+
+    acc[0] = zero4; acc[1] = zero4;
+    gemm_tile16<2, H>(buf, LDA, a.lin1_next_w, H, col0, acc);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int col = col0 + cb * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = q * 4 + r;
+            if (row < nrows) a.x1_out[(size_t)(n0 + row) * H + col] = acc[cb][r];
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// filter role: Wf[e] = nn2(ssp(nn0(edge_attr[e]))) * C(e) for one tile of 32 undirected edges,
+// H/32 waves x 32 columns (the 256-thread stand-alone form is filter_gen_kernel in kernels_mlp.hip)
+// -------------------------------------------------------------------------------------------------
+template <int H>
+__device__ __forceinline__ void filter_role(const ComboFilter& f, int tile, float* smem) {
+    constexpr int LDA = H + 4;
+    constexpr int NT = 2 * H;
+    constexpr int C4 = H / 4;
+    float* buf = smem;
+    float* s_c = smem + T * LDA;
+
+    const int E = *f.e.count;
+    const int e0 = tile * T;
+    if (e0 >= E) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int col0 = (tid >> 6) * 32;
+    const int nrows = min(T, E - e0);
+
+    if (tid < T) s_c[tid] = (tid < nrows && f.e.dist[e0 + tid] <= f.conv_cutoff) ? 1.0f : 0.0f;
+    for (int idx = tid; idx < T * C4; idx += NT) {
+        const int r = idx / C4, c4 = idx % C4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < nrows) v = *reinterpret_cast<const f32x4*>(f.edge_attr + (size_t)(e0 + r) * H + c4 * 4);
+        *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = v;
+    }
+    __syncthreads();
+
+    f32x16 acc[1][1];
+    zero_acc(acc);
+    gemm_tile<1, 1, H>(buf, LDA, f.nn0_w, H, col0, acc);
+    __syncthreads();
+    {
+        const int col = col0 + l31;
+        const float b = f.nn0_b[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf[acc_row(r, hi) * LDA + col] = sspf(acc[0][0][r] + b);
+    }
+    __syncthreads();
+
+    zero_acc(acc);
+    gemm_tile<1, 1, H>(buf, LDA, f.nn2_w, H, col0, acc);
+    __syncthreads();
+    {
+        const int col = col0 + l31;
+        const float b = f.nn2_b[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, hi);
+            buf[row * LDA + col] = (acc[0][0][r] + b) * s_c[row];
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nrows * C4; idx += NT) {
+        const int r = idx / C4, c4 = idx % C4;
+        *reinterpret_cast<f32x4*>(f.out + (size_t)(e0 + r) * H + c4 * 4) =
+            *reinterpret_cast<const f32x4*>(buf + r * LDA + c4 * 4);
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int node_tiles, ComboFilter f) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((int)blockIdx.x < node_tiles)
+        node_role<H>(a, blockIdx.x, smem);
+    else
+        filter_role<H>(f, blockIdx.x - node_tiles, smem);
+}
+
+static inline size_t lds_combo(int H) {
+    const size_t node = (size_t)TN * (H + 4) * 4;
+    const size_t filt = (size_t)(T * (H + 4) + T) * 4;
+    return node > filt ? node : filt;
+}
+
+// layer < 0: node role = lin1 of block 0 only.  filter_layer < 0: no filter role.
+int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N, tsd_edges enc,
+                       const float* Wf_layer, const float* x1_in, float* h, float* x1_out, int filter_layer,
+                       int capacity_u, tsd_edges enc_u, const float* edge_attr, float* Wf_out, hipStream_t st) {
+    const WeightLayout L = weight_layout(c);
+    ComboNode a{};
+    a.N = N;
+    a.row_ptr = enc.row_ptr;
+    a.dst = enc.dst;
+    a.umap = enc.umap;
+    a.Wf = Wf_layer;
+    a.x1_in = x1_in;
+    a.h = h;
+    a.x1_out = x1_out;
+    if (layer < 0) {
+        a.mode = 1;
+        a.lin1_next_w = W + L.layer0 + L.L_lin1_w;
+    } else {
+        const float* B = W + L.layer0 + (size_t)layer * L.layer_stride;
+        a.mode = 0;
+        a.lin2_w = B + L.L_lin2_w;
+        a.lin2_b = B + L.L_lin2_b;
+        a.lin_w = B + L.L_lin_w;
+        a.lin_b = B + L.L_lin_b;
+        a.lin1_next_w = (layer + 1 < c.num_convs) ? B + L.layer_stride + L.L_lin1_w : nullptr;
+    }
+    ComboFilter f{};
+    f.tiles = 0;
+    if (filter_layer >= 0) {
+        const float* B = W + L.layer0 + (size_t)filter_layer * L.layer_stride;
+        f.tiles = (capacity_u + T - 1) / T;
+        f.nn0_w = B + L.L_nn0_w;
+        f.nn0_b = B + L.L_nn0_b;
+        f.nn2_w = B + L.L_nn2_w;
+        f.nn2_b = B + L.L_nn2_b;
+        f.conv_cutoff = c.conv_cutoff;
+        f.e = enc_u;
+        f.edge_attr = edge_attr;
+        f.out = Wf_out;
+    }
+    const int node_tiles = (N + TN - 1) / TN;
+    const int grid = node_tiles + f.tiles;
+    if (grid == 0) return TSD_OK;
+    const size_t lds = lds_combo(c.hidden);
+#define TSD_COMBO(HH)                                                                                         \
+    {                                                                                                         \
+        static bool done = false;                                                                             \
+        if (!done && lds > 48 * 1024)                                                                         \
+            TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_combo_kernel<HH>),                \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+        done = true;                                                                                          \
+        hipLaunchKernelGGL(layer_combo_kernel<HH>, dim3(grid), dim3(2 * HH), lds, st, a, node_tiles, f);      \
+    }
+    switch (c.hidden) {
+        case 64: TSD_COMBO(64) break;
+        case 128: TSD_COMBO(128) break;
+        case 256: TSD_COMBO(256) break;
+        default: set_error("hidden=%d unsupported (64/128/256)", c.hidden); return TSD_ERR_INVALID;
+    }
+#undef TSD_COMBO
+    TSD_LAUNCH_CHECK("layer_combo");
+    return TSD_OK;
+}
+
+}  // namespace tsd

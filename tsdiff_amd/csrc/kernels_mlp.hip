@@ -29,8 +29,11 @@ struct PairW {
 // reference models/encoder/edge.py:58-68, models/epsnet/condensenc.py:156-176,105-115
 // mlp(d) is evaluated once and shared by the r/p branches (identical inputs in the reference).
 // ---------------------------------------------------------------------------------------------
+// Two lists may share one launch (tiles [0, tiles_a) -> list a, the rest -> list b): the encoder list and
+// the few output-graph edges that need their own embedding fill the chip together.
 template <int H>
-__global__ __launch_bounds__(H) void edge_embed_kernel(EdgeEmbedW w, tsd_edges e, float* __restrict__ edge_attr) {
+__global__ __launch_bounds__(H) void edge_embed_kernel(EdgeEmbedW w, tsd_edges ea_, float* __restrict__ out_a,
+                                                       int tiles_a, tsd_edges eb_, float* __restrict__ out_b) {
     constexpr int LDA = 2 * H + 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* buf = smem;
@@ -38,8 +41,11 @@ __global__ __launch_bounds__(H) void edge_embed_kernel(EdgeEmbedW w, tsd_edges e
     int* s_tr = reinterpret_cast<int*>(s_d + T);
     int* s_tp = s_tr + T;
 
+    const bool second = (int)blockIdx.x >= tiles_a;
+    const tsd_edges& e = second ? eb_ : ea_;
+    float* __restrict__ edge_attr = second ? out_b : out_a;
     const int E = *e.count;
-    const int e0 = blockIdx.x * T;
+    const int e0 = (second ? (int)blockIdx.x - tiles_a : (int)blockIdx.x) * T;
     if (e0 >= E) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
@@ -225,7 +231,8 @@ __global__ __launch_bounds__(H) void filter_gen_kernel(const float* __restrict__
                                                        size_t o_nn0_w, size_t o_nn0_b, size_t o_nn2_w,
                                                        size_t o_nn2_b, float conv_cutoff, tsd_edges e,
                                                        const float* __restrict__ edge_attr,
-                                                       float* __restrict__ Wf, size_t wf_layer_stride) {
+                                                       float* __restrict__ Wf, size_t wf_layer_stride,
+                                                       int layer_base) {
     constexpr int LDA = H + 4;
     constexpr int C4 = H / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(H) void filter_gen_kernel(const float* __restrict__
     const int E = *e.count;
     const int e0 = blockIdx.x * T;
     if (e0 >= E) return;
-    const int layer = blockIdx.y;
+    const int layer = blockIdx.y + layer_base;
     const float* Wb = Wl0 + (size_t)layer * layer_stride;
     const int tid = threadIdx.x;
     const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
@@ -530,21 +537,27 @@ static int allow_lds_once(K kernel, size_t bytes, bool& done) {
         default: set_error("hidden=%d unsupported (64/128/256)", H_); return TSD_ERR_INVALID; \
     }
 
-int launch_edge_embed(const tsd_model_cfg& c, const float* W, int capacity, tsd_edges e, float* edge_attr,
-                      hipStream_t st) {
+int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_edges ea, float* out_a, int cap_b,
+                       tsd_edges eb, float* out_b, hipStream_t st) {
     const WeightLayout L = weight_layout(c);
     EdgeEmbedW w{W + L.bond_emb, W + L.emlp_w0, W + L.emlp_b0, W + L.emlp_w1, W + L.emlp_b1,
                  W + L.ecat_w0, W + L.ecat_b0, W + L.ecat_w1, W + L.ecat_b1};
-    const int tiles = (capacity + T - 1) / T;
-    if (tiles == 0) return TSD_OK;
+    const int tiles_a = (cap_a + T - 1) / T, tiles_b = (cap_b + T - 1) / T;
+    if (tiles_a + tiles_b == 0) return TSD_OK;
     const size_t lds = lds_edge_embed(c.hidden);
     TSD_DISPATCH_H(c.hidden, {
         static bool done = false; int r = allow_lds_once(edge_embed_kernel<HH>, lds, done);
         if (r) return r;
-        hipLaunchKernelGGL(edge_embed_kernel<HH>, dim3(tiles), dim3(HH), lds, st, w, e, edge_attr);
+        hipLaunchKernelGGL(edge_embed_kernel<HH>, dim3(tiles_a + tiles_b), dim3(HH), lds, st, w, ea, out_a, tiles_a,
+                           eb, out_b);
     });
     TSD_LAUNCH_CHECK("edge_embed");
     return TSD_OK;
+}
+
+int launch_edge_embed(const tsd_model_cfg& c, const float* W, int capacity, tsd_edges e, float* edge_attr,
+                      hipStream_t st) {
+    return launch_edge_embed2(c, W, capacity, e, edge_attr, 0, e, edge_attr, st);
 }
 
 int launch_cfconv_layer(const tsd_model_cfg& c, const float* W, int layer, int capacity, tsd_edges e,
@@ -568,17 +581,17 @@ int launch_cfconv_layer(const tsd_model_cfg& c, const float* W, int layer, int c
 static inline size_t lds_filter(int H) { return (size_t)(T * (H + 4) + T) * 4; }
 
 int launch_filter_gen(const tsd_model_cfg& c, const float* W, int capacity, tsd_edges e, const float* edge_attr,
-                      float* Wf, hipStream_t st) {
+                      float* Wf, int layer_base, int nlayers, hipStream_t st) {
     const WeightLayout L = weight_layout(c);
     const int tiles = (capacity + T - 1) / T;
-    if (tiles == 0) return TSD_OK;
+    if (tiles == 0 || nlayers <= 0) return TSD_OK;
     const size_t lds = lds_filter(c.hidden);
     TSD_DISPATCH_H(c.hidden, {
         static bool done = false; int r = allow_lds_once(filter_gen_kernel<HH>, lds, done);
         if (r) return r;
-        hipLaunchKernelGGL(filter_gen_kernel<HH>, dim3(tiles, c.num_convs), dim3(HH), lds, st, W + L.layer0,
+        hipLaunchKernelGGL(filter_gen_kernel<HH>, dim3(tiles, nlayers), dim3(HH), lds, st, W + L.layer0,
                            L.layer_stride, L.L_nn0_w, L.L_nn0_b, L.L_nn2_w, L.L_nn2_b, c.conv_cutoff, e, edge_attr,
-                           Wf, (size_t)capacity * HH);
+                           Wf, (size_t)capacity * HH, layer_base);
     });
     TSD_LAUNCH_CHECK("filter_gen");
     return TSD_OK;
