@@ -135,52 +135,45 @@ def main():
     E_enc, E_out = db.enc.num_edges(), db.out.num_edges()
     H, L = cfg["hidden_dim"], cfg["encoder"]["num_convs"]
 
-    # ---- roofline of the dominant kernel: CFConv filter generation (all layers, undirected edge list)
+    # ---- roofline of the dominant kernel: one interaction block per launch (layer_combo_kernel):
+    # node chain of block l (aggregation + 3 dense layers) || CFConv filters of block l+1
     PU = db.P // 2
     Eu = db.enc_u.num_edges()
     ea = torch.randn(max(PU, 1), H, device=dev)
-    wf = torch.empty(L, max(PU, 1), H, device=dev)
-    reps = 20
+    wf = torch.randn(2, max(PU, 1), H, device=dev)
+    xa, xb = torch.randn(N, H, device=dev), torch.empty(N, H, device=dev)
+    hbuf = torch.randn(N, H, device=dev)
+    reps = 50
 
-    def launch_filter():
-        _lib.check(lib.tsd_filter_gen(C.byref(db.cfg), _lib.ptr(db.weights[0]), PU, db.enc_u.struct(),
-                                      _lib.ptr(ea), _lib.ptr(wf), _lib.stream_ptr()))
-    for _ in range(3):
-        launch_filter()
+    def launch_block():
+        _lib.check(lib.tsd_interaction_block(C.byref(db.cfg), _lib.ptr(db.weights[0]), 3, N, db.enc.struct(),
+                                             _lib.ptr(wf[0]), _lib.ptr(xa), _lib.ptr(hbuf), _lib.ptr(xb), 4, PU,
+                                             db.enc_u.struct(), _lib.ptr(ea), _lib.ptr(wf[1]), _lib.stream_ptr()))
+    for _ in range(5):
+        launch_block()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     for _ in range(reps):
-        launch_filter()
+        launch_block()
     ev1.record()
     torch.cuda.synchronize()
     k_ms = ev0.elapsed_time(ev1) / reps
-    flops = float(L) * Eu * (4.0 * H * H + H)  # per layer and undirected edge: two HxH GEMMs + the C mask
+    # algorithmic flops per launch: filters of one layer on the undirected list
+    # (two HxH GEMMs + C mask), aggregation over the directed list, three HxH GEMMs per node
+    flops = Eu * (4.0 * H * H + H) + E_enc * 2.0 * H + N * 6.0 * H * H
     ach = flops / (k_ms * 1e-3) / 1e12
-    roofline = {"kernel": "filter_gen_kernel<256>", "bound": "mfma", "achieved": round(ach, 2),
+    traffic = None
+    try:  # HBM-side bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_summary.py)
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            traffic = round(json.load(fh)["kernels"]["layer_combo_kernel<256>"]["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    roofline = {"kernel": "layer_combo_kernel<256>", "bound": "mfma", "achieved": round(ach, 2),
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": None, "avg_launch_us": round(k_ms * 1e3, 2), "undirected_edges": Eu, "layers": L,
-                "flop_per_edge_layer": 4 * H * H + H}
-    # the HBM/L2-bound companion: segmented aggregation with the materialised filter
-    x1 = torch.randn(N, H, device=dev)
-    agg = torch.empty(N, H, device=dev)
-
-    def launch_agg():
-        _lib.check(lib.tsd_cfconv_aggregate(H, N, _lib.ptr(db.enc.row_ptr), _lib.ptr(db.enc.dst),
-                                            _lib.ptr(db.enc.umap), _lib.ptr(wf[0]), _lib.ptr(x1), _lib.ptr(agg),
-                                            _lib.stream_ptr()))
-    for _ in range(3):
-        launch_agg()
-    ev0.record()
-    for _ in range(reps):
-        launch_agg()
-    ev1.record()
-    torch.cuda.synchronize()
-    a_ms = ev0.elapsed_time(ev1) / reps
-    a_bytes = E_enc * (4.0 * H + 4 + 4) + 2.0 * N * 4 * H + 4.0 * (N + 1)  # SURVEY.md 8(d) byte model (+ umap)
-    roofline["aggregate"] = {"kernel": "cfconv_aggregate_kernel<256>", "bound": "hbm",
-                             "achieved": round(a_bytes / (a_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
-                             "unit": "GB/s", "avg_launch_us": round(a_ms * 1e3, 2),
-                             "note": "27 MB working set at batch 100: L2/MALL resident, launch-latency bound"}
+                "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes)",
+                "avg_launch_us": round(k_ms * 1e3, 2), "undirected_edges": Eu, "directed_edges": E_enc, "nodes": N,
+                "flop_per_launch": flops,
+                "algorithmic_bytes_per_launch": Eu * 4.0 * H * 2 + Eu * 4.0 * H + 4.0 * N * H * 4 + 2e6}
 
     # whole-forward arithmetic rate (SURVEY.md 8a FLOP model), for orientation
     # flops the implemented algorithm executes: per-edge MLPs once per undirected pair (E/2), the out

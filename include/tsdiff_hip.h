@@ -13,6 +13,8 @@
  *   tsd_cfconv_layer    models/encoder/schnet.py:88-107 (filter MLP + message + scatter-add, fused)
  *   tsd_cfconv_aggregate models/encoder/schnet.py:102,106 (MessagePassing aggr="add" alone)
  *   tsd_node_update     models/encoder/schnet.py:103,123-127,223-224 (lin2, ssp, lin, residual, next lin1)
+ *   tsd_filter_gen      models/encoder/schnet.py:94-99 (CFConv filters of all layers, once per undirected pair)
+ *   tsd_interaction_block  one launch per block: node chain of block l || filters of block l+1
  *   tsd_pair_output     models/common.py:226-229 + models/epsnet/condensenc.py:236-237
  *   tsd_eq_transform*   models/geometry.py:22-30
  *   tsd_sampler_step    models/sampler.py:208-251 (clip_norm, LD/DDPM update, NaN flag, center_pos)
@@ -161,6 +163,17 @@ int tsd_filter_gen(const tsd_model_cfg* cfg, const float* w, int32_t capacity, t
  * out[i] = sum_{e: row_ptr[i] <= e < row_ptr[i+1]} x1[dst[e]] * W[umap ? umap[e] : e], edges in order. */
 int tsd_cfconv_aggregate(int32_t hidden, int32_t num_nodes, const int32_t* row_ptr, const int32_t* dst,
                          const int32_t* umap, const float* W, const float* x1, float* out, void* stream);
+
+/* One interaction block in ONE launch (the production path): workgroups [0, ceil(N/16)) run the node
+ * chain of `layer` -- agg[i] = sum_{e in row i} x1_in[dst e] * Wf_layer[enc.umap[e]] in edge order, then
+ * h += lin(ssp(lin2(agg))), x1_out = lin1_{layer+1}(h) -- and the remaining workgroups generate the
+ * CFConv filters of `filter_layer` (normally layer+1; -1: none) into Wf_out on the CUs the short node
+ * chain leaves idle.  layer == -1: the node role is only x1_out = lin1_0(h).
+ * x1_in and x1_out must be different buffers.  reference schnet.py:94-107,123-127,223-224 */
+int tsd_interaction_block(const tsd_model_cfg* cfg, const float* w, int32_t layer, int32_t num_nodes,
+                          tsd_edges enc, const float* Wf_layer, const float* x1_in, float* h, float* x1_out,
+                          int32_t filter_layer, int32_t capacity_u, tsd_edges enc_u, const float* edge_attr,
+                          float* Wf_out, void* stream);
 
 /* h += lin(ssp(lin2(agg) )); if next_layer >= 0 also x1 = lin1_{next_layer}(h).
  * part / enc_row_ptr: only for agg produced by tsd_cfconv_layer (rows cut by tile edges); pass NULL

@@ -153,6 +153,29 @@ def test_layer_kernels_vs_oracle(dev):
     _lib.check(lib.tsd_cfconv_aggregate(H, N, _lib.ptr(db.enc.row_ptr), _lib.ptr(db.enc.dst), _lib.ptr(db.enc.umap),
                                         _lib.ptr(Wf_all[0]), _lib.ptr(x1o), _lib.ptr(agg2), _lib.stream_ptr()))
     assert_close(agg2.cpu().numpy(), trace["agg0"].numpy(), RTOL, "aggregate through umap")
+    # the fused per-block launch must reproduce the piecewise kernels BIT FOR BIT (same arithmetic order)
+    h_a = db.z[0].clone()
+    x_a = torch.zeros(N, H, device=dev)
+    _lib.check(lib.tsd_node_lin1(C.byref(db.cfg), _lib.ptr(W), 0, N, _lib.ptr(h_a), _lib.ptr(x_a), _lib.stream_ptr()))
+    agg_a = torch.zeros(N, H, device=dev)
+    _lib.check(lib.tsd_cfconv_aggregate(H, N, _lib.ptr(db.enc.row_ptr), _lib.ptr(db.enc.dst), _lib.ptr(db.enc.umap),
+                                        _lib.ptr(Wf_all[0]), _lib.ptr(x_a), _lib.ptr(agg_a), _lib.stream_ptr()))
+    x_a2 = torch.zeros(N, H, device=dev)
+    _lib.check(lib.tsd_node_update(C.byref(db.cfg), _lib.ptr(W), 0, 1, N, None, _lib.ptr(agg_a), None,
+                                   _lib.ptr(h_a), _lib.ptr(x_a2), _lib.stream_ptr()))
+    h_b = db.z[0].clone()
+    x_b = torch.zeros(N, H, device=dev)
+    x_b2 = torch.zeros(N, H, device=dev)
+    Wf_b = torch.full((L, PU, H), float("nan"), device=dev)
+    _lib.check(lib.tsd_interaction_block(C.byref(db.cfg), _lib.ptr(W), -1, N, db.enc.struct(), None, None,
+                                         _lib.ptr(h_b), _lib.ptr(x_b), 0, PU, db.enc_u.struct(), _lib.ptr(ea_u),
+                                         _lib.ptr(Wf_b[0]), _lib.stream_ptr()))
+    _lib.check(lib.tsd_interaction_block(C.byref(db.cfg), _lib.ptr(W), 0, N, db.enc.struct(), _lib.ptr(Wf_b[0]),
+                                         _lib.ptr(x_b), _lib.ptr(h_b), _lib.ptr(x_b2), 1, PU, db.enc_u.struct(),
+                                         _lib.ptr(ea_u), _lib.ptr(Wf_b[1]), _lib.stream_ptr()))
+    assert torch.equal(x_b, x_a) and torch.equal(h_b, h_a) and torch.equal(x_b2, x_a2)
+    assert torch.equal(Wf_b[0][:Eu], Wf_all[0][:Eu]) and torch.equal(Wf_b[1][:Eu], Wf_all[1][:Eu])
+    assert_close(h_b.cpu().numpy(), trace["h1"].numpy(), RTOL, "h after fused block 0")
 
 
 def test_forward_vs_oracle_seeded_batch(dev):

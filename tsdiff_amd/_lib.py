@@ -102,6 +102,8 @@ SIGNATURES = {
     "tsd_node_lin1": (C.c_int, [_CFG, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "tsd_cfconv_layer": (C.c_int, [_CFG, _P, C.c_int32, C.c_int32, Edges, _P, _P, _P, _P, _P]),
     "tsd_filter_gen": (C.c_int, [_CFG, _P, C.c_int32, Edges, _P, _P, _P]),
+    "tsd_interaction_block": (C.c_int, [_CFG, _P, C.c_int32, C.c_int32, Edges, _P, _P, _P, _P, C.c_int32, C.c_int32,
+                                        Edges, _P, _P, _P]),
     "tsd_cfconv_aggregate": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "tsd_node_update": (C.c_int, [_CFG, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "tsd_pair_output": (C.c_int, [_CFG, _P, C.c_int32, Edges, _P, _P, _P, _P, _P]),

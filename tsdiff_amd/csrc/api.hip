@@ -314,6 +314,22 @@ int tsd_filter_gen(const tsd_model_cfg* cfg, const float* w, int32_t capacity, t
     return launch_filter_gen(*cfg, w, capacity, edges, edge_attr, Wf, 0, cfg->num_convs, (hipStream_t)stream);
 }
 
+int tsd_interaction_block(const tsd_model_cfg* cfg, const float* w, int32_t layer, int32_t num_nodes,
+                          tsd_edges enc, const float* Wf_layer, const float* x1_in, float* h, float* x1_out,
+                          int32_t filter_layer, int32_t capacity_u, tsd_edges enc_u, const float* edge_attr,
+                          float* Wf_out, void* stream) {
+    int r = check_cfg(cfg);
+    if (r) return r;
+    TSD_REQUIRE(w && h && x1_out, "null pointer");
+    TSD_REQUIRE(layer >= -1 && layer < cfg->num_convs && filter_layer >= -1 && filter_layer < cfg->num_convs,
+                "layer out of range");
+    TSD_REQUIRE(layer < 0 || (Wf_layer && x1_in && enc.row_ptr && enc.dst && enc.umap && x1_in != x1_out),
+                "node role needs Wf_layer, x1_in != x1_out and the directed enc list");
+    TSD_REQUIRE(filter_layer < 0 || (edge_attr && Wf_out && enc_u.count && enc_u.dist), "filter role: null pointer");
+    return launch_layer_combo(*cfg, w, layer, num_nodes, enc, Wf_layer, x1_in, h, x1_out, filter_layer, capacity_u,
+                              enc_u, edge_attr, Wf_out, (hipStream_t)stream);
+}
+
 int tsd_cfconv_aggregate(int32_t hidden, int32_t num_nodes, const int32_t* row_ptr, const int32_t* dst,
                          const int32_t* umap, const float* W, const float* x1, float* out, void* stream) {
     TSD_REQUIRE(row_ptr && dst && W && x1 && out, "null pointer");
