@@ -38,6 +38,13 @@ int launch_topology(int, int, int, int64_t, const int32_t*, const int32_t*, cons
 size_t geometry_scratch_ints(int, int);
 int launch_geometry(const tsd_model_cfg&, int, int, int, const float*, const int32_t*, const int32_t*,
                     const int32_t*, const uint16_t*, tsd_geometry, hipStream_t);
+int launch_geometry_count(const tsd_model_cfg&, int, const float*, const int32_t*, const int32_t*, const int32_t*,
+                          const uint16_t*, tsd_geometry, hipStream_t);
+int launch_geometry_lists(const tsd_model_cfg&, int, int, const float*, const int32_t*, const int32_t*,
+                          const int32_t*, const uint16_t*, tsd_geometry, int32_t*, hipStream_t);
+int launch_step_post(const tsd_model_cfg&, int, int, int, int, int, const int32_t*, const int32_t*, const uint16_t*,
+                     tsd_geometry, const float*, const float*, const float*, float, float, float*, float*, int32_t*,
+                     const int32_t*, hipStream_t);
 int launch_filter_gen(const tsd_model_cfg&, const float*, int, tsd_edges, const float*, float*, int, int,
                       hipStream_t);
 int launch_edge_embed2(const tsd_model_cfg&, const float*, int, tsd_edges, float*, int, tsd_edges, float*,
@@ -129,8 +136,11 @@ static int get_overlap(Overlap** out) {
 // One forward per checkpoint on the current positions.  Every per-edge MLP runs on the UNDIRECTED
 // lists (half the edges of the reference's directed list: edge_attr, W and edge_inv are symmetric);
 // the directed CSR list only drives the aggregation and eq_transform through `umap`.
-static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float* pos, hipStream_t st) {
-    const int N = b.num_nodes, G = b.num_graphs, P = b.num_pairs, M = b.num_models;
+// counts_ready: the per-row member counts are already in geo.scratch (written by the previous step's
+// step_post_kernel); advance: device step counter bumped by the scan kernel (sampling loop only).
+static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float* pos, hipStream_t st,
+                        bool counts_ready = false, int32_t* advance = nullptr) {
+    const int N = b.num_nodes, P = b.num_pairs, M = b.num_models;
     const int PU = P / 2, L = c.num_convs;
     const size_t H = c.hidden;
     const tsd_geometry& g = b.geo;
@@ -139,7 +149,11 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     if ((r = get_overlap(&ov))) return r;
     const bool two = ov->enabled;
     hipStream_t sb = two ? ov->side : st;
-    if ((r = launch_geometry(c, N, G, P, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, g, st))) return r;
+    if (!counts_ready) {
+        if ((r = launch_geometry_count(c, N, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, g, st))) return r;
+    }
+    if ((r = launch_geometry_lists(c, N, P, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, g, advance, st)))
+        return r;
     const Workspace w = carve(c, N, P, b.workspace);
     const size_t wfloats = weight_layout(c).total;
     if (ov->fused) {
@@ -203,19 +217,16 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     return TSD_OK;
 }
 
+// one sampling step of the device-resident loop: lists (from the counts of the previous step's tail) ->
+// M forwards -> fused tail (mean, eq_transform, update, centre, next step's counts)
 static int step_impl(const tsd_model_cfg& c, const tsd_batch& b, int kind, const float* coefs,
-                     const float* noises, float clip, float clip_pos, float* pos, float* traj, float* scratch,
-                     int32_t* status, const int32_t* step_ctr, hipStream_t st) {
+                     const float* noises, float clip, float clip_pos, float* pos, float* traj,
+                     int32_t* status, int32_t* step_ctr, bool advance, hipStream_t st) {
     int r;
-    float* mean = scratch;
-    float* score = scratch + (((size_t)b.num_pairs + 63) & ~size_t(63));
-    if ((r = forward_impl(c, b, pos, st))) return r;
-    if ((r = launch_ensemble_mean(b.num_models, b.num_pairs, b.geo.out, b.edge_inv_u, mean, st))) return r;
-    if ((r = launch_eq_transform_rows(b.num_nodes, pos, b.pair_ptr, b.graph_ptr, b.node_graph, b.geo.out,
-                                      b.geo.pair2out, mean, score, st)))
-        return r;
-    return launch_sampler_step(kind, b.num_nodes, b.num_graphs, b.graph_ptr, score, noises, coefs, clip, clip_pos,
-                               pos, traj, status, step_ctr, st);
+    if ((r = forward_impl(c, b, pos, st, true, advance ? step_ctr : nullptr))) return r;
+    return launch_step_post(c, kind, b.num_nodes, b.num_graphs, b.num_models, b.num_pairs, b.graph_ptr, b.pair_ptr,
+                            b.pair_code, b.geo, b.edge_inv_u, noises, coefs, clip, clip_pos, pos, traj, status,
+                            step_ctr, st);
 }
 
 }  // namespace tsd
@@ -407,26 +418,25 @@ int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t ki
     hipStream_t st = (hipStream_t)stream;
     if (n_steps == 0) return TSD_OK;
     int32_t* step_ctr = status + 1;  // status[1]: device-side step counter (offsets into coefs/noises/traj)
+    (void)scratch;
+    const tsd_batch& b = *batch;
     TSD_HIP(hipMemsetAsync(step_ctr, 0, sizeof(int32_t), st));
-    // step 0 runs eagerly (also performs every one-time function-attribute set-up outside capture)
-    if ((r = step_impl(*cfg, *batch, kind, coefs, noises, clip, clip_pos, pos, traj, scratch, status, step_ctr, st)))
+    if ((r = launch_geometry_count(*cfg, b.num_nodes, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, b.geo,
+                                   st)))
         return r;
-    if ((r = launch_advance(step_ctr, st))) return r;
+    // step 0 runs eagerly (also performs every one-time function-attribute set-up outside capture)
+    if ((r = step_impl(*cfg, b, kind, coefs, noises, clip, clip_pos, pos, traj, status, step_ctr, false, st))) return r;
     if (n_steps == 1) return TSD_OK;
     if (!use_graph) {
-        for (int k = 1; k < n_steps; ++k) {
-            if ((r = step_impl(*cfg, *batch, kind, coefs, noises, clip, clip_pos, pos, traj, scratch, status,
-                               step_ctr, st)))
+        for (int k = 1; k < n_steps; ++k)
+            if ((r = step_impl(*cfg, b, kind, coefs, noises, clip, clip_pos, pos, traj, status, step_ctr, true, st)))
                 return r;
-            if ((r = launch_advance(step_ctr, st))) return r;
-        }
         return TSD_OK;
     }
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     TSD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    r = step_impl(*cfg, *batch, kind, coefs, noises, clip, clip_pos, pos, traj, scratch, status, step_ctr, st);
-    if (!r) r = launch_advance(step_ctr, st);
+    r = step_impl(*cfg, b, kind, coefs, noises, clip, clip_pos, pos, traj, status, step_ctr, true, st);
     hipError_t ce = hipStreamEndCapture(st, &graph);
     if (r) {
         if (graph) (void)hipGraphDestroy(graph);

@@ -171,12 +171,11 @@ struct PairEval {
     }
 };
 
-__device__ __forceinline__ PairEval eval_pair(const float* __restrict__ pos, int i, int j, int code,
-                                              int order_enc, int order_out, float cut2) {
+__device__ __forceinline__ PairEval eval_pair_xyz(float xi, float yi, float zi, float xj, float yj, float zj,
+                                                  int code, int order_enc, int order_out, float cut2) {
     PairEval r;
     // models/geometry.py:18-19  (pos[row] - pos[col]).norm()
-    const float dx = pos[3 * i] - pos[3 * j], dy = pos[3 * i + 1] - pos[3 * j + 1],
-                dz = pos[3 * i + 2] - pos[3 * j + 2];
+    const float dx = xi - xj, dy = yi - yj, dz = zi - zj;
     r.d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
     r.d = sqrtf(r.d2);
     const int bR = code & 31, bP = (code >> 5) & 31, hR = (code >> 10) & 7, hP = (code >> 13) & 7;
@@ -188,6 +187,12 @@ __device__ __forceinline__ PairEval eval_pair(const float* __restrict__ pos, int
     r.in_enc = in_radius || (r.tr_enc | r.tp_enc) != 0;
     r.in_out = in_radius || (r.tr_out | r.tp_out) != 0;
     return r;
+}
+
+__device__ __forceinline__ PairEval eval_pair(const float* __restrict__ pos, int i, int j, int code,
+                                              int order_enc, int order_out, float cut2) {
+    return eval_pair_xyz(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], code,
+                         order_enc, order_out, cut2);
 }
 
 // per-row member counts of the five lists: 0 enc, 1 out, 2 enc_u, 3 out_u, 4 diff_u  (u: j > i only)
@@ -235,9 +240,11 @@ struct ScanOut {
 };
 
 // exclusive scan of NLIST int arrays of length N (+ total at [N]); single workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void scan_kernel(int N, const int32_t* __restrict__ cnt, ScanOut o) {
+__global__ __launch_bounds__(1024) void scan_kernel(int N, const int32_t* __restrict__ cnt, ScanOut o,
+                                                    int32_t* __restrict__ advance) {
     __shared__ int sm[NLIST][1024];
     const int t = threadIdx.x;
+    if (advance && t == 0) *advance += 1;  // device-side step counter of the sampling loop
     const int per = (N + 1023) / 1024;
     const int beg = min(N, t * per), end = min(N, beg + per);
     int x[NLIST];
@@ -395,28 +402,32 @@ size_t geometry_scratch_ints(int N, int P) {
     return (size_t)NLIST * (N + 1);
 }
 
-int launch_geometry(const tsd_model_cfg& c, int N, int G, int P, const float* pos, const int32_t* graph_ptr,
-                    const int32_t* node_graph, const int32_t* pair_ptr, const uint16_t* pair_code,
-                    tsd_geometry g, hipStream_t st) {
-    (void)G;
-    int32_t* cnt = g.scratch;
+int launch_geometry_count(const tsd_model_cfg& c, int N, const float* pos, const int32_t* graph_ptr,
+                          const int32_t* node_graph, const int32_t* pair_ptr, const uint16_t* pair_code,
+                          tsd_geometry g, hipStream_t st) {
+    if (N == 0) return TSD_OK;
     const float cut2 = c.edge_cutoff * c.edge_cutoff;
-    const int blocks = (N + 3) / 4;
-    if (N > 0) {
-        hipLaunchKernelGGL(pair_count_kernel, dim3(blocks), dim3(256), 0, st, N, pos, graph_ptr, node_graph,
-                           pair_ptr, pair_code, c.edge_order, c.pred_edge_order, cut2, cnt);
-        TSD_LAUNCH_CHECK("pair_count");
-    }
+    hipLaunchKernelGGL(pair_count_kernel, dim3((N + 3) / 4), dim3(256), 0, st, N, pos, graph_ptr, node_graph, pair_ptr,
+                       pair_code, c.edge_order, c.pred_edge_order, cut2, g.scratch);
+    TSD_LAUNCH_CHECK("pair_count");
+    return TSD_OK;
+}
+
+// scan of the per-row counts (already in g.scratch) + fill + umap
+int launch_geometry_lists(const tsd_model_cfg& c, int N, int P, const float* pos, const int32_t* graph_ptr,
+                          const int32_t* node_graph, const int32_t* pair_ptr, const uint16_t* pair_code,
+                          tsd_geometry g, int32_t* advance, hipStream_t st) {
+    const float cut2 = c.edge_cutoff * c.edge_cutoff;
     ScanOut so;
     tsd_edges* lists[NLIST] = {&g.enc, &g.out, &g.enc_u, &g.out_u, &g.diff_u};
     for (int q = 0; q < NLIST; ++q) {
         so.row_ptr[q] = lists[q]->row_ptr;
         so.total[q] = lists[q]->count;
     }
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, N, cnt, so);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, N, g.scratch, so, advance);
     TSD_LAUNCH_CHECK("scan");
     if (N > 0) {
-        hipLaunchKernelGGL(pair_fill_kernel, dim3(blocks), dim3(256), 0, st, N, pos, graph_ptr, node_graph,
+        hipLaunchKernelGGL(pair_fill_kernel, dim3((N + 3) / 4), dim3(256), 0, st, N, pos, graph_ptr, node_graph,
                            pair_ptr, pair_code, c.edge_order, c.pred_edge_order, cut2, g, P);
         TSD_LAUNCH_CHECK("pair_fill");
     }
@@ -424,6 +435,171 @@ int launch_geometry(const tsd_model_cfg& c, int N, int G, int P, const float* po
         hipLaunchKernelGGL(edge_umap_kernel, dim3((P + 255) / 256), dim3(256), 0, st, g, graph_ptr, node_graph,
                            pair_ptr, P);
         TSD_LAUNCH_CHECK("edge_umap");
+    }
+    return TSD_OK;
+}
+
+int launch_geometry(const tsd_model_cfg& c, int N, int G, int P, const float* pos, const int32_t* graph_ptr,
+                    const int32_t* node_graph, const int32_t* pair_ptr, const uint16_t* pair_code,
+                    tsd_geometry g, hipStream_t st) {
+    (void)G;
+    int r = launch_geometry_count(c, N, pos, graph_ptr, node_graph, pair_ptr, pair_code, g, st);
+    if (r) return r;
+    return launch_geometry_lists(c, N, P, pos, graph_ptr, node_graph, pair_ptr, pair_code, g, nullptr, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// End of a sampling step, one wave per graph, fused: ensemble mean (reference sampler.py:96-111),
+// eq_transform (geometry.py:22-30), clip_norm + LD/DDPM update + NaN flag + centring (sampler.py:208-253)
+// and -- on the new positions, still in LDS -- the per-row member counts of the NEXT step's edge lists
+// (pair_count).  Replaces five launches (mean, eq_transform, update, advance, count) by one; the step
+// counter is advanced by the next step's scan kernel.
+// eq_transform: edge_inv is evaluated once per undirected pair, so s(i,j) == s(j,i) bit for bit and the
+// reference's two scatter terms are equal: score_i = A_i + A_i with A_i = sum_{e in row i} u_e s_e (edge order).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void step_post_kernel(int kind, int N, int M, int PU,
+                                                       const int32_t* __restrict__ graph_ptr,
+                                                       const int32_t* __restrict__ pair_ptr,
+                                                       const uint16_t* __restrict__ pair_code, tsd_edges out,
+                                                       const float* __restrict__ inv_u,
+                                                       const float* __restrict__ noise,
+                                                       const float* __restrict__ coefs, float clip, float clip_pos,
+                                                       float* __restrict__ pos, float* __restrict__ traj,
+                                                       int32_t* __restrict__ status,
+                                                       const int32_t* __restrict__ step_ctr, int order_enc,
+                                                       int order_out, float cut2, int32_t* __restrict__ cnt) {
+    __shared__ float old_s[3 * (TSD_MAX_GRAPH_NODES + 1)];
+    __shared__ float new_s[3 * (TSD_MAX_GRAPH_NODES + 1)];
+    const size_t k_step = (size_t)*step_ctr;
+    coefs += k_step * TSD_STEP_COEFS;
+    noise += k_step * 3 * (size_t)N;
+    if (traj) traj += k_step * 3 * (size_t)N;
+    const int g = blockIdx.x;
+    const int lo = graph_ptr[g], hi = graph_ptr[g + 1];
+    const int n = hi - lo;
+    const int lane = threadIdx.x;
+    float c[TSD_STEP_COEFS];
+#pragma unroll
+    for (int k = 0; k < TSD_STEP_COEFS; ++k) c[k] = coefs[k];
+    for (int t = lane; t < 3 * n; t += 64) old_s[t] = pos[3 * lo + t];
+    __syncthreads();
+
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    bool bad = false;
+    for (int il = lane; il < n; il += 64) {
+        const int i = lo + il;
+        const float px = old_s[3 * il], py = old_s[3 * il + 1], pz = old_s[3 * il + 2];
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        const int e1 = out.row_ptr[i + 1];
+        for (int e = out.row_ptr[i]; e < e1; ++e) {
+            const int jl = out.dst[e] - lo;
+            const int u = out.umap[e];
+            float s = inv_u[u];
+            for (int m = 1; m < M; ++m) s = __fadd_rn(s, inv_u[(size_t)m * PU + u]);
+            s = s / (float)M;
+            const float inv = 1.0f / out.dist[e];
+            ax = __fadd_rn(ax, __fmul_rn(__fmul_rn(inv, px - old_s[3 * jl]), s));
+            ay = __fadd_rn(ay, __fmul_rn(__fmul_rn(inv, py - old_s[3 * jl + 1]), s));
+            az = __fadd_rn(az, __fmul_rn(__fmul_rn(inv, pz - old_s[3 * jl + 2]), s));
+        }
+        float v[3] = {ax + ax, ay + ay, az + az};
+        float p[3] = {px, py, pz};
+        // clip_norm (sampler.py:265-268)
+        const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(v[0], v[0]), __fmul_rn(v[1], v[1])), __fmul_rn(v[2], v[2])));
+        const float denom = norm > clip ? clip / norm : 1.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float eps = __fmul_rn(v[k], denom);
+            const float nz = noise[3 * i + k];
+            float nx;
+            if (kind == 0) {  // LD, sampler.py:238-244
+                nx = __fadd_rn(__fadd_rn(p[k], __fmul_rn(c[0], eps) / c[1]), __fmul_rn(nz, c[2]));
+            } else {  // DDPM, sampler.py:215-236
+                const float e = -eps;
+                const float pos_C = __fmul_rn(c[0], p[k]);
+                const float pos0 = __fsub_rn(__fmul_rn(c[1], pos_C), __fmul_rn(c[2], e));
+                const float mean = __fadd_rn(__fmul_rn(c[3], pos0), __fmul_rn(c[4], pos_C)) / c[5];
+                nx = __fadd_rn(mean, __fmul_rn(c[6], nz)) / c[7];
+            }
+            bad |= (nx != nx);
+            p[k] = nx;
+        }
+        new_s[3 * il] = p[0];
+        new_s[3 * il + 1] = p[1];
+        new_s[3 * il + 2] = p[2];
+        sx += p[0];
+        sy += p[1];
+        sz += p[2];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        sx += __shfl_xor(sx, off);
+        sy += __shfl_xor(sy, off);
+        sz += __shfl_xor(sz, off);
+    }
+    if (__ballot(bad) != 0ull && lane == 0) atomicOr(status, TSD_STATUS_NAN);
+    const float cntf = (float)max(n, 1);
+    const float mx = sx / cntf, my = sy / cntf, mz = sz / cntf;
+    for (int il = lane; il < n; il += 64) {  // center_pos (sampler.py:260-262) + optional clamp
+        float x = new_s[3 * il] - mx, y = new_s[3 * il + 1] - my, z = new_s[3 * il + 2] - mz;
+        if (clip_pos >= 0.0f) {
+            x = fminf(fmaxf(x, -clip_pos), clip_pos);
+            y = fminf(fmaxf(y, -clip_pos), clip_pos);
+            z = fminf(fmaxf(z, -clip_pos), clip_pos);
+        }
+        new_s[3 * il] = x;
+        new_s[3 * il + 1] = y;
+        new_s[3 * il + 2] = z;
+        const int i = lo + il;
+        pos[3 * i] = x;
+        pos[3 * i + 1] = y;
+        pos[3 * i + 2] = z;
+        if (traj) {
+            traj[3 * i] = x;
+            traj[3 * i + 1] = y;
+            traj[3 * i + 2] = z;
+        }
+    }
+    __syncthreads();
+    // member counts of the next step's lists on the new positions (same arithmetic as pair_count_kernel)
+    for (int il = 0; il < n; ++il) {
+        const int i = lo + il;
+        const int p0 = pair_ptr[i];
+        const float xi = new_s[3 * il], yi = new_s[3 * il + 1], zi = new_s[3 * il + 2];
+        int cq[NLIST] = {0, 0, 0, 0, 0};
+        for (int k0 = 0; k0 < n - 1; k0 += 64) {
+            const int k = k0 + lane;
+            bool mq[NLIST] = {false, false, false, false, false};
+            if (k < n - 1) {
+                const int jl = k + (k >= il ? 1 : 0);
+                const PairEval r = eval_pair_xyz(xi, yi, zi, new_s[3 * jl], new_s[3 * jl + 1], new_s[3 * jl + 2],
+                                                 pair_code[p0 + k], order_enc, order_out, cut2);
+                const bool up = jl > il;
+                mq[0] = r.in_enc;
+                mq[1] = r.in_out;
+                mq[2] = r.in_enc && up;
+                mq[3] = r.in_out && up;
+                mq[4] = r.needs_own_attr() && up;
+            }
+#pragma unroll
+            for (int q = 0; q < NLIST; ++q) cq[q] += __popcll(__ballot(mq[q]));
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < NLIST; ++q) cnt[(size_t)q * (N + 1) + i] = cq[q];
+        }
+    }
+}
+
+int launch_step_post(const tsd_model_cfg& c, int kind, int N, int G, int M, int P, const int32_t* graph_ptr,
+                     const int32_t* pair_ptr, const uint16_t* pair_code, tsd_geometry g, const float* inv_u,
+                     const float* noises, const float* coefs, float clip, float clip_pos, float* pos, float* traj,
+                     int32_t* status, const int32_t* step_ctr, hipStream_t st) {
+    if (G > 0) {
+        hipLaunchKernelGGL(step_post_kernel, dim3(G), dim3(64), 0, st, kind, N, M, P / 2, graph_ptr, pair_ptr,
+                           pair_code, g.out, inv_u, noises, coefs, clip, clip_pos, pos, traj, status, step_ctr,
+                           c.edge_order, c.pred_edge_order, c.edge_cutoff * c.edge_cutoff, g.scratch);
+        TSD_LAUNCH_CHECK("step_post");
     }
     return TSD_OK;
 }
