@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
+                    help="c2: BASELINE configs[1] wb97xd3-like batch (default, the quoted metric); "
+                         "c5: configs[4] synthetic 64-atom graphs, complete pair set (use --graphs 1024)")
     ap.add_argument("--graphs", type=int, default=100, help="graphs per GPU (BASELINE configs[1]: 100)")
     ap.add_argument("--models", type=int, default=1, help="ensemble size M (configs[2] uses 8)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
@@ -81,7 +84,10 @@ def main():
         models.append(model.to(dev))
     sampler = EnsembleSampler(models)
 
-    b = synth.wb97xd3_like_batch(args.graphs, seed=1000 + rank)
+    if args.workload == "c5":
+        b = synth.dense_stress_batch(args.graphs, n=64, seed=1000 + rank)
+    else:
+        b = synth.wb97xd3_like_batch(args.graphs, seed=1000 + rank)
     g = {k: torch.from_numpy(v).to(dev) for k, v in b.items() if isinstance(v, np.ndarray)}
     N = int(g["pos"].shape[0])
     gen = torch.Generator(device=dev)
@@ -89,6 +95,8 @@ def main():
     # compact start geometry (every intra-molecular pair within the 10 A cutoff -- the regime the last
     # ~4000 of the 5000 steps of a real run are in); the timed steps are the LAST K of the schedule
     pos_init = torch.randn(N, 3, device=dev, generator=gen) * 1.5
+    if args.workload == "c5":  # positions inside the 5.5 A cube: every pair within the cutoff
+        pos_init = g["pos"].clone()
 
     def run(n_steps, pos0):
         noises = torch.randn(n_steps, N, 3, device=dev, generator=gen)
@@ -163,17 +171,41 @@ def main():
     flops = Eu * (4.0 * H * H + H) + E_enc * 2.0 * H + N * 6.0 * H * H
     ach = flops / (k_ms * 1e-3) / 1e12
     traffic = None
-    try:  # HBM-side bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_summary.py)
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-            traffic = round(json.load(fh)["kernels"]["layer_combo_kernel<256>"]["hbm_bytes_per_launch"])
-    except Exception:
-        pass
+    if args.workload == "c2":
+        try:  # HBM-side bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_summary.py)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                traffic = round(json.load(fh)["kernels"]["layer_combo_kernel<256>"]["hbm_bytes_per_launch"])
+        except Exception:
+            traffic = None
     roofline = {"kernel": "layer_combo_kernel<256>", "bound": "mfma", "achieved": round(ach, 2),
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes)",
                 "avg_launch_us": round(k_ms * 1e3, 2), "undirected_edges": Eu, "directed_edges": E_enc, "nodes": N,
                 "flop_per_launch": flops,
                 "algorithmic_bytes_per_launch": Eu * 4.0 * H * 2 + Eu * 4.0 * H + 4.0 * N * H * 4 + 2e6}
+    # the HBM-bound form of the message pass: segmented aggregation with a materialised
+    # directed filter W [E,H]: bytes = 1028 E + 2048 N + 4
+    del ea, wf
+    Wd = torch.randn(max(E_enc, 1), H, device=dev)
+    agg = torch.empty(N, H, device=dev)
+
+    def launch_agg():
+        _lib.check(lib.tsd_cfconv_aggregate(H, N, _lib.ptr(db.enc.row_ptr), _lib.ptr(db.enc.dst), None, _lib.ptr(Wd),
+                                            _lib.ptr(xa), _lib.ptr(agg), _lib.stream_ptr()))
+    for _ in range(3):
+        launch_agg()
+    ev0.record()
+    for _ in range(20):
+        launch_agg()
+    ev1.record()
+    torch.cuda.synchronize()
+    a_ms = ev0.elapsed_time(ev1) / 20
+    a_bytes = 1028.0 * E_enc + 2048.0 * N + 4
+    roofline["aggregate"] = {"kernel": "cfconv_aggregate_kernel<256>", "bound": "hbm",
+                             "achieved": round(a_bytes / (a_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": round(a_bytes / (a_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                             "avg_launch_us": round(a_ms * 1e3, 2), "bytes_per_launch": a_bytes}
+    del Wd
 
     # whole-forward arithmetic rate (SURVEY.md 8a FLOP model), for orientation
     # flops the implemented algorithm executes: per-edge MLPs once per undirected pair (E/2), the out
@@ -188,7 +220,7 @@ def main():
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and args.workload == "c2":
         from oracle import tsdiff_oracle as O  # checker / baseline only
         # torch-CPU scales poorly past a few dozen threads on these op sizes (256 threads measured 35 s
         # per forward on the GPU box): use at most 32 and report the count actually used.
@@ -221,8 +253,9 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: wb97xd3-like batch of 100 graphs, LD sampling, last K steps of the "
-                               "5000-step schedule (step_lr 1e-7, clip 1000)",
+        "config": {"workload": ("configs[1]: wb97xd3-like batch of 100 graphs, LD sampling, last K steps of the "
+                                "5000-step schedule (step_lr 1e-7, clip 1000)") if args.workload == "c2" else
+                               "configs[4]: synthetic 64-atom graphs, complete intra-graph pair set, LD sampling",
                    "graphs_per_gpu": args.graphs, "atoms_per_gpu": N, "edges_enc": E_enc, "edges_out": E_out,
                    "checkpoints": args.models, "hidden": H, "num_convs": L, "hipgraph": not args.no_graph,
                    "parallelism": f"graphs sharded over {args.gpus} GPU(s), no collective"},
