@@ -30,7 +30,7 @@ int launch_node_update(const tsd_model_cfg&, const float*, int, int, int, const 
                        const float*, float*, float*, hipStream_t);
 int launch_node_lin1(const tsd_model_cfg&, const float*, int, int, const float*, float*, hipStream_t);
 int launch_pair_output(const tsd_model_cfg&, const float*, int, tsd_edges, const float*, const float*,
-                       const int32_t*, float*, hipStream_t);
+                       const int32_t*, float*, int, size_t, size_t, size_t, hipStream_t);
 size_t raw_weight_floats(const tsd_model_cfg&);
 int launch_pack_weights(const tsd_model_cfg&, const float*, float*, hipStream_t);
 int launch_topology(int, int, int, int64_t, const int32_t*, const int32_t*, const int64_t*, const int64_t*, int,
@@ -47,10 +47,10 @@ int launch_step_post(const tsd_model_cfg&, int, int, int, int, int, const int32_
                      const int32_t*, hipStream_t);
 int launch_filter_gen(const tsd_model_cfg&, const float*, int, tsd_edges, const float*, float*, int, int,
                       hipStream_t);
-int launch_edge_embed2(const tsd_model_cfg&, const float*, int, tsd_edges, float*, int, tsd_edges, float*,
-                       hipStream_t);
+int launch_edge_embed2(const tsd_model_cfg&, const float*, int, tsd_edges, float*, int, tsd_edges, float*, int,
+                       size_t, hipStream_t);
 int launch_layer_combo(const tsd_model_cfg&, const float*, int, int, tsd_edges, const float*, const float*, float*,
-                       float*, int, int, tsd_edges, const float*, float*, hipStream_t);
+                       float*, int, int, tsd_edges, const float*, float*, int, size_t, size_t, size_t, hipStream_t);
 int launch_node_embed(const tsd_model_cfg&, const float*, int, const int64_t*, const int64_t*, const int64_t*,
                       float*, hipStream_t);
 int launch_cfconv_aggregate(int, int, const int32_t*, const int32_t*, const int32_t*, const float*,
@@ -75,23 +75,32 @@ static int check_cfg(const tsd_model_cfg* c) {
 }
 
 struct Workspace {
-    float *ea;   // [P, H]: rows 0..P/2-1 enc_u edges, rows P/2.. separately embedded (diff_u) out edges
-    float *wf;   // [L, P/2, H]: CFConv filters of every layer on the undirected enc list
-    float *h, *x1, *x1b, *agg;
+    // every array holds one block per checkpoint (stride_* floats apart): the M forwards of an ensemble
+    // run in the SAME launches (grid.y = checkpoint), which removes the tile quantisation of batch-100
+    // launches (508 workgroups on 256 CUs) and the per-checkpoint launch boundaries
+    float *ea;   // [M][P, H]: rows 0..P/2-1 enc_u edges, rows P/2.. separately embedded (diff_u) out edges
+    float *wf;   // [M][L, P/2, H]: CFConv filters of every layer on the undirected enc list
+    float *h, *x1, *x1b;  // [M][N, H]
+    float *agg;  // [N, H] (piecewise path only)
+    size_t stride_ea, stride_wf, stride_nh;
     size_t total;
 };
 
-static Workspace carve(const tsd_model_cfg& c, int N, int P, float* base) {
+static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base) {
     Workspace w;
     const size_t H = c.hidden, PU = (size_t)P / 2;
     size_t o = 0;
-    auto take = [&](size_t n) { float* p = base ? base + o : nullptr; o += (n + 63) & ~size_t(63); return p; };
-    w.ea = take(2 * PU * H);
-    w.wf = take((size_t)c.num_convs * PU * H);
-    w.h = take((size_t)N * H);
-    w.x1 = take((size_t)N * H);
-    w.x1b = take((size_t)N * H);
-    w.agg = take((size_t)N * H);
+    auto take = [&](size_t n) { float* p = base ? base + o : nullptr; o += n; return p; };
+    auto pad = [](size_t n) { return (n + 63) & ~size_t(63); };
+    w.stride_ea = pad(2 * PU * H);
+    w.stride_wf = pad((size_t)c.num_convs * PU * H);
+    w.stride_nh = pad((size_t)N * H);
+    w.ea = take(w.stride_ea * M);
+    w.wf = take(w.stride_wf * M);
+    w.h = take(w.stride_nh * M);
+    w.x1 = take(w.stride_nh * M);
+    w.x1b = take(w.stride_nh * M);
+    w.agg = take(w.stride_nh);
     w.total = o;
     return w;
 }
@@ -154,30 +163,36 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     }
     if ((r = launch_geometry_lists(c, N, P, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, g, advance, st)))
         return r;
-    const Workspace w = carve(c, N, P, b.workspace);
+    const Workspace w = carve(c, N, P, M, b.workspace);
     const size_t wfloats = weight_layout(c).total;
     if (ov->fused) {
-        // one launch per interaction block: node chain of block l || filter GEMMs of block l+1
-        for (int m = 0; m < M; ++m) {
-            const float* W = b.weights + (size_t)m * wfloats;
-            if ((r = launch_edge_embed2(c, W, PU, g.enc_u, w.ea, PU, g.diff_u, w.ea + (size_t)PU * H, st))) return r;
-            TSD_HIP(hipMemcpyAsync(w.h, b.z + (size_t)m * N * H, (size_t)N * H * sizeof(float),
-                                   hipMemcpyDeviceToDevice, st));
-            float* xa = w.x1;
-            float* xb = w.x1b;
-            if ((r = launch_layer_combo(c, W, -1, N, g.enc, nullptr, nullptr, w.h, xa, 0, PU, g.enc_u, w.ea, w.wf, st)))
-                return r;
-            for (int l = 0; l < L; ++l) {
-                const int fl = (l + 1 < L) ? l + 1 : -1;
-                if ((r = launch_layer_combo(c, W, l, N, g.enc, w.wf + (size_t)l * PU * H, xa, w.h, xb, fl, PU, g.enc_u,
-                                            w.ea, w.wf + (size_t)(l + 1 < L ? l + 1 : 0) * PU * H, st)))
-                    return r;
-                float* t = xa; xa = xb; xb = t;
-            }
-            if ((r = launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u + (size_t)m * PU, st)))
-                return r;
+        // one launch per interaction block: node chain of block l || filter GEMMs of block l+1;
+        // all M checkpoints in the same launches (grid.y)
+        const float* W = b.weights;
+        if ((r = launch_edge_embed2(c, W, PU, g.enc_u, w.ea, PU, g.diff_u, w.ea + (size_t)PU * H, M, w.stride_ea, st)))
+            return r;
+        if (w.stride_nh == (size_t)N * H) {
+            TSD_HIP(hipMemcpyAsync(w.h, b.z, (size_t)M * N * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+        } else {
+            for (int m = 0; m < M; ++m)
+                TSD_HIP(hipMemcpyAsync(w.h + m * w.stride_nh, b.z + (size_t)m * N * H, (size_t)N * H * sizeof(float),
+                                       hipMemcpyDeviceToDevice, st));
         }
-        return TSD_OK;
+        float* xa = w.x1;
+        float* xb = w.x1b;
+        if ((r = launch_layer_combo(c, W, -1, N, g.enc, nullptr, nullptr, w.h, xa, 0, PU, g.enc_u, w.ea, w.wf, M,
+                                    w.stride_nh, w.stride_ea, w.stride_wf, st)))
+            return r;
+        for (int l = 0; l < L; ++l) {
+            const int fl = (l + 1 < L) ? l + 1 : -1;
+            if ((r = launch_layer_combo(c, W, l, N, g.enc, w.wf + (size_t)l * PU * H, xa, w.h, xb, fl, PU, g.enc_u, w.ea,
+                                        w.wf + (size_t)(l + 1 < L ? l + 1 : 0) * PU * H, M, w.stride_nh, w.stride_ea,
+                                        w.stride_wf, st)))
+                return r;
+            float* t = xa; xa = xb; xb = t;
+        }
+        return launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u, M, w.stride_nh, w.stride_ea,
+                                  (size_t)PU, st);
     }
     for (int m = 0; m < M; ++m) {
         const float* W = b.weights + (size_t)m * wfloats;
@@ -211,7 +226,8 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
             TSD_HIP(hipEventRecord(ov->diff, sb));
             TSD_HIP(hipStreamWaitEvent(st, ov->diff, 0));  // join: A is downstream of all of B's work
         }
-        if ((r = launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u + (size_t)m * PU, st)))
+        if ((r = launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u + (size_t)m * PU, 1, 0, 0,
+                                    0, st)))
             return r;
     }
     return TSD_OK;
@@ -338,7 +354,7 @@ int tsd_interaction_block(const tsd_model_cfg* cfg, const float* w, int32_t laye
                 "node role needs Wf_layer, x1_in != x1_out and the directed enc list");
     TSD_REQUIRE(filter_layer < 0 || (edge_attr && Wf_out && enc_u.count && enc_u.dist), "filter role: null pointer");
     return launch_layer_combo(*cfg, w, layer, num_nodes, enc, Wf_layer, x1_in, h, x1_out, filter_layer, capacity_u,
-                              enc_u, edge_attr, Wf_out, (hipStream_t)stream);
+                              enc_u, edge_attr, Wf_out, 1, 0, 0, 0, (hipStream_t)stream);
 }
 
 int tsd_cfconv_aggregate(int32_t hidden, int32_t num_nodes, const int32_t* row_ptr, const int32_t* dst,
@@ -361,7 +377,8 @@ int tsd_pair_output(const tsd_model_cfg* cfg, const float* w, int32_t capacity, 
                     const float* edge_attr, const int32_t* attr_row, float* edge_inv, void* stream) {
     int r = check_cfg(cfg);
     if (r) return r;
-    return launch_pair_output(*cfg, w, capacity, out, h, edge_attr, attr_row, edge_inv, (hipStream_t)stream);
+    return launch_pair_output(*cfg, w, capacity, out, h, edge_attr, attr_row, edge_inv, 1, 0, 0, 0,
+                              (hipStream_t)stream);
 }
 
 int tsd_eq_transform(int32_t num_nodes, int64_t num_edges, const float* score_d, const float* pos,
@@ -373,9 +390,8 @@ int tsd_eq_transform(int32_t num_nodes, int64_t num_edges, const float* score_d,
 
 size_t tsd_forward_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs,
                                     int32_t num_models) {
-    (void)num_models;  // checkpoints run back to back on one stream and share the activations
     if (check_cfg(cfg)) return 0;
-    return carve(*cfg, num_nodes, num_pairs, nullptr).total;
+    return carve(*cfg, num_nodes, num_pairs, num_models < 1 ? 1 : num_models, nullptr).total;
 }
 
 int tsd_score_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* pos, void* stream) {

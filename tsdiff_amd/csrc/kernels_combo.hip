@@ -234,9 +234,23 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int tile, floa
     }
 }
 
+struct ComboStride {  // per-checkpoint strides (blockIdx.y = checkpoint of the ensemble)
+    size_t w, nh, ea, wf;
+};
+
 template <int H>
-__global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int node_tiles, ComboFilter f) {
+__global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int node_tiles, ComboFilter f,
+                                                            ComboStride sd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    {
+        const size_t m = blockIdx.y;
+        const size_t wo = m * sd.w, no = m * sd.nh;
+        a.Wf += m * sd.wf; a.x1_in += no; a.h += no; a.x1_out += no;
+        a.lin2_w += wo; a.lin2_b += wo; a.lin_w += wo; a.lin_b += wo;
+        if (a.lin1_next_w) a.lin1_next_w += wo;
+        f.nn0_w += wo; f.nn0_b += wo; f.nn2_w += wo; f.nn2_b += wo;
+        f.edge_attr += m * sd.ea; f.out += m * sd.wf;
+    }
     if ((int)blockIdx.x < node_tiles)
         node_role<H>(a, blockIdx.x, smem);
     else
@@ -252,7 +266,8 @@ static inline size_t lds_combo(int H) {
 // layer < 0: node role = lin1 of block 0 only.  filter_layer < 0: no filter role.
 int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N, tsd_edges enc,
                        const float* Wf_layer, const float* x1_in, float* h, float* x1_out, int filter_layer,
-                       int capacity_u, tsd_edges enc_u, const float* edge_attr, float* Wf_out, hipStream_t st) {
+                       int capacity_u, tsd_edges enc_u, const float* edge_attr, float* Wf_out, int M, size_t nh_stride,
+                       size_t ea_stride, size_t wf_stride, hipStream_t st) {
     const WeightLayout L = weight_layout(c);
     ComboNode a{};
     a.N = N;
@@ -293,6 +308,7 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     const int grid = node_tiles + f.tiles;
     if (grid == 0) return TSD_OK;
     const size_t lds = lds_combo(c.hidden);
+    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride};
 #define TSD_COMBO(HH)                                                                                         \
     {                                                                                                         \
         static bool done = false;                                                                             \
@@ -300,7 +316,7 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
             TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_combo_kernel<HH>),                \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
         done = true;                                                                                          \
-        hipLaunchKernelGGL(layer_combo_kernel<HH>, dim3(grid), dim3(2 * HH), lds, st, a, node_tiles, f);      \
+        hipLaunchKernelGGL(layer_combo_kernel<HH>, dim3(grid, M), dim3(2 * HH), lds, st, a, node_tiles, f, sd); \
     }
     switch (c.hidden) {
         case 64: TSD_COMBO(64) break;

@@ -33,8 +33,15 @@ struct PairW {
 // the few output-graph edges that need their own embedding fill the chip together.
 template <int H>
 __global__ __launch_bounds__(H) void edge_embed_kernel(EdgeEmbedW w, tsd_edges ea_, float* __restrict__ out_a,
-                                                       int tiles_a, tsd_edges eb_, float* __restrict__ out_b) {
+                                                       int tiles_a, tsd_edges eb_, float* __restrict__ out_b,
+                                                       size_t wstride, size_t out_stride) {
     constexpr int LDA = 2 * H + 4;
+    {  // blockIdx.y = checkpoint of the ensemble: its weight arena and its output block
+        const size_t wo = (size_t)blockIdx.y * wstride, oo = (size_t)blockIdx.y * out_stride;
+        w.bond_emb += wo; w.w0 += wo; w.b0 += wo; w.w1 += wo; w.b1 += wo;
+        w.cw0 += wo; w.cb0 += wo; w.cw1 += wo; w.cb1 += wo;
+        out_a += oo; out_b += oo;
+    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* buf = smem;
     float* s_d = smem + T * LDA;
@@ -414,9 +421,15 @@ template <int H>
 __global__ __launch_bounds__(H) void pair_output_kernel(PairW w, tsd_edges e, const float* __restrict__ h,
                                                         const float* __restrict__ edge_attr,
                                                         const int32_t* __restrict__ attr_row,
-                                                        float* __restrict__ edge_inv) {
+                                                        float* __restrict__ edge_inv, size_t wstride,
+                                                        size_t h_stride, size_t ea_stride, size_t inv_stride) {
     constexpr int LDA = 2 * H + 4;
     constexpr int NW = H / 64;
+    {  // blockIdx.y = checkpoint of the ensemble
+        const size_t m = blockIdx.y, wo = m * wstride;
+        w.w0 += wo; w.b0 += wo; w.w1 += wo; w.b1 += wo; w.w2 += wo; w.b2 += wo;
+        h += m * h_stride; edge_attr += m * ea_stride; edge_inv += m * inv_stride;
+    }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* buf = smem;
     float* s_red = smem + T * LDA;  // [NW][T]
@@ -439,17 +452,20 @@ __global__ __launch_bounds__(H) void pair_output_kernel(PairW w, tsd_edges e, co
         s_row[tid] = v ? (attr_row ? attr_row[e0 + tid] : e0 + tid) : 0;
     }
     __syncthreads();
-    {
-        const int c = tid;
-#pragma unroll 4
-        for (int r = 0; r < T; ++r) {
-            float a = 0.0f, b = 0.0f;
+    {  // h_src * h_dst || edge_attr row -> LDS, float4 per lane, all loads of a lane independent
+        constexpr int C4 = H / 4;
+#pragma unroll 2
+        for (int idx = tid; idx < T * C4; idx += H) {
+            const int r = idx / C4, c4 = idx % C4;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
             if (r < nrows) {
-                a = h[(size_t)s_src[r] * H + c] * h[(size_t)s_dst[r] * H + c];
-                b = edge_attr[(size_t)s_row[r] * H + c];
+                const f32x4 hs = *reinterpret_cast<const f32x4*>(h + (size_t)s_src[r] * H + c4 * 4);
+                const f32x4 hd = *reinterpret_cast<const f32x4*>(h + (size_t)s_dst[r] * H + c4 * 4);
+                a = hs * hd;
+                b = *reinterpret_cast<const f32x4*>(edge_attr + (size_t)s_row[r] * H + c4 * 4);
             }
-            buf[r * LDA + c] = a;
-            buf[r * LDA + H + c] = b;
+            *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = a;
+            *reinterpret_cast<f32x4*>(buf + r * LDA + H + c4 * 4) = b;
         }
     }
     __syncthreads();
@@ -538,7 +554,7 @@ static int allow_lds_once(K kernel, size_t bytes, bool& done) {
     }
 
 int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_edges ea, float* out_a, int cap_b,
-                       tsd_edges eb, float* out_b, hipStream_t st) {
+                       tsd_edges eb, float* out_b, int M, size_t out_stride, hipStream_t st) {
     const WeightLayout L = weight_layout(c);
     EdgeEmbedW w{W + L.bond_emb, W + L.emlp_w0, W + L.emlp_b0, W + L.emlp_w1, W + L.emlp_b1,
                  W + L.ecat_w0, W + L.ecat_b0, W + L.ecat_w1, W + L.ecat_b1};
@@ -548,8 +564,8 @@ int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_ed
     TSD_DISPATCH_H(c.hidden, {
         static bool done = false; int r = allow_lds_once(edge_embed_kernel<HH>, lds, done);
         if (r) return r;
-        hipLaunchKernelGGL(edge_embed_kernel<HH>, dim3(tiles_a + tiles_b), dim3(HH), lds, st, w, ea, out_a, tiles_a,
-                           eb, out_b);
+        hipLaunchKernelGGL(edge_embed_kernel<HH>, dim3(tiles_a + tiles_b, M), dim3(HH), lds, st, w, ea, out_a, tiles_a,
+                           eb, out_b, L.total, out_stride);
     });
     TSD_LAUNCH_CHECK("edge_embed");
     return TSD_OK;
@@ -557,7 +573,7 @@ int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_ed
 
 int launch_edge_embed(const tsd_model_cfg& c, const float* W, int capacity, tsd_edges e, float* edge_attr,
                       hipStream_t st) {
-    return launch_edge_embed2(c, W, capacity, e, edge_attr, 0, e, edge_attr, st);
+    return launch_edge_embed2(c, W, capacity, e, edge_attr, 0, e, edge_attr, 1, 0, st);
 }
 
 int launch_cfconv_layer(const tsd_model_cfg& c, const float* W, int layer, int capacity, tsd_edges e,
@@ -637,7 +653,8 @@ int launch_node_lin1(const tsd_model_cfg& c, const float* W, int layer, int N, c
 }
 
 int launch_pair_output(const tsd_model_cfg& c, const float* W, int capacity, tsd_edges e, const float* h,
-                       const float* edge_attr, const int32_t* attr_row, float* edge_inv, hipStream_t st) {
+                       const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
+                       size_t ea_stride, size_t inv_stride, hipStream_t st) {
     const WeightLayout L = weight_layout(c);
     PairW w{W + L.out_w0, W + L.out_b0, W + L.out_w1, W + L.out_b1, W + L.out_w2, W + L.out_b2};
     const int tiles = (capacity + T - 1) / T;
@@ -646,7 +663,8 @@ int launch_pair_output(const tsd_model_cfg& c, const float* W, int capacity, tsd
     TSD_DISPATCH_H(c.hidden, {
         static bool done = false; int r = allow_lds_once(pair_output_kernel<HH>, lds, done);
         if (r) return r;
-        hipLaunchKernelGGL(pair_output_kernel<HH>, dim3(tiles), dim3(HH), lds, st, w, e, h, edge_attr, attr_row, edge_inv);
+        hipLaunchKernelGGL(pair_output_kernel<HH>, dim3(tiles, M), dim3(HH), lds, st, w, e, h, edge_attr, attr_row,
+                           edge_inv, L.total, h_stride, ea_stride, inv_stride);
     });
     TSD_LAUNCH_CHECK("pair_output");
     return TSD_OK;
