@@ -242,6 +242,47 @@ int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t ki
                     float* pos, float* traj, float* scratch /* [P + 3N + 128] */, int32_t* status /* [2] */,
                     int32_t use_graph, void* stream);
 
+/* ---- training primitives (BASELINE config 4; reference train.py:124-152, condensenc.py:267-328) -----
+ * First functional form of the training step: every dense layer's forward / dgrad / wgrad is a plain
+ * fp32 GEMM (rocBLAS); the graph-shaped operations and their adjoints are HIP kernels.  The Python host
+ * composes them as torch.autograd.Function nodes (tsdiff_amd/train_ops.py), so `loss.backward()`,
+ * `clip_grad_norm_` and Adam of the unmodified train.py keep working.  All matrices row-major fp32. */
+/* Y[rows,out] = X[rows,in] W[out,in]^T + b */
+int tsd_linear_fwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* b,
+                   float* Y, void* stream);
+/* dX = dY W (NULL: skip); dW = dY^T X (NULL: skip); db = column sums of dY (NULL: skip) */
+int tsd_linear_bwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* dY,
+                   float* dX, float* dW, float* db, void* stream);
+/* kind 0: swish (utils/activation_functions.py), 1: shifted softplus (schnet.py:65-71); x = pre-activation */
+int tsd_act_fwd(int32_t kind, int64_t n, const float* x, float* y, void* stream);
+int tsd_act_bwd(int32_t kind, int64_t n, const float* x, const float* dy, float* dx, void* stream);
+/* y[r,:] = x[r,:] * emb[idx[r],:] (edge.py:66-68); backward also accumulates demb (zeroed by the caller) */
+int tsd_emb_mul_fwd(int32_t rows, int32_t H, const float* x, const float* emb, const uint8_t* idx, float* y,
+                    void* stream);
+int tsd_emb_mul_bwd(int32_t rows, int32_t H, const float* x, const float* emb, const uint8_t* idx,
+                    const float* dy, float* dx, float* demb, void* stream);
+/* y[r,:] = table[idx[r],:] ; dtable[idx[r],:] += dy[r,:] (atom_embedding, condensenc.py:193) */
+int tsd_gather_rows(int32_t rows, int32_t H, const float* table, const int64_t* idx, float* y, void* stream);
+int tsd_scatter_rows_add(int32_t rows, int32_t H, const float* dy, const int64_t* idx, float* dtable,
+                         void* stream);
+/* x[r,:] *= (dist[r] <= cutoff): CFConv mask C, forward and backward (schnet.py:97-99) */
+int tsd_row_mask(int32_t rows, int32_t H, const float* dist, float cutoff, float* x, void* stream);
+/* adjoint of tsd_cfconv_aggregate w.r.t. the filter: dWf[u] = dagg[i]*x1[j] + dagg[j]*x1[i]
+ * (w.r.t. x1 it is tsd_cfconv_aggregate itself with dagg in place of x1) */
+int tsd_aggregate_bwd_filter(int32_t H, int32_t capacity_u, tsd_edges enc_u, const float* dagg, const float* x1,
+                             float* dWf, void* stream);
+/* p[u,:] = h[src u,:] * h[dst u,:] (common.py:226-229) and dh[i,:] = sum_{e in row i} dp[umap e,:] * h[dst e,:] */
+int tsd_pair_product_fwd(int32_t H, int32_t capacity_u, tsd_edges out_u, const float* h, float* p, void* stream);
+int tsd_pair_product_bwd(int32_t num_nodes, int32_t H, tsd_edges out, const float* dp, const float* h, float* dh,
+                         void* stream);
+/* eq_transform (geometry.py:22-30) of a per-undirected-pair score and its adjoint w.r.t. the score */
+int tsd_eq_und_fwd(int32_t num_nodes, tsd_edges out, const float* pos, const float* s_u, float* node_eq,
+                   void* stream);
+int tsd_eq_und_bwd(int32_t capacity_u, tsd_edges out_u, const float* pos, const float* g, float* ds_u,
+                   void* stream);
+/* d[u] = |pos[src u] - pos[dst u]| (get_distance on another geometry, condensenc.py:313) */
+int tsd_pair_distance(int32_t capacity_u, tsd_edges list_u, const float* pos, float* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

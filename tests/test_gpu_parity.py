@@ -261,12 +261,56 @@ def test_get_loss_vs_golden(name, dev):
     d, meta = load_golden(name)
     g = to_dev(batch_inputs(d), dev)
     model = make_model(meta["cfg"], meta["seed"], dev)
+    with torch.no_grad():  # validation path (train.py:160-171): fused inference kernels
+        loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
+                              g["batch"], g["num_nodes_per_graph"], g["num_graphs"],
+                              _time_step=torch.from_numpy(d["time_step"]).to(dev),
+                              _pos_noise=torch.from_numpy(d["pos_noise"]).to(dev))
+    assert loss.shape == d["loss"].shape and not loss.requires_grad
+    assert_close(loss.cpu().numpy(), d["loss"], 5e-5, "loss")
+
+
+@pytest.mark.parametrize("name", ["loss_synth_b4_small", "loss_rxn0_b2_full"])
+def test_training_loss_and_gradients_vs_golden(name, dev):
+    """the reference's loss.mean().backward() (train.py:140-143): loss values, the gradient norm of EVERY
+    parameter tensor and two full gradients against the unchanged reference"""
+    d, meta = load_golden(name)
+    g = to_dev(batch_inputs(d), dev)
+    model = make_model(meta["cfg"], meta["seed"], dev)
+    model.train()
+    model.zero_grad()
     loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
                           g["batch"], g["num_nodes_per_graph"], g["num_graphs"],
                           _time_step=torch.from_numpy(d["time_step"]).to(dev),
                           _pos_noise=torch.from_numpy(d["pos_noise"]).to(dev))
-    assert loss.shape == d["loss"].shape
-    assert_close(loss.cpu().numpy(), d["loss"], 5e-5, "loss")
+    assert loss.requires_grad
+    assert_close(loss.detach().cpu().numpy(), d["loss"], 5e-5, "loss (training path)")
+    loss.mean().backward()
+    worst = 0.0
+    for k, ref in meta["grad_norms"].items():
+        p = dict(model.named_parameters())[k]
+        assert p.grad is not None, k
+        got = float(p.grad.norm())
+        rel = abs(got - ref) / max(ref, 1e-12)
+        worst = max(worst, rel)
+        assert rel < 2e-4, f"grad norm of {k}: {got} vs {ref} (rel {rel:.2e})"
+    gl = model.encoder.interactions[0].conv.lin1.weight.grad.cpu().numpy()
+    assert_close(gl, d["grad_lin1_0"], 2e-4, "d loss / d lin1_0.weight")
+    gw = model.grad_dist_mlp.layers[2].weight.grad.cpu().numpy()
+    assert_close(gw, d["grad_out_w2"], 2e-4, "d loss / d grad_dist_mlp.2.weight")
+    # one Adam step as in train.py:103,144-145 works on these gradients
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.95, 0.999))
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 3000.0)
+    before = model.edge_cat[0].weight.detach().clone()
+    opt.step()
+    assert not torch.equal(before, model.edge_cat[0].weight.detach())
+    # and the packed inference weights follow the update (version counters)
+    with torch.no_grad():
+        l2 = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
+                            g["batch"], g["num_nodes_per_graph"], g["num_graphs"],
+                            _time_step=torch.from_numpy(d["time_step"]).to(dev),
+                            _pos_noise=torch.from_numpy(d["pos_noise"]).to(dev))
+    assert not l2.requires_grad and not torch.equal(l2, loss.detach())
 
 
 def test_nan_raises_floating_point_error(dev):

@@ -114,6 +114,21 @@ SIGNATURES = {
     "tsd_eq_transform_rows": (C.c_int, [C.c_int32, _P, _P, _P, _P, Edges, _P, _P, _P, _P]),
     "tsd_sampler_step": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_float, C.c_float, _P,
                                    _P, _P]),
+    "tsd_linear_fwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    "tsd_linear_bwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "tsd_act_fwd": (C.c_int, [C.c_int32, C.c_int64, _P, _P, _P]),
+    "tsd_act_bwd": (C.c_int, [C.c_int32, C.c_int64, _P, _P, _P, _P]),
+    "tsd_emb_mul_fwd": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    "tsd_emb_mul_bwd": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "tsd_gather_rows": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "tsd_scatter_rows_add": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "tsd_row_mask": (C.c_int, [C.c_int32, C.c_int32, _P, C.c_float, _P, _P]),
+    "tsd_aggregate_bwd_filter": (C.c_int, [C.c_int32, C.c_int32, Edges, _P, _P, _P, _P]),
+    "tsd_pair_product_fwd": (C.c_int, [C.c_int32, C.c_int32, Edges, _P, _P, _P]),
+    "tsd_pair_product_bwd": (C.c_int, [C.c_int32, C.c_int32, Edges, _P, _P, _P, _P]),
+    "tsd_eq_und_fwd": (C.c_int, [C.c_int32, Edges, _P, _P, _P, _P]),
+    "tsd_eq_und_bwd": (C.c_int, [C.c_int32, Edges, _P, _P, _P, _P]),
+    "tsd_pair_distance": (C.c_int, [C.c_int32, Edges, _P, _P, _P]),
     "tsd_sampler_run": (C.c_int, [_CFG, C.POINTER(Batch), C.c_int32, C.c_int32, _P, _P, C.c_float, C.c_float,
                                   _P, _P, _P, _P, C.c_int32, _P]),
 }

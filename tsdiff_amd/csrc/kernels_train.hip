@@ -1,0 +1,348 @@
+// kernels_train.hip -- primitives of the training step (BASELINE config 4; reference train.py:124-152,
+// models/epsnet/condensenc.py:267-328).  First functional form: the dense layers' forward / dgrad / wgrad
+// are PLAIN GEMMs and go to rocBLAS (fp32); everything graph-shaped (segmented aggregation and its two
+// adjoints, pair products, embedding gathers / scatters, distance -> Cartesian chain rule, activations)
+// is hand-written here.  The Python host (tsdiff_amd/train_ops.py) strings them together as
+// torch.autograd.Function nodes so that the reference's unmodified `loss.backward()`, `clip_grad_norm_`
+// and Adam keep working; fusing this path like the sampling path is next round's work.
+//
+// All per-edge work runs on the UNDIRECTED lists (see tsd_geometry): a filter row Wf[u] / score s[u] is
+// used by both directed edges (i,j) and (j,i), so its gradient is the sum of both directions.
+#include <rocblas/rocblas.h>
+
+#include "common.hpp"
+
+namespace tsd {
+
+static rocblas_handle g_blas[16] = {};
+
+static int blas_handle(hipStream_t st, rocblas_handle* out) {
+    int dev = 0;
+    TSD_HIP(hipGetDevice(&dev));
+    rocblas_handle& h = g_blas[dev & 15];
+    if (!h) {
+        if (rocblas_create_handle(&h) != rocblas_status_success) {
+            set_error("rocblas_create_handle failed");
+            return TSD_ERR_HIP;
+        }
+    }
+    if (rocblas_set_stream(h, st) != rocblas_status_success) {
+        set_error("rocblas_set_stream failed");
+        return TSD_ERR_HIP;
+    }
+    *out = h;
+    return TSD_OK;
+}
+
+// row-major C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C, computed as the column-major product
+// C^T = op(B)^T op(A)^T
+int gemm_rm(bool transA, bool transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
+            int ldb, float beta, float* C, int ldc, hipStream_t st) {
+    if (M == 0 || N == 0) return TSD_OK;
+    rocblas_handle h;
+    int r = blas_handle(st, &h);
+    if (r) return r;
+    const rocblas_status s =
+        rocblas_sgemm(h, transB ? rocblas_operation_transpose : rocblas_operation_none,
+                      transA ? rocblas_operation_transpose : rocblas_operation_none, N, M, K, &alpha, B, ldb, A, lda,
+                      &beta, C, ldc);
+    if (s != rocblas_status_success) {
+        set_error("rocblas_sgemm failed (%d)", (int)s);
+        return TSD_ERR_HIP;
+    }
+    return TSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void bias_add_kernel(int64_t n, int cols, const float* __restrict__ b, float* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += b[i % cols];
+}
+
+// column sums of dY [rows, cols] (bias gradient): one workgroup per 64 columns, deterministic tree
+__global__ __launch_bounds__(256) void colsum_kernel(int rows, int cols, const float* __restrict__ dy,
+                                                     float* __restrict__ db) {
+    __shared__ float sm[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int w = threadIdx.x >> 6;
+    float s = 0.0f;
+    if (c < cols)
+        for (int r = w; r < rows; r += 4) s += dy[(size_t)r * cols + c];
+    sm[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < cols) db[c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+
+// activations: kind 0 swish (reference utils/activation_functions.py), 1 shifted softplus (schnet.py:65-71)
+__global__ void act_fwd_kernel(int kind, int64_t n, const float* __restrict__ x, float* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    y[i] = kind == 0 ? swishf(v) : sspf(v);
+}
+__global__ void act_bwd_kernel(int kind, int64_t n, const float* __restrict__ x, const float* __restrict__ dy,
+                               float* __restrict__ dx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    const float sg = __builtin_amdgcn_rcpf(1.0f + fast_exp(-v));  // sigmoid(v)
+    // d swish = sg * (1 + v * (1 - sg)) ; d ssp = d softplus = sg
+    const float d = kind == 0 ? sg * (1.0f + v * (1.0f - sg)) : sg;
+    dx[i] = dy[i] * d;
+}
+
+// y[r,:] = x[r,:] * emb[idx[r],:]   (edge.py:66-68 d_emb * bond_emb(type))
+__global__ void emb_mul_fwd_kernel(int rows, int H, const float* __restrict__ x, const float* __restrict__ emb,
+                                   const uint8_t* __restrict__ idx, float* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * H) return;
+    const int r = (int)(i / H), c = (int)(i % H);
+    y[i] = x[i] * emb[(size_t)idx[r] * H + c];
+}
+// dx = dy * emb[idx];  demb[idx] += dy * x  (atomics: <= 100 rows of H channels)
+__global__ void emb_mul_bwd_kernel(int rows, int H, const float* __restrict__ x, const float* __restrict__ emb,
+                                   const uint8_t* __restrict__ idx, const float* __restrict__ dy,
+                                   float* __restrict__ dx, float* __restrict__ demb) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * H) return;
+    const int r = (int)(i / H), c = (int)(i % H);
+    const size_t e = (size_t)idx[r] * H + c;
+    const float g = dy[i];
+    dx[i] = g * emb[e];
+    atomicAdd(demb + e, g * x[i]);
+}
+
+// y[r,:] = table[idx[r],:]  /  dtable[idx[r],:] += dy[r,:]   (atom_embedding, condensenc.py:193)
+__global__ void gather_rows_kernel(int rows, int H, const float* __restrict__ table, const int64_t* __restrict__ idx,
+                                   float* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * H) return;
+    y[i] = table[(size_t)idx[i / H] * H + (i % H)];
+}
+__global__ void scatter_rows_add_kernel(int rows, int H, const float* __restrict__ dy, const int64_t* __restrict__ idx,
+                                        float* __restrict__ dtable) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * H) return;
+    atomicAdd(dtable + (size_t)idx[i / H] * H + (i % H), dy[i]);
+}
+
+// x[r,:] *= (dist[r] <= cutoff)    CFConv mask C, forward and backward (schnet.py:97-99)
+__global__ void row_mask_kernel(int rows, int H, const float* __restrict__ dist, float cutoff, float* __restrict__ x) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * H) return;
+    if (!(dist[i / H] <= cutoff)) x[i] = 0.0f;
+}
+
+// adjoint of the aggregation w.r.t. the filter: dWf[u] = dagg[i] * x1[j] + dagg[j] * x1[i], u = {i<j}
+__global__ void aggregate_bwd_filter_kernel(int H, tsd_edges eu, const float* __restrict__ dagg,
+                                            const float* __restrict__ x1, float* __restrict__ dWf) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Eu = *eu.count;
+    if (t >= (int64_t)Eu * H) return;
+    const int u = (int)(t / H), c = (int)(t % H);
+    const int i = eu.src[u], j = eu.dst[u];
+    dWf[t] = dagg[(size_t)i * H + c] * x1[(size_t)j * H + c] + dagg[(size_t)j * H + c] * x1[(size_t)i * H + c];
+}
+
+// p[u,:] = h[i,:] * h[j,:] for the undirected out edges (common.py:226-229 first half of h_pair)
+__global__ void pair_product_fwd_kernel(int H, tsd_edges eu, const float* __restrict__ h, float* __restrict__ p) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Eu = *eu.count;
+    if (t >= (int64_t)Eu * H) return;
+    const int u = (int)(t / H), c = (int)(t % H);
+    p[t] = h[(size_t)eu.src[u] * H + c] * h[(size_t)eu.dst[u] * H + c];
+}
+// dh[i,:] = sum_{e in row i} dp[umap e,:] * h[dst e,:]   (deterministic row gather over the directed CSR)
+__global__ void pair_product_bwd_kernel(int N, int H, tsd_edges ed, const float* __restrict__ dp,
+                                        const float* __restrict__ h, float* __restrict__ dh) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)N * H) return;
+    const int i = (int)(t / H), c = (int)(t % H);
+    float s = 0.0f;
+    const int e1 = ed.row_ptr[i + 1];
+    for (int e = ed.row_ptr[i]; e < e1; ++e) s += dp[(size_t)ed.umap[e] * H + c] * h[(size_t)ed.dst[e] * H + c];
+    dh[t] = s;
+}
+
+// node_eq[i] = 2 * sum_{e in row i} ((pos_i - pos_j)/d_e) * s[umap e]     (geometry.py:22-30 on a symmetric s)
+__global__ void eq_und_fwd_kernel(int N, tsd_edges ed, const float* __restrict__ pos, const float* __restrict__ s,
+                                  float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    const float px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
+    const int e1 = ed.row_ptr[i + 1];
+    for (int e = ed.row_ptr[i]; e < e1; ++e) {
+        const int j = ed.dst[e];
+        const float w = s[ed.umap[e]] / ed.dist[e];
+        ax += (px - pos[3 * j]) * w;
+        ay += (py - pos[3 * j + 1]) * w;
+        az += (pz - pos[3 * j + 2]) * w;
+    }
+    out[3 * i] = ax + ax;
+    out[3 * i + 1] = ay + ay;
+    out[3 * i + 2] = az + az;
+}
+// ds[u] = 2 * ((pos_i - pos_j)/d_u) . (g_i - g_j)
+__global__ void eq_und_bwd_kernel(tsd_edges eu, const float* __restrict__ pos, const float* __restrict__ g,
+                                  float* __restrict__ ds) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= *eu.count) return;
+    const int i = eu.src[u], j = eu.dst[u];
+    const float inv = 2.0f / eu.dist[u];
+    ds[u] = inv * ((pos[3 * i] - pos[3 * j]) * (g[3 * i] - g[3 * j]) +
+                   (pos[3 * i + 1] - pos[3 * j + 1]) * (g[3 * i + 1] - g[3 * j + 1]) +
+                   (pos[3 * i + 2] - pos[3 * j + 2]) * (g[3 * i + 2] - g[3 * j + 2]));
+}
+
+// d_gt[u] = |pos0_i - pos0_j|   (get_distance on the clean geometry, condensenc.py:313)
+__global__ void pair_distance_kernel(tsd_edges eu, const float* __restrict__ pos, float* __restrict__ d) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= *eu.count) return;
+    const int i = eu.src[u], j = eu.dst[u];
+    const float dx = pos[3 * i] - pos[3 * j], dy = pos[3 * i + 1] - pos[3 * j + 1], dz = pos[3 * i + 2] - pos[3 * j + 2];
+    d[u] = sqrtf(dx * dx + dy * dy + dz * dz);
+}
+
+static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace tsd
+
+using namespace tsd;
+
+extern "C" {
+
+int tsd_linear_fwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* b, float* Y,
+                   void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int r = gemm_rm(false, true, rows, out, in, 1.0f, X, in, W, in, 0.0f, Y, out, st);  // Y = X W^T
+    if (r) return r;
+    if (b && rows > 0) {
+        const int64_t n = (int64_t)rows * out;
+        hipLaunchKernelGGL(bias_add_kernel, dim3(blocks_for(n)), dim3(256), 0, st, n, out, b, Y);
+        TSD_LAUNCH_CHECK("bias_add");
+    }
+    return TSD_OK;
+}
+
+int tsd_linear_bwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* dY, float* dX,
+                   float* dW, float* db, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int r;
+    if (dX && (r = gemm_rm(false, false, rows, in, out, 1.0f, dY, out, W, in, 0.0f, dX, in, st))) return r;  // dY W
+    if (dW) {
+        if (rows == 0) {
+            TSD_HIP(hipMemsetAsync(dW, 0, (size_t)out * in * sizeof(float), st));
+        } else if ((r = gemm_rm(true, false, out, in, rows, 1.0f, dY, out, X, in, 0.0f, dW, in, st))) {  // dY^T X
+            return r;
+        }
+    }
+    if (db) {
+        hipLaunchKernelGGL(colsum_kernel, dim3((out + 63) / 64), dim3(256), 0, st, rows, out, dY, db);
+        TSD_LAUNCH_CHECK("colsum");
+    }
+    return TSD_OK;
+}
+
+int tsd_act_fwd(int32_t kind, int64_t n, const float* x, float* y, void* stream) {
+    if (n == 0) return TSD_OK;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, kind, n, x, y);
+    TSD_LAUNCH_CHECK("act_fwd");
+    return TSD_OK;
+}
+int tsd_act_bwd(int32_t kind, int64_t n, const float* x, const float* dy, float* dx, void* stream) {
+    if (n == 0) return TSD_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, kind, n, x, dy, dx);
+    TSD_LAUNCH_CHECK("act_bwd");
+    return TSD_OK;
+}
+
+int tsd_emb_mul_fwd(int32_t rows, int32_t H, const float* x, const float* emb, const uint8_t* idx, float* y,
+                    void* stream) {
+    if (rows == 0) return TSD_OK;
+    hipLaunchKernelGGL(emb_mul_fwd_kernel, dim3(blocks_for((int64_t)rows * H)), dim3(256), 0, (hipStream_t)stream,
+                       rows, H, x, emb, idx, y);
+    TSD_LAUNCH_CHECK("emb_mul_fwd");
+    return TSD_OK;
+}
+int tsd_emb_mul_bwd(int32_t rows, int32_t H, const float* x, const float* emb, const uint8_t* idx, const float* dy,
+                    float* dx, float* demb, void* stream) {
+    if (rows == 0) return TSD_OK;
+    hipLaunchKernelGGL(emb_mul_bwd_kernel, dim3(blocks_for((int64_t)rows * H)), dim3(256), 0, (hipStream_t)stream,
+                       rows, H, x, emb, idx, dy, dx, demb);
+    TSD_LAUNCH_CHECK("emb_mul_bwd");
+    return TSD_OK;
+}
+
+int tsd_gather_rows(int32_t rows, int32_t H, const float* table, const int64_t* idx, float* y, void* stream) {
+    if (rows == 0) return TSD_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks_for((int64_t)rows * H)), dim3(256), 0, (hipStream_t)stream,
+                       rows, H, table, idx, y);
+    TSD_LAUNCH_CHECK("gather_rows");
+    return TSD_OK;
+}
+int tsd_scatter_rows_add(int32_t rows, int32_t H, const float* dy, const int64_t* idx, float* dtable, void* stream) {
+    if (rows == 0) return TSD_OK;
+    hipLaunchKernelGGL(scatter_rows_add_kernel, dim3(blocks_for((int64_t)rows * H)), dim3(256), 0,
+                       (hipStream_t)stream, rows, H, dy, idx, dtable);
+    TSD_LAUNCH_CHECK("scatter_rows_add");
+    return TSD_OK;
+}
+
+int tsd_row_mask(int32_t rows, int32_t H, const float* dist, float cutoff, float* x, void* stream) {
+    if (rows == 0) return TSD_OK;
+    hipLaunchKernelGGL(row_mask_kernel, dim3(blocks_for((int64_t)rows * H)), dim3(256), 0, (hipStream_t)stream, rows,
+                       H, dist, cutoff, x);
+    TSD_LAUNCH_CHECK("row_mask");
+    return TSD_OK;
+}
+
+int tsd_aggregate_bwd_filter(int32_t H, int32_t capacity_u, tsd_edges enc_u, const float* dagg, const float* x1,
+                             float* dWf, void* stream) {
+    if (capacity_u == 0) return TSD_OK;
+    hipLaunchKernelGGL(aggregate_bwd_filter_kernel, dim3(blocks_for((int64_t)capacity_u * H)), dim3(256), 0,
+                       (hipStream_t)stream, H, enc_u, dagg, x1, dWf);
+    TSD_LAUNCH_CHECK("aggregate_bwd_filter");
+    return TSD_OK;
+}
+
+int tsd_pair_product_fwd(int32_t H, int32_t capacity_u, tsd_edges out_u, const float* h, float* p, void* stream) {
+    if (capacity_u == 0) return TSD_OK;
+    hipLaunchKernelGGL(pair_product_fwd_kernel, dim3(blocks_for((int64_t)capacity_u * H)), dim3(256), 0,
+                       (hipStream_t)stream, H, out_u, h, p);
+    TSD_LAUNCH_CHECK("pair_product_fwd");
+    return TSD_OK;
+}
+int tsd_pair_product_bwd(int32_t num_nodes, int32_t H, tsd_edges out, const float* dp, const float* h, float* dh,
+                         void* stream) {
+    if (num_nodes == 0) return TSD_OK;
+    hipLaunchKernelGGL(pair_product_bwd_kernel, dim3(blocks_for((int64_t)num_nodes * H)), dim3(256), 0,
+                       (hipStream_t)stream, num_nodes, H, out, dp, h, dh);
+    TSD_LAUNCH_CHECK("pair_product_bwd");
+    return TSD_OK;
+}
+
+int tsd_eq_und_fwd(int32_t num_nodes, tsd_edges out, const float* pos, const float* s_u, float* node_eq,
+                   void* stream) {
+    if (num_nodes == 0) return TSD_OK;
+    hipLaunchKernelGGL(eq_und_fwd_kernel, dim3((num_nodes + 127) / 128), dim3(128), 0, (hipStream_t)stream, num_nodes,
+                       out, pos, s_u, node_eq);
+    TSD_LAUNCH_CHECK("eq_und_fwd");
+    return TSD_OK;
+}
+int tsd_eq_und_bwd(int32_t capacity_u, tsd_edges out_u, const float* pos, const float* g, float* ds_u, void* stream) {
+    if (capacity_u == 0) return TSD_OK;
+    hipLaunchKernelGGL(eq_und_bwd_kernel, dim3((capacity_u + 255) / 256), dim3(256), 0, (hipStream_t)stream, out_u,
+                       pos, g, ds_u);
+    TSD_LAUNCH_CHECK("eq_und_bwd");
+    return TSD_OK;
+}
+int tsd_pair_distance(int32_t capacity_u, tsd_edges list_u, const float* pos, float* d, void* stream) {
+    if (capacity_u == 0) return TSD_OK;
+    hipLaunchKernelGGL(pair_distance_kernel, dim3((capacity_u + 255) / 256), dim3(256), 0, (hipStream_t)stream, list_u,
+                       pos, d);
+    TSD_LAUNCH_CHECK("pair_distance");
+    return TSD_OK;
+}
+
+}  // extern "C"

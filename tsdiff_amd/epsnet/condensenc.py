@@ -161,8 +161,9 @@ class CondenseEncoderEpsNetwork(nn.Module):
     def get_loss(self, atom_type, r_feat, p_feat, pos, bond_index, bond_type, batch, num_nodes_per_graph,
                  num_graphs, anneal_power=2.0, extend_order=True, extend_radius=True,
                  _time_step=None, _pos_noise=None):
-        """reference condensenc.py:267-328.  Forward value only in this round: the backward kernels
-        are the first 'next' row of SURVEY.md 8(f); the returned tensor carries no grad_fn.
+        """reference condensenc.py:267-328.  With autograd enabled (training, train.py:128-145) the loss
+        is differentiable w.r.t. the parameters through the training primitives of tsdiff_amd/train_ops.py;
+        under torch.no_grad() (validation, train.py:160-171) the fused inference kernels are used.
         `_time_step` / `_pos_noise` inject the random draws (parity tests)."""
         node2graph = batch
         dev = pos.device
@@ -175,20 +176,32 @@ class CondenseEncoderEpsNetwork(nn.Module):
             time_step = torch.cat([half_1, half_2], dim=0)[:num_graphs]
         else:
             time_step = _time_step
-        a = self.alphas.index_select(0, time_step)
+        a = self.alphas.detach().index_select(0, time_step)
         a_pos = a.index_select(0, node2graph).unsqueeze(-1)
         pos_noise = torch.randn(size=pos.size(), device=dev) if _pos_noise is None else _pos_noise
-        pos_perturbed = pos + pos_noise * (1.0 - a_pos).sqrt() / a_pos.sqrt()
+        pos_perturbed = (pos + pos_noise * (1.0 - a_pos).sqrt() / a_pos.sqrt()).contiguous()
+        db = self.device_batch(atom_type, r_feat, p_feat, bond_index, bond_type, batch)
+
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if training:
+            from .. import train_ops as T
+            s_u, Eo = T.train_forward(self, db, pos_perturbed)
+            node_eq = T.EqUndirected.apply(s_u, pos_perturbed, db)
+            src_u = db.out_u.src[:Eo].long()
+            a_edge = a.index_select(0, node2graph.index_select(0, src_u))
+            d_gt = T.pair_distance(db, "out_u", pos, Eo)
+            d_target = (d_gt - db.out_u.dist[:Eo]) / (1.0 - a_edge).sqrt() * a_edge.sqrt()
+            pos_target = T.EqUndirected.apply(d_target, pos_perturbed, db)
+            loss = (node_eq - pos_target) ** 2
+            return torch.sum(loss, dim=-1, keepdim=True)
 
         edge_inv, edge_index, edge_length = self(atom_type, r_feat, p_feat, pos_perturbed, bond_index,
                                                  bond_type, batch, time_step, return_edges=True)
-        db = self.device_batch(atom_type, r_feat, p_feat, bond_index, bond_type, batch)
-        node_eq = db.eq_transform_rows(pos_perturbed.contiguous(), edge_inv.contiguous().view(-1))
-
+        node_eq = db.eq_transform_rows(pos_perturbed, edge_inv.contiguous().view(-1))
         edge2graph = node2graph.index_select(0, edge_index[0])
         a_edge = a.index_select(0, edge2graph).unsqueeze(-1)
         d_gt = (pos[edge_index[0]] - pos[edge_index[1]]).norm(dim=-1).unsqueeze(-1)
         d_target = (d_gt - edge_length) / (1.0 - a_edge).sqrt() * a_edge.sqrt()
-        pos_target = db.eq_transform_rows(pos_perturbed.contiguous(), d_target.contiguous().view(-1))
+        pos_target = db.eq_transform_rows(pos_perturbed, d_target.contiguous().view(-1))
         loss = (node_eq - pos_target) ** 2
         return torch.sum(loss, dim=-1, keepdim=True)

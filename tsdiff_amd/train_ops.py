@@ -1,0 +1,288 @@
+"""Differentiable building blocks of the training step (reference train.py:124-152,
+models/epsnet/condensenc.py:267-328) as torch.autograd.Function nodes over the C-ABI training
+primitives of include/tsdiff_hip.h.
+
+torch's autograd engine only SEQUENCES the backward (so the reference's unmodified
+`loss.mean().backward()`, `clip_grad_norm_` and `torch.optim.Adam` keep working); every forward and
+backward computation below runs in libtsdiff_hip.so: the dense layers as rocBLAS fp32 GEMMs, the
+graph-shaped operations (segmented aggregation and both adjoints, pair products, embedding
+gather/scatter, the distance -> Cartesian chain rule, activations) as HIP kernels.  This is the
+first functional form of row A16 / SURVEY 8(f)-1; fusing it like the sampling path is next.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class Linear(torch.autograd.Function):
+    """y = x W^T + b   (torch.nn.Linear semantics; W [out,in])"""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        lib = _lib.load()
+        x, W = _c(x), _c(W)
+        rows, fin = x.shape
+        out = W.shape[0]
+        y = torch.empty(rows, out, dtype=torch.float32, device=x.device)
+        check(lib.tsd_linear_fwd(rows, fin, out, ptr(x), ptr(W), ptr(b), ptr(y), stream_ptr()))
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, W = ctx.saved_tensors
+        dy = _c(dy)
+        rows, fin = x.shape
+        out = W.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W) if ctx.needs_input_grad[1] else None
+        db = torch.empty(out, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        check(lib.tsd_linear_bwd(rows, fin, out, ptr(x), ptr(W), ptr(dy), ptr(dx), ptr(dW), ptr(db), stream_ptr()))
+        return dx, dW, db
+
+
+class Act(torch.autograd.Function):
+    """kind 0: swish, 1: shifted softplus"""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        lib = _lib.load()
+        x = _c(x)
+        y = torch.empty_like(x)
+        check(lib.tsd_act_fwd(kind, x.numel(), ptr(x), ptr(y), stream_ptr()))
+        ctx.save_for_backward(x)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        check(lib.tsd_act_bwd(ctx.kind, x.numel(), ptr(x), ptr(dy), ptr(dx), stream_ptr()))
+        return dx, None
+
+
+class EmbMul(torch.autograd.Function):
+    """y = x * emb[idx]   (idx uint8 edge types)"""
+
+    @staticmethod
+    def forward(ctx, x, emb, idx):
+        lib = _lib.load()
+        x, emb = _c(x), _c(emb)
+        rows, H = x.shape
+        y = torch.empty_like(x)
+        check(lib.tsd_emb_mul_fwd(rows, H, ptr(x), ptr(emb), ptr(idx), ptr(y), stream_ptr()))
+        ctx.save_for_backward(x, emb, idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, emb, idx = ctx.saved_tensors
+        dy = _c(dy)
+        rows, H = x.shape
+        dx = torch.empty_like(x)
+        demb = torch.zeros_like(emb)
+        check(lib.tsd_emb_mul_bwd(rows, H, ptr(x), ptr(emb), ptr(idx), ptr(dy), ptr(dx), ptr(demb), stream_ptr()))
+        return dx, demb, None
+
+
+class GatherRows(torch.autograd.Function):
+    """y = table[idx]   (idx int64)"""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        lib = _lib.load()
+        table = _c(table)
+        rows, H = idx.shape[0], table.shape[1]
+        y = torch.empty(rows, H, dtype=torch.float32, device=table.device)
+        check(lib.tsd_gather_rows(rows, H, ptr(table), ptr(idx), ptr(y), stream_ptr()))
+        ctx.save_for_backward(idx)
+        ctx.shape = table.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (idx,) = ctx.saved_tensors
+        dy = _c(dy)
+        dt = torch.zeros(ctx.shape, dtype=torch.float32, device=dy.device)
+        check(lib.tsd_scatter_rows_add(idx.shape[0], ctx.shape[1], ptr(dy), ptr(idx), ptr(dt), stream_ptr()))
+        return dt, None
+
+
+class RowMask(torch.autograd.Function):
+    """y = x * (dist <= cutoff)[:, None]   (CFConv C)"""
+
+    @staticmethod
+    def forward(ctx, x, dist, cutoff):
+        lib = _lib.load()
+        y = x.clone(memory_format=torch.contiguous_format)
+        check(lib.tsd_row_mask(y.shape[0], y.shape[1], ptr(dist), float(cutoff), ptr(y), stream_ptr()))
+        ctx.save_for_backward(dist)
+        ctx.cutoff = float(cutoff)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        (dist,) = ctx.saved_tensors
+        dx = dy.clone(memory_format=torch.contiguous_format)
+        check(lib.tsd_row_mask(dx.shape[0], dx.shape[1], ptr(dist), ctx.cutoff, ptr(dx), stream_ptr()))
+        return dx, None, None
+
+
+class Aggregate(torch.autograd.Function):
+    """agg[i] = sum_{e in row i} x1[dst e] * Wf[umap e]   (schnet.py:102-107)"""
+
+    @staticmethod
+    def forward(ctx, x1, Wf, db):
+        lib = _lib.load()
+        x1, Wf = _c(x1), _c(Wf)
+        N, H = x1.shape
+        out = torch.empty_like(x1)
+        check(lib.tsd_cfconv_aggregate(H, N, ptr(db.enc.row_ptr), ptr(db.enc.dst), ptr(db.enc.umap), ptr(Wf),
+                                       ptr(x1), ptr(out), stream_ptr()))
+        ctx.save_for_backward(x1, Wf)
+        ctx.db = db
+        return out
+
+    @staticmethod
+    def backward(ctx, dagg):
+        lib = _lib.load()
+        x1, Wf = ctx.saved_tensors
+        db = ctx.db
+        dagg = _c(dagg)
+        N, H = x1.shape
+        # the edge set and Wf are symmetric: the adjoint w.r.t. x1 is the same row-wise aggregation of dagg
+        dx1 = torch.empty_like(x1)
+        check(lib.tsd_cfconv_aggregate(H, N, ptr(db.enc.row_ptr), ptr(db.enc.dst), ptr(db.enc.umap), ptr(Wf),
+                                       ptr(dagg), ptr(dx1), stream_ptr()))
+        dWf = torch.empty_like(Wf)
+        check(lib.tsd_aggregate_bwd_filter(H, Wf.shape[0], db.enc_u.struct(), ptr(dagg), ptr(x1), ptr(dWf),
+                                           stream_ptr()))
+        return dx1, dWf, None
+
+
+class PairProduct(torch.autograd.Function):
+    """p[u] = h[i] * h[j] over the undirected out edges"""
+
+    @staticmethod
+    def forward(ctx, h, db, Eo):
+        lib = _lib.load()
+        h = _c(h)
+        H = h.shape[1]
+        p = torch.empty(Eo, H, dtype=torch.float32, device=h.device)
+        check(lib.tsd_pair_product_fwd(H, Eo, db.out_u.struct(), ptr(h), ptr(p), stream_ptr()))
+        ctx.save_for_backward(h)
+        ctx.db = db
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        lib = _lib.load()
+        (h,) = ctx.saved_tensors
+        dp = _c(dp)
+        dh = torch.empty_like(h)
+        check(lib.tsd_pair_product_bwd(h.shape[0], h.shape[1], ctx.db.out.struct(), ptr(dp), ptr(h), ptr(dh),
+                                       stream_ptr()))
+        return dh, None, None
+
+
+class EqUndirected(torch.autograd.Function):
+    """eq_transform (geometry.py:22-30) of a per-undirected-pair score; differentiable w.r.t. the score"""
+
+    @staticmethod
+    def forward(ctx, s_u, pos, db):
+        lib = _lib.load()
+        s_u, pos = _c(s_u), _c(pos)
+        out = torch.empty(pos.shape[0], 3, dtype=torch.float32, device=pos.device)
+        check(lib.tsd_eq_und_fwd(pos.shape[0], db.out.struct(), ptr(pos), ptr(s_u), ptr(out), stream_ptr()))
+        ctx.save_for_backward(pos)
+        ctx.db = db
+        ctx.n = s_u.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (pos,) = ctx.saved_tensors
+        g = _c(g)
+        ds = torch.empty(ctx.n, dtype=torch.float32, device=g.device)
+        check(lib.tsd_eq_und_bwd(ctx.n, ctx.db.out_u.struct(), ptr(pos), ptr(g), ptr(ds), stream_ptr()))
+        return ds, None, None
+
+
+def pair_distance(db, which, pos, E):
+    lib = _lib.load()
+    lst = db.out_u if which == "out_u" else db.enc_u
+    d = torch.empty(E, dtype=torch.float32, device=pos.device)
+    check(lib.tsd_pair_distance(E, lst.struct(), ptr(_c(pos)), ptr(d), stream_ptr()))
+    return d
+
+
+def linear(x, W, b=None):
+    return Linear.apply(x, W, b)
+
+
+def swish(x):
+    return Act.apply(x, 0)
+
+
+def ssp(x):
+    return Act.apply(x, 1)
+
+
+def train_forward(model, db, pos):
+    """The reference forward_ (condensenc.py:178-239) on the current geometry, differentiable w.r.t. the
+    parameters.  Returns (s_u [Eo] edge_inv per undirected out edge, Eo)."""
+    P = dict(model.named_parameters())
+    cfg = model._cfg
+    L = cfg.num_convs
+    db.geometry(pos)
+    Eu, Eo = db.enc_u.num_edges(), db.out_u.num_edges()  # host syncs (training is not latency critical)
+
+    a = GatherRows.apply(P["atom_embedding.weight"], db.atom_type)
+    wf = P["atom_feat_embedding.weight"]
+    fr = linear(db.r_feat.to(torch.float32), wf)
+    fp = linear(db.p_feat.to(torch.float32), wf)
+    h = torch.cat([a + fr, fp - fr], dim=-1)  # condensenc.py:196-198
+
+    def embed(lst, E):  # condensenc.py:156-176 'bond_w_d', edge.py:58-68
+        d = lst.dist[:E].clone().unsqueeze(-1)
+        e = linear(swish(linear(d, P["edge_encoder.mlp.layers.0.weight"], P["edge_encoder.mlp.layers.0.bias"])),
+                   P["edge_encoder.mlp.layers.1.weight"], P["edge_encoder.mlp.layers.1.bias"])
+        emb = P["edge_encoder.bond_emb.weight"]
+        c = torch.cat([EmbMul.apply(e, emb, lst.type_r[:E]), EmbMul.apply(e, emb, lst.type_p[:E])], dim=-1)
+        s1 = swish(linear(c, P["edge_cat.0.weight"], P["edge_cat.0.bias"]))
+        return linear(s1, P["edge_cat.2.weight"], P["edge_cat.2.bias"])
+
+    ea = embed(db.enc_u, Eu)
+    dist_u = db.enc_u.dist[:Eu].clone()
+    for l in range(L):  # schnet.py:88-128, 223-224
+        p = f"encoder.interactions.{l}."
+        Wf = linear(ssp(linear(ea, P[p + "conv.nn.0.weight"], P[p + "conv.nn.0.bias"])),
+                    P[p + "conv.nn.2.weight"], P[p + "conv.nn.2.bias"])
+        Wf = RowMask.apply(Wf, dist_u, cfg.conv_cutoff)
+        x1 = linear(h, P[p + "conv.lin1.weight"])
+        agg = Aggregate.apply(x1, Wf, db)
+        x = linear(agg, P[p + "conv.lin2.weight"], P[p + "conv.lin2.bias"])
+        h = h + linear(ssp(x), P[p + "lin.weight"], P[p + "lin.bias"])
+    ea_o = embed(db.out_u, Eo)
+    hp = torch.cat([PairProduct.apply(h, db, Eo), ea_o], dim=-1)  # common.py:226-229
+    g = "grad_dist_mlp.layers."
+    x = swish(linear(hp, P[g + "0.weight"], P[g + "0.bias"]))
+    x = swish(linear(x, P[g + "1.weight"], P[g + "1.bias"]))
+    s_u = linear(x, P[g + "2.weight"], P[g + "2.bias"]).view(-1)
+    return s_u, Eo
