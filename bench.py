@@ -41,9 +41,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", choices=["c2", "c5"], default="c2",
+    ap.add_argument("--workload", choices=["c2", "c5", "train"], default="c2",
                     help="c2: BASELINE configs[1] wb97xd3-like batch (default, the quoted metric); "
-                         "c5: configs[4] synthetic 64-atom graphs, complete pair set (use --graphs 1024)")
+                         "c5: configs[4] synthetic 64-atom graphs, complete pair set (use --graphs 1024); "
+                         "train: configs[3] training step (use --graphs 200): get_loss + backward + "
+                         "gradient all-reduce + clip + Adam")
     ap.add_argument("--graphs", type=int, default=100, help="graphs per GPU (BASELINE configs[1]: 100)")
     ap.add_argument("--models", type=int, default=1, help="ensemble size M (configs[2] uses 8)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
@@ -51,6 +53,59 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--cpu-threads", type=int, default=32)
     return ap.parse_args()
+
+
+def bench_train(args, model, dev, rank, world, dist):
+    """BASELINE configs[3]: one training step of configs/train_config.yml (batch 200 graphs per GPU here,
+    weak scaling): loss (get_loss), backward, RCCL gradient all-reduce, clip_grad_norm_, Adam."""
+    from tsdiff_amd import synth
+    from tsdiff_amd.distributed import dp_backward
+    b = synth.wb97xd3_like_batch(args.graphs, seed=2000 + rank)
+    g = {k: torch.from_numpy(v).to(dev) for k, v in b.items() if isinstance(v, np.ndarray)}
+    g["pos"] = (g["pos"] * 1.5).contiguous()
+    N = int(g["pos"].shape[0])
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.95, 0.999))
+
+    def step():
+        opt.zero_grad()
+        loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
+                              g["batch"], g["num_nodes_per_graph"], args.graphs)
+        mean = dp_backward(model, loss)
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 3000.0)
+        opt.step()
+        return mean
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training steps/s (configs[3]: get_loss + backward + grad all-reduce + clip + Adam)",
+            "value": round(args.gpus * args.graphs * args.steps / dt, 1), "unit": "graphs/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[3] training step", "graphs_per_gpu": args.graphs, "atoms_per_gpu": N,
+                       "parallelism": f"graph-batch data parallel over {args.gpus} GPU(s), one RCCL all-reduce of "
+                                      "the flat fp32 gradient per step"},
+            "final_loss": last}))
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main():
@@ -83,6 +138,8 @@ def main():
         model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
         models.append(model.to(dev))
     sampler = EnsembleSampler(models)
+    if args.workload == "train":
+        return bench_train(args, models[0], dev, rank, world, dist)
 
     if args.workload == "c5":
         b = synth.dense_stress_batch(args.graphs, n=64, seed=1000 + rank)

@@ -55,3 +55,35 @@ def test_sample_sharded_gloo_world2():
         ret = mgr.dict()
         mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
         assert ret.get("ok") is True
+
+
+def _dp_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tsdiff_amd.distributed import dp_backward
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 1))
+    x = torch.randn(23, 5)  # "nodes" of the global batch; ranks own unequal shards
+    sl = slice(0, 9) if rank == 0 else slice(9, 23)
+    mean = dp_backward(model, model(x[sl]) ** 2)
+    grads = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    # single-process reference: loss.mean().backward() over all 23 nodes
+    ref = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 1))
+    ref.load_state_dict(model.state_dict())
+    full = ref(x) ** 2
+    full.mean().backward()
+    gref = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    ok = torch.allclose(grads, gref, rtol=1e-5, atol=1e-7) and abs(mean - float(full.mean())) < 1e-6
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_dp_backward_matches_single_process_gloo_world2():
+    port = 29600 + (os.getpid() % 300)
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_dp_worker, args=(2, port, ret), nprocs=2, join=True)
+        assert ret.get(0) is True and ret.get(1) is True

@@ -59,18 +59,32 @@ __global__ void bias_add_kernel(int64_t n, int cols, const float* __restrict__ b
     if (i < n) y[i] += b[i % cols];
 }
 
-// column sums of dY [rows, cols] (bias gradient): one workgroup per 64 columns, deterministic tree
-__global__ __launch_bounds__(256) void colsum_kernel(int rows, int cols, const float* __restrict__ dy,
-                                                     float* __restrict__ db) {
+// column sums of dY [rows, cols] (bias gradient), deterministic two-stage tree:
+// stage 1: grid (cols/64, CS_CHUNKS) workgroups reduce a row chunk each into part[chunk][col];
+// stage 2: one thread per column adds the CS_CHUNKS partials in order.
+constexpr int CS_CHUNKS = 64;
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(int rows, int cols, const float* __restrict__ dy,
+                                                            float* __restrict__ part) {
     __shared__ float sm[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int w = threadIdx.x >> 6;
+    const int per = (rows + CS_CHUNKS - 1) / CS_CHUNKS;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
     float s = 0.0f;
     if (c < cols)
-        for (int r = w; r < rows; r += 4) s += dy[(size_t)r * cols + c];
+        for (int r = r0 + w; r < r1; r += 4) s += dy[(size_t)r * cols + c];
     sm[w][threadIdx.x & 63] = s;
     __syncthreads();
-    if (w == 0 && c < cols) db[c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+    if (w == 0 && c < cols)
+        part[(size_t)blockIdx.y * cols + c] =
+            (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+__global__ void colsum_stage2_kernel(int cols, const float* __restrict__ part, float* __restrict__ db) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.0f;
+    for (int k = 0; k < CS_CHUNKS; ++k) s += part[(size_t)k * cols + c];
+    db[c] = s;
 }
 
 // activations: kind 0 swish (reference utils/activation_functions.py), 1 shifted softplus (schnet.py:65-71)
@@ -226,7 +240,7 @@ int tsd_linear_fwd(int32_t rows, int32_t in, int32_t out, const float* X, const 
 }
 
 int tsd_linear_bwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* dY, float* dX,
-                   float* dW, float* db, void* stream) {
+                   float* dW, float* db, float* scratch, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     int r;
     if (dX && (r = gemm_rm(false, false, rows, in, out, 1.0f, dY, out, W, in, 0.0f, dX, in, st))) return r;  // dY W
@@ -238,7 +252,10 @@ int tsd_linear_bwd(int32_t rows, int32_t in, int32_t out, const float* X, const 
         }
     }
     if (db) {
-        hipLaunchKernelGGL(colsum_kernel, dim3((out + 63) / 64), dim3(256), 0, st, rows, out, dY, db);
+        TSD_REQUIRE(scratch != nullptr, "tsd_linear_bwd: db needs a scratch of 64*out floats");
+        hipLaunchKernelGGL(colsum_stage1_kernel, dim3((out + 63) / 64, CS_CHUNKS), dim3(256), 0, st, rows, out, dY,
+                           scratch);
+        hipLaunchKernelGGL(colsum_stage2_kernel, dim3((out + 255) / 256), dim3(256), 0, st, out, scratch, db);
         TSD_LAUNCH_CHECK("colsum");
     }
     return TSD_OK;

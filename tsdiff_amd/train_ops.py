@@ -21,6 +21,19 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+_SCRATCH = {}
+
+
+def _scratch(device, n):
+    """per-device scratch for the two-stage bias-gradient reduction (64 * out floats)"""
+    key = str(device)
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 64 * 1024), dtype=torch.float32, device=device)
+        _SCRATCH[key] = t
+    return t
+
+
 class Linear(torch.autograd.Function):
     """y = x W^T + b   (torch.nn.Linear semantics; W [out,in])"""
 
@@ -46,7 +59,9 @@ class Linear(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dW = torch.empty_like(W) if ctx.needs_input_grad[1] else None
         db = torch.empty(out, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        check(lib.tsd_linear_bwd(rows, fin, out, ptr(x), ptr(W), ptr(dy), ptr(dx), ptr(dW), ptr(db), stream_ptr()))
+        sc = _scratch(x.device, 64 * out) if db is not None else None
+        check(lib.tsd_linear_bwd(rows, fin, out, ptr(x), ptr(W), ptr(dy), ptr(dx), ptr(dW), ptr(db), ptr(sc),
+                                 stream_ptr()))
         return dx, dW, db
 
 
