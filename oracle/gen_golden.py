@@ -135,7 +135,12 @@ def run_forward_with_trace(R, model, b):
     return {k: v.numpy() for k, v in res.items()}
 
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]
+
+
 def save(name, meta, **arrays):
+    if ONLY and name not in ONLY:
+        return
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **arrays)
@@ -232,6 +237,58 @@ def main():
     save("ddpm_synth_b3_small_12", {"cfg": small_cfg, "seeds": [1], "n_steps": 12, "step_lr": 1e-7,
                                     "clip": 1000, "sampling_type": "ddpm"},
          **inputs_of(b), pos_init=pos_init, noises=noises, pos_final=pos, traj=traj)
+
+    # --- E2: guess-TS modes of dynamic_sampling (sampler.py:149-177), small model -------------------
+    def run_guess(models, b, pos_init, n_steps, **mode):
+        bt = tt(b)
+        noises, init = [], []
+        o_like, o_randn = torch.randn_like, torch.randn
+
+        def rec_like(x, *a, **k):
+            n = o_like(x, *a, **k)
+            noises.append(n.clone())
+            return n
+
+        def rec_randn(*a, **k):
+            n = o_randn(*a, **k)
+            init.append(n.clone())
+            return n
+
+        ens = R.sampler.EnsembleSampler(models)
+        torch.manual_seed(77)
+        torch.randn_like, torch.randn = rec_like, rec_randn
+        try:
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                pos, traj = ens.dynamic_sampling(
+                    bt["atom_type"], bt["r_feat"], bt["p_feat"], torch.from_numpy(pos_init), bt["bond_index"],
+                    bt["bond_type"], bt["batch"], int(b["num_graphs"]), extend_order=True, n_steps=n_steps,
+                    step_lr=1e-7, clip=1000, sampling_type="ld", **mode)
+        finally:
+            torch.randn_like, torch.randn = o_like, o_randn
+        return pos.numpy(), torch.stack(traj).numpy(), torch.stack(noises).numpy(), (init[0].numpy() if init else None)
+
+    b = synth.wb97xd3_like_batch(3, seed=5, n_lo=6, n_hi=12)
+    guess = (b["pos"] * 1.2).astype(np.float32)
+    pos, traj, noises, _ = run_guess([model_small], b, guess, 10, denoise_from_time_t=300)
+    save("ld_guess_denoise_small", {"cfg": small_cfg, "seeds": [1], "n_steps": 10, "step_lr": 1e-7, "clip": 1000,
+                                    "sampling_type": "ld", "denoise_from_time_t": 300},
+         **inputs_of(b), pos_init=guess, noises=noises, pos_final=pos, traj=traj)
+    pos, traj, noises, init = run_guess([model_small], b, guess, 10, denoise_from_time_t=300, noise_from_time_t=100)
+    save("ld_guess_noise_denoise_small", {"cfg": small_cfg, "seeds": [1], "n_steps": 10, "step_lr": 1e-7,
+                                          "clip": 1000, "sampling_type": "ld", "denoise_from_time_t": 300,
+                                          "noise_from_time_t": 100},
+         **inputs_of(b), pos_init=guess, noises=noises, init_noise=init, pos_final=pos, traj=traj)
+
+    # --- E3: a checkpoint in the reference's on-disk format (train.py:221-231), small model -------------
+    if not ONLY or "ckpt_small" in ONLY:
+        full_cfg_tree = R.EasyDict({"model": small_cfg, "train": {"seed": 0, "batch_size": 200}})
+        opt = torch.optim.Adam(model_small.parameters(), lr=5e-4, betas=(0.95, 0.999))
+        sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.8, patience=10, min_lr=1.25e-4)
+        os.makedirs(OUT, exist_ok=True)
+        path = os.path.join(OUT, "ckpt_small.pt")
+        torch.save({"config": full_cfg_tree, "model": model_small.state_dict(), "optimizer": opt.state_dict(),
+                    "scheduler": sched.state_dict(), "iteration": 1000, "avg_val_loss": 1.25}, path)
+        print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
 
     # --- F: get_loss with captured random draws + gradient norms ---------------------------
     def run_loss(model, b, name, cfg, seed):

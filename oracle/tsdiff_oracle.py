@@ -255,7 +255,7 @@ def _compute_alpha(betas, t):  # sampler.py:138-141
 
 def sample(sds, cfg, atom_type, r_feat, p_feat, pos_init, bond_index, bond_type, batch,
            num_nodes_per_graph, noises, n_steps, step_lr=1e-7, clip=1000.0, clip_pos=None,
-           sampling_type="ld"):
+           sampling_type="ld", denoise_from_time_t=None, noise_from_time_t=None, init_noise=None):
     """reference EnsembleSampler.dynamic_sampling default branch (sampler.py:179-254)
     with the per-step Gaussian noise INJECTED (`noises[k]` is the k-th draw of
     `torch.randn_like(pos)`), so that a device implementation can be compared
@@ -264,9 +264,18 @@ def sample(sds, cfg, atom_type, r_feat, p_feat, pos_init, bond_index, bond_type,
     sig = sigmas_from_alphas(alphas)
     T = betas.numel()
     G = len(num_nodes_per_graph)
-    seq = list(range(T - n_steps, T))
+    if noise_from_time_t is not None:  # sampler.py:149-166
+        seq = list(range(denoise_from_time_t - n_steps, denoise_from_time_t))
+        alpha_t = alphas[denoise_from_time_t - 1]
+        alpha_s = alphas[noise_from_time_t - 1] if noise_from_time_t != 0 else 1
+        pos = pos_init + init_noise * ((1.0 - (alpha_t / alpha_s)) / alpha_t).sqrt()
+    elif denoise_from_time_t is not None:  # sampler.py:168-177
+        seq = list(range(denoise_from_time_t - n_steps, denoise_from_time_t))
+        pos = pos_init
+    else:  # sampler.py:179-182
+        seq = list(range(T - n_steps, T))
+        pos = pos_init * sig[-1]
     seq_next = [-1] + seq[:-1]
-    pos = pos_init * sig[-1]
     traj = []
     for k, (i, j) in enumerate(zip(reversed(seq), reversed(seq_next))):
         edge_inv, ei, d = ensemble_forward(sds, cfg, atom_type, r_feat, p_feat, pos, bond_index,

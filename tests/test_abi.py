@@ -84,3 +84,25 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp")):
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in src.replace("# checker", ""), f"{f} mentions the oracle"
+
+
+def test_reference_checkpoint_round_trip(tmp_path):
+    """a checkpoint written by the reference's torch.save (fixture from oracle/gen_golden.py) loads into the
+    drop-in model: config via AttrDict, every state_dict key including the aliases (strict=True)"""
+    import numpy as np
+    from tsdiff_amd import io, synth
+    from tsdiff_amd.epsnet import get_model
+    ck = io.load_checkpoint(os.path.join(ROOT, "tests", "golden", "ckpt_small.pt"))
+    assert ck["iteration"] == 1000 and ck["config"].model.network == "condensenc"
+    model = get_model(ck["config"].model)
+    missing, unexpected = model.load_state_dict(ck["model"], strict=True)
+    assert not missing and not unexpected
+    sd = synth.synth_state_dict(synth.small_model_config(64, 2), 1)
+    for k, v in sd.items():
+        assert np.array_equal(model.state_dict()[k].numpy(), v), k
+    # and our own save format loads back the same way
+    p = str(tmp_path / "ck.pt")
+    io.save_checkpoint(p, ck["config"], model, iteration=7)
+    ck2 = io.load_checkpoint(p)
+    assert ck2["iteration"] == 7 and ck2["config"]["model"]["hidden_dim"] == 64
+    assert all(torch.equal(ck2["model"][k], model.state_dict()[k]) for k in model.state_dict())

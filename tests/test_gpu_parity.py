@@ -216,7 +216,8 @@ def test_ensemble_forward_vs_golden(dev):
     assert_close(edge_inv.cpu().numpy(), d["edge_inv"], RTOL, "ensemble edge_inv")
 
 
-@pytest.mark.parametrize("name", ["ld_rxn0_b1_full_50", "ld_synth_b3_small_ens2_20", "ddpm_synth_b3_small_12"])
+@pytest.mark.parametrize("name", ["ld_rxn0_b1_full_50", "ld_synth_b3_small_ens2_20", "ddpm_synth_b3_small_12",
+                                  "ld_guess_denoise_small", "ld_guess_noise_denoise_small"])
 @pytest.mark.parametrize("use_graph", [True, False])
 def test_sampler_vs_reference_trajectory(name, use_graph, dev):
     from tsdiff_amd.sampler import EnsembleSampler
@@ -228,6 +229,8 @@ def test_sampler_vs_reference_trajectory(name, use_graph, dev):
         g["atom_type"], g["r_feat"], g["p_feat"], torch.from_numpy(d["pos_init"]).to(dev), g["bond_index"],
         g["bond_type"], g["batch"], g["num_graphs"], extend_order=True, n_steps=meta["n_steps"],
         step_lr=meta["step_lr"], clip=meta["clip"], sampling_type=meta["sampling_type"],
+        denoise_from_time_t=meta.get("denoise_from_time_t"), noise_from_time_t=meta.get("noise_from_time_t"),
+        init_noise=torch.from_numpy(d["init_noise"]).to(dev) if "init_noise" in d else None,
         noises=torch.from_numpy(d["noises"]).to(dev), use_graph=use_graph)
     assert len(traj) == meta["n_steps"] and traj[0].device.type == "cpu"
     assert_close(torch.stack(traj).numpy(), d["traj"], 5e-5, "trajectory")

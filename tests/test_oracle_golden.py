@@ -59,7 +59,8 @@ def test_ensemble_forward():
     assert_close(edge_inv.numpy(), d["edge_inv"], RTOL, "edge_inv")
 
 
-@pytest.mark.parametrize("name", ["ld_rxn0_b1_full_50", "ld_synth_b3_small_ens2_20", "ddpm_synth_b3_small_12"])
+@pytest.mark.parametrize("name", ["ld_rxn0_b1_full_50", "ld_synth_b3_small_ens2_20", "ddpm_synth_b3_small_12",
+                                  "ld_guess_denoise_small", "ld_guess_noise_denoise_small"])
 def test_sampler_trajectory(name):
     d, meta = load_golden(name)
     b = batch_inputs(d)
@@ -68,7 +69,10 @@ def test_sampler_trajectory(name):
                          torch.from_numpy(d["pos_init"]), b["bond_index"], b["bond_type"], b["batch"],
                          b["num_nodes_per_graph"].numpy(), torch.from_numpy(d["noises"]),
                          n_steps=meta["n_steps"], step_lr=meta["step_lr"], clip=meta["clip"],
-                         sampling_type=meta["sampling_type"])
+                         sampling_type=meta["sampling_type"],
+                         denoise_from_time_t=meta.get("denoise_from_time_t"),
+                         noise_from_time_t=meta.get("noise_from_time_t"),
+                         init_noise=torch.from_numpy(d["init_noise"]) if "init_noise" in d else None)
     # trajectories amplify rounding differences slightly; positions are O(10) Angstrom
     assert_close(torch.stack(traj).numpy(), d["traj"], 5e-5, "traj")
     assert_close(pos.numpy(), d["pos_final"], 5e-5, "pos_final")

@@ -77,8 +77,9 @@ class EnsembleSampler(nn.Module):
                          extend_order, extend_radius=True, n_steps=100, step_lr=0.0000010, clip=1000,
                          clip_pos=None, denoise_from_time_t=None, noise_from_time_t=None, **kwargs):
         """Same arguments as the reference.  Extra keyword-only knobs (all optional):
-        noises=(n_steps,N,3) tensor to inject the Gaussian draws, return_traj=False to skip the
-        trajectory, use_graph=False to launch eagerly instead of replaying a hipGraph."""
+        noises=(n_steps,N,3) tensor to inject the Gaussian draws (init_noise=(N,3) for the initial draw of the
+        noise_from_time_t mode), return_traj=False to skip the trajectory, use_graph=False to launch
+        eagerly instead of replaying a hipGraph."""
         sampling_type = kwargs.get("sampling_type", "ddpm")
         noises = kwargs.get("noises", None)
         return_traj = kwargs.get("return_traj", True)
@@ -91,7 +92,9 @@ class EnsembleSampler(nn.Module):
                 assert denoise_from_time_t >= noise_from_time_t
                 assert noise_from_time_t >= 0
                 seq = range(denoise_from_time_t - n_steps, denoise_from_time_t)
-                noise = torch.randn(pos_init.size(), device=dev)
+                noise = kwargs.get("init_noise", None)
+                if noise is None:
+                    noise = torch.randn(pos_init.size(), device=dev)
                 alpha_t = self.alphas[denoise_from_time_t - 1]
                 alpha_s = self.alphas[noise_from_time_t - 1] if noise_from_time_t != 0 else 1
                 sigma = ((1.0 - (alpha_t / alpha_s)) / alpha_t).sqrt()
