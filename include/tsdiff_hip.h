@@ -254,7 +254,8 @@ int tsd_linear_fwd(int32_t rows, int32_t in, int32_t out, const float* X, const 
  * of 64*out floats for its deterministic two-stage reduction) */
 int tsd_linear_bwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* dY,
                    float* dX, float* dW, float* db, float* scratch, void* stream);
-/* kind 0: swish (utils/activation_functions.py), 1: shifted softplus (schnet.py:65-71); x = pre-activation */
+/* kind 0: swish (utils/activation_functions.py), 1: shifted softplus (schnet.py:65-71), 2: ReLU, 3: softplus;
+ * x = pre-activation */
 int tsd_act_fwd(int32_t kind, int64_t n, const float* x, float* y, void* stream);
 int tsd_act_bwd(int32_t kind, int64_t n, const float* x, const float* dy, float* dx, void* stream);
 /* y[r,:] = x[r,:] * emb[idx[r],:] (edge.py:66-68); backward also accumulates demb (zeroed by the caller) */
@@ -283,6 +284,18 @@ int tsd_eq_und_bwd(int32_t capacity_u, tsd_edges out_u, const float* pos, const 
                    void* stream);
 /* d[u] = |pos[src u] - pos[dst u]| (get_distance on another geometry, condensenc.py:313) */
 int tsd_pair_distance(int32_t capacity_u, tsd_edges list_u, const float* pos, float* d, void* stream);
+
+/* ---- legacy dual-encoder pieces (secondary: no shipped TSDiff config runs them) ----
+ * GINEConv message + sum aggregation + self term (reference models/encoder/gin.py:61-73):
+ *   out[i] = (1+eps) x[i] + sum_{e: edge_index[1][e] = i} act(x[edge_index[0][e]] + edge_attr[e])
+ * activation 0 none, 1 ReLU, 2 softplus; arbitrary directed int64 edge list; fp32 atomics. */
+int tsd_gine_aggregate(int32_t num_nodes, int64_t num_edges, int32_t H, int32_t activation, float eps,
+                       const float* x, const int64_t* edge_index, const float* edge_attr, float* out,
+                       void* stream);
+/* GaussianSmearingEdgeEncoder (models/encoder/edge.py:18-41): the radial-basis expansion
+ *   out[e] = [exp(coeff (d_e - offset_k)^2) for k < K, bond_emb[type_e]]   -> [E, 2K] */
+int tsd_gaussian_edge_encode(int64_t num_edges, int32_t K, float coeff, const float* d, const float* offset,
+                             const int64_t* type, const float* bond_emb, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -290,6 +290,35 @@ def main():
                     "scheduler": sched.state_dict(), "iteration": 1000, "avg_val_loss": 1.25}, path)
         print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
 
+    # --- E4: legacy encoders called directly: GINEncoder, GaussianSmearingEdgeEncoder --
+    if not ONLY or "legacy_gin_rbf" in ONLY:
+        import importlib
+        gin_mod = importlib.import_module("models.encoder.gin")
+        edge_mod = importlib.import_module("models.encoder.edge")
+        torch.manual_seed(5)
+        Hh = 64
+        enc = gin_mod.GINEncoder(hidden_dim=Hh, num_convs=3, activation="ReLU", embedding=True)
+        b = synth.wb97xd3_like_batch(3, seed=11, n_lo=6, n_hi=12)
+        ei = torch.from_numpy(b["bond_index"])
+        zt = torch.from_numpy(b["atom_type"])
+        ea = torch.randn(ei.shape[1], Hh)
+        with torch.no_grad():
+            out = enc(zt, ei, ea)
+            conv0 = enc.convs[0](enc.node_emb(zt), ei, ea)
+        # edge.py:28 references GaussianSmearing without importing it (NameError in the reference as shipped);
+        # the class it means is models/encoder/schnet.py:14-23 -- bind that name, keep the reference's code
+        edge_mod.GaussianSmearing = importlib.import_module("models.encoder.schnet").GaussianSmearing
+        rbf = edge_mod.GaussianSmearingEdgeEncoder(num_gaussians=32, cutoff=10.0)
+        dlen = (torch.rand(200, 1) * 22.0)
+        typ = torch.randint(0, 26, (200,))
+        with torch.no_grad():
+            rout = rbf(dlen, typ)
+        save("legacy_gin_rbf", {"hidden": Hh, "num_convs": 3},
+             z=zt.numpy(), edge_index=ei.numpy(), edge_attr=ea.numpy(), gin_out=out.numpy(), conv0_out=conv0.numpy(),
+             **{"gin." + k: v.numpy() for k, v in enc.state_dict().items()},
+             rbf_d=dlen.numpy(), rbf_type=typ.numpy(), rbf_out=rout.numpy(),
+             **{"rbf." + k: v.numpy() for k, v in rbf.state_dict().items()})
+
     # --- F: get_loss with captured random draws + gradient norms ---------------------------
     def run_loss(model, b, name, cfg, seed):
         bt = tt(b)

@@ -391,3 +391,28 @@ def test_full_size_properties(dev):
     #  cuts fall depends on the replica's offset in the batch)
     scale = float(per.abs().max())
     assert all(float((per[0] - per[k]).abs().max()) <= 2e-6 * scale for k in range(1, 5))
+
+
+def test_legacy_gin_and_gaussian_rbf_vs_reference(dev):
+    """SURVEY 8a A17/A19 (secondary): GINEConv / GINEncoder and GaussianSmearingEdgeEncoder called directly,
+    against outputs of the reference modules (weights stored in the fixture)."""
+    from tsdiff_amd.encoder import GaussianSmearingEdgeEncoder, GINEncoder
+    d, meta = load_golden("legacy_gin_rbf")
+    enc = GINEncoder(hidden_dim=meta["hidden"], num_convs=meta["num_convs"], activation="ReLU", embedding=True)
+    sd = {k[4:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("gin.")}
+    missing, unexpected = enc.load_state_dict(sd, strict=True)
+    enc = enc.to(dev)
+    z = torch.from_numpy(d["z"]).to(dev)
+    ei = torch.from_numpy(d["edge_index"]).to(dev)
+    ea = torch.from_numpy(d["edge_attr"]).to(dev)
+    conv0 = enc.convs[0](enc.node_emb.weight.detach()[z], ei, ea)
+    assert_close(conv0.cpu().numpy(), d["conv0_out"], RTOL, "GINEConv")
+    out = enc(z, ei, ea)
+    assert_close(out.cpu().numpy(), d["gin_out"], RTOL, "GINEncoder")
+    rbf = GaussianSmearingEdgeEncoder(num_gaussians=32, cutoff=10.0)
+    rsd = {k[4:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("rbf.") and k != "rbf_d"
+           and not k.startswith("rbf_")}
+    rbf.load_state_dict(rsd, strict=True)
+    rbf = rbf.to(dev)
+    rout = rbf(torch.from_numpy(d["rbf_d"]).to(dev), torch.from_numpy(d["rbf_type"]).to(dev))
+    assert_close(rout.cpu().numpy(), d["rbf_out"], 2e-6, "GaussianSmearingEdgeEncoder")

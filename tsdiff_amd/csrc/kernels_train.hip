@@ -92,7 +92,7 @@ __global__ void act_fwd_kernel(int kind, int64_t n, const float* __restrict__ x,
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float v = x[i];
-    y[i] = kind == 0 ? swishf(v) : sspf(v);
+    y[i] = kind == 0 ? swishf(v) : kind == 1 ? sspf(v) : kind == 2 ? fmaxf(v, 0.0f) : sspf(v) + 0.69314718055994530942f;
 }
 __global__ void act_bwd_kernel(int kind, int64_t n, const float* __restrict__ x, const float* __restrict__ dy,
                                float* __restrict__ dx) {
@@ -101,7 +101,7 @@ __global__ void act_bwd_kernel(int kind, int64_t n, const float* __restrict__ x,
     const float v = x[i];
     const float sg = __builtin_amdgcn_rcpf(1.0f + fast_exp(-v));  // sigmoid(v)
     // d swish = sg * (1 + v * (1 - sg)) ; d ssp = d softplus = sg
-    const float d = kind == 0 ? sg * (1.0f + v * (1.0f - sg)) : sg;
+    const float d = kind == 0 ? sg * (1.0f + v * (1.0f - sg)) : kind == 2 ? (v > 0.0f ? 1.0f : 0.0f) : sg;
     dx[i] = dy[i] * d;
 }
 
@@ -218,6 +218,48 @@ __global__ void pair_distance_kernel(tsd_edges eu, const float* __restrict__ pos
     d[u] = sqrtf(dx * dx + dy * dy + dz * dz);
 }
 
+// ---------------------------------------------------------------------------------------------
+// legacy dual-encoder pieces (reference models/encoder/gin.py, edge.py:18-41)
+// ---------------------------------------------------------------------------------------------
+// GINEConv message + aggregation + self term (gin.py:61-73):
+//   out[i] = (1 + eps) * x[i] + sum_{e: dst(e) = i} act(x[src(e)] + edge_attr[e])
+// Arbitrary directed int64 edge list (the legacy local graph is built by the caller): the self term is
+// written first, the messages are added with fp32 atomics.
+__global__ void gine_self_kernel(int64_t n, float scale, const float* __restrict__ x, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = scale * x[i];
+}
+__global__ void gine_message_kernel(int64_t E, int H, int act, const float* __restrict__ x,
+                                    const int64_t* __restrict__ ei, const float* __restrict__ edge_attr,
+                                    float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E * H) return;
+    const int64_t e = t / H;
+    const int c = (int)(t % H);
+    const int64_t j = ei[e], i = ei[E + e];
+    float v = x[j * H + c] + edge_attr[t];
+    if (act == 1) v = fmaxf(v, 0.0f);
+    else if (act == 2) v = sspf(v) + 0.69314718055994530942f;  // softplus
+    atomicAdd(out + i * H + c, v);
+}
+
+// GaussianSmearingEdgeEncoder (edge.py:18-41, schnet.py:14-23):
+//   out[e] = [exp(coeff * (d_e - offset_k)^2), k < K  ||  bond_emb[type_e]]        -> [E, 2K]
+__global__ void gaussian_edge_kernel(int64_t E, int K, float coeff, const float* __restrict__ d,
+                                     const float* __restrict__ offset, const int64_t* __restrict__ type,
+                                     const float* __restrict__ bond_emb, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= E * 2 * K) return;
+    const int64_t e = t / (2 * K);
+    const int c = (int)(t % (2 * K));
+    if (c < K) {
+        const float u = d[e] - offset[c];
+        out[t] = expf(coeff * (u * u));
+    } else {
+        out[t] = bond_emb[type[e] * K + (c - K)];
+    }
+}
+
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace tsd
@@ -271,6 +313,30 @@ int tsd_act_bwd(int32_t kind, int64_t n, const float* x, const float* dy, float*
     if (n == 0) return TSD_OK;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, kind, n, x, dy, dx);
     TSD_LAUNCH_CHECK("act_bwd");
+    return TSD_OK;
+}
+
+int tsd_gine_aggregate(int32_t num_nodes, int64_t num_edges, int32_t H, int32_t activation, float eps,
+                       const float* x, const int64_t* edge_index, const float* edge_attr, float* out,
+                       void* stream) {
+    TSD_REQUIRE(activation >= 0 && activation <= 2, "activation %d (0 none, 1 relu, 2 softplus)", activation);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)num_nodes * H;
+    if (n == 0) return TSD_OK;
+    hipLaunchKernelGGL(gine_self_kernel, dim3(blocks_for(n)), dim3(256), 0, st, n, 1.0f + eps, x, out);
+    if (num_edges > 0)
+        hipLaunchKernelGGL(gine_message_kernel, dim3(blocks_for(num_edges * H)), dim3(256), 0, st, num_edges, H,
+                           activation, x, edge_index, edge_attr, out);
+    TSD_LAUNCH_CHECK("gine_aggregate");
+    return TSD_OK;
+}
+
+int tsd_gaussian_edge_encode(int64_t num_edges, int32_t K, float coeff, const float* d, const float* offset,
+                             const int64_t* type, const float* bond_emb, float* out, void* stream) {
+    if (num_edges == 0) return TSD_OK;
+    hipLaunchKernelGGL(gaussian_edge_kernel, dim3(blocks_for(num_edges * 2 * K)), dim3(256), 0, (hipStream_t)stream,
+                       num_edges, K, coeff, d, offset, type, bond_emb, out);
+    TSD_LAUNCH_CHECK("gaussian_edge_encode");
     return TSD_OK;
 }
 
