@@ -79,6 +79,30 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
                         uv = a.umap[eb + lane];
                     }
                     int k = 0;
+                    constexpr int U = 8;  // edges in flight per wave (2 x 8 float4 loads), added in edge order
+                    for (; k + U <= cnt; k += U) {
+                        float wv[U][V], xv[U][V];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int j = __builtin_amdgcn_readlane(jv, k + u);
+                            const int we = __builtin_amdgcn_readlane(uv, k + u);
+                            const float* wp = a.Wf + (size_t)we * H + lane * V;
+                            const float* xp = a.x1_in + (size_t)j * H + lane * V;
+                            if (V == 4) {
+                                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp);
+                                const f32x4 x4 = *reinterpret_cast<const f32x4*>(xp);
+#pragma unroll
+                                for (int v = 0; v < V; ++v) { wv[u][v] = w4[v]; xv[u][v] = x4[v]; }
+                            } else {
+#pragma unroll
+                                for (int v = 0; v < V; ++v) { wv[u][v] = wp[v]; xv[u][v] = xp[v]; }
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+#pragma unroll
+                            for (int v = 0; v < V; ++v) s[v] = __fadd_rn(s[v], __fmul_rn(xv[u][v], wv[u][v]));
+                    }
                     for (; k + 4 <= cnt; k += 4) {
                         float wv[4][V], xv[4][V];
 #pragma unroll
