@@ -26,7 +26,8 @@
  *   - the library never allocates or frees device memory: outputs and scratch are caller
  *     allocated (torch's caching allocator on the Python side);
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), performs no
- *     host synchronisation and returns 0 on success or a negative TSD_ERR_* code;
+ *     host synchronisation (one exception: tsd_sampler_run with use_graph waits for the stream once at
+ *     the end, to release its graph) and returns 0 on success or a negative TSD_ERR_* code;
  *     tsd_last_error() returns a thread-local message for the last failure;
  *   - floating point is fp32 end to end (fp32 MFMA, exact-f32 FMA chains); indices at this
  *     boundary are int32 except where the reference surface hands over int64 tensors
@@ -239,7 +240,7 @@ int tsd_sampler_step(int32_t kind, int32_t num_nodes, int32_t num_graphs, const 
  * use_graph != 0 captures one step into a hipGraph and replays it. */
 int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t kind, int32_t n_steps,
                     const float* coefs, const float* noises, float clip, float clip_pos,
-                    float* pos, float* traj, float* scratch /* [P + 3N + 128] */, int32_t* status /* [2] */,
+                    float* pos, float* traj, int32_t* status /* [2]: flags, step counter */,
                     int32_t use_graph, void* stream);
 
 /* ---- training primitives (BASELINE config 4; reference train.py:124-152, condensenc.py:267-328) -----

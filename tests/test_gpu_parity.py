@@ -40,10 +40,12 @@ def to_dev(b, dev):
     return {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()}
 
 
-def run_forward(model, g, dev):
+def run_forward(model, g, dev, grad=False):
+    """grad=False: the fused inference kernels (what sampling uses); grad=True: the differentiable path"""
     G = g["num_graphs"]
-    return model(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"],
-                 torch.zeros(G, dtype=torch.long, device=dev))
+    with torch.set_grad_enabled(grad):
+        return model(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
+                     g["batch"], torch.zeros(G, dtype=torch.long, device=dev))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -344,7 +346,8 @@ def test_edge_cases(dev):
     bi = torch.tensor([[3, 4, 3, 5], [4, 3, 5, 3]], device=dev)
     bt = torch.tensor([23, 23, 22, 22], device=dev)
     batch = torch.tensor([0, 1, 1, 2, 2, 2], device=dev)
-    edge_inv, ei, el = model(atom, feat, feat, pos, bi, bt, batch, torch.zeros(3, dtype=torch.long, device=dev))
+    with torch.no_grad():
+        edge_inv, ei, el = model(atom, feat, feat, pos, bi, bt, batch, torch.zeros(3, dtype=torch.long, device=dev))
     assert ei.shape[1] == 6 and set(ei.flatten().tolist()) == {3, 4, 5}
     assert torch.isfinite(edge_inv).all()
     with pytest.raises(ValueError):
@@ -416,3 +419,38 @@ def test_legacy_gin_and_gaussian_rbf_vs_reference(dev):
     rbf = rbf.to(dev)
     rout = rbf(torch.from_numpy(d["rbf_d"]).to(dev), torch.from_numpy(d["rbf_type"]).to(dev))
     assert_close(rout.cpu().numpy(), d["rbf_out"], 2e-6, "GaussianSmearingEdgeEncoder")
+
+
+def test_hidden128_large_graphs_and_differentiable_forward(dev):
+    """H = 128 instantiation, graphs of ~100 atoms (several 64-lane passes per row, rows longer than an edge
+    tile, N not a multiple of the node tile), spread geometries; forward() under autograd == no_grad path"""
+    from oracle import tsdiff_oracle as O
+    from tsdiff_amd import synth
+    cfg = synth.small_model_config(128, 2)
+    b = synth.wb97xd3_like_batch(3, seed=31, n_lo=90, n_hi=110)
+    small = synth.wb97xd3_like_batch(2, seed=32, n_lo=3, n_hi=5)
+    graphs = []
+    for src in (b, small):
+        off = np.concatenate([[0], np.cumsum(src["num_nodes_per_graph"])])
+        for gi in range(src["num_graphs"]):
+            lo, hi = off[gi], off[gi + 1]
+            sel = (src["bond_index"][0] >= lo) & (src["bond_index"][0] < hi)
+            graphs.append({"atom_type": src["atom_type"][lo:hi], "r_feat": src["r_feat"][lo:hi],
+                           "p_feat": src["p_feat"][lo:hi], "pos": src["pos"][lo:hi] * 4.0,
+                           "bond_index": src["bond_index"][:, sel] - lo, "bond_type": src["bond_type"][sel]})
+    bb = synth.collate(graphs)
+    t = {k: torch.from_numpy(v) for k, v in bb.items() if isinstance(v, np.ndarray)}
+    sd = O.to_torch_state(synth.synth_state_dict(cfg, 6))
+    o_inv, o_ei, o_el = O.forward(sd, cfg, t["atom_type"], t["r_feat"], t["p_feat"], t["pos"], t["bond_index"],
+                                  t["bond_type"], bb["num_nodes_per_graph"])
+    assert (o_el > 10.0).any() and o_ei.shape[1] < int((bb["num_nodes_per_graph"] * (bb["num_nodes_per_graph"] - 1)).sum())
+    g = to_dev({**t, "num_graphs": 5}, dev)
+    model = make_model(cfg, 6, dev)
+    edge_inv, ei, el = run_forward(model, g, dev)
+    assert torch.equal(ei.cpu(), o_ei)
+    assert_close(edge_inv.cpu().numpy(), o_inv.numpy(), RTOL, "edge_inv (H=128, ~100-atom graphs)")
+    inv_g, ei_g, _ = run_forward(model, g, dev, grad=True)  # autograd on: training primitives
+    assert inv_g.requires_grad and torch.equal(ei_g, ei)
+    assert_close(inv_g.detach().cpu().numpy(), o_inv.numpy(), RTOL, "edge_inv (differentiable forward)")
+    inv_g.sum().backward()
+    assert model.grad_dist_mlp.layers[0].weight.grad is not None

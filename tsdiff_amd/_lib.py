@@ -132,7 +132,7 @@ SIGNATURES = {
     "tsd_gine_aggregate": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_float, _P, _P, _P, _P, _P]),
     "tsd_gaussian_edge_encode": (C.c_int, [C.c_int64, C.c_int32, C.c_float, _P, _P, _P, _P, _P, _P]),
     "tsd_sampler_run": (C.c_int, [_CFG, C.POINTER(Batch), C.c_int32, C.c_int32, _P, _P, C.c_float, C.c_float,
-                                  _P, _P, _P, _P, C.c_int32, _P]),
+                                  _P, _P, _P, C.c_int32, _P]),
 }
 
 _lib = None

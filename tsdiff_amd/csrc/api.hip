@@ -62,7 +62,6 @@ int launch_eq_transform_rows(int, const float*, const int32_t*, const int32_t*, 
 int launch_ensemble_mean(int, int, tsd_edges, const float*, float*, hipStream_t);
 int launch_sampler_step(int, int, int, const int32_t*, const float*, const float*, const float*, float, float,
                         float*, float*, int32_t*, const int32_t*, hipStream_t);
-int launch_advance(int32_t*, hipStream_t);
 
 static int check_cfg(const tsd_model_cfg* c) {
     TSD_REQUIRE(c != nullptr, "cfg is null");
@@ -105,41 +104,17 @@ static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base)
     return w;
 }
 
-// ---------------------------------------------------------------------------------------------
-// Two-stream forward.  The node-side chain of an interaction block (aggregate -> lin2 -> ssp -> lin ->
-// lin1) is a short dependent sequence on N = 1600 rows that can occupy ~100 of the 256 CUs; the filter
-// GEMMs of the NEXT block do not depend on it.  Stream B (library owned) therefore runs
-// edge_embed -> filter(0) -> filter(1) ... -> edge_embed(diff) while the caller's stream A runs the
-// node chain one block behind, joined by events.  Under stream capture the fork/join becomes two
-// parallel branches of the hipGraph.  TSDIFF_NO_OVERLAP=1 keeps everything on stream A.
-// ---------------------------------------------------------------------------------------------
-struct Overlap {
-    hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr, diff = nullptr;
-    hipEvent_t filt[64] = {};
-    bool enabled = false, fused = true, ready = false;
-};
-static Overlap g_ov[16];
-
-static int get_overlap(Overlap** out) {
-    int dev = 0;
-    TSD_HIP(hipGetDevice(&dev));
-    Overlap& o = g_ov[dev & 15];
-    if (!o.ready) {
-        // TSDIFF_FORWARD = fused (default) | streams | serial   (A/B switches; see kernels_combo.hip)
+// TSDIFF_FORWARD=serial selects the piecewise path (filter_gen for all layers, then aggregate + node_update
+// per block, checkpoints one after the other) -- the A/B baseline of the fused per-block launches.
+// (A two-stream variant, node chain || next block's filters joined by events, measured 1.07 ms/step under
+// hipGraph replay against 0.92 serial and was removed in favour of the in-kernel fusion, kernels_combo.hip.)
+static bool use_fused_path() {
+    static int cached = -1;
+    if (cached < 0) {
         const char* env = getenv("TSDIFF_FORWARD");
-        o.fused = !(env && (env[0] == 's'));
-        o.enabled = env && env[0] == 's' && env[1] == 't';
-        if (o.enabled) {
-            TSD_HIP(hipStreamCreateWithFlags(&o.side, hipStreamNonBlocking));
-            TSD_HIP(hipEventCreateWithFlags(&o.fork, hipEventDisableTiming));
-            TSD_HIP(hipEventCreateWithFlags(&o.diff, hipEventDisableTiming));
-            for (int l = 0; l < 64; ++l) TSD_HIP(hipEventCreateWithFlags(&o.filt[l], hipEventDisableTiming));
-        }
-        o.ready = true;
+        cached = (env && env[0] == 's') ? 0 : 1;
     }
-    *out = &o;
-    return TSD_OK;
+    return cached == 1;
 }
 
 // One forward per checkpoint on the current positions.  Every per-edge MLP runs on the UNDIRECTED
@@ -154,10 +129,6 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     const size_t H = c.hidden;
     const tsd_geometry& g = b.geo;
     int r;
-    Overlap* ov = nullptr;
-    if ((r = get_overlap(&ov))) return r;
-    const bool two = ov->enabled;
-    hipStream_t sb = two ? ov->side : st;
     if (!counts_ready) {
         if ((r = launch_geometry_count(c, N, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, g, st))) return r;
     }
@@ -165,7 +136,7 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
         return r;
     const Workspace w = carve(c, N, P, M, b.workspace);
     const size_t wfloats = weight_layout(c).total;
-    if (ov->fused) {
+    if (use_fused_path()) {
         // one launch per interaction block: node chain of block l || filter GEMMs of block l+1;
         // all M checkpoints in the same launches (grid.y)
         const float* W = b.weights;
@@ -194,24 +165,14 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
         return launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u, M, w.stride_nh, w.stride_ea,
                                   (size_t)PU, st);
     }
-    for (int m = 0; m < M; ++m) {
+    for (int m = 0; m < M; ++m) {  // piecewise path
         const float* W = b.weights + (size_t)m * wfloats;
-        if (two) {  // B starts after everything A has done so far (geometry, previous checkpoint)
-            TSD_HIP(hipEventRecord(ov->fork, st));
-            TSD_HIP(hipStreamWaitEvent(sb, ov->fork, 0));
-        }
-        if ((r = launch_edge_embed(c, W, PU, g.enc_u, w.ea, sb))) return r;
-        if ((r = launch_filter_gen(c, W, PU, g.enc_u, w.ea, w.wf, 0, two ? 1 : L, sb))) return r;
-        if (two) TSD_HIP(hipEventRecord(ov->filt[0], sb));
+        if ((r = launch_edge_embed(c, W, PU, g.enc_u, w.ea, st))) return r;
+        if ((r = launch_filter_gen(c, W, PU, g.enc_u, w.ea, w.wf, 0, L, st))) return r;
         TSD_HIP(hipMemcpyAsync(w.h, b.z + (size_t)m * N * H, (size_t)N * H * sizeof(float),
                                hipMemcpyDeviceToDevice, st));
         if ((r = launch_node_lin1(c, W, 0, N, w.h, w.x1, st))) return r;
         for (int l = 0; l < L; ++l) {
-            if (two && l + 1 < L) {
-                if ((r = launch_filter_gen(c, W, PU, g.enc_u, w.ea, w.wf, l + 1, 1, sb))) return r;
-                TSD_HIP(hipEventRecord(ov->filt[l + 1], sb));
-            }
-            if (two) TSD_HIP(hipStreamWaitEvent(st, ov->filt[l], 0));
             if ((r = launch_cfconv_aggregate(c.hidden, N, g.enc.row_ptr, g.enc.dst, g.enc.umap,
                                              w.wf + (size_t)l * PU * H, w.x1, w.agg, st)))
                 return r;
@@ -219,13 +180,7 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
                                         st)))
                 return r;
         }
-        // out edges whose (d, types) differ from their enc edge (only the hop == edge_order pairs when
-        // pred_edge_order < edge_order) are embedded on their own; every other out edge reuses its enc row
-        if ((r = launch_edge_embed(c, W, PU, g.diff_u, w.ea + (size_t)PU * H, sb))) return r;
-        if (two) {
-            TSD_HIP(hipEventRecord(ov->diff, sb));
-            TSD_HIP(hipStreamWaitEvent(st, ov->diff, 0));  // join: A is downstream of all of B's work
-        }
+        if ((r = launch_edge_embed(c, W, PU, g.diff_u, w.ea + (size_t)PU * H, st))) return r;
         if ((r = launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u + (size_t)m * PU, 1, 0, 0,
                                     0, st)))
             return r;
@@ -425,16 +380,15 @@ int tsd_sampler_step(int32_t kind, int32_t num_nodes, int32_t num_graphs, const 
 
 int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t kind, int32_t n_steps,
                     const float* coefs, const float* noises, float clip, float clip_pos, float* pos, float* traj,
-                    float* scratch, int32_t* status, int32_t use_graph, void* stream) {
+                    int32_t* status, int32_t use_graph, void* stream) {
     int r = check_cfg(cfg);
     if (r) return r;
-    TSD_REQUIRE(batch && coefs && noises && pos && scratch && status, "null pointer");
+    TSD_REQUIRE(batch && coefs && noises && pos && status, "null pointer");
     TSD_REQUIRE(kind == 0 || kind == 1, "kind=%d (0 = ld, 1 = ddpm)", kind);
     TSD_REQUIRE(n_steps >= 0, "n_steps=%d", n_steps);
     hipStream_t st = (hipStream_t)stream;
     if (n_steps == 0) return TSD_OK;
     int32_t* step_ctr = status + 1;  // status[1]: device-side step counter (offsets into coefs/noises/traj)
-    (void)scratch;
     const tsd_batch& b = *batch;
     TSD_HIP(hipMemsetAsync(step_ctr, 0, sizeof(int32_t), st));
     if ((r = launch_geometry_count(*cfg, b.num_nodes, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, b.geo,

@@ -299,12 +299,4 @@ int launch_sampler_step(int kind, int N, int G, const int32_t* graph_ptr, const 
     return TSD_OK;
 }
 
-__global__ void advance_kernel(int32_t* ctr) { *ctr += 1; }
-
-int launch_advance(int32_t* ctr, hipStream_t st) {
-    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1), 0, st, ctr);
-    TSD_LAUNCH_CHECK("advance");
-    return TSD_OK;
-}
-
 }  // namespace tsd

@@ -273,7 +273,7 @@ class DeviceBatch:
         with torch.cuda.stream(run_on):
             check(lib.tsd_sampler_run(C.byref(self.cfg), C.byref(b), kind, n_steps, ptr(coefs), ptr(noises),
                                       float(clip), float(-1.0 if clip_pos is None else clip_pos), ptr(pos),
-                                      ptr(traj), ptr(self.scratch), ptr(self.status), int(bool(use_graph)),
+                                      ptr(traj), ptr(self.status), int(bool(use_graph)),
                                       C.c_void_p(run_on.cuda_stream)))
         if side is not None:
             cur.wait_stream(side)

@@ -145,8 +145,20 @@ class CondenseEncoderEpsNetwork(nn.Module):
     # ------------------------------------------------------------------------------------------
     def forward(self, atom_type, r_feat, p_feat, pos, bond_index, bond_type, batch, time_step,
                 return_edges=True, **kwargs):
-        """reference condensenc.py:241-265; `time_step` and **kwargs are ignored there too."""
+        """reference condensenc.py:241-265; `time_step` and **kwargs are ignored there too.
+        With autograd enabled the result is differentiable w.r.t. the parameters (training primitives,
+        tsdiff_amd/train_ops.py); under torch.no_grad() the fused inference kernels run."""
         db = self.device_batch(atom_type, r_feat, p_feat, bond_index, bond_type, batch)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .. import train_ops as T
+            pos_c = pos.detach().to(torch.float32).contiguous()
+            s_u, _ = T.train_forward(self, db, pos_c)
+            E = db.out.num_edges()
+            edge_inv = s_u.index_select(0, db.out.umap[:E].long()).unsqueeze(-1)  # undirected -> directed order
+            if not return_edges:
+                return edge_inv
+            edge_index, edge_length, _, _ = db.edges_to_torch("out")
+            return edge_inv, edge_index, edge_length
         packed = self.packed_weights()
         db.bind_models([packed], key=("single", id(self), self._packed_key))
         db.forward(pos)
