@@ -251,10 +251,12 @@ int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t ki
 /* Y[rows,out] = X[rows,in] W[out,in]^T + b */
 int tsd_linear_fwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* b,
                    float* Y, void* stream);
-/* dX = dY W (NULL: skip); dW = dY^T X (NULL: skip); db = column sums of dY (NULL: skip; needs `scratch`
- * of 64*out floats for its deterministic two-stage reduction) */
+/* dX = dY W (NULL: skip); dW = dY^T X (NULL: skip); db = column sums of dY (NULL: skip).
+ * scratch: 64*out floats for the deterministic two-stage bias reduction; with >= 64*out*(in+1) floats the
+ * weight gradient of tall problems (rows >= 1024, out and in multiples of 128) runs on the hand-written
+ * row-split MFMA kernel instead of rocBLAS. */
 int tsd_linear_bwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* dY,
-                   float* dX, float* dW, float* db, float* scratch, void* stream);
+                   float* dX, float* dW, float* db, float* scratch, size_t scratch_floats, void* stream);
 /* kind 0: swish (utils/activation_functions.py), 1: shifted softplus (schnet.py:65-71), 2: ReLU, 3: softplus;
  * x = pre-activation */
 int tsd_act_fwd(int32_t kind, int64_t n, const float* x, float* y, void* stream);

@@ -454,3 +454,42 @@ def test_hidden128_large_graphs_and_differentiable_forward(dev):
     assert_close(inv_g.detach().cpu().numpy(), o_inv.numpy(), RTOL, "edge_inv (differentiable forward)")
     inv_g.sum().backward()
     assert model.grad_dist_mlp.layers[0].weight.grad is not None
+
+
+def test_training_primitives_at_scale(dev):
+    """the row-split MFMA wgrad kernel (only used for >= 1024 rows, beyond the goldens' sizes), the bias
+    reduction and the LDS-reduced embedding gradient against fp64 torch references"""
+    import ctypes as C
+    from tsdiff_amd import _lib
+    from tsdiff_amd.train_ops import _scratch
+    lib = _lib.load()
+    torch.manual_seed(0)
+    for rows, fin, out in [(5000, 256, 256), (4097, 512, 256), (1500, 256, 128), (9000, 128, 256)]:
+        X = torch.randn(rows, fin, device=dev)
+        W = torch.randn(out, fin, device=dev) * 0.05
+        dY = torch.randn(rows, out, device=dev)
+        dX = torch.empty_like(X)
+        dW = torch.full((out, fin), float("nan"), device=dev)
+        db = torch.empty(out, device=dev)
+        sc = _scratch(dev, 64 * out * (fin + 1))
+        _lib.check(lib.tsd_linear_bwd(rows, fin, out, _lib.ptr(X), _lib.ptr(W), _lib.ptr(dY), _lib.ptr(dX),
+                                      _lib.ptr(dW), _lib.ptr(db), _lib.ptr(sc), sc.numel(), _lib.stream_ptr()))
+        assert_close(dW.cpu().numpy(), (dY.double().t() @ X.double()).cpu().numpy(), 1e-5, f"dW {rows}x{fin}x{out}")
+        assert_close(dX.cpu().numpy(), (dY.double() @ W.double()).cpu().numpy(), 1e-5, "dX")
+        assert_close(db.cpu().numpy(), dY.double().sum(0).cpu().numpy(), 1e-5, "db")
+        dW2 = torch.empty_like(dW)  # deterministic: a second call is bit-identical
+        _lib.check(lib.tsd_linear_bwd(rows, fin, out, _lib.ptr(X), _lib.ptr(W), _lib.ptr(dY), None, _lib.ptr(dW2),
+                                      None, _lib.ptr(sc), sc.numel(), _lib.stream_ptr()))
+        assert torch.equal(dW, dW2)
+    rows, H = 20000, 256
+    x = torch.randn(rows, H, device=dev)
+    emb = torch.randn(100, H, device=dev)
+    idx = torch.randint(0, 26, (rows,), device=dev, dtype=torch.uint8)
+    dy = torch.randn(rows, H, device=dev)
+    dx = torch.empty_like(x)
+    demb = torch.zeros_like(emb)
+    _lib.check(lib.tsd_emb_mul_bwd(rows, H, _lib.ptr(x), _lib.ptr(emb), _lib.ptr(idx), _lib.ptr(dy), _lib.ptr(dx),
+                                   _lib.ptr(demb), _lib.stream_ptr()))
+    ref = torch.zeros(100, H, device=dev, dtype=torch.float64).index_add_(0, idx.long(), (dy * x).double())
+    assert_close(demb.cpu().numpy(), ref.cpu().numpy(), 1e-5, "demb")
+    assert_close(dx.cpu().numpy(), (dy * emb[idx.long()]).cpu().numpy(), 1e-6, "dx of emb_mul")

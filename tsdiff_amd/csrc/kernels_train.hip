@@ -54,6 +54,88 @@ int gemm_rm(bool transA, bool transB, int M, int N, int K, float alpha, const fl
 }
 
 // ---------------------------------------------------------------------------------------------
+// wgrad: dW[out,in] = dY[rows,out]^T X[rows,in] for the per-edge layers, where rows (26 k at batch 200)
+// is the contraction and out/in are 128..512 -- rocBLAS runs these as 4-8 workgroups (300 us each).
+// Here: grid (in/128, out/128, S row splits); a workgroup of 4 waves (2x2, each 64 out x 64 in = four
+// 32x32 accumulators) streams its row range through LDS in 32-row tiles (register-prefetched), the
+// S partial [out,in] blocks are then summed in split order by wgrad_reduce_kernel (deterministic).
+// A operand = dY^T: lane (i = out, k = row) reads dYs[row][out] -- consecutive lanes, consecutive words.
+// ---------------------------------------------------------------------------------------------
+constexpr int WG_T = 32;            // rows per tile
+constexpr int WG_LD = 128 + 4;      // LDS row stride (floats)
+__global__ __launch_bounds__(256) void wgrad_kernel(int rows, int in, int out, int rows_per_split,
+                                                    const float* __restrict__ dY, const float* __restrict__ X,
+                                                    float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float sY[WG_T * WG_LD];
+    __shared__ __attribute__((aligned(16))) float sX[WG_T * WG_LD];
+    const int in0 = blockIdx.x * 128, out0 = blockIdx.y * 128;
+    const int r_begin = blockIdx.z * rows_per_split, r_end = min(rows, r_begin + rows_per_split);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wo = (wave >> 1) * 64, wi = (wave & 1) * 64;  // this wave's 64 x 64 sub-block
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    // each thread stages 4 float4 of dY and 4 float4 of X per tile: (row = idx / 32, col4 = idx % 32)
+    f32x4 py[4], px[4];
+    auto prefetch = [&](int r0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + q * 256, r = idx >> 5, c4 = idx & 31;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            py[q] = z;
+            px[q] = z;
+            if (r0 + r < r_end) {
+                py[q] = *reinterpret_cast<const f32x4*>(dY + (size_t)(r0 + r) * out + out0 + c4 * 4);
+                px[q] = *reinterpret_cast<const f32x4*>(X + (size_t)(r0 + r) * in + in0 + c4 * 4);
+            }
+        }
+    };
+    if (r_begin < r_end) prefetch(r_begin);
+    for (int r0 = r_begin; r0 < r_end; r0 += WG_T) {
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + q * 256, r = idx >> 5, c4 = idx & 31;
+            *reinterpret_cast<f32x4*>(sY + r * WG_LD + c4 * 4) = py[q];
+            *reinterpret_cast<f32x4*>(sX + r * WG_LD + c4 * 4) = px[q];
+        }
+        __syncthreads();
+        if (r0 + WG_T < r_end) prefetch(r0 + WG_T);
+#pragma unroll 4
+        for (int kk = 0; kk < WG_T / 2; ++kk) {
+            const int row = 2 * kk + hi;
+            const float a0 = sY[row * WG_LD + wo + l31], a1 = sY[row * WG_LD + wo + 32 + l31];
+            const float b0 = sX[row * WG_LD + wi + l31], b1 = sX[row * WG_LD + wi + 32 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    float* P = part + (size_t)blockIdx.z * out * in;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = out0 + wo + a * 32 + acc_row(r, hi), i = in0 + wi + b * 32 + l31;
+                P[(size_t)o * in + i] = acc[a][b][r];
+            }
+}
+__global__ void wgrad_reduce_kernel(int64_t n, int S, const float* __restrict__ part, float* __restrict__ dW) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int k = 0; k < S; ++k) s += part[(size_t)k * n + i];
+    dW[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
 __global__ void bias_add_kernel(int64_t n, int cols, const float* __restrict__ b, float* __restrict__ y) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] += b[i % cols];
@@ -113,17 +195,37 @@ __global__ void emb_mul_fwd_kernel(int rows, int H, const float* __restrict__ x,
     const int r = (int)(i / H), c = (int)(i % H);
     y[i] = x[i] * emb[(size_t)idx[r] * H + c];
 }
-// dx = dy * emb[idx];  demb[idx] += dy * x  (atomics: <= 100 rows of H channels)
-__global__ void emb_mul_bwd_kernel(int rows, int H, const float* __restrict__ x, const float* __restrict__ emb,
-                                   const uint8_t* __restrict__ idx, const float* __restrict__ dy,
-                                   float* __restrict__ dx, float* __restrict__ demb) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)rows * H) return;
-    const int r = (int)(i / H), c = (int)(i % H);
-    const size_t e = (size_t)idx[r] * H + c;
-    const float g = dy[i];
-    dx[i] = g * emb[e];
-    atomicAdd(demb + e, g * x[i]);
+// dx = dy * emb[idx];  demb[idx] += dy * x.  Edge types take ~25 distinct values, so plain atomics from
+// every (row, channel) serialise on a few addresses (190 us): each workgroup (64 channels x a chunk of
+// rows) first sums per type in LDS, then issues one atomic per (type, channel) it has seen.
+constexpr int EMB_ROWS = 100;   // nn.Embedding(100, H)
+__global__ __launch_bounds__(256) void emb_mul_bwd_kernel(int rows, int H, int rows_per_wg,
+                                                          const float* __restrict__ x,
+                                                          const float* __restrict__ emb,
+                                                          const uint8_t* __restrict__ idx,
+                                                          const float* __restrict__ dy, float* __restrict__ dx,
+                                                          float* __restrict__ demb) {
+    __shared__ float acc[EMB_ROWS][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int w = threadIdx.x >> 6;
+    for (int t = threadIdx.x; t < EMB_ROWS * 64; t += 256) acc[t / 64][t % 64] = 0.0f;
+    __syncthreads();
+    const int r0 = blockIdx.y * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
+    if (c < H) {
+        for (int r = r0 + w; r < r1; r += 4) {
+            const int ty = min((int)idx[r], EMB_ROWS - 1);
+            const size_t o = (size_t)r * H + c;
+            const float g = dy[o];
+            dx[o] = g * emb[(size_t)ty * H + c];
+            atomicAdd(&acc[ty][threadIdx.x & 63], g * x[o]);  // LDS atomic, 4 waves share a column
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < EMB_ROWS * 64; t += 256) {
+        const int ty = t / 64, cc = blockIdx.x * 64 + (t % 64);
+        const float v = acc[ty][t % 64];
+        if (v != 0.0f && cc < H) atomicAdd(demb + (size_t)ty * H + cc, v);
+    }
 }
 
 // y[r,:] = table[idx[r],:]  /  dtable[idx[r],:] += dy[r,:]   (atom_embedding, condensenc.py:193)
@@ -282,13 +384,23 @@ int tsd_linear_fwd(int32_t rows, int32_t in, int32_t out, const float* X, const 
 }
 
 int tsd_linear_bwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* dY, float* dX,
-                   float* dW, float* db, float* scratch, void* stream) {
+                   float* dW, float* db, float* scratch, size_t scratch_floats, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     int r;
     if (dX && (r = gemm_rm(false, false, rows, in, out, 1.0f, dY, out, W, in, 0.0f, dX, in, st))) return r;  // dY W
     if (dW) {
+        const int S = rows >= 4096 ? 64 : (rows >= 1024 ? 16 : 0);  // row splits of the hand-written wgrad
         if (rows == 0) {
             TSD_HIP(hipMemsetAsync(dW, 0, (size_t)out * in * sizeof(float), st));
+        } else if (S > 0 && scratch && scratch_floats >= (size_t)S * out * in + 64 * (size_t)out &&
+                   out % 128 == 0 && in % 128 == 0) {
+            const int per = ((rows + S - 1) / S + WG_T - 1) / WG_T * WG_T;
+            float* part = scratch + 64 * (size_t)out;  // the first 64*out floats belong to the bias reduction
+            hipLaunchKernelGGL(wgrad_kernel, dim3(in / 128, out / 128, S), dim3(256), 0, st, rows, in, out, per, dY, X,
+                               part);
+            const int64_t n = (int64_t)out * in;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(n)), dim3(256), 0, st, n, S, part, dW);
+            TSD_LAUNCH_CHECK("wgrad");
         } else if ((r = gemm_rm(true, false, out, in, rows, 1.0f, dY, out, X, in, 0.0f, dW, in, st))) {  // dY^T X
             return r;
         }
@@ -351,8 +463,10 @@ int tsd_emb_mul_fwd(int32_t rows, int32_t H, const float* x, const float* emb, c
 int tsd_emb_mul_bwd(int32_t rows, int32_t H, const float* x, const float* emb, const uint8_t* idx, const float* dy,
                     float* dx, float* demb, void* stream) {
     if (rows == 0) return TSD_OK;
-    hipLaunchKernelGGL(emb_mul_bwd_kernel, dim3(blocks_for((int64_t)rows * H)), dim3(256), 0, (hipStream_t)stream,
-                       rows, H, x, emb, idx, dy, dx, demb);
+    const int chunks = (rows + 255) / 256 < 512 ? (rows + 255) / 256 : 512;
+    const int per = (rows + chunks - 1) / chunks;
+    hipLaunchKernelGGL(emb_mul_bwd_kernel, dim3((H + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, rows, H, per,
+                       x, emb, idx, dy, dx, demb);
     TSD_LAUNCH_CHECK("emb_mul_bwd");
     return TSD_OK;
 }

@@ -59,9 +59,9 @@ class Linear(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dW = torch.empty_like(W) if ctx.needs_input_grad[1] else None
         db = torch.empty(out, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        sc = _scratch(x.device, 64 * out) if db is not None else None
+        sc = _scratch(x.device, 64 * out * (fin + 1))  # bias partials + row-split wgrad partials
         check(lib.tsd_linear_bwd(rows, fin, out, ptr(x), ptr(W), ptr(dy), ptr(dx), ptr(dW), ptr(db), ptr(sc),
-                                 stream_ptr()))
+                                 sc.numel(), stream_ptr()))
         return dx, dW, db
 
 
