@@ -109,6 +109,9 @@ class EasyDict(dict):
     __setitem__ = __setattr__
 
 
+EasyDict.__module__ = "easydict"  # pickles (checkpoints) must name the class as the real package does
+
+
 def scatter(src, index, dim=0, out=None, dim_size=None, reduce="sum"):
     assert dim == 0
     if dim_size is None:
