@@ -106,3 +106,14 @@ def test_reference_checkpoint_round_trip(tmp_path):
     ck2 = io.load_checkpoint(p)
     assert ck2["iteration"] == 7 and ck2["config"]["model"]["hidden_dim"] == 64
     assert all(torch.equal(ck2["model"][k], model.state_dict()[k]) for k in model.state_dict())
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/tsdiff_hip.h must be consumable from C (cgo / JNI / ctypes generators): compile a C99
+    translation unit that includes it and references every declared function"""
+    import subprocess
+    names = _declared_symbols()
+    src = tmp_path / "abi.c"
+    src.write_text('#include "tsdiff_hip.h"\n' + "void* table[] = {" + ", ".join(f"(void*){n}" for n in names) + "};\n")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
+                    "-o", str(tmp_path / "abi.o")], check=True)
