@@ -493,3 +493,32 @@ def test_training_primitives_at_scale(dev):
     ref = torch.zeros(100, H, device=dev, dtype=torch.float64).index_add_(0, idx.long(), (dy * x).double())
     assert_close(demb.cpu().numpy(), ref.cpu().numpy(), 1e-5, "demb")
     assert_close(dx.cpu().numpy(), (dy * emb[idx.long()]).cpu().numpy(), 1e-6, "dx of emb_mul")
+
+
+def test_degenerate_batches(dev):
+    """no pair at all (single-atom graphs only); a graph above TSD_MAX_GRAPH_NODES -> NotImplementedError"""
+    from tsdiff_amd import synth
+    from tsdiff_amd.sampler import EnsembleSampler
+    cfg = synth.small_model_config(64, 2)
+    model = make_model(cfg, 4, dev)
+    F = cfg["feat_dim"]
+    atom = torch.tensor([6, 1, 8], device=dev)
+    feat = torch.zeros(3, F, dtype=torch.long, device=dev)
+    pos = torch.randn(3, 3, device=dev)
+    bi = torch.zeros(2, 0, dtype=torch.long, device=dev)
+    bt = torch.zeros(0, dtype=torch.long, device=dev)
+    batch = torch.tensor([0, 1, 2], device=dev)
+    with torch.no_grad():
+        edge_inv, ei, el = model(atom, feat, feat, pos, bi, bt, batch, torch.zeros(3, dtype=torch.long, device=dev))
+    assert edge_inv.shape == (0, 1) and ei.shape == (2, 0) and el.shape == (0, 1)
+    noises = torch.zeros(4, 3, 3, device=dev)
+    p, traj = EnsembleSampler([model]).dynamic_sampling(atom, feat, feat, pos, bi, bt, batch, 3, True, n_steps=4,
+                                                        step_lr=1e-7, clip=1000, sampling_type="ld", noises=noises)
+    assert torch.equal(p, torch.zeros_like(p))  # every graph is its own centroid
+    n = 300
+    big = synth.wb97xd3_like_batch(1, seed=3, n_lo=n, n_hi=n)
+    g = to_dev({k: torch.from_numpy(v) for k, v in big.items() if isinstance(v, np.ndarray)}, dev)
+    with pytest.raises(NotImplementedError):
+        with torch.no_grad():
+            model(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"],
+                  torch.zeros(1, dtype=torch.long, device=dev))

@@ -123,6 +123,47 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ A, const 
     out[(size_t)blockIdx.x * 256 + tid] = s;
 }
 
+// 8 waves x 32 columns (the layout of the fused per-block launch's filter role)
+template <int PF>
+__global__ __launch_bounds__(512) void probe8(const float* __restrict__ A, const float* __restrict__ W, int nrep,
+                                              float* __restrict__ out) {
+    constexpr int T = 32, LDA = H + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < T * H; idx += 512) smem[(idx / H) * LDA + (idx % H)] = A[idx];
+    __syncthreads();
+    const int col0 = (tid >> 6) * 32;
+    f32x16 acc[1][1];
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    for (int rep = 0; rep < nrep; ++rep) {
+        const float* Wr = W + (size_t)(rep & 1) * H * H;
+        gemm_v1<1, 1, H, PF, false>(smem, LDA, Wr, H, col0, acc, 0);
+    }
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += acc[0][0][r];
+    out[(size_t)blockIdx.x * 512 + tid] = s;
+}
+
+template <int PF>
+static void run8(const char* name, int grid, int nrep, const float* A, const float* W, float* out) {
+    const size_t lds = (size_t)32 * (H + 4) * 4;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((probe8<PF>), dim3(grid), dim3(512), lds, 0, A, W, nrep, out);
+    hipEventRecord(e0, 0);
+    const int it = 5;
+    for (int w = 0; w < it; ++w) hipLaunchKernelGGL((probe8<PF>), dim3(grid), dim3(512), lds, 0, A, W, nrep, out);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= it;
+    const double flop = (double)grid * nrep * 32.0 * H * H * 2.0;
+    printf("%-34s grid %5d nrep %2d      : %8.1f us  %6.1f TFLOP/s\n", name, grid, nrep, ms * 1e3,
+           flop / (ms * 1e-3) / 1e12);
+}
+
 template <int VAR, int RB>
 static void run(const char* name, int grid, int nrep, const float* A, const float* W, float* out) {
     const size_t lds = (size_t)32 * RB * (H + 4) * 4;
@@ -153,9 +194,16 @@ int main() {
     for (auto& v : hW) v = ((rand() / (float)RAND_MAX) - 0.5f) * 0.1f;
     hipMalloc(&A, hA.size() * 4);
     hipMalloc(&W, hW.size() * 4);
-    hipMalloc(&out, (size_t)8192 * 256 * 4);
+    hipMalloc(&out, (size_t)8192 * 512 * 4);
     hipMemcpy(A, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(W, hW.data(), hW.size() * 4, hipMemcpyHostToDevice);
+    for (int g : {408, 815, 2048}) {
+        run<1, 1>("4 waves x 64 cols, chunk4", g, 2, A, W, out);
+        run8<4>("8 waves x 32 cols, chunk4", g, 2, A, W, out);
+        run8<8>("8 waves x 32 cols, chunk8", g, 2, A, W, out);
+        run8<2>("8 waves x 32 cols, chunk2", g, 2, A, W, out);
+        printf("\n");
+    }
     const int grids[] = {50, 256, 815, 2048, 4096};
     for (int g : grids) {
         run<0, 1>("v0 pf1", g, 2, A, W, out);
