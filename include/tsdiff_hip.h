@@ -203,6 +203,7 @@ typedef struct tsd_batch {
     const uint16_t* pair_code;  /* [P] */
     const float* weights;       /* [M, packed_floats] */
     const float* z;             /* [M, N, H] node embeddings (tsd_node_embed), pos independent */
+    const float* x1_0;          /* [M, N, H] lin1 of block 0 applied to z (tsd_node_lin1), pos independent */
     tsd_geometry geo;
     float* workspace;           /* tsd_forward_workspace_floats */
     float* edge_inv_u;          /* [M, P/2] per-checkpoint output on the undirected out list */

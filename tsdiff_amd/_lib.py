@@ -78,6 +78,7 @@ class Batch(C.Structure):
         ("pair_code", C.c_void_p),
         ("weights", C.c_void_p),
         ("z", C.c_void_p),
+        ("x1_0", C.c_void_p),
         ("geo", Geometry),
         ("workspace", C.c_void_p),
         ("edge_inv_u", C.c_void_p),

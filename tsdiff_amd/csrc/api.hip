@@ -49,8 +49,9 @@ int launch_filter_gen(const tsd_model_cfg&, const float*, int, tsd_edges, const 
                       hipStream_t);
 int launch_edge_embed2(const tsd_model_cfg&, const float*, int, tsd_edges, float*, int, tsd_edges, float*, int,
                        size_t, hipStream_t);
-int launch_layer_combo(const tsd_model_cfg&, const float*, int, int, tsd_edges, const float*, const float*, float*,
-                       float*, int, int, tsd_edges, const float*, float*, int, size_t, size_t, size_t, hipStream_t);
+int launch_layer_combo(const tsd_model_cfg&, const float*, int, int, tsd_edges, const float*, const float*,
+                       const float*, float*, float*, int, int, tsd_edges, const float*, float*, int, size_t, size_t,
+                       size_t, hipStream_t);
 int launch_node_embed(const tsd_model_cfg&, const float*, int, const int64_t*, const int64_t*, const int64_t*,
                       float*, hipStream_t);
 int launch_cfconv_aggregate(int, int, const int32_t*, const int32_t*, const int32_t*, const float*,
@@ -142,25 +143,25 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
         const float* W = b.weights;
         if ((r = launch_edge_embed2(c, W, PU, g.enc_u, w.ea, PU, g.diff_u, w.ea + (size_t)PU * H, M, w.stride_ea, st)))
             return r;
-        if (w.stride_nh == (size_t)N * H) {
-            TSD_HIP(hipMemcpyAsync(w.h, b.z, (size_t)M * N * H * sizeof(float), hipMemcpyDeviceToDevice, st));
-        } else {
-            for (int m = 0; m < M; ++m)
-                TSD_HIP(hipMemcpyAsync(w.h + m * w.stride_nh, b.z + (size_t)m * N * H, (size_t)N * H * sizeof(float),
-                                       hipMemcpyDeviceToDevice, st));
+        // block 0 reads z (residual input) and x1_0 = lin1_0(z) straight from the per-batch arrays -- both are
+        // pos independent (computed at bind time) -- so no per-step copy of z and no lin1 launch
+        if (w.stride_nh != (size_t)N * H) {
+            set_error("internal: node stride mismatch");
+            return TSD_ERR_INVALID;
         }
-        float* xa = w.x1;
-        float* xb = w.x1b;
-        if ((r = launch_layer_combo(c, W, -1, N, g.enc, nullptr, nullptr, w.h, xa, 0, PU, g.enc_u, w.ea, w.wf, M,
-                                    w.stride_nh, w.stride_ea, w.stride_wf, st)))
+        if ((r = launch_layer_combo(c, W, -2, N, g.enc, nullptr, nullptr, nullptr, w.h, w.x1, 0, PU, g.enc_u, w.ea, w.wf,
+                                    M, w.stride_nh, w.stride_ea, w.stride_wf, st)))
             return r;
+        const float* xin = b.x1_0;
+        float* xout = w.x1;
         for (int l = 0; l < L; ++l) {
             const int fl = (l + 1 < L) ? l + 1 : -1;
-            if ((r = launch_layer_combo(c, W, l, N, g.enc, w.wf + (size_t)l * PU * H, xa, w.h, xb, fl, PU, g.enc_u, w.ea,
-                                        w.wf + (size_t)(l + 1 < L ? l + 1 : 0) * PU * H, M, w.stride_nh, w.stride_ea,
-                                        w.stride_wf, st)))
+            if ((r = launch_layer_combo(c, W, l, N, g.enc, w.wf + (size_t)l * PU * H, xin, l == 0 ? b.z : w.h, w.h, xout,
+                                        fl, PU, g.enc_u, w.ea, w.wf + (size_t)(l + 1 < L ? l + 1 : 0) * PU * H, M,
+                                        w.stride_nh, w.stride_ea, w.stride_wf, st)))
                 return r;
-            float* t = xa; xa = xb; xb = t;
+            xin = xout;
+            xout = (xout == w.x1) ? w.x1b : w.x1;
         }
         return launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u, M, w.stride_nh, w.stride_ea,
                                   (size_t)PU, st);
@@ -308,8 +309,8 @@ int tsd_interaction_block(const tsd_model_cfg* cfg, const float* w, int32_t laye
     TSD_REQUIRE(layer < 0 || (Wf_layer && x1_in && enc.row_ptr && enc.dst && enc.umap && x1_in != x1_out),
                 "node role needs Wf_layer, x1_in != x1_out and the directed enc list");
     TSD_REQUIRE(filter_layer < 0 || (edge_attr && Wf_out && enc_u.count && enc_u.dist), "filter role: null pointer");
-    return launch_layer_combo(*cfg, w, layer, num_nodes, enc, Wf_layer, x1_in, h, x1_out, filter_layer, capacity_u,
-                              enc_u, edge_attr, Wf_out, 1, 0, 0, 0, (hipStream_t)stream);
+    return launch_layer_combo(*cfg, w, layer, num_nodes, enc, Wf_layer, x1_in, nullptr, h, x1_out, filter_layer,
+                              capacity_u, enc_u, edge_attr, Wf_out, 1, 0, 0, 0, (hipStream_t)stream);
 }
 
 int tsd_cfconv_aggregate(int32_t hidden, int32_t num_nodes, const int32_t* row_ptr, const int32_t* dst,
@@ -354,6 +355,7 @@ int tsd_score_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
     if (r) return r;
     TSD_REQUIRE(batch && pos, "null pointer");
     TSD_REQUIRE(batch->num_models >= 1, "num_models=%d", batch->num_models);
+    TSD_REQUIRE(batch->z && batch->x1_0 && batch->weights && batch->workspace && batch->edge_inv_u, "null batch pointer");
     return forward_impl(*cfg, *batch, pos, (hipStream_t)stream);
 }
 

@@ -23,7 +23,8 @@ struct ComboNode {
     const int32_t *row_ptr, *dst, *umap;
     const float* Wf;  // this block's filters on the undirected list [Eu, H]
     const float* x1_in;
-    float* h;
+    const float* h_in;  // residual input (block 0 reads the pos-independent node embedding z directly)
+    float* h;           // residual output
     float* x1_out;
     const float *lin2_w, *lin2_b, *lin_w, *lin_b, *lin1_next_w;
 };
@@ -166,7 +167,7 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
                 float hn = 0.0f;
                 if (row < nrows) {
                     const size_t o = (size_t)(n0 + row) * H + col;
-                    hn = a.h[o] + (acc[cb][r] + b);
+                    hn = a.h_in[o] + (acc[cb][r] + b);
                     a.h[o] = hn;
                 }
                 buf[row * LDA + col] = hn;
@@ -178,7 +179,7 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
         for (int idx = tid; idx < TN * C4; idx += NT) {
             const int r = idx / C4, c4 = idx % C4;
             f32x4 v = zero4;
-            if (r < nrows) v = *reinterpret_cast<const f32x4*>(a.h + (size_t)(n0 + r) * H + c4 * 4);
+            if (r < nrows) v = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)(n0 + r) * H + c4 * 4);
             *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = v;
         }
         __syncthreads();
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
     {
         const size_t m = blockIdx.y;
         const size_t wo = m * sd.w, no = m * sd.nh;
-        a.Wf += m * sd.wf; a.x1_in += no; a.h += no; a.x1_out += no;
+        a.Wf += m * sd.wf; a.x1_in += no; a.h_in += no; a.h += no; a.x1_out += no;
         a.lin2_w += wo; a.lin2_b += wo; a.lin_w += wo; a.lin_b += wo;
         if (a.lin1_next_w) a.lin1_next_w += wo;
         f.nn0_w += wo; f.nn0_b += wo; f.nn2_w += wo; f.nn2_b += wo;
@@ -287,9 +288,10 @@ static inline size_t lds_combo(int H) {
     return node > filt ? node : filt;
 }
 
-// layer < 0: node role = lin1 of block 0 only.  filter_layer < 0: no filter role.
+// layer == -1: node role = lin1 of block 0 only; layer == -2: no node role.  filter_layer < 0: no filter role.
 int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N, tsd_edges enc,
-                       const float* Wf_layer, const float* x1_in, float* h, float* x1_out, int filter_layer,
+                       const float* Wf_layer, const float* x1_in, const float* h_in, float* h, float* x1_out,
+                       int filter_layer,
                        int capacity_u, tsd_edges enc_u, const float* edge_attr, float* Wf_out, int M, size_t nh_stride,
                        size_t ea_stride, size_t wf_stride, hipStream_t st) {
     const WeightLayout L = weight_layout(c);
@@ -300,6 +302,7 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     a.umap = enc.umap;
     a.Wf = Wf_layer;
     a.x1_in = x1_in;
+    a.h_in = h_in ? h_in : h;
     a.h = h;
     a.x1_out = x1_out;
     if (layer < 0) {
@@ -328,7 +331,7 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
         f.edge_attr = edge_attr;
         f.out = Wf_out;
     }
-    const int node_tiles = (N + TN - 1) / TN;
+    const int node_tiles = layer == -2 ? 0 : (N + TN - 1) / TN;
     const int grid = node_tiles + f.tiles;
     if (grid == 0) return TSD_OK;
     const size_t lds = lds_combo(c.hidden);

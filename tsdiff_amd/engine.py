@@ -194,9 +194,12 @@ class DeviceBatch:
         H = self.cfg.hidden
         self.weights = torch.stack(packed_list) if M > 1 else packed_list[0].reshape(1, -1)
         self.z = torch.empty(M, max(self.N, 1), H, dtype=torch.float32, device=self.device)
-        for m in range(M):
+        self.x1_0 = torch.empty(M, max(self.N, 1), H, dtype=torch.float32, device=self.device)
+        for m in range(M):  # both are pos independent: once per batch and checkpoint
             check(lib.tsd_node_embed(C.byref(self.cfg), ptr(self.weights[m]), self.N, ptr(self.atom_type),
                                      ptr(self.r_feat), ptr(self.p_feat), ptr(self.z[m]), stream_ptr()))
+            check(lib.tsd_node_lin1(C.byref(self.cfg), ptr(self.weights[m]), 0, self.N, ptr(self.z[m]),
+                                    ptr(self.x1_0[m]), stream_ptr()))
         nws = lib.tsd_forward_workspace_floats(C.byref(self.cfg), self.N, self.P, M)
         if self.workspace is None or self.workspace.numel() < nws:
             self.workspace = torch.empty(max(nws, 1), dtype=torch.float32, device=self.device)
@@ -215,7 +218,7 @@ class DeviceBatch:
             num_nodes=self.N, num_graphs=self.G, num_pairs=self.P, num_models=self.M,
             graph_ptr=self.graph_ptr.data_ptr(), node_graph=self.node_graph.data_ptr(),
             pair_ptr=self.pair_ptr.data_ptr(), pair_code=self.pair_code.data_ptr(),
-            weights=self.weights.data_ptr(), z=self.z.data_ptr(),
+            weights=self.weights.data_ptr(), z=self.z.data_ptr(), x1_0=self.x1_0.data_ptr(),
             geo=self.geo_struct(), workspace=self.workspace.data_ptr(),
             edge_inv_u=self.edge_inv_u.data_ptr())
 
