@@ -491,7 +491,33 @@ __global__ __launch_bounds__(64) void step_post_kernel(int kind, int N, int M, i
         const float px = old_s[3 * il], py = old_s[3 * il + 1], pz = old_s[3 * il + 2];
         float ax = 0.f, ay = 0.f, az = 0.f;
         const int e1 = out.row_ptr[i + 1];
-        for (int e = out.row_ptr[i]; e < e1; ++e) {
+        int e = out.row_ptr[i];
+        // 4 edges per round: their index / distance loads and then their edge_inv gathers are independent,
+        // only the adds keep the edge order (the serial chain was 1 us per edge)
+        for (; e + 4 <= e1; e += 4) {
+            int jl[4], u[4];
+            float dd[4], sv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                jl[q] = out.dst[e + q] - lo;
+                u[q] = out.umap[e + q];
+                dd[q] = out.dist[e + q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float s = inv_u[u[q]];
+                for (int m = 1; m < M; ++m) s = __fadd_rn(s, inv_u[(size_t)m * PU + u[q]]);
+                sv[q] = s / (float)M;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float inv = 1.0f / dd[q];
+                ax = __fadd_rn(ax, __fmul_rn(__fmul_rn(inv, px - old_s[3 * jl[q]]), sv[q]));
+                ay = __fadd_rn(ay, __fmul_rn(__fmul_rn(inv, py - old_s[3 * jl[q] + 1]), sv[q]));
+                az = __fadd_rn(az, __fmul_rn(__fmul_rn(inv, pz - old_s[3 * jl[q] + 2]), sv[q]));
+            }
+        }
+        for (; e < e1; ++e) {
             const int jl = out.dst[e] - lo;
             const int u = out.umap[e];
             float s = inv_u[u];
