@@ -102,6 +102,9 @@ typedef struct tsd_geometry {
 } tsd_geometry;
 
 const char* tsd_version(void);
+/* Edge rows per workgroup tile of the filter role of tsd_interaction_block / tsd_score_forward:
+ * 0 = default (32), or force 32 / 64 (process-wide; 64 measured slower at every size, kept as an A/B knob). */
+int tsd_set_filter_tile(int32_t rows);
 const char* tsd_last_error(void);
 
 /* ---- weights ---------------------------------------------------------------------------

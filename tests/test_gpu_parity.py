@@ -522,3 +522,22 @@ def test_degenerate_batches(dev):
         with torch.no_grad():
             model(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"],
                   torch.zeros(1, dtype=torch.long, device=dev))
+
+
+def test_filter_tile_64_is_bit_identical_to_32(dev):
+    """the 64-edge filter tiles used for large launches compute every row exactly like the 32-edge tiles"""
+    from tsdiff_amd import _lib, synth
+    lib = _lib.load()
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    model = make_model(cfg, 0, dev)
+    b = synth.wb97xd3_like_batch(30, seed=2)
+    g = to_dev({k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}, dev)
+    g["pos"] = g["pos"] * 2.0
+    outs = []
+    try:
+        for rows in (32, 64):
+            _lib.check(lib.tsd_set_filter_tile(rows))
+            outs.append(run_forward(model, {**g, "num_graphs": 30}, dev)[0].clone())
+    finally:
+        _lib.check(lib.tsd_set_filter_tile(0))
+    assert torch.equal(outs[0], outs[1])

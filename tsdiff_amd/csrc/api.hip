@@ -64,6 +64,8 @@ int launch_ensemble_mean(int, int, tsd_edges, const float*, float*, hipStream_t)
 int launch_sampler_step(int, int, int, const int32_t*, const float*, const float*, const float*, float, float,
                         float*, float*, int32_t*, const int32_t*, hipStream_t);
 
+extern int g_filter_rows;
+
 static int check_cfg(const tsd_model_cfg* c) {
     TSD_REQUIRE(c != nullptr, "cfg is null");
     TSD_REQUIRE(hidden_supported(c->hidden), "hidden=%d unsupported (64/128/256)", c->hidden);
@@ -206,6 +208,12 @@ static int step_impl(const tsd_model_cfg& c, const tsd_batch& b, int kind, const
 using namespace tsd;
 
 extern "C" {
+
+int tsd_set_filter_tile(int32_t rows) {
+    TSD_REQUIRE(rows == 0 || rows == 32 || rows == 64, "filter tile rows must be 0 (auto), 32 or 64");
+    g_filter_rows = rows;
+    return TSD_OK;
+}
 
 const char* tsd_version(void) { return "tsdiff_hip 0.1 (gfx950, fp32 MFMA)"; }
 const char* tsd_last_error(void) { return g_err; }

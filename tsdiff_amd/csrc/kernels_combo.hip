@@ -202,24 +202,27 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
 // filter role: Wf[e] = nn2(ssp(nn0(edge_attr[e]))) * C(e) for one tile of 32 undirected edges,
 // H/32 waves x 32 columns (the 256-thread stand-alone form is filter_gen_kernel in kernels_mlp.hip)
 // -------------------------------------------------------------------------------------------------
-template <int H>
+// RB = 1: tiles of 32 edges (the default); RB = 2: tiles of 64 edges (every B fragment fetched from L2 feeds
+// twice the MFMAs; faster in the 4-wave probe, slower here -- see launch_layer_combo).  Bit-identical rows.
+template <int H, int RB>
 __device__ __forceinline__ void filter_role(const ComboFilter& f, int tile, float* smem) {
+    constexpr int TR = T * RB;
     constexpr int LDA = H + 4;
     constexpr int NT = 2 * H;
     constexpr int C4 = H / 4;
     float* buf = smem;
-    float* s_c = smem + T * LDA;
+    float* s_c = smem + TR * LDA;
 
     const int E = *f.e.count;
-    const int e0 = tile * T;
+    const int e0 = tile * TR;
     if (e0 >= E) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int col0 = (tid >> 6) * 32;
-    const int nrows = min(T, E - e0);
+    const int nrows = min(TR, E - e0);
 
-    if (tid < T) s_c[tid] = (tid < nrows && f.e.dist[e0 + tid] <= f.conv_cutoff) ? 1.0f : 0.0f;
-    for (int idx = tid; idx < T * C4; idx += NT) {
+    if (tid < TR) s_c[tid] = (tid < nrows && f.e.dist[e0 + tid] <= f.conv_cutoff) ? 1.0f : 0.0f;
+    for (int idx = tid; idx < TR * C4; idx += NT) {
         const int r = idx / C4, c4 = idx % C4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (r < nrows) v = *reinterpret_cast<const f32x4*>(f.edge_attr + (size_t)(e0 + r) * H + c4 * 4);
@@ -227,29 +230,33 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int tile, floa
     }
     __syncthreads();
 
-    f32x16 acc[1][1];
+    f32x16 acc[RB][1];
     zero_acc(acc);
-    gemm_tile<1, 1, H>(buf, LDA, f.nn0_w, H, col0, acc);
+    gemm_tile<RB, 1, H>(buf, LDA, f.nn0_w, H, col0, acc);
     __syncthreads();
     {
         const int col = col0 + l31;
         const float b = f.nn0_b[col];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) buf[acc_row(r, hi) * LDA + col] = sspf(acc[0][0][r] + b);
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) buf[(rb * 32 + acc_row(r, hi)) * LDA + col] = sspf(acc[rb][0][r] + b);
     }
     __syncthreads();
 
     zero_acc(acc);
-    gemm_tile<1, 1, H>(buf, LDA, f.nn2_w, H, col0, acc);
+    gemm_tile<RB, 1, H>(buf, LDA, f.nn2_w, H, col0, acc);
     __syncthreads();
     {
         const int col = col0 + l31;
         const float b = f.nn2_b[col];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = acc_row(r, hi);
-            buf[row * LDA + col] = (acc[0][0][r] + b) * s_c[row];
-        }
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rb * 32 + acc_row(r, hi);
+                buf[row * LDA + col] = (acc[rb][0][r] + b) * s_c[row];
+            }
     }
     __syncthreads();
     for (int idx = tid; idx < nrows * C4; idx += NT) {
@@ -263,7 +270,7 @@ struct ComboStride {  // per-checkpoint strides (blockIdx.y = checkpoint of the 
     size_t w, nh, ea, wf;
 };
 
-template <int H>
+template <int H, int RB>
 __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int node_tiles, ComboFilter f,
                                                             ComboStride sd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -279,14 +286,16 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
     if ((int)blockIdx.x < node_tiles)
         node_role<H>(a, blockIdx.x, smem);
     else
-        filter_role<H>(f, blockIdx.x - node_tiles, smem);
+        filter_role<H, RB>(f, blockIdx.x - node_tiles, smem);
 }
 
-static inline size_t lds_combo(int H) {
+static inline size_t lds_combo(int H, int RB) {
     const size_t node = (size_t)TN * (H + 4) * 4;
-    const size_t filt = (size_t)(T * (H + 4) + T) * 4;
+    const size_t filt = (size_t)(T * RB * (H + 4) + T * RB) * 4;
     return node > filt ? node : filt;
 }
+
+int g_filter_rows = 0;  // 0: automatic, 32 / 64: forced (tsd_set_filter_tile; tests and A/B runs)
 
 // layer == -1: node role = lin1 of block 0 only; layer == -2: no node role.  filter_layer < 0: no filter role.
 int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N, tsd_edges enc,
@@ -317,11 +326,15 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
         a.lin_b = B + L.L_lin_b;
         a.lin1_next_w = (layer + 1 < c.num_convs) ? B + L.layer_stride + L.L_lin1_w : nullptr;
     }
+    // 32-edge filter tiles unless 64 is forced (tsd_set_filter_tile): in this 8-wave layout the 64-edge
+    // tiles measured SLOWER at every size (C5 55.6 vs 53.7 ms/step, M=8 3.60 vs 3.43, batch 1600 6.48 vs 6.12):
+    // 66 KB of LDS halve the resident workgroups, which costs more than the halved B traffic gains.
+    const int RBsel = g_filter_rows == 64 ? 2 : 1;
     ComboFilter f{};
     f.tiles = 0;
     if (filter_layer >= 0) {
         const float* B = W + L.layer0 + (size_t)filter_layer * L.layer_stride;
-        f.tiles = (capacity_u + T - 1) / T;
+        f.tiles = (capacity_u + T * RBsel - 1) / (T * RBsel);
         f.nn0_w = B + L.L_nn0_w;
         f.nn0_b = B + L.L_nn0_b;
         f.nn2_w = B + L.L_nn2_w;
@@ -334,16 +347,20 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     const int node_tiles = layer == -2 ? 0 : (N + TN - 1) / TN;
     const int grid = node_tiles + f.tiles;
     if (grid == 0) return TSD_OK;
-    const size_t lds = lds_combo(c.hidden);
+    const size_t lds = lds_combo(c.hidden, RBsel);
     const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride};
-#define TSD_COMBO(HH)                                                                                         \
+#define TSD_COMBO_RB(HH, RR)                                                                                  \
     {                                                                                                         \
         static bool done = false;                                                                             \
         if (!done && lds > 48 * 1024)                                                                         \
-            TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_combo_kernel<HH>),                \
+            TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_combo_kernel<HH, RR>),            \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
         done = true;                                                                                          \
-        hipLaunchKernelGGL(layer_combo_kernel<HH>, dim3(grid, M), dim3(2 * HH), lds, st, a, node_tiles, f, sd); \
+        hipLaunchKernelGGL((layer_combo_kernel<HH, RR>), dim3(grid, M), dim3(2 * HH), lds, st, a, node_tiles, f, sd); \
+    }
+#define TSD_COMBO(HH)                                                                                         \
+    {                                                                                                         \
+        if (RBsel == 2) TSD_COMBO_RB(HH, 2) else TSD_COMBO_RB(HH, 1)                                          \
     }
     switch (c.hidden) {
         case 64: TSD_COMBO(64) break;
@@ -351,6 +368,7 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
         case 256: TSD_COMBO(256) break;
         default: set_error("hidden=%d unsupported (64/128/256)", c.hidden); return TSD_ERR_INVALID;
     }
+#undef TSD_COMBO_RB
 #undef TSD_COMBO
     TSD_LAUNCH_CHECK("layer_combo");
     return TSD_OK;
