@@ -5,8 +5,7 @@ import and run on torch-CPU in the build container, where torch_geometric,
 torch_scatter, torch_sparse, torch_cluster, rdkit, easydict, torchvision and
 wandb are absent.
 
-Only `oracle/gen_golden.py` and `oracle/check_oracle_vs_reference.py` use this
-module, and only in the build container: /root/reference does not exist on the
+Only `oracle/gen_golden.py` uses this module, and only in the build container: /root/reference does not exist on the
 GPU box.  The arithmetic that the reference delegates to third-party wheels is
 restated here from their published semantics (pinned versions, reference
 env.yaml:191-195):

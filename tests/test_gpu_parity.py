@@ -549,3 +549,35 @@ def test_filter_tile_64_is_bit_identical_to_32(dev):
     finally:
         _lib.check(lib.tsd_set_filter_tile(0))
     assert torch.equal(outs[0], outs[1])
+
+
+def test_piecewise_step_equals_fused_loop(dev):
+    """one LD step assembled from the single-op C-ABI entries (score_forward, ensemble_mean,
+    eq_transform_rows, sampler_step) == the first step of tsd_sampler_run, bit for bit"""
+    import ctypes as C
+    from tsdiff_amd import _lib, synth
+    from tsdiff_amd.sampler import EnsembleSampler
+    lib = _lib.load()
+    cfg = synth.small_model_config(64, 2)
+    models = [make_model(cfg, s, dev) for s in (4, 5)]
+    b = synth.wb97xd3_like_batch(5, seed=13)
+    g = to_dev({k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}, dev)
+    ens = EnsembleSampler(models)
+    N = g["pos"].shape[0]
+    noises = torch.randn(1, N, 3, device=dev)
+    pos_ref, _ = ens.dynamic_sampling(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"],
+                                      g["bond_type"], g["batch"], 5, True, n_steps=1, step_lr=1e-7, clip=1000,
+                                      sampling_type="ld", noises=noises)
+    db = ens._bound_batch(g["atom_type"], g["r_feat"], g["p_feat"], g["bond_index"], g["bond_type"], g["batch"])
+    sig = (1.0 - ens.alphas).sqrt() / ens.alphas.sqrt()
+    pos = (g["pos"] * sig[-1]).contiguous()
+    coefs = ens.step_coefficients([ens.num_timesteps - 1], [-1], "ld", 1e-7).to(dev)
+    db.forward(pos)
+    mean = db.ensemble_mean()
+    score = db.eq_transform_rows(pos, mean)
+    status = torch.zeros(2, dtype=torch.int32, device=dev)
+    _lib.check(lib.tsd_sampler_step(0, N, db.G, _lib.ptr(db.graph_ptr), _lib.ptr(score), _lib.ptr(noises[0]),
+                                    _lib.ptr(coefs[0]), 1000.0, -1.0, _lib.ptr(pos), _lib.ptr(status),
+                                    _lib.stream_ptr()))
+    assert int(status[0]) == 0
+    assert torch.equal(pos, pos_ref)
