@@ -209,24 +209,32 @@ def main():
     wf = torch.randn(2, max(PU, 1), H, device=dev)
     xa, xb = torch.randn(N, H, device=dev), torch.empty(N, H, device=dev)
     hbuf = torch.randn(N, H, device=dev)
-    reps = 50
+    reps = 20
 
-    def launch_block():
-        _lib.check(lib.tsd_interaction_block(C.byref(db.cfg), _lib.ptr(db.weights[0]), 3, N, db.enc.struct(),
-                                             _lib.ptr(wf[0]), _lib.ptr(xa), _lib.ptr(hbuf), _lib.ptr(xb), 4, PU,
-                                             db.enc_u.struct(), _lib.ptr(ea), _lib.ptr(wf[1]), _lib.stream_ptr()))
-    for _ in range(5):
-        launch_block()
+    def launch_blocks():
+        """the L+1 block launches of one forward: [filters 0], [node 0 || filters 1], ..., [node L-1]"""
+        blk = lambda layer, fl, xi, xo: _lib.check(lib.tsd_interaction_block(  # noqa: E731
+            C.byref(db.cfg), _lib.ptr(db.weights[0]), layer, N, db.enc.struct(), _lib.ptr(wf[0]), _lib.ptr(xi),
+            _lib.ptr(hbuf), _lib.ptr(xo), fl, PU, db.enc_u.struct(), _lib.ptr(ea), _lib.ptr(wf[1]),
+            _lib.stream_ptr()))
+        blk(-2, 0, xa, xb)
+        for l in range(L):
+            blk(l, l + 1 if l + 1 < L else -1, xa if l % 2 == 0 else xb, xb if l % 2 == 0 else xa)
+    for _ in range(3):
+        launch_blocks()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     for _ in range(reps):
-        launch_block()
+        launch_blocks()
     ev1.record()
     torch.cuda.synchronize()
-    k_ms = ev0.elapsed_time(ev1) / reps
-    # algorithmic flops per launch: filters of one layer on the undirected list
-    # (two HxH GEMMs + C mask), aggregation over the directed list, three HxH GEMMs per node
-    flops = Eu * (4.0 * H * H + H) + E_enc * 2.0 * H + N * 6.0 * H * H
+    k_ms = ev0.elapsed_time(ev1) / (reps * (L + 1))  # average duration of one layer_combo launch
+    # algorithmic flops (DESIGN.md section 4) of the L+1 launches of a forward, averaged per launch:
+    # L x filters of one layer on the undirected list (two HxH GEMMs + C mask), L x (aggregation over the
+    # directed list + three HxH GEMMs per node)
+    flops = (L * (Eu * (4.0 * H * H + H) + E_enc * 2.0 * H + N * 6.0 * H * H)) / (L + 1)
+    # the same work in SURVEY.md 8(d)'s units (filters counted once per DIRECTED edge, as the reference runs them)
+    flops_survey = (L * (E_enc * (4.0 * H * H + 2.0 * H) + N * 6.0 * H * H)) / (L + 1)
     ach = flops / (k_ms * 1e-3) / 1e12
     traffic = None
     if args.workload == "c2":
@@ -239,7 +247,10 @@ def main():
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                 "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes)",
                 "avg_launch_us": round(k_ms * 1e3, 2), "undirected_edges": Eu, "directed_edges": E_enc, "nodes": N,
-                "flop_per_launch": flops,
+                "flop_per_launch": flops, "launches_per_forward": L + 1,
+                "achieved_in_survey_units": round(flops_survey / (k_ms * 1e-3) / 1e12, 2),
+                "note": "every per-edge MLP runs once per undirected pair: `achieved` counts the flops executed; in "
+                        "SURVEY.md 8(d)'s per-directed-edge units the same launch is `achieved_in_survey_units`",
                 "algorithmic_bytes_per_launch": Eu * 4.0 * H * 2 + Eu * 4.0 * H + 4.0 * N * H * 4 + 2e6}
     # the HBM-bound form of the message pass: segmented aggregation with a materialised
     # directed filter W [E,H]: bytes = 1028 E + 2048 N + 4

@@ -172,7 +172,7 @@ int tsd_cfconv_aggregate(int32_t hidden, int32_t num_nodes, const int32_t* row_p
  * chain of `layer` -- agg[i] = sum_{e in row i} x1_in[dst e] * Wf_layer[enc.umap[e]] in edge order, then
  * h += lin(ssp(lin2(agg))), x1_out = lin1_{layer+1}(h) -- and the remaining workgroups generate the
  * CFConv filters of `filter_layer` (normally layer+1; -1: none) into Wf_out on the CUs the short node
- * chain leaves idle.  layer == -1: the node role is only x1_out = lin1_0(h).
+ * chain leaves idle.  layer == -1: the node role is only x1_out = lin1_0(h); layer == -2: no node role.
  * x1_in and x1_out must be different buffers.  reference schnet.py:94-107,123-127,223-224 */
 int tsd_interaction_block(const tsd_model_cfg* cfg, const float* w, int32_t layer, int32_t num_nodes,
                           tsd_edges enc, const float* Wf_layer, const float* x1_in, float* h, float* x1_out,

@@ -311,8 +311,8 @@ int tsd_interaction_block(const tsd_model_cfg* cfg, const float* w, int32_t laye
                           float* Wf_out, void* stream) {
     int r = check_cfg(cfg);
     if (r) return r;
-    TSD_REQUIRE(w && h && x1_out, "null pointer");
-    TSD_REQUIRE(layer >= -1 && layer < cfg->num_convs && filter_layer >= -1 && filter_layer < cfg->num_convs,
+    TSD_REQUIRE(w && (layer == -2 || (h && x1_out)), "null pointer");
+    TSD_REQUIRE(layer >= -2 && layer < cfg->num_convs && filter_layer >= -1 && filter_layer < cfg->num_convs,
                 "layer out of range");
     TSD_REQUIRE(layer < 0 || (Wf_layer && x1_in && enc.row_ptr && enc.dst && enc.umap && x1_in != x1_out),
                 "node role needs Wf_layer, x1_in != x1_out and the directed enc list");
