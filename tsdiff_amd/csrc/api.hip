@@ -50,8 +50,9 @@ int launch_filter_gen(const tsd_model_cfg&, const float*, int, tsd_edges, const 
 int launch_edge_embed2(const tsd_model_cfg&, const float*, int, tsd_edges, float*, int, tsd_edges, float*, int,
                        size_t, hipStream_t);
 int launch_layer_combo(const tsd_model_cfg&, const float*, int, int, tsd_edges, const float*, const float*,
-                       const float*, float*, float*, int, int, tsd_edges, const float*, float*, int, size_t, size_t,
-                       size_t, hipStream_t);
+                       const float*, float*, float*, int, int, int, int, tsd_edges, const float*, float*, int, size_t,
+                       size_t, size_t, hipStream_t);
+int filter_tiles_per_layer(int);
 int launch_node_embed(const tsd_model_cfg&, const float*, int, const int64_t*, const int64_t*, const int64_t*,
                       float*, hipStream_t);
 int launch_cfconv_aggregate(int, int, const int32_t*, const int32_t*, const int32_t*, const float*,
@@ -151,19 +152,27 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
             set_error("internal: node stride mismatch");
             return TSD_ERR_INVALID;
         }
-        if ((r = launch_layer_combo(c, W, -2, N, g.enc, nullptr, nullptr, nullptr, w.h, w.x1, 0, PU, g.enc_u, w.ea, w.wf,
-                                    M, w.stride_nh, w.stride_ea, w.stride_wf, st)))
-            return r;
+        // The filter tiles of all blocks form one queue (they depend on the geometry only); launch j takes block
+        // j's tiles, so that they are complete before block j's node chain runs in launch j+1.  (Re-cutting the
+        // queue into whole chip rounds -- 512,512,256,... tiles instead of 7 x 408 at batch 100 -- measured
+        // slower, 0.597 vs 0.534 ms/step: 408 filter + 100 node workgroups already are two full rounds of 256.)
+        const int tpl = filter_tiles_per_layer(PU);
+        const long total = (long)L * tpl;
+        long cum = 0;
         const float* xin = b.x1_0;
         float* xout = w.x1;
-        for (int l = 0; l < L; ++l) {
-            const int fl = (l + 1 < L) ? l + 1 : -1;
-            if ((r = launch_layer_combo(c, W, l, N, g.enc, w.wf + (size_t)l * PU * H, xin, l == 0 ? b.z : w.h, w.h, xout,
-                                        fl, PU, g.enc_u, w.ea, w.wf + (size_t)(l + 1 < L ? l + 1 : 0) * PU * H, M,
-                                        w.stride_nh, w.stride_ea, w.stride_wf, st)))
+        for (int j = 0; j <= L; ++j) {
+            const long n = (j < L) ? tpl : total - cum;
+            const int layer = j == 0 ? -2 : j - 1;
+            if ((r = launch_layer_combo(c, W, layer, N, g.enc, layer >= 0 ? w.wf + (size_t)layer * PU * H : nullptr, xin,
+                                        layer == 0 ? b.z : w.h, w.h, xout, 0, (int)cum, (int)n, PU, g.enc_u, w.ea, w.wf,
+                                        M, w.stride_nh, w.stride_ea, w.stride_wf, st)))
                 return r;
-            xin = xout;
-            xout = (xout == w.x1) ? w.x1b : w.x1;
+            cum += n;
+            if (layer >= 0) {
+                xin = xout;
+                xout = (xout == w.x1) ? w.x1b : w.x1;
+            }
         }
         return launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u, M, w.stride_nh, w.stride_ea,
                                   (size_t)PU, st);
@@ -317,8 +326,10 @@ int tsd_interaction_block(const tsd_model_cfg* cfg, const float* w, int32_t laye
     TSD_REQUIRE(layer < 0 || (Wf_layer && x1_in && enc.row_ptr && enc.dst && enc.umap && x1_in != x1_out),
                 "node role needs Wf_layer, x1_in != x1_out and the directed enc list");
     TSD_REQUIRE(filter_layer < 0 || (edge_attr && Wf_out && enc_u.count && enc_u.dist), "filter role: null pointer");
-    return launch_layer_combo(*cfg, w, layer, num_nodes, enc, Wf_layer, x1_in, nullptr, h, x1_out, filter_layer,
-                              capacity_u, enc_u, edge_attr, Wf_out, 1, 0, 0, 0, (hipStream_t)stream);
+    return launch_layer_combo(*cfg, w, layer, num_nodes, enc, Wf_layer, x1_in, nullptr, h, x1_out,
+                              filter_layer < 0 ? 0 : filter_layer, 0,
+                              filter_layer < 0 ? 0 : filter_tiles_per_layer(capacity_u), capacity_u, enc_u, edge_attr,
+                              Wf_out, 1, 0, 0, 0, (hipStream_t)stream);
 }
 
 int tsd_cfconv_aggregate(int32_t hidden, int32_t num_nodes, const int32_t* row_ptr, const int32_t* dst,

@@ -29,13 +29,20 @@ struct ComboNode {
     const float *lin2_w, *lin2_b, *lin_w, *lin_b, *lin1_next_w;
 };
 
+// Filter work is a flat queue of items g = layer * tiles_per_layer + tile over ALL layers (it depends on the
+// geometry only, not on the node states); a launch takes the range [g_begin, g_begin + tiles).
 struct ComboFilter {
-    int tiles;  // 0: no filter role
-    const float *nn0_w, *nn0_b, *nn2_w, *nn2_b;
+    int tiles;            // filter work items of this launch (0: no filter role)
+    int g_begin;          // first item
+    int tiles_per_layer;  // ceil(capacity / tile rows)
+    int layer0;           // layer of item 0 for the WEIGHTS (0 in the forward; the layer itself for single-layer calls)
+    const float* Wl0;     // packed weights of interaction block 0; block l at + l * layer_stride
+    size_t layer_stride, o_nn0_w, o_nn0_b, o_nn2_w, o_nn2_b;
     float conv_cutoff;
     tsd_edges e;
     const float* edge_attr;
-    float* out;  // [Eu, H] of the layer being generated
+    float* wf;            // filters of item layer 0; item layer l at + l * wf_layer_stride
+    size_t wf_layer_stride;
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -205,8 +212,13 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
 // RB = 1: tiles of 32 edges (the default); RB = 2: tiles of 64 edges (every B fragment fetched from L2 feeds
 // twice the MFMAs; faster in the 4-wave probe, slower here -- see launch_layer_combo).  Bit-identical rows.
 template <int H, int RB>
-__device__ __forceinline__ void filter_role(const ComboFilter& f, int tile, float* smem) {
+__device__ __forceinline__ void filter_role(const ComboFilter& f, int item, float* smem) {
     constexpr int TR = T * RB;
+    const int g = f.g_begin + item;
+    const int lrel = g / f.tiles_per_layer, tile = g - lrel * f.tiles_per_layer;
+    const float* Wb = f.Wl0 + (size_t)(f.layer0 + lrel) * f.layer_stride;
+    const float *nn0_w = Wb + f.o_nn0_w, *nn0_b = Wb + f.o_nn0_b, *nn2_w = Wb + f.o_nn2_w, *nn2_b = Wb + f.o_nn2_b;
+    float* out = f.wf + (size_t)lrel * f.wf_layer_stride;
     constexpr int LDA = H + 4;
     constexpr int NT = 2 * H;
     constexpr int C4 = H / 4;
@@ -232,11 +244,11 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int tile, floa
 
     f32x16 acc[RB][1];
     zero_acc(acc);
-    gemm_tile<RB, 1, H>(buf, LDA, f.nn0_w, H, col0, acc);
+    gemm_tile<RB, 1, H>(buf, LDA, nn0_w, H, col0, acc);
     __syncthreads();
     {
         const int col = col0 + l31;
-        const float b = f.nn0_b[col];
+        const float b = nn0_b[col];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -245,11 +257,11 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int tile, floa
     __syncthreads();
 
     zero_acc(acc);
-    gemm_tile<RB, 1, H>(buf, LDA, f.nn2_w, H, col0, acc);
+    gemm_tile<RB, 1, H>(buf, LDA, nn2_w, H, col0, acc);
     __syncthreads();
     {
         const int col = col0 + l31;
-        const float b = f.nn2_b[col];
+        const float b = nn2_b[col];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -261,7 +273,7 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int tile, floa
     __syncthreads();
     for (int idx = tid; idx < nrows * C4; idx += NT) {
         const int r = idx / C4, c4 = idx % C4;
-        *reinterpret_cast<f32x4*>(f.out + (size_t)(e0 + r) * H + c4 * 4) =
+        *reinterpret_cast<f32x4*>(out + (size_t)(e0 + r) * H + c4 * 4) =
             *reinterpret_cast<const f32x4*>(buf + r * LDA + c4 * 4);
     }
 }
@@ -280,8 +292,8 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
         a.Wf += m * sd.wf; a.x1_in += no; a.h_in += no; a.h += no; a.x1_out += no;
         a.lin2_w += wo; a.lin2_b += wo; a.lin_w += wo; a.lin_b += wo;
         if (a.lin1_next_w) a.lin1_next_w += wo;
-        f.nn0_w += wo; f.nn0_b += wo; f.nn2_w += wo; f.nn2_b += wo;
-        f.edge_attr += m * sd.ea; f.out += m * sd.wf;
+        f.Wl0 += wo;
+        f.edge_attr += m * sd.ea; f.wf += m * sd.wf;
     }
     if ((int)blockIdx.x < node_tiles)
         node_role<H>(a, blockIdx.x, smem);
@@ -297,11 +309,18 @@ static inline size_t lds_combo(int H, int RB) {
 
 int g_filter_rows = 0;  // 0: automatic, 32 / 64: forced (tsd_set_filter_tile; tests and A/B runs)
 
-// layer == -1: node role = lin1 of block 0 only; layer == -2: no node role.  filter_layer < 0: no filter role.
+int filter_tiles_per_layer(int capacity_u) {
+    const int RBsel = g_filter_rows == 64 ? 2 : 1;
+    return (capacity_u + T * RBsel - 1) / (T * RBsel);
+}
+
+// layer == -1: node role = lin1 of block 0 only; layer == -2: no node role.
+// Filter role: items [g_begin, g_begin + g_count) of the queue (layer_w0 + g / tiles_per_layer, g % tiles_per_layer);
+// wf_base = filters of queue layer 0.  g_count == 0: no filter role.
 int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N, tsd_edges enc,
                        const float* Wf_layer, const float* x1_in, const float* h_in, float* h, float* x1_out,
-                       int filter_layer,
-                       int capacity_u, tsd_edges enc_u, const float* edge_attr, float* Wf_out, int M, size_t nh_stride,
+                       int layer_w0, int g_begin, int g_count,
+                       int capacity_u, tsd_edges enc_u, const float* edge_attr, float* wf_base, int M, size_t nh_stride,
                        size_t ea_stride, size_t wf_stride, hipStream_t st) {
     const WeightLayout L = weight_layout(c);
     ComboNode a{};
@@ -332,17 +351,22 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     const int RBsel = g_filter_rows == 64 ? 2 : 1;
     ComboFilter f{};
     f.tiles = 0;
-    if (filter_layer >= 0) {
-        const float* B = W + L.layer0 + (size_t)filter_layer * L.layer_stride;
-        f.tiles = (capacity_u + T * RBsel - 1) / (T * RBsel);
-        f.nn0_w = B + L.L_nn0_w;
-        f.nn0_b = B + L.L_nn0_b;
-        f.nn2_w = B + L.L_nn2_w;
-        f.nn2_b = B + L.L_nn2_b;
+    if (g_count > 0) {
+        f.tiles = g_count;
+        f.g_begin = g_begin;
+        f.tiles_per_layer = filter_tiles_per_layer(capacity_u);
+        f.layer0 = layer_w0;
+        f.Wl0 = W + L.layer0;
+        f.layer_stride = L.layer_stride;
+        f.o_nn0_w = L.L_nn0_w;
+        f.o_nn0_b = L.L_nn0_b;
+        f.o_nn2_w = L.L_nn2_w;
+        f.o_nn2_b = L.L_nn2_b;
         f.conv_cutoff = c.conv_cutoff;
         f.e = enc_u;
         f.edge_attr = edge_attr;
-        f.out = Wf_out;
+        f.wf = wf_base;
+        f.wf_layer_stride = (size_t)capacity_u * c.hidden;
     }
     const int node_tiles = layer == -2 ? 0 : (N + TN - 1) / TN;
     const int grid = node_tiles + f.tiles;
