@@ -289,7 +289,7 @@ def main():
 
     # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload
     cpu = None
-    if not args.no_cpu_baseline and args.workload == "c2":
+    if not args.no_cpu_baseline and args.workload == "c2" and args.gpus == 1:  # rank 0 at N=1 only
         from oracle import tsdiff_oracle as O  # checker / baseline only
         # torch-CPU scales poorly past a few dozen threads on these op sizes (256 threads measured 35 s
         # per forward on the GPU box): use at most 32 and report the count actually used.

@@ -239,42 +239,47 @@ struct ScanOut {
     int32_t* total[NLIST];
 };
 
-// exclusive scan of NLIST int arrays of length N (+ total at [N]); single workgroup of 1024 threads
+// exclusive scan of NLIST int arrays of length N (+ total at [N]); single workgroup of 1024 threads:
+// per-thread chunk sums, inclusive scan inside each wave by shuffles, 16 wave totals combined through LDS
 __global__ __launch_bounds__(1024) void scan_kernel(int N, const int32_t* __restrict__ cnt, ScanOut o,
                                                     int32_t* __restrict__ advance) {
-    __shared__ int sm[NLIST][1024];
-    const int t = threadIdx.x;
+    __shared__ int wtot[NLIST][16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (advance && t == 0) *advance += 1;  // device-side step counter of the sampling loop
     const int per = (N + 1023) / 1024;
     const int beg = min(N, t * per), end = min(N, beg + per);
-    int x[NLIST];
+    int x[NLIST], inc[NLIST];
 #pragma unroll
     for (int q = 0; q < NLIST; ++q) {
         int a = 0;
         for (int i = beg; i < end; ++i) a += cnt[(size_t)q * (N + 1) + i];
         x[q] = a;
-        sm[q][t] = a;
+        int v = a;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int u = __shfl_up(v, off);
+            if (lane >= off) v += u;
+        }
+        inc[q] = v;
+        if (lane == 63) wtot[q][wave] = v;
     }
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-        int v[NLIST];
-#pragma unroll
-        for (int q = 0; q < NLIST; ++q) v[q] = (t >= off) ? sm[q][t - off] : 0;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < NLIST; ++q) sm[q][t] += v[q];
-        __syncthreads();
-    }
 #pragma unroll
     for (int q = 0; q < NLIST; ++q) {
-        int r = sm[q][t] - x[q];  // exclusive prefix of this thread's chunk
+        int base = 0, all = 0;
+        for (int w = 0; w < 16; ++w) {
+            const int v = wtot[q][w];
+            if (w < wave) base += v;
+            all += v;
+        }
+        int r = base + inc[q] - x[q];  // exclusive prefix of this thread's chunk
         for (int i = beg; i < end; ++i) {
             o.row_ptr[q][i] = r;
             r += cnt[(size_t)q * (N + 1) + i];
         }
-        if (t == 1023) {
-            o.row_ptr[q][N] = sm[q][1023];
-            *o.total[q] = sm[q][1023];
+        if (t == 0) {
+            o.row_ptr[q][N] = all;
+            *o.total[q] = all;
         }
     }
 }
@@ -470,6 +475,7 @@ __global__ __launch_bounds__(64) void step_post_kernel(int kind, int N, int M, i
                                                        int order_out, float cut2, int32_t* __restrict__ cnt) {
     __shared__ float old_s[3 * (TSD_MAX_GRAPH_NODES + 1)];
     __shared__ float new_s[3 * (TSD_MAX_GRAPH_NODES + 1)];
+    __shared__ int cnt_s[NLIST * (TSD_MAX_GRAPH_NODES + 1)];
     const size_t k_step = (size_t)*step_ctr;
     coefs += k_step * TSD_STEP_COEFS;
     noise += k_step * 3 * (size_t)N;
@@ -587,33 +593,29 @@ __global__ __launch_bounds__(64) void step_post_kernel(int kind, int N, int M, i
         }
     }
     __syncthreads();
-    // member counts of the next step's lists on the new positions (same arithmetic as pair_count_kernel)
-    for (int il = 0; il < n; ++il) {
-        const int i = lo + il;
-        const int p0 = pair_ptr[i];
-        const float xi = new_s[3 * il], yi = new_s[3 * il + 1], zi = new_s[3 * il + 2];
-        int cq[NLIST] = {0, 0, 0, 0, 0};
-        for (int k0 = 0; k0 < n - 1; k0 += 64) {
-            const int k = k0 + lane;
-            bool mq[NLIST] = {false, false, false, false, false};
-            if (k < n - 1) {
-                const int jl = k + (k >= il ? 1 : 0);
-                const PairEval r = eval_pair_xyz(xi, yi, zi, new_s[3 * jl], new_s[3 * jl + 1], new_s[3 * jl + 2],
-                                                 pair_code[p0 + k], order_enc, order_out, cut2);
-                const bool up = jl > il;
-                mq[0] = r.in_enc;
-                mq[1] = r.in_out;
-                mq[2] = r.in_enc && up;
-                mq[3] = r.in_out && up;
-                mq[4] = r.needs_own_attr() && up;
-            }
-#pragma unroll
-            for (int q = 0; q < NLIST; ++q) cq[q] += __popcll(__ballot(mq[q]));
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int q = 0; q < NLIST; ++q) cnt[(size_t)q * (N + 1) + i] = cq[q];
-        }
+    // member counts of the next step's lists on the new positions (same arithmetic as pair_count_kernel):
+    // the graph's n(n-1) ordered pairs spread over the lanes, per-row counters in LDS
+    const int pg0 = pair_ptr[lo];
+    const int npairs = n * (n - 1);
+    for (int t = lane; t < n * NLIST; t += 64) cnt_s[t] = 0;
+    __syncthreads();
+    for (int p = lane; p < npairs; p += 64) {
+        const int il = p / (n - 1), k = p - il * (n - 1);
+        const int jl = k + (k >= il ? 1 : 0);
+        const PairEval r = eval_pair_xyz(new_s[3 * il], new_s[3 * il + 1], new_s[3 * il + 2], new_s[3 * jl],
+                                         new_s[3 * jl + 1], new_s[3 * jl + 2], pair_code[pg0 + p], order_enc, order_out,
+                                         cut2);
+        const bool up = jl > il;
+        if (r.in_enc) atomicAdd(&cnt_s[il * NLIST + 0], 1);
+        if (r.in_out) atomicAdd(&cnt_s[il * NLIST + 1], 1);
+        if (r.in_enc && up) atomicAdd(&cnt_s[il * NLIST + 2], 1);
+        if (r.in_out && up) atomicAdd(&cnt_s[il * NLIST + 3], 1);
+        if (r.needs_own_attr() && up) atomicAdd(&cnt_s[il * NLIST + 4], 1);
+    }
+    __syncthreads();
+    for (int t = lane; t < n * NLIST; t += 64) {
+        const int il = t / NLIST, q = t - il * NLIST;
+        cnt[(size_t)q * (N + 1) + lo + il] = cnt_s[t];
     }
 }
 
