@@ -68,6 +68,7 @@ typedef struct tsd_model_cfg {
     int32_t pred_edge_order; /* config.pred_edge_order (output graph) */
     float edge_cutoff;       /* config.edge_cutoff (radius graph) */
     float conv_cutoff;       /* config.encoder.cutoff (CFConv mask C) */
+    int32_t smooth_conv;     /* config.encoder.smooth_conv: C = 0.5 (cos(pi d / cutoff) + 1) inside the cutoff (schnet.py:92-96) */
 } tsd_model_cfg;
 
 /* One extended-graph edge list in device memory (capacity = num_pairs entries).
@@ -274,8 +275,9 @@ int tsd_emb_mul_bwd(int32_t rows, int32_t H, const float* x, const float* emb, c
 int tsd_gather_rows(int32_t rows, int32_t H, const float* table, const int64_t* idx, float* y, void* stream);
 int tsd_scatter_rows_add(int32_t rows, int32_t H, const float* dy, const int64_t* idx, float* dtable,
                          void* stream);
-/* x[r,:] *= (dist[r] <= cutoff): CFConv mask C, forward and backward (schnet.py:97-99) */
-int tsd_row_mask(int32_t rows, int32_t H, const float* dist, float cutoff, float* x, void* stream);
+/* x[r,:] *= C(dist[r]): CFConv cutoff weight (hard mask, or cosine when smooth != 0), forward and backward
+ * (schnet.py:92-99) */
+int tsd_row_mask(int32_t rows, int32_t H, const float* dist, float cutoff, int32_t smooth, float* x, void* stream);
 /* adjoint of tsd_cfconv_aggregate w.r.t. the filter: dWf[u] = dagg[i]*x1[j] + dagg[j]*x1[i]
  * (w.r.t. x1 it is tsd_cfconv_aggregate itself with dagg in place of x1) */
 int tsd_aggregate_bwd_filter(int32_t H, int32_t capacity_u, tsd_edges enc_u, const float* dagg, const float* x1,

@@ -184,6 +184,17 @@ def main():
     out = run_forward_with_trace(R, model_small, tt(b))
     save("fwd_synth_b6_small", {"cfg": small_cfg, "seed": 1}, **inputs_of(b), **out)
 
+    # --- C2: same graphs, encoder.smooth_conv = True (cosine cutoff, schnet.py:92-96) ------------------------
+    import copy
+    smooth_cfg = copy.deepcopy(small_cfg)
+    smooth_cfg["encoder"]["smooth_conv"] = True
+    if not ONLY or "fwd_synth_b6_small_smooth" in ONLY:
+        model_smooth, _ = build_reference_model(R, smooth_cfg, seed=1)
+        out = run_forward_with_trace(R, model_smooth, tt(b))
+        save("fwd_synth_b6_small_smooth", {"cfg": smooth_cfg, "seed": 1}, **inputs_of(b),
+             edge_inv=out["edge_inv"], edge_index=out["edge_index"], edge_length=out["edge_length"],
+             h_final=out["h_final"], node_eq=out["node_eq"])
+
     # --- D: ensemble forward (M=2), small model ------------------------------------------
     model_small2, _ = build_reference_model(R, small_cfg, seed=2)
     ens = R.sampler.EnsembleSampler([model_small, model_small2])

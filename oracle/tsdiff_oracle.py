@@ -169,10 +169,14 @@ def cfconv_aggregate(x1, W, edge_index, N):
     return torch.zeros(N, W.size(1), dtype=W.dtype).index_add_(0, edge_index[1], msg)
 
 
-def schnet_encoder(sd, z, edge_index, edge_length, edge_attr, num_convs, cutoff, trace=None):
-    """reference schnet.py:203-225 / 110-128 / 74-107 (smooth_conv False)."""
+def schnet_encoder(sd, z, edge_index, edge_length, edge_attr, num_convs, cutoff, trace=None, smooth=False):
+    """reference schnet.py:203-225 / 110-128 / 74-107."""
     h = z
-    C = (edge_length <= cutoff).to(z.dtype).view(-1, 1)
+    if smooth:  # schnet.py:92-96
+        C = 0.5 * (torch.cos(edge_length * math.pi / cutoff) + 1.0)
+        C = (C * (edge_length <= cutoff) * (edge_length >= 0.0)).to(z.dtype).view(-1, 1)
+    else:
+        C = (edge_length <= cutoff).to(z.dtype).view(-1, 1)
     for l in range(num_convs):
         p = f"encoder.interactions.{l}."
         W = F.linear(ssp(F.linear(edge_attr, sd[p + "conv.nn.0.weight"], sd[p + "conv.nn.0.bias"])),
@@ -209,7 +213,8 @@ def forward(sd, cfg, atom_type, r_feat, p_feat, pos, bond_index, bond_type,
     ea = edge_embedding(sd, d, tr, tp)
     if trace is not None:
         trace.update(z=z, enc_edge_index=ei, enc_type_r=tr, enc_type_p=tp, enc_edge_length=d, enc_edge_attr=ea)
-    h = schnet_encoder(sd, z, ei, d, ea, int(enc["num_convs"]), float(enc["cutoff"]), trace)
+    h = schnet_encoder(sd, z, ei, d, ea, int(enc["num_convs"]), float(enc["cutoff"]), trace,
+                       smooth=bool(enc.get("smooth_conv", False)))
     if int(cfg["edge_order"]) != int(cfg["pred_edge_order"]):
         ei, tr, tp = extend_graph(pos, bond_index, bond_type, num_nodes_per_graph,
                                   int(cfg["pred_edge_order"]), float(cfg["edge_cutoff"]))

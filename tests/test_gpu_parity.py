@@ -49,6 +49,18 @@ def run_forward(model, g, dev, grad=False):
 
 
 # ---------------------------------------------------------------------------------------------
+def test_smooth_conv_vs_reference_golden(dev):
+    """encoder.smooth_conv = True: cosine cutoff weight in the filter epilogue (inference and training paths)"""
+    d, meta = load_golden("fwd_synth_b6_small_smooth")
+    g = to_dev(batch_inputs(d), dev)
+    model = make_model(meta["cfg"], meta["seed"], dev)
+    edge_inv, ei, el = run_forward(model, g, dev)
+    assert np.array_equal(ei.cpu().numpy(), d["edge_index"])
+    assert_close(edge_inv.cpu().numpy(), d["edge_inv"], RTOL, "edge_inv (smooth_conv)")
+    inv_g, _, _ = run_forward(model, g, dev, grad=True)
+    assert_close(inv_g.detach().cpu().numpy(), d["edge_inv"], RTOL, "edge_inv (smooth_conv, differentiable path)")
+
+
 @pytest.mark.parametrize("name", ["fwd_rxn0_b1_full", "fwd_rxn0_b4_sigma_full", "fwd_synth_b6_small"])
 def test_forward_vs_reference_golden(name, dev):
     d, meta = load_golden(name)

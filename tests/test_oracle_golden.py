@@ -109,3 +109,16 @@ def test_cfconv_aggregate_symmetric_rows():
     N = x1.shape[0]
     by_row = torch.zeros(N, W.shape[1]).index_add_(0, ei[0], x1[ei[1]] * W)
     assert_close(by_row.numpy(), trace["agg0"].numpy(), 1e-6, "row-vs-col aggregation")
+
+
+def test_smooth_conv_forward():
+    """encoder.smooth_conv = True (cosine cutoff, reference schnet.py:92-96)"""
+    d, meta = load_golden("fwd_synth_b6_small_smooth")
+    assert meta["cfg"]["encoder"]["smooth_conv"] is True
+    b = batch_inputs(d)
+    trace = {}
+    edge_inv, ei, el = O.forward(_sd(meta), meta["cfg"], b["atom_type"], b["r_feat"], b["p_feat"], b["pos"],
+                                 b["bond_index"], b["bond_type"], b["num_nodes_per_graph"].numpy(), trace=trace)
+    assert np.array_equal(ei.numpy(), d["edge_index"])
+    assert_close(trace["h2"].numpy(), d["h_final"], RTOL, "h_final")
+    assert_close(edge_inv.numpy(), d["edge_inv"], RTOL, "edge_inv")

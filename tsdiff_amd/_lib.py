@@ -35,6 +35,7 @@ class ModelCfg(C.Structure):
         ("pred_edge_order", C.c_int32),
         ("edge_cutoff", C.c_float),
         ("conv_cutoff", C.c_float),
+        ("smooth_conv", C.c_int32),
     ]
 
 
@@ -124,7 +125,7 @@ SIGNATURES = {
     "tsd_emb_mul_bwd": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "tsd_gather_rows": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "tsd_scatter_rows_add": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P]),
-    "tsd_row_mask": (C.c_int, [C.c_int32, C.c_int32, _P, C.c_float, _P, _P]),
+    "tsd_row_mask": (C.c_int, [C.c_int32, C.c_int32, _P, C.c_float, C.c_int32, _P, _P]),
     "tsd_aggregate_bwd_filter": (C.c_int, [C.c_int32, C.c_int32, Edges, _P, _P, _P, _P]),
     "tsd_pair_product_fwd": (C.c_int, [C.c_int32, C.c_int32, Edges, _P, _P, _P]),
     "tsd_pair_product_bwd": (C.c_int, [C.c_int32, C.c_int32, Edges, _P, _P, _P, _P]),

@@ -12,7 +12,8 @@ def extend_condensed_graph_edge(pos, bond_index, bond_type, batch, edge_order=4,
     get_distance on the result."""
     N = int(pos.shape[0])
     cfg = engine.ModelCfg(hidden=64, num_convs=1, feat_dim=1, edge_order=int(edge_order),
-                          pred_edge_order=int(edge_order), edge_cutoff=float(cutoff), conv_cutoff=float(cutoff))
+                          pred_edge_order=int(edge_order), edge_cutoff=float(cutoff), conv_cutoff=float(cutoff),
+                          smooth_conv=0)
     at = atom_type if atom_type is not None else torch.zeros(N, dtype=torch.int64, device=pos.device)
     feat = torch.zeros(N, 1, dtype=torch.int64, device=pos.device)
     db = engine.DeviceBatch(cfg, at, feat, feat, bond_index, bond_type, batch)

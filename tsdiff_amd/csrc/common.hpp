@@ -108,6 +108,13 @@ __device__ __forceinline__ float sspf(float x) {  // reference models/encoder/sc
     return (fmaxf(x, 0.0f) + l) - 0.69314718055994530942f;
 }
 
+// CFConv cutoff weight C(d), reference models/encoder/schnet.py:92-98
+__device__ __forceinline__ float cutoff_weight(float d, float cutoff, int smooth) {
+    if (!(d <= cutoff)) return 0.0f;
+    if (!smooth) return 1.0f;
+    return d >= 0.0f ? 0.5f * (cosf(d * 3.14159265358979323846f / cutoff) + 1.0f) : 0.0f;
+}
+
 // ---------------------------------------------------------------------------------------------
 // MFMA tile GEMM:  acc[T x NOUT] += A[T x K] * W^T   (A in LDS, W packed in global/L2)
 //

@@ -39,6 +39,7 @@ struct ComboFilter {
     const float* Wl0;     // packed weights of interaction block 0; block l at + l * layer_stride
     size_t layer_stride, o_nn0_w, o_nn0_b, o_nn2_w, o_nn2_b;
     float conv_cutoff;
+    int smooth;
     tsd_edges e;
     const float* edge_attr;
     float* wf;            // filters of item layer 0; item layer l at + l * wf_layer_stride
@@ -233,7 +234,7 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
     const int col0 = (tid >> 6) * 32;
     const int nrows = min(TR, E - e0);
 
-    if (tid < TR) s_c[tid] = (tid < nrows && f.e.dist[e0 + tid] <= f.conv_cutoff) ? 1.0f : 0.0f;
+    if (tid < TR) s_c[tid] = tid < nrows ? cutoff_weight(f.e.dist[e0 + tid], f.conv_cutoff, f.smooth) : 0.0f;
     for (int idx = tid; idx < TR * C4; idx += NT) {
         const int r = idx / C4, c4 = idx % C4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -363,6 +364,7 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
         f.o_nn2_w = L.L_nn2_w;
         f.o_nn2_b = L.L_nn2_b;
         f.conv_cutoff = c.conv_cutoff;
+        f.smooth = c.smooth_conv;
         f.e = enc_u;
         f.edge_attr = edge_attr;
         f.wf = wf_base;

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(H) void edge_embed_kernel(EdgeEmbedW w, tsd_edges e
 // here in edge order without atomics (rows cut by the tile boundary finish in node_update).
 // ---------------------------------------------------------------------------------------------
 template <int H>
-__global__ __launch_bounds__(H) void cfconv_layer_kernel(CfconvW w, float conv_cutoff, tsd_edges e,
+__global__ __launch_bounds__(H) void cfconv_layer_kernel(CfconvW w, float conv_cutoff, int smooth, tsd_edges e,
                                                          const float* __restrict__ edge_attr,
                                                          const float* __restrict__ x1,
                                                          float* __restrict__ agg, float* __restrict__ part) {
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(H) void cfconv_layer_kernel(CfconvW w, float conv_c
         const int s = v ? e.src[ee] : 0;
         s_src[tid] = s;
         s_dst[tid] = v ? e.dst[ee] : 0;
-        s_c[tid] = (v && e.dist[ee] <= conv_cutoff) ? 1.0f : 0.0f;  // schnet.py:97-98
+        s_c[tid] = v ? cutoff_weight(e.dist[ee], conv_cutoff, smooth) : 0.0f;  // schnet.py:92-98
         s_rp0[tid] = e.row_ptr[s];
         s_rp1[tid] = e.row_ptr[s + 1];
     }
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(H) void cfconv_layer_kernel(CfconvW w, float conv_c
 template <int H>
 __global__ __launch_bounds__(H) void filter_gen_kernel(const float* __restrict__ Wl0, size_t layer_stride,
                                                        size_t o_nn0_w, size_t o_nn0_b, size_t o_nn2_w,
-                                                       size_t o_nn2_b, float conv_cutoff, tsd_edges e,
+                                                       size_t o_nn2_b, float conv_cutoff, int smooth, tsd_edges e,
                                                        const float* __restrict__ edge_attr,
                                                        float* __restrict__ Wf, size_t wf_layer_stride,
                                                        int layer_base) {
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(H) void filter_gen_kernel(const float* __restrict__
     const int col0 = (tid >> 6) * 64;
     const int nrows = min(T, E - e0);
 
-    if (tid < T) s_c[tid] = (tid < nrows && e.dist[e0 + tid] <= conv_cutoff) ? 1.0f : 0.0f;  // schnet.py:97-98
+    if (tid < T) s_c[tid] = tid < nrows ? cutoff_weight(e.dist[e0 + tid], conv_cutoff, smooth) : 0.0f;  // schnet.py:92-98
     for (int idx = tid; idx < T * C4; idx += H) {
         const int r = idx / C4, c4 = idx % C4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -587,7 +587,7 @@ int launch_cfconv_layer(const tsd_model_cfg& c, const float* W, int layer, int c
     TSD_DISPATCH_H(c.hidden, {
         static bool done = false; int r = allow_lds_once(cfconv_layer_kernel<HH>, lds, done);
         if (r) return r;
-        hipLaunchKernelGGL(cfconv_layer_kernel<HH>, dim3(tiles), dim3(HH), lds, st, w, c.conv_cutoff, e,
+        hipLaunchKernelGGL(cfconv_layer_kernel<HH>, dim3(tiles), dim3(HH), lds, st, w, c.conv_cutoff, c.smooth_conv, e,
                            edge_attr, x1, agg, part);
     });
     TSD_LAUNCH_CHECK("cfconv_layer");
@@ -606,7 +606,7 @@ int launch_filter_gen(const tsd_model_cfg& c, const float* W, int capacity, tsd_
         static bool done = false; int r = allow_lds_once(filter_gen_kernel<HH>, lds, done);
         if (r) return r;
         hipLaunchKernelGGL(filter_gen_kernel<HH>, dim3(tiles, nlayers), dim3(HH), lds, st, W + L.layer0,
-                           L.layer_stride, L.L_nn0_w, L.L_nn0_b, L.L_nn2_w, L.L_nn2_b, c.conv_cutoff, e, edge_attr,
+                           L.layer_stride, L.L_nn0_w, L.L_nn0_b, L.L_nn2_w, L.L_nn2_b, c.conv_cutoff, c.smooth_conv, e, edge_attr,
                            Wf, (size_t)capacity * HH, layer_base);
     });
     TSD_LAUNCH_CHECK("filter_gen");

@@ -243,10 +243,12 @@ __global__ void scatter_rows_add_kernel(int rows, int H, const float* __restrict
 }
 
 // x[r,:] *= (dist[r] <= cutoff)    CFConv mask C, forward and backward (schnet.py:97-99)
-__global__ void row_mask_kernel(int rows, int H, const float* __restrict__ dist, float cutoff, float* __restrict__ x) {
+__global__ void row_mask_kernel(int rows, int H, const float* __restrict__ dist, float cutoff, int smooth,
+                                float* __restrict__ x) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)rows * H) return;
-    if (!(dist[i / H] <= cutoff)) x[i] = 0.0f;
+    const float c = cutoff_weight(dist[i / H], cutoff, smooth);
+    if (c != 1.0f) x[i] *= c;
 }
 
 // adjoint of the aggregation w.r.t. the filter: dWf[u] = dagg[i] * x1[j] + dagg[j] * x1[i], u = {i<j}
@@ -486,10 +488,10 @@ int tsd_scatter_rows_add(int32_t rows, int32_t H, const float* dy, const int64_t
     return TSD_OK;
 }
 
-int tsd_row_mask(int32_t rows, int32_t H, const float* dist, float cutoff, float* x, void* stream) {
+int tsd_row_mask(int32_t rows, int32_t H, const float* dist, float cutoff, int32_t smooth, float* x, void* stream) {
     if (rows == 0) return TSD_OK;
     hipLaunchKernelGGL(row_mask_kernel, dim3(blocks_for((int64_t)rows * H)), dim3(256), 0, (hipStream_t)stream, rows,
-                       H, dist, cutoff, x);
+                       H, dist, cutoff, smooth, x);
     TSD_LAUNCH_CHECK("row_mask");
     return TSD_OK;
 }

@@ -45,8 +45,6 @@ def make_cfg(model_config):
         raise ValueError("condensenc needs encoder.hidden_dim == hidden_dim")
     if cfg_get(enc, "name", "schnet") != "schnet":
         raise NotImplementedError("Unknown/unsupported encoder: %s" % cfg_get(enc, "name"))
-    if bool(cfg_get(enc, "smooth_conv", False)):
-        raise NotImplementedError("encoder.smooth_conv=True is not on the shipped path")
     if cfg_get(model_config, "edge_encoder", "mlp") != "mlp":
         raise NotImplementedError("Unknown/unsupported edge encoder: %s" % cfg_get(model_config, "edge_encoder"))
     for k in ("mlp_act", "edge_cat_act"):
@@ -60,6 +58,7 @@ def make_cfg(model_config):
         pred_edge_order=int(cfg_get(model_config, "pred_edge_order")),
         edge_cutoff=float(cfg_get(model_config, "edge_cutoff")),
         conv_cutoff=float(cfg_get(enc, "cutoff")),
+        smooth_conv=int(bool(cfg_get(enc, "smooth_conv", False))),
     )
 
 

@@ -138,15 +138,15 @@ class GatherRows(torch.autograd.Function):
 
 
 class RowMask(torch.autograd.Function):
-    """y = x * (dist <= cutoff)[:, None]   (CFConv C)"""
+    """y = x * C(dist)[:, None]   (CFConv cutoff weight: hard mask or cosine, schnet.py:92-99)"""
 
     @staticmethod
-    def forward(ctx, x, dist, cutoff):
+    def forward(ctx, x, dist, cutoff, smooth):
         lib = _lib.load()
         y = x.clone(memory_format=torch.contiguous_format)
-        check(lib.tsd_row_mask(y.shape[0], y.shape[1], ptr(dist), float(cutoff), ptr(y), stream_ptr()))
+        check(lib.tsd_row_mask(y.shape[0], y.shape[1], ptr(dist), float(cutoff), int(smooth), ptr(y), stream_ptr()))
         ctx.save_for_backward(dist)
-        ctx.cutoff = float(cutoff)
+        ctx.cutoff, ctx.smooth = float(cutoff), int(smooth)
         return y
 
     @staticmethod
@@ -154,8 +154,8 @@ class RowMask(torch.autograd.Function):
         lib = _lib.load()
         (dist,) = ctx.saved_tensors
         dx = dy.clone(memory_format=torch.contiguous_format)
-        check(lib.tsd_row_mask(dx.shape[0], dx.shape[1], ptr(dist), ctx.cutoff, ptr(dx), stream_ptr()))
-        return dx, None, None
+        check(lib.tsd_row_mask(dx.shape[0], dx.shape[1], ptr(dist), ctx.cutoff, ctx.smooth, ptr(dx), stream_ptr()))
+        return dx, None, None, None
 
 
 class Aggregate(torch.autograd.Function):
@@ -289,7 +289,7 @@ def train_forward(model, db, pos):
         p = f"encoder.interactions.{l}."
         Wf = linear(ssp(linear(ea, P[p + "conv.nn.0.weight"], P[p + "conv.nn.0.bias"])),
                     P[p + "conv.nn.2.weight"], P[p + "conv.nn.2.bias"])
-        Wf = RowMask.apply(Wf, dist_u, cfg.conv_cutoff)
+        Wf = RowMask.apply(Wf, dist_u, cfg.conv_cutoff, cfg.smooth_conv)
         x1 = linear(h, P[p + "conv.lin1.weight"])
         agg = Aggregate.apply(x1, Wf, db)
         x = linear(agg, P[p + "conv.lin2.weight"], P[p + "conv.lin2.bias"])
