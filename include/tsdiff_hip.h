@@ -249,17 +249,18 @@ int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t ki
                     int32_t use_graph, void* stream);
 
 /* ---- training primitives (BASELINE config 4; reference train.py:124-152, condensenc.py:267-328) -----
- * First functional form of the training step: every dense layer's forward / dgrad / wgrad is a plain
- * fp32 GEMM (rocBLAS); the graph-shaped operations and their adjoints are HIP kernels.  The Python host
+ * First functional form of the training step, one launch per operation: every dense layer's forward / dgrad /
+ * wgrad on the fp32 MFMA, the graph-shaped operations and their adjoints as plain kernels.  The Python host
  * composes them as torch.autograd.Function nodes (tsdiff_amd/train_ops.py), so `loss.backward()`,
  * `clip_grad_norm_` and Adam of the unmodified train.py keep working.  All matrices row-major fp32. */
-/* Y[rows,out] = X[rows,in] W[out,in]^T + b */
+/* Y[rows,out] = X[rows,in] W[out,in]^T + b.  scratch >= in*out floats: W is packed there and the product
+ * runs on the fp32 MFMA (in, out in {128,256,512}); otherwise / without scratch a plain VALU kernel runs. */
 int tsd_linear_fwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* b,
-                   float* Y, void* stream);
+                   float* Y, float* scratch, size_t scratch_floats, void* stream);
 /* dX = dY W (NULL: skip); dW = dY^T X (NULL: skip); db = column sums of dY (NULL: skip).
- * scratch: 64*out floats for the deterministic two-stage bias reduction; with >= 64*out*(in+1) floats the
- * weight gradient of tall problems (rows >= 1024, out and in multiples of 128) runs on the hand-written
- * row-split MFMA kernel instead of rocBLAS. */
+ * scratch layout: 64*out floats (deterministic two-stage bias reduction) | in*out floats (W packed for the
+ * MFMA dgrad) | S*out*in floats, S <= 64 (row-split MFMA wgrad partials, summed in split order).
+ * With less scratch, or shapes that are not multiples of 128, plain VALU kernels run instead. */
 int tsd_linear_bwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* dY,
                    float* dX, float* dW, float* db, float* scratch, size_t scratch_floats, void* stream);
 /* kind 0: swish (utils/activation_functions.py), 1: shifted softplus (schnet.py:65-71), 2: ReLU, 3: softplus;

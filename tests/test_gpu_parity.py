@@ -477,21 +477,32 @@ def test_hidden128_large_graphs_and_differentiable_forward(dev):
 
 
 def test_training_primitives_at_scale(dev):
-    """the row-split MFMA wgrad kernel (only used for >= 1024 rows, beyond the goldens' sizes), the bias
-    reduction and the LDS-reduced embedding gradient against fp64 torch references"""
+    """the dense-layer kernels (MFMA forward / dgrad / row-split wgrad for 128-multiples, the VALU kernels for
+    the odd shapes), the bias reduction and the LDS-reduced embedding gradient against fp64 torch references"""
     import ctypes as C
     from tsdiff_amd import _lib
     from tsdiff_amd.train_ops import _scratch
     lib = _lib.load()
     torch.manual_seed(0)
-    for rows, fin, out in [(5000, 256, 256), (4097, 512, 256), (1500, 256, 128), (9000, 128, 256)]:
+    for rows, fin, out in [(5000, 256, 256), (4097, 512, 256), (1500, 256, 128), (9000, 128, 256), (33, 256, 512),
+                           (3000, 1, 256), (3000, 25, 128), (3000, 128, 1), (700, 64, 64), (1, 256, 256)]:
         X = torch.randn(rows, fin, device=dev)
         W = torch.randn(out, fin, device=dev) * 0.05
+        b = torch.randn(out, device=dev)
         dY = torch.randn(rows, out, device=dev)
         dX = torch.empty_like(X)
         dW = torch.full((out, fin), float("nan"), device=dev)
         db = torch.empty(out, device=dev)
-        sc = _scratch(dev, 64 * out * (fin + 1))
+        sc = _scratch(dev, 64 * out + fin * out + 64 * out * fin)
+        Y = torch.full((rows, out), float("nan"), device=dev)
+        _lib.check(lib.tsd_linear_fwd(rows, fin, out, _lib.ptr(X), _lib.ptr(W), _lib.ptr(b), _lib.ptr(Y), _lib.ptr(sc),
+                                      sc.numel(), _lib.stream_ptr()))
+        Yref = (X.double() @ W.double().t() + b.double()).cpu().numpy()
+        assert_close(Y.cpu().numpy(), Yref, 1e-5, f"Y {rows}x{fin}x{out}")
+        Y2 = torch.empty_like(Y)  # without scratch: the VALU kernel, same numbers to rounding
+        _lib.check(lib.tsd_linear_fwd(rows, fin, out, _lib.ptr(X), _lib.ptr(W), _lib.ptr(b), _lib.ptr(Y2), None, 0,
+                                      _lib.stream_ptr()))
+        assert_close(Y2.cpu().numpy(), Yref, 1e-5, "Y (no scratch)")
         _lib.check(lib.tsd_linear_bwd(rows, fin, out, _lib.ptr(X), _lib.ptr(W), _lib.ptr(dY), _lib.ptr(dX),
                                       _lib.ptr(dW), _lib.ptr(db), _lib.ptr(sc), sc.numel(), _lib.stream_ptr()))
         assert_close(dW.cpu().numpy(), (dY.double().t() @ X.double()).cpu().numpy(), 1e-5, f"dW {rows}x{fin}x{out}")

@@ -1,56 +1,123 @@
 // kernels_train.hip -- primitives of the training step (BASELINE config 4; reference train.py:124-152,
-// models/epsnet/condensenc.py:267-328).  First functional form: the dense layers' forward / dgrad / wgrad
-// are PLAIN GEMMs and go to rocBLAS (fp32); everything graph-shaped (segmented aggregation and its two
-// adjoints, pair products, embedding gathers / scatters, distance -> Cartesian chain rule, activations)
-// is hand-written here.  The Python host (tsdiff_amd/train_ops.py) strings them together as
+// models/epsnet/condensenc.py:267-328).  First functional form: one launch per operation -- the dense
+// layers' forward / dgrad / wgrad as fp32-MFMA tile kernels, everything graph-shaped (segmented aggregation
+// and its two adjoints, pair products, embedding gathers / scatters, distance -> Cartesian chain rule,
+// activations) as plain kernels -- no vendor BLAS.  The Python host (tsdiff_amd/train_ops.py) strings them together as
 // torch.autograd.Function nodes so that the reference's unmodified `loss.backward()`, `clip_grad_norm_`
 // and Adam keep working; fusing this path like the sampling path is next round's work.
 //
 // All per-edge work runs on the UNDIRECTED lists (see tsd_geometry): a filter row Wf[u] / score s[u] is
 // used by both directed edges (i,j) and (j,i), so its gradient is the sum of both directions.
-#include <rocblas/rocblas.h>
-
 #include "common.hpp"
 
 namespace tsd {
 
-static rocblas_handle g_blas[16] = {};
+// ---------------------------------------------------------------------------------------------
+// Dense layers of the training step, hand written (no vendor BLAS):
+//   forward  Y = X W^T + b      : row tiles of 32 through LDS, W packed on the fly ([in/4][out][in%4]),
+//   dgrad    dX = dY W          : the same kernel with W packed the other way ([out/4][in][out%4]),
+//   wgrad    dW = dY^T X        : the row-split kernel further down,
+// all on the fp32 MFMA (common.hpp::gemm_tile) whenever in/out are multiples of 128/32; the few odd
+// shapes of the network (Linear(1,H), Linear(25,H/2), Linear(H/2,1), small test configs) use the plain
+// VALU kernels at the end of this block.
+// ---------------------------------------------------------------------------------------------
+// Bp[k/4][n][k%4] = M[n][k]   (transposed == false: M = W [nout = n][nin = k], forward)
+// Bp[k/4][n][k%4] = M[k][n]   (transposed == true : M = W [k = out][n = in],   dgrad)
+__global__ void pack_any_kernel(const float* __restrict__ M, float* __restrict__ Bp, int ncols /*n*/, int kdim,
+                                int transposed) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= ncols * kdim) return;
+    const int s = idx & 3;
+    const int n = (idx >> 2) % ncols;
+    const int k = ((idx >> 2) / ncols) * 4 + s;
+    Bp[idx] = transposed ? M[(size_t)k * ncols + n] : M[(size_t)n * kdim + k];
+}
 
-static int blas_handle(hipStream_t st, rocblas_handle* out) {
-    int dev = 0;
-    TSD_HIP(hipGetDevice(&dev));
-    rocblas_handle& h = g_blas[dev & 15];
-    if (!h) {
-        if (rocblas_create_handle(&h) != rocblas_status_success) {
-            set_error("rocblas_create_handle failed");
-            return TSD_ERR_HIP;
+// Y[rows, NOUT] = A[rows, K] * Bp (+ bias): 4 waves, each NOUT/4 columns (CB blocks of 32)
+template <int K, int CB>
+__global__ __launch_bounds__(256) void linear_mfma_kernel(int rows, const float* __restrict__ A,
+                                                          const float* __restrict__ Bp,
+                                                          const float* __restrict__ bias, float* __restrict__ Y) {
+    constexpr int NOUT = CB * 128;
+    constexpr int LDA = K + 4;
+    constexpr int K4 = K / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int r0 = blockIdx.x * 32;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int col0 = (tid >> 6) * (NOUT / 4);
+    const int nrows = min(32, rows - r0);
+    for (int idx = tid; idx < 32 * K4; idx += 256) {
+        const int r = idx / K4, c4 = idx % K4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < nrows) v = *reinterpret_cast<const f32x4*>(A + (size_t)(r0 + r) * K + c4 * 4);
+        *reinterpret_cast<f32x4*>(smem + r * LDA + c4 * 4) = v;
+    }
+    __syncthreads();
+    f32x16 acc[1][CB];
+    zero_acc(acc);
+    gemm_tile<1, CB, K>(smem, LDA, Bp, NOUT, col0, acc);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const int col = col0 + cb * 32 + l31;
+        const float b = bias ? bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, hi);
+            if (row < nrows) Y[(size_t)(r0 + row) * NOUT + col] = acc[0][cb][r] + b;
         }
     }
-    if (rocblas_set_stream(h, st) != rocblas_status_success) {
-        set_error("rocblas_set_stream failed");
-        return TSD_ERR_HIP;
-    }
-    *out = h;
+}
+
+template <int K, int CB>
+static int launch_linear_mfma(int rows, const float* A, const float* Bp, const float* bias, float* Y, hipStream_t st) {
+    const size_t lds = (size_t)32 * (K + 4) * 4;
+    static bool done = false;
+    if (!done && lds > 48 * 1024)
+        TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_mfma_kernel<K, CB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    done = true;
+    hipLaunchKernelGGL((linear_mfma_kernel<K, CB>), dim3((rows + 31) / 32), dim3(256), lds, st, rows, A, Bp, bias, Y);
+    TSD_LAUNCH_CHECK("linear_mfma");
     return TSD_OK;
 }
 
-// row-major C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C, computed as the column-major product
-// C^T = op(B)^T op(A)^T
-int gemm_rm(bool transA, bool transB, int M, int N, int K, float alpha, const float* A, int lda, const float* B,
-            int ldb, float beta, float* C, int ldc, hipStream_t st) {
-    if (M == 0 || N == 0) return TSD_OK;
-    rocblas_handle h;
-    int r = blas_handle(st, &h);
-    if (r) return r;
-    const rocblas_status s =
-        rocblas_sgemm(h, transB ? rocblas_operation_transpose : rocblas_operation_none,
-                      transA ? rocblas_operation_transpose : rocblas_operation_none, N, M, K, &alpha, B, ldb, A, lda,
-                      &beta, C, ldc);
-    if (s != rocblas_status_success) {
-        set_error("rocblas_sgemm failed (%d)", (int)s);
-        return TSD_ERR_HIP;
+static bool mfma_shape(int K, int NOUT) { return (K == 128 || K == 256 || K == 512) && (NOUT == 128 || NOUT == 256 || NOUT == 512); }
+
+static int dispatch_linear_mfma(int rows, int K, int NOUT, const float* A, const float* Bp, const float* bias, float* Y,
+                                hipStream_t st) {
+#define TSD_LM(KK, CC) if (K == KK && NOUT == CC * 128) return launch_linear_mfma<KK, CC>(rows, A, Bp, bias, Y, st);
+    TSD_LM(128, 1) TSD_LM(128, 2) TSD_LM(128, 4) TSD_LM(256, 1) TSD_LM(256, 2) TSD_LM(256, 4)
+    TSD_LM(512, 1) TSD_LM(512, 2) TSD_LM(512, 4)
+#undef TSD_LM
+    set_error("internal: no MFMA instance for K=%d N=%d", K, NOUT);
+    return TSD_ERR_INVALID;
+}
+
+// odd shapes: one thread per output element
+// C[r, n] = sum_k A[r, k] * (transposed ? M[k, n] : M[n, k]) (+ bias[n])
+__global__ void linear_naive_kernel(int rows, int K, int N, const float* __restrict__ A, const float* __restrict__ M,
+                                    int transposed, const float* __restrict__ bias, float* __restrict__ C) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)rows * N) return;
+    const int r = (int)(t / N), n = (int)(t % N);
+    float s = 0.0f;
+    for (int k = 0; k < K; ++k) s = fmaf(A[(size_t)r * K + k], transposed ? M[(size_t)k * N + n] : M[(size_t)n * K + k], s);
+    C[t] = s + (bias ? bias[n] : 0.0f);
+}
+// dW[o, i] = sum_r dY[r, o] * X[r, i]: one workgroup per output element, tree over the rows
+__global__ __launch_bounds__(256) void wgrad_naive_kernel(int rows, int in, int out, const float* __restrict__ dY,
+                                                          const float* __restrict__ X, float* __restrict__ dW) {
+    __shared__ float sm[256];
+    const int o = blockIdx.x / in, i = blockIdx.x % in;
+    float s = 0.0f;
+    for (int r = threadIdx.x; r < rows; r += 256) s = fmaf(dY[(size_t)r * out + o], X[(size_t)r * in + i], s);
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
     }
-    return TSD_OK;
+    if (threadIdx.x == 0) dW[blockIdx.x] = sm[0];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -136,11 +203,6 @@ __global__ void wgrad_reduce_kernel(int64_t n, int S, const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ void bias_add_kernel(int64_t n, int cols, const float* __restrict__ b, float* __restrict__ y) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] += b[i % cols];
-}
-
 // column sums of dY [rows, cols] (bias gradient), deterministic two-stage tree:
 // stage 1: grid (cols/64, CS_CHUNKS) workgroups reduce a row chunk each into part[chunk][col];
 // stage 2: one thread per column adds the CS_CHUNKS partials in order.
@@ -373,42 +435,57 @@ using namespace tsd;
 extern "C" {
 
 int tsd_linear_fwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* b, float* Y,
-                   void* stream) {
+                   float* scratch, size_t scratch_floats, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    int r = gemm_rm(false, true, rows, out, in, 1.0f, X, in, W, in, 0.0f, Y, out, st);  // Y = X W^T
-    if (r) return r;
-    if (b && rows > 0) {
-        const int64_t n = (int64_t)rows * out;
-        hipLaunchKernelGGL(bias_add_kernel, dim3(blocks_for(n)), dim3(256), 0, st, n, out, b, Y);
-        TSD_LAUNCH_CHECK("bias_add");
+    if (rows == 0) return TSD_OK;
+    if (mfma_shape(in, out) && scratch && scratch_floats >= (size_t)in * out) {
+        const int n = in * out;
+        hipLaunchKernelGGL(pack_any_kernel, dim3((n + 255) / 256), dim3(256), 0, st, W, scratch, out, in, 0);
+        return dispatch_linear_mfma(rows, in, out, X, scratch, b, Y, st);
     }
+    const int64_t n = (int64_t)rows * out;
+    hipLaunchKernelGGL(linear_naive_kernel, dim3(blocks_for(n)), dim3(256), 0, st, rows, in, out, X, W, 0, b, Y);
+    TSD_LAUNCH_CHECK("linear_naive");
     return TSD_OK;
 }
 
 int tsd_linear_bwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* dY, float* dX,
                    float* dW, float* db, float* scratch, size_t scratch_floats, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    int r;
-    if (dX && (r = gemm_rm(false, false, rows, in, out, 1.0f, dY, out, W, in, 0.0f, dX, in, st))) return r;  // dY W
-    if (dW) {
-        const int S = rows >= 4096 ? 64 : (rows >= 1024 ? 16 : 0);  // row splits of the hand-written wgrad
+    // scratch layout: [0, 64*out) bias partials | [.., + in*out) packed W for dgrad | wgrad partials
+    const size_t off_pack = 64 * (size_t)out, off_part = off_pack + (size_t)in * out;
+    if (dX && rows > 0) {  // dX = dY W
+        if (mfma_shape(out, in) && scratch && scratch_floats >= off_part) {
+            const int n = in * out;
+            hipLaunchKernelGGL(pack_any_kernel, dim3((n + 255) / 256), dim3(256), 0, st, W, scratch + off_pack, in, out, 1);
+            int r = dispatch_linear_mfma(rows, out, in, dY, scratch + off_pack, nullptr, dX, st);
+            if (r) return r;
+        } else {
+            const int64_t n = (int64_t)rows * in;
+            hipLaunchKernelGGL(linear_naive_kernel, dim3(blocks_for(n)), dim3(256), 0, st, rows, out, in, dY, W, 1,
+                               (const float*)nullptr, dX);
+            TSD_LAUNCH_CHECK("dgrad_naive");
+        }
+    }
+    if (dW) {  // dW = dY^T X
+        const int S = rows >= 4096 ? 64 : (rows >= 512 ? 16 : 4);  // row splits of the MFMA wgrad
         if (rows == 0) {
             TSD_HIP(hipMemsetAsync(dW, 0, (size_t)out * in * sizeof(float), st));
-        } else if (S > 0 && scratch && scratch_floats >= (size_t)S * out * in + 64 * (size_t)out &&
-                   out % 128 == 0 && in % 128 == 0) {
+        } else if (scratch && scratch_floats >= off_part + (size_t)S * out * in && out % 128 == 0 && in % 128 == 0) {
             const int per = ((rows + S - 1) / S + WG_T - 1) / WG_T * WG_T;
-            float* part = scratch + 64 * (size_t)out;  // the first 64*out floats belong to the bias reduction
+            float* part = scratch + off_part;
             hipLaunchKernelGGL(wgrad_kernel, dim3(in / 128, out / 128, S), dim3(256), 0, st, rows, in, out, per, dY, X,
                                part);
             const int64_t n = (int64_t)out * in;
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(n)), dim3(256), 0, st, n, S, part, dW);
             TSD_LAUNCH_CHECK("wgrad");
-        } else if ((r = gemm_rm(true, false, out, in, rows, 1.0f, dY, out, X, in, 0.0f, dW, in, st))) {  // dY^T X
-            return r;
+        } else {
+            hipLaunchKernelGGL(wgrad_naive_kernel, dim3(out * in), dim3(256), 0, st, rows, in, out, dY, X, dW);
+            TSD_LAUNCH_CHECK("wgrad_naive");
         }
     }
     if (db) {
-        TSD_REQUIRE(scratch != nullptr, "tsd_linear_bwd: db needs a scratch of 64*out floats");
+        TSD_REQUIRE(scratch != nullptr && scratch_floats >= off_pack, "tsd_linear_bwd: db needs 64*out scratch floats");
         hipLaunchKernelGGL(colsum_stage1_kernel, dim3((out + 63) / 64, CS_CHUNKS), dim3(256), 0, st, rows, out, dY,
                            scratch);
         hipLaunchKernelGGL(colsum_stage2_kernel, dim3((out + 255) / 256), dim3(256), 0, st, out, scratch, db);

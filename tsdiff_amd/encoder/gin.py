@@ -27,7 +27,7 @@ def _linear(x, lin):
     lib = _lib.load()
     y = torch.empty(x.shape[0], lin.out_features, dtype=torch.float32, device=x.device)
     check(lib.tsd_linear_fwd(x.shape[0], lin.in_features, lin.out_features, ptr(x), ptr(lin.weight.detach()),
-                             ptr(lin.bias.detach()), ptr(y), stream_ptr()))
+                             ptr(lin.bias.detach()), ptr(y), None, 0, stream_ptr()))
     return y
 
 

@@ -4,7 +4,7 @@ primitives of include/tsdiff_hip.h.
 
 torch's autograd engine only SEQUENCES the backward (so the reference's unmodified
 `loss.mean().backward()`, `clip_grad_norm_` and `torch.optim.Adam` keep working); every forward and
-backward computation below runs in libtsdiff_hip.so: the dense layers as rocBLAS fp32 GEMMs, the
+backward computation below runs in libtsdiff_hip.so: the dense layers as fp32-MFMA tile kernels, the
 graph-shaped operations (segmented aggregation and both adjoints, pair products, embedding
 gather/scatter, the distance -> Cartesian chain rule, activations) as HIP kernels.  This is the
 first functional form of row A16 / SURVEY 8(f)-1; fusing it like the sampling path is next.
@@ -44,7 +44,8 @@ class Linear(torch.autograd.Function):
         rows, fin = x.shape
         out = W.shape[0]
         y = torch.empty(rows, out, dtype=torch.float32, device=x.device)
-        check(lib.tsd_linear_fwd(rows, fin, out, ptr(x), ptr(W), ptr(b), ptr(y), stream_ptr()))
+        sc = _scratch(x.device, fin * out)
+        check(lib.tsd_linear_fwd(rows, fin, out, ptr(x), ptr(W), ptr(b), ptr(y), ptr(sc), sc.numel(), stream_ptr()))
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
         return y
@@ -59,7 +60,7 @@ class Linear(torch.autograd.Function):
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dW = torch.empty_like(W) if ctx.needs_input_grad[1] else None
         db = torch.empty(out, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-        sc = _scratch(x.device, 64 * out * (fin + 1))  # bias partials + row-split wgrad partials
+        sc = _scratch(x.device, 64 * out + fin * out + 64 * out * fin)  # bias partials | packed W | wgrad partials
         check(lib.tsd_linear_bwd(rows, fin, out, ptr(x), ptr(W), ptr(dy), ptr(dx), ptr(dW), ptr(db), ptr(sc),
                                  sc.numel(), stream_ptr()))
         return dx, dW, db
