@@ -302,6 +302,28 @@ int tsd_pair_distance(int32_t capacity_u, tsd_edges list_u, const float* pos, fl
 int tsd_gine_aggregate(int32_t num_nodes, int64_t num_edges, int32_t H, int32_t activation, float eps,
                        const float* x, const int64_t* edge_index, const float* edge_attr, float* out,
                        void* stream);
+/* ---- dual-encoder network, reference models/epsnet/dualenc.py ----------------
+ * GINE message pass of the local head over the rows of the symmetric extended edge list `enc`,
+ * restricted to the local edges (enc.type_r > 0, dualenc.py:1222-1223), edge attributes once per
+ * undirected pair (ea_u [capacity_u, H], indexed through enc.umap):
+ *   out[i] = sum_{e in row i, local} act(x[dst e] + ea_u[umap e]) + (1 + eps) x[i]     gin.py:61-73
+ * and its adjoints (dx [N,H], dea_u [capacity_u,H]; either may be NULL). Deterministic, no atomics. */
+int tsd_gine_csr_fwd(int32_t num_nodes, int32_t H, int32_t activation, float eps, tsd_edges enc,
+                     const float* ea_u, const float* x, float* out, void* stream);
+int tsd_gine_csr_bwd(int32_t num_nodes, int32_t capacity_u, int32_t H, int32_t activation, float eps, tsd_edges enc,
+                     tsd_edges enc_u, const float* ea_u, const float* x, const float* dout, float* dx, float* dea_u,
+                     void* stream);
+/* torch.nn.Embedding(max_norm) side effect of the global SchNet's node embedding (schnet.py:151): rows
+ * table[idx[k]] with 2-norm > max_norm are rescaled in place by max_norm / (norm + 1e-7).
+ * scratch: num_rows int32. */
+int tsd_embedding_renorm(int32_t num_rows, int32_t H, int32_t n, const int64_t* idx, float max_norm, float* table,
+                         int32_t* scratch, void* stream);
+/* eps_pos of the dual-encoder sampler (dualenc.py:826-849):
+ *   out = clip_norm(eq_local, clip_local) + clip_norm(eq_global, clip_global) * w_global
+ * a negative clip disables that clip; eq_global NULL drops the global term. */
+int tsd_dual_score(int32_t num_nodes, const float* eq_local, const float* eq_global, float clip_local,
+                   float clip_global, float w_global, float* out, void* stream);
+
 /* GaussianSmearingEdgeEncoder (models/encoder/edge.py:18-41): the radial-basis expansion
  *   out[e] = [exp(coeff (d_e - offset_k)^2) for k < K, bond_emb[type_e]]   -> [E, 2K] */
 int tsd_gaussian_edge_encode(int64_t num_edges, int32_t K, float coeff, const float* d, const float* offset,

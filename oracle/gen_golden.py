@@ -330,6 +330,154 @@ def main():
              rbf_d=dlen.numpy(), rbf_type=typ.numpy(), rbf_out=rout.numpy(),
              **{"rbf." + k: v.numpy() for k, v in rbf.state_dict().items()})
 
+
+    # --- H: GeoDiff legacy dual-encoder network, the unchanged reference class -----------
+    if not ONLY or any(n.startswith("dual_") for n in ONLY):
+        import importlib
+        dual_mod = importlib.import_module("models.epsnet.dualenc")
+
+        def trainable(model):
+            return {k: v for k, v in model.state_dict().items()
+                    if not k.startswith("model_") and k not in ("betas", "alphas")}
+
+        def dual_inputs(b, ts):
+            bt = b["bond_type"] if ts else synth.single_bond_types(b["bond_type"])
+            return {"atom_type": b["atom_type"], "bond_index": b["bond_index"], "bond_type": bt, "batch": b["batch"],
+                    "num_nodes_per_graph": b["num_nodes_per_graph"], "pos": b["pos"]}
+
+        def dual_fwd(model, x, pos, **kw):
+            G = int(x["num_nodes_per_graph"].shape[0])
+            with torch.no_grad():
+                o = model(torch.from_numpy(x["atom_type"]), torch.from_numpy(pos), torch.from_numpy(x["bond_index"]),
+                          torch.from_numpy(x["bond_type"]), torch.from_numpy(x["batch"]),
+                          torch.zeros(G, dtype=torch.long), return_edges=True, **kw)
+            names = ("edge_inv_global", "edge_inv_local", "edge_index", "edge_type", "edge_length", "local_edge_mask")
+            return {n: v.numpy() for n, v in zip(names, o)}
+
+        def dual_loss(model, x, G):
+            cap = {}
+            o_randint = torch.randint
+
+            def rint(*a, **k):
+                v = o_randint(*a, **k)
+                cap.setdefault("half", v.clone())
+                return v
+
+            o_normal = torch.Tensor.normal_
+
+            def nrm(self, *a, **k):
+                o_normal(self, *a, **k)
+                cap.setdefault("pos_noise", self.clone())
+                return self
+
+            # gin.py:139 adds the shortcut IN PLACE to the output of nn.ReLU; torch >= 1.9 differentiates ReLU
+            # through its output and refuses (torch 1.8.1, which the reference pins, used the input).  Swap the
+            # encoder's activation object for an input-differentiated ReLU -- same values, same gradient.
+            class _ReLUFromInput(torch.nn.Module):
+                def forward(self, t):
+                    return t.clamp(min=0)
+
+            saved_act = model.encoder_local.activation
+            model.encoder_local.activation = _ReLUFromInput()
+            torch.manual_seed(77)
+            torch.randint, torch.Tensor.normal_ = rint, nrm
+            try:
+                model.zero_grad()
+                loss, lg, ll = model.get_loss(
+                    torch.from_numpy(x["atom_type"]), torch.from_numpy(x["pos"]), torch.from_numpy(x["bond_index"]),
+                    torch.from_numpy(x["bond_type"]), torch.from_numpy(x["batch"]),
+                    torch.from_numpy(x["num_nodes_per_graph"]), G, return_unreduced_loss=True)
+            finally:
+                torch.randint, torch.Tensor.normal_ = o_randint, o_normal
+            loss.mean().backward()
+            model.encoder_local.activation = saved_act
+            T = model.num_timesteps
+            ts_ = torch.cat([cap["half"], T - cap["half"] - 1])[:G]
+            grads = {k: p.grad.numpy() for k, p in model.named_parameters()
+                     if p.grad is not None and not k.startswith("model_")}
+            return {"time_step": ts_.numpy(), "pos_noise": cap["pos_noise"].numpy(), "loss": loss.detach().numpy(),
+                    "loss_global": lg.detach().numpy(), "loss_local": ll.detach().numpy()}, grads
+
+        def dual_sample(model, x, G, n_steps, **kw):
+            rec = []
+            o_rl = torch.randn_like
+
+            def rl(t, *a, **k):
+                v = o_rl(t, *a, **k)
+                rec.append(v.clone())
+                return v
+
+            torch.manual_seed(31)
+            torch.randn_like = rl
+            try:
+                with contextlib.redirect_stderr(io.StringIO()):
+                    pos, traj = model.langevin_dynamics_sample(
+                        torch.from_numpy(x["atom_type"]), torch.from_numpy(x["pos"]),
+                        torch.from_numpy(x["bond_index"]), torch.from_numpy(x["bond_type"]),
+                        torch.from_numpy(x["batch"]), G, True, n_steps=n_steps, **kw)
+            finally:
+                torch.randn_like = o_rl
+            return torch.stack(rec).numpy(), torch.stack(traj).numpy()
+
+        for ts in (False, True):
+            name = "dual_small_ts" if ts else "dual_small"
+            if ONLY and name not in ONLY:
+                continue
+            cfg_d = synth.small_dual_config(ts=ts)
+            torch.manual_seed(4321)
+            model = dual_mod.DualEncoderEpsNetwork(R.EasyDict(cfg_d))
+            with torch.no_grad():  # make nn.Embedding(max_norm=10) bind for half of the rows
+                model.encoder_global.node_emb.weight[::2] *= 2.5
+                for p in (model.encoder_local.node_emb.weight, model.edge_encoder_local.bond_emb.weight):
+                    p *= 0.5
+            sd0 = {k: v.clone().numpy() for k, v in trainable(model).items()}
+            model.eval()
+            b = synth.wb97xd3_like_batch(4, seed=21, n_lo=5, n_hi=12)
+            x = dual_inputs(b, ts)
+            G = 4
+            arrays = {"sd." + k: v for k, v in sd0.items()}
+            arrays.update({"in_" + k: v for k, v in x.items()})
+            pos_far = (x["pos"] * 4.0).astype(np.float32)
+            for tag, pos, kw in (("fwd", x["pos"], {}), ("far", pos_far, {}),
+                                 ("noorder", pos_far, {"extend_order": False}),
+                                 ("noradius", x["pos"], {"extend_radius": False})):
+                arrays.update({f"{tag}.{k}": v for k, v in dual_fwd(model, x, pos, **kw).items()})
+            lo, grads = dual_loss(model, x, G)
+            arrays.update({"loss." + k: v for k, v in lo.items()})
+            if not ts:  # every gradient in full; the TS variant keeps its size down with norms + three full ones
+                arrays.update({"grad." + k: v for k, v in grads.items()})
+            else:
+                arrays.update({"grad." + k: grads[k] for k in ("edge_cat_global.0.weight", "edge_cat_local.2.weight",
+                                                               "edge_encoder_local.bond_emb.weight")})
+            grad_norms = {k: float(np.linalg.norm(v)) for k, v in grads.items()}
+            if not ts:
+                xs = dict(x)
+                xs["pos"] = (x["pos"] * 0.02).astype(np.float32)  # pos_init; the sampler scales it by sigma_T
+                for st, kw in (("ld", dict(sampling_type="ld", step_lr=1e-6)),
+                               ("ddpm_noisy", dict(clip_local=3.0)),
+                               ("ddpm_det", dict(sampling_type="ddpm_det", global_start_sigma=0.5, clip_pos=40.0)),
+                               ("generalized", dict(sampling_type="generalized", eta=0.7, w_global=0.35))):
+                    noise, traj = dual_sample(model, xs, G, 6, **kw)
+                    arrays[f"samp.{st}.noise"], arrays[f"samp.{st}.traj"] = noise, traj
+                arrays["samp.pos_init"] = xs["pos"]
+            keys = sorted(k for k in model.state_dict().keys())
+            save(name, {"cfg": cfg_d, "state_dict_keys": keys, "grad_norms": grad_norms}, **arrays)
+
+        if not ONLY or "dual_qm9_fwd" in ONLY:  # the shipped legacy config, closed-form weights
+            cfg_d = dict(synth.LEGACY_QM9_MODEL_CONFIG)
+            torch.manual_seed(1)
+            model = dual_mod.DualEncoderEpsNetwork(R.EasyDict(cfg_d))
+            tr = trainable(model)
+            sd = synth.hash_state_dict([(k, v.shape) for k, v in tr.items() if not k.endswith(".eps")], seed=3)
+            model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+            model.eval()
+            b = synth.wb97xd3_like_batch(3, seed=5, n_lo=8, n_hi=20)
+            x = dual_inputs(b, False)
+            o = dual_fwd(model, x, (x["pos"] * 2.0).astype(np.float32))
+            save("dual_qm9_fwd", {"cfg": cfg_d, "seed": 3, "names": [k for k in sd]},
+                 **{"in_" + k: v for k, v in x.items()}, pos=(x["pos"] * 2.0).astype(np.float32),
+                 edge_inv_global=o["edge_inv_global"], edge_inv_local=o["edge_inv_local"], edge_type=o["edge_type"])
+
     # --- F: get_loss with captured random draws + gradient norms ---------------------------
     def run_loss(model, b, name, cfg, seed):
         bt = tt(b)

@@ -169,7 +169,8 @@ def cfconv_aggregate(x1, W, edge_index, N):
     return torch.zeros(N, W.size(1), dtype=W.dtype).index_add_(0, edge_index[1], msg)
 
 
-def schnet_encoder(sd, z, edge_index, edge_length, edge_attr, num_convs, cutoff, trace=None, smooth=False):
+def schnet_encoder(sd, z, edge_index, edge_length, edge_attr, num_convs, cutoff, trace=None, smooth=False,
+                   prefix="encoder."):
     """reference schnet.py:203-225 / 110-128 / 74-107."""
     h = z
     if smooth:  # schnet.py:92-96
@@ -178,7 +179,7 @@ def schnet_encoder(sd, z, edge_index, edge_length, edge_attr, num_convs, cutoff,
     else:
         C = (edge_length <= cutoff).to(z.dtype).view(-1, 1)
     for l in range(num_convs):
-        p = f"encoder.interactions.{l}."
+        p = f"{prefix}interactions.{l}."
         W = F.linear(ssp(F.linear(edge_attr, sd[p + "conv.nn.0.weight"], sd[p + "conv.nn.0.bias"])),
                      sd[p + "conv.nn.2.weight"], sd[p + "conv.nn.2.bias"]) * C
         x1 = F.linear(h, sd[p + "conv.lin1.weight"])

@@ -134,6 +134,11 @@ SIGNATURES = {
     "tsd_pair_distance": (C.c_int, [C.c_int32, Edges, _P, _P, _P]),
     "tsd_gine_aggregate": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_float, _P, _P, _P, _P, _P]),
     "tsd_gaussian_edge_encode": (C.c_int, [C.c_int64, C.c_int32, C.c_float, _P, _P, _P, _P, _P, _P]),
+    "tsd_gine_csr_fwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_float, Edges, _P, _P, _P, _P]),
+    "tsd_gine_csr_bwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, Edges, Edges, _P, _P, _P,
+                                   _P, _P, _P]),
+    "tsd_embedding_renorm": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.c_float, _P, _P, _P]),
+    "tsd_dual_score": (C.c_int, [C.c_int32, _P, _P, C.c_float, C.c_float, C.c_float, _P, _P]),
     "tsd_sampler_run": (C.c_int, [_CFG, C.POINTER(Batch), C.c_int32, C.c_int32, _P, _P, C.c_float, C.c_float,
                                   _P, _P, _P, C.c_int32, _P]),
 }

@@ -426,6 +426,127 @@ __global__ void gaussian_edge_kernel(int64_t E, int K, float coeff, const float*
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Dual-encoder (GeoDiff legacy) network, reference models/epsnet/dualenc.py.
+// The local head's GINE message pass over the rows of the symmetric extended edge list, restricted to
+// the local edges (type > 0, dualenc.py:1222-1223); edge attributes live once per undirected pair:
+//   out[i] = sum_{e in row i, type e > 0} act(x[dst e] + ea_u[umap e])  +  (1 + eps) x[i]
+// (gin.py:61-73: the neighbours of target i arrive in ascending source order = the CSR row order).
+__device__ __forceinline__ float gine_act(int act, float v) {
+    return act == 1 ? fmaxf(v, 0.0f) : act == 2 ? sspf(v) + 0.69314718055994530942f : v;
+}
+__device__ __forceinline__ float gine_dact(int act, float v) {
+    return act == 1 ? (v > 0.0f ? 1.0f : 0.0f) : act == 2 ? __builtin_amdgcn_rcpf(1.0f + fast_exp(-v)) : 1.0f;
+}
+__global__ void gine_csr_fwd_kernel(int H, int act, float eps, const int32_t* __restrict__ row_ptr,
+                                    const int32_t* __restrict__ dst, const int32_t* __restrict__ umap,
+                                    const uint8_t* __restrict__ type, const float* __restrict__ ea_u,
+                                    const float* __restrict__ x, float* __restrict__ out) {
+    const int i = blockIdx.x;
+    const int lo = row_ptr[i], hi = row_ptr[i + 1];
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        float acc = 0.0f;
+        for (int e = lo; e < hi; ++e)
+            if (type[e]) acc += gine_act(act, x[(size_t)dst[e] * H + c] + ea_u[(size_t)umap[e] * H + c]);
+        out[(size_t)i * H + c] = acc + (1.0f + eps) * x[(size_t)i * H + c];
+    }
+}
+// adjoint w.r.t. x: node i sent act(x_i + ea_ij) to every local neighbour j
+//   dx[i] = (1 + eps) dout[i] + sum_{e in row i, local} dout[dst e] * act'(x[i] + ea_u[umap e])
+__global__ void gine_csr_bwd_x_kernel(int H, int act, float eps, const int32_t* __restrict__ row_ptr,
+                                      const int32_t* __restrict__ dst, const int32_t* __restrict__ umap,
+                                      const uint8_t* __restrict__ type, const float* __restrict__ ea_u,
+                                      const float* __restrict__ x, const float* __restrict__ dout,
+                                      float* __restrict__ dx) {
+    const int i = blockIdx.x;
+    const int lo = row_ptr[i], hi = row_ptr[i + 1];
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        const float xi = x[(size_t)i * H + c];
+        float acc = 0.0f;
+        for (int e = lo; e < hi; ++e)
+            if (type[e])
+                acc += dout[(size_t)dst[e] * H + c] * gine_dact(act, xi + ea_u[(size_t)umap[e] * H + c]);
+        dx[(size_t)i * H + c] = acc + (1.0f + eps) * dout[(size_t)i * H + c];
+    }
+}
+// adjoint w.r.t. the undirected edge attribute: pair u = {i, j} carried the messages i -> j and j -> i
+__global__ void gine_csr_bwd_ea_kernel(int Eu, int H, int act, const int32_t* __restrict__ count,
+                                       const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                       const uint8_t* __restrict__ type, const float* __restrict__ ea_u,
+                                       const float* __restrict__ x, const float* __restrict__ dout,
+                                       float* __restrict__ dea_u) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)Eu * H) return;
+    const int u = (int)(t / H), c = (int)(t % H);
+    float g = 0.0f;
+    if (u < *count && type[u]) {
+        const int i = src[u], j = dst[u];
+        const float a = ea_u[t];
+        g = dout[(size_t)j * H + c] * gine_dact(act, x[(size_t)i * H + c] + a) +
+            dout[(size_t)i * H + c] * gine_dact(act, x[(size_t)j * H + c] + a);
+    }
+    dea_u[t] = g;
+}
+
+// torch.nn.Embedding(max_norm) look-up side effect (schnet.py:151 `Embedding(100, H, max_norm=10.0)`):
+// every row that is looked up and whose 2-norm exceeds max_norm is rescaled IN PLACE by
+// max_norm / (norm + 1e-7) before the gather (torch embedding_renorm_).  Idempotent per row.
+__global__ void emb_mark_kernel(int n, const int64_t* __restrict__ idx, int32_t* __restrict__ used) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) used[idx[i]] = 1;
+}
+__global__ __launch_bounds__(64) void emb_renorm_kernel(int H, float max_norm, const int32_t* __restrict__ used,
+                                                        float* __restrict__ table) {
+    const int r = blockIdx.x;
+    if (!used[r]) return;
+    float s = 0.0f;
+    for (int c = threadIdx.x; c < H; c += 64) {
+        const float v = table[(size_t)r * H + c];
+        s = fmaf(v, v, s);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    const float norm = sqrtf(s);
+    if (norm > max_norm) {
+        const float scale = max_norm / (norm + 1e-7f);
+        for (int c = threadIdx.x; c < H; c += 64) table[(size_t)r * H + c] *= scale;
+    }
+}
+
+// eps_pos of the dual-encoder sampler (dualenc.py:826-849):
+//   out = clip_norm(eq_local, clip_local) + clip_norm(eq_global, clip_global) * w_global
+// clip < 0: no clipping; eq_global NULL: the global term is dropped (sigma >= global_start_sigma)
+__global__ void dual_score_kernel(int N, const float* __restrict__ eq_local, const float* __restrict__ eq_global,
+                                  float clip_local, float clip_global, float w_global, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float l[3], g[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) l[k] = eq_local[3 * i + k];
+    if (clip_local >= 0.0f) {
+        const float n = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(l[0], l[0]), __fmul_rn(l[1], l[1])), __fmul_rn(l[2], l[2])));
+        const float d = n > clip_local ? clip_local / n : 1.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) l[k] = __fmul_rn(l[k], d);
+    }
+    if (eq_global) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g[k] = eq_global[3 * i + k];
+        if (clip_global >= 0.0f) {
+            const float n =
+                sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(g[0], g[0]), __fmul_rn(g[1], g[1])), __fmul_rn(g[2], g[2])));
+            const float d = n > clip_global ? clip_global / n : 1.0f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) g[k] = __fmul_rn(g[k], d);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) l[k] = __fadd_rn(l[k], __fmul_rn(g[k], w_global));
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[3 * i + k] = l[k];
+}
+
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace tsd
@@ -519,6 +640,49 @@ int tsd_gine_aggregate(int32_t num_nodes, int64_t num_edges, int32_t H, int32_t 
         hipLaunchKernelGGL(gine_message_kernel, dim3(blocks_for(num_edges * H)), dim3(256), 0, st, num_edges, H,
                            activation, x, edge_index, edge_attr, out);
     TSD_LAUNCH_CHECK("gine_aggregate");
+    return TSD_OK;
+}
+
+int tsd_gine_csr_fwd(int32_t num_nodes, int32_t H, int32_t activation, float eps, tsd_edges enc,
+                     const float* ea_u, const float* x, float* out, void* stream) {
+    TSD_REQUIRE(activation >= 0 && activation <= 2, "activation %d (0 none, 1 relu, 2 softplus)", activation);
+    if (num_nodes == 0) return TSD_OK;
+    hipLaunchKernelGGL(gine_csr_fwd_kernel, dim3(num_nodes), dim3(H < 256 ? (H + 63) / 64 * 64 : 256), 0,
+                       (hipStream_t)stream, H, activation, eps, enc.row_ptr, enc.dst, enc.umap, enc.type_r, ea_u, x, out);
+    TSD_LAUNCH_CHECK("gine_csr_fwd");
+    return TSD_OK;
+}
+int tsd_gine_csr_bwd(int32_t num_nodes, int32_t capacity_u, int32_t H, int32_t activation, float eps, tsd_edges enc,
+                     tsd_edges enc_u, const float* ea_u, const float* x, const float* dout, float* dx, float* dea_u,
+                     void* stream) {
+    TSD_REQUIRE(activation >= 0 && activation <= 2, "activation %d (0 none, 1 relu, 2 softplus)", activation);
+    hipStream_t st = (hipStream_t)stream;
+    if (dx && num_nodes > 0)
+        hipLaunchKernelGGL(gine_csr_bwd_x_kernel, dim3(num_nodes), dim3(H < 256 ? (H + 63) / 64 * 64 : 256), 0, st, H,
+                           activation, eps, enc.row_ptr, enc.dst, enc.umap, enc.type_r, ea_u, x, dout, dx);
+    if (dea_u && capacity_u > 0)
+        hipLaunchKernelGGL(gine_csr_bwd_ea_kernel, dim3(blocks_for((int64_t)capacity_u * H)), dim3(256), 0, st,
+                           capacity_u, H, activation, enc_u.count, enc_u.src, enc_u.dst, enc_u.type_r, ea_u, x, dout,
+                           dea_u);
+    TSD_LAUNCH_CHECK("gine_csr_bwd");
+    return TSD_OK;
+}
+int tsd_embedding_renorm(int32_t num_rows, int32_t H, int32_t n, const int64_t* idx, float max_norm, float* table,
+                         int32_t* scratch, void* stream) {
+    if (n == 0 || num_rows == 0) return TSD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    TSD_HIP(hipMemsetAsync(scratch, 0, (size_t)num_rows * sizeof(int32_t), st));
+    hipLaunchKernelGGL(emb_mark_kernel, dim3(blocks_for(n)), dim3(256), 0, st, n, idx, scratch);
+    hipLaunchKernelGGL(emb_renorm_kernel, dim3(num_rows), dim3(64), 0, st, H, max_norm, scratch, table);
+    TSD_LAUNCH_CHECK("embedding_renorm");
+    return TSD_OK;
+}
+int tsd_dual_score(int32_t num_nodes, const float* eq_local, const float* eq_global, float clip_local,
+                   float clip_global, float w_global, float* out, void* stream) {
+    if (num_nodes == 0) return TSD_OK;
+    hipLaunchKernelGGL(dual_score_kernel, dim3(blocks_for(num_nodes)), dim3(256), 0, (hipStream_t)stream, num_nodes,
+                       eq_local, eq_global, clip_local, clip_global, w_global, out);
+    TSD_LAUNCH_CHECK("dual_score");
     return TSD_OK;
 }
 

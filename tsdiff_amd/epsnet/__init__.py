@@ -6,6 +6,8 @@ def get_model(config):
     if network == "condensenc":
         from .condensenc import CondenseEncoderEpsNetwork
         return CondenseEncoderEpsNetwork(config)
-    # `dualenc` is the GeoDiff legacy network that the shipped train.py / sampler.py cannot drive
-    # (SURVEY.md section 0); `dualenc_general` imports a file that does not exist in the reference.
+    if network == "dualenc":  # GeoDiff legacy network (configs/geodiff_legacy/*.yml)
+        from .dualenc import DualEncoderEpsNetwork
+        return DualEncoderEpsNetwork(config)
+    # `dualenc_general` imports a file that does not exist in the reference.
     raise NotImplementedError("Unknown network: %s" % network)

@@ -269,3 +269,42 @@ def replicate(graph, times, pos_list=None):
             d["pos"] = np.asarray(pos_list[k], dtype=np.float32)
         gs.append(d)
     return collate(gs)
+
+
+# ----------------------------------------------------------------------------
+# GeoDiff legacy dual-encoder network (reference configs/geodiff_legacy/qm9_default.yml:1-16)
+# ----------------------------------------------------------------------------
+LEGACY_QM9_MODEL_CONFIG = {
+    "type": "diffusion", "network": "dualenc", "hidden_dim": 128, "num_convs": 6, "num_convs_local": 4,
+    "cutoff": 10.0, "mlp_act": "ReLU", "beta_schedule": "sigmoid", "beta_start": 1.0e-7, "beta_end": 2.0e-3,
+    "num_diffusion_timesteps": 5000, "edge_order": 3, "edge_encoder": "mlp", "smooth_conv": False,
+}
+
+
+def small_dual_config(hidden=64, num_convs=2, num_convs_local=2, ts=False):
+    cfg = dict(LEGACY_QM9_MODEL_CONFIG)
+    cfg.update(hidden_dim=hidden, num_convs=num_convs, num_convs_local=num_convs_local)
+    if ts:
+        cfg.update(TS=True, edge_cat_act="ReLU")
+    return cfg
+
+
+def single_bond_types(bond_type):
+    """composite r*22+p reaction bond types -> one plain bond type per bond (1..21), for the single-graph
+    legacy network"""
+    bt = np.asarray(bond_type)
+    r, p = bt // NUM_BOND_TYPES, bt % NUM_BOND_TYPES
+    return np.where(r > 0, r, p).astype(np.int64)
+
+
+def hash_state_dict(named_shapes, seed=0):
+    """closed-form weights for ANY list of (name, shape): embeddings ~ U(-sqrt3, sqrt3), matrices and
+    biases ~ U(-1/sqrt(fan), 1/sqrt(fan)) with fan = last dimension (matrices) or length (vectors)."""
+    out = {}
+    for name, shape in named_shapes:
+        shape = tuple(int(x) for x in shape)
+        n = int(np.prod(shape)) if shape else 1
+        u = hash_uniform(n, seed, _stream_id(name))
+        bound = np.sqrt(3.0) if "emb." in name else 1.0 / np.sqrt(max(shape[-1] if shape else 1, 1))
+        out[name] = ((2.0 * u - 1.0) * bound).astype(np.float32).reshape(shape)
+    return out

@@ -302,3 +302,126 @@ def train_forward(model, db, pos):
     x = swish(linear(x, P[g + "1.weight"], P[g + "1.bias"]))
     s_u = linear(x, P[g + "2.weight"], P[g + "2.bias"]).view(-1)
     return s_u, Eo
+
+
+# ---------------------------------------------------------------------------------------------
+# dual-encoder (GeoDiff legacy) network, reference models/epsnet/dualenc.py:206-374
+class Gine(torch.autograd.Function):
+    """GINEConv message pass + self term over the local edges of the symmetric extended graph
+    (gin.py:61-73), edge attributes once per undirected pair."""
+
+    @staticmethod
+    def forward(ctx, x, ea_u, db, act, eps):
+        lib = _lib.load()
+        x, ea_u = _c(x), _c(ea_u)
+        N, H = x.shape
+        out = torch.empty_like(x)
+        check(lib.tsd_gine_csr_fwd(N, H, act, eps, db.enc.struct(), ptr(ea_u), ptr(x), ptr(out), stream_ptr()))
+        ctx.save_for_backward(x, ea_u)
+        ctx.db, ctx.act, ctx.eps = db, act, eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        x, ea_u = ctx.saved_tensors
+        dout = _c(dout)
+        N, H = x.shape
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dea = torch.empty_like(ea_u) if ctx.needs_input_grad[1] else None
+        check(lib.tsd_gine_csr_bwd(N, ea_u.shape[0], H, ctx.act, ctx.eps, ctx.db.enc.struct(), ctx.db.enc_u.struct(),
+                                   ptr(ea_u), ptr(x), ptr(dout), ptr(dx), ptr(dea), stream_ptr()))
+        return dx, dea, None, None, None
+
+
+_ACT_KIND = {"swish": 0, "ReLU": 2, "Softplus": 3}
+_GINE_ACT = {None: 0, "ReLU": 1, "Softplus": 2}
+
+
+def dual_forward(model, db, pos):
+    """Both heads of DualEncoderEpsNetwork.forward on the current geometry, per UNDIRECTED pair of the
+    extended graph (every per-edge quantity of the reference is symmetric under i <-> j).  Differentiable
+    w.r.t. the parameters when autograd is on."""
+    lib = _lib.load()
+    P = dict(model.named_parameters())
+    cfg = db.cfg
+    H = cfg.hidden
+    db.geometry(pos)
+    Eu = db.enc_u.num_edges()  # host sync; the edge set is symmetric: E = 2 Eu
+    E = 2 * Eu
+    t_u, t_dir = db.enc_u.type_r[:Eu], db.enc.type_r[:E]
+    if model.TS:  # dualenc.py:266-283: bonded pairs carry (r, p), k-hop pairs 22 + k - 1 in both slots
+        def raw(lst, n):
+            code = db.pair_code_raw[lst.pair_id[:n].long()].to(torch.int32) & 0xFFFF
+            return (code & 31), ((code >> 5) & 31)
+        r_u, p_u = raw(db.enc_u, Eu)
+        bonded_u = t_u == 1
+        t1_u = torch.where(bonded_u, r_u.to(torch.uint8), t_u).contiguous()
+        t2_u = torch.where(bonded_u, p_u.to(torch.uint8), t_u).contiguous()
+        r_d, p_d = raw(db.enc, E)
+        edge_type_dir = torch.where(t_dir == 1, (r_d * 22 + p_d).to(torch.int64), t_dir.to(torch.int64) + 462)
+    else:
+        t1_u = t2_u = t_u
+        edge_type_dir = torch.where(t_dir < 22, t_dir.to(torch.int64), t_dir.to(torch.int64) + 462)
+    edge_type_dir = torch.where(t_dir == 0, torch.zeros_like(edge_type_dir), edge_type_dir)
+
+    act = _ACT_KIND[model.mlp_act]
+    d = db.enc_u.dist[:Eu].clone().unsqueeze(-1)
+    dist_u = db.enc_u.dist[:Eu].clone()
+
+    def embed(enc, cat):  # edge.py:58-68 (+ dualenc.py:266-283 for TS)
+        e = linear(Act.apply(linear(d, P[enc + ".mlp.layers.0.weight"], P[enc + ".mlp.layers.0.bias"]), act),
+                   P[enc + ".mlp.layers.1.weight"], P[enc + ".mlp.layers.1.bias"])
+        emb = P[enc + ".bond_emb.weight"]
+        if not model.TS:
+            return EmbMul.apply(e, emb, t1_u)
+        c = torch.cat([EmbMul.apply(e, emb, t1_u), EmbMul.apply(e, emb, t2_u)], dim=-1)
+        s1 = Act.apply(linear(c, P[cat + ".0.weight"], P[cat + ".0.bias"]), _ACT_KIND[model.edge_cat_act])
+        return linear(s1, P[cat + ".2.weight"], P[cat + ".2.bias"])
+
+    def pair_mlp(prefix, hp):  # common.py:226-229 + MultiLayerPerceptron
+        x = Act.apply(linear(hp, P[prefix + ".layers.0.weight"], P[prefix + ".layers.0.bias"]), act)
+        x = Act.apply(linear(x, P[prefix + ".layers.1.weight"], P[prefix + ".layers.1.bias"]), act)
+        return linear(x, P[prefix + ".layers.2.weight"], P[prefix + ".layers.2.bias"]).view(-1)
+
+    # ---- global head: SchNet with its own node embedding (schnet.py:203-225, embed_node=True) ----
+    ea_g = embed("edge_encoder_global", "edge_cat_global")
+    w = P["encoder_global.node_emb.weight"]
+    with torch.no_grad():  # nn.Embedding(max_norm=10) renormalises the looked-up rows in place
+        check(lib.tsd_embedding_renorm(w.shape[0], H, db.N, ptr(db.atom_type), 10.0, ptr(w), ptr(db.renorm_scratch),
+                                       stream_ptr()))
+    h = GatherRows.apply(w, db.atom_type)
+    for l in range(cfg.num_convs):
+        p = f"encoder_global.interactions.{l}."
+        Wf = linear(ssp(linear(ea_g, P[p + "conv.nn.0.weight"], P[p + "conv.nn.0.bias"])),
+                    P[p + "conv.nn.2.weight"], P[p + "conv.nn.2.bias"])
+        Wf = RowMask.apply(Wf, dist_u, cfg.conv_cutoff, cfg.smooth_conv)
+        x1 = linear(h, P[p + "conv.lin1.weight"])
+        agg = Aggregate.apply(x1, Wf, db)
+        x = linear(agg, P[p + "conv.lin2.weight"], P[p + "conv.lin2.bias"])
+        h = h + linear(ssp(x), P[p + "lin.weight"], P[p + "lin.bias"])
+    s_global_u = pair_mlp("grad_global_dist_mlp", torch.cat([PairProduct.apply(h, db, Eu), ea_g], dim=-1))
+
+    # ---- local head: GINE on the edges with type > 0 (gin.py:79-149) ----
+    ea_l = embed("edge_encoder_local", "edge_cat_local")
+    enc = model.encoder_local
+    gact, nact = _GINE_ACT[enc.activation], (_ACT_KIND[enc.activation] if enc.activation else None)
+    x = GatherRows.apply(P["encoder_local.node_emb.weight"], db.atom_type)
+    hiddens = []
+    for k, conv in enumerate(enc.convs):
+        q = f"encoder_local.convs.{k}.nn.layers."
+        agg = Gine.apply(x, ea_l, db, gact, float(conv.initial_eps))
+        y = linear(agg, P[q + "0.weight"], P[q + "0.bias"])
+        if nact is not None:
+            y = Act.apply(y, nact)
+        y = linear(y, P[q + "1.weight"], P[q + "1.bias"])
+        if k < len(enc.convs) - 1 and nact is not None:
+            y = Act.apply(y, nact)
+        if enc.short_cut:
+            y = y + x
+        hiddens.append(y)
+        x = y
+    hl = torch.cat(hiddens, dim=-1) if enc.concat_hidden else hiddens[-1]
+    s_local_u = pair_mlp("grad_local_dist_mlp", torch.cat([PairProduct.apply(hl, db, Eu), ea_l], dim=-1))
+    return {"s_global_u": s_global_u, "s_local_u": s_local_u, "Eu": Eu, "E": E, "emb_type_u": t_u,
+            "emb_type_dir": t_dir, "edge_type_dir": edge_type_dir}
