@@ -257,12 +257,24 @@ int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t ki
  * runs on the fp32 MFMA (in, out in {128,256,512}); otherwise / without scratch a plain VALU kernel runs. */
 int tsd_linear_fwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* b,
                    float* Y, float* scratch, size_t scratch_floats, void* stream);
+/* The optimizer rewrites every weight every step: pack all dense weights of a step with ONE launch.
+ * Item k: W[k] [out_dim k, in_dim k] row major -> dst[k] (out*in floats) in the forward layout
+ * (transposed[k] == 0, for tsd_linear_fwd_packed) or the dgrad layout (transposed[k] != 0, `Wp_t` of
+ * tsd_linear_bwd).  W / dst / the three int arrays are HOST arrays of n entries (device pointers inside).
+ * tsd_linear_packable: 1 if (in, out) runs on the MFMA kernels (both in {128, 256, 512}). */
+int tsd_linear_packable(int32_t in, int32_t out);
+int tsd_pack_linear_batch(int32_t n, const float* const* W_host, float* const* dst_host, const int32_t* out_dim_host,
+                          const int32_t* in_dim_host, const int32_t* transposed_host, void* stream);
+int tsd_linear_fwd_packed(int32_t rows, int32_t in, int32_t out, const float* X, const float* Wp, const float* b,
+                          float* Y, void* stream);
 /* dX = dY W (NULL: skip); dW = dY^T X (NULL: skip); db = column sums of dY (NULL: skip).
- * scratch layout: 64*out floats (deterministic two-stage bias reduction) | in*out floats (W packed for the
- * MFMA dgrad) | S*out*in floats, S <= 64 (row-split MFMA wgrad partials, summed in split order).
+ * Wp_t: W packed in the dgrad layout (tsd_pack_linear_batch) or NULL (packed here into scratch).
+ * scratch layout: 64*out floats (bias partials) | in*out floats (W packed for the MFMA dgrad) |
+ * 64*out*in floats (row-split wgrad partials, summed in a fixed order: deterministic).
  * With less scratch, or shapes that are not multiples of 128, plain VALU kernels run instead. */
-int tsd_linear_bwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* dY,
-                   float* dX, float* dW, float* db, float* scratch, size_t scratch_floats, void* stream);
+int tsd_linear_bwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* Wp_t,
+                   const float* dY, float* dX, float* dW, float* db, float* scratch, size_t scratch_floats,
+                   void* stream);
 /* kind 0: swish (utils/activation_functions.py), 1: shifted softplus (schnet.py:65-71), 2: ReLU, 3: softplus;
  * x = pre-activation */
 int tsd_act_fwd(int32_t kind, int64_t n, const float* x, float* y, void* stream);

@@ -503,15 +503,25 @@ def test_training_primitives_at_scale(dev):
         _lib.check(lib.tsd_linear_fwd(rows, fin, out, _lib.ptr(X), _lib.ptr(W), _lib.ptr(b), _lib.ptr(Y2), None, 0,
                                       _lib.stream_ptr()))
         assert_close(Y2.cpu().numpy(), Yref, 1e-5, "Y (no scratch)")
-        _lib.check(lib.tsd_linear_bwd(rows, fin, out, _lib.ptr(X), _lib.ptr(W), _lib.ptr(dY), _lib.ptr(dX),
+        _lib.check(lib.tsd_linear_bwd(rows, fin, out, _lib.ptr(X), _lib.ptr(W), None, _lib.ptr(dY), _lib.ptr(dX),
                                       _lib.ptr(dW), _lib.ptr(db), _lib.ptr(sc), sc.numel(), _lib.stream_ptr()))
         assert_close(dW.cpu().numpy(), (dY.double().t() @ X.double()).cpu().numpy(), 1e-5, f"dW {rows}x{fin}x{out}")
         assert_close(dX.cpu().numpy(), (dY.double() @ W.double()).cpu().numpy(), 1e-5, "dX")
         assert_close(db.cpu().numpy(), dY.double().sum(0).cpu().numpy(), 1e-5, "db")
         dW2 = torch.empty_like(dW)  # deterministic: a second call is bit-identical
-        _lib.check(lib.tsd_linear_bwd(rows, fin, out, _lib.ptr(X), _lib.ptr(W), _lib.ptr(dY), None, _lib.ptr(dW2),
+        _lib.check(lib.tsd_linear_bwd(rows, fin, out, _lib.ptr(X), _lib.ptr(W), None, _lib.ptr(dY), None, _lib.ptr(dW2),
                                       None, _lib.ptr(sc), sc.numel(), _lib.stream_ptr()))
         assert torch.equal(dW, dW2)
+        if lib.tsd_linear_packable(fin, out):  # pre-packed weights (one batched pack per training step): same bits
+            from tsdiff_amd import train_ops as T
+            T.prepack([W])
+            Y3, dX3 = torch.empty_like(Y), torch.empty_like(dX)
+            _lib.check(lib.tsd_linear_fwd_packed(rows, fin, out, _lib.ptr(X), _lib.ptr(T._packed(W, 1)), _lib.ptr(b),
+                                                 _lib.ptr(Y3), _lib.stream_ptr()))
+            _lib.check(lib.tsd_linear_bwd(rows, fin, out, _lib.ptr(X), _lib.ptr(W), _lib.ptr(T._packed(W, 2)),
+                                          _lib.ptr(dY), _lib.ptr(dX3), None, None, _lib.ptr(sc), sc.numel(),
+                                          _lib.stream_ptr()))
+            assert torch.equal(Y3, Y) and torch.equal(dX3, dX)
     rows, H = 20000, 256
     x = torch.randn(rows, H, device=dev)
     emb = torch.randn(100, H, device=dev)

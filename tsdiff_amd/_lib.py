@@ -118,7 +118,10 @@ SIGNATURES = {
     "tsd_sampler_step": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_float, C.c_float, _P,
                                    _P, _P]),
     "tsd_linear_fwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_size_t, _P]),
-    "tsd_linear_bwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "tsd_linear_bwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P]),
+    "tsd_linear_packable": (C.c_int, [C.c_int32, C.c_int32]),
+    "tsd_pack_linear_batch": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "tsd_linear_fwd_packed": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "tsd_act_fwd": (C.c_int, [C.c_int32, C.c_int64, _P, _P, _P]),
     "tsd_act_bwd": (C.c_int, [C.c_int32, C.c_int64, _P, _P, _P, _P]),
     "tsd_emb_mul_fwd": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),

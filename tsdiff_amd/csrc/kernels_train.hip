@@ -130,9 +130,11 @@ __global__ __launch_bounds__(256) void wgrad_naive_kernel(int rows, int in, int 
 // ---------------------------------------------------------------------------------------------
 constexpr int WG_T = 32;            // rows per tile
 constexpr int WG_LD = 128 + 4;      // LDS row stride (floats)
+// With `bias_part` != NULL the workgroups of in-block 0 also sum their dY tile's columns (the bias gradient):
+// partial [split][out], reduced together with the weight partials.
 __global__ __launch_bounds__(256) void wgrad_kernel(int rows, int in, int out, int rows_per_split,
                                                     const float* __restrict__ dY, const float* __restrict__ X,
-                                                    float* __restrict__ part) {
+                                                    float* __restrict__ part, float* __restrict__ bias_part) {
     __shared__ __attribute__((aligned(16))) float sY[WG_T * WG_LD];
     __shared__ __attribute__((aligned(16))) float sX[WG_T * WG_LD];
     const int in0 = blockIdx.x * 128, out0 = blockIdx.y * 128;
@@ -161,6 +163,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int rows, int in, int out, i
             }
         }
     };
+    const bool do_bias = bias_part != nullptr && blockIdx.x == 0 && tid < 128;
+    float bsum = 0.0f;
     if (r_begin < r_end) prefetch(r_begin);
     for (int r0 = r_begin; r0 < r_end; r0 += WG_T) {
         __syncthreads();  // previous tile fully consumed
@@ -172,6 +176,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int rows, int in, int out, i
         }
         __syncthreads();
         if (r0 + WG_T < r_end) prefetch(r0 + WG_T);
+        if (do_bias) {  // rows past r_end were staged as zeros
+#pragma unroll 8
+            for (int r = 0; r < WG_T; ++r) bsum += sY[r * WG_LD + tid];
+        }
 #pragma unroll 4
         for (int kk = 0; kk < WG_T / 2; ++kk) {
             const int row = 2 * kk + hi;
@@ -193,13 +201,87 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int rows, int in, int out, i
                 const int o = out0 + wo + a * 32 + acc_row(r, hi), i = in0 + wi + b * 32 + l31;
                 P[(size_t)o * in + i] = acc[a][b][r];
             }
+    if (do_bias) bias_part[(size_t)blockIdx.z * out + out0 + tid] = bsum;
 }
-__global__ void wgrad_reduce_kernel(int64_t n, int S, const float* __restrict__ part, float* __restrict__ dW) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// sums the S split partials in a fixed order: workgroup = 64 consecutive outputs x 4 split quarters
+// (wave q adds splits [q S/4, (q+1) S/4) in order, then ((q0 + q1) + (q2 + q3))).  The weight partials
+// [S][nW] and the bias partials [S][nB] (nB may be 0) are reduced by the same launch.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(int64_t nW, int nB, int S, const float* __restrict__ part,
+                                                           const float* __restrict__ bias_part,
+                                                           float* __restrict__ dW, float* __restrict__ db) {
+    __shared__ float sm[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const int per = S / 4;
     float s = 0.0f;
-    for (int k = 0; k < S; ++k) s += part[(size_t)k * n + i];
-    dW[i] = s;
+    if (i < nW) {
+        for (int k = q * per; k < (q + 1) * per; ++k) s += part[(size_t)k * nW + i];
+    } else if (i < nW + nB) {
+        for (int k = q * per; k < (q + 1) * per; ++k) s += bias_part[(size_t)k * nB + (i - nW)];
+    }
+    sm[q][lane] = s;
+    __syncthreads();
+    if (q == 0) {
+        const float v = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+        if (i < nW) dW[i] = v;
+        else if (i < nW + nB) db[i - nW] = v;
+    }
+}
+
+// wgrad of the narrow layers (Linear(1,H), Linear(25,H/2), Linear(H/2,1)): dW[o,i] = sum_r dY[r,o] X[r,i], in <= 32.
+// Same two-stage column reduction as the bias gradient with `in` accumulators per thread:
+// stage 1: grid (out/64, CS_CHUNKS) -> part[chunk][o*in + i]; stage 2: sums the chunks in order.
+// The out == 1 case is the same problem with the roles of dY and X swapped.
+constexpr int WS_MAX_IN = 32;
+__global__ __launch_bounds__(256) void wgrad_small_kernel(int rows, int in, int out, const float* __restrict__ dY,
+                                                          const float* __restrict__ X, float* __restrict__ part) {
+    __shared__ float sm[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + lane;
+    const int per = (rows + 63) / 64;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+    float acc[WS_MAX_IN];
+#pragma unroll
+    for (int i = 0; i < WS_MAX_IN; ++i) acc[i] = 0.0f;
+    if (o < out)
+        for (int r = r0 + w; r < r1; r += 4) {
+            const float g = dY[(size_t)r * out + o];
+            const float* xr = X + (size_t)r * in;
+#pragma unroll
+            for (int i = 0; i < WS_MAX_IN; ++i)
+                if (i < in) acc[i] = fmaf(g, xr[i], acc[i]);
+        }
+#pragma unroll
+    for (int i = 0; i < WS_MAX_IN; ++i) {
+        if (i >= in) break;
+        __syncthreads();
+        sm[w][lane] = acc[i];
+        __syncthreads();
+        if (w == 0 && o < out)
+            part[((size_t)blockIdx.y * out + o) * in + i] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// All dense weights of a training step packed by ONE launch (forward layout and transposed dgrad layout):
+// the optimizer changes every weight every step, so per-call packing cost 86 launches (0.4 ms) per step.
+#define TSD_PACK_MAX 48
+struct PackBatch {
+    const float* W[TSD_PACK_MAX];
+    float* dst[TSD_PACK_MAX];
+    int ncols[TSD_PACK_MAX], kdim[TSD_PACK_MAX], transposed[TSD_PACK_MAX];
+};
+__global__ void pack_batch_kernel(PackBatch b) {
+    const int it = blockIdx.y;
+    const int ncols = b.ncols[it], kdim = b.kdim[it];
+    const float* __restrict__ M = b.W[it];
+    float* __restrict__ Bp = b.dst[it];
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < ncols * kdim; idx += gridDim.x * blockDim.x) {
+        const int s = idx & 3;
+        const int n = (idx >> 2) % ncols;
+        const int k = ((idx >> 2) / ncols) * 4 + s;
+        Bp[idx] = b.transposed[it] ? M[(size_t)k * ncols + n] : M[(size_t)n * kdim + k];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -570,16 +652,54 @@ int tsd_linear_fwd(int32_t rows, int32_t in, int32_t out, const float* X, const 
     return TSD_OK;
 }
 
-int tsd_linear_bwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* dY, float* dX,
-                   float* dW, float* db, float* scratch, size_t scratch_floats, void* stream) {
+int tsd_linear_packable(int32_t in, int32_t out) { return mfma_shape(in, out) ? 1 : 0; }
+
+int tsd_pack_linear_batch(int32_t n, const float* const* W, float* const* dst, const int32_t* out_dim,
+                          const int32_t* in_dim, const int32_t* transposed, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n; base += TSD_PACK_MAX) {
+        PackBatch b;
+        const int m = n - base < TSD_PACK_MAX ? n - base : TSD_PACK_MAX;
+        int biggest = 0;
+        for (int k = 0; k < m; ++k) {
+            const int o = out_dim[base + k], i = in_dim[base + k], t = transposed[base + k];
+            TSD_REQUIRE(mfma_shape(i, o), "tsd_pack_linear_batch: layer %d (%d -> %d) has no MFMA instance", base + k, i, o);
+            b.W[k] = W[base + k];
+            b.dst[k] = dst[base + k];
+            b.ncols[k] = t ? i : o;  // forward: B[k = in][n = out]; dgrad: B[k = out][n = in]
+            b.kdim[k] = t ? o : i;
+            b.transposed[k] = t;
+            biggest = o * i > biggest ? o * i : biggest;
+        }
+        const int bx = (biggest + 255) / 256 < 64 ? (biggest + 255) / 256 : 64;
+        hipLaunchKernelGGL(pack_batch_kernel, dim3(bx, m), dim3(256), 0, st, b);
+    }
+    TSD_LAUNCH_CHECK("pack_batch");
+    return TSD_OK;
+}
+
+int tsd_linear_fwd_packed(int32_t rows, int32_t in, int32_t out, const float* X, const float* Wp, const float* b,
+                          float* Y, void* stream) {
+    if (rows == 0) return TSD_OK;
+    TSD_REQUIRE(mfma_shape(in, out), "tsd_linear_fwd_packed: no MFMA instance for %d -> %d", in, out);
+    return dispatch_linear_mfma(rows, in, out, X, Wp, b, Y, (hipStream_t)stream);
+}
+
+int tsd_linear_bwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* Wp_t,
+                   const float* dY, float* dX, float* dW, float* db, float* scratch, size_t scratch_floats,
+                   void* stream) {
     hipStream_t st = (hipStream_t)stream;
     // scratch layout: [0, 64*out) bias partials | [.., + in*out) packed W for dgrad | wgrad partials
     const size_t off_pack = 64 * (size_t)out, off_part = off_pack + (size_t)in * out;
     if (dX && rows > 0) {  // dX = dY W
-        if (mfma_shape(out, in) && scratch && scratch_floats >= off_part) {
-            const int n = in * out;
-            hipLaunchKernelGGL(pack_any_kernel, dim3((n + 255) / 256), dim3(256), 0, st, W, scratch + off_pack, in, out, 1);
-            int r = dispatch_linear_mfma(rows, out, in, dY, scratch + off_pack, nullptr, dX, st);
+        if (mfma_shape(out, in) && (Wp_t || (scratch && scratch_floats >= off_part))) {
+            if (!Wp_t) {
+                const int n = in * out;
+                hipLaunchKernelGGL(pack_any_kernel, dim3((n + 255) / 256), dim3(256), 0, st, W, scratch + off_pack, in,
+                                   out, 1);
+                Wp_t = scratch + off_pack;
+            }
+            int r = dispatch_linear_mfma(rows, out, in, dY, Wp_t, nullptr, dX, st);
             if (r) return r;
         } else {
             const int64_t n = (int64_t)rows * in;
@@ -588,6 +708,7 @@ int tsd_linear_bwd(int32_t rows, int32_t in, int32_t out, const float* X, const 
             TSD_LAUNCH_CHECK("dgrad_naive");
         }
     }
+    bool db_done = false;
     if (dW) {  // dW = dY^T X
         const int S = rows >= 4096 ? 64 : (rows >= 512 ? 16 : 4);  // row splits of the MFMA wgrad
         if (rows == 0) {
@@ -595,17 +716,32 @@ int tsd_linear_bwd(int32_t rows, int32_t in, int32_t out, const float* X, const 
         } else if (scratch && scratch_floats >= off_part + (size_t)S * out * in && out % 128 == 0 && in % 128 == 0) {
             const int per = ((rows + S - 1) / S + WG_T - 1) / WG_T * WG_T;
             float* part = scratch + off_part;
+            float* bpart = db ? scratch : nullptr;  // [S][out], S <= 64
             hipLaunchKernelGGL(wgrad_kernel, dim3(in / 128, out / 128, S), dim3(256), 0, st, rows, in, out, per, dY, X,
-                               part);
+                               part, bpart);
             const int64_t n = (int64_t)out * in;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(n)), dim3(256), 0, st, n, S, part, dW);
+            const int nb = db ? out : 0;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + nb + 63) / 64)), dim3(256), 0, st, n, nb, S,
+                               part, bpart, dW, db);
             TSD_LAUNCH_CHECK("wgrad");
+            db_done = db != nullptr;
+        } else if ((in <= WS_MAX_IN || out == 1) && scratch && scratch_floats >= off_part + 64 * (size_t)out * in) {
+            // narrow layers; out == 1 is the in == 1 problem with dY and X swapped (same dW memory layout)
+            const bool swap = in > WS_MAX_IN;
+            const int o2 = swap ? in : out, i2 = swap ? 1 : in;
+            float* part = scratch + off_part;
+            hipLaunchKernelGGL(wgrad_small_kernel, dim3((o2 + 63) / 64, 64), dim3(256), 0, st, rows, i2, o2,
+                               swap ? X : dY, swap ? dY : X, part);
+            const int64_t n = (int64_t)o2 * i2;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, n, 0, 64, part,
+                               (const float*)nullptr, dW, (float*)nullptr);
+            TSD_LAUNCH_CHECK("wgrad_small");
         } else {
             hipLaunchKernelGGL(wgrad_naive_kernel, dim3(out * in), dim3(256), 0, st, rows, in, out, dY, X, dW);
             TSD_LAUNCH_CHECK("wgrad_naive");
         }
     }
-    if (db) {
+    if (db && !db_done) {
         TSD_REQUIRE(scratch != nullptr && scratch_floats >= off_pack, "tsd_linear_bwd: db needs 64*out scratch floats");
         hipLaunchKernelGGL(colsum_stage1_kernel, dim3((out + 63) / 64, CS_CHUNKS), dim3(256), 0, st, rows, out, dY,
                            scratch);

@@ -34,6 +34,48 @@ def _scratch(device, n):
     return t
 
 
+_PACKED = {}  # W.data_ptr() -> (W._version, forward-packed view, dgrad-packed view, arena, W)
+# (the entry keeps W alive so that its address cannot be recycled by another tensor with an equal version)
+
+
+def prepack(weights):
+    """Pack every MFMA-shaped dense weight of a training step with ONE launch (forward and dgrad layouts);
+    the optimizer rewrites all of them every step.  `Linear` picks the packed copies up by (pointer, version)."""
+    lib = _lib.load()
+    todo = []
+    for W in weights:
+        if W.dim() != 2 or not W.is_contiguous() or not lib.tsd_linear_packable(W.shape[1], W.shape[0]):
+            continue
+        hit = _PACKED.get(W.data_ptr())
+        if hit is None or hit[0] != W._version or hit[4]._cdata != W._cdata:
+            todo.append(W)
+    if not todo:
+        return
+    dev = todo[0].device
+    arena = torch.empty(2 * sum(W.numel() for W in todo), dtype=torch.float32, device=dev)
+    n = 2 * len(todo)
+    Ws, dst, od, idim, tr = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_int32 * n)(), (C.c_int32 * n)(), (C.c_int32 * n)()
+    off = 0
+    for k, W in enumerate(todo):
+        views = []
+        for t in (0, 1):
+            v = arena[off:off + W.numel()]
+            off += W.numel()
+            Ws[2 * k + t], dst[2 * k + t] = W.data_ptr(), v.data_ptr()
+            od[2 * k + t], idim[2 * k + t], tr[2 * k + t] = W.shape[0], W.shape[1], t
+            views.append(v)
+        _PACKED[W.data_ptr()] = (W._version, views[0], views[1], arena, W)
+    check(lib.tsd_pack_linear_batch(n, Ws, dst, od, idim, tr, stream_ptr()))
+    if len(_PACKED) > 512:  # parameters of models that went away
+        for key in [k for k, v in _PACKED.items() if v[3] is not arena][:256]:
+            del _PACKED[key]
+
+
+def _packed(W, which):
+    hit = _PACKED.get(W.data_ptr())
+    return hit[which] if hit is not None and hit[0] == W._version and hit[4]._cdata == W._cdata else None
+
+
 class Linear(torch.autograd.Function):
     """y = x W^T + b   (torch.nn.Linear semantics; W [out,in])"""
 
@@ -44,8 +86,13 @@ class Linear(torch.autograd.Function):
         rows, fin = x.shape
         out = W.shape[0]
         y = torch.empty(rows, out, dtype=torch.float32, device=x.device)
-        sc = _scratch(x.device, fin * out)
-        check(lib.tsd_linear_fwd(rows, fin, out, ptr(x), ptr(W), ptr(b), ptr(y), ptr(sc), sc.numel(), stream_ptr()))
+        wp = _packed(W, 1)
+        if wp is not None:
+            check(lib.tsd_linear_fwd_packed(rows, fin, out, ptr(x), ptr(wp), ptr(b), ptr(y), stream_ptr()))
+        else:
+            sc = _scratch(x.device, fin * out)
+            check(lib.tsd_linear_fwd(rows, fin, out, ptr(x), ptr(W), ptr(b), ptr(y), ptr(sc), sc.numel(),
+                                     stream_ptr()))
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
         return y
@@ -61,8 +108,8 @@ class Linear(torch.autograd.Function):
         dW = torch.empty_like(W) if ctx.needs_input_grad[1] else None
         db = torch.empty(out, dtype=torch.float32, device=x.device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         sc = _scratch(x.device, 64 * out + fin * out + 64 * out * fin)  # bias partials | packed W | wgrad partials
-        check(lib.tsd_linear_bwd(rows, fin, out, ptr(x), ptr(W), ptr(dy), ptr(dx), ptr(dW), ptr(db), ptr(sc),
-                                 sc.numel(), stream_ptr()))
+        check(lib.tsd_linear_bwd(rows, fin, out, ptr(x), ptr(W), ptr(_packed(W, 2)), ptr(dy), ptr(dx), ptr(dW), ptr(db),
+                                 ptr(sc), sc.numel(), stream_ptr()))
         return dx, dW, db
 
 
@@ -266,6 +313,7 @@ def train_forward(model, db, pos):
     P = dict(model.named_parameters())
     cfg = model._cfg
     L = cfg.num_convs
+    prepack(P.values())
     db.geometry(pos)
     Eu, Eo = db.enc_u.num_edges(), db.out_u.num_edges()  # host syncs (training is not latency critical)
 
@@ -346,6 +394,7 @@ def dual_forward(model, db, pos):
     P = dict(model.named_parameters())
     cfg = db.cfg
     H = cfg.hidden
+    prepack(P.values())
     db.geometry(pos)
     Eu = db.enc_u.num_edges()  # host sync; the edge set is symmetric: E = 2 Eu
     E = 2 * Eu
