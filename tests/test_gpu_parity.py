@@ -330,6 +330,36 @@ def test_training_loss_and_gradients_vs_golden(name, dev):
     assert not l2.requires_grad and not torch.equal(l2, loss.detach())
 
 
+def test_fused_training_step_equals_op_by_op(dev, monkeypatch):
+    """csrc/train_step.hip (forward + loss + backward sequenced in C++, one autograd node) against the op-by-op
+    autograd form of the same kernels: loss and EVERY parameter gradient, on a batch with > 4096 undirected
+    edges (all MFMA paths) and on a small-hidden model (all VALU paths)"""
+    from tsdiff_amd import synth
+    for cfg, nG in ((synth.DEFAULT_MODEL_CONFIG, 24), (synth.small_model_config(), 5)):
+        b = synth.wb97xd3_like_batch(nG, seed=3)
+        g = to_dev(batch_inputs({"in_" + k: v for k, v in b.items() if isinstance(v, np.ndarray)}), dev)
+        g["pos"] = (g["pos"] * 1.5).contiguous()
+        G = g["num_graphs"]
+        ts = torch.randint(0, 5000, (G,), device=dev)
+        noise = torch.randn_like(g["pos"])
+        res = {}
+        for mode in ("fused", "ops"):
+            monkeypatch.setenv("TSDIFF_TRAIN", mode)
+            model = make_model(cfg, 1, dev)
+            model.train()
+            loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
+                                  g["batch"], g["num_nodes_per_graph"], G, _time_step=ts, _pos_noise=noise)
+            assert loss.requires_grad and loss.shape == (g["pos"].shape[0], 1)
+            loss.mean().backward()
+            res[mode] = (loss.detach().cpu().numpy(),
+                         {k: p.grad.cpu().numpy() for k, p in model.named_parameters() if p.grad is not None})
+        assert_close(res["fused"][0], res["ops"][0], 2e-6, "loss fused vs op-by-op")
+        assert set(res["fused"][1]) == set(res["ops"][1])
+        assert len(res["fused"][1]) >= 30
+        for k, ref in res["ops"][1].items():
+            assert_close(res["fused"][1][k], ref, 2e-5, f"grad {k} fused vs op-by-op")
+
+
 def test_nan_raises_floating_point_error(dev):
     from tsdiff_amd import synth
     from tsdiff_amd.sampler import EnsembleSampler

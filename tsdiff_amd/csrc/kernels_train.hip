@@ -33,18 +33,19 @@ __global__ void pack_any_kernel(const float* __restrict__ M, float* __restrict__
     Bp[idx] = transposed ? M[(size_t)k * ncols + n] : M[(size_t)n * kdim + k];
 }
 
-// Y[rows, NOUT] = A[rows, K] * Bp (+ bias): 4 waves, each NOUT/4 columns (CB blocks of 32)
+// Y[rows, nout] = A[rows, K] * Bp (+ bias) (+ R): 4 waves, each CB column blocks of 32; a workgroup owns
+// CB*128 columns starting at blockIdx.y * CB*128 (short problems are split over the columns to fill the chip).
+// R (nullable, may alias Y): residual / accumulation source with the layout of Y.
 template <int K, int CB>
-__global__ __launch_bounds__(256) void linear_mfma_kernel(int rows, const float* __restrict__ A,
+__global__ __launch_bounds__(256) void linear_mfma_kernel(int rows, int nout, const float* __restrict__ A,
                                                           const float* __restrict__ Bp,
-                                                          const float* __restrict__ bias, float* __restrict__ Y) {
-    constexpr int NOUT = CB * 128;
+                                                          const float* __restrict__ bias, const float* R, float* Y) {
     constexpr int LDA = K + 4;
     constexpr int K4 = K / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int r0 = blockIdx.x * 32;
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
-    const int col0 = (tid >> 6) * (NOUT / 4);
+    const int col0 = blockIdx.y * (CB * 128) + (tid >> 6) * (CB * 32);
     const int nrows = min(32, rows - r0);
     for (int idx = tid; idx < 32 * K4; idx += 256) {
         const int r = idx / K4, c4 = idx % K4;
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(int rows, const float*
     __syncthreads();
     f32x16 acc[1][CB];
     zero_acc(acc);
-    gemm_tile<1, CB, K>(smem, LDA, Bp, NOUT, col0, acc);
+    gemm_tile<1, CB, K>(smem, LDA, Bp, nout, col0, acc);
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
         const int col = col0 + cb * 32 + l31;
@@ -63,29 +64,38 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(int rows, const float*
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = acc_row(r, hi);
-            if (row < nrows) Y[(size_t)(r0 + row) * NOUT + col] = acc[0][cb][r] + b;
+            if (row < nrows) {
+                const size_t o = (size_t)(r0 + row) * nout + col;
+                float v = acc[0][cb][r] + b;
+                if (R) v += R[o];
+                Y[o] = v;
+            }
         }
     }
 }
 
 template <int K, int CB>
-static int launch_linear_mfma(int rows, const float* A, const float* Bp, const float* bias, float* Y, hipStream_t st) {
+static int launch_linear_mfma(int rows, int nout, const float* A, const float* Bp, const float* bias, const float* R,
+                              float* Y, hipStream_t st) {
     const size_t lds = (size_t)32 * (K + 4) * 4;
     static bool done = false;
     if (!done && lds > 48 * 1024)
         TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_mfma_kernel<K, CB>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     done = true;
-    hipLaunchKernelGGL((linear_mfma_kernel<K, CB>), dim3((rows + 31) / 32), dim3(256), lds, st, rows, A, Bp, bias, Y);
+    hipLaunchKernelGGL((linear_mfma_kernel<K, CB>), dim3((rows + 31) / 32, nout / (CB * 128)), dim3(256), lds, st, rows,
+                       nout, A, Bp, bias, R, Y);
     TSD_LAUNCH_CHECK("linear_mfma");
     return TSD_OK;
 }
 
 static bool mfma_shape(int K, int NOUT) { return (K == 128 || K == 256 || K == 512) && (NOUT == 128 || NOUT == 256 || NOUT == 512); }
 
-static int dispatch_linear_mfma(int rows, int K, int NOUT, const float* A, const float* Bp, const float* bias, float* Y,
-                                hipStream_t st) {
-#define TSD_LM(KK, CC) if (K == KK && NOUT == CC * 128) return launch_linear_mfma<KK, CC>(rows, A, Bp, bias, Y, st);
+static int dispatch_linear_mfma(int rows, int K, int NOUT, const float* A, const float* Bp, const float* bias,
+                                const float* R, float* Y, hipStream_t st) {
+    // fewer than one workgroup per CU with full-width tiles: split the columns over grid.y instead
+    const int CBsel = (rows + 31) / 32 >= 256 ? NOUT / 128 : 1;
+#define TSD_LM(KK, CC) if (K == KK && CBsel == CC) return launch_linear_mfma<KK, CC>(rows, NOUT, A, Bp, bias, R, Y, st);
     TSD_LM(128, 1) TSD_LM(128, 2) TSD_LM(128, 4) TSD_LM(256, 1) TSD_LM(256, 2) TSD_LM(256, 4)
     TSD_LM(512, 1) TSD_LM(512, 2) TSD_LM(512, 4)
 #undef TSD_LM
@@ -96,17 +106,20 @@ static int dispatch_linear_mfma(int rows, int K, int NOUT, const float* A, const
 // odd shapes: one thread per output element
 // C[r, n] = sum_k A[r, k] * (transposed ? M[k, n] : M[n, k]) (+ bias[n])
 __global__ void linear_naive_kernel(int rows, int K, int N, const float* __restrict__ A, const float* __restrict__ M,
-                                    int transposed, const float* __restrict__ bias, float* __restrict__ C) {
+                                    int transposed, const float* __restrict__ bias, const float* R, float* C) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)rows * N) return;
     const int r = (int)(t / N), n = (int)(t % N);
     float s = 0.0f;
     for (int k = 0; k < K; ++k) s = fmaf(A[(size_t)r * K + k], transposed ? M[(size_t)k * N + n] : M[(size_t)n * K + k], s);
-    C[t] = s + (bias ? bias[n] : 0.0f);
+    s += bias ? bias[n] : 0.0f;
+    if (R) s += R[t];
+    C[t] = s;
 }
 // dW[o, i] = sum_r dY[r, o] * X[r, i]: one workgroup per output element, tree over the rows
 __global__ __launch_bounds__(256) void wgrad_naive_kernel(int rows, int in, int out, const float* __restrict__ dY,
-                                                          const float* __restrict__ X, float* __restrict__ dW) {
+                                                          const float* __restrict__ X, float* __restrict__ dW,
+                                                          int accumulate) {
     __shared__ float sm[256];
     const int o = blockIdx.x / in, i = blockIdx.x % in;
     float s = 0.0f;
@@ -117,7 +130,7 @@ __global__ __launch_bounds__(256) void wgrad_naive_kernel(int rows, int in, int 
         if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) dW[blockIdx.x] = sm[0];
+    if (threadIdx.x == 0) dW[blockIdx.x] = accumulate ? dW[blockIdx.x] + sm[0] : sm[0];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -208,7 +221,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int rows, int in, int out, i
 // [S][nW] and the bias partials [S][nB] (nB may be 0) are reduced by the same launch.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int64_t nW, int nB, int S, const float* __restrict__ part,
                                                            const float* __restrict__ bias_part,
-                                                           float* __restrict__ dW, float* __restrict__ db) {
+                                                           float* __restrict__ dW, float* __restrict__ db,
+                                                           int accumulate) {
     __shared__ float sm[4][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
@@ -223,8 +237,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int64_t nW, int nB, i
     __syncthreads();
     if (q == 0) {
         const float v = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
-        if (i < nW) dW[i] = v;
-        else if (i < nW + nB) db[i - nW] = v;
+        if (i < nW) dW[i] = accumulate ? dW[i] + v : v;
+        else if (i < nW + nB) db[i - nW] = accumulate ? db[i - nW] + v : v;
     }
 }
 
@@ -253,12 +267,13 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(int rows, int in, int 
         }
 #pragma unroll
     for (int i = 0; i < WS_MAX_IN; ++i) {
-        if (i >= in) break;
-        __syncthreads();
-        sm[w][lane] = acc[i];
-        __syncthreads();
-        if (w == 0 && o < out)
-            part[((size_t)blockIdx.y * out + o) * in + i] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+        if (i < in) {  // uniform
+            __syncthreads();
+            sm[w][lane] = acc[i];
+            __syncthreads();
+            if (w == 0 && o < out)
+                part[((size_t)blockIdx.y * out + o) * in + i] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+        }
     }
 }
 
@@ -305,12 +320,13 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(int rows, int cols, 
         part[(size_t)blockIdx.y * cols + c] =
             (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
-__global__ void colsum_stage2_kernel(int cols, const float* __restrict__ part, float* __restrict__ db) {
+__global__ void colsum_stage2_kernel(int cols, const float* __restrict__ part, float* __restrict__ db,
+                                     int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cols) return;
     float s = 0.0f;
     for (int k = 0; k < CS_CHUNKS; ++k) s += part[(size_t)k * cols + c];
-    db[c] = s;
+    db[c] = accumulate ? db[c] + s : s;
 }
 
 // activations: kind 0 swish (reference utils/activation_functions.py), 1 shifted softplus (schnet.py:65-71)
@@ -631,6 +647,94 @@ __global__ void dual_score_kernel(int N, const float* __restrict__ eq_local, con
 
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
+// ---------------------------------------------------------------------------------------------
+// dense layer, host side.  Wp / Wp_t: pre-packed weights (pack_batch) or NULL (packed here into scratch).
+// R: residual added to the product (may alias Y).  flags: 1 = dX += , 2 = dW / db += .
+int linear_fwd_impl(int rows, int in, int out, const float* X, const float* W, const float* Wp, const float* b,
+                    const float* R, float* Y, float* scratch, size_t scratch_floats, hipStream_t st) {
+    if (rows == 0) return TSD_OK;
+    if (mfma_shape(in, out) && (Wp || (scratch && scratch_floats >= (size_t)in * out))) {
+        if (!Wp) {
+            const int n = in * out;
+            hipLaunchKernelGGL(pack_any_kernel, dim3((n + 255) / 256), dim3(256), 0, st, W, scratch, out, in, 0);
+            Wp = scratch;
+        }
+        return dispatch_linear_mfma(rows, in, out, X, Wp, b, R, Y, st);
+    }
+    const int64_t n = (int64_t)rows * out;
+    hipLaunchKernelGGL(linear_naive_kernel, dim3(blocks_for(n)), dim3(256), 0, st, rows, in, out, X, W, 0, b, R, Y);
+    TSD_LAUNCH_CHECK("linear_naive");
+    return TSD_OK;
+}
+
+int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, const float* Wp_t, const float* dY,
+                    float* dX, float* dW, float* db, int flags, float* scratch, size_t scratch_floats, hipStream_t st) {
+    // scratch layout: [0, 64*out) bias partials | [.., + in*out) packed W for dgrad | wgrad partials
+    const size_t off_pack = 64 * (size_t)out, off_part = off_pack + (size_t)in * out;
+    const int accW = (flags & 2) ? 1 : 0;
+    if (dX && rows > 0) {  // dX = dY W
+        const float* R = (flags & 1) ? dX : nullptr;
+        if (mfma_shape(out, in) && (Wp_t || (scratch && scratch_floats >= off_part))) {
+            if (!Wp_t) {
+                const int n = in * out;
+                hipLaunchKernelGGL(pack_any_kernel, dim3((n + 255) / 256), dim3(256), 0, st, W, scratch + off_pack, in,
+                                   out, 1);
+                Wp_t = scratch + off_pack;
+            }
+            int r = dispatch_linear_mfma(rows, out, in, dY, Wp_t, nullptr, R, dX, st);
+            if (r) return r;
+        } else {
+            const int64_t n = (int64_t)rows * in;
+            hipLaunchKernelGGL(linear_naive_kernel, dim3(blocks_for(n)), dim3(256), 0, st, rows, out, in, dY, W, 1,
+                               (const float*)nullptr, R, dX);
+            TSD_LAUNCH_CHECK("dgrad_naive");
+        }
+    }
+    bool db_done = false;
+    if (dW) {  // dW = dY^T X
+        const int S = rows >= 4096 ? 64 : (rows >= 512 ? 16 : 4);  // row splits of the MFMA wgrad
+        if (rows == 0) {
+            if (!accW) TSD_HIP(hipMemsetAsync(dW, 0, (size_t)out * in * sizeof(float), st));
+        } else if (scratch && scratch_floats >= off_part + (size_t)S * out * in && out % 128 == 0 && in % 128 == 0) {
+            const int per = ((rows + S - 1) / S + WG_T - 1) / WG_T * WG_T;
+            float* part = scratch + off_part;
+            float* bpart = db ? scratch : nullptr;  // [S][out], S <= 64
+            hipLaunchKernelGGL(wgrad_kernel, dim3(in / 128, out / 128, S), dim3(256), 0, st, rows, in, out, per, dY, X,
+                               part, bpart);
+            const int64_t n = (int64_t)out * in;
+            const int nb = db ? out : 0;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + nb + 63) / 64)), dim3(256), 0, st, n, nb, S,
+                               part, bpart, dW, db, accW);
+            TSD_LAUNCH_CHECK("wgrad");
+            db_done = db != nullptr;
+        } else if ((in <= WS_MAX_IN || out == 1) && scratch && scratch_floats >= off_part + 64 * (size_t)out * in) {
+            // narrow layers; out == 1 is the in == 1 problem with dY and X swapped (same dW memory layout)
+            const bool swap = in > WS_MAX_IN;
+            const int o2 = swap ? in : out, i2 = swap ? 1 : in;
+            float* part = scratch + off_part;
+            hipLaunchKernelGGL(wgrad_small_kernel, dim3((o2 + 63) / 64, 64), dim3(256), 0, st, rows, i2, o2,
+                               swap ? X : dY, swap ? dY : X, part);
+            const int64_t n = (int64_t)o2 * i2;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, n, 0, 64, part,
+                               (const float*)nullptr, dW, (float*)nullptr, accW);
+            TSD_LAUNCH_CHECK("wgrad_small");
+        } else {
+            hipLaunchKernelGGL(wgrad_naive_kernel, dim3(out * in), dim3(256), 0, st, rows, in, out, dY, X, dW, accW);
+            TSD_LAUNCH_CHECK("wgrad_naive");
+        }
+    }
+    if (db && !db_done) {
+        TSD_REQUIRE(scratch != nullptr && scratch_floats >= off_pack, "tsd_linear_bwd: db needs 64*out scratch floats");
+        hipLaunchKernelGGL(colsum_stage1_kernel, dim3((out + 63) / 64, CS_CHUNKS), dim3(256), 0, st, rows, out, dY,
+                           scratch);
+        hipLaunchKernelGGL(colsum_stage2_kernel, dim3((out + 255) / 256), dim3(256), 0, st, out, scratch, db, accW);
+        TSD_LAUNCH_CHECK("colsum");
+    }
+    return TSD_OK;
+}
+
+size_t linear_scratch_floats(int in, int out) { return 64 * (size_t)out + (size_t)in * out + 64 * (size_t)out * in; }
+
 }  // namespace tsd
 
 using namespace tsd;
@@ -639,17 +743,7 @@ extern "C" {
 
 int tsd_linear_fwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* b, float* Y,
                    float* scratch, size_t scratch_floats, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    if (rows == 0) return TSD_OK;
-    if (mfma_shape(in, out) && scratch && scratch_floats >= (size_t)in * out) {
-        const int n = in * out;
-        hipLaunchKernelGGL(pack_any_kernel, dim3((n + 255) / 256), dim3(256), 0, st, W, scratch, out, in, 0);
-        return dispatch_linear_mfma(rows, in, out, X, scratch, b, Y, st);
-    }
-    const int64_t n = (int64_t)rows * out;
-    hipLaunchKernelGGL(linear_naive_kernel, dim3(blocks_for(n)), dim3(256), 0, st, rows, in, out, X, W, 0, b, Y);
-    TSD_LAUNCH_CHECK("linear_naive");
-    return TSD_OK;
+    return linear_fwd_impl(rows, in, out, X, W, nullptr, b, nullptr, Y, scratch, scratch_floats, (hipStream_t)stream);
 }
 
 int tsd_linear_packable(int32_t in, int32_t out) { return mfma_shape(in, out) ? 1 : 0; }
@@ -682,73 +776,13 @@ int tsd_linear_fwd_packed(int32_t rows, int32_t in, int32_t out, const float* X,
                           float* Y, void* stream) {
     if (rows == 0) return TSD_OK;
     TSD_REQUIRE(mfma_shape(in, out), "tsd_linear_fwd_packed: no MFMA instance for %d -> %d", in, out);
-    return dispatch_linear_mfma(rows, in, out, X, Wp, b, Y, (hipStream_t)stream);
+    return dispatch_linear_mfma(rows, in, out, X, Wp, b, nullptr, Y, (hipStream_t)stream);
 }
 
 int tsd_linear_bwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* Wp_t,
                    const float* dY, float* dX, float* dW, float* db, float* scratch, size_t scratch_floats,
                    void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    // scratch layout: [0, 64*out) bias partials | [.., + in*out) packed W for dgrad | wgrad partials
-    const size_t off_pack = 64 * (size_t)out, off_part = off_pack + (size_t)in * out;
-    if (dX && rows > 0) {  // dX = dY W
-        if (mfma_shape(out, in) && (Wp_t || (scratch && scratch_floats >= off_part))) {
-            if (!Wp_t) {
-                const int n = in * out;
-                hipLaunchKernelGGL(pack_any_kernel, dim3((n + 255) / 256), dim3(256), 0, st, W, scratch + off_pack, in,
-                                   out, 1);
-                Wp_t = scratch + off_pack;
-            }
-            int r = dispatch_linear_mfma(rows, out, in, dY, Wp_t, nullptr, dX, st);
-            if (r) return r;
-        } else {
-            const int64_t n = (int64_t)rows * in;
-            hipLaunchKernelGGL(linear_naive_kernel, dim3(blocks_for(n)), dim3(256), 0, st, rows, out, in, dY, W, 1,
-                               (const float*)nullptr, dX);
-            TSD_LAUNCH_CHECK("dgrad_naive");
-        }
-    }
-    bool db_done = false;
-    if (dW) {  // dW = dY^T X
-        const int S = rows >= 4096 ? 64 : (rows >= 512 ? 16 : 4);  // row splits of the MFMA wgrad
-        if (rows == 0) {
-            TSD_HIP(hipMemsetAsync(dW, 0, (size_t)out * in * sizeof(float), st));
-        } else if (scratch && scratch_floats >= off_part + (size_t)S * out * in && out % 128 == 0 && in % 128 == 0) {
-            const int per = ((rows + S - 1) / S + WG_T - 1) / WG_T * WG_T;
-            float* part = scratch + off_part;
-            float* bpart = db ? scratch : nullptr;  // [S][out], S <= 64
-            hipLaunchKernelGGL(wgrad_kernel, dim3(in / 128, out / 128, S), dim3(256), 0, st, rows, in, out, per, dY, X,
-                               part, bpart);
-            const int64_t n = (int64_t)out * in;
-            const int nb = db ? out : 0;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + nb + 63) / 64)), dim3(256), 0, st, n, nb, S,
-                               part, bpart, dW, db);
-            TSD_LAUNCH_CHECK("wgrad");
-            db_done = db != nullptr;
-        } else if ((in <= WS_MAX_IN || out == 1) && scratch && scratch_floats >= off_part + 64 * (size_t)out * in) {
-            // narrow layers; out == 1 is the in == 1 problem with dY and X swapped (same dW memory layout)
-            const bool swap = in > WS_MAX_IN;
-            const int o2 = swap ? in : out, i2 = swap ? 1 : in;
-            float* part = scratch + off_part;
-            hipLaunchKernelGGL(wgrad_small_kernel, dim3((o2 + 63) / 64, 64), dim3(256), 0, st, rows, i2, o2,
-                               swap ? X : dY, swap ? dY : X, part);
-            const int64_t n = (int64_t)o2 * i2;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, n, 0, 64, part,
-                               (const float*)nullptr, dW, (float*)nullptr);
-            TSD_LAUNCH_CHECK("wgrad_small");
-        } else {
-            hipLaunchKernelGGL(wgrad_naive_kernel, dim3(out * in), dim3(256), 0, st, rows, in, out, dY, X, dW);
-            TSD_LAUNCH_CHECK("wgrad_naive");
-        }
-    }
-    if (db && !db_done) {
-        TSD_REQUIRE(scratch != nullptr && scratch_floats >= off_pack, "tsd_linear_bwd: db needs 64*out scratch floats");
-        hipLaunchKernelGGL(colsum_stage1_kernel, dim3((out + 63) / 64, CS_CHUNKS), dim3(256), 0, st, rows, out, dY,
-                           scratch);
-        hipLaunchKernelGGL(colsum_stage2_kernel, dim3((out + 255) / 256), dim3(256), 0, st, out, scratch, db);
-        TSD_LAUNCH_CHECK("colsum");
-    }
-    return TSD_OK;
+    return linear_bwd_impl(rows, in, out, X, W, Wp_t, dY, dX, dW, db, 0, scratch, scratch_floats, (hipStream_t)stream);
 }
 
 int tsd_act_fwd(int32_t kind, int64_t n, const float* x, float* y, void* stream) {

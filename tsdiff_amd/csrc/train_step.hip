@@ -1,0 +1,551 @@
+// train_step.hip -- the training step of the condensed network as TWO library calls (reference train.py:124-152,
+// models/epsnet/condensenc.py:178-239, 267-328): tsd_train_forward evaluates get_loss on the perturbed
+// geometry and keeps every activation the backward pass needs in a caller-provided workspace;
+// tsd_train_backward turns d(loss)/d(loss_i) into the gradient of every parameter (flat, in the order of the
+// flat parameter vector).  Same primitive kernels as the autograd form (tsdiff_amd/train_ops.py), sequenced
+// here instead of by ~450 Python-level autograd nodes per step: the step is no longer host bound, residual
+// adds and gradient accumulations ride in the GEMM epilogues instead of separate elementwise launches.
+//
+// Flat parameter vector `raw` (fp32, no padding), order of tsdiff_amd/engine.py::raw_param_names:
+//   edge_encoder.bond_emb.weight [100,H], edge_encoder.mlp.layers.0.{weight [H,1], bias}, .1.{weight [H,H], bias},
+//   atom_embedding.weight [100,H/2], atom_feat_embedding.weight [H/2,F],
+//   per block: conv.lin1.weight, conv.lin2.{weight,bias}, conv.nn.0.{weight,bias}, conv.nn.2.{weight,bias},
+//              lin.{weight,bias},
+//   grad_dist_mlp.layers.{0 [H,2H], 1 [H/2,H], 2 [1,H/2]}.{weight,bias}, edge_cat.{0 [H,2H], 2 [H,H]}.{weight,bias}
+#include "common.hpp"
+
+namespace tsd {
+
+// kernels_train.hip
+int linear_fwd_impl(int rows, int in, int out, const float* X, const float* W, const float* Wp, const float* b,
+                    const float* R, float* Y, float* scratch, size_t scratch_floats, hipStream_t st);
+int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, const float* Wp_t, const float* dY,
+                    float* dX, float* dW, float* db, int flags, float* scratch, size_t scratch_floats, hipStream_t st);
+size_t linear_scratch_floats(int in, int out);
+// kernels_graph.hip
+int launch_geometry(const tsd_model_cfg&, int, int, int, const float*, const int32_t*, const int32_t*, const int32_t*,
+                    const uint16_t*, tsd_geometry, hipStream_t);
+
+namespace {
+
+struct RawLayout {
+    size_t bond_emb, emlp_w0, emlp_b0, emlp_w1, emlp_b1, atom_emb, atom_feat;
+    size_t layer0, layer_stride, L_lin1_w, L_lin2_w, L_lin2_b, L_nn0_w, L_nn0_b, L_nn2_w, L_nn2_b, L_lin_w, L_lin_b;
+    size_t out_w0, out_b0, out_w1, out_b1, out_w2, out_b2, ecat_w0, ecat_b0, ecat_w1, ecat_b1, total;
+};
+RawLayout raw_layout(const tsd_model_cfg& c) {
+    RawLayout L;
+    const size_t H = c.hidden, F = c.feat_dim, HH = H * H;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += n; return r; };
+    L.bond_emb = take(100 * H);
+    L.emlp_w0 = take(H);
+    L.emlp_b0 = take(H);
+    L.emlp_w1 = take(HH);
+    L.emlp_b1 = take(H);
+    L.atom_emb = take(100 * (H / 2));
+    L.atom_feat = take((H / 2) * F);
+    L.layer0 = o;
+    size_t lo = 0;
+    auto lt = [&](size_t n) { size_t r = lo; lo += n; return r; };
+    L.L_lin1_w = lt(HH);
+    L.L_lin2_w = lt(HH);
+    L.L_lin2_b = lt(H);
+    L.L_nn0_w = lt(HH);
+    L.L_nn0_b = lt(H);
+    L.L_nn2_w = lt(HH);
+    L.L_nn2_b = lt(H);
+    L.L_lin_w = lt(HH);
+    L.L_lin_b = lt(H);
+    L.layer_stride = lo;
+    o += lo * (size_t)c.num_convs;
+    L.out_w0 = take(2 * HH);
+    L.out_b0 = take(H);
+    L.out_w1 = take(HH / 2);
+    L.out_b1 = take(H / 2);
+    L.out_w2 = take(H / 2);
+    L.out_b2 = take(1);
+    L.ecat_w0 = take(2 * HH);
+    L.ecat_b0 = take(H);
+    L.ecat_w1 = take(HH);
+    L.ecat_b1 = take(H);
+    L.total = o;
+    return L;
+}
+
+// everything one edge-embedding evaluation keeps (condensenc.py:156-176, edge.py:58-68)
+struct EmbedSave {
+    float *l0, *s0, *e, *c, *c0, *s1, *ea;  // [E,H] except c [E,2H]
+};
+struct Work {
+    // forward state
+    float *featR, *featP;          // [N,F] fp32 one-hot features
+    float* h;                      // [(L+1), N, H]
+    float *x1, *agg, *x2, *xs;     // [L, N, H] each
+    EmbedSave emb_enc, emb_out;
+    float *f0, *fs, *Wf;           // [L, Eu, H] each
+    float *hp, *g0, *gs0, *g1, *gs1, *s_u;  // pair MLP
+    float *node_eq, *pos_target, *d_target;
+    float *pack_fwd, *pack_t;      // packed dense weights, offsets = raw offsets
+    float* scratch;                // linear scratch
+    size_t scratch_floats;
+    // backward temporaries
+    float *eA, *eB;                // [Emax, 2H] each
+    float *d_ea;                   // [Eu, H]
+    float *nA, *nB, *nC, *dh;      // [N, H] each
+    float* meta;                   // [4]: Eu, Eo as floats are NOT stored here; see counts (host)
+    size_t total;
+};
+
+Work carve(const tsd_model_cfg& c, int N, size_t Eu, size_t Eo, float* base) {
+    Work w;
+    const size_t H = c.hidden, L = c.num_convs, F = c.feat_dim;
+    const size_t Em = Eu > Eo ? Eu : Eo;
+    size_t o = 0;
+    auto take = [&](size_t n) { float* r = base ? base + o : nullptr; o += (n + 63) & ~size_t(63); return r; };
+    w.featR = take((size_t)N * F);
+    w.featP = take((size_t)N * F);
+    w.h = take((L + 1) * N * H);
+    w.x1 = take(L * N * H);
+    w.agg = take(L * N * H);
+    w.x2 = take(L * N * H);
+    w.xs = take(L * N * H);
+    auto take_embed = [&](EmbedSave& e, size_t E) {
+        e.l0 = take(E * H);
+        e.s0 = take(E * H);
+        e.e = take(E * H);
+        e.c = take(E * 2 * H);
+        e.c0 = take(E * H);
+        e.s1 = take(E * H);
+        e.ea = take(E * H);
+    };
+    take_embed(w.emb_enc, Eu);
+    take_embed(w.emb_out, Eo);
+    w.f0 = take(L * Eu * H);
+    w.fs = take(L * Eu * H);
+    w.Wf = take(L * Eu * H);
+    w.hp = take(Eo * 2 * H);
+    w.g0 = take(Eo * H);
+    w.gs0 = take(Eo * H);
+    w.g1 = take(Eo * (H / 2));
+    w.gs1 = take(Eo * (H / 2));
+    w.s_u = take(Eo);
+    w.node_eq = take((size_t)N * 3);
+    w.pos_target = take((size_t)N * 3);
+    w.d_target = take(Eo);
+    const RawLayout R = raw_layout(c);
+    w.pack_fwd = take(R.total);
+    w.pack_t = take(R.total);
+    w.scratch_floats = linear_scratch_floats((int)(2 * H), (int)H);
+    w.scratch = take(w.scratch_floats);
+    w.eA = take(Em * 2 * H);
+    w.eB = take(Em * 2 * H);
+    w.d_ea = take(Eu * H);
+    w.nA = take((size_t)N * H);
+    w.nB = take((size_t)N * H);
+    w.nC = take((size_t)N * H);
+    w.dh = take((size_t)N * H);
+    w.meta = take(64);
+    w.total = o;
+    return w;
+}
+
+inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+// ---- small kernels ----------------------------------------------------------------------------
+__global__ void feats_to_float_kernel(int64_t n, const int64_t* __restrict__ r, const int64_t* __restrict__ p,
+                                      float* __restrict__ fr, float* __restrict__ fp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        fr[i] = (float)r[i];
+        fp[i] = (float)p[i];
+    }
+}
+// z = [Emb[atom] + Wf r , Wf p - Wf r]                                          condensenc.py:193-198
+__global__ void node_embed_raw_kernel(int N, int Hh, int F, const float* __restrict__ atom_emb,
+                                      const float* __restrict__ Wfeat, const int64_t* __restrict__ atom,
+                                      const float* __restrict__ fr, const float* __restrict__ fp,
+                                      float* __restrict__ z) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)N * Hh) return;
+    const int i = (int)(t / Hh), c = (int)(t % Hh);
+    float a = 0.0f, b = 0.0f;
+    for (int f = 0; f < F; ++f) {
+        const float w = Wfeat[(size_t)c * F + f];
+        a = fmaf(fr[(size_t)i * F + f], w, a);
+        b = fmaf(fp[(size_t)i * F + f], w, b);
+    }
+    z[(size_t)i * 2 * Hh + c] = atom_emb[(size_t)atom[i] * Hh + c] + a;
+    z[(size_t)i * 2 * Hh + Hh + c] = b - a;
+}
+// dz -> d atom_emb (scatter), d(Wf r) = dz_lo - dz_hi, d(Wf p) = dz_hi
+__global__ void node_embed_bwd_kernel(int N, int Hh, const int64_t* __restrict__ atom, const float* __restrict__ dz,
+                                      float* __restrict__ d_atom_emb, float* __restrict__ dfr,
+                                      float* __restrict__ dfp) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)N * Hh) return;
+    const int i = (int)(t / Hh), c = (int)(t % Hh);
+    const float lo = dz[(size_t)i * 2 * Hh + c], hi = dz[(size_t)i * 2 * Hh + Hh + c];
+    atomicAdd(d_atom_emb + (size_t)atom[i] * Hh + c, lo);
+    dfr[t] = lo - hi;
+    dfp[t] = hi;
+}
+// c[r] = [e[r] * emb[tr[r]] , e[r] * emb[tp[r]]]                               condensenc.py:169-172
+__global__ void emb_mul2_fwd_kernel(int rows, int H, const float* __restrict__ e, const float* __restrict__ emb,
+                                    const uint8_t* __restrict__ tr, const uint8_t* __restrict__ tp,
+                                    float* __restrict__ c) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)rows * H) return;
+    const int r = (int)(t / H), k = (int)(t % H);
+    const float v = e[t];
+    c[(size_t)r * 2 * H + k] = v * emb[(size_t)tr[r] * H + k];
+    c[(size_t)r * 2 * H + H + k] = v * emb[(size_t)tp[r] * H + k];
+}
+// de = dc_lo * emb[tr] + dc_hi * emb[tp];  demb[tr] += dc_lo * e, demb[tp] += dc_hi * e  (LDS pre-reduction
+// per workgroup as in emb_mul_bwd_kernel: ~25 distinct types)
+__global__ __launch_bounds__(256) void emb_mul2_bwd_kernel(int rows, int H, int rows_per_wg,
+                                                           const float* __restrict__ e, const float* __restrict__ emb,
+                                                           const uint8_t* __restrict__ tr,
+                                                           const uint8_t* __restrict__ tp,
+                                                           const float* __restrict__ dc, float* __restrict__ de,
+                                                           float* __restrict__ demb) {
+    __shared__ float acc[100][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int w = threadIdx.x >> 6;
+    for (int t = threadIdx.x; t < 100 * 64; t += 256) acc[t / 64][t % 64] = 0.0f;
+    __syncthreads();
+    const int r0 = blockIdx.y * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
+    if (c < H) {
+        for (int r = r0 + w; r < r1; r += 4) {
+            const int a = min((int)tr[r], 99), b = min((int)tp[r], 99);
+            const float glo = dc[(size_t)r * 2 * H + c], ghi = dc[(size_t)r * 2 * H + H + c];
+            const float ev = e[(size_t)r * H + c];
+            de[(size_t)r * H + c] = glo * emb[(size_t)a * H + c] + ghi * emb[(size_t)b * H + c];
+            atomicAdd(&acc[a][threadIdx.x & 63], glo * ev);
+            atomicAdd(&acc[b][threadIdx.x & 63], ghi * ev);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 100 * 64; t += 256) {
+        const int ty = t / 64, cc = blockIdx.x * 64 + (t % 64);
+        const float v = acc[ty][t % 64];
+        if (v != 0.0f && cc < H) atomicAdd(demb + (size_t)ty * H + cc, v);
+    }
+}
+__global__ void copy2d_kernel(int64_t rows, int cols, const float* __restrict__ src, int lds_, float* __restrict__ dst,
+                              int ldd) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * cols) return;
+    const int64_t r = t / cols;
+    const int c = (int)(t % cols);
+    dst[r * ldd + c] = src[r * lds_ + c];
+}
+// d_target[u] = (|pos0_i - pos0_j| - d_u) / sqrt(1 - a) * sqrt(a), a = alpha of the pair's graph   condensenc.py:309-318
+__global__ void d_target_kernel(tsd_edges eu, const float* __restrict__ pos0, const int32_t* __restrict__ node_graph,
+                                const float* __restrict__ a_graph, float* __restrict__ out) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= *eu.count) return;
+    const int i = eu.src[u], j = eu.dst[u];
+    const float dx = pos0[3 * i] - pos0[3 * j], dy = pos0[3 * i + 1] - pos0[3 * j + 1], dz = pos0[3 * i + 2] - pos0[3 * j + 2];
+    const float d_gt = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float a = a_graph[node_graph[i]];
+    out[u] = (d_gt - eu.dist[u]) / sqrtf(1.0f - a) * sqrtf(a);
+}
+__global__ void loss_fwd_kernel(int N, const float* __restrict__ eq, const float* __restrict__ tg,
+                                float* __restrict__ loss) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float a = eq[3 * i] - tg[3 * i], b = eq[3 * i + 1] - tg[3 * i + 1], c = eq[3 * i + 2] - tg[3 * i + 2];
+    loss[i] = a * a + b * b + c * c;
+}
+__global__ void loss_bwd_kernel(int N, const float* __restrict__ eq, const float* __restrict__ tg,
+                                const float* __restrict__ dloss, float* __restrict__ deq) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 3 * N) return;
+    deq[t] = 2.0f * (eq[t] - tg[t]) * dloss[t / 3];
+}
+
+struct Ctx {
+    const tsd_model_cfg* c;
+    const tsd_batch* b;
+    RawLayout R;
+    Work w;
+    const float* raw;
+    float* grad;  // backward only
+    hipStream_t st;
+    int N, H, L, F, Eu, Eo;
+    bool packed(int in, int out) const { return (in == 128 || in == 256 || in == 512) && (out == 128 || out == 256 || out == 512); }
+    int lin(int rows, int in, int out, const float* X, size_t w_off, long b_off, const float* Rsd, float* Y) const {
+        const float* Wp = packed(in, out) ? w.pack_fwd + w_off : nullptr;
+        return linear_fwd_impl(rows, in, out, X, raw + w_off, Wp, b_off >= 0 ? raw + b_off : nullptr, Rsd, Y, w.scratch,
+                               w.scratch_floats, st);
+    }
+    // all parameter gradients accumulate (the flat gradient is zeroed once per backward)
+    int lin_bwd(int rows, int in, int out, const float* X, size_t w_off, long b_off, const float* dY, float* dX,
+                bool accumulate_dx) const {
+        const float* Wpt = packed(out, in) ? w.pack_t + w_off : nullptr;
+        return linear_bwd_impl(rows, in, out, X, raw + w_off, Wpt, dY, dX, grad + w_off, b_off >= 0 ? grad + b_off : nullptr,
+                               2 | (accumulate_dx ? 1 : 0), w.scratch, w.scratch_floats, st);
+    }
+};
+
+#define TSD_TRY(expr)          \
+    do {                       \
+        int _r = (expr);       \
+        if (_r) return _r;     \
+    } while (0)
+
+int pack_all(const Ctx& x) {
+    // every MFMA-shaped dense weight, forward and dgrad layouts, a handful of launches
+    const int H = x.H;
+    const float* W[64];
+    float* D[64];
+    int od[64], id[64], tr[64];
+    int n = 0;
+    auto add = [&](size_t off, int out, int in) {
+        if (!x.packed(in, out)) return;
+        for (int t = 0; t < 2; ++t) {
+            W[n] = x.raw + off;
+            D[n] = (t ? x.w.pack_t : x.w.pack_fwd) + off;
+            od[n] = out;
+            id[n] = in;
+            tr[n] = t;
+            ++n;
+        }
+    };
+    auto flush = [&]() -> int {
+        int r = n ? tsd_pack_linear_batch(n, W, D, od, id, tr, (void*)x.st) : TSD_OK;
+        n = 0;
+        return r;
+    };
+    add(x.R.emlp_w1, H, H);
+    add(x.R.ecat_w0, H, 2 * H);
+    add(x.R.ecat_w1, H, H);
+    add(x.R.out_w0, H, 2 * H);
+    add(x.R.out_w1, H / 2, H);
+    TSD_TRY(flush());
+    for (int l = 0; l < x.L; ++l) {
+        const size_t o = x.R.layer0 + (size_t)l * x.R.layer_stride;
+        add(o + x.R.L_lin1_w, H, H);
+        add(o + x.R.L_lin2_w, H, H);
+        add(o + x.R.L_nn0_w, H, H);
+        add(o + x.R.L_nn2_w, H, H);
+        add(o + x.R.L_lin_w, H, H);
+        if (n + 10 > 48) TSD_TRY(flush());
+    }
+    return flush();
+}
+
+int embed_fwd(const Ctx& x, const tsd_edges& lst, int E, const EmbedSave& s) {
+    if (E == 0) return TSD_OK;
+    const int H = x.H;
+    const int64_t n = (int64_t)E * H;
+    // mlp(d) = Linear(1,H) -> swish -> Linear(H,H)                                        edge.py:50-52,66
+    TSD_TRY(x.lin(E, 1, H, lst.dist, x.R.emlp_w0, (long)x.R.emlp_b0, nullptr, s.l0));
+    TSD_TRY(tsd_act_fwd(0, n, s.l0, s.s0, (void*)x.st));
+    TSD_TRY(x.lin(E, H, H, s.s0, x.R.emlp_w1, (long)x.R.emlp_b1, nullptr, s.e));
+    hipLaunchKernelGGL(emb_mul2_fwd_kernel, dim3(nblk(n)), dim3(256), 0, x.st, E, H, s.e, x.raw + x.R.bond_emb,
+                       lst.type_r, lst.type_p, s.c);
+    // edge_cat = Linear(2H,H) -> swish -> Linear(H,H)                              condensenc.py:105-115,173-175
+    TSD_TRY(x.lin(E, 2 * H, H, s.c, x.R.ecat_w0, (long)x.R.ecat_b0, nullptr, s.c0));
+    TSD_TRY(tsd_act_fwd(0, n, s.c0, s.s1, (void*)x.st));
+    TSD_TRY(x.lin(E, H, H, s.s1, x.R.ecat_w1, (long)x.R.ecat_b1, nullptr, s.ea));
+    TSD_LAUNCH_CHECK("embed_fwd");
+    return TSD_OK;
+}
+
+// d_ea [E,H] -> parameter gradients (eA / eB are its temporaries: d_ea must not alias them)
+int embed_bwd(const Ctx& x, const tsd_edges& lst, int E, const EmbedSave& s, const float* d_ea) {
+    if (E == 0) return TSD_OK;
+    const int H = x.H;
+    const int64_t n = (int64_t)E * H;
+    float* tA = x.w.eA;             // [E,2H]
+    float* tB = x.w.eB;             // [E,2H]
+    TSD_TRY(x.lin_bwd(E, H, H, s.s1, x.R.ecat_w1, (long)x.R.ecat_b1, d_ea, tA, false));            // ds1
+    TSD_TRY(tsd_act_bwd(0, n, s.c0, tA, tB, (void*)x.st));                                         // dc0
+    TSD_TRY(x.lin_bwd(E, 2 * H, H, s.c, x.R.ecat_w0, (long)x.R.ecat_b0, tB, tA, false));           // dc [E,2H]
+    const int chunks = (E + 255) / 256 < 512 ? (E + 255) / 256 : 512;
+    hipLaunchKernelGGL(emb_mul2_bwd_kernel, dim3((H + 63) / 64, chunks), dim3(256), 0, x.st, E, H,
+                       (E + chunks - 1) / chunks, s.e, x.raw + x.R.bond_emb, lst.type_r, lst.type_p, tA, tB,
+                       x.grad + x.R.bond_emb);                                                      // de -> tB
+    TSD_TRY(x.lin_bwd(E, H, H, s.s0, x.R.emlp_w1, (long)x.R.emlp_b1, tB, tA, false));              // ds0
+    TSD_TRY(tsd_act_bwd(0, n, s.l0, tA, tB, (void*)x.st));                                         // dl0
+    TSD_TRY(x.lin_bwd(E, 1, H, lst.dist, x.R.emlp_w0, (long)x.R.emlp_b0, tB, nullptr, false));
+    TSD_LAUNCH_CHECK("embed_bwd");
+    return TSD_OK;
+}
+
+int make_ctx(Ctx& x, const tsd_model_cfg* cfg, const tsd_batch* b, const float* raw, float* ws, size_t ws_floats,
+             const int32_t* counts_host, hipStream_t st) {
+    TSD_REQUIRE(cfg && b && raw && ws && counts_host, "null pointer");
+    TSD_REQUIRE(hidden_supported(cfg->hidden), "hidden=%d unsupported (64/128/256)", cfg->hidden);
+    x.c = cfg;
+    x.b = b;
+    x.R = raw_layout(*cfg);
+    x.raw = raw;
+    x.grad = nullptr;
+    x.st = st;
+    x.N = b->num_nodes;
+    x.H = cfg->hidden;
+    x.L = cfg->num_convs;
+    x.F = cfg->feat_dim;
+    x.Eu = counts_host[0];
+    x.Eo = counts_host[1];
+    x.w = carve(*cfg, x.N, (size_t)x.Eu, (size_t)x.Eo, ws);
+    TSD_REQUIRE(x.w.total <= ws_floats, "training workspace too small: %zu < %zu floats", ws_floats, x.w.total);
+    return TSD_OK;
+}
+
+}  // namespace
+}  // namespace tsd
+
+using namespace tsd;
+
+extern "C" {
+
+size_t tsd_train_raw_floats(const tsd_model_cfg* cfg) { return cfg ? raw_layout(*cfg).total : 0; }
+
+size_t tsd_train_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs) {
+    if (!cfg) return 0;
+    return carve(*cfg, num_nodes, (size_t)num_pairs / 2, (size_t)num_pairs / 2, nullptr).total;
+}
+
+int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* raw, const int64_t* atom_type,
+                      const int64_t* r_feat, const int64_t* p_feat, const float* pos0, const float* pos,
+                      const float* a_graph, float* workspace, size_t workspace_floats, float* loss,
+                      int32_t* counts_host, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    TSD_REQUIRE(cfg && batch && raw && atom_type && r_feat && p_feat && pos0 && pos && a_graph && workspace && loss &&
+                    counts_host, "null pointer");
+    const tsd_geometry& g = batch->geo;
+    TSD_TRY(launch_geometry(*cfg, batch->num_nodes, batch->num_graphs, batch->num_pairs, pos, batch->graph_ptr,
+                            batch->node_graph, batch->pair_ptr, batch->pair_code, g, st));
+    // the edge counts size every launch below: the one host sync of the step
+    TSD_HIP(hipMemcpyAsync(&counts_host[0], g.enc_u.count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TSD_HIP(hipMemcpyAsync(&counts_host[1], g.out_u.count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TSD_HIP(hipStreamSynchronize(st));
+    Ctx x;
+    TSD_TRY(make_ctx(x, cfg, batch, raw, workspace, workspace_floats, counts_host, st));
+    const int N = x.N, H = x.H, L = x.L, F = x.F, Eu = x.Eu, Eo = x.Eo;
+    const Work& w = x.w;
+    if (N == 0) return TSD_OK;
+    TSD_TRY(pack_all(x));
+    // node embedding
+    hipLaunchKernelGGL(feats_to_float_kernel, dim3(nblk((int64_t)N * F)), dim3(256), 0, st, (int64_t)N * F, r_feat, p_feat,
+                       w.featR, w.featP);
+    hipLaunchKernelGGL(node_embed_raw_kernel, dim3(nblk((int64_t)N * (H / 2))), dim3(256), 0, st, N, H / 2, F,
+                       raw + x.R.atom_emb, raw + x.R.atom_feat, atom_type, w.featR, w.featP, w.h);
+    TSD_LAUNCH_CHECK("node_embed_raw");
+    TSD_TRY(embed_fwd(x, g.enc_u, Eu, w.emb_enc));
+    TSD_TRY(embed_fwd(x, g.out_u, Eo, w.emb_out));
+    const size_t NH = (size_t)N * H, EH = (size_t)Eu * H;
+    for (int l = 0; l < L; ++l) {  // schnet.py:88-128, 223-224
+        const size_t o = x.R.layer0 + (size_t)l * x.R.layer_stride;
+        float *f0 = w.f0 + l * EH, *fs = w.fs + l * EH, *Wf = w.Wf + l * EH;
+        float *hl = w.h + l * NH, *hn = w.h + (l + 1) * NH;
+        float *x1 = w.x1 + l * NH, *agg = w.agg + l * NH, *x2 = w.x2 + l * NH, *xs = w.xs + l * NH;
+        if (Eu > 0) {
+            TSD_TRY(x.lin(Eu, H, H, w.emb_enc.ea, o + x.R.L_nn0_w, (long)(o + x.R.L_nn0_b), nullptr, f0));
+            TSD_TRY(tsd_act_fwd(1, (int64_t)EH, f0, fs, stream));
+            TSD_TRY(x.lin(Eu, H, H, fs, o + x.R.L_nn2_w, (long)(o + x.R.L_nn2_b), nullptr, Wf));
+            TSD_TRY(tsd_row_mask(Eu, H, g.enc_u.dist, cfg->conv_cutoff, cfg->smooth_conv, Wf, stream));
+        }
+        TSD_TRY(x.lin(N, H, H, hl, o + x.R.L_lin1_w, -1, nullptr, x1));
+        TSD_TRY(tsd_cfconv_aggregate(H, N, g.enc.row_ptr, g.enc.dst, g.enc.umap, Wf, x1, agg, stream));
+        TSD_TRY(x.lin(N, H, H, agg, o + x.R.L_lin2_w, (long)(o + x.R.L_lin2_b), nullptr, x2));
+        TSD_TRY(tsd_act_fwd(1, (int64_t)NH, x2, xs, stream));
+        TSD_TRY(x.lin(N, H, H, xs, o + x.R.L_lin_w, (long)(o + x.R.L_lin_b), hl, hn));  // h + lin(ssp(.))
+    }
+    // pair MLP on [h_i * h_j , edge_attr_out]                                       common.py:226-229
+    if (Eo > 0) {
+        TSD_TRY(tsd_pair_product_fwd(H, Eo, g.out_u, w.h + (size_t)L * NH, w.eA, stream));
+        hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.eA, H, w.hp,
+                           2 * H);
+        hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.emb_out.ea, H,
+                           w.hp + H, 2 * H);
+        TSD_TRY(x.lin(Eo, 2 * H, H, w.hp, x.R.out_w0, (long)x.R.out_b0, nullptr, w.g0));
+        TSD_TRY(tsd_act_fwd(0, (int64_t)Eo * H, w.g0, w.gs0, stream));
+        TSD_TRY(x.lin(Eo, H, H / 2, w.gs0, x.R.out_w1, (long)x.R.out_b1, nullptr, w.g1));
+        TSD_TRY(tsd_act_fwd(0, (int64_t)Eo * (H / 2), w.g1, w.gs1, stream));
+        TSD_TRY(x.lin(Eo, H / 2, 1, w.gs1, x.R.out_w2, (long)x.R.out_b2, nullptr, w.s_u));
+        hipLaunchKernelGGL(d_target_kernel, dim3(nblk(Eo)), dim3(256), 0, st, g.out_u, pos0, batch->node_graph, a_graph,
+                           w.d_target);
+    }
+    // loss                                                                      condensenc.py:303-328
+    TSD_TRY(tsd_eq_und_fwd(N, g.out, pos, w.s_u, w.node_eq, stream));
+    TSD_TRY(tsd_eq_und_fwd(N, g.out, pos, w.d_target, w.pos_target, stream));
+    hipLaunchKernelGGL(loss_fwd_kernel, dim3(nblk(N)), dim3(256), 0, st, N, w.node_eq, w.pos_target, loss);
+    TSD_LAUNCH_CHECK("train_forward");
+    return TSD_OK;
+}
+
+int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* raw, const int64_t* atom_type,
+                       const float* pos, float* workspace, size_t workspace_floats, const int32_t* counts_host,
+                       const float* dloss, float* grad, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    TSD_REQUIRE(dloss && grad && atom_type && pos, "null pointer");
+    Ctx x;
+    TSD_TRY(make_ctx(x, cfg, batch, raw, workspace, workspace_floats, counts_host, st));
+    x.grad = grad;
+    const tsd_geometry& g = batch->geo;
+    const int N = x.N, H = x.H, L = x.L, F = x.F, Eu = x.Eu, Eo = x.Eo;
+    const Work& w = x.w;
+    TSD_HIP(hipMemsetAsync(grad, 0, x.R.total * sizeof(float), st));
+    if (N == 0) return TSD_OK;
+    const size_t NH = (size_t)N * H, EH = (size_t)Eu * H;
+    // loss -> node_eq -> s_u
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(nblk(3 * (int64_t)N)), dim3(256), 0, st, N, w.node_eq, w.pos_target, dloss,
+                       w.nA);
+    TSD_HIP(hipMemsetAsync(w.dh, 0, NH * sizeof(float), st));
+    if (Eo > 0) {
+        float* ds = w.d_target;  // [Eo] (d_target itself is no longer needed)
+        TSD_TRY(tsd_eq_und_bwd(Eo, g.out_u, pos, w.nA, ds, stream));
+        TSD_TRY(x.lin_bwd(Eo, H / 2, 1, w.gs1, x.R.out_w2, (long)x.R.out_b2, ds, w.eA, false));          // dgs1
+        TSD_TRY(tsd_act_bwd(0, (int64_t)Eo * (H / 2), w.g1, w.eA, w.eB, stream));                       // dg1
+        TSD_TRY(x.lin_bwd(Eo, H, H / 2, w.gs0, x.R.out_w1, (long)x.R.out_b1, w.eB, w.eA, false));        // dgs0
+        TSD_TRY(tsd_act_bwd(0, (int64_t)Eo * H, w.g0, w.eA, w.eB, stream));                             // dg0
+        TSD_TRY(x.lin_bwd(Eo, 2 * H, H, w.hp, x.R.out_w0, (long)x.R.out_b0, w.eB, w.eA, false));         // dhp [Eo,2H]
+        // dp (left half) -> dh ; d edge_attr_out (right half) -> embedding of the out list
+        // (embed_bwd uses eA / eB as temporaries: d edge_attr_out is parked in hp, which is free by now)
+        float* dp = w.eB;
+        hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.eA, 2 * H, dp, H);
+        hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.eA + H, 2 * H,
+                           w.hp, H);
+        TSD_TRY(tsd_pair_product_bwd(N, H, g.out, dp, w.h + (size_t)L * NH, w.dh, stream));
+        TSD_TRY(embed_bwd(x, g.out_u, Eo, w.emb_out, w.hp));
+    }
+    if (Eu > 0) TSD_HIP(hipMemsetAsync(w.d_ea, 0, EH * sizeof(float), st));
+    for (int l = L - 1; l >= 0; --l) {
+        const size_t o = x.R.layer0 + (size_t)l * x.R.layer_stride;
+        float *f0 = w.f0 + l * EH, *fs = w.fs + l * EH, *Wf = w.Wf + l * EH;
+        float* hl = w.h + l * NH;
+        float *x1 = w.x1 + l * NH, *agg = w.agg + l * NH, *x2 = w.x2 + l * NH, *xs = w.xs + l * NH;
+        // h_{l+1} = h_l + lin(ssp(lin2(agg)))
+        TSD_TRY(x.lin_bwd(N, H, H, xs, o + x.R.L_lin_w, (long)(o + x.R.L_lin_b), w.dh, w.nA, false));    // dxs
+        TSD_TRY(tsd_act_bwd(1, (int64_t)NH, x2, w.nA, w.nB, stream));                                   // dx2
+        TSD_TRY(x.lin_bwd(N, H, H, agg, o + x.R.L_lin2_w, (long)(o + x.R.L_lin2_b), w.nB, w.nA, false)); // dagg
+        // agg = aggregate(x1, Wf): symmetric edge set and filter => the adjoint w.r.t. x1 is the same gather of dagg
+        TSD_TRY(tsd_cfconv_aggregate(H, N, g.enc.row_ptr, g.enc.dst, g.enc.umap, Wf, w.nA, w.nC, stream)); // dx1
+        if (Eu > 0) {
+            float* dWf = w.eA;
+            TSD_TRY(tsd_aggregate_bwd_filter(H, Eu, g.enc_u, w.nA, x1, dWf, stream));
+            TSD_TRY(tsd_row_mask(Eu, H, g.enc_u.dist, cfg->conv_cutoff, cfg->smooth_conv, dWf, stream));
+            TSD_TRY(x.lin_bwd(Eu, H, H, fs, o + x.R.L_nn2_w, (long)(o + x.R.L_nn2_b), dWf, w.eB, false)); // dfs
+            TSD_TRY(tsd_act_bwd(1, (int64_t)EH, f0, w.eB, w.eA, stream));                                // df0
+            TSD_TRY(x.lin_bwd(Eu, H, H, w.emb_enc.ea, o + x.R.L_nn0_w, (long)(o + x.R.L_nn0_b), w.eA, w.d_ea, true));
+        }
+        TSD_TRY(x.lin_bwd(N, H, H, hl, o + x.R.L_lin1_w, -1, w.nC, w.dh, true));  // dh += dx1 W_lin1 (residual keeps dh)
+    }
+    if (Eu > 0) TSD_TRY(embed_bwd(x, g.enc_u, Eu, w.emb_enc, w.d_ea));
+    // node embedding: dz = dh
+    hipLaunchKernelGGL(node_embed_bwd_kernel, dim3(nblk((int64_t)N * (H / 2))), dim3(256), 0, st, N, H / 2, atom_type, w.dh,
+                       grad + x.R.atom_emb, w.nA, w.nB);
+    TSD_TRY(linear_bwd_impl(N, F, H / 2, w.featR, raw + x.R.atom_feat, nullptr, w.nA, nullptr, grad + x.R.atom_feat,
+                            nullptr, 2, w.scratch, w.scratch_floats, st));
+    TSD_TRY(linear_bwd_impl(N, F, H / 2, w.featP, raw + x.R.atom_feat, nullptr, w.nB, nullptr, grad + x.R.atom_feat,
+                            nullptr, 2, w.scratch, w.scratch_floats, st));
+    TSD_LAUNCH_CHECK("train_backward");
+    return TSD_OK;
+}
+
+}  // extern "C"

@@ -221,6 +221,14 @@ class DeviceBatch:
             geo=self.geo_struct(), workspace=self.workspace.data_ptr(),
             edge_inv_u=self.edge_inv_u.data_ptr())
 
+    def train_struct(self):
+        """tsd_batch for the training step: topology + edge-list buffers only (no bound checkpoints)"""
+        return Batch(
+            num_nodes=self.N, num_graphs=self.G, num_pairs=self.P, num_models=0,
+            graph_ptr=self.graph_ptr.data_ptr(), node_graph=self.node_graph.data_ptr(),
+            pair_ptr=self.pair_ptr.data_ptr(), pair_code=self.pair_code.data_ptr(),
+            weights=None, z=None, x1_0=None, geo=self.geo_struct(), workspace=None, edge_inv_u=None)
+
     # ---- ops -------------------------------------------------------------------------------
     def geometry(self, pos):
         lib = _lib.load()

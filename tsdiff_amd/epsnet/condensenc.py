@@ -6,6 +6,8 @@ signatures and return conventions (condensenc.py:241-328) -- but every computati
 libtsdiff_hip.so on the MI355X.  The `nn.Module` children below only HOLD parameters under the
 reference's names; their own `forward` is never used.
 """
+import os
+
 import numpy as np
 import torch
 from torch import nn
@@ -197,6 +199,10 @@ class CondenseEncoderEpsNetwork(nn.Module):
         training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if training:
             from .. import train_ops as T
+            if os.environ.get("TSDIFF_TRAIN", "fused") != "ops":
+                # forward + loss and the whole backward sequenced in C++ (csrc/train_step.hip): one autograd node
+                return T.fused_train_loss(self, db, pos, pos_perturbed, a)
+            # op-by-op autograd form (same kernels, one node per operation; kept as the cross-check)
             s_u, Eo = T.train_forward(self, db, pos_perturbed)
             node_eq = T.EqUndirected.apply(s_u, pos_perturbed, db)
             src_u = db.out_u.src[:Eo].long()

@@ -474,3 +474,56 @@ def dual_forward(model, db, pos):
     s_local_u = pair_mlp("grad_local_dist_mlp", torch.cat([PairProduct.apply(hl, db, Eu), ea_l], dim=-1))
     return {"s_global_u": s_global_u, "s_local_u": s_local_u, "Eu": Eu, "E": E, "emb_type_u": t_u,
             "emb_type_dir": t_dir, "edge_type_dir": edge_type_dir}
+
+
+# ---------------------------------------------------------------------------------------------
+# The training step as two library calls (tsdiff_amd/csrc/train_step.hip): the whole forward + loss and the
+# whole backward are sequenced in C++; autograd sees ONE node whose inputs are the parameters.
+class FusedTrainLoss(torch.autograd.Function):
+    """loss (N,1) of CondenseEncoderEpsNetwork.get_loss (condensenc.py:267-328), differentiable w.r.t. every
+    parameter.  `params` come in the order of engine.raw_param_names."""
+
+    @staticmethod
+    def forward(ctx, model, db, pos0, pos_perturbed, a_graph, *params):
+        lib = _lib.load()
+        cfg = model._cfg
+        dev = pos0.device
+        raw = torch.cat([p.detach().reshape(-1) for p in params])
+        n_raw = lib.tsd_train_raw_floats(C.byref(cfg))
+        if raw.numel() != n_raw:
+            raise ValueError(f"parameters hold {raw.numel()} floats, the config needs {n_raw}")
+        nws = lib.tsd_train_workspace_floats(C.byref(cfg), db.N, db.P)
+        ws = getattr(db, "_train_ws", None)
+        if ws is None or ws.numel() < nws:
+            ws = torch.empty(max(nws, 1), dtype=torch.float32, device=dev)
+            db._train_ws = ws
+        b = db.train_struct()
+        counts = (C.c_int32 * 2)()
+        loss = torch.empty(db.N, 1, dtype=torch.float32, device=dev)
+        pos0, pos_perturbed, a_graph = _c(pos0.float()), _c(pos_perturbed.float()), _c(a_graph.float())
+        check(lib.tsd_train_forward(C.byref(cfg), C.byref(b), ptr(raw), ptr(db.atom_type), ptr(db.r_feat),
+                                    ptr(db.p_feat), ptr(pos0), ptr(pos_perturbed), ptr(a_graph), ptr(ws), ws.numel(),
+                                    ptr(loss), counts, stream_ptr()))
+        ctx.model, ctx.db, ctx.raw, ctx.ws, ctx.counts, ctx.pos = model, db, raw, ws, counts, pos_perturbed
+        ctx.sizes = [p.numel() for p in params]
+        ctx.shapes = [p.shape for p in params]
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lib = _lib.load()
+        cfg, db = ctx.model._cfg, ctx.db
+        grad = torch.empty_like(ctx.raw)
+        dloss = _c(dloss.float()).view(-1)
+        b = db.train_struct()
+        check(lib.tsd_train_backward(C.byref(cfg), C.byref(b), ptr(ctx.raw), ptr(db.atom_type), ptr(ctx.pos),
+                                     ptr(ctx.ws), ctx.ws.numel(), ctx.counts, ptr(dloss), ptr(grad), stream_ptr()))
+        views = [g.view(s) for g, s in zip(grad.split(ctx.sizes), ctx.shapes)]  # views of ONE flat buffer
+        return (None, None, None, None, None) + tuple(views)
+
+
+def fused_train_loss(model, db, pos0, pos_perturbed, a_graph):
+    from . import engine
+    P = dict(model.named_parameters())
+    params = [P[n] for n in engine.raw_param_names(model._cfg.num_convs)]
+    return FusedTrainLoss.apply(model, db, pos0, pos_perturbed, a_graph, *params)
