@@ -103,7 +103,7 @@ def bench_train(args, model, dev, rank, world, dist):
             "config": {"workload": "configs[3] training step", "graphs_per_gpu": args.graphs, "atoms_per_gpu": N,
                        "parallelism": f"graph-batch data parallel over {args.gpus} GPU(s), one RCCL all-reduce of "
                                       "the flat fp32 gradient per step"},
-            "final_loss": last}))
+            "final_loss": float(last)}))
     if dist is not None:
         dist.destroy_process_group()
 

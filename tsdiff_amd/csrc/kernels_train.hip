@@ -8,7 +8,7 @@
 //
 // All per-edge work runs on the UNDIRECTED lists (see tsd_geometry): a filter row Wf[u] / score s[u] is
 // used by both directed edges (i,j) and (j,i), so its gradient is the sum of both directions.
-#include "common.hpp"
+#include "train_internal.hpp"
 
 namespace tsd {
 
@@ -38,8 +38,7 @@ __global__ void pack_any_kernel(const float* __restrict__ M, float* __restrict__
 // R (nullable, may alias Y): residual / accumulation source with the layout of Y.
 template <int K, int CB>
 __global__ __launch_bounds__(256) void linear_mfma_kernel(int rows, int nout, const float* __restrict__ A,
-                                                          const float* __restrict__ Bp,
-                                                          const float* __restrict__ bias, const float* R, float* Y) {
+                                                          const float* __restrict__ Bp, LinEpi epi, float* Y) {
     constexpr int LDA = K + 4;
     constexpr int K4 = K / 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -60,23 +59,17 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(int rows, int nout, co
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
         const int col = col0 + cb * 32 + l31;
-        const float b = bias ? bias[col] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = acc_row(r, hi);
-            if (row < nrows) {
-                const size_t o = (size_t)(r0 + row) * nout + col;
-                float v = acc[0][cb][r] + b;
-                if (R) v += R[o];
-                Y[o] = v;
-            }
+            if (row < nrows) epi_store(epi, acc[0][cb][r], r0 + row, col, (size_t)(r0 + row) * nout + col, Y);
         }
     }
 }
 
 template <int K, int CB>
-static int launch_linear_mfma(int rows, int nout, const float* A, const float* Bp, const float* bias, const float* R,
-                              float* Y, hipStream_t st) {
+static int launch_linear_mfma(int rows, int nout, const float* A, const float* Bp, const LinEpi& epi, float* Y,
+                              hipStream_t st) {
     const size_t lds = (size_t)32 * (K + 4) * 4;
     static bool done = false;
     if (!done && lds > 48 * 1024)
@@ -84,18 +77,18 @@ static int launch_linear_mfma(int rows, int nout, const float* A, const float* B
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     done = true;
     hipLaunchKernelGGL((linear_mfma_kernel<K, CB>), dim3((rows + 31) / 32, nout / (CB * 128)), dim3(256), lds, st, rows,
-                       nout, A, Bp, bias, R, Y);
+                       nout, A, Bp, epi, Y);
     TSD_LAUNCH_CHECK("linear_mfma");
     return TSD_OK;
 }
 
 static bool mfma_shape(int K, int NOUT) { return (K == 128 || K == 256 || K == 512) && (NOUT == 128 || NOUT == 256 || NOUT == 512); }
 
-static int dispatch_linear_mfma(int rows, int K, int NOUT, const float* A, const float* Bp, const float* bias,
-                                const float* R, float* Y, hipStream_t st) {
+static int dispatch_linear_mfma(int rows, int K, int NOUT, const float* A, const float* Bp, const LinEpi& epi, float* Y,
+                                hipStream_t st) {
     // fewer than one workgroup per CU with full-width tiles: split the columns over grid.y instead
     const int CBsel = (rows + 31) / 32 >= 256 ? NOUT / 128 : 1;
-#define TSD_LM(KK, CC) if (K == KK && CBsel == CC) return launch_linear_mfma<KK, CC>(rows, NOUT, A, Bp, bias, R, Y, st);
+#define TSD_LM(KK, CC) if (K == KK && CBsel == CC) return launch_linear_mfma<KK, CC>(rows, NOUT, A, Bp, epi, Y, st);
     TSD_LM(128, 1) TSD_LM(128, 2) TSD_LM(128, 4) TSD_LM(256, 1) TSD_LM(256, 2) TSD_LM(256, 4)
     TSD_LM(512, 1) TSD_LM(512, 2) TSD_LM(512, 4)
 #undef TSD_LM
@@ -106,15 +99,13 @@ static int dispatch_linear_mfma(int rows, int K, int NOUT, const float* A, const
 // odd shapes: one thread per output element
 // C[r, n] = sum_k A[r, k] * (transposed ? M[k, n] : M[n, k]) (+ bias[n])
 __global__ void linear_naive_kernel(int rows, int K, int N, const float* __restrict__ A, const float* __restrict__ M,
-                                    int transposed, const float* __restrict__ bias, const float* R, float* C) {
+                                    int transposed, LinEpi epi, float* C) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)rows * N) return;
     const int r = (int)(t / N), n = (int)(t % N);
     float s = 0.0f;
     for (int k = 0; k < K; ++k) s = fmaf(A[(size_t)r * K + k], transposed ? M[(size_t)k * N + n] : M[(size_t)n * K + k], s);
-    s += bias ? bias[n] : 0.0f;
-    if (R) s += R[t];
-    C[t] = s;
+    epi_store(epi, s, r, n, (size_t)t, C);
 }
 // dW[o, i] = sum_r dY[r, o] * X[r, i]: one workgroup per output element, tree over the rows
 __global__ __launch_bounds__(256) void wgrad_naive_kernel(int rows, int in, int out, const float* __restrict__ dY,
@@ -334,17 +325,14 @@ __global__ void act_fwd_kernel(int kind, int64_t n, const float* __restrict__ x,
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float v = x[i];
-    y[i] = kind == 0 ? swishf(v) : kind == 1 ? sspf(v) : kind == 2 ? fmaxf(v, 0.0f) : sspf(v) + 0.69314718055994530942f;
+    y[i] = act_apply(kind, v);
 }
 __global__ void act_bwd_kernel(int kind, int64_t n, const float* __restrict__ x, const float* __restrict__ dy,
                                float* __restrict__ dx) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float v = x[i];
-    const float sg = __builtin_amdgcn_rcpf(1.0f + fast_exp(-v));  // sigmoid(v)
-    // d swish = sg * (1 + v * (1 - sg)) ; d ssp = d softplus = sg
-    const float d = kind == 0 ? sg * (1.0f + v * (1.0f - sg)) : kind == 2 ? (v > 0.0f ? 1.0f : 0.0f) : sg;
-    dx[i] = dy[i] * d;
+    dx[i] = dy[i] * act_deriv(kind, v);
 }
 
 // y[r,:] = x[r,:] * emb[idx[r],:]   (edge.py:66-68 d_emb * bond_emb(type))
@@ -412,14 +400,26 @@ __global__ void row_mask_kernel(int rows, int H, const float* __restrict__ dist,
 }
 
 // adjoint of the aggregation w.r.t. the filter: dWf[u] = dagg[i] * x1[j] + dagg[j] * x1[i], u = {i<j}
+// masked != 0: the adjoint of the CFConv cutoff weight is applied as well (dWf *= C(d))
 __global__ void aggregate_bwd_filter_kernel(int H, tsd_edges eu, const float* __restrict__ dagg,
-                                            const float* __restrict__ x1, float* __restrict__ dWf) {
+                                            const float* __restrict__ x1, float* __restrict__ dWf, int masked,
+                                            float cutoff, int smooth) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int Eu = *eu.count;
     if (t >= (int64_t)Eu * H) return;
     const int u = (int)(t / H), c = (int)(t % H);
     const int i = eu.src[u], j = eu.dst[u];
-    dWf[t] = dagg[(size_t)i * H + c] * x1[(size_t)j * H + c] + dagg[(size_t)j * H + c] * x1[(size_t)i * H + c];
+    float v = dagg[(size_t)i * H + c] * x1[(size_t)j * H + c] + dagg[(size_t)j * H + c] * x1[(size_t)i * H + c];
+    if (masked) v *= cutoff_weight(eu.dist[u], cutoff, smooth);
+    dWf[t] = v;
+}
+int launch_aggregate_bwd_filter(int H, int capacity_u, tsd_edges enc_u, const float* dagg, const float* x1, float* dWf,
+                                int masked, float cutoff, int smooth, hipStream_t st) {
+    if (capacity_u == 0) return TSD_OK;
+    hipLaunchKernelGGL(aggregate_bwd_filter_kernel, dim3((unsigned)(((int64_t)capacity_u * H + 255) / 256)), dim3(256), 0,
+                       st, H, enc_u, dagg, x1, dWf, masked, cutoff, smooth);
+    TSD_LAUNCH_CHECK("aggregate_bwd_filter");
+    return TSD_OK;
 }
 
 // p[u,:] = h[i,:] * h[j,:] for the undirected out edges (common.py:226-229 first half of h_pair)
@@ -650,8 +650,8 @@ static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256
 // ---------------------------------------------------------------------------------------------
 // dense layer, host side.  Wp / Wp_t: pre-packed weights (pack_batch) or NULL (packed here into scratch).
 // R: residual added to the product (may alias Y).  flags: 1 = dX += , 2 = dW / db += .
-int linear_fwd_impl(int rows, int in, int out, const float* X, const float* W, const float* Wp, const float* b,
-                    const float* R, float* Y, float* scratch, size_t scratch_floats, hipStream_t st) {
+int linear_fwd_impl(int rows, int in, int out, const float* X, const float* W, const float* Wp, const LinEpi& epi,
+                    float* Y, float* scratch, size_t scratch_floats, hipStream_t st) {
     if (rows == 0) return TSD_OK;
     if (mfma_shape(in, out) && (Wp || (scratch && scratch_floats >= (size_t)in * out))) {
         if (!Wp) {
@@ -659,21 +659,23 @@ int linear_fwd_impl(int rows, int in, int out, const float* X, const float* W, c
             hipLaunchKernelGGL(pack_any_kernel, dim3((n + 255) / 256), dim3(256), 0, st, W, scratch, out, in, 0);
             Wp = scratch;
         }
-        return dispatch_linear_mfma(rows, in, out, X, Wp, b, R, Y, st);
+        return dispatch_linear_mfma(rows, in, out, X, Wp, epi, Y, st);
     }
     const int64_t n = (int64_t)rows * out;
-    hipLaunchKernelGGL(linear_naive_kernel, dim3(blocks_for(n)), dim3(256), 0, st, rows, in, out, X, W, 0, b, R, Y);
+    hipLaunchKernelGGL(linear_naive_kernel, dim3(blocks_for(n)), dim3(256), 0, st, rows, in, out, X, W, 0, epi, Y);
     TSD_LAUNCH_CHECK("linear_naive");
     return TSD_OK;
 }
 
 int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, const float* Wp_t, const float* dY,
-                    float* dX, float* dW, float* db, int flags, float* scratch, size_t scratch_floats, hipStream_t st) {
+                    float* dX, float* dW, float* db, int flags, LinEpi epi, float* scratch, size_t scratch_floats,
+                    hipStream_t st) {
     // scratch layout: [0, 64*out) bias partials | [.., + in*out) packed W for dgrad | wgrad partials
     const size_t off_pack = 64 * (size_t)out, off_part = off_pack + (size_t)in * out;
     const int accW = (flags & 2) ? 1 : 0;
     if (dX && rows > 0) {  // dX = dY W
-        const float* R = (flags & 1) ? dX : nullptr;
+        epi.bias = nullptr;
+        epi.R = (flags & 1) ? dX : nullptr;
         if (mfma_shape(out, in) && (Wp_t || (scratch && scratch_floats >= off_part))) {
             if (!Wp_t) {
                 const int n = in * out;
@@ -681,12 +683,12 @@ int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, c
                                    out, 1);
                 Wp_t = scratch + off_pack;
             }
-            int r = dispatch_linear_mfma(rows, out, in, dY, Wp_t, nullptr, R, dX, st);
+            int r = dispatch_linear_mfma(rows, out, in, dY, Wp_t, epi, dX, st);
             if (r) return r;
         } else {
             const int64_t n = (int64_t)rows * in;
-            hipLaunchKernelGGL(linear_naive_kernel, dim3(blocks_for(n)), dim3(256), 0, st, rows, out, in, dY, W, 1,
-                               (const float*)nullptr, R, dX);
+            hipLaunchKernelGGL(linear_naive_kernel, dim3(blocks_for(n)), dim3(256), 0, st, rows, out, in, dY, W, 1, epi,
+                               dX);
             TSD_LAUNCH_CHECK("dgrad_naive");
         }
     }
@@ -743,7 +745,9 @@ extern "C" {
 
 int tsd_linear_fwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* b, float* Y,
                    float* scratch, size_t scratch_floats, void* stream) {
-    return linear_fwd_impl(rows, in, out, X, W, nullptr, b, nullptr, Y, scratch, scratch_floats, (hipStream_t)stream);
+    LinEpi epi;
+    epi.bias = b;
+    return linear_fwd_impl(rows, in, out, X, W, nullptr, epi, Y, scratch, scratch_floats, (hipStream_t)stream);
 }
 
 int tsd_linear_packable(int32_t in, int32_t out) { return mfma_shape(in, out) ? 1 : 0; }
@@ -776,13 +780,16 @@ int tsd_linear_fwd_packed(int32_t rows, int32_t in, int32_t out, const float* X,
                           float* Y, void* stream) {
     if (rows == 0) return TSD_OK;
     TSD_REQUIRE(mfma_shape(in, out), "tsd_linear_fwd_packed: no MFMA instance for %d -> %d", in, out);
-    return dispatch_linear_mfma(rows, in, out, X, Wp, b, nullptr, Y, (hipStream_t)stream);
+    LinEpi epi;
+    epi.bias = b;
+    return dispatch_linear_mfma(rows, in, out, X, Wp, epi, Y, (hipStream_t)stream);
 }
 
 int tsd_linear_bwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* Wp_t,
                    const float* dY, float* dX, float* dW, float* db, float* scratch, size_t scratch_floats,
                    void* stream) {
-    return linear_bwd_impl(rows, in, out, X, W, Wp_t, dY, dX, dW, db, 0, scratch, scratch_floats, (hipStream_t)stream);
+    return linear_bwd_impl(rows, in, out, X, W, Wp_t, dY, dX, dW, db, 0, LinEpi(), scratch, scratch_floats,
+                           (hipStream_t)stream);
 }
 
 int tsd_act_fwd(int32_t kind, int64_t n, const float* x, float* y, void* stream) {
@@ -909,11 +916,7 @@ int tsd_row_mask(int32_t rows, int32_t H, const float* dist, float cutoff, int32
 
 int tsd_aggregate_bwd_filter(int32_t H, int32_t capacity_u, tsd_edges enc_u, const float* dagg, const float* x1,
                              float* dWf, void* stream) {
-    if (capacity_u == 0) return TSD_OK;
-    hipLaunchKernelGGL(aggregate_bwd_filter_kernel, dim3(blocks_for((int64_t)capacity_u * H)), dim3(256), 0,
-                       (hipStream_t)stream, H, enc_u, dagg, x1, dWf);
-    TSD_LAUNCH_CHECK("aggregate_bwd_filter");
-    return TSD_OK;
+    return launch_aggregate_bwd_filter(H, capacity_u, enc_u, dagg, x1, dWf, 0, 0.0f, 0, (hipStream_t)stream);
 }
 
 int tsd_pair_product_fwd(int32_t H, int32_t capacity_u, tsd_edges out_u, const float* h, float* p, void* stream) {

@@ -1,0 +1,51 @@
+// train_internal.hpp -- shared between kernels_train.hip and train_step.hip (not part of the C ABI)
+#pragma once
+#include "common.hpp"
+
+namespace tsd {
+
+// What a dense layer's epilogue does with the product row r, column n (v = acc + bias[n]):
+//   v *= C(mask_dist[r])               CFConv cutoff weight (schnet.py:92-99), forward of the filter MLP
+//   v *= act'(act_pre[r,n])            adjoint of the activation that FED this layer (dgrad only)
+//   v += R[r,n]                        residual / gradient accumulation (R may alias Y)
+//   Y[r,n] = v;  Y2[r,n] = act(v)      the activation that FOLLOWS this layer, written next to the
+//                                      pre-activation the backward pass needs
+// kinds: 0 swish, 1 shifted softplus, 2 ReLU, 3 softplus (as tsd_act_fwd)
+struct LinEpi {
+    const float* bias = nullptr;
+    const float* R = nullptr;
+    const float* mask_dist = nullptr;
+    float cutoff = 0.0f;
+    int smooth = 0;
+    const float* act_pre = nullptr;
+    int dact_kind = 0;
+    float* Y2 = nullptr;
+    int act_kind = 0;
+};
+
+__device__ __forceinline__ float act_apply(int kind, float v) {
+    return kind == 0 ? swishf(v) : kind == 1 ? sspf(v) : kind == 2 ? fmaxf(v, 0.0f) : sspf(v) + 0.69314718055994530942f;
+}
+__device__ __forceinline__ float act_deriv(int kind, float v) {
+    const float sg = __builtin_amdgcn_rcpf(1.0f + fast_exp(-v));  // sigmoid(v)
+    // d swish = sg * (1 + v * (1 - sg)) ; d ssp = d softplus = sg
+    return kind == 0 ? sg * (1.0f + v * (1.0f - sg)) : kind == 2 ? (v > 0.0f ? 1.0f : 0.0f) : sg;
+}
+__device__ __forceinline__ void epi_store(const LinEpi& e, float v, int row, int col, size_t o, float* Y) {
+    if (e.bias) v += e.bias[col];
+    if (e.mask_dist) v *= cutoff_weight(e.mask_dist[row], e.cutoff, e.smooth);
+    if (e.act_pre) v *= act_deriv(e.dact_kind, e.act_pre[o]);
+    if (e.R) v += e.R[o];
+    Y[o] = v;
+    if (e.Y2) e.Y2[o] = act_apply(e.act_kind, v);
+}
+
+int linear_fwd_impl(int rows, int in, int out, const float* X, const float* W, const float* Wp, const LinEpi& epi,
+                    float* Y, float* scratch, size_t scratch_floats, hipStream_t st);
+// flags: 1 = dX += (sets epi.R = dX), 2 = dW / db +=.  `epi` applies to dX (bias is ignored).
+int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, const float* Wp_t, const float* dY,
+                    float* dX, float* dW, float* db, int flags, LinEpi epi, float* scratch, size_t scratch_floats,
+                    hipStream_t st);
+size_t linear_scratch_floats(int in, int out);
+
+}  // namespace tsd

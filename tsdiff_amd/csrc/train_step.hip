@@ -12,16 +12,13 @@
 //   per block: conv.lin1.weight, conv.lin2.{weight,bias}, conv.nn.0.{weight,bias}, conv.nn.2.{weight,bias},
 //              lin.{weight,bias},
 //   grad_dist_mlp.layers.{0 [H,2H], 1 [H/2,H], 2 [1,H/2]}.{weight,bias}, edge_cat.{0 [H,2H], 2 [H,H]}.{weight,bias}
-#include "common.hpp"
+#include "train_internal.hpp"
 
 namespace tsd {
 
 // kernels_train.hip
-int linear_fwd_impl(int rows, int in, int out, const float* X, const float* W, const float* Wp, const float* b,
-                    const float* R, float* Y, float* scratch, size_t scratch_floats, hipStream_t st);
-int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, const float* Wp_t, const float* dY,
-                    float* dX, float* dW, float* db, int flags, float* scratch, size_t scratch_floats, hipStream_t st);
-size_t linear_scratch_floats(int in, int out);
+int launch_aggregate_bwd_filter(int H, int capacity_u, tsd_edges enc_u, const float* dagg, const float* x1, float* dWf,
+                                int masked, float cutoff, int smooth, hipStream_t st);
 // kernels_graph.hip
 int launch_geometry(const tsd_model_cfg&, int, int, int, const float*, const int32_t*, const int32_t*, const int32_t*,
                     const uint16_t*, tsd_geometry, hipStream_t);
@@ -275,17 +272,36 @@ struct Ctx {
     hipStream_t st;
     int N, H, L, F, Eu, Eo;
     bool packed(int in, int out) const { return (in == 128 || in == 256 || in == 512) && (out == 128 || out == 256 || out == 512); }
-    int lin(int rows, int in, int out, const float* X, size_t w_off, long b_off, const float* Rsd, float* Y) const {
+    // Y = X W^T + b (+ Rsd); act_kind >= 0: Y2 = act(Y) as well
+    int lin(int rows, int in, int out, const float* X, size_t w_off, long b_off, const float* Rsd, float* Y,
+            int act_kind = -1, float* Y2 = nullptr, const float* mask_dist = nullptr) const {
         const float* Wp = packed(in, out) ? w.pack_fwd + w_off : nullptr;
-        return linear_fwd_impl(rows, in, out, X, raw + w_off, Wp, b_off >= 0 ? raw + b_off : nullptr, Rsd, Y, w.scratch,
-                               w.scratch_floats, st);
+        LinEpi e;
+        e.bias = b_off >= 0 ? raw + b_off : nullptr;
+        e.R = Rsd;
+        if (act_kind >= 0) {
+            e.Y2 = Y2;
+            e.act_kind = act_kind;
+        }
+        if (mask_dist) {
+            e.mask_dist = mask_dist;
+            e.cutoff = c->conv_cutoff;
+            e.smooth = c->smooth_conv;
+        }
+        return linear_fwd_impl(rows, in, out, X, raw + w_off, Wp, e, Y, w.scratch, w.scratch_floats, st);
     }
-    // all parameter gradients accumulate (the flat gradient is zeroed once per backward)
+    // all parameter gradients accumulate (the flat gradient is zeroed once per backward).
+    // dact_kind >= 0: dX is multiplied by act'(act_pre) -- the adjoint of the activation that fed this layer
     int lin_bwd(int rows, int in, int out, const float* X, size_t w_off, long b_off, const float* dY, float* dX,
-                bool accumulate_dx) const {
+                bool accumulate_dx, int dact_kind = -1, const float* act_pre = nullptr) const {
         const float* Wpt = packed(out, in) ? w.pack_t + w_off : nullptr;
+        LinEpi e;
+        if (dact_kind >= 0) {
+            e.act_pre = act_pre;
+            e.dact_kind = dact_kind;
+        }
         return linear_bwd_impl(rows, in, out, X, raw + w_off, Wpt, dY, dX, grad + w_off, b_off >= 0 ? grad + b_off : nullptr,
-                               2 | (accumulate_dx ? 1 : 0), w.scratch, w.scratch_floats, st);
+                               2 | (accumulate_dx ? 1 : 0), e, w.scratch, w.scratch_floats, st);
     }
 };
 
@@ -341,14 +357,12 @@ int embed_fwd(const Ctx& x, const tsd_edges& lst, int E, const EmbedSave& s) {
     const int H = x.H;
     const int64_t n = (int64_t)E * H;
     // mlp(d) = Linear(1,H) -> swish -> Linear(H,H)                                        edge.py:50-52,66
-    TSD_TRY(x.lin(E, 1, H, lst.dist, x.R.emlp_w0, (long)x.R.emlp_b0, nullptr, s.l0));
-    TSD_TRY(tsd_act_fwd(0, n, s.l0, s.s0, (void*)x.st));
+    TSD_TRY(x.lin(E, 1, H, lst.dist, x.R.emlp_w0, (long)x.R.emlp_b0, nullptr, s.l0, 0, s.s0));
     TSD_TRY(x.lin(E, H, H, s.s0, x.R.emlp_w1, (long)x.R.emlp_b1, nullptr, s.e));
     hipLaunchKernelGGL(emb_mul2_fwd_kernel, dim3(nblk(n)), dim3(256), 0, x.st, E, H, s.e, x.raw + x.R.bond_emb,
                        lst.type_r, lst.type_p, s.c);
     // edge_cat = Linear(2H,H) -> swish -> Linear(H,H)                              condensenc.py:105-115,173-175
-    TSD_TRY(x.lin(E, 2 * H, H, s.c, x.R.ecat_w0, (long)x.R.ecat_b0, nullptr, s.c0));
-    TSD_TRY(tsd_act_fwd(0, n, s.c0, s.s1, (void*)x.st));
+    TSD_TRY(x.lin(E, 2 * H, H, s.c, x.R.ecat_w0, (long)x.R.ecat_b0, nullptr, s.c0, 0, s.s1));
     TSD_TRY(x.lin(E, H, H, s.s1, x.R.ecat_w1, (long)x.R.ecat_b1, nullptr, s.ea));
     TSD_LAUNCH_CHECK("embed_fwd");
     return TSD_OK;
@@ -358,19 +372,16 @@ int embed_fwd(const Ctx& x, const tsd_edges& lst, int E, const EmbedSave& s) {
 int embed_bwd(const Ctx& x, const tsd_edges& lst, int E, const EmbedSave& s, const float* d_ea) {
     if (E == 0) return TSD_OK;
     const int H = x.H;
-    const int64_t n = (int64_t)E * H;
     float* tA = x.w.eA;             // [E,2H]
     float* tB = x.w.eB;             // [E,2H]
-    TSD_TRY(x.lin_bwd(E, H, H, s.s1, x.R.ecat_w1, (long)x.R.ecat_b1, d_ea, tA, false));            // ds1
-    TSD_TRY(tsd_act_bwd(0, n, s.c0, tA, tB, (void*)x.st));                                         // dc0
+    TSD_TRY(x.lin_bwd(E, H, H, s.s1, x.R.ecat_w1, (long)x.R.ecat_b1, d_ea, tB, false, 0, s.c0));   // dc0
     TSD_TRY(x.lin_bwd(E, 2 * H, H, s.c, x.R.ecat_w0, (long)x.R.ecat_b0, tB, tA, false));           // dc [E,2H]
     const int chunks = (E + 255) / 256 < 512 ? (E + 255) / 256 : 512;
     hipLaunchKernelGGL(emb_mul2_bwd_kernel, dim3((H + 63) / 64, chunks), dim3(256), 0, x.st, E, H,
                        (E + chunks - 1) / chunks, s.e, x.raw + x.R.bond_emb, lst.type_r, lst.type_p, tA, tB,
                        x.grad + x.R.bond_emb);                                                      // de -> tB
-    TSD_TRY(x.lin_bwd(E, H, H, s.s0, x.R.emlp_w1, (long)x.R.emlp_b1, tB, tA, false));              // ds0
-    TSD_TRY(tsd_act_bwd(0, n, s.l0, tA, tB, (void*)x.st));                                         // dl0
-    TSD_TRY(x.lin_bwd(E, 1, H, lst.dist, x.R.emlp_w0, (long)x.R.emlp_b0, tB, nullptr, false));
+    TSD_TRY(x.lin_bwd(E, H, H, s.s0, x.R.emlp_w1, (long)x.R.emlp_b1, tB, tA, false, 0, s.l0));     // dl0
+    TSD_TRY(x.lin_bwd(E, 1, H, lst.dist, x.R.emlp_w0, (long)x.R.emlp_b0, tA, nullptr, false));
     TSD_LAUNCH_CHECK("embed_bwd");
     return TSD_OK;
 }
@@ -445,15 +456,13 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
         float *hl = w.h + l * NH, *hn = w.h + (l + 1) * NH;
         float *x1 = w.x1 + l * NH, *agg = w.agg + l * NH, *x2 = w.x2 + l * NH, *xs = w.xs + l * NH;
         if (Eu > 0) {
-            TSD_TRY(x.lin(Eu, H, H, w.emb_enc.ea, o + x.R.L_nn0_w, (long)(o + x.R.L_nn0_b), nullptr, f0));
-            TSD_TRY(tsd_act_fwd(1, (int64_t)EH, f0, fs, stream));
-            TSD_TRY(x.lin(Eu, H, H, fs, o + x.R.L_nn2_w, (long)(o + x.R.L_nn2_b), nullptr, Wf));
-            TSD_TRY(tsd_row_mask(Eu, H, g.enc_u.dist, cfg->conv_cutoff, cfg->smooth_conv, Wf, stream));
+            TSD_TRY(x.lin(Eu, H, H, w.emb_enc.ea, o + x.R.L_nn0_w, (long)(o + x.R.L_nn0_b), nullptr, f0, 1, fs));
+            TSD_TRY(x.lin(Eu, H, H, fs, o + x.R.L_nn2_w, (long)(o + x.R.L_nn2_b), nullptr, Wf, -1, nullptr,
+                          g.enc_u.dist));  // W = nn(edge_attr) * C
         }
         TSD_TRY(x.lin(N, H, H, hl, o + x.R.L_lin1_w, -1, nullptr, x1));
         TSD_TRY(tsd_cfconv_aggregate(H, N, g.enc.row_ptr, g.enc.dst, g.enc.umap, Wf, x1, agg, stream));
-        TSD_TRY(x.lin(N, H, H, agg, o + x.R.L_lin2_w, (long)(o + x.R.L_lin2_b), nullptr, x2));
-        TSD_TRY(tsd_act_fwd(1, (int64_t)NH, x2, xs, stream));
+        TSD_TRY(x.lin(N, H, H, agg, o + x.R.L_lin2_w, (long)(o + x.R.L_lin2_b), nullptr, x2, 1, xs));
         TSD_TRY(x.lin(N, H, H, xs, o + x.R.L_lin_w, (long)(o + x.R.L_lin_b), hl, hn));  // h + lin(ssp(.))
     }
     // pair MLP on [h_i * h_j , edge_attr_out]                                       common.py:226-229
@@ -463,10 +472,8 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
                            2 * H);
         hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.emb_out.ea, H,
                            w.hp + H, 2 * H);
-        TSD_TRY(x.lin(Eo, 2 * H, H, w.hp, x.R.out_w0, (long)x.R.out_b0, nullptr, w.g0));
-        TSD_TRY(tsd_act_fwd(0, (int64_t)Eo * H, w.g0, w.gs0, stream));
-        TSD_TRY(x.lin(Eo, H, H / 2, w.gs0, x.R.out_w1, (long)x.R.out_b1, nullptr, w.g1));
-        TSD_TRY(tsd_act_fwd(0, (int64_t)Eo * (H / 2), w.g1, w.gs1, stream));
+        TSD_TRY(x.lin(Eo, 2 * H, H, w.hp, x.R.out_w0, (long)x.R.out_b0, nullptr, w.g0, 0, w.gs0));
+        TSD_TRY(x.lin(Eo, H, H / 2, w.gs0, x.R.out_w1, (long)x.R.out_b1, nullptr, w.g1, 0, w.gs1));
         TSD_TRY(x.lin(Eo, H / 2, 1, w.gs1, x.R.out_w2, (long)x.R.out_b2, nullptr, w.s_u));
         hipLaunchKernelGGL(d_target_kernel, dim3(nblk(Eo)), dim3(256), 0, st, g.out_u, pos0, batch->node_graph, a_graph,
                            w.d_target);
@@ -500,16 +507,14 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
     if (Eo > 0) {
         float* ds = w.d_target;  // [Eo] (d_target itself is no longer needed)
         TSD_TRY(tsd_eq_und_bwd(Eo, g.out_u, pos, w.nA, ds, stream));
-        TSD_TRY(x.lin_bwd(Eo, H / 2, 1, w.gs1, x.R.out_w2, (long)x.R.out_b2, ds, w.eA, false));          // dgs1
-        TSD_TRY(tsd_act_bwd(0, (int64_t)Eo * (H / 2), w.g1, w.eA, w.eB, stream));                       // dg1
-        TSD_TRY(x.lin_bwd(Eo, H, H / 2, w.gs0, x.R.out_w1, (long)x.R.out_b1, w.eB, w.eA, false));        // dgs0
-        TSD_TRY(tsd_act_bwd(0, (int64_t)Eo * H, w.g0, w.eA, w.eB, stream));                             // dg0
-        TSD_TRY(x.lin_bwd(Eo, 2 * H, H, w.hp, x.R.out_w0, (long)x.R.out_b0, w.eB, w.eA, false));         // dhp [Eo,2H]
+        TSD_TRY(x.lin_bwd(Eo, H / 2, 1, w.gs1, x.R.out_w2, (long)x.R.out_b2, ds, w.eB, false, 0, w.g1));   // dg1
+        TSD_TRY(x.lin_bwd(Eo, H, H / 2, w.gs0, x.R.out_w1, (long)x.R.out_b1, w.eB, w.eA, false, 0, w.g0)); // dg0
+        TSD_TRY(x.lin_bwd(Eo, 2 * H, H, w.hp, x.R.out_w0, (long)x.R.out_b0, w.eA, w.eB, false));           // dhp [Eo,2H]
         // dp (left half) -> dh ; d edge_attr_out (right half) -> embedding of the out list
         // (embed_bwd uses eA / eB as temporaries: d edge_attr_out is parked in hp, which is free by now)
-        float* dp = w.eB;
-        hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.eA, 2 * H, dp, H);
-        hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.eA + H, 2 * H,
+        float* dp = w.eA;
+        hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.eB, 2 * H, dp, H);
+        hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.eB + H, 2 * H,
                            w.hp, H);
         TSD_TRY(tsd_pair_product_bwd(N, H, g.out, dp, w.h + (size_t)L * NH, w.dh, stream));
         TSD_TRY(embed_bwd(x, g.out_u, Eo, w.emb_out, w.hp));
@@ -521,18 +526,15 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
         float* hl = w.h + l * NH;
         float *x1 = w.x1 + l * NH, *agg = w.agg + l * NH, *x2 = w.x2 + l * NH, *xs = w.xs + l * NH;
         // h_{l+1} = h_l + lin(ssp(lin2(agg)))
-        TSD_TRY(x.lin_bwd(N, H, H, xs, o + x.R.L_lin_w, (long)(o + x.R.L_lin_b), w.dh, w.nA, false));    // dxs
-        TSD_TRY(tsd_act_bwd(1, (int64_t)NH, x2, w.nA, w.nB, stream));                                   // dx2
-        TSD_TRY(x.lin_bwd(N, H, H, agg, o + x.R.L_lin2_w, (long)(o + x.R.L_lin2_b), w.nB, w.nA, false)); // dagg
+        TSD_TRY(x.lin_bwd(N, H, H, xs, o + x.R.L_lin_w, (long)(o + x.R.L_lin_b), w.dh, w.nB, false, 1, x2)); // dx2
+        TSD_TRY(x.lin_bwd(N, H, H, agg, o + x.R.L_lin2_w, (long)(o + x.R.L_lin2_b), w.nB, w.nA, false));     // dagg
         // agg = aggregate(x1, Wf): symmetric edge set and filter => the adjoint w.r.t. x1 is the same gather of dagg
         TSD_TRY(tsd_cfconv_aggregate(H, N, g.enc.row_ptr, g.enc.dst, g.enc.umap, Wf, w.nA, w.nC, stream)); // dx1
         if (Eu > 0) {
             float* dWf = w.eA;
-            TSD_TRY(tsd_aggregate_bwd_filter(H, Eu, g.enc_u, w.nA, x1, dWf, stream));
-            TSD_TRY(tsd_row_mask(Eu, H, g.enc_u.dist, cfg->conv_cutoff, cfg->smooth_conv, dWf, stream));
-            TSD_TRY(x.lin_bwd(Eu, H, H, fs, o + x.R.L_nn2_w, (long)(o + x.R.L_nn2_b), dWf, w.eB, false)); // dfs
-            TSD_TRY(tsd_act_bwd(1, (int64_t)EH, f0, w.eB, w.eA, stream));                                // df0
-            TSD_TRY(x.lin_bwd(Eu, H, H, w.emb_enc.ea, o + x.R.L_nn0_w, (long)(o + x.R.L_nn0_b), w.eA, w.d_ea, true));
+            TSD_TRY(launch_aggregate_bwd_filter(H, Eu, g.enc_u, w.nA, x1, dWf, 1, cfg->conv_cutoff, cfg->smooth_conv, st));
+            TSD_TRY(x.lin_bwd(Eu, H, H, fs, o + x.R.L_nn2_w, (long)(o + x.R.L_nn2_b), dWf, w.eB, false, 1, f0)); // df0
+            TSD_TRY(x.lin_bwd(Eu, H, H, w.emb_enc.ea, o + x.R.L_nn0_w, (long)(o + x.R.L_nn0_b), w.eB, w.d_ea, true));
         }
         TSD_TRY(x.lin_bwd(N, H, H, hl, o + x.R.L_lin1_w, -1, w.nC, w.dh, true));  // dh += dx1 W_lin1 (residual keeps dh)
     }
@@ -541,9 +543,9 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
     hipLaunchKernelGGL(node_embed_bwd_kernel, dim3(nblk((int64_t)N * (H / 2))), dim3(256), 0, st, N, H / 2, atom_type, w.dh,
                        grad + x.R.atom_emb, w.nA, w.nB);
     TSD_TRY(linear_bwd_impl(N, F, H / 2, w.featR, raw + x.R.atom_feat, nullptr, w.nA, nullptr, grad + x.R.atom_feat,
-                            nullptr, 2, w.scratch, w.scratch_floats, st));
+                            nullptr, 2, LinEpi(), w.scratch, w.scratch_floats, st));
     TSD_TRY(linear_bwd_impl(N, F, H / 2, w.featP, raw + x.R.atom_feat, nullptr, w.nB, nullptr, grad + x.R.atom_feat,
-                            nullptr, 2, w.scratch, w.scratch_floats, st));
+                            nullptr, 2, LinEpi(), w.scratch, w.scratch_floats, st));
     TSD_LAUNCH_CHECK("train_backward");
     return TSD_OK;
 }

@@ -64,24 +64,32 @@ def dp_backward(model, loss_nodes, group=None):
     batch, so every rank back-propagates  sum(loss_r) / N_global  and the parameter gradients are summed
     with one all-reduce of the flat fp32 gradient (2.77 M floats = 11 MB for the shipped config; RCCL over
     xGMI on the GPUs, gloo in the CPU tests).  Afterwards `clip_grad_norm_` and the optimizer step see
-    exactly the single-process gradients on every rank.  Returns the global mean loss (python float)."""
+    exactly the single-process gradients on every rank.  Returns the global mean loss as a 0-dim device
+    tensor (no host sync anywhere in here: the host keeps enqueueing the optimizer step and the next batch
+    while the GPU is still in the backward pass; call `.item()` when a number is needed)."""
     distributed = dist.is_initialized() and dist.get_world_size(group) > 1
     stats = torch.stack([loss_nodes.detach().sum(), torch.tensor(float(loss_nodes.shape[0]),
                                                                   device=loss_nodes.device)])
     if distributed:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
-    n_global = float(stats[1].item())
-    (loss_nodes.sum() / n_global).backward()
+    (loss_nodes.sum() / stats[1]).backward()
     if distributed:
         params = [p for p in model.parameters() if p.requires_grad]
-        for p in params:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-        flat = torch.cat([p.grad.reshape(-1) for p in params])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        off = 0
-        for p in params:
-            n = p.numel()
-            p.grad.copy_(flat[off:off + n].view_as(p))
-            off += n
-    return float(stats[0].item()) / n_global
+        flat = getattr(model, "_flat_grad", None)
+        if flat is not None and all(p.grad is not None and p.grad.untyped_storage().data_ptr() ==
+                                    flat.untyped_storage().data_ptr() for p in params) and \
+                sum(p.numel() for p in params) == flat.numel():
+            # the fused training step hands out views of ONE flat gradient buffer: reduce it in place
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        else:
+            for p in params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            flat = torch.cat([p.grad.reshape(-1) for p in params])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            off = 0
+            for p in params:
+                n = p.numel()
+                p.grad.copy_(flat[off:off + n].view_as(p))
+                off += n
+    return stats[0] / stats[1]

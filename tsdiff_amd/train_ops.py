@@ -519,6 +519,7 @@ class FusedTrainLoss(torch.autograd.Function):
         check(lib.tsd_train_backward(C.byref(cfg), C.byref(b), ptr(ctx.raw), ptr(db.atom_type), ptr(ctx.pos),
                                      ptr(ctx.ws), ctx.ws.numel(), ctx.counts, ptr(dloss), ptr(grad), stream_ptr()))
         views = [g.view(s) for g, s in zip(grad.split(ctx.sizes), ctx.shapes)]  # views of ONE flat buffer
+        ctx.model._flat_grad = grad  # (distributed.dp_backward all-reduces it in place)
         return (None, None, None, None, None) + tuple(views)
 
 
