@@ -130,7 +130,7 @@ __device__ __forceinline__ float cutoff_weight(float d, float cutoff, int smooth
 // B is double-buffered in registers in chunks of PF k-blocks: while chunk c is multiplied (PF*4*RB*CB
 // MFMAs = 2048 cycles at RB=1, CB=2), chunk c+1 is in flight from L2 -- one k-block of look-ahead
 // (the first version) exposed the L2 latency every iteration (tools/mfma_probe.hip: 84 -> 93 TFLOP/s).
-template <int RB, int CB, int K>
+template <int RB, int CB, int K, int PF = 4, bool PIN = false>
 __device__ __forceinline__ void gemm_tile(const float* __restrict__ ldsA, int lda,
                                           const float* __restrict__ Bp, int nout, int col0,
                                           f32x16 (&acc)[RB][CB]) {
@@ -140,9 +140,8 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ ldsA, int ld
     const float* aptr = ldsA + l31 * lda + hi * 4;
     const f32x4* bptr = reinterpret_cast<const f32x4*>(Bp) + (size_t)hi * nout + col0 + l31;
     constexpr int KB = K / 8;
-    constexpr int PF = 4;
     constexpr int NC = KB / PF;
-    static_assert(KB % PF == 0, "K must be a multiple of 32");
+    static_assert(KB % PF == 0, "K must be a multiple of 8 * PF");
     f32x4 b0[PF][CB], b1[PF][CB];
     auto loadB = [&](f32x4 (&b)[PF][CB], int chunk) {
 #pragma unroll
@@ -167,12 +166,20 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ ldsA, int ld
                     for (int cb = 0; cb < CB; ++cb)
                         acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][rb][s], b[p][cb][s], acc[rb][cb], 0, 0, 0);
     };
+    // The machine scheduler sinks every load to just before its first use (one k-block of look-ahead).
+    // With >= 2 workgroups per CU the other waves cover that (measured: pinning the pipeline costs 10 % at
+    // configs[1] / configs[4] sizes); a launch with fewer workgroups than CUs is a pure latency chain and
+    // pins the chunked pipeline with scheduling barriers (PIN).
     loadB(b0, 0);
     for (int c = 0; c < NC; c += 2) {
         if (c + 1 < NC) loadB(b1, c + 1);
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
         compute(b0, c);
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
         if (c + 2 < NC) loadB(b0, c + 2);
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < NC) compute(b1, c + 1);
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
     }
 }
 

@@ -36,7 +36,10 @@ __global__ void pack_any_kernel(const float* __restrict__ M, float* __restrict__
 // Y[rows, nout] = A[rows, K] * Bp (+ bias) (+ R): 4 waves, each CB column blocks of 32; a workgroup owns
 // CB*128 columns starting at blockIdx.y * CB*128 (short problems are split over the columns to fill the chip).
 // R (nullable, may alias Y): residual / accumulation source with the layout of Y.
-template <int K, int CB>
+// PF: k-blocks per prefetch chunk of B (common.hpp::gemm_tile).  Short problems (fewer workgroups than CUs, one
+// column block per wave) are pure latency chains: they use PF = 16, i.e. at most four deep chunks in flight
+// two at a time, instead of sixteen shallow ones.
+template <int K, int CB, int PF>
 __global__ __launch_bounds__(256) void linear_mfma_kernel(int rows, int nout, const float* __restrict__ A,
                                                           const float* __restrict__ Bp, LinEpi epi, float* Y) {
     constexpr int LDA = K + 4;
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(int rows, int nout, co
     __syncthreads();
     f32x16 acc[1][CB];
     zero_acc(acc);
-    gemm_tile<1, CB, K>(smem, LDA, Bp, nout, col0, acc);
+    gemm_tile<1, CB, K, PF, (PF > 4)>(smem, LDA, Bp, nout, col0, acc);
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
         const int col = col0 + cb * 32 + l31;
@@ -70,13 +73,14 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(int rows, int nout, co
 template <int K, int CB>
 static int launch_linear_mfma(int rows, int nout, const float* A, const float* Bp, const LinEpi& epi, float* Y,
                               hipStream_t st) {
+    constexpr int PF = CB == 1 ? 16 : 4;
     const size_t lds = (size_t)32 * (K + 4) * 4;
     static bool done = false;
     if (!done && lds > 48 * 1024)
-        TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_mfma_kernel<K, CB>),
+        TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_mfma_kernel<K, CB, PF>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     done = true;
-    hipLaunchKernelGGL((linear_mfma_kernel<K, CB>), dim3((rows + 31) / 32, nout / (CB * 128)), dim3(256), lds, st, rows,
+    hipLaunchKernelGGL((linear_mfma_kernel<K, CB, PF>), dim3((rows + 31) / 32, nout / (CB * 128)), dim3(256), lds, st, rows,
                        nout, A, Bp, epi, Y);
     TSD_LAUNCH_CHECK("linear_mfma");
     return TSD_OK;
@@ -694,7 +698,7 @@ int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, c
     }
     bool db_done = false;
     if (dW) {  // dW = dY^T X
-        const int S = rows >= 4096 ? 64 : (rows >= 512 ? 16 : 4);  // row splits of the MFMA wgrad
+        const int S = rows >= 4096 ? 64 : (rows >= 1024 ? 32 : (rows >= 256 ? 16 : 4));  // row splits of the MFMA wgrad
         if (rows == 0) {
             if (!accW) TSD_HIP(hipMemsetAsync(dW, 0, (size_t)out * in * sizeof(float), st));
         } else if (scratch && scratch_floats >= off_part + (size_t)S * out * in && out % 128 == 0 && in % 128 == 0) {
