@@ -52,6 +52,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--combo-cols", type=int, default=0, choices=[0, 32, 64],
+                    help="A/B knob: output columns per wave of the per-block launch (0 = library default)")
+    ap.add_argument("--filter-tile", type=int, default=0, choices=[0, 32, 64],
+                    help="A/B knob: undirected pairs per workgroup of the CFConv filter role (0 = library default)")
     return ap.parse_args()
 
 
@@ -131,6 +135,10 @@ def main():
     from tsdiff_amd.utils import AttrDict
 
     lib = _lib.load()  # raises if the HIP extension is missing: no fallback
+    if args.filter_tile:
+        _lib.check(lib.tsd_set_filter_tile(args.filter_tile))
+    if args.combo_cols:
+        _lib.check(lib.tsd_set_combo_cols(args.combo_cols))
     cfg = synth.DEFAULT_MODEL_CONFIG
     models = []
     for m in range(args.models):

@@ -106,6 +106,9 @@ const char* tsd_version(void);
 /* Edge rows per workgroup tile of the filter role of tsd_interaction_block / tsd_score_forward:
  * 0 = default (32), or force 32 / 64 (process-wide; 64 measured slower at every size, kept as an A/B knob). */
 int tsd_set_filter_tile(int32_t rows);
+/* A/B knob of the same launch: output columns per wave, 0 = library default, 32 (H/32 waves per workgroup, one
+ * accumulator block per wave) or 64 (H/64 waves, two accumulator blocks per B fragment).  Bit-identical results. */
+int tsd_set_combo_cols(int32_t cols);
 const char* tsd_last_error(void);
 
 /* ---- weights ---------------------------------------------------------------------------

@@ -1,0 +1,6 @@
+P='import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], d["value"], d["roofline"]["frac"], d["roofline"]["avg_launch_us"])'
+python -m pytest tests -m gpu -q -x 2>&1 | tail -2
+python bench.py --steps 1000 --warmup 50 --no-cpu-baseline 2>&1 | tail -1 | python -c "$P"
+python bench.py --workload c5 --graphs 1024 --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "$P"
+python bench.py --models 8 --steps 200 --warmup 20 --no-cpu-baseline 2>&1 | tail -1 | python -c "$P"
+python bench.py --workload train --graphs 200 --steps 50 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200

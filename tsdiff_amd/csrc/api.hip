@@ -66,6 +66,7 @@ int launch_sampler_step(int, int, int, const int32_t*, const float*, const float
                         float*, float*, int32_t*, const int32_t*, hipStream_t);
 
 extern int g_filter_rows;
+extern int g_combo_cols;
 
 static int check_cfg(const tsd_model_cfg* c) {
     TSD_REQUIRE(c != nullptr, "cfg is null");
@@ -221,6 +222,12 @@ extern "C" {
 int tsd_set_filter_tile(int32_t rows) {
     TSD_REQUIRE(rows == 0 || rows == 32 || rows == 64, "filter tile rows must be 0 (auto), 32 or 64");
     g_filter_rows = rows;
+    return TSD_OK;
+}
+
+int tsd_set_combo_cols(int32_t cols) {
+    TSD_REQUIRE(cols == 0 || cols == 32 || cols == 64, "columns per wave must be 0 (auto), 32 or 64");
+    g_combo_cols = cols;
     return TSD_OK;
 }
 

@@ -51,11 +51,12 @@ struct ComboFilter {
 // bit-identical to a sequential scatter_add), then the three dense layers of tsd_node_update.
 // reference schnet.py:101-107 (message/aggregate), :103 (lin2), :123-127, :223-224
 // -------------------------------------------------------------------------------------------------
-template <int H>
+template <int H, int CBF>
 __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* smem) {
     constexpr int LDA = H + 4;
-    constexpr int NT = 2 * H;
-    constexpr int NW = H / 32;
+    constexpr int NT = 2 * H / CBF;
+    constexpr int NW = NT / 64;
+    constexpr int CB16 = 2 * CBF;  // 16-wide column blocks per wave
     constexpr int RPW = TN / NW;  // rows aggregated per wave
     constexpr int V = H / 64;     // channels per lane during aggregation
     constexpr int C4 = H / 4;
@@ -65,9 +66,9 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
     const int n0 = tile * TN;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, l15 = lane & 15;
-    const int col0 = wave * 32;
+    const int col0 = wave * 32 * CBF;
     const int nrows = min(TN, a.N - n0);
-    f32x4 acc[2];
+    f32x4 acc[CB16];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     if (a.mode == 0) {
@@ -150,11 +151,12 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
         }
         __syncthreads();
 
-        acc[0] = zero4; acc[1] = zero4;
-        gemm_tile16<2, H>(buf, LDA, a.lin2_w, H, col0, acc);
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) acc[cb] = zero4;
+        gemm_tile16<CB16, H>(buf, LDA, a.lin2_w, H, col0, acc);
         __syncthreads();
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
+        for (int cb = 0; cb < CB16; ++cb) {
             const int col = col0 + cb * 16 + l15;
             const float b = a.lin2_b[col];
 #pragma unroll
@@ -162,11 +164,12 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
         }
         __syncthreads();
 
-        acc[0] = zero4; acc[1] = zero4;
-        gemm_tile16<2, H>(buf, LDA, a.lin_w, H, col0, acc);
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) acc[cb] = zero4;
+        gemm_tile16<CB16, H>(buf, LDA, a.lin_w, H, col0, acc);
         __syncthreads();
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
+        for (int cb = 0; cb < CB16; ++cb) {
             const int col = col0 + cb * 16 + l15;
             const float b = a.lin_b[col];
 #pragma unroll
@@ -193,10 +196,11 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
         __syncthreads();
     }
 
-    acc[0] = zero4; acc[1] = zero4;
-    gemm_tile16<2, H>(buf, LDA, a.lin1_next_w, H, col0, acc);
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < CB16; ++cb) acc[cb] = zero4;
+    gemm_tile16<CB16, H>(buf, LDA, a.lin1_next_w, H, col0, acc);
+#pragma unroll
+    for (int cb = 0; cb < CB16; ++cb) {
         const int col = col0 + cb * 16 + l15;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -212,8 +216,9 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
 // -------------------------------------------------------------------------------------------------
 // RB = 1: tiles of 32 edges (the default); RB = 2: tiles of 64 edges (every B fragment fetched from L2 feeds
 // twice the MFMAs; faster in the 4-wave probe, slower here -- see launch_layer_combo).  Bit-identical rows.
-template <int H, int RB>
+template <int H, int RB, int CBF>
 __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, float* smem) {
+    static_assert(RB == 1 || CBF == 1, "the 64-edge layout has its own wave mapping");
     constexpr int TR = T * RB;
     const int g = f.g_begin + item;
     const int lrel = g / f.tiles_per_layer, tile = g - lrel * f.tiles_per_layer;
@@ -221,7 +226,7 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
     const float *nn0_w = Wb + f.o_nn0_w, *nn0_b = Wb + f.o_nn0_b, *nn2_w = Wb + f.o_nn2_w, *nn2_b = Wb + f.o_nn2_b;
     float* out = f.wf + (size_t)lrel * f.wf_layer_stride;
     constexpr int LDA = H + 4;
-    constexpr int NT = 2 * H;
+    constexpr int NT = 2 * H / CBF;
     constexpr int C4 = H / 4;
     float* buf = smem;
     float* s_c = smem + TR * LDA;
@@ -231,45 +236,91 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
     if (e0 >= E) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
-    const int col0 = (tid >> 6) * 32;
+    const int col0 = (tid >> 6) * 32 * CBF;
     const int nrows = min(TR, E - e0);
 
     if (tid < TR) s_c[tid] = tid < nrows ? cutoff_weight(f.e.dist[e0 + tid], f.conv_cutoff, f.smooth) : 0.0f;
-    for (int idx = tid; idx < TR * C4; idx += NT) {
-        const int r = idx / C4, c4 = idx % C4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < nrows) v = *reinterpret_cast<const f32x4*>(f.edge_attr + (size_t)(e0 + r) * H + c4 * 4);
-        *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = v;
+    {   // edge_attr tile -> LDS with every load of a thread in flight together (rows past the end clamped)
+        constexpr int NIT = TR * C4 / NT;
+        static_assert(TR * C4 % NT == 0, "tile / block mismatch");
+        f32x4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+            v[it] = *reinterpret_cast<const f32x4*>(f.edge_attr + (size_t)(e0 + min(r, nrows - 1)) * H + c4 * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = r < nrows ? v[it] : z;
+        }
     }
     __syncthreads();
 
-    f32x16 acc[RB][1];
+    if constexpr (RB == 2) {
+        // 64-edge tile as TWO row groups of H/64 waves; a wave owns 32 rows x 64 columns (two accumulators per
+        // B load: tools/mfma_probe2.hip measures 137 TFLOP/s for this loop against 97 for one accumulator)
+        constexpr int WPG = H / 64;                       // waves per row group
+        const int wave = tid >> 6;
+        const int grp = wave / WPG, gcol0 = (wave % WPG) * 64;
+        float* gbuf = buf + grp * 32 * LDA;
+        f32x16 acc[1][2];
+        zero_acc(acc);
+        gemm_tile<1, 2, H>(gbuf, LDA, nn0_w, H, gcol0, acc);
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int col = gcol0 + cb * 32 + l31;
+            const float b = nn0_b[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gbuf[acc_row(r, hi) * LDA + col] = sspf(acc[0][cb][r] + b);
+        }
+        __syncthreads();
+        zero_acc(acc);
+        gemm_tile<1, 2, H>(gbuf, LDA, nn2_w, H, gcol0, acc);
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int col = gcol0 + cb * 32 + l31;
+            const float b = nn2_b[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = acc_row(r, hi);
+                gbuf[row * LDA + col] = (acc[0][cb][r] + b) * s_c[grp * 32 + row];
+            }
+        }
+    } else {
+    f32x16 acc[RB][CBF];
     zero_acc(acc);
-    gemm_tile<RB, 1, H>(buf, LDA, nn0_w, H, col0, acc);
+    gemm_tile<RB, CBF, H>(buf, LDA, nn0_w, H, col0, acc);
     __syncthreads();
-    {
-        const int col = col0 + l31;
+#pragma unroll
+    for (int cb = 0; cb < CBF; ++cb) {
+        const int col = col0 + cb * 32 + l31;
         const float b = nn0_b[col];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) buf[(rb * 32 + acc_row(r, hi)) * LDA + col] = sspf(acc[rb][0][r] + b);
+            for (int r = 0; r < 16; ++r) buf[(rb * 32 + acc_row(r, hi)) * LDA + col] = sspf(acc[rb][cb][r] + b);
     }
     __syncthreads();
 
     zero_acc(acc);
-    gemm_tile<RB, 1, H>(buf, LDA, nn2_w, H, col0, acc);
+    gemm_tile<RB, CBF, H>(buf, LDA, nn2_w, H, col0, acc);
     __syncthreads();
-    {
-        const int col = col0 + l31;
+#pragma unroll
+    for (int cb = 0; cb < CBF; ++cb) {
+        const int col = col0 + cb * 32 + l31;
         const float b = nn2_b[col];
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rb * 32 + acc_row(r, hi);
-                buf[row * LDA + col] = (acc[rb][0][r] + b) * s_c[row];
+                buf[row * LDA + col] = (acc[rb][cb][r] + b) * s_c[row];
             }
+    }
     }
     __syncthreads();
     for (int idx = tid; idx < nrows * C4; idx += NT) {
@@ -283,9 +334,9 @@ struct ComboStride {  // per-checkpoint strides (blockIdx.y = checkpoint of the 
     size_t w, nh, ea, wf;
 };
 
-template <int H, int RB>
-__global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int node_tiles, ComboFilter f,
-                                                            ComboStride sd) {
+template <int H, int RB, int CBF>
+__global__ __launch_bounds__(2 * H / CBF) void layer_combo_kernel(ComboNode a, int node_tiles, ComboFilter f,
+                                                                  ComboStride sd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     {
         const size_t m = blockIdx.y;
@@ -297,9 +348,9 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
         f.edge_attr += m * sd.ea; f.wf += m * sd.wf;
     }
     if ((int)blockIdx.x < node_tiles)
-        node_role<H>(a, blockIdx.x, smem);
+        node_role<H, CBF>(a, blockIdx.x, smem);
     else
-        filter_role<H, RB>(f, blockIdx.x - node_tiles, smem);
+        filter_role<H, RB, CBF>(f, blockIdx.x - node_tiles, smem);
 }
 
 static inline size_t lds_combo(int H, int RB) {
@@ -309,6 +360,7 @@ static inline size_t lds_combo(int H, int RB) {
 }
 
 int g_filter_rows = 0;  // 0: automatic, 32 / 64: forced (tsd_set_filter_tile; tests and A/B runs)
+int g_combo_cols = 0;   // output columns per wave of the per-block launch: 0 automatic, 32 or 64 (tsd_set_combo_cols)
 
 int filter_tiles_per_layer(int capacity_u) {
     const int RBsel = g_filter_rows == 64 ? 2 : 1;
@@ -374,19 +426,22 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     const int grid = node_tiles + f.tiles;
     if (grid == 0) return TSD_OK;
     const size_t lds = lds_combo(c.hidden, RBsel);
+    const int cols = g_combo_cols == 64 ? 64 : 32;
     const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride};
-#define TSD_COMBO_RB(HH, RR)                                                                                  \
+#define TSD_COMBO_RB(HH, RR, CC)                                                                              \
     {                                                                                                         \
         static bool done = false;                                                                             \
         if (!done && lds > 48 * 1024)                                                                         \
-            TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_combo_kernel<HH, RR>),            \
+            TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_combo_kernel<HH, RR, CC>),        \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
         done = true;                                                                                          \
-        hipLaunchKernelGGL((layer_combo_kernel<HH, RR>), dim3(grid, M), dim3(2 * HH), lds, st, a, node_tiles, f, sd); \
+        hipLaunchKernelGGL((layer_combo_kernel<HH, RR, CC>), dim3(grid, M), dim3(2 * HH / CC), lds, st, a,    \
+                           node_tiles, f, sd);                                                                \
     }
 #define TSD_COMBO(HH)                                                                                         \
     {                                                                                                         \
-        if (RBsel == 2) TSD_COMBO_RB(HH, 2) else TSD_COMBO_RB(HH, 1)                                          \
+        if (RBsel == 2) TSD_COMBO_RB(HH, 2, 1) else if (cols == 64) TSD_COMBO_RB(HH, 1, 2)                    \
+        else TSD_COMBO_RB(HH, 1, 1)                                                                           \
     }
     switch (c.hidden) {
         case 64: TSD_COMBO(64) break;

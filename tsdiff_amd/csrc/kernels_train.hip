@@ -8,6 +8,8 @@
 //
 // All per-edge work runs on the UNDIRECTED lists (see tsd_geometry): a filter row Wf[u] / score s[u] is
 // used by both directed edges (i,j) and (j,i), so its gradient is the sum of both directions.
+#include <stdlib.h>
+
 #include "train_internal.hpp"
 
 namespace tsd {
@@ -39,21 +41,32 @@ __global__ void pack_any_kernel(const float* __restrict__ M, float* __restrict__
 // PF: k-blocks per prefetch chunk of B (common.hpp::gemm_tile).  Short problems (fewer workgroups than CUs, one
 // column block per wave) are pure latency chains: they use PF = 16, i.e. at most four deep chunks in flight
 // two at a time, instead of sixteen shallow ones.
-template <int K, int CB, int PF>
-__global__ __launch_bounds__(256) void linear_mfma_kernel(int rows, int nout, const float* __restrict__ A,
-                                                          const float* __restrict__ Bp, LinEpi epi, float* Y) {
+template <int K, int CB, int PF, int NW>
+__global__ __launch_bounds__(64 * NW) void linear_mfma_kernel(int rows, int nout, const float* __restrict__ A,
+                                                              const float* __restrict__ Bp, LinEpi epi, float* Y) {
     constexpr int LDA = K + 4;
     constexpr int K4 = K / 4;
+    constexpr int NT = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int r0 = blockIdx.x * 32;
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
-    const int col0 = blockIdx.y * (CB * 128) + (tid >> 6) * (CB * 32);
+    const int col0 = blockIdx.y * (CB * 32 * NW) + (tid >> 6) * (CB * 32);
     const int nrows = min(32, rows - r0);
-    for (int idx = tid; idx < 32 * K4; idx += 256) {
-        const int r = idx / K4, c4 = idx % K4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < nrows) v = *reinterpret_cast<const f32x4*>(A + (size_t)(r0 + r) * K + c4 * 4);
-        *reinterpret_cast<f32x4*>(smem + r * LDA + c4 * 4) = v;
+    {   // A tile -> LDS: all loads of a thread in flight together (a guarded load per iteration makes the
+        // compiler wait for each one: 8 serial HBM round trips per workgroup); rows past the end are clamped
+        constexpr int NIT = 32 * K4 / NT;
+        f32x4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / K4, c4 = idx % K4;
+            v[it] = *reinterpret_cast<const f32x4*>(A + (size_t)(r0 + min(r, nrows - 1)) * K + c4 * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / K4, c4 = idx % K4;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(smem + r * LDA + c4 * 4) = r < nrows ? v[it] : z;
+        }
     }
     __syncthreads();
     f32x16 acc[1][CB];
@@ -70,31 +83,49 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(int rows, int nout, co
     }
 }
 
-template <int K, int CB>
+template <int K, int CB, int NW, int PF>
 static int launch_linear_mfma(int rows, int nout, const float* A, const float* Bp, const LinEpi& epi, float* Y,
                               hipStream_t st) {
-    constexpr int PF = CB == 1 ? 16 : 4;
     const size_t lds = (size_t)32 * (K + 4) * 4;
     static bool done = false;
     if (!done && lds > 48 * 1024)
-        TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_mfma_kernel<K, CB, PF>),
+        TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_mfma_kernel<K, CB, PF, NW>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     done = true;
-    hipLaunchKernelGGL((linear_mfma_kernel<K, CB, PF>), dim3((rows + 31) / 32, nout / (CB * 128)), dim3(256), lds, st, rows,
-                       nout, A, Bp, epi, Y);
+    hipLaunchKernelGGL((linear_mfma_kernel<K, CB, PF, NW>), dim3((rows + 31) / 32, nout / (CB * 32 * NW)),
+                       dim3(64 * NW), lds, st, rows, nout, A, Bp, epi, Y);
     TSD_LAUNCH_CHECK("linear_mfma");
     return TSD_OK;
 }
 
 static bool mfma_shape(int K, int NOUT) { return (K == 128 || K == 256 || K == 512) && (NOUT == 128 || NOUT == 256 || NOUT == 512); }
 
+int g_linear_layout = 0;  // A/B knob (env TSDIFF_LINEAR_LAYOUT): 0 = 8 waves x 32 columns, 1 = 4 waves x 64 columns
+
 static int dispatch_linear_mfma(int rows, int K, int NOUT, const float* A, const float* Bp, const LinEpi& epi, float* Y,
                                 hipStream_t st) {
-    // fewer than one workgroup per CU with full-width tiles: split the columns over grid.y instead
-    const int CBsel = (rows + 31) / 32 >= 256 ? NOUT / 128 : 1;
-#define TSD_LM(KK, CC) if (K == KK && CBsel == CC) return launch_linear_mfma<KK, CC>(rows, NOUT, A, Bp, epi, Y, st);
-    TSD_LM(128, 1) TSD_LM(128, 2) TSD_LM(128, 4) TSD_LM(256, 1) TSD_LM(256, 2) TSD_LM(256, 4)
-    TSD_LM(512, 1) TSD_LM(512, 2) TSD_LM(512, 4)
+    static int init = 0;
+    if (!init) {
+        const char* e = getenv("TSDIFF_LINEAR_LAYOUT");
+        if (e) g_linear_layout = atoi(e);
+        init = 1;
+    }
+    // fewer than one workgroup per CU with full-width tiles: 4 waves x 32 columns, the columns split over
+    // grid.y, deep pinned prefetch (a latency chain)
+    const bool small = (rows + 31) / 32 < 256;
+#define TSD_LM(KK)                                                                                              \
+    if (K == KK) {                                                                                              \
+        if (small) return launch_linear_mfma<KK, 1, 4, 16>(rows, NOUT, A, Bp, epi, Y, st);                      \
+        if (g_linear_layout == 1) {                                                                             \
+            if (NOUT == 128) return launch_linear_mfma<KK, 1, 4, 4>(rows, NOUT, A, Bp, epi, Y, st);             \
+            if (NOUT == 256) return launch_linear_mfma<KK, 2, 4, 4>(rows, NOUT, A, Bp, epi, Y, st);             \
+            return launch_linear_mfma<KK, 4, 4, 4>(rows, NOUT, A, Bp, epi, Y, st);                              \
+        }                                                                                                       \
+        if (NOUT == 128) return launch_linear_mfma<KK, 1, 4, 4>(rows, NOUT, A, Bp, epi, Y, st);                 \
+        if (NOUT == 256) return launch_linear_mfma<KK, 1, 8, 4>(rows, NOUT, A, Bp, epi, Y, st);                 \
+        return launch_linear_mfma<KK, 2, 8, 4>(rows, NOUT, A, Bp, epi, Y, st);                                  \
+    }
+    TSD_LM(128) TSD_LM(256) TSD_LM(512)
 #undef TSD_LM
     set_error("internal: no MFMA instance for K=%d N=%d", K, NOUT);
     return TSD_ERR_INVALID;
