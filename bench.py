@@ -248,7 +248,9 @@ def main():
     if args.workload == "c2":
         try:  # HBM-side bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_summary.py)
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                traffic = round(json.load(fh)["kernels"]["layer_combo_kernel<256>"]["hbm_bytes_per_launch"])
+                kern = json.load(fh)["kernels"]
+                key = [k for k in kern if k.startswith("layer_combo_kernel<256")][0]  # template tail varies
+                traffic = round(kern[key]["hbm_bytes_per_launch"])
         except Exception:
             traffic = None
     roofline = {"kernel": "layer_combo_kernel<256>", "bound": "mfma", "achieved": round(ach, 2),
