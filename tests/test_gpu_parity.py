@@ -218,6 +218,60 @@ def test_forward_vs_oracle_seeded_batch(dev):
     assert torch.equal(S, S.t())
 
 
+def test_random_topologies_edge_lists_bit_exact(dev):
+    """index work is bit exact: 24 random batches -- ring-rich and multi-fragment bond graphs, R-only / P-only
+    bonds, 2..60 atoms, edge orders 1..6, cutoffs from 'no radius edge' to 'all pairs' -- the device topology +
+    geometry kernels against the pinned oracle's extend_graph (edge_index, type_r, type_p, both orders)"""
+    import ctypes as C
+    from oracle import tsdiff_oracle as O
+    from tsdiff_amd import _lib, engine, synth
+    rng = np.random.default_rng(1234)
+    for trial in range(24):
+        G = int(rng.integers(1, 7))
+        nn = rng.integers(2, 61, size=G)
+        off = np.concatenate([[0], np.cumsum(nn)])
+        bi, bt = [], []
+        for g, n in enumerate(nn):
+            m = int(rng.integers(0, 3 * n))  # 0 bonds (all fragments) .. ring rich
+            seen = set()
+            for _ in range(m):
+                i, j = (int(v) for v in rng.integers(0, n, size=2))
+                if i == j or (min(i, j), max(i, j)) in seen:
+                    continue
+                seen.add((min(i, j), max(i, j)))
+                r, p = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+                if r == 0 and p == 0:
+                    r = 1
+                t = r * 22 + p
+                bi += [(off[g] + i, off[g] + j), (off[g] + j, off[g] + i)]
+                bt += [t, t]
+        order = np.lexsort((np.array([b[1] for b in bi], dtype=np.int64), np.array([b[0] for b in bi], dtype=np.int64))) \
+            if bi else np.zeros(0, np.int64)
+        bond_index = (np.array(bi, dtype=np.int64).reshape(-1, 2)[order].T if bi else np.zeros((2, 0), np.int64))
+        bond_type = np.array(bt, dtype=np.int64)[order] if bi else np.zeros(0, np.int64)
+        N = int(off[-1])
+        pos = (rng.standard_normal((N, 3)) * rng.choice([0.5, 3.0, 8.0])).astype(np.float32)
+        e_ord, p_ord = int(rng.integers(1, 7)), int(rng.integers(1, 7))
+        cutoff = float(rng.choice([0.0, 2.5, 10.0, 100.0]))
+        cfg = dict(synth.small_model_config())
+        cfg.update(edge_order=e_ord, pred_edge_order=p_ord, edge_cutoff=cutoff)
+        mc = engine.make_cfg(cfg)
+        at = torch.ones(N, dtype=torch.int64, device=dev)
+        feat = torch.zeros(N, 25, dtype=torch.int64, device=dev)
+        batch = torch.from_numpy(np.repeat(np.arange(G), nn)).to(dev)
+        db = engine.DeviceBatch(mc, at, feat, feat, torch.from_numpy(bond_index).to(dev),
+                                torch.from_numpy(bond_type).to(dev), batch)
+        db.geometry(torch.from_numpy(pos).to(dev))
+        for which, o in (("enc", e_ord), ("out", p_ord)):
+            ei, el, tr, tp = db.edges_to_torch(which)
+            o_ei, o_tr, o_tp = O.extend_graph(torch.from_numpy(pos), bond_index, bond_type, nn, o, cutoff)
+            tag = f"trial {trial} {which} order {o} cutoff {cutoff}"
+            assert torch.equal(ei.cpu(), o_ei), tag
+            assert torch.equal(tr.cpu(), o_tr) and torch.equal(tp.cpu(), o_tp), tag
+            d_ref = (torch.from_numpy(pos)[o_ei[0]] - torch.from_numpy(pos)[o_ei[1]]).norm(dim=-1)
+            assert_close(el.view(-1).cpu().numpy(), d_ref.numpy(), 1e-6, tag + " edge_length")
+
+
 def test_ensemble_forward_vs_golden(dev):
     from tsdiff_amd.sampler import EnsembleSampler
     d, meta = load_golden("ens_synth_b6_small")
