@@ -387,9 +387,10 @@ def test_training_loss_and_gradients_vs_golden(name, dev):
 def test_fused_training_step_equals_op_by_op(dev, monkeypatch):
     """csrc/train_step.hip (forward + loss + backward sequenced in C++, one autograd node) against the op-by-op
     autograd form of the same kernels: loss and EVERY parameter gradient, on a batch with > 4096 undirected
-    edges (all MFMA paths) and on a small-hidden model (all VALU paths)"""
+    edges (all MFMA paths), on a small-hidden model (all VALU paths) and at hidden 128 (mixed)"""
     from tsdiff_amd import synth
-    for cfg, nG in ((synth.DEFAULT_MODEL_CONFIG, 24), (synth.small_model_config(), 5)):
+    for cfg, nG in ((synth.DEFAULT_MODEL_CONFIG, 24), (synth.small_model_config(), 5),
+                    (synth.small_model_config(128, 3), 30)):
         b = synth.wb97xd3_like_batch(nG, seed=3)
         g = to_dev(batch_inputs({"in_" + k: v for k, v in b.items() if isinstance(v, np.ndarray)}), dev)
         g["pos"] = (g["pos"] * 1.5).contiguous()

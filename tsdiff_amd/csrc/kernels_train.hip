@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int64_t nW, int nB, i
 // stage 1: grid (out/64, CS_CHUNKS) -> part[chunk][o*in + i]; stage 2: sums the chunks in order.
 // The out == 1 case is the same problem with the roles of dY and X swapped.
 constexpr int WS_MAX_IN = 32;
+template <int MAXIN>  // 1 (the Linear(1,H) / Linear(H/2,1) layers: no wasted predicated lanes) or WS_MAX_IN
 __global__ __launch_bounds__(256) void wgrad_small_kernel(int rows, int in, int out, const float* __restrict__ dY,
                                                           const float* __restrict__ X, float* __restrict__ part) {
     __shared__ float sm[4][64];
@@ -280,19 +281,19 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(int rows, int in, int 
     const int o = blockIdx.x * 64 + lane;
     const int per = (rows + 63) / 64;
     const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
-    float acc[WS_MAX_IN];
+    float acc[MAXIN];
 #pragma unroll
-    for (int i = 0; i < WS_MAX_IN; ++i) acc[i] = 0.0f;
+    for (int i = 0; i < MAXIN; ++i) acc[i] = 0.0f;
     if (o < out)
         for (int r = r0 + w; r < r1; r += 4) {
             const float g = dY[(size_t)r * out + o];
             const float* xr = X + (size_t)r * in;
 #pragma unroll
-            for (int i = 0; i < WS_MAX_IN; ++i)
+            for (int i = 0; i < MAXIN; ++i)
                 if (i < in) acc[i] = fmaf(g, xr[i], acc[i]);
         }
 #pragma unroll
-    for (int i = 0; i < WS_MAX_IN; ++i) {
+    for (int i = 0; i < MAXIN; ++i) {
         if (i < in) {  // uniform
             __syncthreads();
             sm[w][lane] = acc[i];
@@ -749,8 +750,12 @@ int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, c
             const bool swap = in > WS_MAX_IN;
             const int o2 = swap ? in : out, i2 = swap ? 1 : in;
             float* part = scratch + off_part;
-            hipLaunchKernelGGL(wgrad_small_kernel, dim3((o2 + 63) / 64, 64), dim3(256), 0, st, rows, i2, o2,
-                               swap ? X : dY, swap ? dY : X, part);
+            if (i2 == 1)
+                hipLaunchKernelGGL(wgrad_small_kernel<1>, dim3((o2 + 63) / 64, 64), dim3(256), 0, st, rows, i2, o2,
+                                   swap ? X : dY, swap ? dY : X, part);
+            else
+                hipLaunchKernelGGL(wgrad_small_kernel<WS_MAX_IN>, dim3((o2 + 63) / 64, 64), dim3(256), 0, st, rows, i2,
+                                   o2, swap ? X : dY, swap ? dY : X, part);
             const int64_t n = (int64_t)o2 * i2;
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, n, 0, 64, part,
                                (const float*)nullptr, dW, (float*)nullptr, accW);
