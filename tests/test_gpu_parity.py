@@ -409,6 +409,16 @@ def test_fused_training_step_equals_op_by_op(dev, monkeypatch):
             res[mode] = (loss.detach().cpu().numpy(),
                          {k: p.grad.cpu().numpy() for k, p in model.named_parameters() if p.grad is not None})
         assert_close(res["fused"][0], res["ops"][0], 2e-6, "loss fused vs op-by-op")
+        # the fused step has no atomics: a second evaluation gives bit-identical gradients
+        monkeypatch.setenv("TSDIFF_TRAIN", "fused")
+        model = make_model(cfg, 1, dev)
+        model.train()
+        loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
+                              g["batch"], g["num_nodes_per_graph"], G, _time_step=ts, _pos_noise=noise)
+        loss.mean().backward()
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                assert np.array_equal(p.grad.cpu().numpy(), res["fused"][1][k]), f"grad {k} not reproducible"
         assert set(res["fused"][1]) == set(res["ops"][1])
         assert len(res["fused"][1]) >= 30
         for k, ref in res["ops"][1].items():

@@ -134,6 +134,7 @@ Work carve(const tsd_model_cfg& c, int N, size_t Eu, size_t Eo, float* base) {
     w.pack_fwd = take(R.total);
     w.pack_t = take(R.total);
     w.scratch_floats = linear_scratch_floats((int)(2 * H), (int)H);
+    if (w.scratch_floats < (size_t)512 * 32 * H) w.scratch_floats = (size_t)512 * 32 * H;  // embedding-gradient partials
     w.scratch = take(w.scratch_floats);
     w.eA = take(Em * 2 * H);
     w.eB = take(Em * 2 * H);
@@ -175,17 +176,37 @@ __global__ void node_embed_raw_kernel(int N, int Hh, int F, const float* __restr
     z[(size_t)i * 2 * Hh + c] = atom_emb[(size_t)atom[i] * Hh + c] + a;
     z[(size_t)i * 2 * Hh + Hh + c] = b - a;
 }
-// dz -> d atom_emb (scatter), d(Wf r) = dz_lo - dz_hi, d(Wf p) = dz_hi
-__global__ void node_embed_bwd_kernel(int N, int Hh, const int64_t* __restrict__ atom, const float* __restrict__ dz,
-                                      float* __restrict__ d_atom_emb, float* __restrict__ dfr,
+// dz -> d(Wf r) = dz_lo - dz_hi, d(Wf p) = dz_hi
+__global__ void node_embed_bwd_kernel(int N, int Hh, const float* __restrict__ dz, float* __restrict__ dfr,
                                       float* __restrict__ dfp) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)N * Hh) return;
     const int i = (int)(t / Hh), c = (int)(t % Hh);
     const float lo = dz[(size_t)i * 2 * Hh + c], hi = dz[(size_t)i * 2 * Hh + Hh + c];
-    atomicAdd(d_atom_emb + (size_t)atom[i] * Hh + c, lo);
     dfr[t] = lo - hi;
     dfp[t] = hi;
+}
+// d atom_emb[a, c] = sum over the nodes with atom type a of dz[i, c], in node order, without atomics:
+// grid (100 embedding rows, node chunks); partial [chunk][100][Hh], summed in chunk order by the second kernel.
+constexpr int AE_CHUNKS = 16;
+__global__ void atom_emb_grad_kernel(int N, int Hh, const int64_t* __restrict__ atom, const float* __restrict__ dz,
+                                     float* __restrict__ part) {
+    const int a = blockIdx.x, chunk = blockIdx.y;
+    const int per = (N + AE_CHUNKS - 1) / AE_CHUNKS;
+    const int i0 = chunk * per, i1 = min(N, i0 + per);
+    for (int c = threadIdx.x; c < Hh; c += blockDim.x) {
+        float s = 0.0f;
+        for (int i = i0; i < i1; ++i)
+            if (atom[i] == a) s += dz[(size_t)i * 2 * Hh + c];
+        part[((size_t)chunk * 100 + a) * Hh + c] = s;
+    }
+}
+__global__ void atom_emb_grad_reduce_kernel(int n, const float* __restrict__ part, float* __restrict__ g) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float s = 0.0f;
+    for (int k = 0; k < AE_CHUNKS; ++k) s += part[(size_t)k * n + t];
+    g[t] += s;
 }
 // c[r] = [e[r] * emb[tr[r]] , e[r] * emb[tp[r]]]                               condensenc.py:169-172
 __global__ void emb_mul2_fwd_kernel(int rows, int H, const float* __restrict__ e, const float* __restrict__ emb,
@@ -198,36 +219,48 @@ __global__ void emb_mul2_fwd_kernel(int rows, int H, const float* __restrict__ e
     c[(size_t)r * 2 * H + k] = v * emb[(size_t)tr[r] * H + k];
     c[(size_t)r * 2 * H + H + k] = v * emb[(size_t)tp[r] * H + k];
 }
-// de = dc_lo * emb[tr] + dc_hi * emb[tp];  demb[tr] += dc_lo * e, demb[tp] += dc_hi * e  (LDS pre-reduction
-// per workgroup as in emb_mul_bwd_kernel: ~25 distinct types)
+// de = dc_lo * emb[tr] + dc_hi * emb[tp];  d emb[t] = sum of dc_lo * e over the rows with tr == t plus dc_hi * e over
+// those with tp == t.  Deterministic: every wave owns a private [ET][64] accumulator in LDS and walks its rows in
+// order, the four waves are combined in a fixed order into partial[chunk][ET][H], a second kernel sums the
+// chunks in order.  ET = 32 edge types: bond 1..21, 22 + hop - 1 for hop <= 7 (tsd_model_cfg orders are <= 7).
+constexpr int ET = 32;
 __global__ __launch_bounds__(256) void emb_mul2_bwd_kernel(int rows, int H, int rows_per_wg,
                                                            const float* __restrict__ e, const float* __restrict__ emb,
                                                            const uint8_t* __restrict__ tr,
                                                            const uint8_t* __restrict__ tp,
                                                            const float* __restrict__ dc, float* __restrict__ de,
-                                                           float* __restrict__ demb) {
-    __shared__ float acc[100][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+                                                           float* __restrict__ part) {
+    __shared__ float acc[4][ET][64];
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 64 + lane;
     const int w = threadIdx.x >> 6;
-    for (int t = threadIdx.x; t < 100 * 64; t += 256) acc[t / 64][t % 64] = 0.0f;
+    for (int t = threadIdx.x; t < 4 * ET * 64; t += 256) (&acc[0][0][0])[t] = 0.0f;
     __syncthreads();
     const int r0 = blockIdx.y * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
     if (c < H) {
         for (int r = r0 + w; r < r1; r += 4) {
-            const int a = min((int)tr[r], 99), b = min((int)tp[r], 99);
+            const int a = min((int)tr[r], ET - 1), b = min((int)tp[r], ET - 1);
             const float glo = dc[(size_t)r * 2 * H + c], ghi = dc[(size_t)r * 2 * H + H + c];
             const float ev = e[(size_t)r * H + c];
             de[(size_t)r * H + c] = glo * emb[(size_t)a * H + c] + ghi * emb[(size_t)b * H + c];
-            atomicAdd(&acc[a][threadIdx.x & 63], glo * ev);
-            atomicAdd(&acc[b][threadIdx.x & 63], ghi * ev);
+            acc[w][a][lane] += glo * ev;  // private to (wave, lane): plain read-modify-write
+            acc[w][b][lane] += ghi * ev;
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < 100 * 64; t += 256) {
-        const int ty = t / 64, cc = blockIdx.x * 64 + (t % 64);
-        const float v = acc[ty][t % 64];
-        if (v != 0.0f && cc < H) atomicAdd(demb + (size_t)ty * H + cc, v);
+    for (int t = threadIdx.x; t < ET * 64; t += 256) {
+        const int ty = t / 64, l = t % 64, cc = blockIdx.x * 64 + l;
+        if (cc < H)
+            part[((size_t)blockIdx.y * ET + ty) * H + cc] = (acc[0][ty][l] + acc[1][ty][l]) + (acc[2][ty][l] + acc[3][ty][l]);
     }
+}
+__global__ void emb_grad_reduce_kernel(int chunks, int n /* ET * H */, const float* __restrict__ part,
+                                       float* __restrict__ demb) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    float s = 0.0f;
+    for (int k = 0; k < chunks; ++k) s += part[(size_t)k * n + t];
+    demb[t] += s;
 }
 __global__ void copy2d_kernel(int64_t rows, int cols, const float* __restrict__ src, int lds_, float* __restrict__ dst,
                               int ldd) {
@@ -379,7 +412,9 @@ int embed_bwd(const Ctx& x, const tsd_edges& lst, int E, const EmbedSave& s, con
     const int chunks = (E + 255) / 256 < 512 ? (E + 255) / 256 : 512;
     hipLaunchKernelGGL(emb_mul2_bwd_kernel, dim3((H + 63) / 64, chunks), dim3(256), 0, x.st, E, H,
                        (E + chunks - 1) / chunks, s.e, x.raw + x.R.bond_emb, lst.type_r, lst.type_p, tA, tB,
-                       x.grad + x.R.bond_emb);                                                      // de -> tB
+                       x.w.scratch);                                                                // de -> tB
+    hipLaunchKernelGGL(emb_grad_reduce_kernel, dim3(nblk(ET * H)), dim3(256), 0, x.st, chunks, ET * H, x.w.scratch,
+                       x.grad + x.R.bond_emb);  // rows [0, ET) of the [100, H] table
     TSD_TRY(x.lin_bwd(E, H, H, s.s0, x.R.emlp_w1, (long)x.R.emlp_b1, tB, tA, false, 0, s.l0));     // dl0
     TSD_TRY(x.lin_bwd(E, 1, H, lst.dist, x.R.emlp_w0, (long)x.R.emlp_b0, tA, nullptr, false));
     TSD_LAUNCH_CHECK("embed_bwd");
@@ -540,8 +575,12 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
     }
     if (Eu > 0) TSD_TRY(embed_bwd(x, g.enc_u, Eu, w.emb_enc, w.d_ea));
     // node embedding: dz = dh
-    hipLaunchKernelGGL(node_embed_bwd_kernel, dim3(nblk((int64_t)N * (H / 2))), dim3(256), 0, st, N, H / 2, atom_type, w.dh,
-                       grad + x.R.atom_emb, w.nA, w.nB);
+    hipLaunchKernelGGL(node_embed_bwd_kernel, dim3(nblk((int64_t)N * (H / 2))), dim3(256), 0, st, N, H / 2, w.dh, w.nA,
+                       w.nB);
+    hipLaunchKernelGGL(atom_emb_grad_kernel, dim3(100, AE_CHUNKS), dim3(H / 2 < 256 ? H / 2 : 256), 0, st, N, H / 2,
+                       atom_type, w.dh, w.scratch);
+    hipLaunchKernelGGL(atom_emb_grad_reduce_kernel, dim3(nblk(100 * (H / 2))), dim3(256), 0, st, 100 * (H / 2), w.scratch,
+                       grad + x.R.atom_emb);
     TSD_TRY(linear_bwd_impl(N, F, H / 2, w.featR, raw + x.R.atom_feat, nullptr, w.nA, nullptr, grad + x.R.atom_feat,
                             nullptr, 2, LinEpi(), w.scratch, w.scratch_floats, st));
     TSD_TRY(linear_bwd_impl(N, F, H / 2, w.featP, raw + x.R.atom_feat, nullptr, w.nB, nullptr, grad + x.R.atom_feat,
