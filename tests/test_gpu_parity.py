@@ -272,6 +272,48 @@ def test_random_topologies_edge_lists_bit_exact(dev):
             assert_close(el.view(-1).cpu().numpy(), d_ref.numpy(), 1e-6, tag + " edge_length")
 
 
+def test_batch_cache_follows_the_input_tensors(dev):
+    """the per-model DeviceBatch cache is keyed on tensor identity + version: overwriting the inputs in place with
+    another reaction of the same shapes, or passing fresh tensors, must rebuild the topology (no stale reuse)"""
+    from oracle import tsdiff_oracle as O
+    from tsdiff_amd import synth
+    cfg = synth.small_model_config()
+    model = make_model(cfg, 2, dev)
+    sd = O.to_torch_state(synth.synth_state_dict(cfg, 2))
+    rng = np.random.default_rng(0)
+    n = 9
+    def chain(perm):  # a 9-atom chain whose bonds follow `perm`; same tensor shapes for every permutation
+        bi = []
+        for a, b_ in zip(perm[:-1], perm[1:]):
+            bi += [(a, b_), (b_, a)]
+        bi.sort()
+        bond_index = np.array(bi, dtype=np.int64).T
+        return bond_index, np.full(bond_index.shape[1], 1 * 22 + 1, dtype=np.int64)
+    feats = np.zeros((n, 25), dtype=np.int64)
+    pos = (rng.standard_normal((n, 3)) * 6.0).astype(np.float32)  # spread: hop-only and radius-only pairs differ
+    base = {"atom_type": np.full(n, 6, dtype=np.int64), "r_feat": feats, "p_feat": feats, "pos": pos,
+            "batch": np.zeros(n, dtype=np.int64)}
+    biA, btA = chain(list(range(n)))
+    biB, btB = chain([0, 5, 2, 7, 4, 1, 6, 3, 8])
+    g = {k: torch.from_numpy(v).to(dev) for k, v in base.items()}
+    g["bond_index"], g["bond_type"], g["num_graphs"] = torch.from_numpy(biA).to(dev), torch.from_numpy(btA).to(dev), 1
+    def ref(bi, bt):
+        return O.forward(sd, cfg, torch.from_numpy(base["atom_type"]), torch.from_numpy(feats), torch.from_numpy(feats),
+                         torch.from_numpy(pos), torch.from_numpy(bi), torch.from_numpy(bt), np.array([n]))
+    for bi, bt in ((biA, btA), (biB, btB), (biA, btA)):
+        g["bond_index"].copy_(torch.from_numpy(bi))  # same storage, new content: version bump
+        g["bond_type"].copy_(torch.from_numpy(bt))
+        inv, ei, _ = run_forward(model, g, dev)
+        o_inv, o_ei, _ = ref(bi, bt)
+        assert torch.equal(ei.cpu(), o_ei)
+        assert_close(inv.cpu().numpy(), o_inv.numpy(), 2e-5, "edge_inv after an in-place input change")
+    g2 = dict(g)
+    g2["bond_index"], g2["bond_type"] = torch.from_numpy(biB).to(dev), torch.from_numpy(btB).to(dev)  # fresh tensors
+    inv, ei, _ = run_forward(model, g2, dev)
+    o_inv, o_ei, _ = ref(biB, btB)
+    assert torch.equal(ei.cpu(), o_ei)
+
+
 def test_ensemble_forward_vs_golden(dev):
     from tsdiff_amd.sampler import EnsembleSampler
     d, meta = load_golden("ens_synth_b6_small")

@@ -134,14 +134,16 @@ class CondenseEncoderEpsNetwork(nn.Module):
         return self._packed
 
     def device_batch(self, atom_type, r_feat, p_feat, bond_index, bond_type, batch, num_nodes_per_graph=None):
+        # cache of the last two batches, keyed on the identity (TensorImpl) and version of the input tensors; the
+        # entry keeps the tensors alive, so their addresses cannot be recycled for other data while it is cached
         ts = (atom_type, r_feat, p_feat, bond_index, bond_type, batch)
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in ts)
-        for k, db in self._batches:
+        key = tuple((t._cdata, t._version) for t in ts)
+        for k, _, db in self._batches:
             if k == key:
                 return db
         db = engine.DeviceBatch(self._cfg, atom_type, r_feat, p_feat, bond_index, bond_type, batch,
                                 num_nodes_per_graph)
-        self._batches = [(key, db)] + self._batches[:1]
+        self._batches = [(key, ts, db)] + self._batches[:1]
         return db
 
     # ------------------------------------------------------------------------------------------

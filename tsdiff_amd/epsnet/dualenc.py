@@ -92,9 +92,9 @@ class DualEncoderEpsNetwork(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def device_batch(self, atom_type, bond_index, bond_type, batch, extend_order=True, extend_radius=True):
-        ts = (atom_type, bond_index, bond_type, batch)
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in ts) + (bool(extend_order), bool(extend_radius))
-        for k, db in self._batches:
+        ts = (atom_type, bond_index, bond_type, batch)  # (the cache entry keeps them alive: no address recycling)
+        key = tuple((t._cdata, t._version) for t in ts) + (bool(extend_order), bool(extend_radius))
+        for k, _, db in self._batches:
             if k == key:
                 return db
         if atom_type.device.type != "cuda":
@@ -120,7 +120,7 @@ class DualEncoderEpsNetwork(nn.Module):
                                          ptr(db.pair_code_raw), ptr(st), stream_ptr()))
             if int(st[0].item()) & (_lib.STATUS_BAD_BOND | _lib.STATUS_ASYMMETRIC):
                 raise ValueError("bond_index/bond_type: malformed bond list")
-        self._batches = [(key, db)] + self._batches[:2]
+        self._batches = [(key, ts, db)] + self._batches[:2]
         return db
 
     def _heads(self, db, pos):
