@@ -458,8 +458,8 @@ size_t tsd_train_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, i
 
 int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* raw, const int64_t* atom_type,
                       const int64_t* r_feat, const int64_t* p_feat, const float* pos0, const float* pos,
-                      const float* a_graph, float* workspace, size_t workspace_floats, float* loss,
-                      int32_t* counts_host, void* stream) {
+                      const float* a_graph, const int32_t* topo_status, float* workspace, size_t workspace_floats,
+                      float* loss, int32_t* counts_host, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     TSD_REQUIRE(cfg && batch && raw && atom_type && r_feat && p_feat && pos0 && pos && a_graph && workspace && loss &&
                     counts_host, "null pointer");
@@ -469,7 +469,10 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
     // the edge counts size every launch below: the one host sync of the step
     TSD_HIP(hipMemcpyAsync(&counts_host[0], g.enc_u.count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     TSD_HIP(hipMemcpyAsync(&counts_host[1], g.out_u.count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    counts_host[2] = 0;
+    if (topo_status) TSD_HIP(hipMemcpyAsync(&counts_host[2], topo_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     TSD_HIP(hipStreamSynchronize(st));
+    if (counts_host[2] & (TSD_STATUS_BAD_BOND | TSD_STATUS_ASYMMETRIC)) return TSD_OK;  // the caller raises
     Ctx x;
     TSD_TRY(make_ctx(x, cfg, batch, raw, workspace, workspace_floats, counts_host, st));
     const int N = x.N, H = x.H, L = x.L, F = x.F, Eu = x.Eu, Eo = x.Eo;

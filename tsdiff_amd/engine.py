@@ -92,13 +92,15 @@ class EdgeList:
         i32 = dict(dtype=torch.int32, device=device)
         self.count = torch.zeros(1, **i32)
         self.row_ptr = torch.zeros(N + 1, **i32)
-        self.src = torch.zeros(max(P, 1), **i32)
-        self.dst = torch.zeros(max(P, 1), **i32)
-        self.dist = torch.zeros(max(P, 1), dtype=torch.float32, device=device)
-        self.type_r = torch.zeros(max(P, 1), dtype=torch.uint8, device=device)
-        self.type_p = torch.zeros(max(P, 1), dtype=torch.uint8, device=device)
-        self.pair_id = torch.zeros(max(P, 1), **i32)
-        self.umap = torch.zeros(max(P, 1), **i32)
+        # entries [0, count) of the per-edge arrays are rewritten by every geometry build and nothing reads
+        # past count: no fill launches for them (a fresh batch per training step builds 35 of these)
+        self.src = torch.empty(max(P, 1), **i32)
+        self.dst = torch.empty(max(P, 1), **i32)
+        self.dist = torch.empty(max(P, 1), dtype=torch.float32, device=device)
+        self.type_r = torch.empty(max(P, 1), dtype=torch.uint8, device=device)
+        self.type_p = torch.empty(max(P, 1), dtype=torch.uint8, device=device)
+        self.pair_id = torch.empty(max(P, 1), **i32)
+        self.umap = torch.empty(max(P, 1), **i32)
 
     def struct(self):
         return Edges(*[C.c_void_p(t.data_ptr()) for t in (
@@ -116,7 +118,7 @@ class DeviceBatch:
     Built once per batch (the reference recomputes all of it 5000 x M times)."""
 
     def __init__(self, cfg, atom_type, r_feat, p_feat, bond_index, bond_type, batch=None,
-                 num_nodes_per_graph=None):
+                 num_nodes_per_graph=None, defer_status=False):
         lib = _lib.load()
         dev = atom_type.device
         if dev.type != "cuda":
@@ -162,12 +164,11 @@ class DeviceBatch:
         check(lib.tsd_topology_build(N, G, P, nb, ptr(self.graph_ptr), ptr(self.pair_base), ptr(bond_index),
                                      ptr(bond_type), max_order, self.max_n, ptr(self.node_graph),
                                      ptr(self.pair_ptr), ptr(self.pair_code), ptr(self.status), stream_ptr()))
-        st = int(self.status[0].item())  # one sync per batch
-        if st & _lib.STATUS_BAD_BOND:
-            raise ValueError("bond_index/bond_type: self loop, bond across graphs or value out of range")
-        if st & _lib.STATUS_ASYMMETRIC:
-            raise ValueError("bond list must contain both directions of every bond with equal types "
-                             "(reference utils/datasets.py:491-507)")
+        # the topology status word needs a host read: now (one sync per batch), or -- training -- together with
+        # the edge counts that tsd_train_forward reads anyway
+        self.status_pending = True
+        if not defer_status:
+            self.check_status()
         self.enc = EdgeList(N, P, dev)      # directed lists: the reference's edge_index order
         self.out = EdgeList(N, P, dev)
         self.enc_u = EdgeList(N, P // 2, dev)  # undirected (src < dst) lists the per-edge MLPs run on
@@ -182,6 +183,17 @@ class DeviceBatch:
         self.z = None
         self._z_key = None
         self.scratch = torch.zeros(((P + 63) // 64) * 64 + 3 * N + 128, dtype=torch.float32, device=dev)
+
+    def check_status(self, word=None):
+        if not self.status_pending:
+            return
+        st = int(self.status[0].item()) if word is None else int(word)
+        self.status_pending = False
+        if st & _lib.STATUS_BAD_BOND:
+            raise ValueError("bond_index/bond_type: self loop, bond across graphs or value out of range")
+        if st & _lib.STATUS_ASYMMETRIC:
+            raise ValueError("bond list must contain both directions of every bond with equal types "
+                             "(reference utils/datasets.py:491-507)")
 
     # ---- per-checkpoint state ----------------------------------------------------------------
     def bind_models(self, packed_list, key):
@@ -232,6 +244,7 @@ class DeviceBatch:
     # ---- ops -------------------------------------------------------------------------------
     def geometry(self, pos):
         lib = _lib.load()
+        self.check_status()
         pos = pos.to(torch.float32).contiguous()
         check(lib.tsd_geometry_build(C.byref(self.cfg), self.N, self.G, self.P, ptr(pos), ptr(self.graph_ptr),
                                      ptr(self.node_graph), ptr(self.pair_ptr), ptr(self.pair_code),
@@ -240,6 +253,7 @@ class DeviceBatch:
     def forward(self, pos):
         """geometry + M forwards; results stay on the device (self.edge_inv_u[m, :E_out/2])."""
         lib = _lib.load()
+        self.check_status()
         pos = pos.to(torch.float32).contiguous()
         b = self.struct()
         check(lib.tsd_score_forward(C.byref(self.cfg), C.byref(b), ptr(pos), stream_ptr()))
@@ -270,6 +284,7 @@ class DeviceBatch:
 
     def sampler_run(self, kind, pos, coefs, noises, clip, clip_pos, want_traj, use_graph=True):
         lib = _lib.load()
+        self.check_status()
         n_steps = int(coefs.shape[0])
         traj = (torch.empty(n_steps, self.N, 3, dtype=torch.float32, device=self.device) if want_traj else None)
         self.status.zero_()

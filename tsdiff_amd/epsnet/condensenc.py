@@ -133,7 +133,8 @@ class CondenseEncoderEpsNetwork(nn.Module):
             self._packed_key = key
         return self._packed
 
-    def device_batch(self, atom_type, r_feat, p_feat, bond_index, bond_type, batch, num_nodes_per_graph=None):
+    def device_batch(self, atom_type, r_feat, p_feat, bond_index, bond_type, batch, num_nodes_per_graph=None,
+                     defer_status=False):
         # cache of the last two batches, keyed on the identity (TensorImpl) and version of the input tensors; the
         # entry keeps the tensors alive, so their addresses cannot be recycled for other data while it is cached
         ts = (atom_type, r_feat, p_feat, bond_index, bond_type, batch)
@@ -142,7 +143,7 @@ class CondenseEncoderEpsNetwork(nn.Module):
             if k == key:
                 return db
         db = engine.DeviceBatch(self._cfg, atom_type, r_feat, p_feat, bond_index, bond_type, batch,
-                                num_nodes_per_graph)
+                                num_nodes_per_graph, defer_status=defer_status)
         self._batches = [(key, ts, db)] + self._batches[:1]
         return db
 
@@ -196,12 +197,14 @@ class CondenseEncoderEpsNetwork(nn.Module):
         a_pos = a.index_select(0, node2graph).unsqueeze(-1)
         pos_noise = torch.randn(size=pos.size(), device=dev) if _pos_noise is None else _pos_noise
         pos_perturbed = (pos + pos_noise * (1.0 - a_pos).sqrt() / a_pos.sqrt()).contiguous()
-        db = self.device_batch(atom_type, r_feat, p_feat, bond_index, bond_type, batch)
-
         training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        fused = training and os.environ.get("TSDIFF_TRAIN", "fused") != "ops"
+        # (the fused step reads the topology status together with its edge counts: one host sync less per batch)
+        db = self.device_batch(atom_type, r_feat, p_feat, bond_index, bond_type, batch, num_nodes_per_graph,
+                               defer_status=fused)
         if training:
             from .. import train_ops as T
-            if os.environ.get("TSDIFF_TRAIN", "fused") != "ops":
+            if fused:
                 # forward + loss and the whole backward sequenced in C++ (csrc/train_step.hip): one autograd node
                 return T.fused_train_loss(self, db, pos, pos_perturbed, a)
             # op-by-op autograd form (same kernels, one node per operation; kept as the cross-check)

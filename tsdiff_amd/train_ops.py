@@ -493,17 +493,20 @@ class FusedTrainLoss(torch.autograd.Function):
         if raw.numel() != n_raw:
             raise ValueError(f"parameters hold {raw.numel()} floats, the config needs {n_raw}")
         nws = lib.tsd_train_workspace_floats(C.byref(cfg), db.N, db.P)
-        ws = getattr(db, "_train_ws", None)
-        if ws is None or ws.numel() < nws:
-            ws = torch.empty(max(nws, 1), dtype=torch.float32, device=dev)
-            db._train_ws = ws
+        ws = getattr(model, "_train_ws", None)  # one arena per model, grown on demand, reused by every batch
+        if ws is None or ws.numel() < nws or ws.device != dev:
+            ws = None
+            model._train_ws = None  # release before growing
+            ws = torch.empty(max(int(nws * 1.15), 1), dtype=torch.float32, device=dev)
+            model._train_ws = ws
         b = db.train_struct()
-        counts = (C.c_int32 * 2)()
+        counts = (C.c_int32 * 3)()  # undirected edge counts of the two lists, topology status word
         loss = torch.empty(db.N, 1, dtype=torch.float32, device=dev)
         pos0, pos_perturbed, a_graph = _c(pos0.float()), _c(pos_perturbed.float()), _c(a_graph.float())
         check(lib.tsd_train_forward(C.byref(cfg), C.byref(b), ptr(raw), ptr(db.atom_type), ptr(db.r_feat),
-                                    ptr(db.p_feat), ptr(pos0), ptr(pos_perturbed), ptr(a_graph), ptr(ws), ws.numel(),
-                                    ptr(loss), counts, stream_ptr()))
+                                    ptr(db.p_feat), ptr(pos0), ptr(pos_perturbed), ptr(a_graph), ptr(db.status),
+                                    ptr(ws), ws.numel(), ptr(loss), counts, stream_ptr()))
+        db.check_status(counts[2])  # malformed bond lists raise ValueError here (results are discarded)
         ctx.model, ctx.db, ctx.raw, ctx.ws, ctx.counts, ctx.pos = model, db, raw, ws, counts, pos_perturbed
         ctx.sizes = [p.numel() for p in params]
         ctx.shapes = [p.shape for p in params]
