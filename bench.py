@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--reuse-batch", action="store_true",
                     help="train workload only: ONE batch for every step with its topology cached (A/B; the default "
                          "rotates 8 batches and rebuilds the topology every step like a real data loader)")
+    ap.add_argument("--node-run", type=int, default=0,
+                    help="A/B knob: consecutive node tiles kept on one XCD (0 = library default, 1 = plain order)")
     ap.add_argument("--combo-cols", type=int, default=0, choices=[0, 32, 64],
                     help="A/B knob: output columns per wave of the per-block launch (0 = library default)")
     ap.add_argument("--filter-tile", type=int, default=0, choices=[0, 32, 64],
@@ -153,6 +155,8 @@ def main():
         _lib.check(lib.tsd_set_filter_tile(args.filter_tile))
     if args.combo_cols:
         _lib.check(lib.tsd_set_combo_cols(args.combo_cols))
+    if args.node_run:
+        _lib.check(lib.tsd_set_node_run(args.node_run))
     cfg = synth.DEFAULT_MODEL_CONFIG
     models = []
     for m in range(args.models):

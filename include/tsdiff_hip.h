@@ -109,6 +109,9 @@ int tsd_set_filter_tile(int32_t rows);
 /* A/B knob of the same launch: output columns per wave, 0 = library default, 32 (H/32 waves per workgroup, one
  * accumulator block per wave) or 64 (H/64 waves, two accumulator blocks per B fragment).  Bit-identical results. */
 int tsd_set_combo_cols(int32_t cols);
+/* XCD-aware node-tile order of the same launch: runs of `run` consecutive 16-node tiles (one 64-atom graph = 4
+ * tiles) are kept on ONE XCD, whose L2 then serves the x1 / filter rows they share.  1 = plain order. */
+int tsd_set_node_run(int32_t run);
 const char* tsd_last_error(void);
 
 /* ---- weights ---------------------------------------------------------------------------

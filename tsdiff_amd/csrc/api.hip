@@ -67,6 +67,7 @@ int launch_sampler_step(int, int, int, const int32_t*, const float*, const float
 
 extern int g_filter_rows;
 extern int g_combo_cols;
+extern int g_node_run;
 
 static int check_cfg(const tsd_model_cfg* c) {
     TSD_REQUIRE(c != nullptr, "cfg is null");
@@ -222,6 +223,12 @@ extern "C" {
 int tsd_set_filter_tile(int32_t rows) {
     TSD_REQUIRE(rows == 0 || rows == 32 || rows == 64, "filter tile rows must be 0 (auto), 32 or 64");
     g_filter_rows = rows;
+    return TSD_OK;
+}
+
+int tsd_set_node_run(int32_t run) {
+    TSD_REQUIRE(run >= 1 && run <= 64, "node tiles per XCD run must be in 1..64");
+    g_node_run = run;
     return TSD_OK;
 }
 

@@ -332,6 +332,7 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
 
 struct ComboStride {  // per-checkpoint strides (blockIdx.y = checkpoint of the ensemble)
     size_t w, nh, ea, wf;
+    int node_run;  // consecutive node tiles kept on one XCD (1: plain order)
 };
 
 template <int H, int RB, int CBF>
@@ -347,9 +348,22 @@ __global__ __launch_bounds__(2 * H / CBF) void layer_combo_kernel(ComboNode a, i
         f.Wl0 += wo;
         f.edge_attr += m * sd.ea; f.wf += m * sd.wf;
     }
-    if ((int)blockIdx.x < node_tiles)
-        node_role<H, CBF>(a, blockIdx.x, smem);
-    else
+    if ((int)blockIdx.x < node_tiles) {
+        // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), and the node
+        // tiles of one graph read the same x1 rows and -- from both endpoints -- the same filter rows.  Runs of
+        // `run` consecutive tiles therefore go to ONE XCD: the q-th workgroup of XCD x takes tile
+        // ((q / run) * 8 + x) * run + q % run.  The tail that does not fill 8 * run keeps the identity order.
+        int tile = blockIdx.x;
+        const int run = sd.node_run;
+        if (run > 1) {
+            const int full = node_tiles / (8 * run) * (8 * run);
+            if (tile < full) {
+                const int x = tile & 7, q = tile >> 3;
+                tile = ((q / run) * 8 + x) * run + q % run;
+            }
+        }
+        node_role<H, CBF>(a, tile, smem);
+    } else
         filter_role<H, RB, CBF>(f, blockIdx.x - node_tiles, smem);
 }
 
@@ -360,6 +374,7 @@ static inline size_t lds_combo(int H, int RB) {
 }
 
 int g_filter_rows = 0;  // 0: automatic, 32 / 64: forced (tsd_set_filter_tile; tests and A/B runs)
+int g_node_run = 4;     // node tiles per XCD run (tsd_set_node_run; 1 = plain order)
 int g_combo_cols = 0;   // output columns per wave of the per-block launch: 0 automatic, 32 or 64 (tsd_set_combo_cols)
 
 int filter_tiles_per_layer(int capacity_u) {
@@ -427,7 +442,7 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     if (grid == 0) return TSD_OK;
     const size_t lds = lds_combo(c.hidden, RBsel);
     const int cols = g_combo_cols == 64 ? 64 : 32;
-    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride};
+    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, g_node_run};
 #define TSD_COMBO_RB(HH, RR, CC)                                                                              \
     {                                                                                                         \
         static bool done = false;                                                                             \
