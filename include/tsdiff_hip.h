@@ -255,10 +255,11 @@ int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t ki
                     int32_t use_graph, void* stream);
 
 /* ---- training primitives (BASELINE config 4; reference train.py:124-152, condensenc.py:267-328) -----
- * First functional form of the training step, one launch per operation: every dense layer's forward / dgrad /
- * wgrad on the fp32 MFMA, the graph-shaped operations and their adjoints as plain kernels.  The Python host
- * composes them as torch.autograd.Function nodes (tsdiff_amd/train_ops.py), so `loss.backward()`,
- * `clip_grad_norm_` and Adam of the unmodified train.py keep working.  All matrices row-major fp32. */
+ * One launch per operation: every dense layer's forward / dgrad / wgrad on the fp32 MFMA, the graph-shaped
+ * operations and their adjoints as plain kernels.  tsd_train_forward / tsd_train_backward (further down)
+ * sequence them for a whole step; the Python host also exposes them one by one as torch.autograd.Function
+ * nodes (tsdiff_amd/train_ops.py: the differentiable forward(), the legacy network, cross-checks).
+ * All matrices row-major fp32. */
 /* Y[rows,out] = X[rows,in] W[out,in]^T + b.  scratch >= in*out floats: W is packed there and the product
  * runs on the fp32 MFMA (in, out in {128,256,512}); otherwise / without scratch a plain VALU kernel runs. */
 int tsd_linear_fwd(int32_t rows, int32_t in, int32_t out, const float* X, const float* W, const float* b,

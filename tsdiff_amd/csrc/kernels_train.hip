@@ -1,10 +1,10 @@
 // kernels_train.hip -- primitives of the training step (BASELINE config 4; reference train.py:124-152,
-// models/epsnet/condensenc.py:267-328).  First functional form: one launch per operation -- the dense
-// layers' forward / dgrad / wgrad as fp32-MFMA tile kernels, everything graph-shaped (segmented aggregation
-// and its two adjoints, pair products, embedding gathers / scatters, distance -> Cartesian chain rule,
-// activations) as plain kernels -- no vendor BLAS.  The Python host (tsdiff_amd/train_ops.py) strings them together as
-// torch.autograd.Function nodes so that the reference's unmodified `loss.backward()`, `clip_grad_norm_`
-// and Adam keep working; fusing this path like the sampling path is next round's work.
+// models/epsnet/condensenc.py:267-328): the dense layers' forward / dgrad / wgrad as fp32-MFMA tile kernels
+// (bias, activation, its adjoint, cutoff mask, residual / accumulation in the epilogues), everything
+// graph-shaped (segmented aggregation and its two adjoints, pair products, embedding gathers / scatters,
+// distance -> Cartesian chain rule) as plain kernels -- no vendor BLAS.  Two hosts sequence them:
+// csrc/train_step.hip (the whole step in C++, what get_loss uses) and tsdiff_amd/train_ops.py (one
+// torch.autograd.Function node per operation: the differentiable forward() and the cross-check).
 //
 // All per-edge work runs on the UNDIRECTED lists (see tsd_geometry): a filter row Wf[u] / score s[u] is
 // used by both directed edges (i,j) and (j,i), so its gradient is the sum of both directions.
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void wgrad_naive_kernel(int rows, int in, int 
 
 // ---------------------------------------------------------------------------------------------
 // wgrad: dW[out,in] = dY[rows,out]^T X[rows,in] for the per-edge layers, where rows (26 k at batch 200)
-// is the contraction and out/in are 128..512 -- rocBLAS runs these as 4-8 workgroups (300 us each).
+// is the contraction and out/in are 128..512 -- a BLAS call runs these as 4-8 workgroups (300 us each).
 // Here: grid (in/128, out/128, S row splits); a workgroup of 4 waves (2x2, each 64 out x 64 in = four
 // 32x32 accumulators) streams its row range through LDS in 32-row tiles (register-prefetched), the
 // S partial [out,in] blocks are then summed in split order by wgrad_reduce_kernel (deterministic).

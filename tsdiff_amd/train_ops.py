@@ -6,8 +6,12 @@ torch's autograd engine only SEQUENCES the backward (so the reference's unmodifi
 `loss.mean().backward()`, `clip_grad_norm_` and `torch.optim.Adam` keep working); every forward and
 backward computation below runs in libtsdiff_hip.so: the dense layers as fp32-MFMA tile kernels, the
 graph-shaped operations (segmented aggregation and both adjoints, pair products, embedding
-gather/scatter, the distance -> Cartesian chain rule, activations) as HIP kernels.  This is the
-first functional form of row A16 / SURVEY 8(f)-1; fusing it like the sampling path is next.
+gather/scatter, the distance -> Cartesian chain rule, activations) as HIP kernels.
+
+`get_loss` in training mode does NOT come through these nodes any more: FusedTrainLoss at the end of this file
+hands the whole forward + loss and the whole backward to csrc/train_step.hip (one node).  The per-operation
+nodes serve the differentiable `forward()`, the legacy dual-encoder network and the cross-check of the fused
+step (`TSDIFF_TRAIN=ops`).
 """
 import ctypes as C
 
