@@ -130,7 +130,12 @@ __device__ __forceinline__ float cutoff_weight(float d, float cutoff, int smooth
 // B is double-buffered in registers in chunks of PF k-blocks: while chunk c is multiplied (PF*4*RB*CB
 // MFMAs = 2048 cycles at RB=1, CB=2), chunk c+1 is in flight from L2 -- one k-block of look-ahead
 // (the first version) exposed the L2 latency every iteration (tools/mfma_probe.hip: 84 -> 93 TFLOP/s).
-template <int RB, int CB, int K, int PF = 4, bool PIN = false>
+// SPLIT (off; kept as a measured experiment): accumulate every output element as TWO partial sums (MFMA
+// steps 0,2 and 1,3 of each k-block) so that consecutive MFMAs of a one-column-block wave alternate
+// accumulators -- the guide prices a foreign instruction between two MFMAs on the SAME accumulator at ~43
+// cycles, and tools/mfma_probe2.hip measures 97 (one accumulator) vs 137 TFLOP/s (two).  In the real kernels
+// it changed nothing for the better (C2 0.549 vs 0.523 ms/step, C5 53.2 vs 52.0, training 6.60 vs 6.55).
+template <int RB, int CB, int K, int PF = 4, bool PIN = false, bool SPLIT = false>
 __device__ __forceinline__ void gemm_tile(const float* __restrict__ ldsA, int lda,
                                           const float* __restrict__ Bp, int nout, int col0,
                                           f32x16 (&acc)[RB][CB]) {
@@ -142,6 +147,15 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ ldsA, int ld
     constexpr int KB = K / 8;
     constexpr int NC = KB / PF;
     static_assert(KB % PF == 0, "K must be a multiple of 8 * PF");
+    f32x16 acc2[RB][CB];
+    if (SPLIT) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[rb][cb][r] = 0.0f;
+    }
     f32x4 b0[PF][CB], b1[PF][CB];
     auto loadB = [&](f32x4 (&b)[PF][CB], int chunk) {
 #pragma unroll
@@ -163,8 +177,12 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ ldsA, int ld
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                    for (int cb = 0; cb < CB; ++cb)
-                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][rb][s], b[p][cb][s], acc[rb][cb], 0, 0, 0);
+                    for (int cb = 0; cb < CB; ++cb) {
+                        if (SPLIT && (s & 1))
+                            acc2[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][rb][s], b[p][cb][s], acc2[rb][cb], 0, 0, 0);
+                        else
+                            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][rb][s], b[p][cb][s], acc[rb][cb], 0, 0, 0);
+                    }
     };
     // The machine scheduler sinks every load to just before its first use (one k-block of look-ahead).
     // With >= 2 workgroups per CU the other waves cover that (measured: pinning the pipeline costs 10 % at
@@ -180,6 +198,14 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ ldsA, int ld
         if (PIN) __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < NC) compute(b1, c + 1);
         if (PIN) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (SPLIT) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[rb][cb][r] += acc2[rb][cb][r];
     }
 }
 

@@ -10,6 +10,8 @@
 // Roles never communicate; the kernel boundary orders block l's filter before block l's aggregation.
 //
 // Both roles run with 2H threads = H/32 waves, 32 output columns per wave.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace tsd {
@@ -333,6 +335,7 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
 struct ComboStride {  // per-checkpoint strides (blockIdx.y = checkpoint of the ensemble)
     size_t w, nh, ea, wf;
     int node_run;  // consecutive node tiles kept on one XCD (1: plain order)
+    int phase_sleep;
 };
 
 template <int H, int RB, int CBF>
@@ -363,8 +366,15 @@ __global__ __launch_bounds__(2 * H / CBF) void layer_combo_kernel(ComboNode a, i
             }
         }
         node_role<H, CBF>(a, tile, smem);
-    } else
-        filter_role<H, RB, CBF>(f, blockIdx.x - node_tiles, smem);
+    } else {
+        // phase shift (experiment knob): workgroups of every second dispatch round start late, so that the two
+        // workgroups sharing a CU do not run their load / epilogue phases in lockstep
+        const int item = blockIdx.x - node_tiles;
+        if (sd.phase_sleep > 0 && ((item >> 8) & 1)) {
+            for (int k = 0; k < sd.phase_sleep; ++k) __builtin_amdgcn_s_sleep(32);  // 32 * 64 cycles = 0.85 us
+        }
+        filter_role<H, RB, CBF>(f, item, smem);
+    }
 }
 
 static inline size_t lds_combo(int H, int RB) {
@@ -440,9 +450,11 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     const int node_tiles = layer == -2 ? 0 : (N + TN - 1) / TN;
     const int grid = node_tiles + f.tiles;
     if (grid == 0) return TSD_OK;
-    const size_t lds = lds_combo(c.hidden, RBsel);
+    static const size_t lds_pad = getenv("TSDIFF_COMBO_LDS_PAD") ? (size_t)atoi(getenv("TSDIFF_COMBO_LDS_PAD")) : 0;
+    const size_t lds = lds_combo(c.hidden, RBsel) + lds_pad;  // (experiment knob: caps the resident workgroups per CU)
     const int cols = g_combo_cols == 64 ? 64 : 32;
-    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, g_node_run};
+    static const int phase_sleep = getenv("TSDIFF_PHASE_SLEEP") ? atoi(getenv("TSDIFF_PHASE_SLEEP")) : 0;
+    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, g_node_run, phase_sleep};
 #define TSD_COMBO_RB(HH, RR, CC)                                                                              \
     {                                                                                                         \
         static bool done = false;                                                                             \
