@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--reuse-batch", action="store_true",
                     help="train workload only: ONE batch for every step with its topology cached (A/B; the default "
                          "rotates 8 batches and rebuilds the topology every step like a real data loader)")
+    ap.add_argument("--combo-prefetch", type=int, default=0, choices=[0, 4, 8],
+                    help="A/B knob: k-blocks per B prefetch chunk of the filter role (8 = pinned pipeline)")
     ap.add_argument("--node-run", type=int, default=0,
                     help="A/B knob: consecutive node tiles kept on one XCD (0 = library default, 1 = plain order)")
     ap.add_argument("--combo-cols", type=int, default=0, choices=[0, 32, 64],
@@ -157,6 +159,8 @@ def main():
         _lib.check(lib.tsd_set_combo_cols(args.combo_cols))
     if args.node_run:
         _lib.check(lib.tsd_set_node_run(args.node_run))
+    if args.combo_prefetch:
+        _lib.check(lib.tsd_set_combo_prefetch(args.combo_prefetch))
     cfg = synth.DEFAULT_MODEL_CONFIG
     models = []
     for m in range(args.models):

@@ -112,6 +112,9 @@ int tsd_set_combo_cols(int32_t cols);
 /* XCD-aware node-tile order of the same launch: runs of `run` consecutive 16-node tiles (one 64-atom graph = 4
  * tiles) are kept on ONE XCD, whose L2 then serves the x1 / filter rows they share.  1 = plain order. */
 int tsd_set_node_run(int32_t run);
+/* B-operand prefetch of the filter role: 0 / 4 = four k-blocks per chunk, placement left to the compiler's
+ * scheduler; 8 = eight k-blocks per chunk, the chunked pipeline pinned with scheduling barriers. */
+int tsd_set_combo_prefetch(int32_t kblocks);
 const char* tsd_last_error(void);
 
 /* ---- weights ---------------------------------------------------------------------------

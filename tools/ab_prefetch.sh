@@ -1,0 +1,7 @@
+P='import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], d["value"], d["roofline"]["frac"], d["roofline"]["avg_launch_us"])'
+for pf in 4 8; do
+echo "combo prefetch $pf"
+python bench.py --steps 1000 --warmup 50 --no-cpu-baseline --combo-prefetch $pf 2>&1 | tail -1 | python -c "$P"
+python bench.py --workload c5 --graphs 1024 --steps 10 --warmup 2 --no-cpu-baseline --combo-prefetch $pf 2>&1 | tail -1 | python -c "$P"
+python bench.py --models 8 --steps 200 --warmup 20 --no-cpu-baseline --combo-prefetch $pf 2>&1 | tail -1 | python -c "$P"
+done

@@ -3,6 +3,8 @@
 //   1: + A operand from LDS  (ds_read_b128 per 4 MFMAs)
 //   2: + B operand from L2   (global_load_dwordx4 per column block per 4 MFMAs), scheduler free
 //   3: like 2 with the chunked pipeline pinned by sched_barrier
+//   4: A and B operands both from LDS (B pre-staged once: no global loads in the loop) -- isolates the cost of
+//      the global-load return path from the cost of feeding two operands
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mfma_probe2.hip -o gpurun_out/mfma_probe2
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -20,6 +22,11 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ A, const 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     for (int idx = tid; idx < 32 * H; idx += 256) smem[(idx / H) * LDA + (idx % H)] = A[idx];
+    if (VAR == 4) {  // stage this workgroup's B once: 4 waves x KB x CB x 64 lanes float4 = K * 4*CB*32 floats
+        f32x4* bl = reinterpret_cast<f32x4*>(smem + 32 * LDA);
+        const f32x4* src = reinterpret_cast<const f32x4*>(W);
+        for (int idx = tid; idx < 4 * 8 * CB * 64; idx += 256) bl[idx] = src[idx];
+    }
     __syncthreads();
     const int col0 = (tid >> 6) * (CB * 32);
     const int nout = 4 * CB * 32;
@@ -31,7 +38,22 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ A, const 
     f32x4 breg = *reinterpret_cast<const f32x4*>(W + lane * 4);
     for (int rep = 0; rep < nrep; ++rep) {
         const f32x4* bptr = reinterpret_cast<const f32x4*>(W + (size_t)(rep & 1) * H * nout) + (size_t)hi * nout + col0 + l31;
-        if (VAR <= 1) {
+        if (VAR == 4) {
+            // B for this wave: [KB][CB][64 lanes] float4 in LDS after the A tile (pre-staged below, outside the loop)
+            const f32x4* bl = reinterpret_cast<const f32x4*>(smem + 32 * LDA) + (size_t)(tid >> 6) * 8 * CB * 64 + lane;  // 8 k-blocks staged, reused cyclically
+#pragma unroll 4
+            for (int kb = 0; kb < KB; ++kb) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(aptr + kb * 8);
+                f32x4 b[CB];
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) b[cb] = bl[((kb & 7) * CB + cb) * 64];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb)
+                        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[cb][s], acc[cb], 0, 0, 0);
+            }
+        } else if (VAR <= 1) {
 #pragma unroll 4
             for (int kb = 0; kb < KB; ++kb) {
                 f32x4 a = areg;
@@ -127,6 +149,10 @@ int main() {
         run<0, 1, 4>("regs only", grid, nrep, A, W, out, extra);
         run<2, 1, 4>("A LDS + B L2 (free sched)", grid, nrep, A, W, out, extra);
         run<3, 1, 8>("A LDS + B L2 (pinned)", grid, nrep, A, W, out, extra);
+        if (extra <= 40 * 1024) {  // + staged B: 4 waves x 8 k-blocks x CB x 64 lanes x 16 B
+            run<4, 1, 4>("A LDS + B LDS", grid, nrep, A, W, out, extra + 32 * 1024);
+            run<4, 2, 4>("A LDS + B LDS", grid, nrep, A, W, out, (extra ? 10 * 1024 : 0) + 64 * 1024);
+        }
         printf("\n");
     }
     return 0;

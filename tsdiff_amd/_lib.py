@@ -95,6 +95,7 @@ SIGNATURES = {
     "tsd_set_filter_tile": (C.c_int, [C.c_int32]),
     "tsd_set_combo_cols": (C.c_int, [C.c_int32]),
     "tsd_set_node_run": (C.c_int, [C.c_int32]),
+    "tsd_set_combo_prefetch": (C.c_int, [C.c_int32]),
     "tsd_raw_weight_floats": (C.c_size_t, [_CFG]),
     "tsd_packed_weight_floats": (C.c_size_t, [_CFG]),
     "tsd_pack_weights": (C.c_int, [_CFG, _P, _P, _P]),

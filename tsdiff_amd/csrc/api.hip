@@ -68,6 +68,7 @@ int launch_sampler_step(int, int, int, const int32_t*, const float*, const float
 extern int g_filter_rows;
 extern int g_combo_cols;
 extern int g_node_run;
+extern int g_combo_prefetch;
 
 static int check_cfg(const tsd_model_cfg* c) {
     TSD_REQUIRE(c != nullptr, "cfg is null");
@@ -223,6 +224,12 @@ extern "C" {
 int tsd_set_filter_tile(int32_t rows) {
     TSD_REQUIRE(rows == 0 || rows == 32 || rows == 64, "filter tile rows must be 0 (auto), 32 or 64");
     g_filter_rows = rows;
+    return TSD_OK;
+}
+
+int tsd_set_combo_prefetch(int32_t kblocks) {
+    TSD_REQUIRE(kblocks == 0 || kblocks == 4 || kblocks == 8, "prefetch chunk must be 0 (default), 4 or 8 k-blocks");
+    g_combo_prefetch = kblocks;
     return TSD_OK;
 }
 

@@ -218,7 +218,7 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
 // -------------------------------------------------------------------------------------------------
 // RB = 1: tiles of 32 edges (the default); RB = 2: tiles of 64 edges (every B fragment fetched from L2 feeds
 // twice the MFMAs; faster in the 4-wave probe, slower here -- see launch_layer_combo).  Bit-identical rows.
-template <int H, int RB, int CBF>
+template <int H, int RB, int CBF, int PFF>
 __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, float* smem) {
     static_assert(RB == 1 || CBF == 1, "the 64-edge layout has its own wave mapping");
     constexpr int TR = T * RB;
@@ -295,7 +295,7 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
     } else {
     f32x16 acc[RB][CBF];
     zero_acc(acc);
-    gemm_tile<RB, CBF, H>(buf, LDA, nn0_w, H, col0, acc);
+    gemm_tile<RB, CBF, H, PFF, (PFF > 4)>(buf, LDA, nn0_w, H, col0, acc);
     __syncthreads();
 #pragma unroll
     for (int cb = 0; cb < CBF; ++cb) {
@@ -309,7 +309,7 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
     __syncthreads();
 
     zero_acc(acc);
-    gemm_tile<RB, CBF, H>(buf, LDA, nn2_w, H, col0, acc);
+    gemm_tile<RB, CBF, H, PFF, (PFF > 4)>(buf, LDA, nn2_w, H, col0, acc);
     __syncthreads();
 #pragma unroll
     for (int cb = 0; cb < CBF; ++cb) {
@@ -338,7 +338,7 @@ struct ComboStride {  // per-checkpoint strides (blockIdx.y = checkpoint of the 
     int phase_sleep;
 };
 
-template <int H, int RB, int CBF>
+template <int H, int RB, int CBF, int PFF>
 __global__ __launch_bounds__(2 * H / CBF) void layer_combo_kernel(ComboNode a, int node_tiles, ComboFilter f,
                                                                   ComboStride sd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(2 * H / CBF) void layer_combo_kernel(ComboNode a, i
         if (sd.phase_sleep > 0 && ((item >> 8) & 1)) {
             for (int k = 0; k < sd.phase_sleep; ++k) __builtin_amdgcn_s_sleep(32);  // 32 * 64 cycles = 0.85 us
         }
-        filter_role<H, RB, CBF>(f, item, smem);
+        filter_role<H, RB, CBF, PFF>(f, item, smem);
     }
 }
 
@@ -385,6 +385,7 @@ static inline size_t lds_combo(int H, int RB) {
 
 int g_filter_rows = 0;  // 0: automatic, 32 / 64: forced (tsd_set_filter_tile; tests and A/B runs)
 int g_node_run = 4;     // node tiles per XCD run (tsd_set_node_run; 1 = plain order)
+int g_combo_prefetch = 0;  // k-blocks per pinned B prefetch chunk of the filter role: 0 / 4 = scheduler's choice, 8 = pinned
 int g_combo_cols = 0;   // output columns per wave of the per-block launch: 0 automatic, 32 or 64 (tsd_set_combo_cols)
 
 int filter_tiles_per_layer(int capacity_u) {
@@ -455,20 +456,20 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     const int cols = g_combo_cols == 64 ? 64 : 32;
     static const int phase_sleep = getenv("TSDIFF_PHASE_SLEEP") ? atoi(getenv("TSDIFF_PHASE_SLEEP")) : 0;
     const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, g_node_run, phase_sleep};
-#define TSD_COMBO_RB(HH, RR, CC)                                                                              \
+#define TSD_COMBO_RB(HH, RR, CC, PP)                                                                          \
     {                                                                                                         \
         static bool done = false;                                                                             \
         if (!done && lds > 48 * 1024)                                                                         \
-            TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_combo_kernel<HH, RR, CC>),        \
+            TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_combo_kernel<HH, RR, CC, PP>),    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
         done = true;                                                                                          \
-        hipLaunchKernelGGL((layer_combo_kernel<HH, RR, CC>), dim3(grid, M), dim3(2 * HH / CC), lds, st, a,    \
+        hipLaunchKernelGGL((layer_combo_kernel<HH, RR, CC, PP>), dim3(grid, M), dim3(2 * HH / CC), lds, st, a,\
                            node_tiles, f, sd);                                                                \
     }
 #define TSD_COMBO(HH)                                                                                         \
     {                                                                                                         \
-        if (RBsel == 2) TSD_COMBO_RB(HH, 2, 1) else if (cols == 64) TSD_COMBO_RB(HH, 1, 2)                    \
-        else TSD_COMBO_RB(HH, 1, 1)                                                                           \
+        if (RBsel == 2) TSD_COMBO_RB(HH, 2, 1, 4) else if (cols == 64) TSD_COMBO_RB(HH, 1, 2, 4)              \
+        else if (g_combo_prefetch == 8 && HH >= 128) TSD_COMBO_RB(HH, 1, 1, 8) else TSD_COMBO_RB(HH, 1, 1, 4) \
     }
     switch (c.hidden) {
         case 64: TSD_COMBO(64) break;
