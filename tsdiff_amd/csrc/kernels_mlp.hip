@@ -419,13 +419,13 @@ __global__ __launch_bounds__(2 * H) void node_update_kernel(NodeW w, int N, cons
 // reference models/common.py:226-229, models/epsnet/condensenc.py:72-76,236-237
 // ---------------------------------------------------------------------------------------------
 template <int H>
-__global__ __launch_bounds__(H) void pair_output_kernel(PairW w, tsd_edges e, const float* __restrict__ h,
+__global__ __launch_bounds__(2 * H) void pair_output_kernel(PairW w, tsd_edges e, const float* __restrict__ h,
                                                         const float* __restrict__ edge_attr,
                                                         const int32_t* __restrict__ attr_row,
                                                         float* __restrict__ edge_inv, size_t wstride,
                                                         size_t h_stride, size_t ea_stride, size_t inv_stride) {
     constexpr int LDA = 2 * H + 4;
-    constexpr int NW = H / 64;
+    constexpr int NW = H / 64;   // waves of the second GEMM (H/2 columns, 32 per wave); the block has 2 NW waves
     {  // blockIdx.y = checkpoint of the ensemble
         const size_t m = blockIdx.y, wo = m * wstride;
         w.w0 += wo; w.b0 += wo; w.w1 += wo; w.b1 += wo; w.w2 += wo; w.b2 += wo;
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(H) void pair_output_kernel(PairW w, tsd_edges e, co
     {  // h_src * h_dst || edge_attr row -> LDS, float4 per lane, all loads of a lane independent
         constexpr int C4 = H / 4;
 #pragma unroll 2
-        for (int idx = tid; idx < T * C4; idx += H) {
+        for (int idx = tid; idx < T * C4; idx += 2 * H) {
             const int r = idx / C4, c4 = idx % C4;
             f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
             if (r < nrows) {
@@ -471,22 +471,19 @@ __global__ __launch_bounds__(H) void pair_output_kernel(PairW w, tsd_edges e, co
     }
     __syncthreads();
 
-    {
-        f32x16 acc[1][2];
-        const int col0 = wave * 64;
+    {   // 2H -> H: H/32 waves x 32 columns
+        f32x16 acc[1][1];
+        const int col0 = wave * 32;
         zero_acc(acc);
-        gemm_tile<1, 2, 2 * H>(buf, LDA, w.w0, H, col0, acc);
+        gemm_tile<1, 1, 2 * H>(buf, LDA, w.w0, H, col0, acc);
         __syncthreads();
+        const int col = col0 + l31;
+        const float b = w.b0[col];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const int col = col0 + cb * 32 + l31;
-            const float b = w.b0[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) buf[acc_row(r, hi) * LDA + col] = swishf(acc[0][cb][r] + b);
-        }
+        for (int r = 0; r < 16; ++r) buf[acc_row(r, hi) * LDA + col] = swishf(acc[0][0][r] + b);
         __syncthreads();
     }
-    {
+    if (wave < NW) {  // H -> H/2 and the final dot: the first H/64 waves
         f32x16 acc[1][1];
         const int col = wave * 32 + l31;
         zero_acc(acc);
@@ -664,7 +661,7 @@ int launch_pair_output(const tsd_model_cfg& c, const float* W, int capacity, tsd
     TSD_DISPATCH_H(c.hidden, {
         static bool done = false; int r = allow_lds_once(pair_output_kernel<HH>, lds, done);
         if (r) return r;
-        hipLaunchKernelGGL(pair_output_kernel<HH>, dim3(tiles, M), dim3(HH), lds, st, w, e, h, edge_attr, attr_row,
+        hipLaunchKernelGGL(pair_output_kernel<HH>, dim3(tiles, M), dim3(2 * HH), lds, st, w, e, h, edge_attr, attr_row,
                            edge_inv, L.total, h_stride, ea_stride, inv_stride);
     });
     TSD_LAUNCH_CHECK("pair_output");
