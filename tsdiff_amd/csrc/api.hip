@@ -30,7 +30,7 @@ int launch_node_update(const tsd_model_cfg&, const float*, int, int, int, const 
                        const float*, float*, float*, hipStream_t);
 int launch_node_lin1(const tsd_model_cfg&, const float*, int, int, const float*, float*, hipStream_t);
 int launch_pair_output(const tsd_model_cfg&, const float*, int, tsd_edges, const float*, const float*,
-                       const int32_t*, float*, int, size_t, size_t, size_t, hipStream_t);
+                       const int32_t*, float*, int, size_t, size_t, size_t, hipStream_t, const float*, size_t);
 size_t raw_weight_floats(const tsd_model_cfg&);
 int launch_pack_weights(const tsd_model_cfg&, const float*, float*, hipStream_t);
 int launch_topology(int, int, int, int64_t, const int32_t*, const int32_t*, const int64_t*, const int64_t*, int,
@@ -51,7 +51,7 @@ int launch_edge_embed2(const tsd_model_cfg&, const float*, int, tsd_edges, float
                        size_t, hipStream_t);
 int launch_layer_combo(const tsd_model_cfg&, const float*, int, int, tsd_edges, const float*, const float*,
                        const float*, float*, float*, int, int, int, int, tsd_edges, const float*, float*, int, size_t,
-                       size_t, size_t, hipStream_t);
+                       size_t, size_t, hipStream_t, const ComboPre*, size_t);
 int filter_tiles_per_layer(int);
 int launch_node_embed(const tsd_model_cfg&, const float*, int, const int64_t*, const int64_t*, const int64_t*,
                       float*, hipStream_t);
@@ -88,7 +88,8 @@ struct Workspace {
     float *wf;   // [M][L, P/2, H]: CFConv filters of every layer on the undirected enc list
     float *h, *x1, *x1b;  // [M][N, H]
     float *agg;  // [N, H] (piecewise path only)
-    size_t stride_ea, stride_wf, stride_nh;
+    float *pre;  // [M][P/2, H]: node-independent half of the pair MLP's first layer (ComboPre)
+    size_t stride_ea, stride_wf, stride_nh, stride_pre;
     size_t total;
 };
 
@@ -107,6 +108,8 @@ static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base)
     w.x1 = take(w.stride_nh * M);
     w.x1b = take(w.stride_nh * M);
     w.agg = take(w.stride_nh);
+    w.stride_pre = pad(PU * H);
+    w.pre = take(w.stride_pre * M);
     w.total = o;
     return w;
 }
@@ -115,6 +118,16 @@ static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base)
 // per block, checkpoints one after the other) -- the A/B baseline of the fused per-block launches.
 // (A two-stream variant, node chain || next block's filters joined by events, measured 1.07 ms/step under
 // hipGraph replay against 0.92 serial and was removed in favour of the in-kernel fusion, kernels_combo.hip.)
+// TSDIFF_PAIR_PRE=0 keeps the whole pair MLP in pair_output_kernel (A/B of the ComboPre role)
+static bool pre_role_enabled() {
+    static int cached = -1;
+    if (cached < 0) {
+        const char* env = getenv("TSDIFF_PAIR_PRE");
+        cached = (env && env[0] == '0') ? 0 : 1;
+    }
+    return cached == 1 && g_filter_rows != 64 && g_combo_cols != 64;
+}
+
 static bool use_fused_path() {
     static int cached = -1;
     if (cached < 0) {
@@ -164,12 +177,28 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
         long cum = 0;
         const float* xin = b.x1_0;
         float* xout = w.x1;
+        // the last launch has no filter tiles left: its free CUs compute the node-independent half of the pair
+        // MLP's first layer (ComboPre), which pair_output_kernel then only completes
+        const WeightLayout WL = weight_layout(c);
+        ComboPre pre{};
+        pre.tiles = (PU + TSD_EDGE_TILE - 1) / TSD_EDGE_TILE;
+        pre.e = g.out_u;
+        pre.edge_attr = w.ea;
+        pre.attr_row = g.attr_row;
+        pre.w0b = W + WL.out_w0 + H * H;  // packed [k/4][out][k%4]: the k >= H half is contiguous
+        pre.b0 = W + WL.out_b0;
+        pre.out = w.pre;
+        // (only when the node chain of the last block leaves most of the chip idle: at batch 100 it occupies ~100
+        // of the 256 CUs; with an ensemble or a large batch the launch is full and the extra role only adds work:
+        // C2 0.518 -> 0.511 ms/step, C5 51.1 -> 51.6, M = 8 3.10 -> 3.13)
+        const bool use_pre = pre_role_enabled() && (long)((N + TSD_NODE_TILE - 1) / TSD_NODE_TILE) * M <= 256;
         for (int j = 0; j <= L; ++j) {
             const long n = (j < L) ? tpl : total - cum;
             const int layer = j == 0 ? -2 : j - 1;
             if ((r = launch_layer_combo(c, W, layer, N, g.enc, layer >= 0 ? w.wf + (size_t)layer * PU * H : nullptr, xin,
                                         layer == 0 ? b.z : w.h, w.h, xout, 0, (int)cum, (int)n, PU, g.enc_u, w.ea, w.wf,
-                                        M, w.stride_nh, w.stride_ea, w.stride_wf, st)))
+                                        M, w.stride_nh, w.stride_ea, w.stride_wf, st,
+                                        (use_pre && j == L) ? &pre : nullptr, w.stride_pre)))
                 return r;
             cum += n;
             if (layer >= 0) {
@@ -178,7 +207,7 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
             }
         }
         return launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u, M, w.stride_nh, w.stride_ea,
-                                  (size_t)PU, st);
+                                  (size_t)PU, st, use_pre ? w.pre : nullptr, w.stride_pre);
     }
     for (int m = 0; m < M; ++m) {  // piecewise path
         const float* W = b.weights + (size_t)m * wfloats;
@@ -197,7 +226,7 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
         }
         if ((r = launch_edge_embed(c, W, PU, g.diff_u, w.ea + (size_t)PU * H, st))) return r;
         if ((r = launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u + (size_t)m * PU, 1, 0, 0,
-                                    0, st)))
+                                    0, st, nullptr, 0)))
             return r;
     }
     return TSD_OK;
@@ -350,7 +379,7 @@ int tsd_interaction_block(const tsd_model_cfg* cfg, const float* w, int32_t laye
     return launch_layer_combo(*cfg, w, layer, num_nodes, enc, Wf_layer, x1_in, nullptr, h, x1_out,
                               filter_layer < 0 ? 0 : filter_layer, 0,
                               filter_layer < 0 ? 0 : filter_tiles_per_layer(capacity_u), capacity_u, enc_u, edge_attr,
-                              Wf_out, 1, 0, 0, 0, (hipStream_t)stream);
+                              Wf_out, 1, 0, 0, 0, (hipStream_t)stream, nullptr, 0);
 }
 
 int tsd_cfconv_aggregate(int32_t hidden, int32_t num_nodes, const int32_t* row_ptr, const int32_t* dst,
@@ -374,7 +403,7 @@ int tsd_pair_output(const tsd_model_cfg* cfg, const float* w, int32_t capacity, 
     int r = check_cfg(cfg);
     if (r) return r;
     return launch_pair_output(*cfg, w, capacity, out, h, edge_attr, attr_row, edge_inv, 1, 0, 0, 0,
-                              (hipStream_t)stream);
+                              (hipStream_t)stream, nullptr, 0);
 }
 
 int tsd_eq_transform(int32_t num_nodes, int64_t num_edges, const float* score_d, const float* pos,

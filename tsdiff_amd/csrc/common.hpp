@@ -88,6 +88,16 @@ inline WeightLayout weight_layout(const tsd_model_cfg& c) {
     return L;
 }
 
+// optional third role of the per-block launch (kernels_combo.hip), filled by the forward in api.hip
+struct ComboPre {
+    int tiles;  // 0: no pre role
+    tsd_edges e;
+    const float* edge_attr;
+    const int32_t* attr_row;  // edge_attr row of out edge e (NULL: e)
+    const float *w0b, *b0;    // packed W0 rows k in [H, 2H), bias
+    float* out;               // [capacity_u, H]
+};
+
 inline bool hidden_supported(int H) { return H == 64 || H == 128 || H == 256; }
 
 // ---------------------------------------------------------------------------------------------

@@ -332,15 +332,52 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
     }
 }
 
+// "pre" role: the half of the pair MLP's first layer that does not depend on the node states,
+//   pre[e] = edge_attr_out[e] . W0[:, H:2H]^T + b0                        (common.py:226-229, condensenc.py:236)
+// for a tile of 32 undirected out edges.  It rides in the LAST block launch, whose filter slot is empty (the node
+// chain of the last block occupies ~100 of the 256 CUs), and halves the first GEMM of pair_output_kernel.
+
+template <int H>
+__device__ __forceinline__ void pre_role(const ComboPre& q, int tile, float* smem) {
+    constexpr int LDA = H + 4, NT = 2 * H, C4 = H / 4;
+    float* buf = smem;
+    int* s_row = reinterpret_cast<int*>(smem + T * LDA);
+    const int E = *q.e.count;
+    const int e0 = tile * T;
+    if (e0 >= E) return;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int col0 = (tid >> 6) * 32;
+    const int nrows = min(T, E - e0);
+    if (tid < T) s_row[tid] = q.attr_row ? q.attr_row[e0 + min(tid, nrows - 1)] : e0 + min(tid, nrows - 1);
+    __syncthreads();
+    for (int idx = tid; idx < T * C4; idx += NT) {
+        const int r = idx / C4, c4 = idx % C4;
+        *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) =
+            *reinterpret_cast<const f32x4*>(q.edge_attr + (size_t)s_row[r] * H + c4 * 4);
+    }
+    __syncthreads();
+    f32x16 acc[1][1];
+    zero_acc(acc);
+    gemm_tile<1, 1, H>(buf, LDA, q.w0b, H, col0, acc);
+    const int col = col0 + l31;
+    const float b = q.b0[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi);
+        if (row < nrows) q.out[(size_t)(e0 + row) * H + col] = acc[0][0][r] + b;
+    }
+}
+
 struct ComboStride {  // per-checkpoint strides (blockIdx.y = checkpoint of the ensemble)
     size_t w, nh, ea, wf;
     int node_run;  // consecutive node tiles kept on one XCD (1: plain order)
     int phase_sleep;
+    size_t pre;    // stride of ComboPre::out
 };
 
 template <int H, int RB, int CBF, int PFF>
 __global__ __launch_bounds__(2 * H / CBF) void layer_combo_kernel(ComboNode a, int node_tiles, ComboFilter f,
-                                                                  ComboStride sd) {
+                                                                  ComboStride sd, ComboPre q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     {
         const size_t m = blockIdx.y;
@@ -350,6 +387,9 @@ __global__ __launch_bounds__(2 * H / CBF) void layer_combo_kernel(ComboNode a, i
         if (a.lin1_next_w) a.lin1_next_w += wo;
         f.Wl0 += wo;
         f.edge_attr += m * sd.ea; f.wf += m * sd.wf;
+        if (q.tiles) {
+            q.edge_attr += m * sd.ea; q.w0b += wo; q.b0 += wo; q.out += m * sd.pre;
+        }
     }
     if ((int)blockIdx.x < node_tiles) {
         // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), and the node
@@ -370,6 +410,10 @@ __global__ __launch_bounds__(2 * H / CBF) void layer_combo_kernel(ComboNode a, i
         // phase shift (experiment knob): workgroups of every second dispatch round start late, so that the two
         // workgroups sharing a CU do not run their load / epilogue phases in lockstep
         const int item = blockIdx.x - node_tiles;
+        if (CBF == 1 && item >= f.tiles) {  // (the pre role is built for the H/32-wave layout)
+            pre_role<H>(q, item - f.tiles, smem);
+            return;
+        }
         if (sd.phase_sleep > 0 && ((item >> 8) & 1)) {
             for (int k = 0; k < sd.phase_sleep; ++k) __builtin_amdgcn_s_sleep(32);  // 32 * 64 cycles = 0.85 us
         }
@@ -400,7 +444,7 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
                        const float* Wf_layer, const float* x1_in, const float* h_in, float* h, float* x1_out,
                        int layer_w0, int g_begin, int g_count,
                        int capacity_u, tsd_edges enc_u, const float* edge_attr, float* wf_base, int M, size_t nh_stride,
-                       size_t ea_stride, size_t wf_stride, hipStream_t st) {
+                       size_t ea_stride, size_t wf_stride, hipStream_t st, const ComboPre* pre, size_t pre_stride) {
     const WeightLayout L = weight_layout(c);
     ComboNode a{};
     a.N = N;
@@ -449,13 +493,15 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
         f.wf_layer_stride = (size_t)capacity_u * c.hidden;
     }
     const int node_tiles = layer == -2 ? 0 : (N + TN - 1) / TN;
-    const int grid = node_tiles + f.tiles;
+    ComboPre q{};
+    if (pre && pre->tiles > 0 && g_filter_rows != 64 && g_combo_cols != 64) q = *pre;  // H/32-wave layout only
+    const int grid = node_tiles + f.tiles + q.tiles;
     if (grid == 0) return TSD_OK;
     static const size_t lds_pad = getenv("TSDIFF_COMBO_LDS_PAD") ? (size_t)atoi(getenv("TSDIFF_COMBO_LDS_PAD")) : 0;
     const size_t lds = lds_combo(c.hidden, RBsel) + lds_pad;  // (experiment knob: caps the resident workgroups per CU)
     const int cols = g_combo_cols == 64 ? 64 : 32;
     static const int phase_sleep = getenv("TSDIFF_PHASE_SLEEP") ? atoi(getenv("TSDIFF_PHASE_SLEEP")) : 0;
-    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, g_node_run, phase_sleep};
+    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, g_node_run, phase_sleep, pre_stride};
 #define TSD_COMBO_RB(HH, RR, CC, PP)                                                                          \
     {                                                                                                         \
         static bool done = false;                                                                             \
@@ -464,7 +510,7 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
         done = true;                                                                                          \
         hipLaunchKernelGGL((layer_combo_kernel<HH, RR, CC, PP>), dim3(grid, M), dim3(2 * HH / CC), lds, st, a,\
-                           node_tiles, f, sd);                                                                \
+                           node_tiles, f, sd, q);                                                                \
     }
 #define TSD_COMBO(HH)                                                                                         \
     {                                                                                                         \

@@ -423,13 +423,15 @@ __global__ __launch_bounds__(2 * H) void pair_output_kernel(PairW w, tsd_edges e
                                                         const float* __restrict__ edge_attr,
                                                         const int32_t* __restrict__ attr_row,
                                                         float* __restrict__ edge_inv, size_t wstride,
-                                                        size_t h_stride, size_t ea_stride, size_t inv_stride) {
+                                                        size_t h_stride, size_t ea_stride, size_t inv_stride,
+                                                        const float* __restrict__ pre, size_t pre_stride) {
     constexpr int LDA = 2 * H + 4;
     constexpr int NW = H / 64;   // waves of the second GEMM (H/2 columns, 32 per wave); the block has 2 NW waves
     {  // blockIdx.y = checkpoint of the ensemble
         const size_t m = blockIdx.y, wo = m * wstride;
         w.w0 += wo; w.b0 += wo; w.w1 += wo; w.b1 += wo; w.w2 += wo; w.b2 += wo;
         h += m * h_stride; edge_attr += m * ea_stride; edge_inv += m * inv_stride;
+        if (pre) pre += m * pre_stride;
     }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* buf = smem;
@@ -463,24 +465,37 @@ __global__ __launch_bounds__(2 * H) void pair_output_kernel(PairW w, tsd_edges e
                 const f32x4 hs = *reinterpret_cast<const f32x4*>(h + (size_t)s_src[r] * H + c4 * 4);
                 const f32x4 hd = *reinterpret_cast<const f32x4*>(h + (size_t)s_dst[r] * H + c4 * 4);
                 a = hs * hd;
-                b = *reinterpret_cast<const f32x4*>(edge_attr + (size_t)s_row[r] * H + c4 * 4);
+                if (!pre) b = *reinterpret_cast<const f32x4*>(edge_attr + (size_t)s_row[r] * H + c4 * 4);
             }
             *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = a;
-            *reinterpret_cast<f32x4*>(buf + r * LDA + H + c4 * 4) = b;
+            if (!pre) *reinterpret_cast<f32x4*>(buf + r * LDA + H + c4 * 4) = b;
         }
     }
     __syncthreads();
 
-    {   // 2H -> H: H/32 waves x 32 columns
+    {   // 2H -> H on H/32 waves x 32 columns, summed as (edge_attr half + bias) then + (h_i*h_j half): the first
+        // part is node independent and normally arrives precomputed in `pre` (ComboPre role of the last block
+        // launch); without it the same two GEMMs run here, in the same order, so both forms are bit-identical
         f32x16 acc[1][1];
         const int col0 = wave * 32;
-        zero_acc(acc);
-        gemm_tile<1, 1, 2 * H>(buf, LDA, w.w0, H, col0, acc);
-        __syncthreads();
         const int col = col0 + l31;
-        const float b = w.b0[col];
+        if (pre) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) buf[acc_row(r, hi) * LDA + col] = swishf(acc[0][0][r] + b);
+            for (int r = 0; r < 16; ++r) {
+                const int row = acc_row(r, hi);
+                acc[0][0][r] = row < nrows ? pre[(size_t)(e0 + row) * H + col] : 0.0f;
+            }
+        } else {
+            zero_acc(acc);
+            gemm_tile<1, 1, H>(buf + H, LDA, w.w0 + (size_t)H * H, H, col0, acc);
+            const float b = w.b0[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] += b;
+        }
+        gemm_tile<1, 1, H>(buf, LDA, w.w0, H, col0, acc);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) buf[acc_row(r, hi) * LDA + col] = swishf(acc[0][0][r]);
         __syncthreads();
     }
     if (wave < NW) {  // H -> H/2 and the final dot: the first H/64 waves
@@ -652,7 +667,7 @@ int launch_node_lin1(const tsd_model_cfg& c, const float* W, int layer, int N, c
 
 int launch_pair_output(const tsd_model_cfg& c, const float* W, int capacity, tsd_edges e, const float* h,
                        const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
-                       size_t ea_stride, size_t inv_stride, hipStream_t st) {
+                       size_t ea_stride, size_t inv_stride, hipStream_t st, const float* pre, size_t pre_stride) {
     const WeightLayout L = weight_layout(c);
     PairW w{W + L.out_w0, W + L.out_b0, W + L.out_w1, W + L.out_b1, W + L.out_w2, W + L.out_b2};
     const int tiles = (capacity + T - 1) / T;
@@ -662,7 +677,7 @@ int launch_pair_output(const tsd_model_cfg& c, const float* W, int capacity, tsd
         static bool done = false; int r = allow_lds_once(pair_output_kernel<HH>, lds, done);
         if (r) return r;
         hipLaunchKernelGGL(pair_output_kernel<HH>, dim3(tiles, M), dim3(2 * HH), lds, st, w, e, h, edge_attr, attr_row,
-                           edge_inv, L.total, h_stride, ea_stride, inv_stride);
+                           edge_inv, L.total, h_stride, ea_stride, inv_stride, pre, pre_stride);
     });
     TSD_LAUNCH_CHECK("pair_output");
     return TSD_OK;
