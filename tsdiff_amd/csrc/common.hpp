@@ -224,7 +224,10 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ ldsA, int ld
 // k is permuted in groups of 16: step s of k-block kb consumes k = kb*16 + q*4 + s on lane quarter q, so a
 // lane reads one float4 of A and one float4 of B per column block per 4 MFMAs, from the SAME packed
 // weight layout ([k/4][out][k%4]) as the 32-row variant.  CB = 16-wide column blocks of this wave.
-template <int CB, int K>
+// PF / PIN as in gemm_tile: the node chain of the per-block launch is a latency chain that shares its CU with
+// filter workgroups streaming weights, so it prefetches deep (PF = K/32: the whole B slice of a GEMM in two
+// chunks, both in flight from the start) and pins that order.
+template <int CB, int K, int PF = 4, bool PIN = false>
 __device__ __forceinline__ void gemm_tile16(const float* __restrict__ ldsA, int lda,
                                             const float* __restrict__ Bp, int nout, int col0,
                                             f32x4 (&acc)[CB]) {
@@ -234,9 +237,8 @@ __device__ __forceinline__ void gemm_tile16(const float* __restrict__ ldsA, int 
     const float* aptr = ldsA + l15 * lda + q * 4;
     const f32x4* bptr = reinterpret_cast<const f32x4*>(Bp) + (size_t)q * nout + col0 + l15;
     constexpr int KB = K / 16;
-    constexpr int PF = 4;
     constexpr int NC = KB / PF;
-    static_assert(KB % PF == 0, "K must be a multiple of 64");
+    static_assert(KB % PF == 0, "K must be a multiple of 16 * PF");
     f32x4 b0[PF][CB], b1[PF][CB];
     auto loadB = [&](f32x4 (&b)[PF][CB], int chunk) {
 #pragma unroll
@@ -259,9 +261,13 @@ __device__ __forceinline__ void gemm_tile16(const float* __restrict__ ldsA, int 
     loadB(b0, 0);
     for (int c = 0; c < NC; c += 2) {
         if (c + 1 < NC) loadB(b1, c + 1);
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
         compute(b0, c);
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
         if (c + 2 < NC) loadB(b0, c + 2);
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < NC) compute(b1, c + 1);
+        if (PIN) __builtin_amdgcn_sched_barrier(0);
     }
 }
 

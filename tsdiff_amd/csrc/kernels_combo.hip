@@ -14,6 +14,10 @@
 
 #include "common.hpp"
 
+#ifndef TSD_NODE_PF_DEEP
+#define TSD_NODE_PF_DEEP 0  // measured: C2 0.556 vs 0.519 ms/step, C5 57.6 vs 52.0 with the deep pinned prefetch
+#endif
+
 namespace tsd {
 
 constexpr int T = TSD_EDGE_TILE;   // 32 edges per filter tile
@@ -54,11 +58,12 @@ struct ComboFilter {
 // reference schnet.py:101-107 (message/aggregate), :103 (lin2), :123-127, :223-224
 // -------------------------------------------------------------------------------------------------
 template <int H, int CBF>
-__device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* smem) {
+__device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* smem, int ablate = 0) {
     constexpr int LDA = H + 4;
     constexpr int NT = 2 * H / CBF;
     constexpr int NW = NT / 64;
     constexpr int CB16 = 2 * CBF;  // 16-wide column blocks per wave
+    constexpr int NPF = (TSD_NODE_PF_DEEP && H >= 128) ? H / 32 : 4;  // k-blocks per prefetch chunk of the node GEMMs
     constexpr int RPW = TN / NW;  // rows aggregated per wave
     constexpr int V = H / 64;     // channels per lane during aggregation
     constexpr int C4 = H / 4;
@@ -81,7 +86,7 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
             float s[V];
 #pragma unroll
             for (int v = 0; v < V; ++v) s[v] = 0.0f;
-            if (i < a.N) {
+            if (i < a.N && !(ablate & 16)) {
                 const int e0 = a.row_ptr[i], e1 = a.row_ptr[i + 1];
                 for (int eb = e0; eb < e1; eb += 64) {
                     const int cnt = min(64, e1 - eb);
@@ -155,7 +160,7 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
 
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) acc[cb] = zero4;
-        gemm_tile16<CB16, H>(buf, LDA, a.lin2_w, H, col0, acc);
+        if (!(ablate & 32)) gemm_tile16<CB16, H, NPF, (NPF > 4)>(buf, LDA, a.lin2_w, H, col0, acc);
         __syncthreads();
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
@@ -168,7 +173,7 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
 
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) acc[cb] = zero4;
-        gemm_tile16<CB16, H>(buf, LDA, a.lin_w, H, col0, acc);
+        if (!(ablate & 32)) gemm_tile16<CB16, H, NPF, (NPF > 4)>(buf, LDA, a.lin_w, H, col0, acc);
         __syncthreads();
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
@@ -200,7 +205,7 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
 
 #pragma unroll
     for (int cb = 0; cb < CB16; ++cb) acc[cb] = zero4;
-    gemm_tile16<CB16, H>(buf, LDA, a.lin1_next_w, H, col0, acc);
+    if (!(ablate & 32)) gemm_tile16<CB16, H, NPF, (NPF > 4)>(buf, LDA, a.lin1_next_w, H, col0, acc);
 #pragma unroll
     for (int cb = 0; cb < CB16; ++cb) {
         const int col = col0 + cb * 16 + l15;
@@ -219,7 +224,7 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
 // RB = 1: tiles of 32 edges (the default); RB = 2: tiles of 64 edges (every B fragment fetched from L2 feeds
 // twice the MFMAs; faster in the 4-wave probe, slower here -- see launch_layer_combo).  Bit-identical rows.
 template <int H, int RB, int CBF, int PFF>
-__device__ __forceinline__ void filter_role(const ComboFilter& f, int item, float* smem) {
+__device__ __forceinline__ void filter_role(const ComboFilter& f, int item, float* smem, int ablate = 0) {
     static_assert(RB == 1 || CBF == 1, "the 64-edge layout has its own wave mapping");
     constexpr int TR = T * RB;
     const int g = f.g_begin + item;
@@ -242,7 +247,7 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
     const int nrows = min(TR, E - e0);
 
     if (tid < TR) s_c[tid] = tid < nrows ? cutoff_weight(f.e.dist[e0 + tid], f.conv_cutoff, f.smooth) : 0.0f;
-    {   // edge_attr tile -> LDS with every load of a thread in flight together (rows past the end clamped)
+    if (!(ablate & 4)) {   // edge_attr tile -> LDS with every load of a thread in flight together (rows past the end clamped)
         constexpr int NIT = TR * C4 / NT;
         static_assert(TR * C4 % NT == 0, "tile / block mismatch");
         f32x4 v[NIT];
@@ -304,12 +309,15 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) buf[(rb * 32 + acc_row(r, hi)) * LDA + col] = sspf(acc[rb][cb][r] + b);
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[rb][cb][r] + b;
+                buf[(rb * 32 + acc_row(r, hi)) * LDA + col] = (ablate & 1) ? v : sspf(v);
+            }
     }
     __syncthreads();
 
     zero_acc(acc);
-    gemm_tile<RB, CBF, H, PFF, (PFF > 4)>(buf, LDA, nn2_w, H, col0, acc);
+    if (!(ablate & 8)) gemm_tile<RB, CBF, H, PFF, (PFF > 4)>(buf, LDA, nn2_w, H, col0, acc);
     __syncthreads();
 #pragma unroll
     for (int cb = 0; cb < CBF; ++cb) {
@@ -325,6 +333,7 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
     }
     }
     __syncthreads();
+    if (ablate & 2) return;
     for (int idx = tid; idx < nrows * C4; idx += NT) {
         const int r = idx / C4, c4 = idx % C4;
         *reinterpret_cast<f32x4*>(out + (size_t)(e0 + r) * H + c4 * 4) =
@@ -373,6 +382,9 @@ struct ComboStride {  // per-checkpoint strides (blockIdx.y = checkpoint of the 
     int node_run;  // consecutive node tiles kept on one XCD (1: plain order)
     int phase_sleep;
     size_t pre;    // stride of ComboPre::out
+    int node_prio; // raise the wave priority of the node role (TSDIFF_NODE_PRIO, default on)
+    int ablate;    // timing experiments only (TSDIFF_ABLATE): 1 no ssp, 2 no Wf store, 4 no tile load, 8 no 2nd GEMM,
+                   // 16 no aggregation, 32 no node GEMMs
 };
 
 template <int H, int RB, int CBF, int PFF>
@@ -405,7 +417,10 @@ __global__ __launch_bounds__(2 * H / CBF) void layer_combo_kernel(ComboNode a, i
                 tile = ((q / run) * 8 + x) * run + q % run;
             }
         }
-        node_role<H, CBF>(a, tile, smem);
+        // the node chain is the critical path of the launch (ablations: removing filter-role work barely shortens
+        // it): its waves get issue priority over the filter waves they share a SIMD with
+        if (sd.node_prio > 0) __builtin_amdgcn_s_setprio(3);
+        node_role<H, CBF>(a, tile, smem, sd.ablate);
     } else {
         // phase shift (experiment knob): workgroups of every second dispatch round start late, so that the two
         // workgroups sharing a CU do not run their load / epilogue phases in lockstep
@@ -417,7 +432,7 @@ __global__ __launch_bounds__(2 * H / CBF) void layer_combo_kernel(ComboNode a, i
         if (sd.phase_sleep > 0 && ((item >> 8) & 1)) {
             for (int k = 0; k < sd.phase_sleep; ++k) __builtin_amdgcn_s_sleep(32);  // 32 * 64 cycles = 0.85 us
         }
-        filter_role<H, RB, CBF, PFF>(f, item, smem);
+        filter_role<H, RB, CBF, PFF>(f, item, smem, sd.ablate);
     }
 }
 
@@ -501,7 +516,9 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     const size_t lds = lds_combo(c.hidden, RBsel) + lds_pad;  // (experiment knob: caps the resident workgroups per CU)
     const int cols = g_combo_cols == 64 ? 64 : 32;
     static const int phase_sleep = getenv("TSDIFF_PHASE_SLEEP") ? atoi(getenv("TSDIFF_PHASE_SLEEP")) : 0;
-    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, g_node_run, phase_sleep, pre_stride};
+    static const int ablate = getenv("TSDIFF_ABLATE") ? atoi(getenv("TSDIFF_ABLATE")) : 0;
+    static const int node_prio = getenv("TSDIFF_NODE_PRIO") ? atoi(getenv("TSDIFF_NODE_PRIO")) : 1;
+    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, g_node_run, phase_sleep, pre_stride, node_prio, ablate};
 #define TSD_COMBO_RB(HH, RR, CC, PP)                                                                          \
     {                                                                                                         \
         static bool done = false;                                                                             \
