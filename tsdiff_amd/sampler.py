@@ -49,29 +49,32 @@ class EnsembleSampler(nn.Module):
     # ------------------------------------------------------------------------------------------
     def step_coefficients(self, seq, seq_next, sampling_type, step_lr):
         """(n_steps, 8) fp32 table, one row per iteration in execution order, evaluated with the same
-        fp32 tensor expressions as the reference loop body (sampler.py:215-244)."""
+        fp32 tensor expressions as the reference loop body (sampler.py:215-244) -- elementwise on the
+        whole index vector at once (identical values: the reference's ops are elementwise too; a Python loop
+        over 5000 steps would put ~30 000 tiny launches in front of the sampling loop)."""
         dev = self.alphas.device
         sigmas = (1.0 - self.alphas).sqrt() / self.alphas.sqrt()
-        rows = []
+        idx = torch.tensor(list(reversed(seq)), dtype=torch.long, device=dev)
+        n = idx.numel()
+        zero = torch.zeros(n, dtype=torch.float32, device=dev)
         if sampling_type == "ld":
-            for i in reversed(seq):
-                step_size = step_lr * (sigmas[i] / 0.01) ** 2
-                rows.append(torch.stack([step_size, sigmas[i], torch.sqrt(step_size * 2)]
-                                        + [torch.zeros((), device=dev)] * 5))
+            sig = sigmas.index_select(0, idx)
+            step_size = step_lr * (sig / 0.01) ** 2
+            rows = torch.stack([step_size, sig, torch.sqrt(step_size * 2), zero, zero, zero, zero, zero], dim=1)
         elif sampling_type == "ddpm":
+            jdx = torch.tensor(list(reversed(seq_next)), dtype=torch.long, device=dev)
             beta = torch.cat([torch.zeros(1, device=dev), self.betas], dim=0)
             acp = (1 - beta).cumprod(dim=0)
-            for i, j in zip(reversed(seq), reversed(seq_next)):
-                at, atm1 = acp[i + 1], acp[j + 1]
-                beta_t = 1 - at / atm1
-                mask = 1.0 - float(i == 0)
-                rows.append(torch.stack([
-                    at.sqrt(), (1.0 / at).sqrt(), (1.0 / at - 1).sqrt(), atm1.sqrt() * beta_t,
-                    (1 - beta_t).sqrt() * (1 - atm1), 1.0 - at, mask * torch.exp(0.5 * beta_t.log()),
-                    atm1.sqrt()]))
+            at, atm1 = acp.index_select(0, idx + 1), acp.index_select(0, jdx + 1)
+            beta_t = 1 - at / atm1
+            mask = 1.0 - (idx == 0).to(torch.float32)
+            rows = torch.stack([
+                at.sqrt(), (1.0 / at).sqrt(), (1.0 / at - 1).sqrt(), atm1.sqrt() * beta_t,
+                (1 - beta_t).sqrt() * (1 - atm1), 1.0 - at, mask * torch.exp(0.5 * beta_t.log()),
+                atm1.sqrt()], dim=1)
         else:
             raise NotImplementedError(sampling_type)
-        return torch.stack(rows).to(torch.float32).contiguous()
+        return rows.to(torch.float32).contiguous()
 
     def dynamic_sampling(self, atom_type, r_feat, p_feat, pos_init, bond_index, bond_type, batch, num_graphs,
                          extend_order, extend_radius=True, n_steps=100, step_lr=0.0000010, clip=1000,
