@@ -41,14 +41,14 @@ int launch_geometry(const tsd_model_cfg&, int, int, int, const float*, const int
 int launch_geometry_count(const tsd_model_cfg&, int, const float*, const int32_t*, const int32_t*, const int32_t*,
                           const uint16_t*, tsd_geometry, hipStream_t);
 int launch_geometry_lists(const tsd_model_cfg&, int, int, const float*, const int32_t*, const int32_t*,
-                          const int32_t*, const uint16_t*, tsd_geometry, int32_t*, hipStream_t);
+                          const int32_t*, const uint16_t*, tsd_geometry, int32_t*, hipStream_t, bool);
 int launch_step_post(const tsd_model_cfg&, int, int, int, int, int, const int32_t*, const int32_t*, const uint16_t*,
                      tsd_geometry, const float*, const float*, const float*, float, float, float*, float*, int32_t*,
                      const int32_t*, hipStream_t);
 int launch_filter_gen(const tsd_model_cfg&, const float*, int, tsd_edges, const float*, float*, int, int,
                       hipStream_t);
 int launch_edge_embed2(const tsd_model_cfg&, const float*, int, tsd_edges, float*, int, tsd_edges, float*, int,
-                       size_t, hipStream_t);
+                       size_t, hipStream_t, const UmapRole*);
 int launch_layer_combo(const tsd_model_cfg&, const float*, int, int, tsd_edges, const float*, const float*,
                        const float*, float*, float*, int, int, int, int, tsd_edges, const float*, float*, int, size_t,
                        size_t, size_t, hipStream_t, const ComboPre*, size_t);
@@ -152,15 +152,26 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     if (!counts_ready) {
         if ((r = launch_geometry_count(c, N, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, g, st))) return r;
     }
-    if ((r = launch_geometry_lists(c, N, P, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, g, advance, st)))
+    // fused path: the directed-edge -> undirected-pair map is not needed before the first block launch, so it
+    // runs as an extra role of the edge-embedding launch instead of a launch of its own on the critical path
+    const bool fused = use_fused_path();
+    if ((r = launch_geometry_lists(c, N, P, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, g, advance, st,
+                                   fused)))
         return r;
     const Workspace w = carve(c, N, P, M, b.workspace);
     const size_t wfloats = weight_layout(c).total;
-    if (use_fused_path()) {
+    if (fused) {
         // one launch per interaction block: node chain of block l || filter GEMMs of block l+1;
         // all M checkpoints in the same launches (grid.y)
         const float* W = b.weights;
-        if ((r = launch_edge_embed2(c, W, PU, g.enc_u, w.ea, PU, g.diff_u, w.ea + (size_t)PU * H, M, w.stride_ea, st)))
+        UmapRole um{};
+        um.g = g;
+        um.graph_ptr = b.graph_ptr;
+        um.node_graph = b.node_graph;
+        um.pair_ptr = b.pair_ptr;
+        um.P = P;
+        if ((r = launch_edge_embed2(c, W, PU, g.enc_u, w.ea, PU, g.diff_u, w.ea + (size_t)PU * H, M, w.stride_ea, st,
+                                    &um)))
             return r;
         // block 0 reads z (residual input) and x1_0 = lin1_0(z) straight from the per-batch arrays -- both are
         // pos independent (computed at bind time) -- so no per-step copy of z and no lin1 launch

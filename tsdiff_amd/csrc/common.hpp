@@ -88,6 +88,41 @@ inline WeightLayout weight_layout(const tsd_model_cfg& c) {
     return L;
 }
 
+// directed edge e -> index of its undirected pair in the matching *_u list (needs every row's fill to be
+// complete).  Stand-alone: edge_umap_kernel (kernels_graph.hip); in the fused forward it rides as an extra role
+// of the edge-embedding launch, which needs the undirected lists only (UmapRole, kernels_mlp.hip).
+__device__ __forceinline__ void edge_umap_body(const tsd_geometry& g, const int32_t* __restrict__ graph_ptr,
+                                               const int32_t* __restrict__ node_graph,
+                                               const int32_t* __restrict__ pair_ptr, int P, int e) {
+    const int Ee = *g.enc.count, Eo = *g.out.count;
+    if (e < Ee) {
+        const int i = g.enc.src[e], j = g.enc.dst[e];
+        int p = g.enc.pair_id[e];
+        if (i > j) {
+            const int lo = graph_ptr[node_graph[i]];
+            const int il = i - lo, jl = j - lo;
+            p = pair_ptr[j] + il - (il > jl ? 1 : 0);
+        }
+        g.enc.umap[e] = g.pair2u[p];
+    }
+    if (e < Eo) {
+        const int i = g.out.src[e], j = g.out.dst[e];
+        int p = g.out.pair_id[e];
+        if (i > j) {
+            const int lo = graph_ptr[node_graph[i]];
+            const int il = i - lo, jl = j - lo;
+            p = pair_ptr[j] + il - (il > jl ? 1 : 0);
+        }
+        g.out.umap[e] = g.pair2u[(size_t)P + p];
+    }
+}
+struct UmapRole {
+    int blocks;  // 0: no umap role
+    tsd_geometry g;
+    const int32_t *graph_ptr, *node_graph, *pair_ptr;
+    int P;
+};
+
 // optional third role of the per-block launch (kernels_combo.hip), filled by the forward in api.hip
 struct ComboPre {
     int tiles;  // 0: no pre role

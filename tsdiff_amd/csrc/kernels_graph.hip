@@ -378,28 +378,7 @@ __global__ __launch_bounds__(256) void pair_fill_kernel(int N, const float* __re
 __global__ void edge_umap_kernel(tsd_geometry g, const int32_t* __restrict__ graph_ptr,
                                  const int32_t* __restrict__ node_graph, const int32_t* __restrict__ pair_ptr,
                                  int P) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    const int Ee = *g.enc.count, Eo = *g.out.count;
-    if (e < Ee) {
-        const int i = g.enc.src[e], j = g.enc.dst[e];
-        int p = g.enc.pair_id[e];
-        if (i > j) {
-            const int lo = graph_ptr[node_graph[i]];
-            const int il = i - lo, jl = j - lo;
-            p = pair_ptr[j] + il - (il > jl ? 1 : 0);
-        }
-        g.enc.umap[e] = g.pair2u[p];
-    }
-    if (e < Eo) {
-        const int i = g.out.src[e], j = g.out.dst[e];
-        int p = g.out.pair_id[e];
-        if (i > j) {
-            const int lo = graph_ptr[node_graph[i]];
-            const int il = i - lo, jl = j - lo;
-            p = pair_ptr[j] + il - (il > jl ? 1 : 0);
-        }
-        g.out.umap[e] = g.pair2u[(size_t)P + p];
-    }
+    edge_umap_body(g, graph_ptr, node_graph, pair_ptr, P, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 size_t geometry_scratch_ints(int N, int P) {
@@ -421,7 +400,7 @@ int launch_geometry_count(const tsd_model_cfg& c, int N, const float* pos, const
 // scan of the per-row counts (already in g.scratch) + fill + umap
 int launch_geometry_lists(const tsd_model_cfg& c, int N, int P, const float* pos, const int32_t* graph_ptr,
                           const int32_t* node_graph, const int32_t* pair_ptr, const uint16_t* pair_code,
-                          tsd_geometry g, int32_t* advance, hipStream_t st) {
+                          tsd_geometry g, int32_t* advance, hipStream_t st, bool skip_umap) {
     const float cut2 = c.edge_cutoff * c.edge_cutoff;
     ScanOut so;
     tsd_edges* lists[NLIST] = {&g.enc, &g.out, &g.enc_u, &g.out_u, &g.diff_u};
@@ -436,7 +415,7 @@ int launch_geometry_lists(const tsd_model_cfg& c, int N, int P, const float* pos
                            pair_ptr, pair_code, c.edge_order, c.pred_edge_order, cut2, g, P);
         TSD_LAUNCH_CHECK("pair_fill");
     }
-    if (P > 0) {
+    if (P > 0 && !skip_umap) {  // (skipped when the caller runs the umap as a role of the embedding launch)
         hipLaunchKernelGGL(edge_umap_kernel, dim3((P + 255) / 256), dim3(256), 0, st, g, graph_ptr, node_graph,
                            pair_ptr, P);
         TSD_LAUNCH_CHECK("edge_umap");
@@ -450,7 +429,7 @@ int launch_geometry(const tsd_model_cfg& c, int N, int G, int P, const float* po
     (void)G;
     int r = launch_geometry_count(c, N, pos, graph_ptr, node_graph, pair_ptr, pair_code, g, st);
     if (r) return r;
-    return launch_geometry_lists(c, N, P, pos, graph_ptr, node_graph, pair_ptr, pair_code, g, nullptr, st);
+    return launch_geometry_lists(c, N, P, pos, graph_ptr, node_graph, pair_ptr, pair_code, g, nullptr, st, false);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -34,8 +34,15 @@ struct PairW {
 template <int H>
 __global__ __launch_bounds__(2 * H) void edge_embed_kernel(EdgeEmbedW w, tsd_edges ea_, float* __restrict__ out_a,
                                                        int tiles_a, tsd_edges eb_, float* __restrict__ out_b,
-                                                       size_t wstride, size_t out_stride) {
+                                                       size_t wstride, size_t out_stride, int embed_tiles,
+                                                       UmapRole um) {
     constexpr int LDA = 2 * H + 4;
+    if ((int)blockIdx.x >= embed_tiles) {  // extra role: directed-edge -> undirected-pair map (checkpoint 0 only)
+        if (blockIdx.y == 0)
+            edge_umap_body(um.g, um.graph_ptr, um.node_graph, um.pair_ptr, um.P,
+                           ((int)blockIdx.x - embed_tiles) * (2 * H) + (int)threadIdx.x);
+        return;
+    }
     {  // blockIdx.y = checkpoint of the ensemble: its weight arena and its output block
         const size_t wo = (size_t)blockIdx.y * wstride, oo = (size_t)blockIdx.y * out_stride;
         w.bond_emb += wo; w.w0 += wo; w.b0 += wo; w.w1 += wo; w.b1 += wo;
@@ -567,18 +574,23 @@ static int allow_lds_once(K kernel, size_t bytes, bool& done) {
     }
 
 int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_edges ea, float* out_a, int cap_b,
-                       tsd_edges eb, float* out_b, int M, size_t out_stride, hipStream_t st) {
+                       tsd_edges eb, float* out_b, int M, size_t out_stride, hipStream_t st, const UmapRole* umap) {
     const WeightLayout L = weight_layout(c);
     EdgeEmbedW w{W + L.bond_emb, W + L.emlp_w0, W + L.emlp_b0, W + L.emlp_w1, W + L.emlp_b1,
                  W + L.ecat_w0, W + L.ecat_b0, W + L.ecat_w1, W + L.ecat_b1};
     const int tiles_a = (cap_a + T - 1) / T, tiles_b = (cap_b + T - 1) / T;
-    if (tiles_a + tiles_b == 0) return TSD_OK;
+    UmapRole um{};
+    if (umap && umap->P > 0) {
+        um = *umap;
+        um.blocks = (um.P + 2 * c.hidden - 1) / (2 * c.hidden);
+    }
+    if (tiles_a + tiles_b + um.blocks == 0) return TSD_OK;
     const size_t lds = lds_edge_embed(c.hidden);
     TSD_DISPATCH_H(c.hidden, {
         static bool done = false; int r = allow_lds_once(edge_embed_kernel<HH>, lds, done);
         if (r) return r;
-        hipLaunchKernelGGL(edge_embed_kernel<HH>, dim3(tiles_a + tiles_b, M), dim3(2 * HH), lds, st, w, ea, out_a, tiles_a,
-                           eb, out_b, L.total, out_stride);
+        hipLaunchKernelGGL(edge_embed_kernel<HH>, dim3(tiles_a + tiles_b + um.blocks, M), dim3(2 * HH), lds, st, w, ea,
+                           out_a, tiles_a, eb, out_b, L.total, out_stride, tiles_a + tiles_b, um);
     });
     TSD_LAUNCH_CHECK("edge_embed");
     return TSD_OK;
@@ -586,7 +598,7 @@ int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_ed
 
 int launch_edge_embed(const tsd_model_cfg& c, const float* W, int capacity, tsd_edges e, float* edge_attr,
                       hipStream_t st) {
-    return launch_edge_embed2(c, W, capacity, e, edge_attr, 0, e, edge_attr, 1, 0, st);
+    return launch_edge_embed2(c, W, capacity, e, edge_attr, 0, e, edge_attr, 1, 0, st, nullptr);
 }
 
 int launch_cfconv_layer(const tsd_model_cfg& c, const float* W, int layer, int capacity, tsd_edges e,
