@@ -68,8 +68,9 @@ def dp_backward(model, loss_nodes, group=None):
     tensor (no host sync anywhere in here: the host keeps enqueueing the optimizer step and the next batch
     while the GPU is still in the backward pass; call `.item()` when a number is needed)."""
     distributed = dist.is_initialized() and dist.get_world_size(group) > 1
-    stats = torch.stack([loss_nodes.detach().sum(), torch.tensor(float(loss_nodes.shape[0]),
-                                                                  device=loss_nodes.device)])
+    # (new_full is a fill kernel: torch.tensor(x, device=cuda) would be a synchronous host-to-device copy, i.e.
+    # a hidden stream sync between the forward and the backward pass)
+    stats = torch.stack([loss_nodes.detach().sum(), loss_nodes.new_full((), float(loss_nodes.shape[0]))])
     if distributed:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
     (loss_nodes.sum() / stats[1]).backward()

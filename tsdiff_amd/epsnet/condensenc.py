@@ -120,8 +120,18 @@ class CondenseEncoderEpsNetwork(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _weight_tensors(self):
-        sd = dict(self.named_parameters())
-        return {n: sd[n] for n in engine.raw_param_names(self._cfg.num_convs)}
+        return dict(zip(engine.raw_param_names(self._cfg.num_convs), self.raw_params()))
+
+    def raw_params(self):
+        """the trainable tensors in the order of the flat parameter vector (engine.raw_param_names); cached: walking
+        the module tree costs ~0.4 ms, once per training step otherwise.  nn.Module._apply (.to / .cuda / .float)
+        keeps the Parameter objects, so the list stays valid."""
+        lst = getattr(self, "_raw_param_list", None)
+        if lst is None:
+            P = dict(self.named_parameters())
+            lst = [P[n] for n in engine.raw_param_names(self._cfg.num_convs)]
+            self._raw_param_list = lst
+        return lst
 
     def packed_weights(self):
         """MFMA-packed fp32 arena in HBM, rebuilt when any parameter changed (version counters)."""
@@ -154,7 +164,7 @@ class CondenseEncoderEpsNetwork(nn.Module):
         With autograd enabled the result is differentiable w.r.t. the parameters (training primitives,
         tsdiff_amd/train_ops.py); under torch.no_grad() the fused inference kernels run."""
         db = self.device_batch(atom_type, r_feat, p_feat, bond_index, bond_type, batch)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.raw_params()):
             from .. import train_ops as T
             pos_c = pos.detach().to(torch.float32).contiguous()
             s_u, _ = T.train_forward(self, db, pos_c)
@@ -197,7 +207,7 @@ class CondenseEncoderEpsNetwork(nn.Module):
         a_pos = a.index_select(0, node2graph).unsqueeze(-1)
         pos_noise = torch.randn(size=pos.size(), device=dev) if _pos_noise is None else _pos_noise
         pos_perturbed = (pos + pos_noise * (1.0 - a_pos).sqrt() / a_pos.sqrt()).contiguous()
-        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.raw_params())
         fused = training and os.environ.get("TSDIFF_TRAIN", "fused") != "ops"
         # (the fused step reads the topology status together with its edge counts: one host sync less per batch)
         db = self.device_batch(atom_type, r_feat, p_feat, bond_index, bond_type, batch, num_nodes_per_graph,

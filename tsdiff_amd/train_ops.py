@@ -531,7 +531,4 @@ class FusedTrainLoss(torch.autograd.Function):
 
 
 def fused_train_loss(model, db, pos0, pos_perturbed, a_graph):
-    from . import engine
-    P = dict(model.named_parameters())
-    params = [P[n] for n in engine.raw_param_names(model._cfg.num_convs)]
-    return FusedTrainLoss.apply(model, db, pos0, pos_perturbed, a_graph, *params)
+    return FusedTrainLoss.apply(model, db, pos0, pos_perturbed, a_graph, *model.raw_params())
