@@ -347,6 +347,35 @@ def test_sampler_vs_reference_trajectory(name, use_graph, dev):
     assert_close(pos.cpu().numpy(), d["pos_final"], 5e-5, "final positions")
 
 
+def test_python_level_sampler_loop_over_forward_matches_reference_trajectory(dev):
+    """drop-in at the forward() level: a host-side Langevin loop written the way models/sampler.py:187-254 drives a
+    model -- model.forward() per step, eq_transform, clip_norm, update, center_pos in torch -- on top of the
+    tsdiff_amd model reproduces the reference's 50-step trajectory (so the reference's own unmodified sampler
+    class, which only calls forward() and eq_transform, works over these models too)"""
+    from tsdiff_amd.geometry import eq_transform
+    from tsdiff_amd.sampler import center_pos, clip_norm
+    d, meta = load_golden("ld_rxn0_b1_full_50")
+    g = to_dev(batch_inputs(d), dev)
+    model = make_model(meta["cfg"], meta["seeds"][0], dev)
+    n_steps, step_lr, clip = meta["n_steps"], meta["step_lr"], meta["clip"]
+    sigmas = (1.0 - model.alphas).sqrt() / model.alphas.sqrt()
+    T = model.num_timesteps
+    pos = torch.from_numpy(d["pos_init"]).to(dev) * sigmas[-1]
+    noises = torch.from_numpy(d["noises"]).to(dev)
+    traj = []
+    with torch.no_grad():
+        for k, i in enumerate(reversed(range(T - n_steps, T))):
+            t = torch.full((g["num_graphs"],), i, dtype=torch.long, device=dev)
+            edge_inv, edge_index, edge_length = model(g["atom_type"], g["r_feat"], g["p_feat"], pos, g["bond_index"],
+                                                      g["bond_type"], g["batch"], t, return_edges=True)
+            eps_pos = clip_norm(eq_transform(edge_inv, pos, edge_index, edge_length), limit=clip)
+            step_size = step_lr * (sigmas[i] / 0.01) ** 2
+            pos = pos + step_size * eps_pos / sigmas[i] + noises[k] * torch.sqrt(step_size * 2)
+            pos = center_pos(pos, g["batch"])
+            traj.append(pos.clone())
+    assert_close(torch.stack(traj).cpu().numpy(), d["traj"], 5e-5, "python-level loop trajectory")
+
+
 def test_graph_replay_equals_eager(dev):
     from tsdiff_amd import synth
     from tsdiff_amd.sampler import EnsembleSampler
