@@ -534,6 +534,16 @@ def test_edge_cases(dev):
     with pytest.raises(ValueError):  # bond across graphs
         model(atom, feat, feat, pos, torch.tensor([[0, 1], [1, 0]], device=dev), torch.tensor([23, 23], device=dev),
               batch, torch.zeros(3, dtype=torch.long, device=dev))
+    # the training step reads the topology status together with its edge counts: same error, and the edge-case
+    # batch (1-atom graph, edge-less graph) trains
+    model.train()
+    nn_ = torch.tensor([1, 2, 3], device=dev)
+    with pytest.raises(ValueError):
+        model.get_loss(atom, feat, feat, pos, bi[:, :3].contiguous(), bt[:3].contiguous(), batch, nn_, 3)
+    loss = model.get_loss(atom, feat, feat, pos, bi, bt, batch, nn_, 3)
+    loss.mean().backward()
+    assert torch.isfinite(loss).all() and loss.shape == (6, 1)
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
 
 
 def test_full_size_properties(dev):
