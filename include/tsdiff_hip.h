@@ -26,9 +26,12 @@
  *   - the library never allocates or frees device memory: outputs and scratch are caller
  *     allocated (torch's caching allocator on the Python side);
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), performs no
- *     host synchronisation (one exception: tsd_sampler_run with use_graph waits for the stream once at
- *     the end, to release its graph) and returns 0 on success or a negative TSD_ERR_* code;
+ *     host synchronisation (exceptions, each documented at its declaration: the one-shot tsd_sampler_run
+ *     and tsd_train_forward) and returns 0 on success or a negative TSD_ERR_* code;
  *     tsd_last_error() returns a thread-local message for the last failure;
+ *   - no mutable process-global state: the only globals are that thread-local error string and
+ *     per-device "kernel attributes set" bits; a process may drive several devices (the device current
+ *     at the call is used), one stream per call;
  *   - floating point is fp32 end to end (fp32 MFMA, exact-f32 FMA chains); indices at this
  *     boundary are int32 except where the reference surface hands over int64 tensors
  *     (bond_index, bond_type, atom_type, r_feat, p_feat);
@@ -103,18 +106,6 @@ typedef struct tsd_geometry {
 } tsd_geometry;
 
 const char* tsd_version(void);
-/* Edge rows per workgroup tile of the filter role of tsd_interaction_block / tsd_score_forward:
- * 0 = default (32), or force 32 / 64 (process-wide; 64 measured slower at every size, kept as an A/B knob). */
-int tsd_set_filter_tile(int32_t rows);
-/* A/B knob of the same launch: output columns per wave, 0 = library default, 32 (H/32 waves per workgroup, one
- * accumulator block per wave) or 64 (H/64 waves, two accumulator blocks per B fragment).  Bit-identical results. */
-int tsd_set_combo_cols(int32_t cols);
-/* XCD-aware node-tile order of the same launch: runs of `run` consecutive 16-node tiles (one 64-atom graph = 4
- * tiles) are kept on ONE XCD, whose L2 then serves the x1 / filter rows they share.  1 = plain order. */
-int tsd_set_node_run(int32_t run);
-/* B-operand prefetch of the filter role: 0 / 4 = four k-blocks per chunk, placement left to the compiler's
- * scheduler; 8 = eight k-blocks per chunk, the chunked pipeline pinned with scheduling barriers. */
-int tsd_set_combo_prefetch(int32_t kblocks);
 const char* tsd_last_error(void);
 
 /* ---- weights ---------------------------------------------------------------------------
@@ -249,13 +240,53 @@ int tsd_sampler_step(int32_t kind, int32_t num_nodes, int32_t num_graphs, const 
                      const float* score_pos, const float* noise, const float* coefs /* [8] device */,
                      float clip, float clip_pos /* <0: none */, float* pos, int32_t* status, void* stream);
 
-/* The device-resident sampling loop: n_steps x (geometry, M forwards, mean, eq_transform,
- * update, centre).  coefs [n_steps,8], noises [n_steps,N,3]; traj [n_steps,N,3] or NULL.
- * use_graph != 0 captures one step into a hipGraph and replays it. */
+/* ---- the device-resident sampling loop (reference models/sampler.py:187-254) --------------------
+ * One step = geometry lists, M forwards, ensemble mean, eq_transform, clip, LD/DDPM update, NaN flag,
+ * centring, and the member counts of the next step's lists.  A *plan* is a host object holding ONE such step
+ * captured into a hipGraph and instantiated; it is created once per (batch, bound checkpoints, kind, clip)
+ * and replayed by every later call, so that a call costs its launches only (r01: capture + instantiate +
+ * destroy were ~11 ms inside every call).  Everything a call may change is read by the captured kernels
+ * from `tsd_sampler_state`, a 64-byte block of DEVICE memory owned by the caller. */
+typedef struct tsd_run_args {
+    const float* coefs;   /* [n_steps, TSD_STEP_COEFS] */
+    const float* noises;  /* [n_steps, N, 3] injected Gaussian draws (parity tests), or NULL: the draws of
+                             sampler.py:213 are generated on the device, Philox4x32-10 keyed by `seed`,
+                             counter = offset + step * N + atom, Box-Muller -> 3 of 4 normals */
+    float* traj;          /* [n_steps, N, 3] or NULL */
+    uint64_t seed;
+    uint64_t offset;
+} tsd_run_args;
+typedef struct tsd_sampler_state {
+    int32_t flags;        /* TSD_STATUS_* bits, sticky; the caller zeroes and reads them */
+    int32_t step;         /* device-side step counter (row of coefs / noises / traj) */
+    int32_t reserved[2];
+    tsd_run_args args;    /* written by tsd_sampler_plan_run */
+    int32_t pad[2];
+} tsd_sampler_state;
+typedef struct tsd_sampler_plan tsd_sampler_plan;
+
+/* Captures one step on `stream` (must not be the legacy default stream) into a graph; nothing executes.
+ * `batch`'s arrays, `pos` [N,3] (updated in place by every step) and `state` must stay alive and unmoved
+ * for the life of the plan.  kind 0 = LD, 1 = DDPM; clip_pos < 0: no clamp. */
+int tsd_sampler_plan_create(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t kind, float clip,
+                            float clip_pos, float* pos, tsd_sampler_state* state, void* stream,
+                            tsd_sampler_plan** plan_out);
+/* n_steps steps from the current contents of `pos`; asynchronous, no host sync.  use_graph == 0 launches the
+ * same kernels eagerly (bit-identical; tests).  Calls on one plan must be stream-ordered. */
+int tsd_sampler_plan_run(tsd_sampler_plan* plan, int32_t n_steps, const tsd_run_args* args, int32_t use_graph,
+                         void* stream);
+/* The caller must have synchronised with every stream the plan was run on. */
+void tsd_sampler_plan_destroy(tsd_sampler_plan* plan);
+
+/* One-shot form: plan_create + plan_run + stream synchronise + plan_destroy (use the plan calls to keep the
+ * graph across calls).  noises NULL: device Philox with (seed, offset). */
 int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t kind, int32_t n_steps,
-                    const float* coefs, const float* noises, float clip, float clip_pos,
-                    float* pos, float* traj, int32_t* status /* [2]: flags, step counter */,
-                    int32_t use_graph, void* stream);
+                    const float* coefs, const float* noises, uint64_t seed, uint64_t offset, float clip,
+                    float clip_pos, float* pos, float* traj, tsd_sampler_state* state, int32_t use_graph,
+                    void* stream);
+/* The normal draws of the device generator alone: out[k] for k in [0, 3 n): atom i = k / 3 of counter
+ * offset + i (what step s of a run with N atoms uses at offset + s * N).  Tests / reproducibility. */
+int tsd_philox_normal(uint64_t seed, uint64_t offset, int64_t n_atoms, float* out /* [n_atoms, 3] */, void* stream);
 
 /* ---- training primitives (BASELINE config 4; reference train.py:124-152, condensenc.py:267-328) -----
  * One launch per operation: every dense layer's forward / dgrad / wgrad on the fp32 MFMA, the graph-shaped

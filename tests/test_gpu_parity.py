@@ -741,23 +741,141 @@ def test_degenerate_batches(dev):
                   torch.zeros(1, dtype=torch.long, device=dev))
 
 
-def test_filter_tile_64_is_bit_identical_to_32(dev):
-    """the 64-edge filter tiles used for large launches compute every row exactly like the 32-edge tiles"""
-    from tsdiff_amd import _lib, synth
-    lib = _lib.load()
-    cfg = synth.DEFAULT_MODEL_CONFIG
-    model = make_model(cfg, 0, dev)
-    b = synth.wb97xd3_like_batch(30, seed=2)
+def _sampling_setup(dev, graphs=6, seed=9, hidden=64, convs=2, model_seeds=(4,)):
+    from tsdiff_amd import synth
+    from tsdiff_amd.sampler import EnsembleSampler
+    cfg = synth.small_model_config(hidden, convs)
+    models = [make_model(cfg, s, dev) for s in model_seeds]
+    b = synth.wb97xd3_like_batch(graphs, seed=seed)
     g = to_dev({k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}, dev)
-    g["pos"] = g["pos"] * 2.0
-    outs = []
-    try:
-        for rows in (32, 64):
-            _lib.check(lib.tsd_set_filter_tile(rows))
-            outs.append(run_forward(model, {**g, "num_graphs": 30}, dev)[0].clone())
-    finally:
-        _lib.check(lib.tsd_set_filter_tile(0))
-    assert torch.equal(outs[0], outs[1])
+    return EnsembleSampler(models), g, graphs
+
+
+def _sample(ens, g, G, n_steps, **kw):
+    return ens.dynamic_sampling(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
+                                g["batch"], G, True, n_steps=n_steps, step_lr=1e-7, clip=1000, sampling_type="ld", **kw)
+
+
+def test_cached_step_graph_is_reused_and_call_independent(dev):
+    """the step graph is captured once per (batch, checkpoints, kind, clip) and replayed by later calls with other
+    noise buffers, step counts and trajectories: results equal the eager launches bit for bit every time"""
+    ens, g, G = _sampling_setup(dev)
+    N = g["pos"].shape[0]
+    db = ens._bound_batch(g["atom_type"], g["r_feat"], g["p_feat"], g["bond_index"], g["bond_type"], g["batch"])
+    assert len(db._plans) == 0
+    res = []
+    for n_steps in (7, 3, 12):
+        noises = torch.randn(n_steps, N, 3, device=dev)
+        a_pos, a_traj = _sample(ens, g, G, n_steps, noises=noises, use_graph=True)
+        plans = dict(db._plans)
+        assert len(plans) == 1
+        e_pos, e_traj = _sample(ens, g, G, n_steps, noises=noises, use_graph=False)
+        assert torch.equal(a_pos, e_pos) and torch.equal(torch.stack(a_traj), torch.stack(e_traj))
+        res.append(plans)
+    assert res[0][next(iter(res[0]))].value == res[2][next(iter(res[2]))].value  # the same plan object served all calls
+    # another clip value is another plan; new weights drop the plans of the old ones
+    ens.dynamic_sampling(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
+                         g["batch"], G, True, n_steps=2, step_lr=1e-7, clip=10, sampling_type="ld")
+    assert len(db._plans) == 2
+    with torch.no_grad():
+        ens.models[0].edge_encoder.bond_emb.weight.add_(0.0)  # bumps the version counter: weights are re-packed
+    _sample(ens, g, G, 2)
+    assert len(db._plans) == 1
+
+
+def test_device_philox_noise_reproducible_and_normal(dev):
+    """noises=None: the Gaussian draws of sampler.py:213 come from the in-kernel Philox generator -- bitwise
+    reproducible for a seed (graph == eager, chunked == whole), different across seeds and steps, N(0,1) moments"""
+    import ctypes as C
+    from tsdiff_amd import _lib
+    lib = _lib.load()
+    n = 400_000
+    z = torch.empty(n, 3, device=dev)
+    _lib.check(lib.tsd_philox_normal(77, 5, n, _lib.ptr(z), _lib.stream_ptr()))
+    zc = z.double().cpu()
+    assert abs(float(zc.mean())) < 4e-3 and abs(float(zc.var()) - 1.0) < 6e-3
+    assert abs(float((zc ** 3).mean())) < 2e-2 and abs(float((zc ** 4).mean()) - 3.0) < 5e-2
+    cm = np.corrcoef(zc.numpy().T)
+    assert np.abs(cm - np.eye(3)).max() < 6e-3       # the three components of an atom are uncorrelated
+    assert abs(float((zc[:-1, 0] * zc[1:, 0]).mean())) < 6e-3  # neighbouring counters too
+    z2 = torch.empty(n, 3, device=dev)
+    _lib.check(lib.tsd_philox_normal(77, 5, n, _lib.ptr(z2), _lib.stream_ptr()))
+    assert torch.equal(z, z2)
+    _lib.check(lib.tsd_philox_normal(78, 5, n, _lib.ptr(z2), _lib.stream_ptr()))
+    assert not torch.equal(z, z2)
+    _lib.check(lib.tsd_philox_normal(77, 6, n - 1, _lib.ptr(z2), _lib.stream_ptr()))  # counter = offset + atom
+    assert torch.equal(z[1:], z2[: n - 1])
+    # known-answer test of the block function: Random123's kat vector for philox4x32-10, all-ones counter/key is
+    # not expressible through this interface (counter words 2,3 are 0), so pin zero counter / zero key instead
+    # philox4x32_10(ctr=0, key=0) = 6627e8d5 e169c58d bc57ac4c 9b00dbd8 (Random123 kat_vectors)
+    _lib.check(lib.tsd_philox_normal(0, 0, 1, _lib.ptr(z2), _lib.stream_ptr()))
+    u0 = ((0x6627e8d5 >> 8) + 0.5) / 16777216.0
+    u1 = ((0xe169c58d >> 8) + 0.5) / 16777216.0
+    exp0 = np.sqrt(-2 * np.log(u0)) * np.cos(2 * np.pi * u1)
+    assert abs(float(z2[0, 0]) - exp0) < 1e-5
+
+    ens, g, G = _sampling_setup(dev)
+    N = g["pos"].shape[0]
+    a, ta = _sample(ens, g, G, 9, seed=123)
+    b, tb = _sample(ens, g, G, 9, seed=123, use_graph=False)
+    c, _ = _sample(ens, g, G, 9, seed=124)
+    assert torch.equal(a, b) and torch.equal(torch.stack(ta), torch.stack(tb)) and not torch.equal(a, c)
+    # the same run with the draws materialised by tsd_philox_normal and injected: identical trajectory
+    nz = torch.empty(9, N, 3, device=dev)
+    _lib.check(lib.tsd_philox_normal(123, 0, 9 * N, _lib.ptr(nz), _lib.stream_ptr()))
+    d, td = _sample(ens, g, G, 9, noises=nz)
+    assert torch.equal(a, d) and torch.equal(torch.stack(ta), torch.stack(td))
+    torch.manual_seed(5)
+    e1, _ = _sample(ens, g, G, 4)
+    torch.manual_seed(5)
+    e2, _ = _sample(ens, g, G, 4)
+    assert torch.equal(e1, e2)  # seeded from torch's generator: torch.manual_seed reproduces a run
+
+
+def test_one_shot_sampler_run_abi(dev):
+    """tsd_sampler_run (plan create + run + sync + destroy in one call) == the cached-plan path"""
+    import ctypes as C
+    from tsdiff_amd import _lib
+    lib = _lib.load()
+    ens, g, G = _sampling_setup(dev, model_seeds=(4, 5))
+    N = g["pos"].shape[0]
+    noises = torch.randn(5, N, 3, device=dev)
+    ref, ref_traj = _sample(ens, g, G, 5, noises=noises)
+    db = ens._bound_batch(g["atom_type"], g["r_feat"], g["p_feat"], g["bond_index"], g["bond_type"], g["batch"])
+    sig = (1.0 - ens.alphas).sqrt() / ens.alphas.sqrt()
+    T = ens.num_timesteps
+    coefs = ens.step_coefficients(list(range(T - 5, T)), [-1] + list(range(T - 5, T - 1)), "ld", 1e-7)
+    for use_graph in (1, 0):
+        pos = (g["pos"] * sig[-1]).contiguous()
+        traj = torch.empty(5, N, 3, device=dev)
+        state = torch.zeros(_lib.SAMPLER_STATE_INTS, dtype=torch.int32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        b = db.struct()
+        _lib.check(lib.tsd_sampler_run(C.byref(db.cfg), C.byref(b), 0, 5, _lib.ptr(coefs), _lib.ptr(noises), 0, 0,
+                                       1000.0, -1.0, _lib.ptr(pos), _lib.ptr(traj), _lib.ptr(state), use_graph,
+                                       C.c_void_p(side.cuda_stream)))
+        side.synchronize()
+        assert int(state[0]) == 0 and int(state[1]) == 4
+        assert torch.equal(pos, ref) and torch.equal(traj.cpu(), torch.stack(ref_traj))
+    # capture on the legacy default stream is refused, not crashed
+    plan = C.c_void_p()
+    rc = lib.tsd_sampler_plan_create(C.byref(db.cfg), C.byref(db.struct()), 0, 1000.0, -1.0, _lib.ptr(db.pos_work),
+                                     _lib.ptr(db.status), C.c_void_p(0), C.byref(plan))
+    assert rc == _lib.TSD_ERR_INVALID
+
+
+def test_ensemble_members_must_share_the_config(dev):
+    from tsdiff_amd import synth
+    from tsdiff_amd.sampler import EnsembleSampler
+    cfg_a = synth.small_model_config(64, 2)
+    cfg_b = dict(cfg_a, edge_order=3)
+    ens = EnsembleSampler([make_model(cfg_a, 1, dev), make_model(cfg_b, 2, dev)])
+    b = synth.wb97xd3_like_batch(2, seed=1)
+    g = to_dev({k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}, dev)
+    with pytest.raises(NotImplementedError):
+        ens(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"],
+            torch.zeros(2, dtype=torch.long, device=dev))
 
 
 def test_piecewise_step_equals_fused_loop(dev):

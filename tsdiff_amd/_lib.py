@@ -86,16 +86,25 @@ class Batch(C.Structure):
     ]
 
 
+class RunArgs(C.Structure):  # tsd_run_args
+    _fields_ = [
+        ("coefs", C.c_void_p),
+        ("noises", C.c_void_p),
+        ("traj", C.c_void_p),
+        ("seed", C.c_uint64),
+        ("offset", C.c_uint64),
+    ]
+
+
+SAMPLER_STATE_INTS = 16  # sizeof(tsd_sampler_state) / 4; [0] = flags, [1] = step counter
+
+
 # name -> (restype, argtypes); every symbol declared in include/tsdiff_hip.h
 _P = C.c_void_p
 _CFG = C.POINTER(ModelCfg)
 SIGNATURES = {
     "tsd_version": (C.c_char_p, []),
     "tsd_last_error": (C.c_char_p, []),
-    "tsd_set_filter_tile": (C.c_int, [C.c_int32]),
-    "tsd_set_combo_cols": (C.c_int, [C.c_int32]),
-    "tsd_set_node_run": (C.c_int, [C.c_int32]),
-    "tsd_set_combo_prefetch": (C.c_int, [C.c_int32]),
     "tsd_raw_weight_floats": (C.c_size_t, [_CFG]),
     "tsd_packed_weight_floats": (C.c_size_t, [_CFG]),
     "tsd_pack_weights": (C.c_int, [_CFG, _P, _P, _P]),
@@ -149,8 +158,13 @@ SIGNATURES = {
                                    _P, _P, _P]),
     "tsd_embedding_renorm": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.c_float, _P, _P, _P]),
     "tsd_dual_score": (C.c_int, [C.c_int32, _P, _P, C.c_float, C.c_float, C.c_float, _P, _P]),
-    "tsd_sampler_run": (C.c_int, [_CFG, C.POINTER(Batch), C.c_int32, C.c_int32, _P, _P, C.c_float, C.c_float,
-                                  _P, _P, _P, C.c_int32, _P]),
+    "tsd_sampler_plan_create": (C.c_int, [_CFG, C.POINTER(Batch), C.c_int32, C.c_float, C.c_float, _P, _P, _P,
+                                          C.POINTER(_P)]),
+    "tsd_sampler_plan_run": (C.c_int, [_P, C.c_int32, C.POINTER(RunArgs), C.c_int32, _P]),
+    "tsd_sampler_plan_destroy": (None, [_P]),
+    "tsd_sampler_run": (C.c_int, [_CFG, C.POINTER(Batch), C.c_int32, C.c_int32, _P, _P, C.c_uint64, C.c_uint64,
+                                  C.c_float, C.c_float, _P, _P, _P, C.c_int32, _P]),
+    "tsd_philox_normal": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, _P, _P]),
 }
 
 _lib = None

@@ -43,15 +43,16 @@ int launch_geometry_count(const tsd_model_cfg&, int, const float*, const int32_t
 int launch_geometry_lists(const tsd_model_cfg&, int, int, const float*, const int32_t*, const int32_t*,
                           const int32_t*, const uint16_t*, tsd_geometry, int32_t*, hipStream_t, bool);
 int launch_step_post(const tsd_model_cfg&, int, int, int, int, int, const int32_t*, const int32_t*, const uint16_t*,
-                     tsd_geometry, const float*, const float*, const float*, float, float, float*, float*, int32_t*,
-                     const int32_t*, hipStream_t);
+                     tsd_geometry, const float*, float, float, float*, tsd_sampler_state*, hipStream_t);
+int launch_set_run_args(tsd_sampler_state*, const tsd_run_args&, hipStream_t);
+int launch_philox_normal(uint64_t, uint64_t, int64_t, float*, hipStream_t);
 int launch_filter_gen(const tsd_model_cfg&, const float*, int, tsd_edges, const float*, float*, int, int,
                       hipStream_t);
 int launch_edge_embed2(const tsd_model_cfg&, const float*, int, tsd_edges, float*, int, tsd_edges, float*, int,
                        size_t, hipStream_t, const UmapRole*);
 int launch_layer_combo(const tsd_model_cfg&, const float*, int, int, tsd_edges, const float*, const float*,
-                       const float*, float*, float*, int, int, int, int, tsd_edges, const float*, float*, int, size_t,
-                       size_t, size_t, hipStream_t, const ComboPre*, size_t);
+                       const float*, float*, float*, int, int, int, int, tsd_edges, const float*, float*, int, int,
+                       size_t, size_t, size_t, hipStream_t, const ComboPre*, size_t);
 int filter_tiles_per_layer(int);
 int launch_node_embed(const tsd_model_cfg&, const float*, int, const int64_t*, const int64_t*, const int64_t*,
                       float*, hipStream_t);
@@ -64,11 +65,6 @@ int launch_eq_transform_rows(int, const float*, const int32_t*, const int32_t*, 
 int launch_ensemble_mean(int, int, tsd_edges, const float*, float*, hipStream_t);
 int launch_sampler_step(int, int, int, const int32_t*, const float*, const float*, const float*, float, float,
                         float*, float*, int32_t*, const int32_t*, hipStream_t);
-
-extern int g_filter_rows;
-extern int g_combo_cols;
-extern int g_node_run;
-extern int g_combo_prefetch;
 
 static int check_cfg(const tsd_model_cfg* c) {
     TSD_REQUIRE(c != nullptr, "cfg is null");
@@ -85,13 +81,16 @@ struct Workspace {
     // run in the SAME launches (grid.y = checkpoint), which removes the tile quantisation of batch-100
     // launches (508 workgroups on 256 CUs) and the per-checkpoint launch boundaries
     float *ea;   // [M][P, H]: rows 0..P/2-1 enc_u edges, rows P/2.. separately embedded (diff_u) out edges
-    float *wf;   // [M][L, P/2, H]: CFConv filters of every layer on the undirected enc list
+    float *wf;   // [M][S, P/2, H]: CFConv filters on the undirected enc list, a ring of S = min(L, 2) layer slots:
+                 // launch j writes block j's filters, launch j+1 is their only reader
     float *h, *x1, *x1b;  // [M][N, H]
-    float *agg;  // [N, H] (piecewise path only)
     float *pre;  // [M][P/2, H]: node-independent half of the pair MLP's first layer (ComboPre)
     size_t stride_ea, stride_wf, stride_nh, stride_pre;
+    int wf_slots;
     size_t total;
 };
+
+constexpr int WF_RING = 2;
 
 static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base) {
     Workspace w;
@@ -100,41 +99,18 @@ static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base)
     auto take = [&](size_t n) { float* p = base ? base + o : nullptr; o += n; return p; };
     auto pad = [](size_t n) { return (n + 63) & ~size_t(63); };
     w.stride_ea = pad(2 * PU * H);
-    w.stride_wf = pad((size_t)c.num_convs * PU * H);
+    w.wf_slots = c.num_convs < WF_RING ? c.num_convs : WF_RING;
+    w.stride_wf = pad((size_t)w.wf_slots * PU * H);
     w.stride_nh = pad((size_t)N * H);
     w.ea = take(w.stride_ea * M);
     w.wf = take(w.stride_wf * M);
     w.h = take(w.stride_nh * M);
     w.x1 = take(w.stride_nh * M);
     w.x1b = take(w.stride_nh * M);
-    w.agg = take(w.stride_nh);
     w.stride_pre = pad(PU * H);
     w.pre = take(w.stride_pre * M);
     w.total = o;
     return w;
-}
-
-// TSDIFF_FORWARD=serial selects the piecewise path (filter_gen for all layers, then aggregate + node_update
-// per block, checkpoints one after the other) -- the A/B baseline of the fused per-block launches.
-// (A two-stream variant, node chain || next block's filters joined by events, measured 1.07 ms/step under
-// hipGraph replay against 0.92 serial and was removed in favour of the in-kernel fusion, kernels_combo.hip.)
-// TSDIFF_PAIR_PRE=0 keeps the whole pair MLP in pair_output_kernel (A/B of the ComboPre role)
-static bool pre_role_enabled() {
-    static int cached = -1;
-    if (cached < 0) {
-        const char* env = getenv("TSDIFF_PAIR_PRE");
-        cached = (env && env[0] == '0') ? 0 : 1;
-    }
-    return cached == 1 && g_filter_rows != 64 && g_combo_cols != 64;
-}
-
-static bool use_fused_path() {
-    static int cached = -1;
-    if (cached < 0) {
-        const char* env = getenv("TSDIFF_FORWARD");
-        cached = (env && env[0] == 's') ? 0 : 1;
-    }
-    return cached == 1;
 }
 
 // One forward per checkpoint on the current positions.  Every per-edge MLP runs on the UNDIRECTED
@@ -152,140 +128,107 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     if (!counts_ready) {
         if ((r = launch_geometry_count(c, N, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, g, st))) return r;
     }
-    // fused path: the directed-edge -> undirected-pair map is not needed before the first block launch, so it
-    // runs as an extra role of the edge-embedding launch instead of a launch of its own on the critical path
-    const bool fused = use_fused_path();
+    // the directed-edge -> undirected-pair map is not needed before the first block launch, so it runs as an
+    // extra role of the edge-embedding launch instead of a launch of its own on the critical path
     if ((r = launch_geometry_lists(c, N, P, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, g, advance, st,
-                                   fused)))
+                                   true)))
         return r;
     const Workspace w = carve(c, N, P, M, b.workspace);
-    const size_t wfloats = weight_layout(c).total;
-    if (fused) {
-        // one launch per interaction block: node chain of block l || filter GEMMs of block l+1;
-        // all M checkpoints in the same launches (grid.y)
-        const float* W = b.weights;
-        UmapRole um{};
-        um.g = g;
-        um.graph_ptr = b.graph_ptr;
-        um.node_graph = b.node_graph;
-        um.pair_ptr = b.pair_ptr;
-        um.P = P;
-        if ((r = launch_edge_embed2(c, W, PU, g.enc_u, w.ea, PU, g.diff_u, w.ea + (size_t)PU * H, M, w.stride_ea, st,
-                                    &um)))
-            return r;
-        // block 0 reads z (residual input) and x1_0 = lin1_0(z) straight from the per-batch arrays -- both are
-        // pos independent (computed at bind time) -- so no per-step copy of z and no lin1 launch
-        if (w.stride_nh != (size_t)N * H) {
-            set_error("internal: node stride mismatch");
-            return TSD_ERR_INVALID;
-        }
-        // The filter tiles of all blocks form one queue (they depend on the geometry only); launch j takes block
-        // j's tiles, so that they are complete before block j's node chain runs in launch j+1.  (Re-cutting the
-        // queue into whole chip rounds -- 512,512,256,... tiles instead of 7 x 408 at batch 100 -- measured
-        // slower, 0.597 vs 0.534 ms/step: 408 filter + 100 node workgroups already are two full rounds of 256.)
-        const int tpl = filter_tiles_per_layer(PU);
-        const long total = (long)L * tpl;
-        long cum = 0;
-        const float* xin = b.x1_0;
-        float* xout = w.x1;
-        // the last launch has no filter tiles left: its free CUs compute the node-independent half of the pair
-        // MLP's first layer (ComboPre), which pair_output_kernel then only completes
-        const WeightLayout WL = weight_layout(c);
-        ComboPre pre{};
-        pre.tiles = (PU + TSD_EDGE_TILE - 1) / TSD_EDGE_TILE;
-        pre.e = g.out_u;
-        pre.edge_attr = w.ea;
-        pre.attr_row = g.attr_row;
-        pre.w0b = W + WL.out_w0 + H * H;  // packed [k/4][out][k%4]: the k >= H half is contiguous
-        pre.b0 = W + WL.out_b0;
-        pre.out = w.pre;
-        // (only when the node chain of the last block leaves most of the chip idle: at batch 100 it occupies ~100
-        // of the 256 CUs; with an ensemble or a large batch the launch is full and the extra role only adds work:
-        // C2 0.518 -> 0.511 ms/step, C5 51.1 -> 51.6, M = 8 3.10 -> 3.13)
-        const bool use_pre = pre_role_enabled() && (long)((N + TSD_NODE_TILE - 1) / TSD_NODE_TILE) * M <= 256;
-        for (int j = 0; j <= L; ++j) {
-            const long n = (j < L) ? tpl : total - cum;
-            const int layer = j == 0 ? -2 : j - 1;
-            if ((r = launch_layer_combo(c, W, layer, N, g.enc, layer >= 0 ? w.wf + (size_t)layer * PU * H : nullptr, xin,
-                                        layer == 0 ? b.z : w.h, w.h, xout, 0, (int)cum, (int)n, PU, g.enc_u, w.ea, w.wf,
-                                        M, w.stride_nh, w.stride_ea, w.stride_wf, st,
-                                        (use_pre && j == L) ? &pre : nullptr, w.stride_pre)))
-                return r;
-            cum += n;
-            if (layer >= 0) {
-                xin = xout;
-                xout = (xout == w.x1) ? w.x1b : w.x1;
-            }
-        }
-        return launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u, M, w.stride_nh, w.stride_ea,
-                                  (size_t)PU, st, use_pre ? w.pre : nullptr, w.stride_pre);
+    // one launch per interaction block: node chain of block l || filter GEMMs of block l+1;
+    // all M checkpoints in the same launches (grid.y)
+    const float* W = b.weights;
+    UmapRole um{};
+    um.g = g;
+    um.graph_ptr = b.graph_ptr;
+    um.node_graph = b.node_graph;
+    um.pair_ptr = b.pair_ptr;
+    um.P = P;
+    if ((r = launch_edge_embed2(c, W, PU, g.enc_u, w.ea, PU, g.diff_u, w.ea + (size_t)PU * H, M, w.stride_ea, st,
+                                &um)))
+        return r;
+    // block 0 reads z (residual input) and x1_0 = lin1_0(z) straight from the per-batch arrays -- both are
+    // pos independent (computed at bind time) -- so no per-step copy of z and no lin1 launch
+    if (w.stride_nh != (size_t)N * H) {
+        set_error("internal: node stride mismatch");
+        return TSD_ERR_INVALID;
     }
-    for (int m = 0; m < M; ++m) {  // piecewise path
-        const float* W = b.weights + (size_t)m * wfloats;
-        if ((r = launch_edge_embed(c, W, PU, g.enc_u, w.ea, st))) return r;
-        if ((r = launch_filter_gen(c, W, PU, g.enc_u, w.ea, w.wf, 0, L, st))) return r;
-        TSD_HIP(hipMemcpyAsync(w.h, b.z + (size_t)m * N * H, (size_t)N * H * sizeof(float),
-                               hipMemcpyDeviceToDevice, st));
-        if ((r = launch_node_lin1(c, W, 0, N, w.h, w.x1, st))) return r;
-        for (int l = 0; l < L; ++l) {
-            if ((r = launch_cfconv_aggregate(c.hidden, N, g.enc.row_ptr, g.enc.dst, g.enc.umap,
-                                             w.wf + (size_t)l * PU * H, w.x1, w.agg, st)))
-                return r;
-            if ((r = launch_node_update(c, W, l, (l + 1 < L) ? l + 1 : -1, N, nullptr, w.agg, nullptr, w.h, w.x1,
-                                        st)))
-                return r;
-        }
-        if ((r = launch_edge_embed(c, W, PU, g.diff_u, w.ea + (size_t)PU * H, st))) return r;
-        if ((r = launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u + (size_t)m * PU, 1, 0, 0,
-                                    0, st, nullptr, 0)))
+    // The filter tiles of all blocks form one queue (they depend on the geometry only); launch j takes block
+    // j's tiles, so that they are complete before block j's node chain runs in launch j+1.  Launch j+1 is the
+    // only reader of block j's filters, so they live in a ring of two layer slots (block l -> slot l % 2) --
+    // the working set of a launch pair instead of all L layers (r01: 14.8 GB at config C5, now 4.2 GB).
+    const int tpl = filter_tiles_per_layer(PU);
+    const float* xin = b.x1_0;
+    float* xout = w.x1;
+    // the last launch has no filter tiles left: its free CUs compute the node-independent half of the pair
+    // MLP's first layer (ComboPre), which pair_output_kernel then only completes
+    const WeightLayout WL = weight_layout(c);
+    ComboPre pre{};
+    pre.tiles = (PU + TSD_EDGE_TILE - 1) / TSD_EDGE_TILE;
+    pre.e = g.out_u;
+    pre.edge_attr = w.ea;
+    pre.attr_row = g.attr_row;
+    pre.w0b = W + WL.out_w0 + H * H;  // packed [k/4][out][k%4]: the k >= H half is contiguous
+    pre.b0 = W + WL.out_b0;
+    pre.out = w.pre;
+    // (only when the node chain of the last block leaves most of the chip idle: at batch 100 it occupies ~100
+    // of the 256 CUs; with an ensemble or a large batch the launch is full and the extra role only adds work:
+    // C2 0.518 -> 0.511 ms/step, C5 51.1 -> 51.6, M = 8 3.10 -> 3.13)
+    const bool use_pre = (long)((N + TSD_NODE_TILE - 1) / TSD_NODE_TILE) * M <= 256;
+    for (int j = 0; j <= L; ++j) {
+        const int layer = j == 0 ? -2 : j - 1;  // node chain of this launch; its filters were written by launch j-1
+        const float* wf_read = layer >= 0 ? w.wf + (size_t)(layer % w.wf_slots) * PU * H : nullptr;
+        if ((r = launch_layer_combo(c, W, layer, N, g.enc, wf_read, xin, layer == 0 ? b.z : w.h, w.h, xout, 0,
+                                    j * tpl, j < L ? tpl : 0, PU, g.enc_u, w.ea, w.wf, w.wf_slots, M, w.stride_nh,
+                                    w.stride_ea, w.stride_wf, st, (use_pre && j == L) ? &pre : nullptr, w.stride_pre)))
             return r;
+        if (layer >= 0) {
+            xin = xout;
+            xout = (xout == w.x1) ? w.x1b : w.x1;
+        }
     }
-    return TSD_OK;
+    return launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u, M, w.stride_nh, w.stride_ea,
+                              (size_t)PU, st, use_pre ? w.pre : nullptr, w.stride_pre);
 }
 
 // one sampling step of the device-resident loop: lists (from the counts of the previous step's tail) ->
 // M forwards -> fused tail (mean, eq_transform, update, centre, next step's counts)
-static int step_impl(const tsd_model_cfg& c, const tsd_batch& b, int kind, const float* coefs,
-                     const float* noises, float clip, float clip_pos, float* pos, float* traj,
-                     int32_t* status, int32_t* step_ctr, bool advance, hipStream_t st) {
+static int step_impl(const tsd_model_cfg& c, const tsd_batch& b, int kind, float clip, float clip_pos, float* pos,
+                     tsd_sampler_state* state, hipStream_t st) {
     int r;
-    if ((r = forward_impl(c, b, pos, st, true, advance ? step_ctr : nullptr))) return r;
+    if ((r = forward_impl(c, b, pos, st, true, &state->step))) return r;
     return launch_step_post(c, kind, b.num_nodes, b.num_graphs, b.num_models, b.num_pairs, b.graph_ptr, b.pair_ptr,
-                            b.pair_code, b.geo, b.edge_inv_u, noises, coefs, clip, clip_pos, pos, traj, status,
-                            step_ctr, st);
+                            b.pair_code, b.geo, b.edge_inv_u, clip, clip_pos, pos, state, st);
 }
 
+}  // namespace tsd
+
+// the plan: one captured + instantiated step, replayed by every call (include/tsdiff_hip.h)
+struct tsd_sampler_plan {
+    tsd_model_cfg cfg;
+    tsd_batch batch;
+    int kind;
+    float clip, clip_pos;
+    float* pos;
+    tsd_sampler_state* state;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+namespace tsd {
+static int check_batch(const tsd_batch* batch) {
+    TSD_REQUIRE(batch != nullptr, "batch is null");
+    TSD_REQUIRE(batch->num_models >= 1, "num_models=%d", batch->num_models);
+    TSD_REQUIRE(batch->z && batch->x1_0 && batch->weights && batch->workspace && batch->edge_inv_u,
+                "null batch pointer");
+    return TSD_OK;
+}
 }  // namespace tsd
 
 using namespace tsd;
 
 extern "C" {
 
-int tsd_set_filter_tile(int32_t rows) {
-    TSD_REQUIRE(rows == 0 || rows == 32 || rows == 64, "filter tile rows must be 0 (auto), 32 or 64");
-    g_filter_rows = rows;
-    return TSD_OK;
-}
-
-int tsd_set_combo_prefetch(int32_t kblocks) {
-    TSD_REQUIRE(kblocks == 0 || kblocks == 4 || kblocks == 8, "prefetch chunk must be 0 (default), 4 or 8 k-blocks");
-    g_combo_prefetch = kblocks;
-    return TSD_OK;
-}
-
-int tsd_set_node_run(int32_t run) {
-    TSD_REQUIRE(run >= 1 && run <= 64, "node tiles per XCD run must be in 1..64");
-    g_node_run = run;
-    return TSD_OK;
-}
-
-int tsd_set_combo_cols(int32_t cols) {
-    TSD_REQUIRE(cols == 0 || cols == 32 || cols == 64, "columns per wave must be 0 (auto), 32 or 64");
-    g_combo_cols = cols;
-    return TSD_OK;
-}
-
-const char* tsd_version(void) { return "tsdiff_hip 0.1 (gfx950, fp32 MFMA)"; }
+const char* tsd_version(void) { return "tsdiff_hip 0.2 (gfx950, fp32 MFMA)"; }
 const char* tsd_last_error(void) { return g_err; }
 
 size_t tsd_raw_weight_floats(const tsd_model_cfg* cfg) {
@@ -390,7 +333,7 @@ int tsd_interaction_block(const tsd_model_cfg* cfg, const float* w, int32_t laye
     return launch_layer_combo(*cfg, w, layer, num_nodes, enc, Wf_layer, x1_in, nullptr, h, x1_out,
                               filter_layer < 0 ? 0 : filter_layer, 0,
                               filter_layer < 0 ? 0 : filter_tiles_per_layer(capacity_u), capacity_u, enc_u, edge_attr,
-                              Wf_out, 1, 0, 0, 0, (hipStream_t)stream, nullptr, 0);
+                              Wf_out, 1, 1, 0, 0, 0, (hipStream_t)stream, nullptr, 0);
 }
 
 int tsd_cfconv_aggregate(int32_t hidden, int32_t num_nodes, const int32_t* row_ptr, const int32_t* dst,
@@ -433,9 +376,8 @@ size_t tsd_forward_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes,
 int tsd_score_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* pos, void* stream) {
     int r = check_cfg(cfg);
     if (r) return r;
-    TSD_REQUIRE(batch && pos, "null pointer");
-    TSD_REQUIRE(batch->num_models >= 1, "num_models=%d", batch->num_models);
-    TSD_REQUIRE(batch->z && batch->x1_0 && batch->weights && batch->workspace && batch->edge_inv_u, "null batch pointer");
+    if ((r = check_batch(batch))) return r;
+    TSD_REQUIRE(pos, "null pointer");
     return forward_impl(*cfg, *batch, pos, (hipStream_t)stream);
 }
 
@@ -460,51 +402,91 @@ int tsd_sampler_step(int32_t kind, int32_t num_nodes, int32_t num_graphs, const 
                                pos, nullptr, status, nullptr, (hipStream_t)stream);
 }
 
-int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t kind, int32_t n_steps,
-                    const float* coefs, const float* noises, float clip, float clip_pos, float* pos, float* traj,
-                    int32_t* status, int32_t use_graph, void* stream) {
+int tsd_philox_normal(uint64_t seed, uint64_t offset, int64_t n_atoms, float* out, void* stream) {
+    TSD_REQUIRE(n_atoms >= 0 && (n_atoms == 0 || out), "bad argument");
+    return launch_philox_normal(seed, offset, n_atoms, out, (hipStream_t)stream);
+}
+
+int tsd_sampler_plan_create(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t kind, float clip,
+                            float clip_pos, float* pos, tsd_sampler_state* state, void* stream,
+                            tsd_sampler_plan** plan_out) {
     int r = check_cfg(cfg);
     if (r) return r;
-    TSD_REQUIRE(batch && coefs && noises && pos && status, "null pointer");
+    if ((r = check_batch(batch))) return r;
+    TSD_REQUIRE(pos && state && plan_out, "null pointer");
     TSD_REQUIRE(kind == 0 || kind == 1, "kind=%d (0 = ld, 1 = ddpm)", kind);
-    TSD_REQUIRE(n_steps >= 0, "n_steps=%d", n_steps);
+    TSD_REQUIRE(stream != nullptr, "stream capture is illegal on the legacy default stream: pass a created stream");
     hipStream_t st = (hipStream_t)stream;
+    tsd_sampler_plan* p = new tsd_sampler_plan{*cfg, *batch, kind, clip, clip_pos, pos, state, nullptr, nullptr};
+    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+        delete p;
+        return check_hip(e, "hipStreamBeginCapture");
+    }
+    r = step_impl(p->cfg, p->batch, kind, clip, clip_pos, pos, state, st);
+    e = hipStreamEndCapture(st, &p->graph);
+    if (r == TSD_OK) r = check_hip(e, "hipStreamEndCapture");
+    if (r == TSD_OK) r = check_hip(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+    if (r != TSD_OK) {
+        if (p->graph) (void)hipGraphDestroy(p->graph);
+        delete p;
+        return r;
+    }
+    *plan_out = p;
+    return TSD_OK;
+}
+
+int tsd_sampler_plan_run(tsd_sampler_plan* plan, int32_t n_steps, const tsd_run_args* args, int32_t use_graph,
+                         void* stream) {
+    TSD_REQUIRE(plan && args, "null pointer");
+    TSD_REQUIRE(n_steps >= 0, "n_steps=%d", n_steps);
+    TSD_REQUIRE(n_steps == 0 || args->coefs, "null coefs");
     if (n_steps == 0) return TSD_OK;
-    int32_t* step_ctr = status + 1;  // status[1]: device-side step counter (offsets into coefs/noises/traj)
-    const tsd_batch& b = *batch;
-    TSD_HIP(hipMemsetAsync(step_ctr, 0, sizeof(int32_t), st));
-    if ((r = launch_geometry_count(*cfg, b.num_nodes, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, b.geo,
-                                   st)))
+    hipStream_t st = (hipStream_t)stream;
+    const tsd_batch& b = plan->batch;
+    int r;
+    if ((r = launch_set_run_args(plan->state, *args, st))) return r;
+    // member counts of the first step's lists (later steps get them from the previous step's tail kernel)
+    if ((r = launch_geometry_count(plan->cfg, b.num_nodes, plan->pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code,
+                                   b.geo, st)))
         return r;
-    // step 0 runs eagerly (also performs every one-time function-attribute set-up outside capture)
-    if ((r = step_impl(*cfg, b, kind, coefs, noises, clip, clip_pos, pos, traj, status, step_ctr, false, st))) return r;
-    if (n_steps == 1) return TSD_OK;
-    if (!use_graph) {
-        for (int k = 1; k < n_steps; ++k)
-            if ((r = step_impl(*cfg, b, kind, coefs, noises, clip, clip_pos, pos, traj, status, step_ctr, true, st)))
-                return r;
-        return TSD_OK;
+    for (int k = 0; k < n_steps; ++k) {
+        if (use_graph) {
+            TSD_HIP(hipGraphLaunch(plan->exec, st));
+        } else if ((r = step_impl(plan->cfg, b, plan->kind, plan->clip, plan->clip_pos, plan->pos, plan->state, st))) {
+            return r;
+        }
     }
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    TSD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    r = step_impl(*cfg, b, kind, coefs, noises, clip, clip_pos, pos, traj, status, step_ctr, true, st);
-    hipError_t ce = hipStreamEndCapture(st, &graph);
-    if (r) {
-        if (graph) (void)hipGraphDestroy(graph);
-        return r;
+    return TSD_OK;
+}
+
+void tsd_sampler_plan_destroy(tsd_sampler_plan* plan) {
+    if (!plan) return;
+    if (plan->exec) (void)hipGraphExecDestroy(plan->exec);
+    if (plan->graph) (void)hipGraphDestroy(plan->graph);
+    delete plan;
+}
+
+int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t kind, int32_t n_steps,
+                    const float* coefs, const float* noises, uint64_t seed, uint64_t offset, float clip,
+                    float clip_pos, float* pos, float* traj, tsd_sampler_state* state, int32_t use_graph,
+                    void* stream) {
+    tsd_sampler_plan* plan = nullptr;
+    int r;
+    if (use_graph) {
+        if ((r = tsd_sampler_plan_create(cfg, batch, kind, clip, clip_pos, pos, state, stream, &plan))) return r;
+    } else {  // eager: no capture, the same kernels launched one by one
+        if ((r = check_cfg(cfg))) return r;
+        if ((r = check_batch(batch))) return r;
+        TSD_REQUIRE(pos && state, "null pointer");
+        TSD_REQUIRE(kind == 0 || kind == 1, "kind=%d (0 = ld, 1 = ddpm)", kind);
+        plan = new tsd_sampler_plan{*cfg, *batch, kind, clip, clip_pos, pos, state, nullptr, nullptr};
     }
-    TSD_HIP(ce);
-    hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (ie != hipSuccess) {
-        (void)hipGraphDestroy(graph);
-        return check_hip(ie, "hipGraphInstantiate");
-    }
-    for (int k = 1; k < n_steps && r == TSD_OK; ++k) r = check_hip(hipGraphLaunch(exec, st), "hipGraphLaunch");
+    const tsd_run_args args{coefs, noises, traj, seed, offset};
+    r = tsd_sampler_plan_run(plan, n_steps, &args, use_graph, stream);
     // the exec object must outlive its launches: wait for the stream before destroying it
-    hipError_t se = hipStreamSynchronize(st);
-    (void)hipGraphExecDestroy(exec);
-    (void)hipGraphDestroy(graph);
+    const hipError_t se = use_graph ? hipStreamSynchronize((hipStream_t)stream) : hipSuccess;
+    tsd_sampler_plan_destroy(plan);
     if (r) return r;
     return check_hip(se, "hipStreamSynchronize");
 }

@@ -1,6 +1,7 @@
 // common.hpp -- shared device/host helpers of libtsdiff_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -33,6 +34,25 @@ int check_hip(hipError_t e, const char* what);
             return TSD_ERR_INVALID;                                \
         }                                                          \
     } while (0)
+
+// One-time set-up per DEVICE (a kernel's dynamic-LDS limit is a per-device function attribute, and one process
+// may drive several GPUs): first_on_current_device() is true exactly once per device id for each instance.
+struct DeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    bool first_on_current_device() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess) return true;
+        const uint64_t bit = 1ull << (d & 63);
+        return !(mask.fetch_or(bit) & bit);
+    }
+};
+template <typename K>
+static inline int allow_lds(K kernel, size_t bytes, DeviceOnce& once) {
+    if (bytes > 48 * 1024 && once.first_on_current_device())
+        TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return TSD_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // packed weight arena (floats).  Dense matrix W[out][in] is stored as Bp[in/4][out][in%4] so that
@@ -153,6 +173,38 @@ __device__ __forceinline__ float sspf(float x) {  // reference models/encoder/sc
     return (fmaxf(x, 0.0f) + l) - 0.69314718055994530942f;
 }
 
+// Philox4x32-10 (Salmon et al., SC'11): counter-based generator for the Gaussian draws of the sampling loop
+// (reference models/sampler.py:213 torch.randn_like): key = seed, counter = (ctr, 0), four u32 per call.
+struct u32x4 { uint32_t x, y, z, w; };
+__host__ __device__ __forceinline__ u32x4 philox4x32_10(uint64_t ctr, uint64_t seed) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return {c0, c1, c2, c3};
+}
+// three standard normals of counter `ctr` (Box-Muller on the four uniforms; the fourth normal is dropped)
+__device__ __forceinline__ void philox_normal3(uint64_t ctr, uint64_t seed, float (&z)[3]) {
+    const u32x4 r = philox4x32_10(ctr, seed);
+    const float u0 = ((float)(r.x >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1), 24 bits
+    const float u1 = ((float)(r.y >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(r.z >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u3 = ((float)(r.w >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+    float sa, ca, sb, cb;
+    sincospif(2.0f * u1, &sa, &ca);
+    sincospif(2.0f * u3, &sb, &cb);
+    (void)sb;
+    z[0] = ra * ca;
+    z[1] = ra * sa;
+    z[2] = rb * cb;
+}
+
 // CFConv cutoff weight C(d), reference models/encoder/schnet.py:92-98
 __device__ __forceinline__ float cutoff_weight(float d, float cutoff, int smooth) {
     if (!(d <= cutoff)) return 0.0f;
@@ -175,12 +227,7 @@ __device__ __forceinline__ float cutoff_weight(float d, float cutoff, int smooth
 // B is double-buffered in registers in chunks of PF k-blocks: while chunk c is multiplied (PF*4*RB*CB
 // MFMAs = 2048 cycles at RB=1, CB=2), chunk c+1 is in flight from L2 -- one k-block of look-ahead
 // (the first version) exposed the L2 latency every iteration (tools/mfma_probe.hip: 84 -> 93 TFLOP/s).
-// SPLIT (off; kept as a measured experiment): accumulate every output element as TWO partial sums (MFMA
-// steps 0,2 and 1,3 of each k-block) so that consecutive MFMAs of a one-column-block wave alternate
-// accumulators -- the guide prices a foreign instruction between two MFMAs on the SAME accumulator at ~43
-// cycles, and tools/mfma_probe2.hip measures 97 (one accumulator) vs 137 TFLOP/s (two).  In the real kernels
-// it changed nothing for the better (C2 0.549 vs 0.523 ms/step, C5 53.2 vs 52.0, training 6.60 vs 6.55).
-template <int RB, int CB, int K, int PF = 4, bool PIN = false, bool SPLIT = false>
+template <int RB, int CB, int K, int PF = 4, bool PIN = false>
 __device__ __forceinline__ void gemm_tile(const float* __restrict__ ldsA, int lda,
                                           const float* __restrict__ Bp, int nout, int col0,
                                           f32x16 (&acc)[RB][CB]) {
@@ -192,15 +239,6 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ ldsA, int ld
     constexpr int KB = K / 8;
     constexpr int NC = KB / PF;
     static_assert(KB % PF == 0, "K must be a multiple of 8 * PF");
-    f32x16 acc2[RB][CB];
-    if (SPLIT) {
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc2[rb][cb][r] = 0.0f;
-    }
     f32x4 b0[PF][CB], b1[PF][CB];
     auto loadB = [&](f32x4 (&b)[PF][CB], int chunk) {
 #pragma unroll
@@ -222,12 +260,8 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ ldsA, int ld
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                    for (int cb = 0; cb < CB; ++cb) {
-                        if (SPLIT && (s & 1))
-                            acc2[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][rb][s], b[p][cb][s], acc2[rb][cb], 0, 0, 0);
-                        else
-                            acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][rb][s], b[p][cb][s], acc[rb][cb], 0, 0, 0);
-                    }
+                    for (int cb = 0; cb < CB; ++cb)
+                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][rb][s], b[p][cb][s], acc[rb][cb], 0, 0, 0);
     };
     // The machine scheduler sinks every load to just before its first use (one k-block of look-ahead).
     // With >= 2 workgroups per CU the other waves cover that (measured: pinning the pipeline costs 10 % at
@@ -243,14 +277,6 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ ldsA, int ld
         if (PIN) __builtin_amdgcn_sched_barrier(0);
         if (c + 1 < NC) compute(b1, c + 1);
         if (PIN) __builtin_amdgcn_sched_barrier(0);
-    }
-    if (SPLIT) {
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[rb][cb][r] += acc2[rb][cb][r];
     }
 }
 

@@ -10,13 +10,7 @@
 // Roles never communicate; the kernel boundary orders block l's filter before block l's aggregation.
 //
 // Both roles run with 2H threads = H/32 waves, 32 output columns per wave.
-#include <stdlib.h>
-
 #include "common.hpp"
-
-#ifndef TSD_NODE_PF_DEEP
-#define TSD_NODE_PF_DEEP 0  // measured: C2 0.556 vs 0.519 ms/step, C5 57.6 vs 52.0 with the deep pinned prefetch
-#endif
 
 namespace tsd {
 
@@ -48,8 +42,9 @@ struct ComboFilter {
     int smooth;
     tsd_edges e;
     const float* edge_attr;
-    float* wf;            // filters of item layer 0; item layer l at + l * wf_layer_stride
+    float* wf;            // filter slot 0; the filters of item layer l go to slot l % wf_slots
     size_t wf_layer_stride;
+    int wf_slots;
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -57,13 +52,12 @@ struct ComboFilter {
 // bit-identical to a sequential scatter_add), then the three dense layers of tsd_node_update.
 // reference schnet.py:101-107 (message/aggregate), :103 (lin2), :123-127, :223-224
 // -------------------------------------------------------------------------------------------------
-template <int H, int CBF>
-__device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* smem, int ablate = 0) {
+template <int H>
+__device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* smem) {
     constexpr int LDA = H + 4;
-    constexpr int NT = 2 * H / CBF;
+    constexpr int NT = 2 * H;
     constexpr int NW = NT / 64;
-    constexpr int CB16 = 2 * CBF;  // 16-wide column blocks per wave
-    constexpr int NPF = (TSD_NODE_PF_DEEP && H >= 128) ? H / 32 : 4;  // k-blocks per prefetch chunk of the node GEMMs
+    constexpr int CB16 = 2;  // 16-wide column blocks per wave
     constexpr int RPW = TN / NW;  // rows aggregated per wave
     constexpr int V = H / 64;     // channels per lane during aggregation
     constexpr int C4 = H / 4;
@@ -73,7 +67,7 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
     const int n0 = tile * TN;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, l15 = lane & 15;
-    const int col0 = wave * 32 * CBF;
+    const int col0 = wave * 32;
     const int nrows = min(TN, a.N - n0);
     f32x4 acc[CB16];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -86,7 +80,7 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
             float s[V];
 #pragma unroll
             for (int v = 0; v < V; ++v) s[v] = 0.0f;
-            if (i < a.N && !(ablate & 16)) {
+            if (i < a.N) {
                 const int e0 = a.row_ptr[i], e1 = a.row_ptr[i + 1];
                 for (int eb = e0; eb < e1; eb += 64) {
                     const int cnt = min(64, e1 - eb);
@@ -160,7 +154,7 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
 
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) acc[cb] = zero4;
-        if (!(ablate & 32)) gemm_tile16<CB16, H, NPF, (NPF > 4)>(buf, LDA, a.lin2_w, H, col0, acc);
+        gemm_tile16<CB16, H>(buf, LDA, a.lin2_w, H, col0, acc);
         __syncthreads();
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
@@ -173,7 +167,7 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
 
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) acc[cb] = zero4;
-        if (!(ablate & 32)) gemm_tile16<CB16, H, NPF, (NPF > 4)>(buf, LDA, a.lin_w, H, col0, acc);
+        gemm_tile16<CB16, H>(buf, LDA, a.lin_w, H, col0, acc);
         __syncthreads();
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
@@ -205,7 +199,7 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
 
 #pragma unroll
     for (int cb = 0; cb < CB16; ++cb) acc[cb] = zero4;
-    if (!(ablate & 32)) gemm_tile16<CB16, H, NPF, (NPF > 4)>(buf, LDA, a.lin1_next_w, H, col0, acc);
+    gemm_tile16<CB16, H>(buf, LDA, a.lin1_next_w, H, col0, acc);
 #pragma unroll
     for (int cb = 0; cb < CB16; ++cb) {
         const int col = col0 + cb * 16 + l15;
@@ -221,35 +215,31 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
 // filter role: Wf[e] = nn2(ssp(nn0(edge_attr[e]))) * C(e) for one tile of 32 undirected edges,
 // H/32 waves x 32 columns (the 256-thread stand-alone form is filter_gen_kernel in kernels_mlp.hip)
 // -------------------------------------------------------------------------------------------------
-// RB = 1: tiles of 32 edges (the default); RB = 2: tiles of 64 edges (every B fragment fetched from L2 feeds
-// twice the MFMAs; faster in the 4-wave probe, slower here -- see launch_layer_combo).  Bit-identical rows.
-template <int H, int RB, int CBF, int PFF>
-__device__ __forceinline__ void filter_role(const ComboFilter& f, int item, float* smem, int ablate = 0) {
-    static_assert(RB == 1 || CBF == 1, "the 64-edge layout has its own wave mapping");
-    constexpr int TR = T * RB;
+template <int H>
+__device__ __forceinline__ void filter_role(const ComboFilter& f, int item, float* smem) {
     const int g = f.g_begin + item;
     const int lrel = g / f.tiles_per_layer, tile = g - lrel * f.tiles_per_layer;
     const float* Wb = f.Wl0 + (size_t)(f.layer0 + lrel) * f.layer_stride;
     const float *nn0_w = Wb + f.o_nn0_w, *nn0_b = Wb + f.o_nn0_b, *nn2_w = Wb + f.o_nn2_w, *nn2_b = Wb + f.o_nn2_b;
-    float* out = f.wf + (size_t)lrel * f.wf_layer_stride;
+    float* out = f.wf + (size_t)(lrel % f.wf_slots) * f.wf_layer_stride;
     constexpr int LDA = H + 4;
-    constexpr int NT = 2 * H / CBF;
+    constexpr int NT = 2 * H;
     constexpr int C4 = H / 4;
     float* buf = smem;
-    float* s_c = smem + TR * LDA;
+    float* s_c = smem + T * LDA;
 
     const int E = *f.e.count;
-    const int e0 = tile * TR;
+    const int e0 = tile * T;
     if (e0 >= E) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
-    const int col0 = (tid >> 6) * 32 * CBF;
-    const int nrows = min(TR, E - e0);
+    const int col0 = (tid >> 6) * 32;
+    const int nrows = min(T, E - e0);
 
-    if (tid < TR) s_c[tid] = tid < nrows ? cutoff_weight(f.e.dist[e0 + tid], f.conv_cutoff, f.smooth) : 0.0f;
-    if (!(ablate & 4)) {   // edge_attr tile -> LDS with every load of a thread in flight together (rows past the end clamped)
-        constexpr int NIT = TR * C4 / NT;
-        static_assert(TR * C4 % NT == 0, "tile / block mismatch");
+    if (tid < T) s_c[tid] = tid < nrows ? cutoff_weight(f.e.dist[e0 + tid], f.conv_cutoff, f.smooth) : 0.0f;
+    {   // edge_attr tile -> LDS with every load of a thread in flight together (rows past the end clamped)
+        constexpr int NIT = T * C4 / NT;
+        static_assert(T * C4 % NT == 0, "tile / block mismatch");
         f32x4 v[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -265,75 +255,31 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
     }
     __syncthreads();
 
-    if constexpr (RB == 2) {
-        // 64-edge tile as TWO row groups of H/64 waves; a wave owns 32 rows x 64 columns (two accumulators per
-        // B load: tools/mfma_probe2.hip measures 137 TFLOP/s for this loop against 97 for one accumulator)
-        constexpr int WPG = H / 64;                       // waves per row group
-        const int wave = tid >> 6;
-        const int grp = wave / WPG, gcol0 = (wave % WPG) * 64;
-        float* gbuf = buf + grp * 32 * LDA;
-        f32x16 acc[1][2];
-        zero_acc(acc);
-        gemm_tile<1, 2, H>(gbuf, LDA, nn0_w, H, gcol0, acc);
-        __syncthreads();
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const int col = gcol0 + cb * 32 + l31;
-            const float b = nn0_b[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) gbuf[acc_row(r, hi) * LDA + col] = sspf(acc[0][cb][r] + b);
-        }
-        __syncthreads();
-        zero_acc(acc);
-        gemm_tile<1, 2, H>(gbuf, LDA, nn2_w, H, gcol0, acc);
-        __syncthreads();
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const int col = gcol0 + cb * 32 + l31;
-            const float b = nn2_b[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = acc_row(r, hi);
-                gbuf[row * LDA + col] = (acc[0][cb][r] + b) * s_c[grp * 32 + row];
-            }
-        }
-    } else {
-    f32x16 acc[RB][CBF];
+    f32x16 acc[1][1];
     zero_acc(acc);
-    gemm_tile<RB, CBF, H, PFF, (PFF > 4)>(buf, LDA, nn0_w, H, col0, acc);
+    gemm_tile<1, 1, H>(buf, LDA, nn0_w, H, col0, acc);
     __syncthreads();
-#pragma unroll
-    for (int cb = 0; cb < CBF; ++cb) {
-        const int col = col0 + cb * 32 + l31;
+    {
+        const int col = col0 + l31;
         const float b = nn0_b[col];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc[rb][cb][r] + b;
-                buf[(rb * 32 + acc_row(r, hi)) * LDA + col] = (ablate & 1) ? v : sspf(v);
-            }
+        for (int r = 0; r < 16; ++r) buf[acc_row(r, hi) * LDA + col] = sspf(acc[0][0][r] + b);
     }
     __syncthreads();
 
     zero_acc(acc);
-    if (!(ablate & 8)) gemm_tile<RB, CBF, H, PFF, (PFF > 4)>(buf, LDA, nn2_w, H, col0, acc);
+    gemm_tile<1, 1, H>(buf, LDA, nn2_w, H, col0, acc);
     __syncthreads();
-#pragma unroll
-    for (int cb = 0; cb < CBF; ++cb) {
-        const int col = col0 + cb * 32 + l31;
+    {
+        const int col = col0 + l31;
         const float b = nn2_b[col];
 #pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rb * 32 + acc_row(r, hi);
-                buf[row * LDA + col] = (acc[rb][cb][r] + b) * s_c[row];
-            }
-    }
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, hi);
+            buf[row * LDA + col] = (acc[0][0][r] + b) * s_c[row];
+        }
     }
     __syncthreads();
-    if (ablate & 2) return;
     for (int idx = tid; idx < nrows * C4; idx += NT) {
         const int r = idx / C4, c4 = idx % C4;
         *reinterpret_cast<f32x4*>(out + (size_t)(e0 + r) * H + c4 * 4) =
@@ -378,18 +324,14 @@ __device__ __forceinline__ void pre_role(const ComboPre& q, int tile, float* sme
 }
 
 struct ComboStride {  // per-checkpoint strides (blockIdx.y = checkpoint of the ensemble)
-    size_t w, nh, ea, wf;
-    int node_run;  // consecutive node tiles kept on one XCD (1: plain order)
-    int phase_sleep;
-    size_t pre;    // stride of ComboPre::out
-    int node_prio; // raise the wave priority of the node role (TSDIFF_NODE_PRIO, default on)
-    int ablate;    // timing experiments only (TSDIFF_ABLATE): 1 no ssp, 2 no Wf store, 4 no tile load, 8 no 2nd GEMM,
-                   // 16 no aggregation, 32 no node GEMMs
+    size_t w, nh, ea, wf, pre;
 };
 
-template <int H, int RB, int CBF, int PFF>
-__global__ __launch_bounds__(2 * H / CBF) void layer_combo_kernel(ComboNode a, int node_tiles, ComboFilter f,
-                                                                  ComboStride sd, ComboPre q) {
+constexpr int NODE_RUN = 4;  // consecutive node tiles kept on one XCD (one 64-atom graph = 4 tiles)
+
+template <int H>
+__global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int node_tiles, ComboFilter f,
+                                                            ComboStride sd, ComboPre q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     {
         const size_t m = blockIdx.y;
@@ -406,60 +348,45 @@ __global__ __launch_bounds__(2 * H / CBF) void layer_combo_kernel(ComboNode a, i
     if ((int)blockIdx.x < node_tiles) {
         // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), and the node
         // tiles of one graph read the same x1 rows and -- from both endpoints -- the same filter rows.  Runs of
-        // `run` consecutive tiles therefore go to ONE XCD: the q-th workgroup of XCD x takes tile
+        // NODE_RUN consecutive tiles therefore go to ONE XCD: the q-th workgroup of XCD x takes tile
         // ((q / run) * 8 + x) * run + q % run.  The tail that does not fill 8 * run keeps the identity order.
         int tile = blockIdx.x;
-        const int run = sd.node_run;
-        if (run > 1) {
-            const int full = node_tiles / (8 * run) * (8 * run);
-            if (tile < full) {
-                const int x = tile & 7, q = tile >> 3;
-                tile = ((q / run) * 8 + x) * run + q % run;
-            }
+        const int full = node_tiles / (8 * NODE_RUN) * (8 * NODE_RUN);
+        if (tile < full) {
+            const int x = tile & 7, qq = tile >> 3;
+            tile = ((qq / NODE_RUN) * 8 + x) * NODE_RUN + qq % NODE_RUN;
         }
-        // the node chain is the critical path of the launch (ablations: removing filter-role work barely shortens
-        // it): its waves get issue priority over the filter waves they share a SIMD with
-        if (sd.node_prio > 0) __builtin_amdgcn_s_setprio(3);
-        node_role<H, CBF>(a, tile, smem, sd.ablate);
+        // the node chain is the critical path of the launch: its waves get issue priority over the filter waves
+        // they share a SIMD with
+        __builtin_amdgcn_s_setprio(3);
+        node_role<H>(a, tile, smem);
     } else {
-        // phase shift (experiment knob): workgroups of every second dispatch round start late, so that the two
-        // workgroups sharing a CU do not run their load / epilogue phases in lockstep
         const int item = blockIdx.x - node_tiles;
-        if (CBF == 1 && item >= f.tiles) {  // (the pre role is built for the H/32-wave layout)
+        if (item >= f.tiles) {
             pre_role<H>(q, item - f.tiles, smem);
             return;
         }
-        if (sd.phase_sleep > 0 && ((item >> 8) & 1)) {
-            for (int k = 0; k < sd.phase_sleep; ++k) __builtin_amdgcn_s_sleep(32);  // 32 * 64 cycles = 0.85 us
-        }
-        filter_role<H, RB, CBF, PFF>(f, item, smem, sd.ablate);
+        filter_role<H>(f, item, smem);
     }
 }
 
-static inline size_t lds_combo(int H, int RB) {
+static inline size_t lds_combo(int H) {
     const size_t node = (size_t)TN * (H + 4) * 4;
-    const size_t filt = (size_t)(T * RB * (H + 4) + T * RB) * 4;
+    const size_t filt = (size_t)(T * (H + 4) + T) * 4;
     return node > filt ? node : filt;
 }
 
-int g_filter_rows = 0;  // 0: automatic, 32 / 64: forced (tsd_set_filter_tile; tests and A/B runs)
-int g_node_run = 4;     // node tiles per XCD run (tsd_set_node_run; 1 = plain order)
-int g_combo_prefetch = 0;  // k-blocks per pinned B prefetch chunk of the filter role: 0 / 4 = scheduler's choice, 8 = pinned
-int g_combo_cols = 0;   // output columns per wave of the per-block launch: 0 automatic, 32 or 64 (tsd_set_combo_cols)
-
-int filter_tiles_per_layer(int capacity_u) {
-    const int RBsel = g_filter_rows == 64 ? 2 : 1;
-    return (capacity_u + T * RBsel - 1) / (T * RBsel);
-}
+int filter_tiles_per_layer(int capacity_u) { return (capacity_u + T - 1) / T; }
 
 // layer == -1: node role = lin1 of block 0 only; layer == -2: no node role.
 // Filter role: items [g_begin, g_begin + g_count) of the queue (layer_w0 + g / tiles_per_layer, g % tiles_per_layer);
-// wf_base = filters of queue layer 0.  g_count == 0: no filter role.
+// wf_base = filter slot 0, layer l of the queue writes slot l % wf_slots.  g_count == 0: no filter role.
 int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N, tsd_edges enc,
                        const float* Wf_layer, const float* x1_in, const float* h_in, float* h, float* x1_out,
                        int layer_w0, int g_begin, int g_count,
-                       int capacity_u, tsd_edges enc_u, const float* edge_attr, float* wf_base, int M, size_t nh_stride,
-                       size_t ea_stride, size_t wf_stride, hipStream_t st, const ComboPre* pre, size_t pre_stride) {
+                       int capacity_u, tsd_edges enc_u, const float* edge_attr, float* wf_base, int wf_slots, int M,
+                       size_t nh_stride, size_t ea_stride, size_t wf_stride, hipStream_t st, const ComboPre* pre,
+                       size_t pre_stride) {
     const WeightLayout L = weight_layout(c);
     ComboNode a{};
     a.N = N;
@@ -483,10 +410,6 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
         a.lin_b = B + L.L_lin_b;
         a.lin1_next_w = (layer + 1 < c.num_convs) ? B + L.layer_stride + L.L_lin1_w : nullptr;
     }
-    // 32-edge filter tiles unless 64 is forced (tsd_set_filter_tile): in this 8-wave layout the 64-edge
-    // tiles measured SLOWER at every size (C5 55.6 vs 53.7 ms/step, M=8 3.60 vs 3.43, batch 1600 6.48 vs 6.12):
-    // 66 KB of LDS halve the resident workgroups, which costs more than the halved B traffic gains.
-    const int RBsel = g_filter_rows == 64 ? 2 : 1;
     ComboFilter f{};
     f.tiles = 0;
     if (g_count > 0) {
@@ -506,33 +429,22 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
         f.edge_attr = edge_attr;
         f.wf = wf_base;
         f.wf_layer_stride = (size_t)capacity_u * c.hidden;
+        f.wf_slots = wf_slots < 1 ? 1 : wf_slots;
     }
     const int node_tiles = layer == -2 ? 0 : (N + TN - 1) / TN;
     ComboPre q{};
-    if (pre && pre->tiles > 0 && g_filter_rows != 64 && g_combo_cols != 64) q = *pre;  // H/32-wave layout only
+    if (pre && pre->tiles > 0) q = *pre;
     const int grid = node_tiles + f.tiles + q.tiles;
     if (grid == 0) return TSD_OK;
-    static const size_t lds_pad = getenv("TSDIFF_COMBO_LDS_PAD") ? (size_t)atoi(getenv("TSDIFF_COMBO_LDS_PAD")) : 0;
-    const size_t lds = lds_combo(c.hidden, RBsel) + lds_pad;  // (experiment knob: caps the resident workgroups per CU)
-    const int cols = g_combo_cols == 64 ? 64 : 32;
-    static const int phase_sleep = getenv("TSDIFF_PHASE_SLEEP") ? atoi(getenv("TSDIFF_PHASE_SLEEP")) : 0;
-    static const int ablate = getenv("TSDIFF_ABLATE") ? atoi(getenv("TSDIFF_ABLATE")) : 0;
-    static const int node_prio = getenv("TSDIFF_NODE_PRIO") ? atoi(getenv("TSDIFF_NODE_PRIO")) : 1;
-    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, g_node_run, phase_sleep, pre_stride, node_prio, ablate};
-#define TSD_COMBO_RB(HH, RR, CC, PP)                                                                          \
-    {                                                                                                         \
-        static bool done = false;                                                                             \
-        if (!done && lds > 48 * 1024)                                                                         \
-            TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_combo_kernel<HH, RR, CC, PP>),    \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
-        done = true;                                                                                          \
-        hipLaunchKernelGGL((layer_combo_kernel<HH, RR, CC, PP>), dim3(grid, M), dim3(2 * HH / CC), lds, st, a,\
-                           node_tiles, f, sd, q);                                                                \
-    }
-#define TSD_COMBO(HH)                                                                                         \
-    {                                                                                                         \
-        if (RBsel == 2) TSD_COMBO_RB(HH, 2, 1, 4) else if (cols == 64) TSD_COMBO_RB(HH, 1, 2, 4)              \
-        else if (g_combo_prefetch == 8 && HH >= 128) TSD_COMBO_RB(HH, 1, 1, 8) else TSD_COMBO_RB(HH, 1, 1, 4) \
+    const size_t lds = lds_combo(c.hidden);
+    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, pre_stride};
+#define TSD_COMBO(HH)                                                                                       \
+    {                                                                                                       \
+        static DeviceOnce once;                                                                             \
+        int r = allow_lds(layer_combo_kernel<HH>, lds, once);                                               \
+        if (r) return r;                                                                                    \
+        hipLaunchKernelGGL((layer_combo_kernel<HH>), dim3(grid, M), dim3(2 * HH), lds, st, a, node_tiles, f, \
+                           sd, q);                                                                          \
     }
     switch (c.hidden) {
         case 64: TSD_COMBO(64) break;
@@ -540,7 +452,6 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
         case 256: TSD_COMBO(256) break;
         default: set_error("hidden=%d unsupported (64/128/256)", c.hidden); return TSD_ERR_INVALID;
     }
-#undef TSD_COMBO_RB
 #undef TSD_COMBO
     TSD_LAUNCH_CHECK("layer_combo");
     return TSD_OK;

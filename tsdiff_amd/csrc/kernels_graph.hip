@@ -144,12 +144,10 @@ int launch_topology(int N, int G, int P, int64_t nb, const int32_t* graph_ptr, c
     }
     if (G > 0) {
         const size_t lds = (size_t)2 * max_n * max_n + 16;
-        static bool done = false;
-        if (!done || lds > 48 * 1024) {
+        static DeviceOnce once;
+        if (once.first_on_current_device())
             TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hop_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            done = true;
-        }
         hipLaunchKernelGGL(hop_kernel, dim3(G), dim3(256), lds, st, graph_ptr, pair_base, pair_code, max_order,
                            status);
         TSD_LAUNCH_CHECK("hop");
@@ -445,20 +443,21 @@ __global__ __launch_bounds__(64) void step_post_kernel(int kind, int N, int M, i
                                                        const int32_t* __restrict__ graph_ptr,
                                                        const int32_t* __restrict__ pair_ptr,
                                                        const uint16_t* __restrict__ pair_code, tsd_edges out,
-                                                       const float* __restrict__ inv_u,
-                                                       const float* __restrict__ noise,
-                                                       const float* __restrict__ coefs, float clip, float clip_pos,
-                                                       float* __restrict__ pos, float* __restrict__ traj,
-                                                       int32_t* __restrict__ status,
-                                                       const int32_t* __restrict__ step_ctr, int order_enc,
-                                                       int order_out, float cut2, int32_t* __restrict__ cnt) {
+                                                       const float* __restrict__ inv_u, float clip, float clip_pos,
+                                                       float* __restrict__ pos, tsd_sampler_state* __restrict__ ss,
+                                                       int order_enc, int order_out, float cut2,
+                                                       int32_t* __restrict__ cnt) {
     __shared__ float old_s[3 * (TSD_MAX_GRAPH_NODES + 1)];
     __shared__ float new_s[3 * (TSD_MAX_GRAPH_NODES + 1)];
     __shared__ int cnt_s[NLIST * (TSD_MAX_GRAPH_NODES + 1)];
-    const size_t k_step = (size_t)*step_ctr;
-    coefs += k_step * TSD_STEP_COEFS;
-    noise += k_step * 3 * (size_t)N;
-    if (traj) traj += k_step * 3 * (size_t)N;
+    // everything a call may change comes from the device-resident state block (the captured graph is reused
+    // by every call): the row of the coefficient / noise / trajectory arrays is the device-side step counter
+    const size_t k_step = (size_t)ss->step;
+    const float* __restrict__ coefs = ss->args.coefs + k_step * TSD_STEP_COEFS;
+    const float* __restrict__ noise = ss->args.noises ? ss->args.noises + k_step * 3 * (size_t)N : nullptr;
+    float* __restrict__ traj = ss->args.traj ? ss->args.traj + k_step * 3 * (size_t)N : nullptr;
+    const uint64_t seed = ss->args.seed, ctr0 = ss->args.offset + k_step * (uint64_t)N;
+    int32_t* status = &ss->flags;
     const int g = blockIdx.x;
     const int lo = graph_ptr[g], hi = graph_ptr[g + 1];
     const int n = hi - lo;
@@ -518,10 +517,16 @@ __global__ __launch_bounds__(64) void step_post_kernel(int kind, int N, int M, i
         // clip_norm (sampler.py:265-268)
         const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(v[0], v[0]), __fmul_rn(v[1], v[1])), __fmul_rn(v[2], v[2])));
         const float denom = norm > clip ? clip / norm : 1.0f;
+        float zn[3];
+        if (noise) {
+            zn[0] = noise[3 * i]; zn[1] = noise[3 * i + 1]; zn[2] = noise[3 * i + 2];
+        } else {
+            philox_normal3(ctr0 + (uint64_t)i, seed, zn);  // sampler.py:213 randn_like, generated in place
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float eps = __fmul_rn(v[k], denom);
-            const float nz = noise[3 * i + k];
+            const float nz = zn[k];
             float nx;
             if (kind == 0) {  // LD, sampler.py:238-244
                 nx = __fadd_rn(__fadd_rn(p[k], __fmul_rn(c[0], eps) / c[1]), __fmul_rn(nz, c[2]));
@@ -600,14 +605,41 @@ __global__ __launch_bounds__(64) void step_post_kernel(int kind, int N, int M, i
 
 int launch_step_post(const tsd_model_cfg& c, int kind, int N, int G, int M, int P, const int32_t* graph_ptr,
                      const int32_t* pair_ptr, const uint16_t* pair_code, tsd_geometry g, const float* inv_u,
-                     const float* noises, const float* coefs, float clip, float clip_pos, float* pos, float* traj,
-                     int32_t* status, const int32_t* step_ctr, hipStream_t st) {
+                     float clip, float clip_pos, float* pos, tsd_sampler_state* state, hipStream_t st) {
     if (G > 0) {
         hipLaunchKernelGGL(step_post_kernel, dim3(G), dim3(64), 0, st, kind, N, M, P / 2, graph_ptr, pair_ptr,
-                           pair_code, g.out, inv_u, noises, coefs, clip, clip_pos, pos, traj, status, step_ctr,
-                           c.edge_order, c.pred_edge_order, c.edge_cutoff * c.edge_cutoff, g.scratch);
+                           pair_code, g.out, inv_u, clip, clip_pos, pos, state, c.edge_order, c.pred_edge_order,
+                           c.edge_cutoff * c.edge_cutoff, g.scratch);
         TSD_LAUNCH_CHECK("step_post");
     }
+    return TSD_OK;
+}
+
+// per-call inputs of the captured step -> the device-resident state block (flags untouched); step = -1: the
+// scan kernel of every step, the first included, advances it
+__global__ void set_run_args_kernel(tsd_sampler_state* ss, tsd_run_args a) {
+    ss->args = a;
+    ss->step = -1;
+}
+int launch_set_run_args(tsd_sampler_state* ss, const tsd_run_args& a, hipStream_t st) {
+    hipLaunchKernelGGL(set_run_args_kernel, dim3(1), dim3(1), 0, st, ss, a);
+    TSD_LAUNCH_CHECK("set_run_args");
+    return TSD_OK;
+}
+
+__global__ void philox_normal_kernel(uint64_t seed, uint64_t offset, int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float z[3];
+    philox_normal3(offset + (uint64_t)i, seed, z);
+    out[3 * i] = z[0];
+    out[3 * i + 1] = z[1];
+    out[3 * i + 2] = z[2];
+}
+int launch_philox_normal(uint64_t seed, uint64_t offset, int64_t n, float* out, hipStream_t st) {
+    if (n <= 0) return TSD_OK;
+    hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, seed, offset, n, out);
+    TSD_LAUNCH_CHECK("philox_normal");
     return TSD_OK;
 }
 

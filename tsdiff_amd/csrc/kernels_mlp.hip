@@ -555,16 +555,6 @@ static inline size_t lds_cfconv(int H) { return (size_t)(T * (H + 4) + 5 * T) * 
 static inline size_t lds_node(int H) { return (size_t)(TN * (H + 4) + 2 * TN) * 4; }
 static inline size_t lds_pair(int H) { return (size_t)(T * (2 * H + 4) + (H / 64) * T + 3 * T) * 4; }
 
-template <typename K>
-static int allow_lds_once(K kernel, size_t bytes, bool& done) {
-    if (!done && bytes > 48 * 1024) {
-        TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    }
-    done = true;
-    return TSD_OK;
-}
-
 #define TSD_DISPATCH_H(H_, ...)                                     \
     switch (H_) {                                                   \
         case 64: { constexpr int HH = 64; __VA_ARGS__; } break;     \
@@ -587,7 +577,7 @@ int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_ed
     if (tiles_a + tiles_b + um.blocks == 0) return TSD_OK;
     const size_t lds = lds_edge_embed(c.hidden);
     TSD_DISPATCH_H(c.hidden, {
-        static bool done = false; int r = allow_lds_once(edge_embed_kernel<HH>, lds, done);
+        static DeviceOnce once; int r = allow_lds(edge_embed_kernel<HH>, lds, once);
         if (r) return r;
         hipLaunchKernelGGL(edge_embed_kernel<HH>, dim3(tiles_a + tiles_b + um.blocks, M), dim3(2 * HH), lds, st, w, ea,
                            out_a, tiles_a, eb, out_b, L.total, out_stride, tiles_a + tiles_b, um);
@@ -610,7 +600,7 @@ int launch_cfconv_layer(const tsd_model_cfg& c, const float* W, int layer, int c
     if (tiles == 0) return TSD_OK;
     const size_t lds = lds_cfconv(c.hidden);
     TSD_DISPATCH_H(c.hidden, {
-        static bool done = false; int r = allow_lds_once(cfconv_layer_kernel<HH>, lds, done);
+        static DeviceOnce once; int r = allow_lds(cfconv_layer_kernel<HH>, lds, once);
         if (r) return r;
         hipLaunchKernelGGL(cfconv_layer_kernel<HH>, dim3(tiles), dim3(HH), lds, st, w, c.conv_cutoff, c.smooth_conv, e,
                            edge_attr, x1, agg, part);
@@ -628,7 +618,7 @@ int launch_filter_gen(const tsd_model_cfg& c, const float* W, int capacity, tsd_
     if (tiles == 0 || nlayers <= 0) return TSD_OK;
     const size_t lds = lds_filter(c.hidden);
     TSD_DISPATCH_H(c.hidden, {
-        static bool done = false; int r = allow_lds_once(filter_gen_kernel<HH>, lds, done);
+        static DeviceOnce once; int r = allow_lds(filter_gen_kernel<HH>, lds, once);
         if (r) return r;
         hipLaunchKernelGGL(filter_gen_kernel<HH>, dim3(tiles, nlayers), dim3(HH), lds, st, W + L.layer0,
                            L.layer_stride, L.L_nn0_w, L.L_nn0_b, L.L_nn2_w, L.L_nn2_b, c.conv_cutoff, c.smooth_conv, e, edge_attr,
@@ -649,7 +639,7 @@ int launch_node_update(const tsd_model_cfg& c, const float* W, int layer, int ne
     if (tiles == 0) return TSD_OK;
     const size_t lds = lds_node(c.hidden);
     TSD_DISPATCH_H(c.hidden, {
-        static bool done = false; int r = allow_lds_once(node_update_kernel<HH, 0>, lds, done);
+        static DeviceOnce once; int r = allow_lds(node_update_kernel<HH, 0>, lds, once);
         if (r) return r;
         hipLaunchKernelGGL((node_update_kernel<HH, 0>), dim3(tiles), dim3(2 * HH), lds, st, w, N, row_ptr, agg, part,
                            h, x1);
@@ -667,7 +657,7 @@ int launch_node_lin1(const tsd_model_cfg& c, const float* W, int layer, int N, c
     if (tiles == 0) return TSD_OK;
     const size_t lds = lds_node(c.hidden);
     TSD_DISPATCH_H(c.hidden, {
-        static bool done = false; int r = allow_lds_once(node_update_kernel<HH, 1>, lds, done);
+        static DeviceOnce once; int r = allow_lds(node_update_kernel<HH, 1>, lds, once);
         if (r) return r;
         hipLaunchKernelGGL((node_update_kernel<HH, 1>), dim3(tiles), dim3(2 * HH), lds, st, w, N,
                            (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr,
@@ -686,7 +676,7 @@ int launch_pair_output(const tsd_model_cfg& c, const float* W, int capacity, tsd
     if (tiles == 0) return TSD_OK;
     const size_t lds = lds_pair(c.hidden);
     TSD_DISPATCH_H(c.hidden, {
-        static bool done = false; int r = allow_lds_once(pair_output_kernel<HH>, lds, done);
+        static DeviceOnce once; int r = allow_lds(pair_output_kernel<HH>, lds, once);
         if (r) return r;
         hipLaunchKernelGGL(pair_output_kernel<HH>, dim3(tiles, M), dim3(2 * HH), lds, st, w, e, h, edge_attr, attr_row,
                            edge_inv, L.total, h_stride, ea_stride, inv_stride, pre, pre_stride);

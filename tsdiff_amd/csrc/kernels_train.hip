@@ -87,11 +87,11 @@ template <int K, int CB, int NW, int PF>
 static int launch_linear_mfma(int rows, int nout, const float* A, const float* Bp, const LinEpi& epi, float* Y,
                               hipStream_t st) {
     const size_t lds = (size_t)32 * (K + 4) * 4;
-    static bool done = false;
-    if (!done && lds > 48 * 1024)
-        TSD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_mfma_kernel<K, CB, PF, NW>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    done = true;
+    static DeviceOnce once;
+    {
+        int r = allow_lds(linear_mfma_kernel<K, CB, PF, NW>, lds, once);
+        if (r) return r;
+    }
     hipLaunchKernelGGL((linear_mfma_kernel<K, CB, PF, NW>), dim3((rows + 31) / 32, nout / (CB * 32 * NW)),
                        dim3(64 * NW), lds, st, rows, nout, A, Bp, epi, Y);
     TSD_LAUNCH_CHECK("linear_mfma");
@@ -100,27 +100,14 @@ static int launch_linear_mfma(int rows, int nout, const float* A, const float* B
 
 static bool mfma_shape(int K, int NOUT) { return (K == 128 || K == 256 || K == 512) && (NOUT == 128 || NOUT == 256 || NOUT == 512); }
 
-int g_linear_layout = 0;  // A/B knob (env TSDIFF_LINEAR_LAYOUT): 0 = 8 waves x 32 columns, 1 = 4 waves x 64 columns
-
 static int dispatch_linear_mfma(int rows, int K, int NOUT, const float* A, const float* Bp, const LinEpi& epi, float* Y,
                                 hipStream_t st) {
-    static int init = 0;
-    if (!init) {
-        const char* e = getenv("TSDIFF_LINEAR_LAYOUT");
-        if (e) g_linear_layout = atoi(e);
-        init = 1;
-    }
     // fewer than one workgroup per CU with full-width tiles: 4 waves x 32 columns, the columns split over
     // grid.y, deep pinned prefetch (a latency chain)
     const bool small = (rows + 31) / 32 < 256;
 #define TSD_LM(KK)                                                                                              \
     if (K == KK) {                                                                                              \
         if (small) return launch_linear_mfma<KK, 1, 4, 16>(rows, NOUT, A, Bp, epi, Y, st);                      \
-        if (g_linear_layout == 1) {                                                                             \
-            if (NOUT == 128) return launch_linear_mfma<KK, 1, 4, 4>(rows, NOUT, A, Bp, epi, Y, st);             \
-            if (NOUT == 256) return launch_linear_mfma<KK, 2, 4, 4>(rows, NOUT, A, Bp, epi, Y, st);             \
-            return launch_linear_mfma<KK, 4, 4, 4>(rows, NOUT, A, Bp, epi, Y, st);                              \
-        }                                                                                                       \
         if (NOUT == 128) return launch_linear_mfma<KK, 1, 4, 4>(rows, NOUT, A, Bp, epi, Y, st);                 \
         if (NOUT == 256) return launch_linear_mfma<KK, 1, 8, 4>(rows, NOUT, A, Bp, epi, Y, st);                 \
         return launch_linear_mfma<KK, 2, 8, 4>(rows, NOUT, A, Bp, epi, Y, st);                                  \

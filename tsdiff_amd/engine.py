@@ -62,6 +62,11 @@ def make_cfg(model_config):
     )
 
 
+def cfg_tuple(cfg):
+    """the fields of a tsd_model_cfg as a comparable tuple"""
+    return tuple(getattr(cfg, f) for f, _ in cfg._fields_)
+
+
 def pack_weights(cfg, named_tensors, device):
     """named_tensors: name -> tensor (reference state_dict names).  Returns packed fp32 device arena."""
     lib = _lib.load()
@@ -153,7 +158,8 @@ class DeviceBatch:
         self.node_graph = torch.zeros(max(N, 1), **i32)
         self.pair_ptr = torch.zeros(N + 1, **i32)
         self.pair_code = torch.zeros(max(P, 1), dtype=torch.int16, device=dev)
-        self.status = torch.zeros(4, **i32)
+        # tsd_sampler_state: [0] status flags (also the topology build's status word), [1] step counter, run args
+        self.status = torch.zeros(_lib.SAMPLER_STATE_INTS, **i32)
         self.atom_type = atom_type.to(torch.int64).contiguous()
         self.r_feat = r_feat.to(torch.int64).contiguous()
         self.p_feat = p_feat.to(torch.int64).contiguous()
@@ -182,6 +188,8 @@ class DeviceBatch:
         self.edge_inv = None
         self.z = None
         self._z_key = None
+        self.pos_work = torch.zeros(max(N, 1), 3, dtype=torch.float32, device=dev)  # the loop's in-place positions
+        self._plans = {}  # (kind, clip, clip_pos) -> tsd_sampler_plan* of the bound checkpoints
         self.scratch = torch.zeros(((P + 63) // 64) * 64 + 3 * N + 128, dtype=torch.float32, device=dev)
 
     def check_status(self, word=None):
@@ -201,6 +209,7 @@ class DeviceBatch:
         lib = _lib.load()
         if self._z_key == key:
             return
+        self.drop_plans()  # captured graphs hold the old weight / workspace pointers
         M = len(packed_list)
         H = self.cfg.hidden
         self.weights = torch.stack(packed_list) if M > 1 else packed_list[0].reshape(1, -1)
@@ -282,27 +291,57 @@ class DeviceBatch:
         ei = torch.stack([el.src[:E], el.dst[:E]]).to(torch.int64)
         return ei, el.dist[:E].clone().unsqueeze(-1), el.type_r[:E].to(torch.int64), el.type_p[:E].to(torch.int64)
 
-    def sampler_run(self, kind, pos, coefs, noises, clip, clip_pos, want_traj, use_graph=True):
+    # ---- the device-resident sampling loop ---------------------------------------------------
+    def drop_plans(self):
+        if not getattr(self, "_plans", None):
+            return
+        torch.cuda.synchronize(self.device)  # an exec must outlive its launches
         lib = _lib.load()
-        self.check_status()
-        n_steps = int(coefs.shape[0])
-        traj = (torch.empty(n_steps, self.N, 3, dtype=torch.float32, device=self.device) if want_traj else None)
-        self.status.zero_()
-        b = self.struct()
+        for plan in self._plans.values():
+            lib.tsd_sampler_plan_destroy(plan)
+        self._plans = {}
+
+    def __del__(self):
+        try:
+            self.drop_plans()
+        except Exception:
+            pass
+
+    def sampler_plan(self, kind, clip, clip_pos):
+        """the captured + instantiated hipGraph of one sampling step for the bound checkpoints; built once and
+        replayed by every later dynamic_sampling call on this batch (reference loop: models/sampler.py:187-254)"""
+        key = (int(kind), float(clip), float(-1.0 if clip_pos is None else clip_pos))
+        plan = self._plans.get(key)
+        if plan is None:
+            lib = _lib.load()
+            self.check_status()
+            b = self.struct()
+            side = _side_stream(self.device)  # capture is illegal on the legacy default stream
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            plan = C.c_void_p()
+            check(lib.tsd_sampler_plan_create(C.byref(self.cfg), C.byref(b), key[0], key[1], key[2],
+                                              ptr(self.pos_work), ptr(self.status), C.c_void_p(side.cuda_stream),
+                                              C.byref(plan)))
+            self._plans[key] = plan
+        return plan
+
+    def sampler_run(self, kind, coefs, noises, seed, offset, clip, clip_pos, traj, use_graph=True):
+        """n = coefs.shape[0] steps on self.pos_work, asynchronous on the current stream (no host sync).
+        noises None: device Philox draws keyed by (seed, offset)."""
+        lib = _lib.load()
+        plan = self.sampler_plan(kind, clip, clip_pos)
+        args = _lib.RunArgs(coefs=coefs.data_ptr(), noises=None if noises is None else noises.data_ptr(),
+                            traj=None if traj is None else traj.data_ptr(), seed=int(seed), offset=int(offset))
         cur = torch.cuda.current_stream(self.device)
-        # hipStreamBeginCapture is illegal on the legacy default stream: run the loop on a side stream
-        side = _side_stream(self.device) if (use_graph and cur.cuda_stream == 0) else None
+        # a graph may not be launched into the legacy default stream either: hop to the side stream
+        side = _side_stream(self.device) if cur.cuda_stream == 0 else None
         run_on = side if side is not None else cur
         if side is not None:
             side.wait_stream(cur)
-        with torch.cuda.stream(run_on):
-            check(lib.tsd_sampler_run(C.byref(self.cfg), C.byref(b), kind, n_steps, ptr(coefs), ptr(noises),
-                                      float(clip), float(-1.0 if clip_pos is None else clip_pos), ptr(pos),
-                                      ptr(traj), ptr(self.status), int(bool(use_graph)),
-                                      C.c_void_p(run_on.cuda_stream)))
+        check(lib.tsd_sampler_plan_run(plan, int(coefs.shape[0]), C.byref(args), int(bool(use_graph)),
+                                       C.c_void_p(run_on.cuda_stream)))
         if side is not None:
             cur.wait_stream(side)
-        return traj
 
 
 def eq_transform(score_d, pos, edge_index, edge_length):

@@ -22,10 +22,17 @@ class EnsembleSampler(nn.Module):
         self.alphas = models[0].alphas
         self.betas = models[0].betas
         self.num_timesteps = models[0].num_timesteps
+        self._coef_cache = {}
 
     # ------------------------------------------------------------------------------------------
     def _bound_batch(self, atom_type, r_feat, p_feat, bond_index, bond_type, batch, num_graphs=None):
         m0 = self.models[0]
+        for m in self.models[1:]:
+            # the checkpoints of an ensemble run in the same launches on ONE set of edge lists (the reference runs
+            # each model's own forward, sampler.py:78-109): that needs identical network / graph settings
+            if engine.cfg_tuple(m._cfg) != engine.cfg_tuple(m0._cfg):
+                raise NotImplementedError("ensemble members with different model configs "
+                                          f"({engine.cfg_tuple(m._cfg)} vs {engine.cfg_tuple(m0._cfg)})")
         db = m0.device_batch(atom_type, r_feat, p_feat, bond_index, bond_type, batch)
         if num_graphs is not None and int(num_graphs) != db.G:
             raise ValueError(f"num_graphs={num_graphs} but batch holds {db.G} graphs")
@@ -47,48 +54,79 @@ class EnsembleSampler(nn.Module):
         return edge_inv, edge_index, edge_length
 
     # ------------------------------------------------------------------------------------------
-    def step_coefficients(self, seq, seq_next, sampling_type, step_lr):
-        """(n_steps, 8) fp32 table, one row per iteration in execution order, evaluated with the same
-        fp32 tensor expressions as the reference loop body (sampler.py:215-244) -- elementwise on the
-        whole index vector at once (identical values: the reference's ops are elementwise too; a Python loop
-        over 5000 steps would put ~30 000 tiny launches in front of the sampling loop)."""
+    def _coef_tables(self, sampling_type, step_lr):
+        """(T, 8) fp32 coefficient rows for EVERY time index i (with the reference loop's j = i - 1), plus the
+        rows for j = -1 (the first element of a sequence, sampler.py:190), evaluated with the same fp32 tensor
+        expressions as the reference loop body (sampler.py:215-244) on the whole index vector at once (identical
+        values: the reference's ops are elementwise).  Built once per (type, step_lr, schedule)."""
         dev = self.alphas.device
-        sigmas = (1.0 - self.alphas).sqrt() / self.alphas.sqrt()
-        idx = torch.tensor(list(reversed(seq)), dtype=torch.long, device=dev)
-        n = idx.numel()
-        zero = torch.zeros(n, dtype=torch.float32, device=dev)
+        key = ("tab", sampling_type, float(step_lr), str(dev), self.alphas.data_ptr(), self.alphas._version,
+               self.betas._version)
+        hit = self._coef_cache.get(key)
+        if hit is not None:
+            return hit
+        T = self.num_timesteps
+        idx = torch.arange(T, dtype=torch.long, device=dev)
+        zero = torch.zeros(T, dtype=torch.float32, device=dev)
         if sampling_type == "ld":
+            sigmas = (1.0 - self.alphas).sqrt() / self.alphas.sqrt()
             sig = sigmas.index_select(0, idx)
             step_size = step_lr * (sig / 0.01) ** 2
-            rows = torch.stack([step_size, sig, torch.sqrt(step_size * 2), zero, zero, zero, zero, zero], dim=1)
+            main = torch.stack([step_size, sig, torch.sqrt(step_size * 2), zero, zero, zero, zero, zero], dim=1)
+            first = main
         elif sampling_type == "ddpm":
-            jdx = torch.tensor(list(reversed(seq_next)), dtype=torch.long, device=dev)
             beta = torch.cat([torch.zeros(1, device=dev), self.betas], dim=0)
             acp = (1 - beta).cumprod(dim=0)
-            at, atm1 = acp.index_select(0, idx + 1), acp.index_select(0, jdx + 1)
-            beta_t = 1 - at / atm1
-            mask = 1.0 - (idx == 0).to(torch.float32)
-            rows = torch.stack([
-                at.sqrt(), (1.0 / at).sqrt(), (1.0 / at - 1).sqrt(), atm1.sqrt() * beta_t,
-                (1 - beta_t).sqrt() * (1 - atm1), 1.0 - at, mask * torch.exp(0.5 * beta_t.log()),
-                atm1.sqrt()], dim=1)
+
+            def rows(jdx):
+                at, atm1 = acp.index_select(0, idx + 1), acp.index_select(0, jdx + 1)
+                beta_t = 1 - at / atm1
+                mask = 1.0 - (idx == 0).to(torch.float32)
+                return torch.stack([
+                    at.sqrt(), (1.0 / at).sqrt(), (1.0 / at - 1).sqrt(), atm1.sqrt() * beta_t,
+                    (1 - beta_t).sqrt() * (1 - atm1), 1.0 - at, mask * torch.exp(0.5 * beta_t.log()),
+                    atm1.sqrt()], dim=1)
+            main, first = rows(idx - 1), rows(torch.full_like(idx, -1))
         else:
             raise NotImplementedError(sampling_type)
-        return rows.to(torch.float32).contiguous()
+        hit = (main.to(torch.float32).contiguous(), first.to(torch.float32).contiguous())
+        self._coef_cache[key] = hit
+        return hit
+
+    def step_coefficients(self, seq, seq_next, sampling_type, step_lr):
+        """(n_steps, 8) fp32 table, one row per iteration in execution order (reversed seq).  seq must be the
+        reference's contiguous range with seq_next = [-1] + seq[:-1] (sampler.py:187-190)."""
+        n = len(seq)
+        main, first = self._coef_tables(sampling_type, step_lr)
+        if n == 0:
+            return main[:0]
+        assert list(seq_next) == [-1] + list(seq[:-1]) and seq[-1] - seq[0] == n - 1, "non-contiguous sequence"
+        key = ("rows", sampling_type, float(step_lr), seq[0], n, main.data_ptr())
+        hit = self._coef_cache.get(key)
+        if hit is not None:
+            return hit
+        rows = main[seq[0]:seq[0] + n].flip(0).contiguous()
+        rows[n - 1] = first[seq[0]]
+        if len(self._coef_cache) > 16:
+            self._coef_cache.clear()
+        self._coef_cache[key] = rows
+        return rows
 
     def dynamic_sampling(self, atom_type, r_feat, p_feat, pos_init, bond_index, bond_type, batch, num_graphs,
                          extend_order, extend_radius=True, n_steps=100, step_lr=0.0000010, clip=1000,
                          clip_pos=None, denoise_from_time_t=None, noise_from_time_t=None, **kwargs):
         """Same arguments as the reference.  Extra keyword-only knobs (all optional):
         noises=(n_steps,N,3) tensor to inject the Gaussian draws (init_noise=(N,3) for the initial draw of the
-        noise_from_time_t mode), return_traj=False to skip the trajectory, use_graph=False to launch
-        eagerly instead of replaying a hipGraph."""
+        noise_from_time_t mode); without it the draws are generated on the device (Philox4x32-10, seeded from
+        torch's CPU generator so torch.manual_seed reproduces a run, or seed=int) -- no (n_steps,N,3) buffer;
+        return_traj=False to skip the trajectory, use_graph=False to launch eagerly instead of replaying the
+        batch's cached hipGraph."""
         sampling_type = kwargs.get("sampling_type", "ddpm")
         noises = kwargs.get("noises", None)
         return_traj = kwargs.get("return_traj", True)
         use_graph = kwargs.get("use_graph", True)
+        seed = kwargs.get("seed", None)
         dev = pos_init.device
-        sigmas = (1.0 - self.alphas).sqrt() / self.alphas.sqrt()
         with torch.no_grad():
             if noise_from_time_t is not None:  # sampler.py:149-166
                 assert denoise_from_time_t >= n_steps
@@ -108,24 +146,43 @@ class EnsembleSampler(nn.Module):
                 pos = pos_init
             else:  # sampler.py:179-182
                 seq = range(self.num_timesteps - n_steps, self.num_timesteps)
+                sigmas = (1.0 - self.alphas).sqrt() / self.alphas.sqrt()
                 pos = pos_init * sigmas[-1]
             seq = list(seq)
             seq_next = [-1] + seq[:-1]
-            pos = pos.to(torch.float32).contiguous().clone()
-            N = pos.shape[0]
 
             db = self._bound_batch(atom_type, r_feat, p_feat, bond_index, bond_type, batch, num_graphs)
-            coefs = self.step_coefficients(seq, seq_next, sampling_type, step_lr).to(dev)
-            if noises is None:
-                noises = torch.randn(len(seq), N, 3, dtype=torch.float32, device=dev)
-            noises = noises.to(device=dev, dtype=torch.float32).contiguous()
+            N = db.N
+            if tuple(pos.shape) != (N, 3):
+                raise ValueError(f"pos_init has shape {tuple(pos.shape)}, batch holds {N} atoms")
+            coefs = self.step_coefficients(seq, seq_next, sampling_type, step_lr)
+            if coefs.device != dev:
+                coefs = coefs.to(dev)
+            n = len(seq)
+            if noises is not None:
+                noises = noises.to(device=dev, dtype=torch.float32).contiguous()
+                if tuple(noises.shape) != (n, N, 3):
+                    raise ValueError(f"noises has shape {tuple(noises.shape)}, expected {(n, N, 3)}")
+            elif seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # CPU generator: no device sync
             kind = 0 if sampling_type == "ld" else 1
-            traj = db.sampler_run(kind, pos, coefs, noises, clip, clip_pos, return_traj, use_graph)
+            db.pos_work[:N].copy_(pos)  # the loop updates this buffer in place (its address is captured in the graph)
+            db.status.zero_()
+            pos_traj = []
+            # the trajectory leaves the device in chunks of at most ~256 MB (5000 steps of config C5 are 3.9 GB)
+            chunk = n if not return_traj else max(1, min(n, (64 << 20) // max(3 * N, 1)))
+            for k0 in range(0, n, chunk):
+                k1 = min(n, k0 + chunk)
+                traj = torch.empty(k1 - k0, N, 3, dtype=torch.float32, device=dev) if return_traj else None
+                db.sampler_run(kind, coefs[k0:k1], None if noises is None else noises[k0:k1], seed or 0, k0 * N,
+                               clip, clip_pos, traj, use_graph)
+                if return_traj:
+                    pos_traj += list(traj.cpu().unbind(0))
             status = int(db.status[0].item())  # the single host sync of the loop
             if status & _lib.STATUS_NAN:
                 print("NaN detected. Please restart.")
                 raise FloatingPointError()
-            pos_traj = list(traj.cpu().unbind(0)) if return_traj else []
+            pos = db.pos_work[:N].clone()
         return pos, pos_traj
 
 
