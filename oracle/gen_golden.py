@@ -479,7 +479,7 @@ def main():
                  edge_inv_global=o["edge_inv_global"], edge_inv_local=o["edge_inv_local"], edge_type=o["edge_type"])
 
     # --- F: get_loss with captured random draws + gradient norms ---------------------------
-    def run_loss(model, b, name, cfg, seed):
+    def run_loss(model, b, name, cfg, seed, all_grads=False):
         bt = tt(b)
         cap = {}
         o_randint, o_randn = torch.randint, torch.randn
@@ -510,6 +510,12 @@ def main():
         time_step = torch.cat([half_1, t0 + t1 - 1 - half_1])[:G]
         gn = {k: float(p.grad.norm()) for k, p in model.named_parameters()
               if p.grad is not None and not k.startswith("model")}
+        if all_grads:  # every parameter's gradient, elementwise (small config: ~100 k floats)
+            full = {"grad." + k: p.grad.numpy() for k, p in model.named_parameters()
+                    if p.grad is not None and not k.startswith("model")}
+            save(name, {"cfg": cfg, "seed": seed, "grad_norms": gn}, **inputs_of(b),
+                 time_step=time_step.numpy(), pos_noise=cap["pos_noise"].numpy(), loss=loss.detach().numpy(), **full)
+            return
         save(name, {"cfg": cfg, "seed": seed, "grad_norms": gn}, **inputs_of(b),
              time_step=time_step.numpy(), pos_noise=cap["pos_noise"].numpy(), loss=loss.detach().numpy(),
              grad_lin1_0=model.encoder.interactions[0].conv.lin1.weight.grad.numpy(),
@@ -518,8 +524,18 @@ def main():
     b = synth.wb97xd3_like_batch(4, seed=8, n_lo=6, n_hi=14)
     b["pos"] = (b["pos"] * 1.5).astype(np.float32)
     run_loss(model_small, b, "loss_synth_b4_small", small_cfg, 1)
+    run_loss(model_small, b, "grads_synth_b4_small", small_cfg, 1, all_grads=True)  # same draws (seed 99), all gradients
     b = synth.replicate(g0, 2, [rxn0["pos_gen"][2], rxn0["pos_gen"][3]])
     run_loss(model_full, b, "loss_rxn0_b2_full", full_cfg, 0)
+
+    # --- F2: result-pickle fixture: the first two records of the reference's own samples_all.pkl (a data file the
+    # reference tree holds), re-written record for record by tsdiff_amd.io (rdkit Mol blobs pass through as bytes)
+    if not ONLY or "samples_rxn0_2" in ONLY:
+        from tsdiff_amd import io as tio
+        recs = tio.load_samples(os.path.join(ref_shims.REFERENCE_ROOT, "birkholz_benchmark/rxn_0/samples_all.pkl"))
+        path = os.path.join(OUT, "samples_rxn0_2.pkl")
+        tio.save_samples(path, recs[:2])
+        print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
 
     # --- G: schedule constants -----------------------------------------------------------
     save("schedule_full", {"cfg": full_cfg}, betas=model_full.betas.detach().numpy(),

@@ -102,10 +102,23 @@ def test_reference_checkpoint_round_trip(tmp_path):
         assert np.array_equal(model.state_dict()[k].numpy(), v), k
     # and our own save format loads back the same way
     p = str(tmp_path / "ck.pt")
-    io.save_checkpoint(p, ck["config"], model, iteration=7)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.95, 0.999))
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.8, patience=10)
+    io.save_checkpoint(p, ck["config"], model, opt, sched, iteration=7, avg_val_loss=0.5)
     ck2 = io.load_checkpoint(p)
-    assert ck2["iteration"] == 7 and ck2["config"]["model"]["hidden_dim"] == 64
+    # attribute access like the reference's sampling.py:128 / train.py:113-118 (config is an EasyDict there)
+    assert ck2["iteration"] == 7 and ck2["config"].model.hidden_dim == 64 and ck2["config"].train.batch_size == 200
     assert all(torch.equal(ck2["model"][k], model.state_dict()[k]) for k in model.state_dict())
+    opt.load_state_dict(ck2["optimizer"])
+    sched.load_state_dict(ck2["scheduler"])
+    with pytest.raises(ValueError):
+        io.save_checkpoint(p, ck["config"], model, None, None)
+    # on disk the config is the reference's class (a reader with easydict installed gets an EasyDict back) and
+    # nothing in the file needs this package to be importable
+    import zipfile
+    with zipfile.ZipFile(p) as z:
+        pk = z.read([n for n in z.namelist() if n.endswith("data.pkl")][0])
+    assert b"easydict\nEasyDict" in pk and b"tsdiff_amd" not in pk
 
 
 def test_header_is_plain_c(tmp_path):

@@ -88,6 +88,26 @@ def test_get_loss(name):
     assert_close(loss.numpy(), d["loss"], 5e-5, "loss")
 
 
+def test_get_loss_gradients_elementwise():
+    """pins the oracle's autograd: EVERY parameter gradient of loss.mean() against the unchanged reference's,
+    element by element (the GPU parity tests use the oracle's autograd as the checker for the full-size model)"""
+    d, meta = load_golden("grads_synth_b4_small")
+    b = batch_inputs(d)
+    sd = _sd(meta)
+    for v in sd.values():
+        v.requires_grad_(True)
+    loss = O.get_loss(sd, meta["cfg"], b["atom_type"], b["r_feat"], b["p_feat"], b["pos"], b["bond_index"],
+                      b["bond_type"], b["batch"], b["num_nodes_per_graph"].numpy(), torch.from_numpy(d["time_step"]),
+                      torch.from_numpy(d["pos_noise"]))
+    assert_close(loss.detach().numpy(), d["loss"], 5e-5, "loss")
+    loss.mean().backward()
+    keys = [k[5:] for k in d if k.startswith("grad.")]
+    assert len(keys) == len(meta["grad_norms"]) >= 30
+    for k in keys:
+        assert sd[k].grad is not None, k
+        assert_close(sd[k].grad.numpy(), d["grad." + k], 5e-5, "d loss / d " + k)
+
+
 def test_schedule():
     d, meta = load_golden("schedule_full")
     betas, alphas = O.beta_schedule(meta["cfg"])

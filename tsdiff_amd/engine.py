@@ -188,6 +188,7 @@ class DeviceBatch:
         self.edge_inv = None
         self.z = None
         self._z_key = None
+        self.geo_gen = 0  # bumped whenever the edge lists are rebuilt (saved training contexts check it)
         self.pos_work = torch.zeros(max(N, 1), 3, dtype=torch.float32, device=dev)  # the loop's in-place positions
         self._plans = {}  # (kind, clip, clip_pos) -> tsd_sampler_plan* of the bound checkpoints
         self.scratch = torch.zeros(((P + 63) // 64) * 64 + 3 * N + 128, dtype=torch.float32, device=dev)
@@ -254,6 +255,7 @@ class DeviceBatch:
     def geometry(self, pos):
         lib = _lib.load()
         self.check_status()
+        self.geo_gen += 1
         pos = pos.to(torch.float32).contiguous()
         check(lib.tsd_geometry_build(C.byref(self.cfg), self.N, self.G, self.P, ptr(pos), ptr(self.graph_ptr),
                                      ptr(self.node_graph), ptr(self.pair_ptr), ptr(self.pair_code),
@@ -263,6 +265,7 @@ class DeviceBatch:
         """geometry + M forwards; results stay on the device (self.edge_inv_u[m, :E_out/2])."""
         lib = _lib.load()
         self.check_status()
+        self.geo_gen += 1
         pos = pos.to(torch.float32).contiguous()
         b = self.struct()
         check(lib.tsd_score_forward(C.byref(self.cfg), C.byref(b), ptr(pos), stream_ptr()))
@@ -330,6 +333,7 @@ class DeviceBatch:
         noises None: device Philox draws keyed by (seed, offset)."""
         lib = _lib.load()
         plan = self.sampler_plan(kind, clip, clip_pos)
+        self.geo_gen += 1
         args = _lib.RunArgs(coefs=coefs.data_ptr(), noises=None if noises is None else noises.data_ptr(),
                             traj=None if traj is None else traj.data_ptr(), seed=int(seed), offset=int(offset))
         cur = torch.cuda.current_stream(self.device)

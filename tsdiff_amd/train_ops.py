@@ -511,15 +511,32 @@ class FusedTrainLoss(torch.autograd.Function):
                                     ptr(db.p_feat), ptr(pos0), ptr(pos_perturbed), ptr(a_graph), ptr(db.status),
                                     ptr(ws), ws.numel(), ptr(loss), counts, stream_ptr()))
         db.check_status(counts[2])  # malformed bond lists raise ValueError here (results are discarded)
+        # The saved activations live in the model's shared arena and the edge lists in the cached batch: both are
+        # overwritten by the next get_loss / forward / geometry build.  Stamp them so that backward can tell.
+        db.geo_gen += 1
+        model._train_ws_gen = getattr(model, "_train_ws_gen", 0) + 1
+        ctx.stamp = (db.geo_gen, model._train_ws_gen)
+        ctx.used = False
         ctx.model, ctx.db, ctx.raw, ctx.ws, ctx.counts, ctx.pos = model, db, raw, ws, counts, pos_perturbed
         ctx.sizes = [p.numel() for p in params]
         ctx.shapes = [p.shape for p in params]
         return loss
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dloss):
         lib = _lib.load()
         cfg, db = ctx.model._cfg, ctx.db
+        if ctx.used:
+            raise RuntimeError("tsdiff_amd: the fused training step supports ONE backward per get_loss "
+                               "(tsd_train_backward consumes its saved activations in place)")
+        if ctx.stamp != (db.geo_gen, getattr(ctx.model, "_train_ws_gen", 0)):
+            raise RuntimeError(
+                "tsdiff_amd: the activations of this get_loss were overwritten before backward() -- another "
+                "get_loss / forward / sampling call ran on the same model or batch in between.  The fused training "
+                "step keeps ONE step's activations per model (reference order: get_loss, backward, step; "
+                "train.py:128-145).  Call backward first, or set TSDIFF_TRAIN=ops for the op-by-op autograd form.")
+        ctx.used = True
         grad = torch.empty_like(ctx.raw)
         dloss = _c(dloss.float()).view(-1)
         b = db.train_struct()
