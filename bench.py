@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- LD sampling throughput of the TSDiff score-network hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 500 --warmup 50
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -14,9 +14,14 @@ H=256 / 7-block condensenc network with closed-form synthetic weights, fp32, one
 Inputs are resident in HBM before the timed region; graphs shard across ranks with no data-path
 collective (each rank samples its own 100 graphs).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel (fused CFConv layer, fp32-MFMA-bound) timed live with events
-  cpu_baseline -- the CPU oracle (our restatement of the reference, kind "port") on the host cores
+Prints ONE JSON line on rank 0 (contract in the task statement).  Besides the headline fields:
+  roofline      -- the dominant kernel (one interaction block per launch, fp32-MFMA-bound) timed live with
+                   events, plus `aggregate`: the HBM-bound message-passing form (segmented reduce with a
+                   materialised filter) at BASELINE configs[4] size -- the >= 70 %-of-HBM target
+  cpu_baseline  -- the CPU oracle (our restatement of the reference, kind "port") on the host cores, at 32
+                   threads and at os.cpu_count(), plus the configs[4] chunk protocol of BASELINE.md 5.3
+  c5 / ensemble8 / train -- the other BASELINE configs this GPU runs (N = 1 only, a few steps each)
+Other workloads as the main line: --workload c5 | train (torchrun for N > 1 as above).
 """
 import argparse
 import ctypes as C
@@ -46,195 +51,103 @@ def parse():
                          "c5: configs[4] synthetic 64-atom graphs, complete pair set (use --graphs 1024); "
                          "train: configs[3] training step (use --graphs 200): get_loss + backward + "
                          "gradient all-reduce + clip + Adam")
-    ap.add_argument("--graphs", type=int, default=100, help="graphs per GPU (BASELINE configs[1]: 100)")
+    ap.add_argument("--graphs", type=int, default=0, help="graphs per GPU (default: 100 / 1024 / 200 by workload)")
     ap.add_argument("--models", type=int, default=1, help="ensemble size M (configs[2] uses 8)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the c5 / ensemble8 / train sub-objects")
     ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--reuse-batch", action="store_true",
                     help="train workload only: ONE batch for every step with its topology cached (A/B; the default "
                          "rotates 8 batches and rebuilds the topology every step like a real data loader)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.graphs <= 0:
+        a.graphs = {"c2": 100, "c5": 1024, "train": 200}[a.workload]
+    return a
 
 
-def bench_train(args, model, dev, rank, world, dist):
-    """BASELINE configs[3]: one training step of configs/train_config.yml (batch 200 graphs per GPU here,
-    weak scaling): loss (get_loss), backward, RCCL gradient all-reduce, clip_grad_norm_, Adam."""
+# ---------------------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------------------
+def to_dev(b, dev):
+    return {k: torch.from_numpy(v).to(dev) for k, v in b.items() if isinstance(v, np.ndarray)}
+
+
+def make_models(cfg, seeds, dev):
     from tsdiff_amd import synth
-    from tsdiff_amd.distributed import dp_backward
-    # a new batch every step, as a data loader delivers them: 8 distinct synthetic batches rotate and the model's
-    # batch cache is dropped before each step, so topology construction (k-hop pair codes, buffers) is inside
-    # the timed region like everything else
-    batches = []
-    for k in range(1 if args.reuse_batch else 8):
-        b = synth.wb97xd3_like_batch(args.graphs, seed=2000 + 16 * rank + k)
-        g = {kk: torch.from_numpy(v).to(dev) for kk, v in b.items() if isinstance(v, np.ndarray)}
-        g["pos"] = (g["pos"] * 1.5).contiguous()
-        batches.append(g)
-    N = int(sum(g["pos"].shape[0] for g in batches) / len(batches))
-    model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.95, 0.999))
-    counter = [0]
-
-    def step():
-        g = batches[counter[0] % len(batches)]
-        counter[0] += 1
-        if not args.reuse_batch:
-            model._batches.clear()
-        opt.zero_grad()
-        loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
-                              g["batch"], g["num_nodes_per_graph"], args.graphs)
-        mean = dp_backward(model, loss)
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 3000.0)
-        opt.step()
-        return mean
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        last = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    if rank == 0:
-        print(json.dumps({
-            "metric": "training steps/s (configs[3]: get_loss + backward + grad all-reduce + clip + Adam)",
-            "value": round(args.gpus * args.graphs * args.steps / dt, 1), "unit": "graphs/s",
-            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[3] training step", "graphs_per_gpu": args.graphs, "atoms_per_gpu": N,
-                       "parallelism": f"graph-batch data parallel over {args.gpus} GPU(s), one RCCL all-reduce of "
-                                      "the flat fp32 gradient per step"},
-            "final_loss": float(last)}))
-    if dist is not None:
-        dist.destroy_process_group()
-
-
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:  # one rank per GPU, launched by torch.distributed.run for N > 1: never report ranks that do not exist
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python -m torch.distributed.run "
-                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`")
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU
-        import torch.distributed as dist_
-        dist = dist_
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL; used for the barrier / max only
-
-    from tsdiff_amd import _lib, synth
     from tsdiff_amd.epsnet import get_model
-    from tsdiff_amd.sampler import EnsembleSampler
     from tsdiff_amd.utils import AttrDict
-
-    lib = _lib.load()  # raises if the HIP extension is missing: no fallback
-    cfg = synth.DEFAULT_MODEL_CONFIG
     models = []
-    for m in range(args.models):
+    for m in seeds:
         model = get_model(AttrDict(cfg))
         sd = synth.synth_state_dict(cfg, seed=m)
         model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
         models.append(model.to(dev))
-    sampler = EnsembleSampler(models)
-    if args.workload == "train":
-        return bench_train(args, models[0], dev, rank, world, dist)
+    return models
 
-    if args.workload == "c5":
-        b = synth.dense_stress_batch(args.graphs, n=64, seed=1000 + rank)
-    else:
-        b = synth.wb97xd3_like_batch(args.graphs, seed=1000 + rank)
-    g = {k: torch.from_numpy(v).to(dev) for k, v in b.items() if isinstance(v, np.ndarray)}
-    N = int(g["pos"].shape[0])
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    # compact start geometry (every intra-molecular pair within the 10 A cutoff -- the regime the last
-    # ~4000 of the 5000 steps of a real run are in); the timed steps are the LAST K of the schedule
-    pos_init = torch.randn(N, 3, device=dev, generator=gen) * 1.5
-    if args.workload == "c5":  # positions inside the 5.5 A cube: every pair within the cutoff
-        pos_init = g["pos"].clone()
 
-    def run(n_steps, pos0):
-        # the product's default path: Gaussian draws generated on the device (Philox), no trajectory kept
-        return sampler.dynamic_sampling(
-            g["atom_type"], g["r_feat"], g["p_feat"], pos0, g["bond_index"], g["bond_type"], g["batch"],
-            args.graphs, extend_order=True, n_steps=n_steps, step_lr=1e-7, clip=1000, sampling_type="ld",
-            denoise_from_time_t=n_steps, return_traj=False, use_graph=not args.no_graph, seed=1234 + rank)
+def forward_flops(E_enc, E_out, E_diff, N, L, M):
+    """(executed, reference-formulation) flops of one forward per checkpoint set (SURVEY.md 8a FLOP model, H = 256).
+    Executed: per-edge MLPs once per undirected pair (E/2), the out graph's embedding only for the edges that differ."""
+    F = ((E_enc // 2) * (131584 + 393216 + L * 262144) + E_enc * L * 512 + E_diff * (131584 + 393216)
+         + (E_out // 2) * (327936 + 256) + N * (L * 393216 + 13000)) * M
+    F_ref = (E_enc * (131584 + 393216 + L * 262144 + L * 512) + E_out * (131584 + 393216 + 327936 + 256)
+             + N * (L * 393216 + 13000)) * M
+    return F, F_ref
 
-    def timed(n_steps):
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+
+def sync_all(dist):
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+class SamplingRun:
+    """LD sampling of one resident batch through the product's default path (device Philox draws, no trajectory)."""
+
+    def __init__(self, sampler, g, graphs, pos_init, use_graph, seed):
+        self.s, self.g, self.G, self.pos_init, self.use_graph, self.seed = sampler, g, graphs, pos_init, use_graph, seed
+
+    def run(self, n_steps):
+        g = self.g
+        return self.s.dynamic_sampling(
+            g["atom_type"], g["r_feat"], g["p_feat"], self.pos_init, g["bond_index"], g["bond_type"], g["batch"],
+            self.G, extend_order=True, n_steps=n_steps, step_lr=1e-7, clip=1000, sampling_type="ld",
+            denoise_from_time_t=n_steps, return_traj=False, use_graph=self.use_graph, seed=self.seed)
+
+    def timed(self, n_steps, dist=None):
+        sync_all(dist)
         t0 = time.perf_counter()
-        p, _ = run(n_steps, pos_init)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        p, _ = self.run(n_steps)
+        sync_all(dist)
         return time.perf_counter() - t0, p
 
-    # warm-up: builds topology, packs weights, captures the step graph (kept by the batch), W untimed steps
-    if args.warmup > 0:
-        run(args.warmup, pos_init)
-    dt, pos = timed(args.steps)  # the timed region: EXACTLY K steps
-    assert torch.isfinite(pos).all()
-    # fixed cost of a call (host set-up, state upload, first-step counts, final status read, position copy):
-    # a 1-step call costs fixed + one step; the K-step call gives the per-step time of the same schedule tail
-    t1 = min(timed(1)[0] for _ in range(3))
-    steady_ms = (dt - t1) / max(args.steps - 1, 1) * 1e3
-    fixed_ms = t1 * 1e3 - steady_ms
+    def db(self):
+        g = self.g
+        return self.s._bound_batch(g["atom_type"], g["r_feat"], g["p_feat"], g["bond_index"], g["bond_type"], g["batch"])
 
-    tot_atoms = torch.tensor([float(N)], device=dev)
-    tmax = torch.tensor([dt], device=dev)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot_atoms, op=dist.ReduceOp.SUM)
-    dt = float(tmax.item())
-    atoms = float(tot_atoms.item())
 
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
-
-    db = sampler._bound_batch(g["atom_type"], g["r_feat"], g["p_feat"], g["bond_index"], g["bond_type"], g["batch"])
-    E_enc, E_out = db.enc.num_edges(), db.out.num_edges()
+def combo_roofline(lib, db, cfg, dev, reps=20):
+    """the dominant kernel: one interaction block per launch (layer_combo_kernel: node chain of block l || CFConv
+    filters of block l+1), its L+1 launches of a forward timed live with events on the launch stream"""
+    from tsdiff_amd import _lib
     H, L = cfg["hidden_dim"], cfg["encoder"]["num_convs"]
-
-    # ---- roofline of the dominant kernel: one interaction block per launch (layer_combo_kernel):
-    # node chain of block l (aggregation + 3 dense layers) || CFConv filters of block l+1
-    PU = db.P // 2
-    Eu = db.enc_u.num_edges()
+    N, PU = db.N, db.P // 2
+    E_enc, Eu = db.enc.num_edges(), db.enc_u.num_edges()
     ea = torch.randn(max(PU, 1), H, device=dev)
     wf = torch.randn(2, max(PU, 1), H, device=dev)
     xa, xb = torch.randn(N, H, device=dev), torch.empty(N, H, device=dev)
     hbuf = torch.randn(N, H, device=dev)
-    reps = 20
 
     def launch_blocks():
-        """the L+1 block launches of one forward: [filters 0], [node 0 || filters 1], ..., [node L-1]"""
-        blk = lambda layer, fl, xi, xo: _lib.check(lib.tsd_interaction_block(  # noqa: E731
-            C.byref(db.cfg), _lib.ptr(db.weights[0]), layer, N, db.enc.struct(), _lib.ptr(wf[0]), _lib.ptr(xi),
-            _lib.ptr(hbuf), _lib.ptr(xo), fl, PU, db.enc_u.struct(), _lib.ptr(ea), _lib.ptr(wf[1]),
-            _lib.stream_ptr()))
+        """[filters 0], [node 0 || filters 1], ..., [node L-1]; block l's filters live in ring slot l % 2"""
+        def blk(layer, fl, xi, xo):
+            _lib.check(lib.tsd_interaction_block(
+                C.byref(db.cfg), _lib.ptr(db.weights[0]), layer, N, db.enc.struct(),
+                _lib.ptr(wf[layer % 2]) if layer >= 0 else None, _lib.ptr(xi), _lib.ptr(hbuf), _lib.ptr(xo), fl, PU,
+                db.enc_u.struct(), _lib.ptr(ea), _lib.ptr(wf[fl % 2]) if fl >= 0 else None, _lib.stream_ptr()))
         blk(-2, 0, xa, xb)
         for l in range(L):
             blk(l, l + 1 if l + 1 < L else -1, xa if l % 2 == 0 else xb, xb if l % 2 == 0 else xa)
@@ -254,91 +167,270 @@ def main():
     # the same work in SURVEY.md 8(d)'s units (filters counted once per DIRECTED edge, as the reference runs them)
     flops_survey = (L * (E_enc * (4.0 * H * H + 2.0 * H) + N * 6.0 * H * H)) / (L + 1)
     ach = flops / (k_ms * 1e-3) / 1e12
-    traffic = None
-    if args.workload == "c2":
-        try:  # HBM-side bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_summary.py)
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
-                kern = json.load(fh)["kernels"]
-                key = [k for k in kern if k.startswith("layer_combo_kernel<256")][0]  # template tail varies
-                traffic = round(kern[key]["hbm_bytes_per_launch"])
-        except Exception:
-            traffic = None
-    roofline = {"kernel": "layer_combo_kernel<256>", "bound": "mfma", "achieved": round(ach, 2),
-                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes)",
-                "avg_launch_us": round(k_ms * 1e3, 2), "undirected_edges": Eu, "directed_edges": E_enc, "nodes": N,
-                "flop_per_launch": flops, "launches_per_forward": L + 1,
-                "achieved_in_survey_units": round(flops_survey / (k_ms * 1e-3) / 1e12, 2),
-                "note": "every per-edge MLP runs once per undirected pair: `achieved` counts the flops executed; in "
-                        "SURVEY.md 8(d)'s per-directed-edge units the same launch is `achieved_in_survey_units`",
-                "algorithmic_bytes_per_launch": Eu * 4.0 * H * 2 + Eu * 4.0 * H + 4.0 * N * H * 4 + 2e6}
-    # the HBM-bound form of the message pass: segmented aggregation with a materialised
-    # directed filter W [E,H]: bytes = 1028 E + 2048 N + 4
-    del ea, wf
-    Wd = torch.randn(max(E_enc, 1), H, device=dev)
+    del ea, wf, xa, xb, hbuf
+    return {"kernel": "layer_combo_kernel<256>", "bound": "mfma", "achieved": round(ach, 2),
+            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            "traffic": None, "avg_launch_us": round(k_ms * 1e3, 2), "undirected_edges": Eu, "directed_edges": E_enc,
+            "nodes": N, "flop_per_launch": flops, "launches_per_forward": L + 1,
+            "achieved_in_survey_units": round(flops_survey / (k_ms * 1e-3) / 1e12, 2),
+            "note": "every per-edge MLP runs once per undirected pair: `achieved` counts the flops executed; in "
+                    "SURVEY.md 8(d)'s per-directed-edge units the same launch is `achieved_in_survey_units`",
+            # average launch: L/(L+1) x [edge_attr read + filter write + filter read (rows of 4H bytes) + node rows
+            # (h in, x1 in, x1 out, h out) + the block's 5 H x H weight matrices]
+            "algorithmic_bytes_per_launch": (Eu * 4.0 * H * 3 + 4.0 * N * H * 4 + 5 * 4.0 * H * H) * L / (L + 1)}
+
+
+def aggregate_roofline(lib, db, H, dev, reps=20):
+    """the HBM-bound form of the message pass: segmented aggregation with a materialised
+    directed filter W [E,H]: bytes = 1028 E + 2048 N + 4 (at H = 256)"""
+    from tsdiff_amd import _lib
+    N, E = db.N, db.enc.num_edges()
+    Wd = torch.randn(max(E, 1), H, device=dev)
+    x1 = torch.randn(N, H, device=dev)
     agg = torch.empty(N, H, device=dev)
 
-    def launch_agg():
+    def launch():
         _lib.check(lib.tsd_cfconv_aggregate(H, N, _lib.ptr(db.enc.row_ptr), _lib.ptr(db.enc.dst), None, _lib.ptr(Wd),
-                                            _lib.ptr(xa), _lib.ptr(agg), _lib.stream_ptr()))
+                                            _lib.ptr(x1), _lib.ptr(agg), _lib.stream_ptr()))
     for _ in range(3):
-        launch_agg()
+        launch()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
-    for _ in range(20):
-        launch_agg()
+    for _ in range(reps):
+        launch()
     ev1.record()
     torch.cuda.synchronize()
-    a_ms = ev0.elapsed_time(ev1) / 20
-    a_bytes = 1028.0 * E_enc + 2048.0 * N + 4
-    roofline["aggregate"] = {"kernel": "cfconv_aggregate_kernel<256>", "bound": "hbm",
-                             "achieved": round(a_bytes / (a_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": round(a_bytes / (a_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                             "avg_launch_us": round(a_ms * 1e3, 2), "bytes_per_launch": a_bytes}
-    del Wd
+    a_ms = ev0.elapsed_time(ev1) / reps
+    a_bytes = (4.0 * H + 4) * E + 8.0 * H * N + 4
+    gbs = a_bytes / (a_ms * 1e-3) / 1e9
+    del Wd, x1, agg
+    return {"kernel": "cfconv_aggregate_kernel<256>", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
+            "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_us": round(a_ms * 1e3, 2),
+            "bytes_per_launch": a_bytes, "directed_edges": E, "nodes": N,
+            "workload": "configs[4] size: W [E,256] fp32 streamed once, x1 gathered, one row-sum per node"}
 
-    # whole-forward arithmetic rate (SURVEY.md 8a FLOP model), for orientation
-    # flops the implemented algorithm executes: per-edge MLPs once per undirected pair (E/2), the out
-    # graph's embedding only for the edges that differ; the reference's formulation is 2x that
-    E_diff = db.diff_u.num_edges()
-    F = ((E_enc // 2) * (131584 + 393216 + L * 262144) + E_enc * L * 512 + E_diff * (131584 + 393216)
-         + (E_out // 2) * (327936 + 256) + N * (L * 393216 + 13000)) * args.models
-    F_ref = (E_enc * (131584 + 393216 + L * 262144 + L * 512) + E_out * (131584 + 393216 + 327936 + 256)
-             + N * (L * 393216 + 13000)) * args.models
+
+def pmc_traffic(name_prefix, fname):
+    """HBM-side bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_summary.py)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", fname)) as fh:
+            kern = json.load(fh)["kernels"]
+        key = [k for k in kern if k.startswith(name_prefix)][0]  # template tail varies
+        return round(kern[key]["hbm_bytes_per_launch"]), "profiles/" + fname
+    except Exception:
+        return None, None
+
+
+# ---------------------------------------------------------------------------------------------------
+# training step (BASELINE configs[3])
+# ---------------------------------------------------------------------------------------------------
+def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist):
+    """one training step of configs/train_config.yml per iteration: loss (get_loss), backward, RCCL gradient
+    all-reduce, clip_grad_norm_, Adam.  Returns (seconds, last mean loss, atoms per batch, executed flops per step)."""
+    from tsdiff_amd import synth
+    from tsdiff_amd.distributed import dp_backward
+    # a new batch every step, as a data loader delivers them: 8 distinct synthetic batches rotate and the model's
+    # batch cache is dropped before each step, so topology construction (k-hop pair codes, buffers) is inside
+    # the timed region like everything else
+    batches = []
+    for k in range(1 if reuse_batch else 8):
+        g = to_dev(synth.wb97xd3_like_batch(graphs, seed=2000 + 16 * rank + k), dev)
+        g["pos"] = (g["pos"] * 1.5).contiguous()
+        batches.append(g)
+    N = int(sum(g["pos"].shape[0] for g in batches) / len(batches))
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.95, 0.999))
+    counter = [0]
+
+    def step():
+        g = batches[counter[0] % len(batches)]
+        counter[0] += 1
+        if not reuse_batch:
+            model._batches.clear()
+        opt.zero_grad()
+        loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
+                              g["batch"], g["num_nodes_per_graph"], graphs)
+        mean = dp_backward(model, loss)
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 3000.0)
+        opt.step()
+        return mean
+    for _ in range(warmup):
+        step()
+    sync_all(dist)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    sync_all(dist)
+    dt = time.perf_counter() - t0
+    # executed arithmetic of a step ~ 3 x the forward's dense layers (forward, dgrad, wgrad) on the undirected lists
+    db = model._batches[0][2]
+    L = model._cfg.num_convs
+    F, _ = forward_flops(db.enc.num_edges(), db.out.num_edges(), db.diff_u.num_edges(), db.N, L, 1)
+    model.eval()
+    return dt, float(last), N, 3.0 * F
+
+
+def bench_train_main(args, model, dev, rank, world, dist):
+    dt, last, N, flops = run_train(model, args.graphs, args.steps, args.warmup, args.reuse_batch, dev, rank, dist)
+    tmax = torch.tensor([dt], device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        tf = flops / (dt / args.steps) / 1e12
+        print(json.dumps({
+            "metric": "training steps/s (configs[3]: get_loss + backward + grad all-reduce + clip + Adam)",
+            "value": round(world * args.graphs * args.steps / dt, 1), "unit": "graphs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[3] training step", "graphs_per_gpu": args.graphs, "atoms_per_gpu": N,
+                       "parallelism": f"graph-batch data parallel over {world} GPU(s), one RCCL all-reduce of "
+                                      "the flat fp32 gradient per step"},
+            "roofline": {"kernel": "whole training step (forward + dgrad + wgrad tile GEMMs, optimizer, host)",
+                         "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "flop_per_step": flops, "note": "executed flops = 3 x the forward's (undirected formulation)"},
+            "final_loss": last}))
+
+
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle on the host cores, bounded samples
+# ---------------------------------------------------------------------------------------------------
+def cpu_ld_rate(O, cfg, b, pos0, M, threads, max_steps, budget_s):
+    """atoms*steps/s and fwd/s of the torch-CPU oracle's LD loop on batch `b` with `threads` intra-op threads"""
+    from tsdiff_amd import synth
+    torch.set_num_threads(threads)
+    t = {k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}
+    sds = [O.to_torch_state(synth.synth_state_dict(cfg, seed=m)) for m in range(M)]
+    N = t["pos"].shape[0]
+    nz = torch.randn(max_steps + 1, N, 3)
+
+    def run(S):
+        c0 = time.perf_counter()
+        O.sample(sds, cfg, t["atom_type"], t["r_feat"], t["p_feat"], pos0, t["bond_index"], t["bond_type"], t["batch"],
+                 b["num_nodes_per_graph"], nz, S)
+        return time.perf_counter() - c0
+    t1 = run(1)  # warm-up + cost estimate
+    S = int(max(1, min(max_steps, budget_s / max(t1, 1e-3))))
+    cdt = run(S) if S > 1 else t1
+    return N * S / cdt, S * M / cdt, S, N
+
+
+def cpu_baseline(args, cfg, b, pos_init):
+    from oracle import tsdiff_oracle as O  # checker / baseline only
+    from tsdiff_amd import synth
+    ncpu = os.cpu_count() or 1
+    # torch-CPU scales poorly past a few dozen threads on these op sizes: the record carries the rate at
+    # --cpu-threads (32) AND at every host core, on the same bounded sample
+    nthreads = max(1, min(ncpu, args.cpu_threads))
+    pos0 = pos_init.cpu() / 12.1685  # O.sample multiplies by sigma_T
+    v, f, S, N = cpu_ld_rate(O, cfg, b, pos0, args.models, nthreads, args.cpu_steps, 15.0)
+    out = {"value": round(v, 1), "unit": "atoms*steps/s", "cores": nthreads, "kind": "port", "fwd_per_s": round(f, 3),
+           "sample": f"{S} LD steps of the same {args.graphs}-graph batch (N={N}), torch-CPU oracle, "
+                     f"{nthreads} of {ncpu} host cores"}
+    if ncpu != nthreads:
+        va, fa, Sa, _ = cpu_ld_rate(O, cfg, b, pos0, args.models, ncpu, 3, 10.0)
+        out["all_cores"] = {"value": round(va, 1), "cores": ncpu, "fwd_per_s": round(fa, 3),
+                            "sample": f"{Sa} LD step(s) of the same batch with torch.set_num_threads({ncpu})"}
+    # configs[4] by the protocol of BASELINE.md 5.3: a 16-graph chunk (N = 1024) of the 1024 x 64-atom batch; the
+    # whole batch is 64 such chunks, i.e. 64 x the time at the same atoms*steps/s
+    bc = synth.dense_stress_batch(16, n=64, seed=1000)
+    pc = torch.from_numpy(bc["pos"]) / 12.1685
+    vc, fc, Sc, Nc = cpu_ld_rate(O, cfg, bc, pc, 1, nthreads, 3, 10.0)
+    out["c5"] = {"value": round(vc, 1), "unit": "atoms*steps/s", "cores": nthreads, "kind": "port",
+                 "fwd_per_s_full_batch": round(fc / 64.0, 4),
+                 "sample": f"{Sc} LD step(s) of a 16-graph chunk (N={Nc}) of configs[4]; the full 1024-graph batch is "
+                           "64 chunks (x64 time, same atoms*steps/s)"}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:  # one rank per GPU, launched by torch.distributed.run for N > 1: never report ranks that do not exist
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)  # before any other GPU call of this process
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL; used for the barrier / max (and the gradient all-reduce)
+
+    from tsdiff_amd import _lib, synth
+    from tsdiff_amd.sampler import EnsembleSampler
+
+    lib = _lib.load()  # raises if the HIP extension is missing: no fallback
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    H, L = cfg["hidden_dim"], cfg["encoder"]["num_convs"]
+    models = make_models(cfg, range(args.models), dev)
+    if args.workload == "train":
+        bench_train_main(args, models[0], dev, rank, world, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    sampler = EnsembleSampler(models)
+
+    if args.workload == "c5":
+        b = synth.dense_stress_batch(args.graphs, n=64, seed=1000 + rank)
+    else:
+        b = synth.wb97xd3_like_batch(args.graphs, seed=1000 + rank)
+    g = to_dev(b, dev)
+    N = int(g["pos"].shape[0])
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    # compact start geometry (every intra-molecular pair within the 10 A cutoff -- the regime the last
+    # ~4000 of the 5000 steps of a real run are in); the timed steps are the LAST K of the schedule
+    pos_init = torch.randn(N, 3, device=dev, generator=gen) * 1.5
+    if args.workload == "c5":  # positions inside the 5.5 A cube: every pair within the cutoff
+        pos_init = g["pos"].clone()
+    run = SamplingRun(sampler, g, args.graphs, pos_init, not args.no_graph, 1234 + rank)
+
+    # warm-up: builds topology, packs weights, captures the step graph (kept by the batch), W untimed steps
+    if args.warmup > 0:
+        run.run(args.warmup)
+    dt, pos = run.timed(args.steps, dist)  # the timed region: EXACTLY K steps
+    assert torch.isfinite(pos).all()
+    # fixed cost of a call (host set-up, state upload, first-step counts, final status read, position copy):
+    # a 1-step call costs fixed + one step; the K-step call gives the per-step time of the same schedule tail
+    t1 = min(run.timed(1, dist)[0] for _ in range(3))
+    steady_ms = (dt - t1) / max(args.steps - 1, 1) * 1e3
+    fixed_ms = t1 * 1e3 - steady_ms
+
+    tot_atoms = torch.tensor([float(N)], device=dev)
+    tmax = torch.tensor([dt], device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot_atoms, op=dist.ReduceOp.SUM)
+    dt = float(tmax.item())
+    atoms = float(tot_atoms.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    db = run.db()
+    E_enc, E_out, E_diff = db.enc.num_edges(), db.out.num_edges(), db.diff_u.num_edges()
+    roofline = combo_roofline(lib, db, cfg, dev)
+    fname = "r02_pmc_traffic.json" if args.workload == "c2" else "r02_pmc_traffic_c5.json"
+    roofline["traffic"], roofline["traffic_source"] = pmc_traffic("layer_combo_kernel<256", fname)
+    F, F_ref = forward_flops(E_enc, E_out, E_diff, N, L, args.models)
     step_s = dt / args.steps
-    fwd_tflops = F / step_s / 1e12
-
-    # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload
-    cpu = None
-    if not args.no_cpu_baseline and args.workload == "c2" and args.gpus == 1:  # rank 0 at N=1 only
-        from oracle import tsdiff_oracle as O  # checker / baseline only
-        # torch-CPU scales poorly past a few dozen threads on these op sizes (256 threads measured 35 s
-        # per forward on the GPU box): use at most 32 and report the count actually used.
-        nthreads = max(1, min(os.cpu_count() or 1, args.cpu_threads))
-        torch.set_num_threads(nthreads)
-        t = {k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}
-        sds = [O.to_torch_state(synth.synth_state_dict(cfg, seed=m)) for m in range(args.models)]
-        pos_c = pos_init.cpu()
-        nz = torch.randn(args.cpu_steps + 1, N, 3)
-
-        def cpu_run(S):
-            c0 = time.perf_counter()
-            O.sample(sds, cfg, t["atom_type"], t["r_feat"], t["p_feat"], pos_c / 12.1685, t["bond_index"],
-                     t["bond_type"], t["batch"], b["num_nodes_per_graph"], nz, S)
-            return time.perf_counter() - c0
-        t1 = cpu_run(1)  # warm-up + cost estimate
-        S = int(max(2, min(args.cpu_steps, 20.0 / max(t1, 1e-3))))  # ~20 s of CPU work at most
-        cdt = cpu_run(S)
-        cpu = {"value": round(N * S / cdt, 1), "unit": "atoms*steps/s", "cores": nthreads,
-               "kind": "port", "fwd_per_s": round(S * args.models / cdt, 3),
-               "sample": f"{S} LD steps of the same {args.graphs}-graph batch (N={N}), torch-CPU oracle, "
-                         f"{nthreads} of {os.cpu_count()} host cores"}
 
     out = {
         "metric": "score-net fwd/sec & atoms·steps/sec, LD sampling on wb97xd3 batch=100",
         "value": round(atoms * args.steps / dt, 1),
         "unit": "atoms*steps/s",
-        "fwd_per_s": round(args.gpus * args.models * args.steps / dt, 2),
-        "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "fwd_per_s": round(world * args.models * args.steps / dt, 2),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
         "fixed_ms_per_call": round(fixed_ms, 3), "steady_ms_per_step": round(steady_ms, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -348,12 +440,73 @@ def main():
                                "configs[4]: synthetic 64-atom graphs, complete intra-graph pair set, LD sampling",
                    "graphs_per_gpu": args.graphs, "atoms_per_gpu": N, "edges_enc": E_enc, "edges_out": E_out,
                    "checkpoints": args.models, "hidden": H, "num_convs": L, "hipgraph": not args.no_graph,
-                   "parallelism": f"graphs sharded over {args.gpus} GPU(s), no collective"},
-        "forward_tflops": round(fwd_tflops, 2),
+                   "noise": "device Philox4x32-10", "parallelism": f"graphs sharded over {world} GPU(s), no collective"},
+        "forward_tflops": round(F / step_s / 1e12, 2),
         "forward_tflops_reference_formulation": round(F_ref / step_s / 1e12, 2),
         "roofline": roofline,
-        "cpu_baseline": cpu,
     }
+
+    extras = world == 1 and args.workload == "c2" and not args.no_extras
+    db5 = db if args.workload == "c5" else None
+    # ---- BASELINE configs[4]: 1024 x 64-atom graphs, complete pair sets (N = 65 536, E = 4 128 768)
+    if extras:
+        t0 = time.perf_counter()
+        g5 = to_dev(synth.dense_stress_batch(1024, n=64, seed=1000), dev)
+        s5 = EnsembleSampler(models[:1])
+        run5 = SamplingRun(s5, g5, 1024, g5["pos"].clone(), not args.no_graph, 77)
+        run5.run(2)
+        K5 = 4
+        dt5, p5 = run5.timed(K5)
+        assert torch.isfinite(p5).all()
+        db5 = run5.db()
+        rf5 = combo_roofline(lib, db5, cfg, dev, reps=3)
+        rf5["traffic"], rf5["traffic_source"] = pmc_traffic("layer_combo_kernel<256", "r02_pmc_traffic_c5.json")
+        N5 = 1024 * 64
+        F5, _ = forward_flops(db5.enc.num_edges(), db5.out.num_edges(), db5.diff_u.num_edges(), N5, L, 1)
+        out["c5"] = {"workload": "configs[4]: 1024 x 64-atom graphs, complete pair set, LD sampling, 1 checkpoint",
+                     "steps": K5, "ms_per_step": round(dt5 / K5 * 1e3, 3), "value": round(N5 * K5 / dt5, 1),
+                     "unit": "atoms*steps/s", "fwd_per_s": round(K5 / dt5, 3), "atoms": N5,
+                     "edges_enc": db5.enc.num_edges(), "forward_tflops": round(F5 / (dt5 / K5) / 1e12, 2),
+                     "roofline": rf5}
+    if db5 is not None:
+        agg = aggregate_roofline(lib, db5, H, dev)
+        agg["traffic"], agg["traffic_source"] = pmc_traffic("cfconv_aggregate_kernel<256", "r02_pmc_traffic_c5.json")
+        roofline["aggregate"] = agg
+    if extras:
+        out["c5"]["wall_s"] = round(time.perf_counter() - t0, 1)
+        del run5, s5, db5, g5
+        models[0]._batches.clear()
+        torch.cuda.empty_cache()
+        # ---- BASELINE configs[2]'s per-GPU unit: the same 100-graph batch with an ensemble of 8 checkpoints
+        m8 = (models + make_models(cfg, range(len(models), 8), dev))[:8]
+        s8 = EnsembleSampler(m8)
+        run8 = SamplingRun(s8, g, args.graphs, pos_init, not args.no_graph, 99)
+        run8.run(3)
+        K8 = 20
+        dt8, p8 = run8.timed(K8)
+        assert torch.isfinite(p8).all()
+        F8, _ = forward_flops(E_enc, E_out, E_diff, N, L, 8)
+        out["ensemble8"] = {"workload": "configs[2] per-GPU unit: the configs[1] batch with an 8-checkpoint ensemble "
+                                        "(all checkpoints in the same launches)", "steps": K8,
+                            "ms_per_step": round(dt8 / K8 * 1e3, 3), "value": round(N * K8 / dt8, 1),
+                            "unit": "atoms*steps/s", "fwd_per_s": round(8 * K8 / dt8, 1),
+                            "forward_tflops": round(F8 / (dt8 / K8) / 1e12, 2)}
+        del run8, s8, m8
+        models[0]._batches.clear()
+        # ---- BASELINE configs[3]: one training step at batch 200
+        Kt = 10
+        dtt, last, Nt, flt = run_train(models[0], 200, Kt, 3, False, dev, 0, None)
+        tf = flt / (dtt / Kt) / 1e12
+        out["train"] = {"workload": "configs[3]: training step at batch 200 (get_loss + backward + clip + Adam), a new "
+                                    "batch every step", "steps": Kt, "ms_per_step": round(dtt / Kt * 1e3, 3),
+                        "value": round(200 * Kt / dtt, 1), "unit": "graphs/s", "atoms": Nt,
+                        "executed_tflops": round(tf, 2), "frac_of_fp32_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "final_loss": last}
+
+    # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload (rank 0 at N=1 only)
+    out["cpu_baseline"] = None
+    if not args.no_cpu_baseline and args.workload == "c2" and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args, cfg, b, pos_init)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
