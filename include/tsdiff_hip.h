@@ -55,6 +55,7 @@ extern "C" {
 
 #define TSD_EDGE_TILE 32         /* edges per workgroup tile of every per-edge kernel */
 #define TSD_NODE_TILE 16         /* nodes per workgroup tile of the per-node kernels */
+#define TSD_EDGE_PAD 8           /* spare entries every tsd_edges array must carry past its capacity */
 #define TSD_MAX_GRAPH_NODES 255  /* two u8 hop matrices of n*n must fit in the 160 KiB LDS */
 #define TSD_NUM_BOND_TYPES 22    /* len(rdkit BondType.names), reference utils/chem.py:21 */
 
@@ -74,8 +75,9 @@ typedef struct tsd_model_cfg {
     int32_t smooth_conv;     /* config.encoder.smooth_conv: C = 0.5 (cos(pi d / cutoff) + 1) inside the cutoff (schnet.py:92-96) */
 } tsd_model_cfg;
 
-/* One extended-graph edge list in device memory (capacity = num_pairs entries).
- * Sorted row-major by (src, dst) exactly like the reference's edge_index. */
+/* One extended-graph edge list in device memory (capacity = num_pairs entries + TSD_EDGE_PAD spare ones: the
+ * node role of tsd_interaction_block reads dst / umap eight edges at a time and may touch, never use, up to
+ * seven entries past the last edge).  Sorted row-major by (src, dst) exactly like the reference's edge_index. */
 typedef struct tsd_edges {
     int32_t* count;    /* [1]   number of edges E */
     int32_t* row_ptr;  /* [N+1] CSR over src */

@@ -16,6 +16,7 @@ TSD_ERR_UNSUPPORTED = -3
 TSD_ERR_NAN = -4
 
 EDGE_TILE = 32
+EDGE_PAD = 8  # TSD_EDGE_PAD: spare entries every tsd_edges array carries past its capacity
 MAX_GRAPH_NODES = 255
 STEP_COEFS = 8
 STATUS_NAN = 1

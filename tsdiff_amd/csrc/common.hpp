@@ -223,113 +223,185 @@ __device__ __forceinline__ float cutoff_weight(float d, float cutoff, int smooth
 // block (global_load_dwordx4, a wave reads 1 KiB contiguous) per 4 MFMAs.
 //
 // RB = T/32 row blocks, CB = column blocks (32 wide) owned by this wave starting at col0.
+//
+// The B feed is a RING of R k-blocks in flight per wave, issued by inline asm with counted `s_waitcnt vmcnt`:
+// hipcc's scheduler collapses every source-level prefetch of this loop to two loads in flight, each re-issued
+// into the registers its MFMAs have just consumed, with 64-bit VALU address arithmetic between the dependent
+// MFMAs (r01: 62-67 % of the MFMA rate in the GEMM phases).  The asm loads are invisible to that scheduler:
+// wave-uniform base in SGPRs (advanced by SALU), one 32-bit lane offset in a VGPR, R loads deep.  Measured in
+// tools/mfma_probe3.hip in this kernel shape (8 waves x 32 columns, one accumulator per wave, 2 workgroups per
+// CU): compiler-scheduled loop 135 TFLOP/s, ring of 4 or 8: 152 (registers-only ceiling: 152).
+//
+// Contract of the asm loads (cdna_hip_programming.md 5.7): a destination counts as written at the asm statement,
+// so every consumer takes its operand from the `s_waitcnt` statement that names the registers "+v" (a true data
+// dependency: no MFMA can be scheduled above its wait); loads return in issue order, so compiler-issued loads
+// that are older or younger than the ring only make the counted waits conservative; the kernels issue no
+// global STORES while a ring is in flight.
 // ---------------------------------------------------------------------------------------------
-// B is double-buffered in registers in chunks of PF k-blocks: while chunk c is multiplied (PF*4*RB*CB
-// MFMAs = 2048 cycles at RB=1, CB=2), chunk c+1 is in flight from L2 -- one k-block of look-ahead
-// (the first version) exposed the L2 latency every iteration (tools/mfma_probe.hip: 84 -> 93 TFLOP/s).
-template <int RB, int CB, int K, int PF = 4, bool PIN = false>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// one B fragment (float4 per lane) for CB column blocks of k-block `kb`: CB loads, column block cb at +cb*cb_bytes
+template <int CB>
+__device__ __forceinline__ void ring_issue(f32x4 (&b)[CB], const char* __restrict__ sbase /* wave-uniform */,
+                                           unsigned voff /* lane byte offset */, int cb_bytes) {
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const char* sb = sbase + (size_t)cb * cb_bytes;
+#if defined(TSD_EXP) && TSD_EXP == 3  // timing experiment: no B loads at all (MFMAs on whatever the registers hold)
+        asm volatile("" : "=v"(b[cb]) : "v"(voff), "s"(sb));
+#else
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[cb]) : "v"(voff), "s"(sb) : "memory");
+#endif
+    }
+}
+// wait until at most N younger loads are outstanding and hand the fragment to its consumers
+template <int N, int CB>
+__device__ __forceinline__ void ring_wait(f32x4 (&b)[CB]) {
+    static_assert(CB >= 1 && CB <= 4, "");
+    if constexpr (CB == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(b[0]) : "n"(N) : "memory");
+    if constexpr (CB == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory");
+    if constexpr (CB == 3)
+        asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : "n"(N) : "memory");
+    if constexpr (CB == 4)
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+}
+
+template <int V>
+struct IntC { static constexpr int value = V; };
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(IntC<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// ring depth: as many k-blocks as fit 32 VGPRs of fragments
+template <int CB>
+constexpr int ring_depth() { return CB == 1 ? 8 : (CB == 2 ? 4 : 2); }
+
+// The ring split in two calls, so that a kernel can put the first R k-blocks in flight BEFORE a barrier /
+// epilogue and consume them after it (ring_start ... gemm_tile_ring); gemm_tile is start + consume.
+template <int CB, int R>
+struct BRing {
+    f32x4 b[R][CB];
+    const char* base;   // wave-uniform: packed matrix + this GEMM's first k-block
+    unsigned voff;      // lane byte offset inside a k-block row pair
+    int kb_bytes, cb_bytes;
+};
+
+template <int CB, int R, int KB>
+__device__ __forceinline__ void ring_start(BRing<CB, R>& r, const float* __restrict__ Bp, int nout, unsigned lane_f4,
+                                           int kb_rows /* k rows of float4 per k-block: 2 (32x32x2) or 4 (16x16x4) */,
+                                           int cb_f4 /* float4 per column block: 32 or 16 */) {
+    r.base = reinterpret_cast<const char*>(Bp);
+    r.voff = lane_f4 * 16u;
+    r.kb_bytes = kb_rows * nout * 16;
+    r.cb_bytes = cb_f4 * 16;
+    static_for<0, (R < KB ? R : KB)>([&](auto i) {
+        constexpr int I = decltype(i)::value;
+        ring_issue<CB>(r.b[I], r.base + (size_t)I * r.kb_bytes, r.voff, r.cb_bytes);
+    });
+}
+
+template <int RB, int CB, int K, int R>
+__device__ __forceinline__ void gemm_tile_ring(BRing<CB, R>& r, const float* __restrict__ ldsA, int lda,
+                                               f32x16 (&acc)[RB][CB]) {
+    const int lane = threadIdx.x & 63;
+    const float* aptr = ldsA + (lane & 31) * lda + (lane >> 5) * 4;
+    constexpr int KB = K / 8;
+    static_for<0, KB>([&](auto kbc) {
+        constexpr int kb = decltype(kbc)::value;
+        constexpr int slot = kb % R;
+        constexpr int younger = ((kb + R <= KB) ? R : KB - kb) - 1;  // k-blocks issued after this one, still wanted
+        f32x4 a[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) a[rb] = *reinterpret_cast<const f32x4*>(aptr + rb * 32 * lda + kb * 8);
+        ring_wait<younger * CB, CB>(r.b[slot]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+#if defined(TSD_EXP) && TSD_EXP == 2  // timing experiment: loads and waits only, no MFMA (wrong results)
+                    acc[rb][cb][s] += a[rb][s] * r.b[slot][cb][s];
+#elif defined(TSD_EXP) && TSD_EXP == 4  // loads at the MFMA pace, the pipe itself idle: sleep 64 cycles per MFMA
+                    acc[rb][cb][s] += a[rb][s] * r.b[slot][cb][s];
+                    __builtin_amdgcn_s_sleep(1);
+#else
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb][s], r.b[slot][cb][s], acc[rb][cb], 0, 0, 0);
+#endif
+                }
+        // refill the slot: its MFMAs have been issued (operands are read at issue), the data lands an L2 latency later
+        if constexpr (kb + R < KB) ring_issue<CB>(r.b[slot], r.base + (size_t)(kb + R) * r.kb_bytes, r.voff, r.cb_bytes);
+    });
+}
+
+template <int RB, int CB, int K>
 __device__ __forceinline__ void gemm_tile(const float* __restrict__ ldsA, int lda,
                                           const float* __restrict__ Bp, int nout, int col0,
                                           f32x16 (&acc)[RB][CB]) {
+    constexpr int R = ring_depth<CB>();
     const int lane = threadIdx.x & 63;
-    const int hi = lane >> 5;
-    const int l31 = lane & 31;
-    const float* aptr = ldsA + l31 * lda + hi * 4;
-    const f32x4* bptr = reinterpret_cast<const f32x4*>(Bp) + (size_t)hi * nout + col0 + l31;
-    constexpr int KB = K / 8;
-    constexpr int NC = KB / PF;
-    static_assert(KB % PF == 0, "K must be a multiple of 8 * PF");
-    f32x4 b0[PF][CB], b1[PF][CB];
-    auto loadB = [&](f32x4 (&b)[PF][CB], int chunk) {
-#pragma unroll
-        for (int p = 0; p < PF; ++p)
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) b[p][cb] = bptr[(size_t)(chunk * PF + p) * 2 * nout + cb * 32];
-    };
-    auto compute = [&](const f32x4 (&b)[PF][CB], int chunk) {
-        f32x4 a[PF][RB];
-#pragma unroll
-        for (int p = 0; p < PF; ++p)
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-                a[p][rb] = *reinterpret_cast<const f32x4*>(aptr + rb * 32 * lda + (chunk * PF + p) * 8);
-#pragma unroll
-        for (int p = 0; p < PF; ++p)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-                    for (int cb = 0; cb < CB; ++cb)
-                        acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[p][rb][s], b[p][cb][s], acc[rb][cb], 0, 0, 0);
-    };
-    // The machine scheduler sinks every load to just before its first use (one k-block of look-ahead).
-    // With >= 2 workgroups per CU the other waves cover that (measured: pinning the pipeline costs 10 % at
-    // configs[1] / configs[4] sizes); a launch with fewer workgroups than CUs is a pure latency chain and
-    // pins the chunked pipeline with scheduling barriers (PIN).
-    loadB(b0, 0);
-    for (int c = 0; c < NC; c += 2) {
-        if (c + 1 < NC) loadB(b1, c + 1);
-        if (PIN) __builtin_amdgcn_sched_barrier(0);
-        compute(b0, c);
-        if (PIN) __builtin_amdgcn_sched_barrier(0);
-        if (c + 2 < NC) loadB(b0, c + 2);
-        if (PIN) __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < NC) compute(b1, c + 1);
-        if (PIN) __builtin_amdgcn_sched_barrier(0);
-    }
+    BRing<CB, R> r;
+    ring_start<CB, R, K / 8>(r, Bp, nout, (unsigned)((lane >> 5) * nout + col0 + (lane & 31)), 2, 32);
+    gemm_tile_ring<RB, CB, K, R>(r, ldsA, lda, acc);
 }
+
+#ifdef TSD_EXP
+// timing experiment (variant builds): the same loop with every k-block reading k-block 0 (wrong results)
+template <int RB, int CB, int K>
+__device__ __forceinline__ void gemm_tile_exp(const float* __restrict__ ldsA, int lda, const float* __restrict__ Bp,
+                                              int nout, int col0, f32x16 (&acc)[RB][CB]) {
+    constexpr int R = ring_depth<CB>();
+    const int lane = threadIdx.x & 63;
+    BRing<CB, R> r;
+    ring_start<CB, R, K / 8>(r, Bp, nout, (unsigned)((lane >> 5) * nout + col0 + (lane & 31)), 2, 32);
+    r.kb_bytes = 0;
+    gemm_tile_ring<RB, CB, K, R>(r, ldsA, lda, acc);
+}
+#endif
 
 // 16-row variant on the 16x16x4 f32 MFMA (same rate, half the rows): A lane l holds A[i = l&15][k = l>>4],
 // B lane l holds B[k = l>>4][j = l&15], C/D: col = l&15, row = (l>>4)*4 + r, r in [0,4).
 // k is permuted in groups of 16: step s of k-block kb consumes k = kb*16 + q*4 + s on lane quarter q, so a
 // lane reads one float4 of A and one float4 of B per column block per 4 MFMAs, from the SAME packed
 // weight layout ([k/4][out][k%4]) as the 32-row variant.  CB = 16-wide column blocks of this wave.
-// PF / PIN as in gemm_tile: the node chain of the per-block launch is a latency chain that shares its CU with
-// filter workgroups streaming weights, so it prefetches deep (PF = K/32: the whole B slice of a GEMM in two
-// chunks, both in flight from the start) and pins that order.
-template <int CB, int K, int PF = 4, bool PIN = false>
+template <int CB, int K, int R>
+__device__ __forceinline__ void gemm_tile16_ring(BRing<CB, R>& r, const float* __restrict__ ldsA, int lda,
+                                                 f32x4 (&acc)[CB]) {
+    const int lane = threadIdx.x & 63;
+    const float* aptr = ldsA + (lane & 15) * lda + (lane >> 4) * 4;
+    constexpr int KB = K / 16;
+    static_for<0, KB>([&](auto kbc) {
+        constexpr int kb = decltype(kbc)::value;
+        constexpr int slot = kb % R;
+        constexpr int younger = ((kb + R <= KB) ? R : KB - kb) - 1;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(aptr + kb * 16);
+        ring_wait<younger * CB, CB>(r.b[slot]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+                acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], r.b[slot][cb][s], acc[cb], 0, 0, 0);
+        if constexpr (kb + R < KB) ring_issue<CB>(r.b[slot], r.base + (size_t)(kb + R) * r.kb_bytes, r.voff, r.cb_bytes);
+    });
+}
+
+template <int CB, int K>
 __device__ __forceinline__ void gemm_tile16(const float* __restrict__ ldsA, int lda,
                                             const float* __restrict__ Bp, int nout, int col0,
                                             f32x4 (&acc)[CB]) {
+    constexpr int R = ring_depth<CB>();
     const int lane = threadIdx.x & 63;
-    const int q = lane >> 4;
-    const int l15 = lane & 15;
-    const float* aptr = ldsA + l15 * lda + q * 4;
-    const f32x4* bptr = reinterpret_cast<const f32x4*>(Bp) + (size_t)q * nout + col0 + l15;
-    constexpr int KB = K / 16;
-    constexpr int NC = KB / PF;
-    static_assert(KB % PF == 0, "K must be a multiple of 16 * PF");
-    f32x4 b0[PF][CB], b1[PF][CB];
-    auto loadB = [&](f32x4 (&b)[PF][CB], int chunk) {
-#pragma unroll
-        for (int p = 0; p < PF; ++p)
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) b[p][cb] = bptr[(size_t)(chunk * PF + p) * 4 * nout + cb * 16];
-    };
-    auto compute = [&](const f32x4 (&b)[PF][CB], int chunk) {
-        f32x4 a[PF];
-#pragma unroll
-        for (int p = 0; p < PF; ++p) a[p] = *reinterpret_cast<const f32x4*>(aptr + (chunk * PF + p) * 16);
-#pragma unroll
-        for (int p = 0; p < PF; ++p)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb)
-                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[p][s], b[p][cb][s], acc[cb], 0, 0, 0);
-    };
-    loadB(b0, 0);
-    for (int c = 0; c < NC; c += 2) {
-        if (c + 1 < NC) loadB(b1, c + 1);
-        if (PIN) __builtin_amdgcn_sched_barrier(0);
-        compute(b0, c);
-        if (PIN) __builtin_amdgcn_sched_barrier(0);
-        if (c + 2 < NC) loadB(b0, c + 2);
-        if (PIN) __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < NC) compute(b1, c + 1);
-        if (PIN) __builtin_amdgcn_sched_barrier(0);
-    }
+    BRing<CB, R> r;
+    ring_start<CB, R, K / 16>(r, Bp, nout, (unsigned)((lane >> 4) * nout + col0 + (lane & 15)), 4, 16);
+    gemm_tile16_ring<CB, K, R>(r, ldsA, lda, acc);
 }
 
 template <int RB, int CB>

@@ -12,6 +12,49 @@
 // Both roles run with 2H threads = H/32 waves, 32 output columns per wave.
 #include "common.hpp"
 
+// Phase timeline of the per-block launch (variant builds only: tools/build_variant.sh trace "-DTSD_TRACE";
+// tools/trace_combo.py reads it).  32 u64 slots per workgroup: [0..7] s_memtime at phase boundaries (wave 0), [8..15] / [16..23] every wave's end of its
+// first / second GEMM, slot 31 = HW_ID | XCC_ID << 32 | role << 40.
+#ifdef TSD_TRACE
+static unsigned long long* g_tsd_trace_host = nullptr;  // variant builds only
+extern "C" int tsd_debug_trace(void* buf) {
+    g_tsd_trace_host = (unsigned long long*)buf;
+    return 0;
+}
+#define TSD_TRACE_AT(slot)                                                                                      \
+    do {                                                                                                        \
+        if (trace_buf && threadIdx.x == 0)                                                                      \
+            trace_buf[((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * 32 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define TSD_TRACE_WAVE(base)                                                                                    \
+    do {                                                                                                        \
+        if (trace_buf && (threadIdx.x & 63) == 0)                                                               \
+            trace_buf[((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * 32 + (base) + (threadIdx.x >> 6)] = \
+                __builtin_amdgcn_s_memtime();                                                                   \
+    } while (0)
+#define TSD_TRACE_ID(role)                                                                                      \
+    do {                                                                                                        \
+        if (trace_buf && threadIdx.x == 0)                                                                      \
+            trace_buf[((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * 32 + 31] =                        \
+                (unsigned long long)__builtin_amdgcn_s_getreg(63492) |                                          \
+                ((unsigned long long)(__builtin_amdgcn_s_getreg(63508) & 15) << 32) | ((unsigned long long)(role) << 40); \
+    } while (0)
+#define TSD_TRACE_REAL(slot)                                                                                    \
+    do {                                                                                                        \
+        if (trace_buf && threadIdx.x == 0)                                                                      \
+            trace_buf[((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y) * 32 + (slot)] = wall_clock64();    \
+    } while (0)
+#define TSD_TRACE_ARG , unsigned long long* trace_buf
+#define TSD_TRACE_PASS , trace_buf
+#else
+#define TSD_TRACE_AT(slot)
+#define TSD_TRACE_WAVE(base)
+#define TSD_TRACE_ID(role)
+#define TSD_TRACE_REAL(slot)
+#define TSD_TRACE_ARG
+#define TSD_TRACE_PASS
+#endif
+
 namespace tsd {
 
 constexpr int T = TSD_EDGE_TILE;   // 32 edges per filter tile
@@ -47,13 +90,24 @@ struct ComboFilter {
     int wf_slots;
 };
 
+template <int V>
+struct VRow {  // V consecutive channels of a row held by one lane (a register tuple the asm loads can name)
+    typedef float type __attribute__((ext_vector_type(V)));
+    static __device__ __forceinline__ float get(const type& x, int v) { return x[v]; }
+};
+template <>
+struct VRow<1> {
+    typedef float type;
+    static __device__ __forceinline__ float get(const type& x, int) { return x; }
+};
+
 // -------------------------------------------------------------------------------------------------
 // node role: agg[i] = sum_{e in row i} x1[dst e] * Wf[umap e]  (edge order, product rounded then added:
 // bit-identical to a sequential scatter_add), then the three dense layers of tsd_node_update.
 // reference schnet.py:101-107 (message/aggregate), :103 (lin2), :123-127, :223-224
 // -------------------------------------------------------------------------------------------------
 template <int H>
-__device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* smem) {
+__device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* smem TSD_TRACE_ARG) {
     constexpr int LDA = H + 4;
     constexpr int NT = 2 * H;
     constexpr int NW = NT / 64;
@@ -72,115 +126,135 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
     f32x4 acc[CB16];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+    TSD_TRACE_ID(1);
+    TSD_TRACE_AT(0);
+    // biases and the residual input of this lane's outputs: requested first, they arrive under the aggregation
+    float b_lin2[CB16], b_lin[CB16], h_res[CB16][4];
     if (a.mode == 0) {
-#pragma unroll 1
-        for (int rr = 0; rr < RPW; ++rr) {
-            const int r = __builtin_amdgcn_readfirstlane(wave * RPW + rr);
-            const int i = n0 + r;
-            float s[V];
 #pragma unroll
-            for (int v = 0; v < V; ++v) s[v] = 0.0f;
-            if (i < a.N) {
-                const int e0 = a.row_ptr[i], e1 = a.row_ptr[i + 1];
-                for (int eb = e0; eb < e1; eb += 64) {
-                    const int cnt = min(64, e1 - eb);
-                    int jv = 0, uv = 0;
-                    if (lane < cnt) {  // one coalesced index load per 64 edges, broadcast by readlane
-                        jv = a.dst[eb + lane];
-                        uv = a.umap[eb + lane];
-                    }
-                    int k = 0;
-                    constexpr int U = 8;  // edges in flight per wave (2 x 8 float4 loads), added in edge order
-                    for (; k + U <= cnt; k += U) {
-                        float wv[U][V], xv[U][V];
+        for (int cb = 0; cb < CB16; ++cb) {
+            const int col = col0 + cb * 16 + l15;
+            b_lin2[cb] = a.lin2_b[col];
+            b_lin[cb] = a.lin_b[col];
 #pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const int j = __builtin_amdgcn_readlane(jv, k + u);
-                            const int we = __builtin_amdgcn_readlane(uv, k + u);
-                            const float* wp = a.Wf + (size_t)we * H + lane * V;
-                            const float* xp = a.x1_in + (size_t)j * H + lane * V;
-                            if (V == 4) {
-                                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp);
-                                const f32x4 x4 = *reinterpret_cast<const f32x4*>(xp);
+            for (int r = 0; r < 4; ++r) {
+                const int row = q * 4 + r;
+                h_res[cb][r] = row < nrows ? a.h_in[(size_t)(n0 + row) * H + col] : 0.0f;
+            }
+        }
+    }
+    if (a.mode == 0) {
+        // The RPW rows of this wave are consecutive, so their edges are ONE contiguous CSR range
+        // [rp[first], rp[first + RPW]): one load of the RPW + 1 row offsets, one coalesced load of the indices per
+        // 64 edges, then batches of U edges in flight across the row boundaries -- 2 + ceil(edges / U) dependent
+        // memory round trips per wave (the per-row form with its 4 / 1-edge tail loops took ~14: the aggregation
+        // was 22 of the 36 us of a node tile at batch 100, and the node chain is the critical path of the launch).
+        // Sums stay per row, in edge order, product rounded then added: bit-identical to a sequential scatter_add.
+        const int first = n0 + wave * RPW;
+        const int rpv = a.row_ptr[min(first + min(lane, RPW), a.N)];  // lanes 0..RPW: offsets of this wave's rows
+        const int E0 = __builtin_amdgcn_readlane(rpv, 0), E1 = __builtin_amdgcn_readlane(rpv, RPW);
+        int rr = 0;                                        // current row (wave-uniform)
+        int row_end = __builtin_amdgcn_readlane(rpv, 1);   // end of the current row's edges
+        float s[V];
 #pragma unroll
-                                for (int v = 0; v < V; ++v) { wv[u][v] = w4[v]; xv[u][v] = x4[v]; }
-                            } else {
+        for (int v = 0; v < V; ++v) s[v] = 0.0f;
+        auto flush = [&]() {  // row rr is complete: its sums go to the LDS tile, the next row starts
 #pragma unroll
-                                for (int v = 0; v < V; ++v) { wv[u][v] = wp[v]; xv[u][v] = xp[v]; }
-                            }
-                        }
+            for (int v = 0; v < V; ++v) {
+                buf[(wave * RPW + rr) * LDA + lane * V + v] = s[v];
+                s[v] = 0.0f;
+            }
+            ++rr;
+            row_end = __builtin_amdgcn_readlane(rpv, min(rr + 1, RPW));
+        };
+        // The gather runs beside the MFMA streams of the filter tiles on the same SIMDs, and an fp32 MFMA holds the
+        // SIMD's vector issue port for its 64 cycles: every VALU instruction of this wave waits for an MFMA boundary
+        // (traced at batch 100: the aggregation takes 6 us alone on its CU, 21 us beside a filter tile -- the same
+        // with the filter's weight loads removed, 7 us with its MFMAs removed).  So the loop is written to need almost
+        // no VALU work: the edge indices come by SCALAR loads (8 consecutive edges per s_load_dwordx8), the row bases
+        // are SALU arithmetic, the row loads take an SGPR base + one lane-offset VGPR (inline asm: hipcc builds a
+        // 64-bit VGPR address per load), which leaves the products and sums.
+        constexpr int U = 8;  // edges in flight per wave (2 x 8 row loads of H floats)
+        typedef int i32x8 __attribute__((ext_vector_type(8)));
+        typedef typename VRow<V>::type vrow;
+        const unsigned lane_b = (unsigned)lane * (V * 4u);  // this lane's byte offset inside a row
+        for (int e = E0; e < E1; e += U) {
+            i32x8 jd, ud;  // dst / umap of edges e .. e+7 (the lists carry 8 spare entries: tsdiff_hip.h)
+            asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(jd) : "s"(a.dst + e) : "memory");
+            asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(ud) : "s"(a.umap + e) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(jd), "+s"(ud)::"memory");
+            vrow wv[U], xv[U];
 #pragma unroll
-                        for (int u = 0; u < U; ++u)
-#pragma unroll
-                            for (int v = 0; v < V; ++v) s[v] = __fadd_rn(s[v], __fmul_rn(xv[u][v], wv[u][v]));
-                    }
-                    for (; k + 4 <= cnt; k += 4) {
-                        float wv[4][V], xv[4][V];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int j = __builtin_amdgcn_readlane(jv, k + u);
-                            const int we = __builtin_amdgcn_readlane(uv, k + u);
-                            const float* wp = a.Wf + (size_t)we * H + lane * V;
-                            const float* xp = a.x1_in + (size_t)j * H + lane * V;
-                            if (V == 4) {
-                                const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp);
-                                const f32x4 x4 = *reinterpret_cast<const f32x4*>(xp);
-#pragma unroll
-                                for (int v = 0; v < V; ++v) { wv[u][v] = w4[v]; xv[u][v] = x4[v]; }
-                            } else {
-#pragma unroll
-                                for (int v = 0; v < V; ++v) { wv[u][v] = wp[v]; xv[u][v] = xp[v]; }
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-#pragma unroll
-                            for (int v = 0; v < V; ++v) s[v] = __fadd_rn(s[v], __fmul_rn(xv[u][v], wv[u][v]));
-                    }
-                    for (; k < cnt; ++k) {
-                        const int j = __builtin_amdgcn_readlane(jv, k);
-                        const int we = __builtin_amdgcn_readlane(uv, k);
-#pragma unroll
-                        for (int v = 0; v < V; ++v)
-                            s[v] = __fadd_rn(s[v], __fmul_rn(a.x1_in[(size_t)j * H + lane * V + v],
-                                                             a.Wf[(size_t)we * H + lane * V + v]));
-                    }
+            for (int u = 0; u < U; ++u) {
+                // slots past this wave's range hold other rows' (or no) edges: they re-read slot 0 and are not added
+                const bool live = e + u < E1;
+                const int we = live ? ud[u] : ud[0], j = live ? jd[u] : jd[0];
+                const float* wrow = a.Wf + (size_t)we * H;
+                const float* xrow = a.x1_in + (size_t)j * H;
+                if constexpr (V == 4) {
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wv[u]) : "v"(lane_b), "s"(wrow) : "memory");
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(xv[u]) : "v"(lane_b), "s"(xrow) : "memory");
+                } else if constexpr (V == 2) {
+                    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(wv[u]) : "v"(lane_b), "s"(wrow) : "memory");
+                    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(xv[u]) : "v"(lane_b), "s"(xrow) : "memory");
+                } else {
+                    asm volatile("global_load_dword %0, %1, %2" : "=v"(wv[u]) : "v"(lane_b), "s"(wrow) : "memory");
+                    asm volatile("global_load_dword %0, %1, %2" : "=v"(xv[u]) : "v"(lane_b), "s"(xrow) : "memory");
                 }
             }
+            // one wait for the batch, naming every destination (the consumers below depend on this statement)
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]), "+v"(wv[4]), "+v"(wv[5]), "+v"(wv[6]),
+                           "+v"(wv[7]), "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]),
+                           "+v"(xv[6]), "+v"(xv[7])::"memory");
+            static_assert(U == 8, "the wait statement names 8 + 8 registers");
 #pragma unroll
-            for (int v = 0; v < V; ++v) buf[r * LDA + lane * V + v] = s[v];
+            for (int u = 0; u < U; ++u) {
+                if (e + u < E1) {
+                    while (e + u >= row_end) flush();  // (also steps over rows without edges)
+#pragma unroll
+                    for (int v = 0; v < V; ++v)
+                        s[v] = __fadd_rn(s[v], __fmul_rn(VRow<V>::get(xv[u], v), VRow<V>::get(wv[u], v)));
+                }
+            }
         }
+        while (rr < RPW) flush();  // the last row, and rows past it without edges (or past the last node): zeros
+        TSD_TRACE_WAVE(16);
         __syncthreads();
+        TSD_TRACE_AT(1);
 
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) acc[cb] = zero4;
         gemm_tile16<CB16, H>(buf, LDA, a.lin2_w, H, col0, acc);
+        TSD_TRACE_WAVE(8);
+        TSD_TRACE_AT(2);
         __syncthreads();
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
             const int col = col0 + cb * 16 + l15;
-            const float b = a.lin2_b[col];
+            const float b = b_lin2[cb];
 #pragma unroll
             for (int r = 0; r < 4; ++r) buf[(q * 4 + r) * LDA + col] = sspf(acc[cb][r] + b);
         }
         __syncthreads();
+        TSD_TRACE_AT(3);
 
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) acc[cb] = zero4;
         gemm_tile16<CB16, H>(buf, LDA, a.lin_w, H, col0, acc);
+        TSD_TRACE_AT(4);
         __syncthreads();
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
             const int col = col0 + cb * 16 + l15;
-            const float b = a.lin_b[col];
+            const float b = b_lin[cb];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = q * 4 + r;
                 float hn = 0.0f;
                 if (row < nrows) {
-                    const size_t o = (size_t)(n0 + row) * H + col;
-                    hn = a.h_in[o] + (acc[cb][r] + b);
-                    a.h[o] = hn;
+                    hn = h_res[cb][r] + (acc[cb][r] + b);
+                    a.h[(size_t)(n0 + row) * H + col] = hn;
                 }
                 buf[row * LDA + col] = hn;
             }
@@ -197,9 +271,11 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
         __syncthreads();
     }
 
+    TSD_TRACE_AT(5);
 #pragma unroll
     for (int cb = 0; cb < CB16; ++cb) acc[cb] = zero4;
     gemm_tile16<CB16, H>(buf, LDA, a.lin1_next_w, H, col0, acc);
+    TSD_TRACE_AT(6);
 #pragma unroll
     for (int cb = 0; cb < CB16; ++cb) {
         const int col = col0 + cb * 16 + l15;
@@ -209,6 +285,7 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
             if (row < nrows) a.x1_out[(size_t)(n0 + row) * H + col] = acc[cb][r];
         }
     }
+    TSD_TRACE_AT(7);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -216,7 +293,7 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
 // H/32 waves x 32 columns (the 256-thread stand-alone form is filter_gen_kernel in kernels_mlp.hip)
 // -------------------------------------------------------------------------------------------------
 template <int H>
-__device__ __forceinline__ void filter_role(const ComboFilter& f, int item, float* smem) {
+__device__ __forceinline__ void filter_role(const ComboFilter& f, int item, float* smem TSD_TRACE_ARG) {
     const int g = f.g_begin + item;
     const int lrel = g / f.tiles_per_layer, tile = g - lrel * f.tiles_per_layer;
     const float* Wb = f.Wl0 + (size_t)(f.layer0 + lrel) * f.layer_stride;
@@ -235,6 +312,8 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
     const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int col0 = (tid >> 6) * 32;
     const int nrows = min(T, E - e0);
+    TSD_TRACE_ID(2);
+    TSD_TRACE_AT(0);
 
     if (tid < T) s_c[tid] = tid < nrows ? cutoff_weight(f.e.dist[e0 + tid], f.conv_cutoff, f.smooth) : 0.0f;
     {   // edge_attr tile -> LDS with every load of a thread in flight together (rows past the end clamped)
@@ -253,11 +332,23 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
             *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = r < nrows ? v[it] : z;
         }
     }
+#ifdef TSD_EXP_SLEEP  // experiment: the filter tiles that share a CU with a node tile (dispatch-order heuristic) start late
+    if ((int)blockIdx.x >= 256 && (int)blockIdx.x < 256 + TSD_EXP_NODE_TILES) {
+        for (int k = 0; k < TSD_EXP_SLEEP; ++k) __builtin_amdgcn_s_sleep(64);  // 64 * 64 cycles = 1.7 us
+    }
+#endif
     __syncthreads();
+    TSD_TRACE_AT(1);
 
     f32x16 acc[1][1];
     zero_acc(acc);
+#if defined(TSD_EXP) && TSD_EXP == 1  // experiment: every k-block reads the SAME 8 KiB of weights (L1 resident: no L2 traffic)
+    gemm_tile_exp<1, 1, H>(buf, LDA, nn0_w, H, col0, acc);
+#else
     gemm_tile<1, 1, H>(buf, LDA, nn0_w, H, col0, acc);
+#endif
+    TSD_TRACE_WAVE(8);
+    TSD_TRACE_AT(2);
     __syncthreads();
     {
         const int col = col0 + l31;
@@ -266,9 +357,16 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
         for (int r = 0; r < 16; ++r) buf[acc_row(r, hi) * LDA + col] = sspf(acc[0][0][r] + b);
     }
     __syncthreads();
+    TSD_TRACE_AT(3);
 
     zero_acc(acc);
+#if defined(TSD_EXP) && TSD_EXP == 1
+    gemm_tile_exp<1, 1, H>(buf, LDA, nn2_w, H, col0, acc);
+#else
     gemm_tile<1, 1, H>(buf, LDA, nn2_w, H, col0, acc);
+#endif
+    TSD_TRACE_WAVE(16);
+    TSD_TRACE_AT(4);
     __syncthreads();
     {
         const int col = col0 + l31;
@@ -280,11 +378,13 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
         }
     }
     __syncthreads();
+    TSD_TRACE_AT(5);
     for (int idx = tid; idx < nrows * C4; idx += NT) {
         const int r = idx / C4, c4 = idx % C4;
         *reinterpret_cast<f32x4*>(out + (size_t)(e0 + r) * H + c4 * 4) =
             *reinterpret_cast<const f32x4*>(buf + r * LDA + c4 * 4);
     }
+    TSD_TRACE_AT(6);
 }
 
 // "pre" role: the half of the pair MLP's first layer that does not depend on the node states,
@@ -325,13 +425,14 @@ __device__ __forceinline__ void pre_role(const ComboPre& q, int tile, float* sme
 
 struct ComboStride {  // per-checkpoint strides (blockIdx.y = checkpoint of the ensemble)
     size_t w, nh, ea, wf, pre;
+    int node_stride;  // 1: node tiles are the first workgroups; S > 1 (odd): node tile j is workgroup j * S
 };
 
 constexpr int NODE_RUN = 4;  // consecutive node tiles kept on one XCD (one 64-atom graph = 4 tiles)
 
 template <int H>
 __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int node_tiles, ComboFilter f,
-                                                            ComboStride sd, ComboPre q) {
+                                                            ComboStride sd, ComboPre q TSD_TRACE_ARG) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     {
         const size_t m = blockIdx.y;
@@ -345,12 +446,20 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
             q.edge_attr += m * sd.ea; q.w0b += wo; q.b0 += wo; q.out += m * sd.pre;
         }
     }
-    if ((int)blockIdx.x < node_tiles) {
+    // Workgroup -> role.  Small launches (every workgroup resident at once) put the node tiles first.  Large ones
+    // spread them through the grid with an odd stride: the node role of a big batch is HBM-bound (it streams the
+    // block's filters), the filter role MFMA-bound, and with the node tiles first the two ran one after the other
+    // (configs[4]: 0.80 + 4.19 ms per launch); interleaved they share the chip.
+    const int S = sd.node_stride;
+    const int b = blockIdx.x;
+    const bool is_node = S <= 1 ? b < node_tiles : (b % S == 0 && b / S < node_tiles);
+    if (is_node) {
         // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), and the node
         // tiles of one graph read the same x1 rows and -- from both endpoints -- the same filter rows.  Runs of
-        // NODE_RUN consecutive tiles therefore go to ONE XCD: the q-th workgroup of XCD x takes tile
-        // ((q / run) * 8 + x) * run + q % run.  The tail that does not fill 8 * run keeps the identity order.
-        int tile = blockIdx.x;
+        // NODE_RUN consecutive tiles therefore go to ONE XCD: node workgroup j runs on XCD (j * S) & 7, a bijection of
+        // j & 7 for odd S, so the q-th node workgroup of residue x = j & 7 takes tile ((q / run) * 8 + x) * run + q % run.
+        // The tail that does not fill 8 * run keeps the identity order.
+        int tile = S <= 1 ? b : b / S;
         const int full = node_tiles / (8 * NODE_RUN) * (8 * NODE_RUN);
         if (tile < full) {
             const int x = tile & 7, qq = tile >> 3;
@@ -359,14 +468,18 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
         // the node chain is the critical path of the launch: its waves get issue priority over the filter waves
         // they share a SIMD with
         __builtin_amdgcn_s_setprio(3);
-        node_role<H>(a, tile, smem);
+        TSD_TRACE_REAL(24);
+        node_role<H>(a, tile, smem TSD_TRACE_PASS);
+        TSD_TRACE_REAL(25);
     } else {
-        const int item = blockIdx.x - node_tiles;
+        const int item = b - (S <= 1 ? node_tiles : min(node_tiles, b / S + 1));
         if (item >= f.tiles) {
             pre_role<H>(q, item - f.tiles, smem);
             return;
         }
-        filter_role<H>(f, item, smem);
+        TSD_TRACE_REAL(24);
+        filter_role<H>(f, item, smem TSD_TRACE_PASS);
+        TSD_TRACE_REAL(25);
     }
 }
 
@@ -437,14 +550,25 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     const int grid = node_tiles + f.tiles + q.tiles;
     if (grid == 0) return TSD_OK;
     const size_t lds = lds_combo(c.hidden);
-    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, pre_stride};
+    // interleave only when the launch is many chip-fulls deep (the node tiles alone over-subscribe the chip)
+    int node_stride = 1;
+    if (node_tiles >= 1024 && grid >= 3 * node_tiles) {
+        node_stride = grid / node_tiles;
+        if (node_stride % 2 == 0) --node_stride;
+    }
+    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, pre_stride, node_stride};
+#ifdef TSD_TRACE
+#define TSD_TRACE_HOST , g_tsd_trace_host
+#else
+#define TSD_TRACE_HOST
+#endif
 #define TSD_COMBO(HH)                                                                                       \
     {                                                                                                       \
         static DeviceOnce once;                                                                             \
         int r = allow_lds(layer_combo_kernel<HH>, lds, once);                                               \
         if (r) return r;                                                                                    \
         hipLaunchKernelGGL((layer_combo_kernel<HH>), dim3(grid, M), dim3(2 * HH), lds, st, a, node_tiles, f, \
-                           sd, q);                                                                          \
+                           sd, q TSD_TRACE_HOST);                                                           \
     }
     switch (c.hidden) {
         case 64: TSD_COMBO(64) break;

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64 * NW) void linear_mfma_kernel(int rows, int nout
     __syncthreads();
     f32x16 acc[1][CB];
     zero_acc(acc);
-    gemm_tile<1, CB, K, PF, (PF > 4)>(smem, LDA, Bp, nout, col0, acc);
+    gemm_tile<1, CB, K>(smem, LDA, Bp, nout, col0, acc);
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
         const int col = col0 + cb * 32 + l31;

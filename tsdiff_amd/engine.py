@@ -97,15 +97,17 @@ class EdgeList:
         i32 = dict(dtype=torch.int32, device=device)
         self.count = torch.zeros(1, **i32)
         self.row_ptr = torch.zeros(N + 1, **i32)
-        # entries [0, count) of the per-edge arrays are rewritten by every geometry build and nothing reads
-        # past count: no fill launches for them (a fresh batch per training step builds 35 of these)
-        self.src = torch.empty(max(P, 1), **i32)
-        self.dst = torch.empty(max(P, 1), **i32)
-        self.dist = torch.empty(max(P, 1), dtype=torch.float32, device=device)
-        self.type_r = torch.empty(max(P, 1), dtype=torch.uint8, device=device)
-        self.type_p = torch.empty(max(P, 1), dtype=torch.uint8, device=device)
-        self.pair_id = torch.empty(max(P, 1), **i32)
-        self.umap = torch.empty(max(P, 1), **i32)
+        # entries [0, count) of the per-edge arrays are rewritten by every geometry build and nothing uses values
+        # past count: no fill launches for them (a fresh batch per training step builds 35 of these).  Every array
+        # carries TSD_EDGE_PAD spare entries: the node role fetches dst / umap 8 edges at a time by scalar loads.
+        cap = max(P, 1) + _lib.EDGE_PAD
+        self.src = torch.empty(cap, **i32)
+        self.dst = torch.empty(cap, **i32)
+        self.dist = torch.empty(cap, dtype=torch.float32, device=device)
+        self.type_r = torch.empty(cap, dtype=torch.uint8, device=device)
+        self.type_p = torch.empty(cap, dtype=torch.uint8, device=device)
+        self.pair_id = torch.empty(cap, **i32)
+        self.umap = torch.empty(cap, **i32)
 
     def struct(self):
         return Edges(*[C.c_void_p(t.data_ptr()) for t in (
