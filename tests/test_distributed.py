@@ -75,6 +75,7 @@ def _dp_worker(rank, world, port, ret):
     full.mean().backward()
     gref = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
     ok = torch.allclose(grads, gref, rtol=1e-5, atol=1e-7) and abs(mean - float(full.mean())) < 1e-6
+    ok = ok and model._last_reduce == "gather-scatter"
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()

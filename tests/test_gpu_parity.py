@@ -1164,3 +1164,41 @@ def test_fused_training_context_is_single_use_and_detects_overwrites(dev):
               torch.zeros(g["num_graphs"], dtype=torch.long, device=dev))
     with pytest.raises(RuntimeError, match="overwritten"):
         l3.mean().backward()
+
+
+def test_dp_backward_flat_gradient_path_on_the_real_model(dev):
+    """BASELINE configs[3] data parallelism without a second GPU: dp_backward on the REAL model with a reducer that
+    emulates a second rank holding the same shard (x2).  The fused step's gradients are views of one flat buffer,
+    which is reduced in place: every p.grad doubles, the loss normaliser counts both shards, clip_grad_norm_ sees
+    the reduced gradient -- i.e. exactly the single-process gradient of the doubled batch's mean"""
+    from tsdiff_amd.distributed import dp_backward
+    d, meta = load_golden("loss_synth_b4_small")
+    g = to_dev(batch_inputs(d), dev)
+    kw = dict(_time_step=torch.from_numpy(d["time_step"]).to(dev), _pos_noise=torch.from_numpy(d["pos_noise"]).to(dev))
+    args = (g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"],
+            g["num_nodes_per_graph"], g["num_graphs"])
+    ref = make_model(meta["cfg"], meta["seed"], dev)
+    ref.train()
+    ref.get_loss(*args, **kw).mean().backward()
+    ref_grads = {k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None}
+    ref_norm = float(torch.nn.utils.clip_grad_norm_(ref.parameters(), 1e9))
+
+    model = make_model(meta["cfg"], meta["seed"], dev)
+    model.train()
+    calls = []
+
+    def twice(t):  # what an all-reduce over two ranks with identical shards returns
+        calls.append(t.numel())
+        t.mul_(2.0)
+    loss = model.get_loss(*args, **kw)
+    mean = dp_backward(model, loss, reduce_fn=twice)
+    n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    assert model._last_reduce == "flat-in-place" and calls == [2, n_params]   # 2 scalars, then ONE flat buffer
+    assert abs(float(mean) - float(loss.mean())) < 1e-6 * abs(float(loss.mean()))
+    # sum over "two ranks" of d(sum loss_r / 2N)/dp = d(mean loss)/dp: identical to the single-process gradient
+    for k, p in model.named_parameters():
+        if k in ref_grads:
+            assert torch.allclose(p.grad, ref_grads[k], rtol=1e-6, atol=1e-12), k
+    norm = float(torch.nn.utils.clip_grad_norm_(model.parameters(), 1e9))
+    assert abs(norm - ref_norm) <= 1e-5 * ref_norm
+    torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.95, 0.999)).step()   # train.py:144-145 on the reduced gradient

@@ -9,12 +9,12 @@ GPUs of one node (one process per GPU, no data-path collective), the way `sampli
 Synthetic reactions and closed-form weights (the wb97xd3 pickles and trained checkpoints are LFS blobs absent
 from the reference tree); real use replaces `make_graphs` by the unpickled test set and `make_models` by
 `tsdiff_amd.io.load_checkpoint` + `get_model(ckpt["config"].model)` + `load_state_dict(ckpt["model"])`.
-Rank 0 prints one JSON line and (with --out) pickles the list of generated positions in the original order.
+Rank 0 prints one JSON line and (with --out DIR) writes DIR/samples_all.pkl in the reference's result format
+(`sampling.py:218-243`: a list of PyG `Data` records, one per reaction, with `pos_gen`; tsdiff_amd.io).
 """
 import argparse
 import json
 import os
-import pickle
 import sys
 import time
 
@@ -106,8 +106,13 @@ def main():
                           "checkpoint_forwards_per_s": round(
                               -(-args.graphs // (args.batch_size * world)) * world * args.models * args.steps / dt, 1)}))
         if args.out:
-            with open(args.out, "wb") as f:
-                pickle.dump([r.numpy() for r in res], f)
+            from tsdiff_amd import io as tio
+            w = tio.ResultWriter(args.out)
+            recs = [tio.SampleRecord(atom_type=g["atom_type"], r_feat=g["r_feat"], p_feat=g["p_feat"], pos=g["pos"],
+                                     edge_index=g["bond_index"], edge_type=g["bond_type"], smiles=f"synthetic_{k}",
+                                     pos_gen=r) for k, (g, r) in enumerate(zip(graphs, res))]
+            w.add_batch(recs)
+            print("wrote", w.finish())
     if "RANK" in os.environ:
         torch.distributed.destroy_process_group()
 

@@ -446,20 +446,24 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
             q.edge_attr += m * sd.ea; q.w0b += wo; q.b0 += wo; q.out += m * sd.pre;
         }
     }
-    // Workgroup -> role.  Small launches (every workgroup resident at once) put the node tiles first.  Large ones
-    // spread them through the grid with an odd stride: the node role of a big batch is HBM-bound (it streams the
-    // block's filters), the filter role MFMA-bound, and with the node tiles first the two ran one after the other
-    // (configs[4]: 0.80 + 4.19 ms per launch); interleaved they share the chip.
+    // Workgroup -> role.  Small launches (every workgroup resident at once, S = 1) put the node tiles first; large
+    // ones (S > 1, odd) spread them through the grid, so that the node role's HBM-bound gather of a big batch and the
+    // MFMA-bound filter tiles at least share the chip in time.  (Measured and dropped at batch 100: pairing the node
+    // tiles with each other on a CU -- workgroups b and b + 256 share one -- instead of with filter tiles: a node
+    // tile gathers 3x slower beside an fp32 MFMA stream, 6 -> 21 us, but the launch stays bound by the CUs that run
+    // two filter tiles, 40.4 vs 39.5 us.)
     const int S = sd.node_stride;
     const int b = blockIdx.x;
-    const bool is_node = S <= 1 ? b < node_tiles : (b % S == 0 && b / S < node_tiles);
+    const bool is_node = S > 1 ? (b % S == 0 && b / S < node_tiles) : b < node_tiles;
+    const int node_id = S > 1 ? b / S : b;
+    const int others_before = S > 1 ? b - min(node_tiles, b / S + 1) : b - node_tiles;
     if (is_node) {
         // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), and the node
         // tiles of one graph read the same x1 rows and -- from both endpoints -- the same filter rows.  Runs of
         // NODE_RUN consecutive tiles therefore go to ONE XCD: node workgroup j runs on XCD (j * S) & 7, a bijection of
         // j & 7 for odd S, so the q-th node workgroup of residue x = j & 7 takes tile ((q / run) * 8 + x) * run + q % run.
         // The tail that does not fill 8 * run keeps the identity order.
-        int tile = S <= 1 ? b : b / S;
+        int tile = node_id;
         const int full = node_tiles / (8 * NODE_RUN) * (8 * NODE_RUN);
         if (tile < full) {
             const int x = tile & 7, qq = tile >> 3;
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
         node_role<H>(a, tile, smem TSD_TRACE_PASS);
         TSD_TRACE_REAL(25);
     } else {
-        const int item = b - (S <= 1 ? node_tiles : min(node_tiles, b / S + 1));
+        const int item = others_before;
         if (item >= f.tiles) {
             pre_role<H>(q, item - f.tiles, smem);
             return;

@@ -57,7 +57,11 @@ def sample_sharded(graphs, sample_fn, group=None):
 # -------------------------------------------------------------------------------------------------
 # data-parallel training step (BASELINE config 4): graphs shard across ranks, ONE collective
 # -------------------------------------------------------------------------------------------------
-def dp_backward(model, loss_nodes, group=None):
+def _all_reduce_sum(t, group=None):
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def dp_backward(model, loss_nodes, group=None, reduce_fn=None):
     """Backward of the reference's `loss.mean()` (train.py:140-143) over the GLOBAL batch.
 
     `loss_nodes` is this rank's (N_r, 1) per-node loss.  The reference averages over all nodes of the
@@ -66,13 +70,18 @@ def dp_backward(model, loss_nodes, group=None):
     xGMI on the GPUs, gloo in the CPU tests).  Afterwards `clip_grad_norm_` and the optimizer step see
     exactly the single-process gradients on every rank.  Returns the global mean loss as a 0-dim device
     tensor (no host sync anywhere in here: the host keeps enqueueing the optimizer step and the next batch
-    while the GPU is still in the backward pass; call `.item()` when a number is needed)."""
-    distributed = dist.is_initialized() and dist.get_world_size(group) > 1
+    while the GPU is still in the backward pass; call `.item()` when a number is needed).
+
+    `reduce_fn(tensor)` replaces the in-place sum all-reduce (tests: a reducer that emulates a second rank
+    exercises the flat-gradient path of the real model on one GPU); with it the reduction runs whether or not
+    a process group exists."""
+    distributed = reduce_fn is not None or (dist.is_initialized() and dist.get_world_size(group) > 1)
+    reduce = reduce_fn if reduce_fn is not None else (lambda t: _all_reduce_sum(t, group))
     # (new_full is a fill kernel: torch.tensor(x, device=cuda) would be a synchronous host-to-device copy, i.e.
     # a hidden stream sync between the forward and the backward pass)
     stats = torch.stack([loss_nodes.detach().sum(), loss_nodes.new_full((), float(loss_nodes.shape[0]))])
     if distributed:
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+        reduce(stats)
     (loss_nodes.sum() / stats[1]).backward()
     if distributed:
         params = [p for p in model.parameters() if p.requires_grad]
@@ -81,16 +90,18 @@ def dp_backward(model, loss_nodes, group=None):
                                     flat.untyped_storage().data_ptr() for p in params) and \
                 sum(p.numel() for p in params) == flat.numel():
             # the fused training step hands out views of ONE flat gradient buffer: reduce it in place
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            reduce(flat)
+            model._last_reduce = "flat-in-place"
         else:
             for p in params:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
             flat = torch.cat([p.grad.reshape(-1) for p in params])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            reduce(flat)
             off = 0
             for p in params:
                 n = p.numel()
                 p.grad.copy_(flat[off:off + n].view_as(p))
                 off += n
+            model._last_reduce = "gather-scatter"
     return stats[0] / stats[1]
