@@ -1,7 +1,7 @@
 #!/bin/bash
 # All profile artefacts of a round in one gpurun call:   gpurun -- 'bash tools/profile_round.sh r02'
 # Writes gpurun_out/<tag>_*: kernel-trace stats (c2, c5, train), HBM traffic PMC passes (c2, c5: FETCH_SIZE and
-# WRITE_SIZE in separate passes), SQ issue/stall/MFMA-busy counters (c2, c5).  Copy what is to be judged to profiles/.
+# WRITE_SIZE in separate passes), SQ issue/stall/MFMA-busy counters (c2, c5; MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch time x clock)).  Copy what is to be judged to profiles/.
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 db() { ls $1/*/*results.db $1/*results.db 2>/dev/null | head -1; }
@@ -24,14 +24,12 @@ python3 tools/pmc_summary.py $(db /tmp/p_f5) $(db /tmp/p_w5) gpurun_out/${TAG}_p
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAVES"
 rocprofv3 --kernel-trace --pmc $SQ -d /tmp/p_sq -o sq -- python3 bench.py --steps 30 --warmup 5 $B > gpurun_out/${TAG}_pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc $SQ -d /tmp/p_sq5 -o sq -- python3 bench.py --workload c5 --steps 3 --warmup 1 $B > gpurun_out/${TAG}_pmc_sq5.log 2>&1
-rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE -d /tmp/p_clk -o clk -- python3 bench.py --steps 30 --warmup 5 $B > gpurun_out/${TAG}_pmc_clk.log 2>&1
 {
   echo "# SQ counters per launch (rocprofv3 --kernel-trace --pmc, one pass), $TAG"
   echo; echo "## configs[1] (batch 100)"; echo '```'
   python3 tools/pmc_kernel_table.py $(db /tmp/p_sq) layer_combo
   python3 tools/pmc_kernel_table.py $(db /tmp/p_sq) edge_embed
   python3 tools/pmc_kernel_table.py $(db /tmp/p_sq) pair_output
-  python3 tools/pmc_kernel_table.py $(db /tmp/p_clk) layer_combo
   echo '```'; echo; echo "## configs[4] (1024 x 64 atoms)"; echo '```'
   python3 tools/pmc_kernel_table.py $(db /tmp/p_sq5) layer_combo
   python3 tools/pmc_kernel_table.py $(db /tmp/p_sq5) cfconv_aggregate
