@@ -251,11 +251,7 @@ __device__ __forceinline__ void ring_issue(f32x4 (&b)[CB], const char* __restric
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
         const char* sb = sbase + (size_t)cb * cb_bytes;
-#if defined(TSD_EXP) && TSD_EXP == 3  // timing experiment: no B loads at all (MFMAs on whatever the registers hold)
-        asm volatile("" : "=v"(b[cb]) : "v"(voff), "s"(sb));
-#else
         asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[cb]) : "v"(voff), "s"(sb) : "memory");
-#endif
     }
 }
 // wait until at most N younger loads are outstanding and hand the fragment to its consumers
@@ -327,16 +323,8 @@ __device__ __forceinline__ void gemm_tile_ring(BRing<CB, R>& r, const float* __r
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-#if defined(TSD_EXP) && TSD_EXP == 2  // timing experiment: loads and waits only, no MFMA (wrong results)
-                    acc[rb][cb][s] += a[rb][s] * r.b[slot][cb][s];
-#elif defined(TSD_EXP) && TSD_EXP == 4  // loads at the MFMA pace, the pipe itself idle: sleep 64 cycles per MFMA
-                    acc[rb][cb][s] += a[rb][s] * r.b[slot][cb][s];
-                    __builtin_amdgcn_s_sleep(1);
-#else
+                for (int cb = 0; cb < CB; ++cb)
                     acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[rb][s], r.b[slot][cb][s], acc[rb][cb], 0, 0, 0);
-#endif
-                }
         // refill the slot: its MFMAs have been issued (operands are read at issue), the data lands an L2 latency later
         if constexpr (kb + R < KB) ring_issue<CB>(r.b[slot], r.base + (size_t)(kb + R) * r.kb_bytes, r.voff, r.cb_bytes);
     });
@@ -352,20 +340,6 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ ldsA, int ld
     ring_start<CB, R, K / 8>(r, Bp, nout, (unsigned)((lane >> 5) * nout + col0 + (lane & 31)), 2, 32);
     gemm_tile_ring<RB, CB, K, R>(r, ldsA, lda, acc);
 }
-
-#ifdef TSD_EXP
-// timing experiment (variant builds): the same loop with every k-block reading k-block 0 (wrong results)
-template <int RB, int CB, int K>
-__device__ __forceinline__ void gemm_tile_exp(const float* __restrict__ ldsA, int lda, const float* __restrict__ Bp,
-                                              int nout, int col0, f32x16 (&acc)[RB][CB]) {
-    constexpr int R = ring_depth<CB>();
-    const int lane = threadIdx.x & 63;
-    BRing<CB, R> r;
-    ring_start<CB, R, K / 8>(r, Bp, nout, (unsigned)((lane >> 5) * nout + col0 + (lane & 31)), 2, 32);
-    r.kb_bytes = 0;
-    gemm_tile_ring<RB, CB, K, R>(r, ldsA, lda, acc);
-}
-#endif
 
 // 16-row variant on the 16x16x4 f32 MFMA (same rate, half the rows): A lane l holds A[i = l&15][k = l>>4],
 // B lane l holds B[k = l>>4][j = l&15], C/D: col = l&15, row = (l>>4)*4 + r, r in [0,4).

@@ -332,21 +332,12 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
             *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = r < nrows ? v[it] : z;
         }
     }
-#ifdef TSD_EXP_SLEEP  // experiment: the filter tiles that share a CU with a node tile (dispatch-order heuristic) start late
-    if ((int)blockIdx.x >= 256 && (int)blockIdx.x < 256 + TSD_EXP_NODE_TILES) {
-        for (int k = 0; k < TSD_EXP_SLEEP; ++k) __builtin_amdgcn_s_sleep(64);  // 64 * 64 cycles = 1.7 us
-    }
-#endif
     __syncthreads();
     TSD_TRACE_AT(1);
 
     f32x16 acc[1][1];
     zero_acc(acc);
-#if defined(TSD_EXP) && TSD_EXP == 1  // experiment: every k-block reads the SAME 8 KiB of weights (L1 resident: no L2 traffic)
-    gemm_tile_exp<1, 1, H>(buf, LDA, nn0_w, H, col0, acc);
-#else
     gemm_tile<1, 1, H>(buf, LDA, nn0_w, H, col0, acc);
-#endif
     TSD_TRACE_WAVE(8);
     TSD_TRACE_AT(2);
     __syncthreads();
@@ -360,11 +351,7 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
     TSD_TRACE_AT(3);
 
     zero_acc(acc);
-#if defined(TSD_EXP) && TSD_EXP == 1
-    gemm_tile_exp<1, 1, H>(buf, LDA, nn2_w, H, col0, acc);
-#else
     gemm_tile<1, 1, H>(buf, LDA, nn2_w, H, col0, acc);
-#endif
     TSD_TRACE_WAVE(16);
     TSD_TRACE_AT(4);
     __syncthreads();
