@@ -362,9 +362,10 @@ int tsd_gine_aggregate(int32_t num_nodes, int64_t num_edges, int32_t H, int32_t 
  * (no padding; tsd_train_raw_floats floats).  tsd_train_forward builds the geometry of `pos` (the perturbed
  * positions), evaluates the network and loss[i] = |eq_transform(edge_inv) - eq_transform(d_target)|^2 per node
  * (d_target from the clean positions `pos0` and the per-graph alpha `a_graph` [G]), and keeps every
- * activation in `workspace` (tsd_train_workspace_floats(cfg, N, P) floats).  counts_host [3] (HOST memory)
- * receives the two undirected edge counts and the topology status word (the call synchronises the stream once
- * to read them; a fresh batch needs no other host read) and must be
+ * activation in `workspace` (tsd_train_workspace_floats(cfg, N, P) floats).  counts_host [4] (HOST memory)
+ * receives the undirected edge counts of the encoder and output lists, the topology status word and the number of
+ * output edges embedded separately (the call synchronises the stream once to read them; a fresh batch needs no
+ * other host read) and must be
  * handed unchanged to tsd_train_backward, which turns dloss [N] = d(objective)/d(loss) into
  * grad [tsd_train_raw_floats], the gradient of every parameter in the layout of `raw`. */
 size_t tsd_train_raw_floats(const tsd_model_cfg* cfg);
@@ -373,7 +374,7 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
                       const int64_t* r_feat, const int64_t* p_feat, const float* pos0, const float* pos,
                       const float* a_graph, const int32_t* topo_status /* tsd_topology_build's status word or NULL */,
                       float* workspace, size_t workspace_floats, float* loss,
-                      int32_t* counts_host /* [3] */, void* stream);
+                      int32_t* counts_host /* [4] */, void* stream);
 int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* raw, const int64_t* atom_type,
                        const float* pos, float* workspace, size_t workspace_floats, const int32_t* counts_host,
                        const float* dloss, float* grad, void* stream);

@@ -29,8 +29,6 @@ int launch_cfconv_layer(const tsd_model_cfg&, const float*, int, int, tsd_edges,
 int launch_node_update(const tsd_model_cfg&, const float*, int, int, int, const int32_t*, const float*,
                        const float*, float*, float*, hipStream_t);
 int launch_node_lin1(const tsd_model_cfg&, const float*, int, int, const float*, float*, hipStream_t);
-int launch_pair_output(const tsd_model_cfg&, const float*, int, tsd_edges, const float*, const float*,
-                       const int32_t*, float*, int, size_t, size_t, size_t, hipStream_t, const float*, size_t);
 size_t raw_weight_floats(const tsd_model_cfg&);
 int launch_pack_weights(const tsd_model_cfg&, const float*, float*, hipStream_t);
 int launch_topology(int, int, int, int64_t, const int32_t*, const int32_t*, const int64_t*, const int64_t*, int,
@@ -48,12 +46,6 @@ int launch_set_run_args(tsd_sampler_state*, const tsd_run_args&, hipStream_t);
 int launch_philox_normal(uint64_t, uint64_t, int64_t, float*, hipStream_t);
 int launch_filter_gen(const tsd_model_cfg&, const float*, int, tsd_edges, const float*, float*, int, int,
                       hipStream_t);
-int launch_edge_embed2(const tsd_model_cfg&, const float*, int, tsd_edges, float*, int, tsd_edges, float*, int,
-                       size_t, hipStream_t, const UmapRole*);
-int launch_layer_combo(const tsd_model_cfg&, const float*, int, int, tsd_edges, const float*, const float*,
-                       const float*, float*, float*, int, int, int, int, tsd_edges, const float*, float*, int, int,
-                       size_t, size_t, size_t, hipStream_t, const ComboPre*, size_t);
-int filter_tiles_per_layer(int);
 int launch_node_embed(const tsd_model_cfg&, const float*, int, const int64_t*, const int64_t*, const int64_t*,
                       float*, hipStream_t);
 int launch_cfconv_aggregate(int, int, const int32_t*, const int32_t*, const int32_t*, const float*,

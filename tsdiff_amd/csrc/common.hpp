@@ -153,6 +153,42 @@ struct ComboPre {
     float* out;               // [capacity_u, H]
 };
 
+// Side outputs of the fused forward kernels for the training step (train_step.hip): the activations the
+// backward pass reads, written next to the inference results by the SAVE instantiations of the same kernels.
+struct EmbedSave {    // rows are edge-attribute rows: enc_u edge e -> e, k-th diff_u edge -> capacity_u + k
+    float *l0, *s0;   // Linear(1,H)(d) and its swish                         [rows,H]
+    float *e, *c;     // e = mlp(d) [rows,H]; c = [e * emb[type_r], e * emb[type_p]] [rows,2H]
+    float *c0, *s1;   // edge_cat.0(c) and its swish                           [rows,H]
+};
+struct FilterSave {   // per interaction block: [layer][capacity_u, H]
+    float *f0, *fs;   // nn.0 output and its shifted softplus
+};
+struct NodeSave {     // the block of this launch, [N,H] each
+    float *agg, *x2, *xs;  // CFConv aggregate; lin2 output and its shifted softplus
+};
+struct PairSave {     // [capacity_u, .]
+    float* hp;        // [2H]: h_i * h_j || edge_attr_out
+    float *g0, *gs0;  // [H]: first layer of the pair MLP and its swish
+    float *g1, *gs1;  // [H/2]: second layer and its swish
+};
+
+// launchers of the fused forward kernels shared by the inference forward (api.hip) and the training step
+// (train_step.hip); `save` != NULL selects the SAVE instantiation
+int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_edges ea, float* out_a, int cap_b,
+                       tsd_edges eb, float* out_b, int M, size_t out_stride, hipStream_t st, const UmapRole* umap,
+                       const EmbedSave* save = nullptr, int save_b_row = 0);
+int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N, tsd_edges enc, const float* Wf_layer,
+                       const float* x1_in, const float* h_in, float* h, float* x1_out, int layer_w0, int g_begin,
+                       int g_count, int capacity_u, tsd_edges enc_u, const float* edge_attr, float* wf_base,
+                       int wf_slots, int M, size_t nh_stride, size_t ea_stride, size_t wf_stride, hipStream_t st,
+                       const ComboPre* pre, size_t pre_stride, const FilterSave* fsave = nullptr,
+                       const NodeSave* nsave = nullptr);
+int filter_tiles_per_layer(int capacity_u);
+int launch_pair_output(const tsd_model_cfg& c, const float* W, int capacity, tsd_edges e, const float* h,
+                       const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
+                       size_t ea_stride, size_t inv_stride, hipStream_t st, const float* pre, size_t pre_stride,
+                       const PairSave* save = nullptr);
+
 inline bool hidden_supported(int H) { return H == 64 || H == 128 || H == 256; }
 
 // ---------------------------------------------------------------------------------------------

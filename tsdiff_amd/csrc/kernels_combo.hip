@@ -106,8 +106,8 @@ struct VRow<1> {
 // bit-identical to a sequential scatter_add), then the three dense layers of tsd_node_update.
 // reference schnet.py:101-107 (message/aggregate), :103 (lin2), :123-127, :223-224
 // -------------------------------------------------------------------------------------------------
-template <int H>
-__device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* smem TSD_TRACE_ARG) {
+template <int H, bool SAVE>
+__device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* smem, const NodeSave& ns TSD_TRACE_ARG) {
     constexpr int LDA = H + 4;
     constexpr int NT = 2 * H;
     constexpr int NW = NT / 64;
@@ -162,6 +162,9 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 buf[(wave * RPW + rr) * LDA + lane * V + v] = s[v];
+                if constexpr (SAVE) {
+                    if (first + rr < a.N) ns.agg[(size_t)(first + rr) * H + lane * V + v] = s[v];
+                }
                 s[v] = 0.0f;
             }
             ++rr;
@@ -234,7 +237,16 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
             const int col = col0 + cb * 16 + l15;
             const float b = b_lin2[cb];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) buf[(q * 4 + r) * LDA + col] = sspf(acc[cb][r] + b);
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[cb][r] + b, sv = sspf(v);
+                buf[(q * 4 + r) * LDA + col] = sv;
+                if constexpr (SAVE) {
+                    if (q * 4 + r < nrows) {
+                        ns.x2[(size_t)(n0 + q * 4 + r) * H + col] = v;
+                        ns.xs[(size_t)(n0 + q * 4 + r) * H + col] = sv;
+                    }
+                }
+            }
         }
         __syncthreads();
         TSD_TRACE_AT(3);
@@ -292,8 +304,8 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
 // filter role: Wf[e] = nn2(ssp(nn0(edge_attr[e]))) * C(e) for one tile of 32 undirected edges,
 // H/32 waves x 32 columns (the 256-thread stand-alone form is filter_gen_kernel in kernels_mlp.hip)
 // -------------------------------------------------------------------------------------------------
-template <int H>
-__device__ __forceinline__ void filter_role(const ComboFilter& f, int item, float* smem TSD_TRACE_ARG) {
+template <int H, bool SAVE>
+__device__ __forceinline__ void filter_role(const ComboFilter& f, int item, float* smem, const FilterSave& fsv TSD_TRACE_ARG) {
     const int g = f.g_begin + item;
     const int lrel = g / f.tiles_per_layer, tile = g - lrel * f.tiles_per_layer;
     const float* Wb = f.Wl0 + (size_t)(f.layer0 + lrel) * f.layer_stride;
@@ -345,7 +357,18 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
         const int col = col0 + l31;
         const float b = nn0_b[col];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) buf[acc_row(r, hi) * LDA + col] = sspf(acc[0][0][r] + b);
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, hi);
+            const float v = acc[0][0][r] + b, sv = sspf(v);
+            buf[row * LDA + col] = sv;
+            if constexpr (SAVE) {  // the training step keeps every block's filters and activations: slot = block
+                if (row < nrows) {
+                    const size_t o = (size_t)lrel * f.wf_layer_stride + (size_t)(e0 + row) * H + col;
+                    fsv.f0[o] = v;
+                    fsv.fs[o] = sv;
+                }
+            }
+        }
     }
     __syncthreads();
     TSD_TRACE_AT(3);
@@ -417,9 +440,10 @@ struct ComboStride {  // per-checkpoint strides (blockIdx.y = checkpoint of the 
 
 constexpr int NODE_RUN = 4;  // consecutive node tiles kept on one XCD (one 64-atom graph = 4 tiles)
 
-template <int H>
+template <int H, bool SAVE>
 __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int node_tiles, ComboFilter f,
-                                                            ComboStride sd, ComboPre q TSD_TRACE_ARG) {
+                                                            ComboStride sd, ComboPre q, FilterSave fsv,
+                                                            NodeSave ns TSD_TRACE_ARG) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     {
         const size_t m = blockIdx.y;
@@ -460,7 +484,7 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
         // they share a SIMD with
         __builtin_amdgcn_s_setprio(3);
         TSD_TRACE_REAL(24);
-        node_role<H>(a, tile, smem TSD_TRACE_PASS);
+        node_role<H, SAVE>(a, tile, smem, ns TSD_TRACE_PASS);
         TSD_TRACE_REAL(25);
     } else {
         const int item = others_before;
@@ -469,7 +493,7 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
             return;
         }
         TSD_TRACE_REAL(24);
-        filter_role<H>(f, item, smem TSD_TRACE_PASS);
+        filter_role<H, SAVE>(f, item, smem, fsv TSD_TRACE_PASS);
         TSD_TRACE_REAL(25);
     }
 }
@@ -490,7 +514,7 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
                        int layer_w0, int g_begin, int g_count,
                        int capacity_u, tsd_edges enc_u, const float* edge_attr, float* wf_base, int wf_slots, int M,
                        size_t nh_stride, size_t ea_stride, size_t wf_stride, hipStream_t st, const ComboPre* pre,
-                       size_t pre_stride) {
+                       size_t pre_stride, const FilterSave* fsave, const NodeSave* nsave) {
     const WeightLayout L = weight_layout(c);
     ComboNode a{};
     a.N = N;
@@ -554,12 +578,25 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
 #define TSD_TRACE_HOST
 #endif
 #define TSD_COMBO(HH)                                                                                       \
-    {                                                                                                       \
+    if (save) {                                                                                             \
         static DeviceOnce once;                                                                             \
-        int r = allow_lds(layer_combo_kernel<HH>, lds, once);                                               \
+        int r = allow_lds(layer_combo_kernel<HH, true>, lds, once);                                         \
         if (r) return r;                                                                                    \
-        hipLaunchKernelGGL((layer_combo_kernel<HH>), dim3(grid, M), dim3(2 * HH), lds, st, a, node_tiles, f, \
-                           sd, q TSD_TRACE_HOST);                                                           \
+        hipLaunchKernelGGL((layer_combo_kernel<HH, true>), dim3(grid, M), dim3(2 * HH), lds, st, a, node_tiles, f, \
+                           sd, q, fsv, nsv TSD_TRACE_HOST);                                                 \
+    } else {                                                                                                \
+        static DeviceOnce once;                                                                             \
+        int r = allow_lds(layer_combo_kernel<HH, false>, lds, once);                                        \
+        if (r) return r;                                                                                    \
+        hipLaunchKernelGGL((layer_combo_kernel<HH, false>), dim3(grid, M), dim3(2 * HH), lds, st, a, node_tiles, f, \
+                           sd, q, fsv, nsv TSD_TRACE_HOST);                                                 \
+    }
+    const bool save = fsave != nullptr || nsave != nullptr;
+    const FilterSave fsv = fsave ? *fsave : FilterSave{};
+    const NodeSave nsv = nsave ? *nsave : NodeSave{};
+    if (save && ((f.tiles > 0 && !fsave) || (node_tiles > 0 && a.mode == 0 && !nsave) || M != 1)) {
+        set_error("internal: the saving block launch needs both save sets and one checkpoint");
+        return TSD_ERR_INVALID;
     }
     switch (c.hidden) {
         case 64: TSD_COMBO(64) break;

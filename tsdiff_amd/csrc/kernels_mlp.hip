@@ -31,11 +31,13 @@ struct PairW {
 // ---------------------------------------------------------------------------------------------
 // Two lists may share one launch (tiles [0, tiles_a) -> list a, the rest -> list b): the encoder list and
 // the few output-graph edges that need their own embedding fill the chip together.
-template <int H>
+// SAVE: the training step's instantiation also writes the intermediate activations (EmbedSave, row = edge-attribute
+// row: list b starts at row `save_b_row`).
+template <int H, bool SAVE>
 __global__ __launch_bounds__(2 * H) void edge_embed_kernel(EdgeEmbedW w, tsd_edges ea_, float* __restrict__ out_a,
                                                        int tiles_a, tsd_edges eb_, float* __restrict__ out_b,
                                                        size_t wstride, size_t out_stride, int embed_tiles,
-                                                       UmapRole um) {
+                                                       UmapRole um, EmbedSave sv, int save_b_row) {
     constexpr int LDA = 2 * H + 4;
     if ((int)blockIdx.x >= embed_tiles) {  // extra role: directed-edge -> undirected-pair map (checkpoint 0 only)
         if (blockIdx.y == 0)
@@ -64,6 +66,7 @@ __global__ __launch_bounds__(2 * H) void edge_embed_kernel(EdgeEmbedW w, tsd_edg
     const int tid = threadIdx.x;
     const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int col0 = (tid >> 6) * 32;  // 2H threads = H/32 waves x 32 columns (measured faster than H/64 x 64)
+    const size_t srow0 = (size_t)(second ? save_b_row : 0) + e0;  // SAVE: first row of this tile in the save arrays
 
     if (tid < T) {
         const int ee = e0 + tid;
@@ -77,7 +80,16 @@ __global__ __launch_bounds__(2 * H) void edge_embed_kernel(EdgeEmbedW w, tsd_edg
         const int c = tid % H, r0 = (tid / H) * (T / 2);
         const float w0 = w.w0[c], b0 = w.b0[c];
 #pragma unroll 8
-        for (int r = r0; r < r0 + T / 2; ++r) buf[r * LDA + c] = swishf(w0 * s_d[r] + b0);
+        for (int r = r0; r < r0 + T / 2; ++r) {
+            const float l = w0 * s_d[r] + b0, sl = swishf(l);
+            buf[r * LDA + c] = sl;
+            if constexpr (SAVE) {
+                if (e0 + r < E) {
+                    sv.l0[(srow0 + r) * H + c] = l;
+                    sv.s0[(srow0 + r) * H + c] = sl;
+                }
+            }
+        }
     }
     __syncthreads();
 
@@ -93,8 +105,16 @@ __global__ __launch_bounds__(2 * H) void edge_embed_kernel(EdgeEmbedW w, tsd_edg
         for (int r = 0; r < 16; ++r) {
             const int row = acc_row(r, hi);
             const float v = acc[0][cb][r] + b;
-            buf[row * LDA + col] = v * w.bond_emb[s_tr[row] * H + col];
-            buf[row * LDA + H + col] = v * w.bond_emb[s_tp[row] * H + col];
+            const float vr = v * w.bond_emb[s_tr[row] * H + col], vp = v * w.bond_emb[s_tp[row] * H + col];
+            buf[row * LDA + col] = vr;
+            buf[row * LDA + H + col] = vp;
+            if constexpr (SAVE) {
+                if (e0 + row < E) {
+                    sv.e[(srow0 + row) * H + col] = v;
+                    sv.c[(srow0 + row) * 2 * H + col] = vr;
+                    sv.c[(srow0 + row) * 2 * H + H + col] = vp;
+                }
+            }
         }
     }
     __syncthreads();
@@ -107,7 +127,17 @@ __global__ __launch_bounds__(2 * H) void edge_embed_kernel(EdgeEmbedW w, tsd_edg
         const int col = col0 + cb * 32 + l31;
         const float b = w.cb0[col];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) buf[acc_row(r, hi) * LDA + col] = swishf(acc[0][cb][r] + b);
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, hi);
+            const float v = acc[0][cb][r] + b, sv1 = swishf(v);
+            buf[row * LDA + col] = sv1;
+            if constexpr (SAVE) {
+                if (e0 + row < E) {
+                    sv.c0[(srow0 + row) * H + col] = v;
+                    sv.s1[(srow0 + row) * H + col] = sv1;
+                }
+            }
+        }
     }
     __syncthreads();
 
@@ -425,13 +455,15 @@ __global__ __launch_bounds__(2 * H) void node_update_kernel(NodeW w, int N, cons
 // A10: edge_inv = grad_dist_mlp([h_src * h_dst, edge_attr_out])     (2H -> H -> H/2 -> 1, swish)
 // reference models/common.py:226-229, models/epsnet/condensenc.py:72-76,236-237
 // ---------------------------------------------------------------------------------------------
-template <int H>
+// SAVE (training step, `pre` == NULL): also writes the staged input rows and both layers' pre-/post-activations.
+template <int H, bool SAVE>
 __global__ __launch_bounds__(2 * H) void pair_output_kernel(PairW w, tsd_edges e, const float* __restrict__ h,
                                                         const float* __restrict__ edge_attr,
                                                         const int32_t* __restrict__ attr_row,
                                                         float* __restrict__ edge_inv, size_t wstride,
                                                         size_t h_stride, size_t ea_stride, size_t inv_stride,
-                                                        const float* __restrict__ pre, size_t pre_stride) {
+                                                        const float* __restrict__ pre, size_t pre_stride,
+                                                        PairSave sv) {
     constexpr int LDA = 2 * H + 4;
     constexpr int NW = H / 64;   // waves of the second GEMM (H/2 columns, 32 per wave); the block has 2 NW waves
     {  // blockIdx.y = checkpoint of the ensemble
@@ -476,6 +508,12 @@ __global__ __launch_bounds__(2 * H) void pair_output_kernel(PairW w, tsd_edges e
             }
             *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = a;
             if (!pre) *reinterpret_cast<f32x4*>(buf + r * LDA + H + c4 * 4) = b;
+            if constexpr (SAVE) {
+                if (r < nrows) {
+                    *reinterpret_cast<f32x4*>(sv.hp + (size_t)(e0 + r) * 2 * H + c4 * 4) = a;
+                    *reinterpret_cast<f32x4*>(sv.hp + (size_t)(e0 + r) * 2 * H + H + c4 * 4) = b;
+                }
+            }
         }
     }
     __syncthreads();
@@ -502,7 +540,17 @@ __global__ __launch_bounds__(2 * H) void pair_output_kernel(PairW w, tsd_edges e
         gemm_tile<1, 1, H>(buf, LDA, w.w0, H, col0, acc);
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) buf[acc_row(r, hi) * LDA + col] = swishf(acc[0][0][r]);
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, hi);
+            const float v = acc[0][0][r], sg = swishf(v);
+            buf[row * LDA + col] = sg;
+            if constexpr (SAVE) {
+                if (row < nrows) {
+                    sv.g0[(size_t)(e0 + row) * H + col] = v;
+                    sv.gs0[(size_t)(e0 + row) * H + col] = sg;
+                }
+            }
+        }
         __syncthreads();
     }
     if (wave < NW) {  // H -> H/2 and the final dot: the first H/64 waves
@@ -513,7 +561,15 @@ __global__ __launch_bounds__(2 * H) void pair_output_kernel(PairW w, tsd_edges e
         const float b = w.b1[col], w2 = w.w2[col];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            float v = swishf(acc[0][0][r] + b) * w2;
+            const float g = acc[0][0][r] + b, sg = swishf(g);
+            if constexpr (SAVE) {
+                const int row = acc_row(r, hi);
+                if (row < nrows) {
+                    sv.g1[(size_t)(e0 + row) * (H / 2) + col] = g;
+                    sv.gs1[(size_t)(e0 + row) * (H / 2) + col] = sg;
+                }
+            }
+            float v = sg * w2;
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 8);
             v += __shfl_xor(v, 4);
@@ -564,7 +620,8 @@ static inline size_t lds_pair(int H) { return (size_t)(T * (2 * H + 4) + (H / 64
     }
 
 int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_edges ea, float* out_a, int cap_b,
-                       tsd_edges eb, float* out_b, int M, size_t out_stride, hipStream_t st, const UmapRole* umap) {
+                       tsd_edges eb, float* out_b, int M, size_t out_stride, hipStream_t st, const UmapRole* umap,
+                       const EmbedSave* save, int save_b_row) {
     const WeightLayout L = weight_layout(c);
     EdgeEmbedW w{W + L.bond_emb, W + L.emlp_w0, W + L.emlp_b0, W + L.emlp_w1, W + L.emlp_b1,
                  W + L.ecat_w0, W + L.ecat_b0, W + L.ecat_w1, W + L.ecat_b1};
@@ -576,19 +633,30 @@ int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_ed
     }
     if (tiles_a + tiles_b + um.blocks == 0) return TSD_OK;
     const size_t lds = lds_edge_embed(c.hidden);
-    TSD_DISPATCH_H(c.hidden, {
-        static DeviceOnce once; int r = allow_lds(edge_embed_kernel<HH>, lds, once);
-        if (r) return r;
-        hipLaunchKernelGGL(edge_embed_kernel<HH>, dim3(tiles_a + tiles_b + um.blocks, M), dim3(2 * HH), lds, st, w, ea,
-                           out_a, tiles_a, eb, out_b, L.total, out_stride, tiles_a + tiles_b, um);
-    });
+    if (save) {
+        TSD_DISPATCH_H(c.hidden, {
+            static DeviceOnce once; int r = allow_lds(edge_embed_kernel<HH, true>, lds, once);
+            if (r) return r;
+            hipLaunchKernelGGL((edge_embed_kernel<HH, true>), dim3(tiles_a + tiles_b + um.blocks, M), dim3(2 * HH), lds,
+                               st, w, ea, out_a, tiles_a, eb, out_b, L.total, out_stride, tiles_a + tiles_b, um, *save,
+                               save_b_row);
+        });
+    } else {
+        TSD_DISPATCH_H(c.hidden, {
+            static DeviceOnce once; int r = allow_lds(edge_embed_kernel<HH, false>, lds, once);
+            if (r) return r;
+            hipLaunchKernelGGL((edge_embed_kernel<HH, false>), dim3(tiles_a + tiles_b + um.blocks, M), dim3(2 * HH), lds,
+                               st, w, ea, out_a, tiles_a, eb, out_b, L.total, out_stride, tiles_a + tiles_b, um,
+                               EmbedSave{}, 0);
+        });
+    }
     TSD_LAUNCH_CHECK("edge_embed");
     return TSD_OK;
 }
 
 int launch_edge_embed(const tsd_model_cfg& c, const float* W, int capacity, tsd_edges e, float* edge_attr,
                       hipStream_t st) {
-    return launch_edge_embed2(c, W, capacity, e, edge_attr, 0, e, edge_attr, 1, 0, st, nullptr);
+    return launch_edge_embed2(c, W, capacity, e, edge_attr, 0, e, edge_attr, 1, 0, st, nullptr, nullptr, 0);
 }
 
 int launch_cfconv_layer(const tsd_model_cfg& c, const float* W, int layer, int capacity, tsd_edges e,
@@ -669,18 +737,32 @@ int launch_node_lin1(const tsd_model_cfg& c, const float* W, int layer, int N, c
 
 int launch_pair_output(const tsd_model_cfg& c, const float* W, int capacity, tsd_edges e, const float* h,
                        const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
-                       size_t ea_stride, size_t inv_stride, hipStream_t st, const float* pre, size_t pre_stride) {
+                       size_t ea_stride, size_t inv_stride, hipStream_t st, const float* pre, size_t pre_stride,
+                       const PairSave* save) {
     const WeightLayout L = weight_layout(c);
     PairW w{W + L.out_w0, W + L.out_b0, W + L.out_w1, W + L.out_b1, W + L.out_w2, W + L.out_b2};
     const int tiles = (capacity + T - 1) / T;
     if (tiles == 0) return TSD_OK;
     const size_t lds = lds_pair(c.hidden);
-    TSD_DISPATCH_H(c.hidden, {
-        static DeviceOnce once; int r = allow_lds(pair_output_kernel<HH>, lds, once);
-        if (r) return r;
-        hipLaunchKernelGGL(pair_output_kernel<HH>, dim3(tiles, M), dim3(2 * HH), lds, st, w, e, h, edge_attr, attr_row,
-                           edge_inv, L.total, h_stride, ea_stride, inv_stride, pre, pre_stride);
-    });
+    if (save) {
+        if (pre) {
+            set_error("internal: pair_output saves need the unsplit first layer");
+            return TSD_ERR_INVALID;
+        }
+        TSD_DISPATCH_H(c.hidden, {
+            static DeviceOnce once; int r = allow_lds(pair_output_kernel<HH, true>, lds, once);
+            if (r) return r;
+            hipLaunchKernelGGL((pair_output_kernel<HH, true>), dim3(tiles, M), dim3(2 * HH), lds, st, w, e, h, edge_attr,
+                               attr_row, edge_inv, L.total, h_stride, ea_stride, inv_stride, pre, pre_stride, *save);
+        });
+    } else {
+        TSD_DISPATCH_H(c.hidden, {
+            static DeviceOnce once; int r = allow_lds(pair_output_kernel<HH, false>, lds, once);
+            if (r) return r;
+            hipLaunchKernelGGL((pair_output_kernel<HH, false>), dim3(tiles, M), dim3(2 * HH), lds, st, w, e, h, edge_attr,
+                               attr_row, edge_inv, L.total, h_stride, ea_stride, inv_stride, pre, pre_stride, PairSave{});
+        });
+    }
     TSD_LAUNCH_CHECK("pair_output");
     return TSD_OK;
 }

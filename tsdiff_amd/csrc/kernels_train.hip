@@ -305,12 +305,43 @@ __global__ void pack_batch_kernel(PackBatch b) {
     const int ncols = b.ncols[it], kdim = b.kdim[it];
     const float* __restrict__ M = b.W[it];
     float* __restrict__ Bp = b.dst[it];
+    if (b.transposed[it] == 2) {  // plain copy of ncols floats (biases, embedding tables)
+        for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < ncols; idx += gridDim.x * blockDim.x) Bp[idx] = M[idx];
+        return;
+    }
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < ncols * kdim; idx += gridDim.x * blockDim.x) {
         const int s = idx & 3;
         const int n = (idx >> 2) % ncols;
         const int k = ((idx >> 2) / ncols) * 4 + s;
         Bp[idx] = b.transposed[it] ? M[(size_t)k * ncols + n] : M[(size_t)n * kdim + k];
     }
+}
+
+int launch_pack_items(int n, const PackItem* items, hipStream_t st) {
+    for (int base = 0; base < n; base += TSD_PACK_MAX) {
+        PackBatch b;
+        const int m = n - base < TSD_PACK_MAX ? n - base : TSD_PACK_MAX;
+        int biggest = 0;
+        for (int k = 0; k < m; ++k) {
+            const PackItem& it = items[base + k];
+            b.W[k] = it.src;
+            b.dst[k] = it.dst;
+            b.transposed[k] = it.mode;
+            if (it.mode == 2) {
+                b.ncols[k] = it.out;
+                b.kdim[k] = 1;
+            } else {
+                b.ncols[k] = it.mode ? it.in : it.out;  // forward: B[k = in][n = out]; dgrad: B[k = out][n = in]
+                b.kdim[k] = it.mode ? it.out : it.in;
+            }
+            const int sz = it.mode == 2 ? it.out : it.out * it.in;
+            biggest = sz > biggest ? sz : biggest;
+        }
+        const int bx = (biggest + 255) / 256 < 64 ? (biggest + 255) / 256 : 64;
+        hipLaunchKernelGGL(pack_batch_kernel, dim3(bx, m), dim3(256), 0, st, b);
+    }
+    TSD_LAUNCH_CHECK("pack_items");
+    return TSD_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

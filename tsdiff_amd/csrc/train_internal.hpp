@@ -48,4 +48,13 @@ int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, c
                     hipStream_t st);
 size_t linear_scratch_floats(int in, int out);
 
+// the optimizer rewrites every weight every step: all layout conversions of a step in a few launches.
+// mode 0: W [out,in] -> forward MFMA layout [in/4][out][in%4]; 1: dgrad layout (W^T); 2: copy of `out` floats
+struct PackItem {
+    const float* src;
+    float* dst;
+    int out, in, mode;
+};
+int launch_pack_items(int n, const PackItem* items, hipStream_t st);
+
 }  // namespace tsd

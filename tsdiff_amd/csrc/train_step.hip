@@ -2,9 +2,12 @@
 // models/epsnet/condensenc.py:178-239, 267-328): tsd_train_forward evaluates get_loss on the perturbed
 // geometry and keeps every activation the backward pass needs in a caller-provided workspace;
 // tsd_train_backward turns d(loss)/d(loss_i) into the gradient of every parameter (flat, in the order of the
-// flat parameter vector).  Same primitive kernels as the autograd form (tsdiff_amd/train_ops.py), sequenced
-// here instead of by ~450 Python-level autograd nodes per step: the step is no longer host bound, residual
-// adds and gradient accumulations ride in the GEMM epilogues instead of separate elementwise launches.
+// flat parameter vector).  The forward pass IS the inference forward (the fused per-tile kernels of kernels_mlp.hip /
+// kernels_combo.hip in their SAVE instantiations, which write the activations next to the results; the edge
+// embedding is evaluated once per undirected pair and shared by the encoder and output lists, as in api.hip);
+// the backward pass is the primitive kernels of the autograd form (tsdiff_amd/train_ops.py) sequenced here
+// instead of by ~450 Python-level autograd nodes per step, residual adds and gradient accumulations riding in
+// the GEMM epilogues.
 //
 // Flat parameter vector `raw` (fp32, no padding), order of tsdiff_amd/engine.py::raw_param_names:
 //   edge_encoder.bond_emb.weight [100,H], edge_encoder.mlp.layers.0.{weight [H,1], bias}, .1.{weight [H,H], bias},
@@ -12,6 +15,8 @@
 //   per block: conv.lin1.weight, conv.lin2.{weight,bias}, conv.nn.0.{weight,bias}, conv.nn.2.{weight,bias},
 //              lin.{weight,bias},
 //   grad_dist_mlp.layers.{0 [H,2H], 1 [H/2,H], 2 [1,H/2]}.{weight,bias}, edge_cat.{0 [H,2H], 2 [H,H]}.{weight,bias}
+#include <vector>
+
 #include "train_internal.hpp"
 
 namespace tsd {
@@ -70,34 +75,31 @@ RawLayout raw_layout(const tsd_model_cfg& c) {
     return L;
 }
 
-// everything one edge-embedding evaluation keeps (condensenc.py:156-176, edge.py:58-68)
-struct EmbedSave {
-    float *l0, *s0, *e, *c, *c0, *s1, *ea;  // [E,H] except c [E,2H]
-};
 struct Work {
-    // forward state
+    // forward state (rows of the per-edge arrays by CAPACITY PU = P/2, so that the layout does not depend on the
+    // edge counts of the step)
     float *featR, *featP;          // [N,F] fp32 one-hot features
     float* h;                      // [(L+1), N, H]
     float *x1, *agg, *x2, *xs;     // [L, N, H] each
-    EmbedSave emb_enc, emb_out;
-    float *f0, *fs, *Wf;           // [L, Eu, H] each
+    EmbedSave emb;                 // [2 PU, .]: rows [0, Eu) enc_u edges, rows [PU, PU + Ed) separately embedded out edges
+    float* ea;                     // [2 PU, H] edge attributes, same rows (condensenc.py:156-176, edge.py:58-68)
+    float *f0, *fs, *Wf;           // [L, PU, H] each
     float *hp, *g0, *gs0, *g1, *gs1, *s_u;  // pair MLP
     float *node_eq, *pos_target, *d_target;
-    float *pack_fwd, *pack_t;      // packed dense weights, offsets = raw offsets
+    float* pack_inf;               // packed weights, layout of tsd_pack_weights (the fused forward kernels)
+    float* pack_t;                 // dgrad layouts of the dense weights, offsets = raw offsets
     float* scratch;                // linear scratch
     size_t scratch_floats;
     // backward temporaries
-    float *eA, *eB;                // [Emax, 2H] each
-    float *d_ea;                   // [Eu, H]
+    float *eA, *eB;                // [PU, 2H] each
+    float *d_ea;                   // [2 PU, H], rows as `ea`
     float *nA, *nB, *nC, *dh;      // [N, H] each
-    float* meta;                   // [4]: Eu, Eo as floats are NOT stored here; see counts (host)
     size_t total;
 };
 
-Work carve(const tsd_model_cfg& c, int N, size_t Eu, size_t Eo, float* base) {
+Work carve(const tsd_model_cfg& c, int N, size_t PU, float* base) {
     Work w;
     const size_t H = c.hidden, L = c.num_convs, F = c.feat_dim;
-    const size_t Em = Eu > Eo ? Eu : Eo;
     size_t o = 0;
     auto take = [&](size_t n) { float* r = base ? base + o : nullptr; o += (n + 63) & ~size_t(63); return r; };
     w.featR = take((size_t)N * F);
@@ -107,43 +109,38 @@ Work carve(const tsd_model_cfg& c, int N, size_t Eu, size_t Eo, float* base) {
     w.agg = take(L * N * H);
     w.x2 = take(L * N * H);
     w.xs = take(L * N * H);
-    auto take_embed = [&](EmbedSave& e, size_t E) {
-        e.l0 = take(E * H);
-        e.s0 = take(E * H);
-        e.e = take(E * H);
-        e.c = take(E * 2 * H);
-        e.c0 = take(E * H);
-        e.s1 = take(E * H);
-        e.ea = take(E * H);
-    };
-    take_embed(w.emb_enc, Eu);
-    take_embed(w.emb_out, Eo);
-    w.f0 = take(L * Eu * H);
-    w.fs = take(L * Eu * H);
-    w.Wf = take(L * Eu * H);
-    w.hp = take(Eo * 2 * H);
-    w.g0 = take(Eo * H);
-    w.gs0 = take(Eo * H);
-    w.g1 = take(Eo * (H / 2));
-    w.gs1 = take(Eo * (H / 2));
-    w.s_u = take(Eo);
+    w.emb.l0 = take(2 * PU * H);
+    w.emb.s0 = take(2 * PU * H);
+    w.emb.e = take(2 * PU * H);
+    w.emb.c = take(2 * PU * 2 * H);
+    w.emb.c0 = take(2 * PU * H);
+    w.emb.s1 = take(2 * PU * H);
+    w.ea = take(2 * PU * H);
+    w.f0 = take(L * PU * H);
+    w.fs = take(L * PU * H);
+    w.Wf = take(L * PU * H);
+    w.hp = take(PU * 2 * H);
+    w.g0 = take(PU * H);
+    w.gs0 = take(PU * H);
+    w.g1 = take(PU * (H / 2));
+    w.gs1 = take(PU * (H / 2));
+    w.s_u = take(PU);
     w.node_eq = take((size_t)N * 3);
     w.pos_target = take((size_t)N * 3);
-    w.d_target = take(Eo);
+    w.d_target = take(PU);
     const RawLayout R = raw_layout(c);
-    w.pack_fwd = take(R.total);
+    w.pack_inf = take(weight_layout(c).total);
     w.pack_t = take(R.total);
     w.scratch_floats = linear_scratch_floats((int)(2 * H), (int)H);
     if (w.scratch_floats < (size_t)512 * 32 * H) w.scratch_floats = (size_t)512 * 32 * H;  // embedding-gradient partials
     w.scratch = take(w.scratch_floats);
-    w.eA = take(Em * 2 * H);
-    w.eB = take(Em * 2 * H);
-    w.d_ea = take(Eu * H);
+    w.eA = take(PU * 2 * H);
+    w.eB = take(PU * 2 * H);
+    w.d_ea = take(2 * PU * H);
     w.nA = take((size_t)N * H);
     w.nB = take((size_t)N * H);
     w.nC = take((size_t)N * H);
     w.dh = take((size_t)N * H);
-    w.meta = take(64);
     w.total = o;
     return w;
 }
@@ -208,17 +205,6 @@ __global__ void atom_emb_grad_reduce_kernel(int n, const float* __restrict__ par
     for (int k = 0; k < AE_CHUNKS; ++k) s += part[(size_t)k * n + t];
     g[t] += s;
 }
-// c[r] = [e[r] * emb[tr[r]] , e[r] * emb[tp[r]]]                               condensenc.py:169-172
-__global__ void emb_mul2_fwd_kernel(int rows, int H, const float* __restrict__ e, const float* __restrict__ emb,
-                                    const uint8_t* __restrict__ tr, const uint8_t* __restrict__ tp,
-                                    float* __restrict__ c) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (int64_t)rows * H) return;
-    const int r = (int)(t / H), k = (int)(t % H);
-    const float v = e[t];
-    c[(size_t)r * 2 * H + k] = v * emb[(size_t)tr[r] * H + k];
-    c[(size_t)r * 2 * H + H + k] = v * emb[(size_t)tp[r] * H + k];
-}
 // de = dc_lo * emb[tr] + dc_hi * emb[tp];  d emb[t] = sum of dc_lo * e over the rows with tr == t plus dc_hi * e over
 // those with tp == t.  Deterministic: every wave owns a private [ET][64] accumulator in LDS and walks its rows in
 // order, the four waves are combined in a fixed order into partial[chunk][ET][H], a second kernel sums the
@@ -270,6 +256,16 @@ __global__ void copy2d_kernel(int64_t rows, int cols, const float* __restrict__ 
     const int c = (int)(t % cols);
     dst[r * ldd + c] = src[r * lds_ + c];
 }
+// dst[row[r]] = src[r] for rows with distinct targets (the out edges' share of the edge-attribute gradient:
+// every out_u edge owns one row of the attribute matrix, geo.attr_row)
+__global__ void scatter_rows_kernel(int64_t rows, int cols, const float* __restrict__ src, int lds_,
+                                    const int32_t* __restrict__ row, float* __restrict__ dst) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * cols) return;
+    const int64_t r = t / cols;
+    const int c = (int)(t % cols);
+    dst[(size_t)row[r] * cols + c] = src[r * lds_ + c];
+}
 // d_target[u] = (|pos0_i - pos0_j| - d_u) / sqrt(1 - a) * sqrt(a), a = alpha of the pair's graph   condensenc.py:309-318
 __global__ void d_target_kernel(tsd_edges eu, const float* __restrict__ pos0, const int32_t* __restrict__ node_graph,
                                 const float* __restrict__ a_graph, float* __restrict__ out) {
@@ -303,26 +299,8 @@ struct Ctx {
     const float* raw;
     float* grad;  // backward only
     hipStream_t st;
-    int N, H, L, F, Eu, Eo;
+    int N, H, L, F, PU, Eu, Eo, Ed;
     bool packed(int in, int out) const { return (in == 128 || in == 256 || in == 512) && (out == 128 || out == 256 || out == 512); }
-    // Y = X W^T + b (+ Rsd); act_kind >= 0: Y2 = act(Y) as well
-    int lin(int rows, int in, int out, const float* X, size_t w_off, long b_off, const float* Rsd, float* Y,
-            int act_kind = -1, float* Y2 = nullptr, const float* mask_dist = nullptr) const {
-        const float* Wp = packed(in, out) ? w.pack_fwd + w_off : nullptr;
-        LinEpi e;
-        e.bias = b_off >= 0 ? raw + b_off : nullptr;
-        e.R = Rsd;
-        if (act_kind >= 0) {
-            e.Y2 = Y2;
-            e.act_kind = act_kind;
-        }
-        if (mask_dist) {
-            e.mask_dist = mask_dist;
-            e.cutoff = c->conv_cutoff;
-            e.smooth = c->smooth_conv;
-        }
-        return linear_fwd_impl(rows, in, out, X, raw + w_off, Wp, e, Y, w.scratch, w.scratch_floats, st);
-    }
     // all parameter gradients accumulate (the flat gradient is zeroed once per backward).
     // dact_kind >= 0: dX is multiplied by act'(act_pre) -- the adjoint of the activation that fed this layer
     int lin_bwd(int rows, int in, int out, const float* X, size_t w_off, long b_off, const float* dY, float* dX,
@@ -344,61 +322,48 @@ struct Ctx {
         if (_r) return _r;     \
     } while (0)
 
+// Every layout conversion of the step in two launches: the packed arena the fused forward kernels read
+// (layout of tsd_pack_weights) and the dgrad layouts of the dense weights (offsets of the raw vector).
 int pack_all(const Ctx& x) {
-    // every MFMA-shaped dense weight, forward and dgrad layouts, a handful of launches
-    const int H = x.H;
-    const float* W[64];
-    float* D[64];
-    int od[64], id[64], tr[64];
-    int n = 0;
-    auto add = [&](size_t off, int out, int in) {
-        if (!x.packed(in, out)) return;
-        for (int t = 0; t < 2; ++t) {
-            W[n] = x.raw + off;
-            D[n] = (t ? x.w.pack_t : x.w.pack_fwd) + off;
-            od[n] = out;
-            id[n] = in;
-            tr[n] = t;
-            ++n;
-        }
+    const int H = x.H, L = x.L;
+    const WeightLayout I = weight_layout(*x.c);
+    const RawLayout& R = x.R;
+    std::vector<PackItem> it;
+    it.reserve(128);
+    float* D = x.w.pack_inf;
+    auto cp = [&](size_t dst, size_t src, int n) { it.push_back({x.raw + src, D + dst, n, 1, 2}); };
+    auto pk = [&](size_t dst, size_t src, int out, int in) {
+        it.push_back({x.raw + src, D + dst, out, in, 0});
+        if (x.packed(out, in)) it.push_back({x.raw + src, x.w.pack_t + src, out, in, 1});
     };
-    auto flush = [&]() -> int {
-        int r = n ? tsd_pack_linear_batch(n, W, D, od, id, tr, (void*)x.st) : TSD_OK;
-        n = 0;
-        return r;
-    };
-    add(x.R.emlp_w1, H, H);
-    add(x.R.ecat_w0, H, 2 * H);
-    add(x.R.ecat_w1, H, H);
-    add(x.R.out_w0, H, 2 * H);
-    add(x.R.out_w1, H / 2, H);
-    TSD_TRY(flush());
-    for (int l = 0; l < x.L; ++l) {
-        const size_t o = x.R.layer0 + (size_t)l * x.R.layer_stride;
-        add(o + x.R.L_lin1_w, H, H);
-        add(o + x.R.L_lin2_w, H, H);
-        add(o + x.R.L_nn0_w, H, H);
-        add(o + x.R.L_nn2_w, H, H);
-        add(o + x.R.L_lin_w, H, H);
-        if (n + 10 > 48) TSD_TRY(flush());
+    cp(I.bond_emb, R.bond_emb, 100 * H);
+    cp(I.emlp_w0, R.emlp_w0, H);
+    cp(I.emlp_b0, R.emlp_b0, H);
+    pk(I.emlp_w1, R.emlp_w1, H, H);
+    cp(I.emlp_b1, R.emlp_b1, H);
+    pk(I.ecat_w0, R.ecat_w0, H, 2 * H);
+    cp(I.ecat_b0, R.ecat_b0, H);
+    pk(I.ecat_w1, R.ecat_w1, H, H);
+    cp(I.ecat_b1, R.ecat_b1, H);
+    for (int l = 0; l < L; ++l) {
+        const size_t i = I.layer0 + (size_t)l * I.layer_stride, r = R.layer0 + (size_t)l * R.layer_stride;
+        pk(i + I.L_lin1_w, r + R.L_lin1_w, H, H);
+        pk(i + I.L_lin2_w, r + R.L_lin2_w, H, H);
+        cp(i + I.L_lin2_b, r + R.L_lin2_b, H);
+        pk(i + I.L_nn0_w, r + R.L_nn0_w, H, H);
+        cp(i + I.L_nn0_b, r + R.L_nn0_b, H);
+        pk(i + I.L_nn2_w, r + R.L_nn2_w, H, H);
+        cp(i + I.L_nn2_b, r + R.L_nn2_b, H);
+        pk(i + I.L_lin_w, r + R.L_lin_w, H, H);
+        cp(i + I.L_lin_b, r + R.L_lin_b, H);
     }
-    return flush();
-}
-
-int embed_fwd(const Ctx& x, const tsd_edges& lst, int E, const EmbedSave& s) {
-    if (E == 0) return TSD_OK;
-    const int H = x.H;
-    const int64_t n = (int64_t)E * H;
-    // mlp(d) = Linear(1,H) -> swish -> Linear(H,H)                                        edge.py:50-52,66
-    TSD_TRY(x.lin(E, 1, H, lst.dist, x.R.emlp_w0, (long)x.R.emlp_b0, nullptr, s.l0, 0, s.s0));
-    TSD_TRY(x.lin(E, H, H, s.s0, x.R.emlp_w1, (long)x.R.emlp_b1, nullptr, s.e));
-    hipLaunchKernelGGL(emb_mul2_fwd_kernel, dim3(nblk(n)), dim3(256), 0, x.st, E, H, s.e, x.raw + x.R.bond_emb,
-                       lst.type_r, lst.type_p, s.c);
-    // edge_cat = Linear(2H,H) -> swish -> Linear(H,H)                              condensenc.py:105-115,173-175
-    TSD_TRY(x.lin(E, 2 * H, H, s.c, x.R.ecat_w0, (long)x.R.ecat_b0, nullptr, s.c0, 0, s.s1));
-    TSD_TRY(x.lin(E, H, H, s.s1, x.R.ecat_w1, (long)x.R.ecat_b1, nullptr, s.ea));
-    TSD_LAUNCH_CHECK("embed_fwd");
-    return TSD_OK;
+    pk(I.out_w0, R.out_w0, H, 2 * H);
+    cp(I.out_b0, R.out_b0, H);
+    pk(I.out_w1, R.out_w1, H / 2, H);
+    cp(I.out_b1, R.out_b1, H / 2);
+    cp(I.out_w2, R.out_w2, H / 2);
+    cp(I.out_b2, R.out_b2, 1);
+    return launch_pack_items((int)it.size(), it.data(), x.st);
 }
 
 // d_ea [E,H] -> parameter gradients (eA / eB are its temporaries: d_ea must not alias them)
@@ -421,6 +386,11 @@ int embed_bwd(const Ctx& x, const tsd_edges& lst, int E, const EmbedSave& s, con
     return TSD_OK;
 }
 
+// the save arrays of the edge embedding from row `row` on
+EmbedSave embed_rows(const EmbedSave& s, size_t row, size_t H) {
+    return EmbedSave{s.l0 + row * H, s.s0 + row * H, s.e + row * H, s.c + row * 2 * H, s.c0 + row * H, s.s1 + row * H};
+}
+
 int make_ctx(Ctx& x, const tsd_model_cfg* cfg, const tsd_batch* b, const float* raw, float* ws, size_t ws_floats,
              const int32_t* counts_host, hipStream_t st) {
     TSD_REQUIRE(cfg && b && raw && ws && counts_host, "null pointer");
@@ -435,9 +405,13 @@ int make_ctx(Ctx& x, const tsd_model_cfg* cfg, const tsd_batch* b, const float* 
     x.H = cfg->hidden;
     x.L = cfg->num_convs;
     x.F = cfg->feat_dim;
+    x.PU = b->num_pairs / 2;
     x.Eu = counts_host[0];
     x.Eo = counts_host[1];
-    x.w = carve(*cfg, x.N, (size_t)x.Eu, (size_t)x.Eo, ws);
+    x.Ed = counts_host[3];
+    TSD_REQUIRE(x.Eu >= 0 && x.Eu <= x.PU && x.Eo >= 0 && x.Eo <= x.PU && x.Ed >= 0 && x.Ed <= x.PU,
+                "edge counts (%d, %d, %d) outside the capacity %d", x.Eu, x.Eo, x.Ed, x.PU);
+    x.w = carve(*cfg, x.N, (size_t)x.PU, ws);
     TSD_REQUIRE(x.w.total <= ws_floats, "training workspace too small: %zu < %zu floats", ws_floats, x.w.total);
     return TSD_OK;
 }
@@ -453,7 +427,7 @@ size_t tsd_train_raw_floats(const tsd_model_cfg* cfg) { return cfg ? raw_layout(
 
 size_t tsd_train_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs) {
     if (!cfg) return 0;
-    return carve(*cfg, num_nodes, (size_t)num_pairs / 2, (size_t)num_pairs / 2, nullptr).total;
+    return carve(*cfg, num_nodes, (size_t)num_pairs / 2, nullptr).total;
 }
 
 int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* raw, const int64_t* atom_type,
@@ -466,53 +440,47 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
     const tsd_geometry& g = batch->geo;
     TSD_TRY(launch_geometry(*cfg, batch->num_nodes, batch->num_graphs, batch->num_pairs, pos, batch->graph_ptr,
                             batch->node_graph, batch->pair_ptr, batch->pair_code, g, st));
-    // the edge counts size every launch below: the one host sync of the step
+    // the edge counts size the launches of the backward pass: the one host sync of the step
     TSD_HIP(hipMemcpyAsync(&counts_host[0], g.enc_u.count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     TSD_HIP(hipMemcpyAsync(&counts_host[1], g.out_u.count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TSD_HIP(hipMemcpyAsync(&counts_host[3], g.diff_u.count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     counts_host[2] = 0;
     if (topo_status) TSD_HIP(hipMemcpyAsync(&counts_host[2], topo_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     TSD_HIP(hipStreamSynchronize(st));
     if (counts_host[2] & (TSD_STATUS_BAD_BOND | TSD_STATUS_ASYMMETRIC)) return TSD_OK;  // the caller raises
     Ctx x;
     TSD_TRY(make_ctx(x, cfg, batch, raw, workspace, workspace_floats, counts_host, st));
-    const int N = x.N, H = x.H, L = x.L, F = x.F, Eu = x.Eu, Eo = x.Eo;
+    const int N = x.N, H = x.H, L = x.L, F = x.F, PU = x.PU, Eu = x.Eu, Eo = x.Eo, Ed = x.Ed;
     const Work& w = x.w;
     if (N == 0) return TSD_OK;
     TSD_TRY(pack_all(x));
+    const float* W = w.pack_inf;
     // node embedding
     hipLaunchKernelGGL(feats_to_float_kernel, dim3(nblk((int64_t)N * F)), dim3(256), 0, st, (int64_t)N * F, r_feat, p_feat,
                        w.featR, w.featP);
     hipLaunchKernelGGL(node_embed_raw_kernel, dim3(nblk((int64_t)N * (H / 2))), dim3(256), 0, st, N, H / 2, F,
                        raw + x.R.atom_emb, raw + x.R.atom_feat, atom_type, w.featR, w.featP, w.h);
     TSD_LAUNCH_CHECK("node_embed_raw");
-    TSD_TRY(embed_fwd(x, g.enc_u, Eu, w.emb_enc));
-    TSD_TRY(embed_fwd(x, g.out_u, Eo, w.emb_out));
-    const size_t NH = (size_t)N * H, EH = (size_t)Eu * H;
-    for (int l = 0; l < L; ++l) {  // schnet.py:88-128, 223-224
-        const size_t o = x.R.layer0 + (size_t)l * x.R.layer_stride;
-        float *f0 = w.f0 + l * EH, *fs = w.fs + l * EH, *Wf = w.Wf + l * EH;
-        float *hl = w.h + l * NH, *hn = w.h + (l + 1) * NH;
-        float *x1 = w.x1 + l * NH, *agg = w.agg + l * NH, *x2 = w.x2 + l * NH, *xs = w.xs + l * NH;
-        if (Eu > 0) {
-            TSD_TRY(x.lin(Eu, H, H, w.emb_enc.ea, o + x.R.L_nn0_w, (long)(o + x.R.L_nn0_b), nullptr, f0, 1, fs));
-            TSD_TRY(x.lin(Eu, H, H, fs, o + x.R.L_nn2_w, (long)(o + x.R.L_nn2_b), nullptr, Wf, -1, nullptr,
-                          g.enc_u.dist));  // W = nn(edge_attr) * C
-        }
-        TSD_TRY(x.lin(N, H, H, hl, o + x.R.L_lin1_w, -1, nullptr, x1));
-        TSD_TRY(tsd_cfconv_aggregate(H, N, g.enc.row_ptr, g.enc.dst, g.enc.umap, Wf, x1, agg, stream));
-        TSD_TRY(x.lin(N, H, H, agg, o + x.R.L_lin2_w, (long)(o + x.R.L_lin2_b), nullptr, x2, 1, xs));
-        TSD_TRY(x.lin(N, H, H, xs, o + x.R.L_lin_w, (long)(o + x.R.L_lin_b), hl, hn));  // h + lin(ssp(.))
+    const size_t NH = (size_t)N * H, CH = (size_t)PU * H;  // strides of the per-block node / edge arrays
+    // edge attributes of every undirected pair once: the enc_u rows, then the out edges that differ (geo.attr_row)
+    TSD_TRY(launch_edge_embed2(*cfg, W, Eu, g.enc_u, w.ea, Ed, g.diff_u, w.ea + CH, 1, 0, st, nullptr, &w.emb, PU));
+    // one launch per interaction block: node chain of block l || filter GEMMs of block l+1   schnet.py:88-128, 223-224
+    const int tpl = filter_tiles_per_layer(PU);
+    const FilterSave fsv{w.f0, w.fs};
+    for (int j = 0; j <= L; ++j) {
+        const int layer = j - 1;  // -1: x1_0 = lin1_0(h_0) only
+        const int lc = layer < 0 ? 0 : layer;
+        const NodeSave nsv{w.agg + lc * NH, w.x2 + lc * NH, w.xs + lc * NH};
+        TSD_TRY(launch_layer_combo(*cfg, W, layer, N, g.enc, w.Wf + lc * CH, w.x1 + lc * NH, w.h + lc * NH,
+                                   w.h + (size_t)(layer + 1) * NH, layer + 1 < L ? w.x1 + (size_t)(layer + 1) * NH : w.nA,
+                                   0, j * tpl, j < L ? tpl : 0, PU, g.enc_u, w.ea, w.Wf, L, 1, 0, 0, 0, st, nullptr, 0,
+                                   &fsv, &nsv));
     }
     // pair MLP on [h_i * h_j , edge_attr_out]                                       common.py:226-229
     if (Eo > 0) {
-        TSD_TRY(tsd_pair_product_fwd(H, Eo, g.out_u, w.h + (size_t)L * NH, w.eA, stream));
-        hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.eA, H, w.hp,
-                           2 * H);
-        hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.emb_out.ea, H,
-                           w.hp + H, 2 * H);
-        TSD_TRY(x.lin(Eo, 2 * H, H, w.hp, x.R.out_w0, (long)x.R.out_b0, nullptr, w.g0, 0, w.gs0));
-        TSD_TRY(x.lin(Eo, H, H / 2, w.gs0, x.R.out_w1, (long)x.R.out_b1, nullptr, w.g1, 0, w.gs1));
-        TSD_TRY(x.lin(Eo, H / 2, 1, w.gs1, x.R.out_w2, (long)x.R.out_b2, nullptr, w.s_u));
+        const PairSave psv{w.hp, w.g0, w.gs0, w.g1, w.gs1};
+        TSD_TRY(launch_pair_output(*cfg, W, Eo, g.out_u, w.h + (size_t)L * NH, w.ea, g.attr_row, w.s_u, 1, 0, 0, 0, st,
+                                   nullptr, 0, &psv));
         hipLaunchKernelGGL(d_target_kernel, dim3(nblk(Eo)), dim3(256), 0, st, g.out_u, pos0, batch->node_graph, a_graph,
                            w.d_target);
     }
@@ -533,31 +501,31 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
     TSD_TRY(make_ctx(x, cfg, batch, raw, workspace, workspace_floats, counts_host, st));
     x.grad = grad;
     const tsd_geometry& g = batch->geo;
-    const int N = x.N, H = x.H, L = x.L, F = x.F, Eu = x.Eu, Eo = x.Eo;
+    const int N = x.N, H = x.H, L = x.L, F = x.F, PU = x.PU, Eu = x.Eu, Eo = x.Eo, Ed = x.Ed;
     const Work& w = x.w;
     TSD_HIP(hipMemsetAsync(grad, 0, x.R.total * sizeof(float), st));
     if (N == 0) return TSD_OK;
-    const size_t NH = (size_t)N * H, EH = (size_t)Eu * H;
+    const size_t NH = (size_t)N * H, EH = (size_t)PU * H;  // strides of the per-block node / edge arrays
     // loss -> node_eq -> s_u
     hipLaunchKernelGGL(loss_bwd_kernel, dim3(nblk(3 * (int64_t)N)), dim3(256), 0, st, N, w.node_eq, w.pos_target, dloss,
                        w.nA);
     TSD_HIP(hipMemsetAsync(w.dh, 0, NH * sizeof(float), st));
+    // attribute gradient of every embedded pair: rows [0, Eu) enc_u edges, rows [PU, PU + Ed) the out edges' own
+    if (Eu > 0) TSD_HIP(hipMemsetAsync(w.d_ea, 0, (size_t)Eu * H * sizeof(float), st));
+    if (Ed > 0) TSD_HIP(hipMemsetAsync(w.d_ea + EH, 0, (size_t)Ed * H * sizeof(float), st));
     if (Eo > 0) {
         float* ds = w.d_target;  // [Eo] (d_target itself is no longer needed)
         TSD_TRY(tsd_eq_und_bwd(Eo, g.out_u, pos, w.nA, ds, stream));
         TSD_TRY(x.lin_bwd(Eo, H / 2, 1, w.gs1, x.R.out_w2, (long)x.R.out_b2, ds, w.eB, false, 0, w.g1));   // dg1
         TSD_TRY(x.lin_bwd(Eo, H, H / 2, w.gs0, x.R.out_w1, (long)x.R.out_b1, w.eB, w.eA, false, 0, w.g0)); // dg0
         TSD_TRY(x.lin_bwd(Eo, 2 * H, H, w.hp, x.R.out_w0, (long)x.R.out_b0, w.eA, w.eB, false));           // dhp [Eo,2H]
-        // dp (left half) -> dh ; d edge_attr_out (right half) -> embedding of the out list
-        // (embed_bwd uses eA / eB as temporaries: d edge_attr_out is parked in hp, which is free by now)
+        // dp (left half) -> dh ; d edge_attr_out (right half) -> the out edges' rows of the attribute gradient
         float* dp = w.eA;
         hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.eB, 2 * H, dp, H);
-        hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.eB + H, 2 * H,
-                           w.hp, H);
+        hipLaunchKernelGGL(scatter_rows_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.eB + H,
+                           2 * H, g.attr_row, w.d_ea);
         TSD_TRY(tsd_pair_product_bwd(N, H, g.out, dp, w.h + (size_t)L * NH, w.dh, stream));
-        TSD_TRY(embed_bwd(x, g.out_u, Eo, w.emb_out, w.hp));
     }
-    if (Eu > 0) TSD_HIP(hipMemsetAsync(w.d_ea, 0, EH * sizeof(float), st));
     for (int l = L - 1; l >= 0; --l) {
         const size_t o = x.R.layer0 + (size_t)l * x.R.layer_stride;
         float *f0 = w.f0 + l * EH, *fs = w.fs + l * EH, *Wf = w.Wf + l * EH;
@@ -572,11 +540,12 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
             float* dWf = w.eA;
             TSD_TRY(launch_aggregate_bwd_filter(H, Eu, g.enc_u, w.nA, x1, dWf, 1, cfg->conv_cutoff, cfg->smooth_conv, st));
             TSD_TRY(x.lin_bwd(Eu, H, H, fs, o + x.R.L_nn2_w, (long)(o + x.R.L_nn2_b), dWf, w.eB, false, 1, f0)); // df0
-            TSD_TRY(x.lin_bwd(Eu, H, H, w.emb_enc.ea, o + x.R.L_nn0_w, (long)(o + x.R.L_nn0_b), w.eB, w.d_ea, true));
+            TSD_TRY(x.lin_bwd(Eu, H, H, w.ea, o + x.R.L_nn0_w, (long)(o + x.R.L_nn0_b), w.eB, w.d_ea, true));
         }
         TSD_TRY(x.lin_bwd(N, H, H, hl, o + x.R.L_lin1_w, -1, w.nC, w.dh, true));  // dh += dx1 W_lin1 (residual keeps dh)
     }
-    if (Eu > 0) TSD_TRY(embed_bwd(x, g.enc_u, Eu, w.emb_enc, w.d_ea));
+    if (Eu > 0) TSD_TRY(embed_bwd(x, g.enc_u, Eu, w.emb, w.d_ea));
+    if (Ed > 0) TSD_TRY(embed_bwd(x, g.diff_u, Ed, embed_rows(w.emb, (size_t)PU, (size_t)H), w.d_ea + EH));
     // node embedding: dz = dh
     hipLaunchKernelGGL(node_embed_bwd_kernel, dim3(nblk((int64_t)N * (H / 2))), dim3(256), 0, st, N, H / 2, w.dh, w.nA,
                        w.nB);

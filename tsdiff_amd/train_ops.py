@@ -504,7 +504,7 @@ class FusedTrainLoss(torch.autograd.Function):
             ws = torch.empty(max(int(nws * 1.15), 1), dtype=torch.float32, device=dev)
             model._train_ws = ws
         b = db.train_struct()
-        counts = (C.c_int32 * 3)()  # undirected edge counts of the two lists, topology status word
+        counts = (C.c_int32 * 4)()  # undirected edge counts of the two lists, topology status word, separately embedded out edges
         loss = torch.empty(db.N, 1, dtype=torch.float32, device=dev)
         pos0, pos_perturbed, a_graph = _c(pos0.float()), _c(pos_perturbed.float()), _c(a_graph.float())
         check(lib.tsd_train_forward(C.byref(cfg), C.byref(b), ptr(raw), ptr(db.atom_type), ptr(db.r_feat),
