@@ -158,28 +158,37 @@ constexpr int WG_T = 32;            // rows per tile
 constexpr int WG_LD = 128 + 4;      // LDS row stride (floats)
 // With `bias_part` != NULL the workgroups of in-block 0 also sum their dY tile's columns (the bias gradient):
 // partial [split][out], reduced together with the weight partials.
-__global__ __launch_bounds__(256) void wgrad_kernel(int rows, int in, int out, int rows_per_split,
-                                                    const float* __restrict__ dY, const float* __restrict__ X,
-                                                    float* __restrict__ part, float* __restrict__ bias_part) {
-    __shared__ __attribute__((aligned(16))) float sY[WG_T * WG_LD];
-    __shared__ __attribute__((aligned(16))) float sX[WG_T * WG_LD];
+// Workgroup = 8 waves on one 128 x 128 output block: wave (g, c) owns out rows [64 g, 64 g + 64) x in columns
+// [32 c, 32 c + 32) -- two waves per SIMD hide each other's LDS / barrier latency (the 4-wave form, one wave per
+// SIMD with a 64 x 64 block each, ran at 0.47 of the MFMA peak on the 22 k-row layers).
+// A batch of equally shaped problems shares one launch: blockIdx.z = item * S + split (WgradBatch).
+constexpr int WG_NT = 512;
+struct WgradItem {
+    const float *dY, *X;
+};
+constexpr int WG_BATCH_MAX = 24;
+struct WgradBatch {
+    WgradItem it[WG_BATCH_MAX];
+};
+__device__ __forceinline__ void wgrad_body(int rows, int in, int out, int rows_per_split, int split,
+                                           const float* __restrict__ dY, const float* __restrict__ X,
+                                           float* __restrict__ part, float* __restrict__ bias_part, float* sY,
+                                           float* sX) {
     const int in0 = blockIdx.x * 128, out0 = blockIdx.y * 128;
-    const int r_begin = blockIdx.z * rows_per_split, r_end = min(rows, r_begin + rows_per_split);
+    const int r_begin = split * rows_per_split, r_end = min(rows, r_begin + rows_per_split);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
-    const int wo = (wave >> 1) * 64, wi = (wave & 1) * 64;  // this wave's 64 x 64 sub-block
-    f32x16 acc[2][2];
+    const int wo = (wave >> 2) * 64, wi = (wave & 3) * 32;  // this wave's 64 x 32 sub-block
+    f32x16 acc[2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    // each thread stages 4 float4 of dY and 4 float4 of X per tile: (row = idx / 32, col4 = idx % 32)
-    f32x4 py[4], px[4];
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+    // each thread stages 2 float4 of dY and 2 float4 of X per tile: (row = idx / 32, col4 = idx % 32)
+    f32x4 py[2], px[2];
     auto prefetch = [&](int r0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int idx = tid + q * 256, r = idx >> 5, c4 = idx & 31;
+        for (int q = 0; q < 2; ++q) {
+            const int idx = tid + q * WG_NT, r = idx >> 5, c4 = idx & 31;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             py[q] = z;
             px[q] = z;
@@ -195,8 +204,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int rows, int in, int out, i
     for (int r0 = r_begin; r0 < r_end; r0 += WG_T) {
         __syncthreads();  // previous tile fully consumed
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int idx = tid + q * 256, r = idx >> 5, c4 = idx & 31;
+        for (int q = 0; q < 2; ++q) {
+            const int idx = tid + q * WG_NT, r = idx >> 5, c4 = idx & 31;
             *reinterpret_cast<f32x4*>(sY + r * WG_LD + c4 * 4) = py[q];
             *reinterpret_cast<f32x4*>(sX + r * WG_LD + c4 * 4) = px[q];
         }
@@ -206,36 +215,72 @@ __global__ __launch_bounds__(256) void wgrad_kernel(int rows, int in, int out, i
 #pragma unroll 8
             for (int r = 0; r < WG_T; ++r) bsum += sY[r * WG_LD + tid];
         }
-#pragma unroll 4
+#pragma unroll 8
         for (int kk = 0; kk < WG_T / 2; ++kk) {
             const int row = 2 * kk + hi;
             const float a0 = sY[row * WG_LD + wo + l31], a1 = sY[row * WG_LD + wo + 32 + l31];
-            const float b0 = sX[row * WG_LD + wi + l31], b1 = sX[row * WG_LD + wi + 32 + l31];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            const float b0 = sX[row * WG_LD + wi + l31];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1], 0, 0, 0);
         }
     }
-    float* P = part + (size_t)blockIdx.z * out * in;
+    float* P = part + (size_t)split * out * in;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = out0 + wo + a * 32 + acc_row(r, hi), i = in0 + wi + b * 32 + l31;
-                P[(size_t)o * in + i] = acc[a][b][r];
-            }
-    if (do_bias) bias_part[(size_t)blockIdx.z * out + out0 + tid] = bsum;
+        for (int r = 0; r < 16; ++r) {
+            const int o = out0 + wo + a * 32 + acc_row(r, hi), i = in0 + wi + l31;
+            P[(size_t)o * in + i] = acc[a][r];
+        }
+    if (do_bias) bias_part[(size_t)split * out + out0 + tid] = bsum;
+}
+__global__ __launch_bounds__(WG_NT) void wgrad_kernel(int rows, int in, int out, int rows_per_split,
+                                                      const float* __restrict__ dY, const float* __restrict__ X,
+                                                      float* __restrict__ part, float* __restrict__ bias_part) {
+    __shared__ __attribute__((aligned(16))) float sY[WG_T * WG_LD];
+    __shared__ __attribute__((aligned(16))) float sX[WG_T * WG_LD];
+    wgrad_body(rows, in, out, rows_per_split, blockIdx.z, dY, X, part, bias_part, sY, sX);
+}
+// item k: partials at part + k * S * out * in, bias partials at bias_part + k * S * out (NULL: none)
+__global__ __launch_bounds__(WG_NT) void wgrad_batch_kernel(int rows, int in, int out, int rows_per_split, int S,
+                                                            WgradBatch b, float* __restrict__ part,
+                                                            float* __restrict__ bias_part) {
+    __shared__ __attribute__((aligned(16))) float sY[WG_T * WG_LD];
+    __shared__ __attribute__((aligned(16))) float sX[WG_T * WG_LD];
+    const int item = blockIdx.z / S, split = blockIdx.z - item * S;
+    wgrad_body(rows, in, out, rows_per_split, split, b.it[item].dY, b.it[item].X, part + (size_t)item * S * out * in,
+               bias_part ? bias_part + (size_t)item * S * out : nullptr, sY, sX);
 }
 // sums the S split partials in a fixed order: workgroup = 64 consecutive outputs x 4 split quarters
 // (wave q adds splits [q S/4, (q+1) S/4) in order, then ((q0 + q1) + (q2 + q3))).  The weight partials
 // [S][nW] and the bias partials [S][nB] (nB may be 0) are reduced by the same launch.
+struct WgradOut {
+    float *dW, *db;  // db NULL: no bias
+};
+struct WgradOutBatch {
+    WgradOut it[WG_BATCH_MAX];
+};
+__device__ __forceinline__ void wgrad_reduce_body(int64_t nW, int nB, int S, const float* __restrict__ part,
+                                                  const float* __restrict__ bias_part, float* __restrict__ dW,
+                                                  float* __restrict__ db, int accumulate);
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(int64_t nW, int nB, int S,
+                                                                 const float* __restrict__ part,
+                                                                 const float* __restrict__ bias_part,
+                                                                 WgradOutBatch o, int accumulate) {
+    const int k = blockIdx.y;
+    const bool hb = o.it[k].db != nullptr;
+    wgrad_reduce_body(nW, hb ? nB : 0, S, part + (size_t)k * S * nW, bias_part + (size_t)k * S * nB, o.it[k].dW,
+                      o.it[k].db, accumulate);
+}
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int64_t nW, int nB, int S, const float* __restrict__ part,
                                                            const float* __restrict__ bias_part,
                                                            float* __restrict__ dW, float* __restrict__ db,
                                                            int accumulate) {
+    wgrad_reduce_body(nW, nB, S, part, bias_part, dW, db, accumulate);
+}
+__device__ __forceinline__ void wgrad_reduce_body(int64_t nW, int nB, int S, const float* __restrict__ part,
+                                                  const float* __restrict__ bias_part, float* __restrict__ dW,
+                                                  float* __restrict__ db, int accumulate) {
     __shared__ float sm[4][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
@@ -729,7 +774,7 @@ int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, c
     const int accW = (flags & 2) ? 1 : 0;
     if (dX && rows > 0) {  // dX = dY W
         epi.bias = nullptr;
-        epi.R = (flags & 1) ? dX : nullptr;
+        if (!(flags & 4)) epi.R = (flags & 1) ? dX : nullptr;
         if (mfma_shape(out, in) && (Wp_t || (scratch && scratch_floats >= off_part))) {
             if (!Wp_t) {
                 const int n = in * out;
@@ -755,7 +800,7 @@ int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, c
             const int per = ((rows + S - 1) / S + WG_T - 1) / WG_T * WG_T;
             float* part = scratch + off_part;
             float* bpart = db ? scratch : nullptr;  // [S][out], S <= 64
-            hipLaunchKernelGGL(wgrad_kernel, dim3(in / 128, out / 128, S), dim3(256), 0, st, rows, in, out, per, dY, X,
+            hipLaunchKernelGGL(wgrad_kernel, dim3(in / 128, out / 128, S), dim3(WG_NT), 0, st, rows, in, out, per, dY, X,
                                part, bpart);
             const int64_t n = (int64_t)out * in;
             const int nb = db ? out : 0;
@@ -790,6 +835,37 @@ int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, c
         hipLaunchKernelGGL(colsum_stage2_kernel, dim3((out + 255) / 256), dim3(256), 0, st, out, scratch, db, accW);
         TSD_LAUNCH_CHECK("colsum");
     }
+    return TSD_OK;
+}
+
+// dW_k (+)= dY_k^T X_k (and db_k (+)= column sums of dY_k where db_k != NULL) for n equally shaped problems in two
+// launches; `part` holds n * S * (out * in + out) floats, S = wgrad_batch_splits(rows).
+int wgrad_batch_splits(int rows) { return rows >= 16384 ? 16 : 8; }
+size_t wgrad_batch_scratch_floats(int n, int rows, int in, int out) {
+    return (size_t)n * wgrad_batch_splits(rows) * ((size_t)out * in + out);
+}
+int launch_wgrad_batch(int n, int rows, int in, int out, const float* const* dY, const float* const* X, float* const* dW,
+                       float* const* db, int accumulate, float* part, hipStream_t st) {
+    if (n == 0) return TSD_OK;
+    TSD_REQUIRE(out % 128 == 0 && in % 128 == 0 && rows > 0, "wgrad batch: shape %d x %d, %d rows", out, in, rows);
+    const int S = wgrad_batch_splits(rows);
+    const int per = ((rows + S - 1) / S + WG_T - 1) / WG_T * WG_T;
+    const int64_t nW = (int64_t)out * in;
+    for (int base = 0; base < n; base += WG_BATCH_MAX) {
+        const int m = n - base < WG_BATCH_MAX ? n - base : WG_BATCH_MAX;
+        WgradBatch b;
+        WgradOutBatch o;
+        for (int k = 0; k < m; ++k) {
+            b.it[k] = WgradItem{dY[base + k], X[base + k]};
+            o.it[k] = WgradOut{dW[base + k], db ? db[base + k] : nullptr};
+        }
+        float* bpart = part + (size_t)m * S * nW;
+        hipLaunchKernelGGL(wgrad_batch_kernel, dim3(in / 128, out / 128, m * S), dim3(WG_NT), 0, st, rows, in, out, per,
+                           S, b, part, bpart);
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)((nW + out + 63) / 64), m), dim3(256), 0, st, nW,
+                           out, S, part, bpart, o, accumulate);
+    }
+    TSD_LAUNCH_CHECK("wgrad_batch");
     return TSD_OK;
 }
 

@@ -42,11 +42,16 @@ __device__ __forceinline__ void epi_store(const LinEpi& e, float v, int row, int
 
 int linear_fwd_impl(int rows, int in, int out, const float* X, const float* W, const float* Wp, const LinEpi& epi,
                     float* Y, float* scratch, size_t scratch_floats, hipStream_t st);
-// flags: 1 = dX += (sets epi.R = dX), 2 = dW / db +=.  `epi` applies to dX (bias is ignored).
+// flags: 1 = dX += (sets epi.R = dX), 2 = dW / db +=, 4 = epi.R is the caller's (dX = dY W + R, R != dX).
+// `epi` applies to dX (bias is ignored).  dW == NULL / db == NULL: that gradient is not computed.
 int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, const float* Wp_t, const float* dY,
                     float* dX, float* dW, float* db, int flags, LinEpi epi, float* scratch, size_t scratch_floats,
                     hipStream_t st);
 size_t linear_scratch_floats(int in, int out);
+int wgrad_batch_splits(int rows);
+size_t wgrad_batch_scratch_floats(int n, int rows, int in, int out);
+int launch_wgrad_batch(int n, int rows, int in, int out, const float* const* dY, const float* const* X, float* const* dW,
+                       float* const* db, int accumulate, float* part, hipStream_t st);
 
 // the optimizer rewrites every weight every step: all layout conversions of a step in a few launches.
 // mode 0: W [out,in] -> forward MFMA layout [in/4][out][in%4]; 1: dgrad layout (W^T); 2: copy of `out` floats

@@ -94,6 +94,8 @@ struct Work {
     float *eA, *eB;                // [PU, 2H] each
     float *d_ea;                   // [2 PU, H], rows as `ea`
     float *nA, *nB, *nC, *dh;      // [N, H] each
+    float *dhs, *dx2s, *dx1s;      // [(L+1), N, H], [L, N, H], [L, N, H]: the node-level dY of every block (batched wgrad)
+    float* wpart;                  // split partials of the batched node wgrads
     size_t total;
 };
 
@@ -141,6 +143,10 @@ Work carve(const tsd_model_cfg& c, int N, size_t PU, float* base) {
     w.nB = take((size_t)N * H);
     w.nC = take((size_t)N * H);
     w.dh = take((size_t)N * H);
+    w.dhs = take((L + 1) * N * H);
+    w.dx2s = take(L * N * H);
+    w.dx1s = take(L * N * H);
+    w.wpart = take(N > 0 && H % 128 == 0 ? wgrad_batch_scratch_floats((int)(3 * L), N, (int)H, (int)H) : 0);
     w.total = o;
     return w;
 }
@@ -313,6 +319,19 @@ struct Ctx {
         }
         return linear_bwd_impl(rows, in, out, X, raw + w_off, Wpt, dY, dX, grad + w_off, b_off >= 0 ? grad + b_off : nullptr,
                                2 | (accumulate_dx ? 1 : 0), e, w.scratch, w.scratch_floats, st);
+    }
+    // dX = dY W (* act'(act_pre)) (+ Rsd) only: the weight gradient of the layer is taken later, batched
+    int dgrad(int rows, int in, int out, size_t w_off, const float* dY, float* dX, const float* Rsd, int dact_kind = -1,
+              const float* act_pre = nullptr) const {
+        const float* Wpt = packed(out, in) ? w.pack_t + w_off : nullptr;
+        LinEpi e;
+        if (dact_kind >= 0) {
+            e.act_pre = act_pre;
+            e.dact_kind = dact_kind;
+        }
+        e.R = Rsd;
+        return linear_bwd_impl(rows, in, out, nullptr, raw + w_off, Wpt, dY, dX, nullptr, nullptr, 4, e, w.scratch,
+                               w.scratch_floats, st);
     }
 };
 
@@ -526,31 +545,61 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
                            2 * H, g.attr_row, w.d_ea);
         TSD_TRY(tsd_pair_product_bwd(N, H, g.out, dp, w.h + (size_t)L * NH, w.dh, stream));
     }
+    // The node-level layers (N rows) keep their dY per block and take their weight gradients in ONE batched launch
+    // after the loop: 3 L problems of N rows each are launch-latency bound one by one (13 + 5 us each, 21 per step).
+    const bool batch_wg = (H % 128 == 0);
+    const float* dh_cur = w.dh;  // d loss / d h_{l+1}
     for (int l = L - 1; l >= 0; --l) {
         const size_t o = x.R.layer0 + (size_t)l * x.R.layer_stride;
         float *f0 = w.f0 + l * EH, *fs = w.fs + l * EH, *Wf = w.Wf + l * EH;
         float* hl = w.h + l * NH;
         float *x1 = w.x1 + l * NH, *agg = w.agg + l * NH, *x2 = w.x2 + l * NH, *xs = w.xs + l * NH;
+        float *dx2 = batch_wg ? w.dx2s + l * NH : w.nB, *dx1 = batch_wg ? w.dx1s + l * NH : w.nC;
+        float* dh_next = batch_wg ? w.dhs + l * NH : w.dh;
         // h_{l+1} = h_l + lin(ssp(lin2(agg)))
-        TSD_TRY(x.lin_bwd(N, H, H, xs, o + x.R.L_lin_w, (long)(o + x.R.L_lin_b), w.dh, w.nB, false, 1, x2)); // dx2
-        TSD_TRY(x.lin_bwd(N, H, H, agg, o + x.R.L_lin2_w, (long)(o + x.R.L_lin2_b), w.nB, w.nA, false));     // dagg
+        if (batch_wg) {
+            TSD_TRY(x.dgrad(N, H, H, o + x.R.L_lin_w, dh_cur, dx2, nullptr, 1, x2));
+            TSD_TRY(x.dgrad(N, H, H, o + x.R.L_lin2_w, dx2, w.nA, nullptr));
+        } else {
+            TSD_TRY(x.lin_bwd(N, H, H, xs, o + x.R.L_lin_w, (long)(o + x.R.L_lin_b), dh_cur, dx2, false, 1, x2));
+            TSD_TRY(x.lin_bwd(N, H, H, agg, o + x.R.L_lin2_w, (long)(o + x.R.L_lin2_b), dx2, w.nA, false));  // dagg
+        }
         // agg = aggregate(x1, Wf): symmetric edge set and filter => the adjoint w.r.t. x1 is the same gather of dagg
-        TSD_TRY(tsd_cfconv_aggregate(H, N, g.enc.row_ptr, g.enc.dst, g.enc.umap, Wf, w.nA, w.nC, stream)); // dx1
+        TSD_TRY(tsd_cfconv_aggregate(H, N, g.enc.row_ptr, g.enc.dst, g.enc.umap, Wf, w.nA, dx1, stream));
         if (Eu > 0) {
             float* dWf = w.eA;
             TSD_TRY(launch_aggregate_bwd_filter(H, Eu, g.enc_u, w.nA, x1, dWf, 1, cfg->conv_cutoff, cfg->smooth_conv, st));
             TSD_TRY(x.lin_bwd(Eu, H, H, fs, o + x.R.L_nn2_w, (long)(o + x.R.L_nn2_b), dWf, w.eB, false, 1, f0)); // df0
             TSD_TRY(x.lin_bwd(Eu, H, H, w.ea, o + x.R.L_nn0_w, (long)(o + x.R.L_nn0_b), w.eB, w.d_ea, true));
         }
-        TSD_TRY(x.lin_bwd(N, H, H, hl, o + x.R.L_lin1_w, -1, w.nC, w.dh, true));  // dh += dx1 W_lin1 (residual keeps dh)
+        // d loss / d h_l = d loss / d h_{l+1} (residual) + dx1 W_lin1
+        if (batch_wg) {
+            TSD_TRY(x.dgrad(N, H, H, o + x.R.L_lin1_w, dx1, dh_next, dh_cur));
+            dh_cur = dh_next;
+        } else {
+            TSD_TRY(x.lin_bwd(N, H, H, hl, o + x.R.L_lin1_w, -1, dx1, w.dh, true));
+        }
     }
+    if (batch_wg) {
+        std::vector<const float*> dYs, Xs;
+        std::vector<float*> dWs, dbs;
+        for (int l = 0; l < L; ++l) {
+            const size_t o = x.R.layer0 + (size_t)l * x.R.layer_stride;
+            const float* dh_up = l == L - 1 ? w.dh : w.dhs + (size_t)(l + 1) * NH;  // d loss / d h_{l+1}
+            dYs.push_back(dh_up);              Xs.push_back(w.xs + l * NH);  dWs.push_back(grad + o + x.R.L_lin_w);  dbs.push_back(grad + o + x.R.L_lin_b);
+            dYs.push_back(w.dx2s + l * NH);    Xs.push_back(w.agg + l * NH); dWs.push_back(grad + o + x.R.L_lin2_w); dbs.push_back(grad + o + x.R.L_lin2_b);
+            dYs.push_back(w.dx1s + l * NH);    Xs.push_back(w.h + l * NH);   dWs.push_back(grad + o + x.R.L_lin1_w); dbs.push_back(nullptr);
+        }
+        TSD_TRY(launch_wgrad_batch((int)dYs.size(), N, H, H, dYs.data(), Xs.data(), dWs.data(), dbs.data(), 1, w.wpart, st));
+    }
+    const float* dz = dh_cur;  // d loss / d h_0
     if (Eu > 0) TSD_TRY(embed_bwd(x, g.enc_u, Eu, w.emb, w.d_ea));
     if (Ed > 0) TSD_TRY(embed_bwd(x, g.diff_u, Ed, embed_rows(w.emb, (size_t)PU, (size_t)H), w.d_ea + EH));
     // node embedding: dz = dh
-    hipLaunchKernelGGL(node_embed_bwd_kernel, dim3(nblk((int64_t)N * (H / 2))), dim3(256), 0, st, N, H / 2, w.dh, w.nA,
+    hipLaunchKernelGGL(node_embed_bwd_kernel, dim3(nblk((int64_t)N * (H / 2))), dim3(256), 0, st, N, H / 2, dz, w.nA,
                        w.nB);
     hipLaunchKernelGGL(atom_emb_grad_kernel, dim3(100, AE_CHUNKS), dim3(H / 2 < 256 ? H / 2 : 256), 0, st, N, H / 2,
-                       atom_type, w.dh, w.scratch);
+                       atom_type, dz, w.scratch);
     hipLaunchKernelGGL(atom_emb_grad_reduce_kernel, dim3(nblk(100 * (H / 2))), dim3(256), 0, st, 100 * (H / 2), w.scratch,
                        grad + x.R.atom_emb);
     TSD_TRY(linear_bwd_impl(N, F, H / 2, w.featR, raw + x.R.atom_feat, nullptr, w.nA, nullptr, grad + x.R.atom_feat,
