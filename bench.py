@@ -245,7 +245,10 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist):
         batches.append(g)
     N = int(sum(g["pos"].shape[0] for g in batches) / len(batches))
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.95, 0.999))
+    from tsdiff_amd import optim
+    from types import SimpleNamespace
+    # configs/train_config.yml's optimizer block through the mirror of utils.common.get_optimizer (train.py:103)
+    opt = optim.get_optimizer(SimpleNamespace(type="adam", lr=5e-4, weight_decay=0.0, beta1=0.95, beta2=0.999), model)
     counter = [0]
 
     def step():
@@ -257,7 +260,7 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist):
         loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
                               g["batch"], g["num_nodes_per_graph"], graphs)
         mean = dp_backward(model, loss)
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 3000.0)
+        optim.clip_grad_norm_(model.parameters(), 3000.0)
         opt.step()
         return mean
     for _ in range(warmup):

@@ -1202,3 +1202,67 @@ def test_dp_backward_flat_gradient_path_on_the_real_model(dev):
     norm = float(torch.nn.utils.clip_grad_norm_(model.parameters(), 1e9))
     assert abs(norm - ref_norm) <= 1e-5 * ref_norm
     torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.95, 0.999)).step()   # train.py:144-145 on the reduced gradient
+
+
+def test_flat_optimizer_step_equals_torch_adam(dev, tmp_path):
+    """tsdiff_amd.optim (train.py:103,144-145 on the flat vectors): clip_grad_norm_ + Adam over the fused step's flat
+    gradient against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam on an identical model, three steps (the clip
+    active in one of them), weight decay on; then the optimizer checkpoints cross-load in both directions and the
+    cached inference weights follow the updated parameters"""
+    from tsdiff_amd import optim
+    d, meta = load_golden("loss_synth_b4_small")
+    g = to_dev(batch_inputs(d), dev)
+    kw = dict(_time_step=torch.from_numpy(d["time_step"]).to(dev), _pos_noise=torch.from_numpy(d["pos_noise"]).to(dev))
+    args = (g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"],
+            g["num_nodes_per_graph"], g["num_graphs"])
+    ref, mod = make_model(meta["cfg"], meta["seed"], dev), make_model(meta["cfg"], meta["seed"], dev)
+    ref.train(), mod.train()
+    o_ref = torch.optim.Adam(ref.parameters(), lr=5e-4, betas=(0.95, 0.999), weight_decay=1e-3)
+    flat = optim.flatten_parameters(mod)
+    assert optim.flatten_parameters(mod) is flat and flat.numel() == sum(p.numel() for p in mod.raw_params())
+    assert set(mod.state_dict()) == set(ref.state_dict())
+    o_mod = optim.Adam(mod.parameters(), lr=5e-4, betas=(0.95, 0.999), weight_decay=1e-3)
+    with torch.no_grad():
+        inv0 = mod(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"],
+                   torch.zeros(g["num_graphs"], dtype=torch.long, device=dev))[0].clone()
+    for it, max_norm in enumerate((1e9, 0.05, 1e9)):
+        norms = []
+        for m, o, clip in ((ref, o_ref, torch.nn.utils.clip_grad_norm_), (mod, o_mod, optim.clip_grad_norm_)):
+            o.zero_grad()
+            m.get_loss(*args, **kw).mean().backward()
+            norms.append(float(clip(m.parameters(), max_norm)))
+            o.step()
+        assert abs(norms[0] - norms[1]) <= 2e-6 * norms[0], norms
+        assert norms[0] > 0.05  # the second step really clips
+        for (k, a), (_, b) in zip(ref.named_parameters(), mod.named_parameters()):
+            assert_close(b.detach().cpu().numpy(), a.detach().cpu().numpy(), 2e-5, f"step {it} param {k}")
+    assert mod.raw_params()[0].data_ptr() == flat.data_ptr() and mod._flat_grad.numel() == flat.numel()
+    assert o_mod._flat_state and o_mod._flat_state[0][1].numel() == flat.numel()  # the one-launch path ran
+    with torch.no_grad():  # the inference path sees the updated weights (packed arena rebuilt)
+        inv1 = mod(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"],
+                   torch.zeros(g["num_graphs"], dtype=torch.long, device=dev))[0]
+        invr = ref(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"],
+                   torch.zeros(g["num_graphs"], dtype=torch.long, device=dev))[0]
+    assert not torch.equal(inv0, inv1)
+    assert_close(inv1.cpu().numpy(), invr.cpu().numpy(), 2e-5, "edge_inv after three optimizer steps")
+    # checkpoints: ours -> torch.optim.Adam and back (train.py:116,225)
+    sd = o_mod.state_dict()
+    torch.save(sd, tmp_path / "opt.pt")
+    o_t = torch.optim.Adam(ref.parameters(), lr=5e-4, betas=(0.95, 0.999), weight_decay=1e-3)
+    o_t.load_state_dict(torch.load(tmp_path / "opt.pt", weights_only=False))
+    st_t, st_r = o_t.state_dict()["state"], o_ref.state_dict()["state"]
+    assert set(st_t) == set(st_r) and len(st_t) >= 30
+    for k in st_r:
+        assert float(st_t[k]["step"]) == float(st_r[k]["step"]) == 3.0
+        assert_close(st_t[k]["exp_avg"].cpu().numpy(), st_r[k]["exp_avg"].cpu().numpy(), 2e-5, f"exp_avg {k}")
+        assert_close(st_t[k]["exp_avg_sq"].cpu().numpy(), st_r[k]["exp_avg_sq"].cpu().numpy(), 2e-5, f"exp_avg_sq {k}")
+    o_new = optim.Adam(mod.parameters(), lr=5e-4, betas=(0.95, 0.999), weight_decay=1e-3)
+    import copy
+    o_new.load_state_dict(copy.deepcopy(o_ref.state_dict()))  # (load_state_dict keeps references to same-device tensors)
+    for m, o in ((ref, o_ref), (mod, o_new)):
+        o.zero_grad()
+        m.get_loss(*args, **kw).mean().backward()
+        o.step()
+    for (k, a), (_, b) in zip(ref.named_parameters(), mod.named_parameters()):
+        assert_close(b.detach().cpu().numpy(), a.detach().cpu().numpy(), 3e-5, f"resumed step param {k}")
+    assert float(next(iter(o_new.state.values()))["step"]) == 4.0

@@ -1,0 +1,62 @@
+"""CPU: tsdiff_amd.optim's fallback path (parameters / gradients that are not flat) is torch.optim.Adam and
+torch.nn.utils.clip_grad_norm_ themselves; the flat-layout detection; get_optimizer mirrors utils/common.py:58-70."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from tsdiff_amd import optim
+
+
+def _net(seed):
+    torch.manual_seed(seed)
+    return torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3))
+
+
+def test_fallback_equals_torch_adam_and_clip():
+    a, b = _net(0), _net(0)
+    oa = torch.optim.Adam(a.parameters(), lr=1e-2, betas=(0.95, 0.999), weight_decay=1e-2)
+    ob = optim.Adam(b.parameters(), lr=1e-2, betas=(0.95, 0.999), weight_decay=1e-2)
+    x = torch.randn(11, 5)
+    for _ in range(4):
+        for m, o, clip in ((a, oa, torch.nn.utils.clip_grad_norm_), (b, ob, optim.clip_grad_norm_)):
+            o.zero_grad()
+            m(x).square().mean().backward()
+            n = clip(m.parameters(), 0.3)
+            o.step()
+        assert torch.is_tensor(n)
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.equal(p, q)
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["param_groups"][0]["lr"] == sb["param_groups"][0]["lr"] and set(sa["state"]) == set(sb["state"])
+    for k in sa["state"]:
+        assert torch.equal(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"])
+        assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"]) == 4.0
+    oa2 = torch.optim.Adam(a.parameters(), lr=1e-2, betas=(0.95, 0.999), weight_decay=1e-2)
+    oa2.load_state_dict(sb)  # our checkpoints load into torch's optimizer
+
+
+def test_flat_layout_detection():
+    flat = torch.arange(24, dtype=torch.float32)
+    views = [flat[0:6].view(2, 3), flat[6:10], flat[10:24].view(7, 2)]
+    assert optim._flat_base(views).data_ptr() == flat.data_ptr() and optim._flat_base(views).numel() == 24
+    assert optim._flat_base([views[0], views[2]]) is None          # a gap
+    assert optim._flat_base([views[1], views[0]]) is None          # out of order
+    assert [v.data_ptr() for v in optim._by_offset([views[2], views[0], views[1]])] == [v.data_ptr() for v in views]
+    assert optim._flat_base([torch.zeros(3), torch.zeros(3)]) is None
+    lay = optim._Layout([views[2], views[0], views[1]])
+    assert lay.params_flat().data_ptr() == flat.data_ptr() and lay.offsets == [0, 24, 40] and lay.n == 24
+    sub = optim._flat_base(views[1:])                               # a suffix of the buffer tiles a slice of it
+    assert sub.numel() == 18 and sub.data_ptr() == flat[6:].data_ptr()
+    assert optim._flat_base([views[0].t()]) is None                 # not contiguous
+
+
+def test_get_optimizer_mirrors_the_reference():
+    net = _net(1)
+    cfg = SimpleNamespace(type="adam", lr=5e-4, weight_decay=0.0, beta1=0.95, beta2=0.999)
+    o = optim.get_optimizer(cfg, net)
+    g = o.param_groups[0]
+    assert g["lr"] == 5e-4 and g["betas"] == (0.95, 0.999) and g["weight_decay"] == 0.0 and g["eps"] == 1e-8
+    torch.optim.lr_scheduler.ReduceLROnPlateau(o, factor=0.6, patience=10, min_lr=1e-6)  # utils/common.py:73-80
+    with pytest.raises(NotImplementedError):
+        optim.get_optimizer(SimpleNamespace(type="sgd"), net)

@@ -11,7 +11,9 @@ cfg = synth.DEFAULT_MODEL_CONFIG
 model = get_model(AttrDict(cfg))
 model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(cfg, 0).items()}, strict=False)
 model = model.to(dev).train()
-opt = torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.95, 0.999))
+from types import SimpleNamespace
+from tsdiff_amd import optim
+opt = optim.get_optimizer(SimpleNamespace(type='adam', lr=5e-4, weight_decay=0.0, beta1=0.95, beta2=0.999), model)
 batches = []
 for k in range(4):
     b = synth.wb97xd3_like_batch(200, seed=2000 + k)
@@ -24,7 +26,7 @@ def step(i):
     opt.zero_grad()
     loss = model.get_loss(g['atom_type'], g['r_feat'], g['p_feat'], g['pos'], g['bond_index'], g['bond_type'], g['batch'], g['num_nodes_per_graph'], 200)
     dp_backward(model, loss)
-    torch.nn.utils.clip_grad_norm_(model.parameters(), 3000.0)
+    optim.clip_grad_norm_(model.parameters(), 3000.0)
     opt.step()
 for i in range(5): step(i)
 torch.cuda.synchronize()
@@ -32,4 +34,4 @@ pr = cProfile.Profile(); pr.enable()
 for i in range(20): step(i)
 torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats('tottime').print_stats(22)
+pstats.Stats(pr).sort_stats('tottime').print_stats(40)

@@ -154,6 +154,9 @@ SIGNATURES = {
     "tsd_train_workspace_floats": (C.c_size_t, [_CFG, C.c_int32, C.c_int32]),
     "tsd_train_forward": (C.c_int, [_CFG, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P]),
     "tsd_train_backward": (C.c_int, [_CFG, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P, _P]),
+    "tsd_grad_norm_clip": (C.c_int, [C.c_int64, _P, C.c_float, _P, _P, _P]),
+    "tsd_adam_step": (C.c_int, [C.c_int64, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                C.c_int64, _P]),
     "tsd_gine_csr_fwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_float, Edges, _P, _P, _P, _P]),
     "tsd_gine_csr_bwd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, Edges, Edges, _P, _P, _P,
                                    _P, _P, _P]),

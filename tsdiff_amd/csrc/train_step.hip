@@ -15,6 +15,8 @@
 //   per block: conv.lin1.weight, conv.lin2.{weight,bias}, conv.nn.0.{weight,bias}, conv.nn.2.{weight,bias},
 //              lin.{weight,bias},
 //   grad_dist_mlp.layers.{0 [H,2H], 1 [H/2,H], 2 [1,H/2]}.{weight,bias}, edge_cat.{0 [H,2H], 2 [H,H]}.{weight,bias}
+#include <math.h>
+
 #include <vector>
 
 #include "train_internal.hpp"
@@ -297,6 +299,56 @@ __global__ void loss_bwd_kernel(int N, const float* __restrict__ eq, const float
     deq[t] = 2.0f * (eq[t] - tg[t]) * dloss[t / 3];
 }
 
+// ---- optimizer on the flat parameter / gradient vectors (reference train.py:144-145, utils/common.py:58-68) ----
+// |g|: fixed-order two-stage sum of squares (NORM_WG workgroups, then one), no atomics
+constexpr int NORM_WG = 256;
+__global__ __launch_bounds__(256) void sumsq_stage1_kernel(int64_t n, const float* __restrict__ g, float* __restrict__ part) {
+    __shared__ float sm[256];
+    const int64_t per = ((n + NORM_WG - 1) / NORM_WG + 3) & ~int64_t(3);
+    const int64_t i0 = blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+    float s = 0.0f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) s = fmaf(g[i], g[i], s);
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sm[0];
+}
+__global__ __launch_bounds__(256) void sumsq_stage2_kernel(const float* __restrict__ part, float* __restrict__ norm) {
+    __shared__ float sm[256];
+    sm[threadIdx.x] = threadIdx.x < NORM_WG ? part[threadIdx.x] : 0.0f;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) norm[0] = sqrtf(sm[0]);
+}
+// g *= min(1, max_norm / (norm + 1e-6))                               torch.nn.utils.clip_grad_norm_
+__global__ void clip_scale_kernel(int64_t n, float* __restrict__ g, const float* __restrict__ norm, float max_norm) {
+    const float coef = fminf(max_norm / (norm[0] + 1e-6f), 1.0f);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && coef < 1.0f) g[i] *= coef;
+}
+// torch.optim.Adam (no amsgrad, minimise): g += wd p; m = lerp(m, g, 1 - b1); v = b2 v + (1 - b2) g^2;
+// p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+__global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, float lr, float b1, float b2, float eps, float wd, float step_size,
+                            float inv_sqrt_bc2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i];
+    const float pi = p[i];
+    if (wd != 0.0f) gi = fmaf(wd, pi, gi);
+    const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+}
+
 struct Ctx {
     const tsd_model_cfg* c;
     const tsd_batch* b;
@@ -447,6 +499,28 @@ size_t tsd_train_raw_floats(const tsd_model_cfg* cfg) { return cfg ? raw_layout(
 size_t tsd_train_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs) {
     if (!cfg) return 0;
     return carve(*cfg, num_nodes, (size_t)num_pairs / 2, nullptr).total;
+}
+
+int tsd_grad_norm_clip(int64_t n, float* grad, float max_norm, float* scratch, float* norm, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    TSD_REQUIRE(n >= 0 && grad && scratch && norm, "null pointer");
+    hipLaunchKernelGGL(sumsq_stage1_kernel, dim3(NORM_WG), dim3(256), 0, st, n, grad, scratch);
+    hipLaunchKernelGGL(sumsq_stage2_kernel, dim3(1), dim3(256), 0, st, scratch, norm);
+    if (max_norm > 0.0f && n > 0)
+        hipLaunchKernelGGL(clip_scale_kernel, dim3(nblk(n)), dim3(256), 0, st, n, grad, norm, max_norm);
+    TSD_LAUNCH_CHECK("grad_norm_clip");
+    return TSD_OK;
+}
+
+int tsd_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int64_t step, void* stream) {
+    TSD_REQUIRE(n >= 0 && param && grad && exp_avg && exp_avg_sq && step >= 1, "bad argument");
+    if (n == 0) return TSD_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, n, param, grad, exp_avg, exp_avg_sq,
+                       lr, beta1, beta2, eps, weight_decay, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)));
+    TSD_LAUNCH_CHECK("adam_step");
+    return TSD_OK;
 }
 
 int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* raw, const int64_t* atom_type,

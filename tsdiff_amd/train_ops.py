@@ -492,7 +492,14 @@ class FusedTrainLoss(torch.autograd.Function):
         lib = _lib.load()
         cfg = model._cfg
         dev = pos0.device
-        raw = torch.cat([p.detach().reshape(-1) for p in params])
+        # parameters re-homed in one flat buffer (optim.flatten_parameters) are handed over as they lie
+        flat = getattr(model, "_flat_param", None)
+        if flat is not None and flat.device == dev and params[0].data_ptr() == flat.data_ptr() and \
+                params[-1].data_ptr() + 4 * params[-1].numel() == flat.data_ptr() + 4 * flat.numel() and \
+                sum(p.numel() for p in params) == flat.numel():
+            raw = flat.detach()
+        else:
+            raw = torch.cat([p.detach().reshape(-1) for p in params])
         n_raw = lib.tsd_train_raw_floats(C.byref(cfg))
         if raw.numel() != n_raw:
             raise ValueError(f"parameters hold {raw.numel()} floats, the config needs {n_raw}")
