@@ -97,7 +97,8 @@ struct Work {
     float *d_ea;                   // [2 PU, H], rows as `ea`
     float *nA, *nB, *nC, *dh;      // [N, H] each
     float *dhs, *dx2s, *dx1s;      // [(L+1), N, H], [L, N, H], [L, N, H]: the node-level dY of every block (batched wgrad)
-    float* wpart;                  // split partials of the batched node wgrads
+    float* wpart;                  // split partials of the batched wgrads (node level, then filter level)
+    float *dWfs, *df0s;            // [L, PU, H] each: the filter MLP's dY of every block (batched wgrad)
     size_t total;
 };
 
@@ -148,7 +149,16 @@ Work carve(const tsd_model_cfg& c, int N, size_t PU, float* base) {
     w.dhs = take((L + 1) * N * H);
     w.dx2s = take(L * N * H);
     w.dx1s = take(L * N * H);
-    w.wpart = take(N > 0 && H % 128 == 0 ? wgrad_batch_scratch_floats((int)(3 * L), N, (int)H, (int)H) : 0);
+    {
+        size_t a = 0, b = 0;
+        if (N > 0 && H % 128 == 0) {
+            a = wgrad_batch_scratch_floats((int)(3 * L), N, (int)H, (int)H);
+            b = PU > 0 ? wgrad_batch_scratch_floats((int)(2 * L), (int)PU, (int)H, (int)H) : 0;
+        }
+        w.wpart = take(a > b ? a : b);
+    }
+    w.dWfs = take(H % 128 == 0 ? L * PU * H : 0);
+    w.df0s = take(H % 128 == 0 ? L * PU * H : 0);
     w.total = o;
     return w;
 }
@@ -641,10 +651,16 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
         // agg = aggregate(x1, Wf): symmetric edge set and filter => the adjoint w.r.t. x1 is the same gather of dagg
         TSD_TRY(tsd_cfconv_aggregate(H, N, g.enc.row_ptr, g.enc.dst, g.enc.umap, Wf, w.nA, dx1, stream));
         if (Eu > 0) {
-            float* dWf = w.eA;
+            float* dWf = batch_wg ? w.dWfs + l * EH : w.eA;
+            float* df0 = batch_wg ? w.df0s + l * EH : w.eB;
             TSD_TRY(launch_aggregate_bwd_filter(H, Eu, g.enc_u, w.nA, x1, dWf, 1, cfg->conv_cutoff, cfg->smooth_conv, st));
-            TSD_TRY(x.lin_bwd(Eu, H, H, fs, o + x.R.L_nn2_w, (long)(o + x.R.L_nn2_b), dWf, w.eB, false, 1, f0)); // df0
-            TSD_TRY(x.lin_bwd(Eu, H, H, w.ea, o + x.R.L_nn0_w, (long)(o + x.R.L_nn0_b), w.eB, w.d_ea, true));
+            if (batch_wg) {
+                TSD_TRY(x.dgrad(Eu, H, H, o + x.R.L_nn2_w, dWf, df0, nullptr, 1, f0));
+                TSD_TRY(x.dgrad(Eu, H, H, o + x.R.L_nn0_w, df0, w.d_ea, w.d_ea));
+            } else {
+                TSD_TRY(x.lin_bwd(Eu, H, H, fs, o + x.R.L_nn2_w, (long)(o + x.R.L_nn2_b), dWf, df0, false, 1, f0));
+                TSD_TRY(x.lin_bwd(Eu, H, H, w.ea, o + x.R.L_nn0_w, (long)(o + x.R.L_nn0_b), df0, w.d_ea, true));
+            }
         }
         // d loss / d h_l = d loss / d h_{l+1} (residual) + dx1 W_lin1
         if (batch_wg) {
@@ -665,6 +681,15 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
             dYs.push_back(w.dx1s + l * NH);    Xs.push_back(w.h + l * NH);   dWs.push_back(grad + o + x.R.L_lin1_w); dbs.push_back(nullptr);
         }
         TSD_TRY(launch_wgrad_batch((int)dYs.size(), N, H, H, dYs.data(), Xs.data(), dWs.data(), dbs.data(), 1, w.wpart, st));
+        if (Eu > 0) {  // the filter MLPs of all blocks: 2 L problems of Eu rows
+            dYs.clear(), Xs.clear(), dWs.clear(), dbs.clear();
+            for (int l = 0; l < L; ++l) {
+                const size_t o = x.R.layer0 + (size_t)l * x.R.layer_stride;
+                dYs.push_back(w.dWfs + l * EH); Xs.push_back(w.fs + l * EH); dWs.push_back(grad + o + x.R.L_nn2_w); dbs.push_back(grad + o + x.R.L_nn2_b);
+                dYs.push_back(w.df0s + l * EH); Xs.push_back(w.ea);          dWs.push_back(grad + o + x.R.L_nn0_w); dbs.push_back(grad + o + x.R.L_nn0_b);
+            }
+            TSD_TRY(launch_wgrad_batch((int)dYs.size(), Eu, H, H, dYs.data(), Xs.data(), dWs.data(), dbs.data(), 1, w.wpart, st));
+        }
     }
     const float* dz = dh_cur;  // d loss / d h_0
     if (Eu > 0) TSD_TRY(embed_bwd(x, g.enc_u, Eu, w.emb, w.d_ea));
