@@ -653,11 +653,11 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
         if (Eu > 0) {
             float* dWf = batch_wg ? w.dWfs + l * EH : w.eA;
             float* df0 = batch_wg ? w.df0s + l * EH : w.eB;
-            TSD_TRY(launch_aggregate_bwd_filter(H, Eu, g.enc_u, w.nA, x1, dWf, 1, cfg->conv_cutoff, cfg->smooth_conv, st));
             if (batch_wg) {
-                TSD_TRY(x.dgrad(Eu, H, H, o + x.R.L_nn2_w, dWf, df0, nullptr, 1, f0));
-                TSD_TRY(x.dgrad(Eu, H, H, o + x.R.L_nn0_w, df0, w.d_ea, w.d_ea));
+                TSD_TRY(launch_filter_bwd(H, Eu, g.enc_u, w.nA, x1, f0, w.pack_t + o + x.R.L_nn2_w, w.pack_t + o + x.R.L_nn0_w,
+                                          cfg->conv_cutoff, cfg->smooth_conv, dWf, df0, w.d_ea, st));
             } else {
+                TSD_TRY(launch_aggregate_bwd_filter(H, Eu, g.enc_u, w.nA, x1, dWf, 1, cfg->conv_cutoff, cfg->smooth_conv, st));
                 TSD_TRY(x.lin_bwd(Eu, H, H, fs, o + x.R.L_nn2_w, (long)(o + x.R.L_nn2_b), dWf, df0, false, 1, f0));
                 TSD_TRY(x.lin_bwd(Eu, H, H, w.ea, o + x.R.L_nn0_w, (long)(o + x.R.L_nn0_b), df0, w.d_ea, true));
             }
