@@ -10,7 +10,7 @@
 // Roles never communicate; the kernel boundary orders block l's filter before block l's aggregation.
 //
 // Both roles run with 2H threads = H/32 waves, 32 output columns per wave.
-#include "common.hpp"
+#include "train_internal.hpp"
 
 // Phase timeline of the per-block launch (variant builds only: tools/build_variant.sh trace "-DTSD_TRACE";
 // tools/trace_combo.py reads it).  32 u64 slots per workgroup: [0..7] s_memtime at phase boundaries (wave 0), [8..15] / [16..23] every wave's end of its
@@ -102,6 +102,103 @@ struct VRow<1> {
 };
 
 // -------------------------------------------------------------------------------------------------
+// The aggregation of one tile of TN nodes: buf[r] = sum_{e in row n0 + r} x[dst e] * Wf[umap e] (edge order, product
+// rounded then added: bit-identical to a sequential scatter_add), rows past N zero.  Shared by the node role of the
+// per-block launch (x = x1, the CFConv message; schnet.py:101-107) and by the backward node chain of the
+// training step (x = d loss / d agg: the same gather is the adjoint w.r.t. x1).  SAVE: rows also go to `save` [N,H].
+// -------------------------------------------------------------------------------------------------
+template <int H, bool SAVE>
+__device__ __forceinline__ void aggregate_tile(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ dst,
+                                               const int32_t* __restrict__ umap, const float* __restrict__ Wf,
+                                               const float* __restrict__ x, int N, int n0, float* buf,
+                                               float* __restrict__ save) {
+    constexpr int LDA = H + 4;
+    constexpr int NW = 2 * H / 64;
+    constexpr int RPW = TN / NW;  // rows aggregated per wave
+    constexpr int V = H / 64;     // channels per lane during aggregation
+    static_assert(TN % NW == 0, "");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // The RPW rows of this wave are consecutive, so their edges are ONE contiguous CSR range
+    // [rp[first], rp[first + RPW]): one load of the RPW + 1 row offsets, one coalesced load of the indices per
+    // 64 edges, then batches of U edges in flight across the row boundaries -- 2 + ceil(edges / U) dependent
+    // memory round trips per wave (the per-row form with its 4 / 1-edge tail loops took ~14: the aggregation
+    // was 22 of the 36 us of a node tile at batch 100, and the node chain is the critical path of the launch).
+    // Sums stay per row, in edge order, product rounded then added: bit-identical to a sequential scatter_add.
+    const int first = n0 + wave * RPW;
+    const int rpv = row_ptr[min(first + min(lane, RPW), N)];  // lanes 0..RPW: offsets of this wave's rows
+    const int E0 = __builtin_amdgcn_readlane(rpv, 0), E1 = __builtin_amdgcn_readlane(rpv, RPW);
+    int rr = 0;                                        // current row (wave-uniform)
+    int row_end = __builtin_amdgcn_readlane(rpv, 1);   // end of the current row's edges
+    float s[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) s[v] = 0.0f;
+    auto flush = [&]() {  // row rr is complete: its sums go to the LDS tile, the next row starts
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            buf[(wave * RPW + rr) * LDA + lane * V + v] = s[v];
+            if constexpr (SAVE) {
+                if (first + rr < N) save[(size_t)(first + rr) * H + lane * V + v] = s[v];
+            }
+            s[v] = 0.0f;
+        }
+        ++rr;
+        row_end = __builtin_amdgcn_readlane(rpv, min(rr + 1, RPW));
+    };
+    // The gather runs beside the MFMA streams of the filter tiles on the same SIMDs, and an fp32 MFMA holds the
+    // SIMD's vector issue port for its 64 cycles: every VALU instruction of this wave waits for an MFMA boundary
+    // (traced at batch 100: the aggregation takes 6 us alone on its CU, 21 us beside a filter tile -- the same
+    // with the filter's weight loads removed, 7 us with its MFMAs removed).  So the loop is written to need almost
+    // no VALU work: the edge indices come by SCALAR loads (8 consecutive edges per s_load_dwordx8), the row bases
+    // are SALU arithmetic, the row loads take an SGPR base + one lane-offset VGPR (inline asm: hipcc builds a
+    // 64-bit VGPR address per load), which leaves the products and sums.
+    constexpr int U = 8;  // edges in flight per wave (2 x 8 row loads of H floats)
+    typedef int i32x8 __attribute__((ext_vector_type(8)));
+    typedef typename VRow<V>::type vrow;
+    const unsigned lane_b = (unsigned)lane * (V * 4u);  // this lane's byte offset inside a row
+    for (int e = E0; e < E1; e += U) {
+        i32x8 jd, ud;  // dst / umap of edges e .. e+7 (the lists carry 8 spare entries: tsdiff_hip.h)
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(jd) : "s"(dst + e) : "memory");
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(ud) : "s"(umap + e) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(jd), "+s"(ud)::"memory");
+        vrow wv[U], xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // slots past this wave's range hold other rows' (or no) edges: they re-read slot 0 and are not added
+            const bool live = e + u < E1;
+            const int we = live ? ud[u] : ud[0], j = live ? jd[u] : jd[0];
+            const float* wrow = Wf + (size_t)we * H;
+            const float* xrow = x + (size_t)j * H;
+            if constexpr (V == 4) {
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wv[u]) : "v"(lane_b), "s"(wrow) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(xv[u]) : "v"(lane_b), "s"(xrow) : "memory");
+            } else if constexpr (V == 2) {
+                asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(wv[u]) : "v"(lane_b), "s"(wrow) : "memory");
+                asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(xv[u]) : "v"(lane_b), "s"(xrow) : "memory");
+            } else {
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(wv[u]) : "v"(lane_b), "s"(wrow) : "memory");
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(xv[u]) : "v"(lane_b), "s"(xrow) : "memory");
+            }
+        }
+        // one wait for the batch, naming every destination (the consumers below depend on this statement)
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]), "+v"(wv[4]), "+v"(wv[5]), "+v"(wv[6]),
+                       "+v"(wv[7]), "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]),
+                       "+v"(xv[6]), "+v"(xv[7])::"memory");
+        static_assert(U == 8, "the wait statement names 8 + 8 registers");
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (e + u < E1) {
+                while (e + u >= row_end) flush();  // (also steps over rows without edges)
+#pragma unroll
+                for (int v = 0; v < V; ++v)
+                    s[v] = __fadd_rn(s[v], __fmul_rn(VRow<V>::get(xv[u], v), VRow<V>::get(wv[u], v)));
+            }
+        }
+    }
+    while (rr < RPW) flush();  // the last row, and rows past it without edges (or past the last node): zeros
+}
+
+// -------------------------------------------------------------------------------------------------
 // node role: agg[i] = sum_{e in row i} x1[dst e] * Wf[umap e]  (edge order, product rounded then added:
 // bit-identical to a sequential scatter_add), then the three dense layers of tsd_node_update.
 // reference schnet.py:101-107 (message/aggregate), :103 (lin2), :123-127, :223-224
@@ -110,12 +207,8 @@ template <int H, bool SAVE>
 __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* smem, const NodeSave& ns TSD_TRACE_ARG) {
     constexpr int LDA = H + 4;
     constexpr int NT = 2 * H;
-    constexpr int NW = NT / 64;
     constexpr int CB16 = 2;  // 16-wide column blocks per wave
-    constexpr int RPW = TN / NW;  // rows aggregated per wave
-    constexpr int V = H / 64;     // channels per lane during aggregation
     constexpr int C4 = H / 4;
-    static_assert(TN % NW == 0, "");
     float* buf = smem;
 
     const int n0 = tile * TN;
@@ -144,84 +237,7 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
         }
     }
     if (a.mode == 0) {
-        // The RPW rows of this wave are consecutive, so their edges are ONE contiguous CSR range
-        // [rp[first], rp[first + RPW]): one load of the RPW + 1 row offsets, one coalesced load of the indices per
-        // 64 edges, then batches of U edges in flight across the row boundaries -- 2 + ceil(edges / U) dependent
-        // memory round trips per wave (the per-row form with its 4 / 1-edge tail loops took ~14: the aggregation
-        // was 22 of the 36 us of a node tile at batch 100, and the node chain is the critical path of the launch).
-        // Sums stay per row, in edge order, product rounded then added: bit-identical to a sequential scatter_add.
-        const int first = n0 + wave * RPW;
-        const int rpv = a.row_ptr[min(first + min(lane, RPW), a.N)];  // lanes 0..RPW: offsets of this wave's rows
-        const int E0 = __builtin_amdgcn_readlane(rpv, 0), E1 = __builtin_amdgcn_readlane(rpv, RPW);
-        int rr = 0;                                        // current row (wave-uniform)
-        int row_end = __builtin_amdgcn_readlane(rpv, 1);   // end of the current row's edges
-        float s[V];
-#pragma unroll
-        for (int v = 0; v < V; ++v) s[v] = 0.0f;
-        auto flush = [&]() {  // row rr is complete: its sums go to the LDS tile, the next row starts
-#pragma unroll
-            for (int v = 0; v < V; ++v) {
-                buf[(wave * RPW + rr) * LDA + lane * V + v] = s[v];
-                if constexpr (SAVE) {
-                    if (first + rr < a.N) ns.agg[(size_t)(first + rr) * H + lane * V + v] = s[v];
-                }
-                s[v] = 0.0f;
-            }
-            ++rr;
-            row_end = __builtin_amdgcn_readlane(rpv, min(rr + 1, RPW));
-        };
-        // The gather runs beside the MFMA streams of the filter tiles on the same SIMDs, and an fp32 MFMA holds the
-        // SIMD's vector issue port for its 64 cycles: every VALU instruction of this wave waits for an MFMA boundary
-        // (traced at batch 100: the aggregation takes 6 us alone on its CU, 21 us beside a filter tile -- the same
-        // with the filter's weight loads removed, 7 us with its MFMAs removed).  So the loop is written to need almost
-        // no VALU work: the edge indices come by SCALAR loads (8 consecutive edges per s_load_dwordx8), the row bases
-        // are SALU arithmetic, the row loads take an SGPR base + one lane-offset VGPR (inline asm: hipcc builds a
-        // 64-bit VGPR address per load), which leaves the products and sums.
-        constexpr int U = 8;  // edges in flight per wave (2 x 8 row loads of H floats)
-        typedef int i32x8 __attribute__((ext_vector_type(8)));
-        typedef typename VRow<V>::type vrow;
-        const unsigned lane_b = (unsigned)lane * (V * 4u);  // this lane's byte offset inside a row
-        for (int e = E0; e < E1; e += U) {
-            i32x8 jd, ud;  // dst / umap of edges e .. e+7 (the lists carry 8 spare entries: tsdiff_hip.h)
-            asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(jd) : "s"(a.dst + e) : "memory");
-            asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(ud) : "s"(a.umap + e) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(jd), "+s"(ud)::"memory");
-            vrow wv[U], xv[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                // slots past this wave's range hold other rows' (or no) edges: they re-read slot 0 and are not added
-                const bool live = e + u < E1;
-                const int we = live ? ud[u] : ud[0], j = live ? jd[u] : jd[0];
-                const float* wrow = a.Wf + (size_t)we * H;
-                const float* xrow = a.x1_in + (size_t)j * H;
-                if constexpr (V == 4) {
-                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wv[u]) : "v"(lane_b), "s"(wrow) : "memory");
-                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(xv[u]) : "v"(lane_b), "s"(xrow) : "memory");
-                } else if constexpr (V == 2) {
-                    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(wv[u]) : "v"(lane_b), "s"(wrow) : "memory");
-                    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(xv[u]) : "v"(lane_b), "s"(xrow) : "memory");
-                } else {
-                    asm volatile("global_load_dword %0, %1, %2" : "=v"(wv[u]) : "v"(lane_b), "s"(wrow) : "memory");
-                    asm volatile("global_load_dword %0, %1, %2" : "=v"(xv[u]) : "v"(lane_b), "s"(xrow) : "memory");
-                }
-            }
-            // one wait for the batch, naming every destination (the consumers below depend on this statement)
-            asm volatile("s_waitcnt vmcnt(0)"
-                         : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]), "+v"(wv[4]), "+v"(wv[5]), "+v"(wv[6]),
-                           "+v"(wv[7]), "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]),
-                           "+v"(xv[6]), "+v"(xv[7])::"memory");
-            static_assert(U == 8, "the wait statement names 8 + 8 registers");
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (e + u < E1) {
-                    while (e + u >= row_end) flush();  // (also steps over rows without edges)
-#pragma unroll
-                    for (int v = 0; v < V; ++v)
-                        s[v] = __fadd_rn(s[v], __fmul_rn(VRow<V>::get(xv[u], v), VRow<V>::get(wv[u], v)));
-                }
-            }
-        }
-        while (rr < RPW) flush();  // the last row, and rows past it without edges (or past the last node): zeros
+        aggregate_tile<H, SAVE>(a.row_ptr, a.dst, a.umap, a.Wf, a.x1_in, a.N, n0, buf, SAVE ? ns.agg : nullptr);
         TSD_TRACE_WAVE(16);
         __syncthreads();
         TSD_TRACE_AT(1);
@@ -431,6 +447,126 @@ __device__ __forceinline__ void pre_role(const ComboPre& q, int tile, float* sme
         const int row = acc_row(r, hi);
         if (row < nrows) q.out[(size_t)(e0 + row) * H + col] = acc[0][0][r] + b;
     }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Backward node chain of the training step between two blocks, one tile of TN nodes per workgroup -- the adjoint
+// of the node role above, same shape (one gather + three 16-row GEMMs):
+//   dx1_l  = sum_e dagg_l[dst e] * Wf_l[umap e]            (the symmetric edge set makes the adjoint the same gather)
+//   dh_l   = dh_{l+1} + dx1_l . W_lin1_l                   (residual + lin1 dgrad; schnet.py:223-224)
+//   dx2_{l-1}  = (dh_l . W_lin_{l-1}) * ssp'(x2_{l-1})
+//   dagg_{l-1} = dx2_{l-1} . W_lin2_{l-1}
+// first != 0: the chain starts at dh_l (given), no gather (the top block); last != 0: it stops at dh_0.
+// The weight gradients of the three layers read dx1, dh, dx2 later (batched); weights in the dgrad layout.
+// -------------------------------------------------------------------------------------------------
+struct NodeBwd {
+    int N, first, last;
+    const int32_t *row_ptr, *dst, *umap;
+    const float *Wf, *dagg_in;       // block l
+    const float *dh_up;              // d loss / d h_{l+1}  (first: d loss / d h_l itself)
+    const float *w_lin1_t;           // block l
+    const float *w_lin_t, *w_lin2_t; // block l-1
+    const float *x2_prev;            // block l-1 pre-activation
+    float *dx1, *dh, *dx2_prev, *dagg_prev;
+};
+template <int H>
+__global__ __launch_bounds__(2 * H) void node_bwd_kernel(NodeBwd a) {
+    constexpr int LDA = H + 4, NT = 2 * H, CB16 = 2, C4 = H / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* buf = smem;
+    const int n0 = blockIdx.x * TN;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, l15 = lane & 15;
+    const int col0 = wave * 32;
+    const int nrows = min(TN, a.N - n0);
+    f32x4 acc[CB16];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (!a.first) {
+        aggregate_tile<H, true>(a.row_ptr, a.dst, a.umap, a.Wf, a.dagg_in, a.N, n0, buf, a.dx1);
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) acc[cb] = zero4;
+        gemm_tile16<CB16, H>(buf, LDA, a.w_lin1_t, H, col0, acc);
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) {
+            const int col = col0 + cb * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = q * 4 + r;
+                float v = 0.0f;
+                if (row < nrows) {
+                    const size_t o = (size_t)(n0 + row) * H + col;
+                    v = a.dh_up[o] + acc[cb][r];
+                    a.dh[o] = v;
+                }
+                buf[row * LDA + col] = v;
+            }
+        }
+    } else {
+        for (int idx = tid; idx < TN * C4; idx += NT) {
+            const int r = idx / C4, c4 = idx % C4;
+            f32x4 v = zero4;
+            if (r < nrows) v = *reinterpret_cast<const f32x4*>(a.dh_up + (size_t)(n0 + r) * H + c4 * 4);
+            *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = v;
+        }
+    }
+    if (a.last) return;
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < CB16; ++cb) acc[cb] = zero4;
+    gemm_tile16<CB16, H>(buf, LDA, a.w_lin_t, H, col0, acc);
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < CB16; ++cb) {
+        const int col = col0 + cb * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = q * 4 + r;
+            float v = 0.0f;
+            if (row < nrows) {
+                const size_t o = (size_t)(n0 + row) * H + col;
+                v = acc[cb][r] * act_deriv(1, a.x2_prev[o]);
+                a.dx2_prev[o] = v;
+            }
+            buf[row * LDA + col] = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < CB16; ++cb) acc[cb] = zero4;
+    gemm_tile16<CB16, H>(buf, LDA, a.w_lin2_t, H, col0, acc);
+#pragma unroll
+    for (int cb = 0; cb < CB16; ++cb) {
+        const int col = col0 + cb * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = q * 4 + r;
+            if (row < nrows) a.dagg_prev[(size_t)(n0 + row) * H + col] = acc[cb][r];
+        }
+    }
+}
+int launch_node_bwd(int H, int N, int first, int last, tsd_edges enc, const float* Wf, const float* dagg_in,
+                    const float* dh_up, const float* w_lin1_t, const float* w_lin_t, const float* w_lin2_t,
+                    const float* x2_prev, float* dx1, float* dh, float* dx2_prev, float* dagg_prev, hipStream_t st) {
+    if (N == 0) return TSD_OK;
+    NodeBwd a{N, first, last, enc.row_ptr, enc.dst, enc.umap, Wf, dagg_in, dh_up, w_lin1_t, w_lin_t, w_lin2_t, x2_prev,
+              dx1, dh, dx2_prev, dagg_prev};
+    const size_t lds = (size_t)TN * (H + 4) * 4;
+    const int tiles = (N + TN - 1) / TN;
+#define TSD_NB(HH)                                                                              \
+    {                                                                                           \
+        static DeviceOnce once;                                                                 \
+        int r = allow_lds(node_bwd_kernel<HH>, lds, once);                                      \
+        if (r) return r;                                                                        \
+        hipLaunchKernelGGL(node_bwd_kernel<HH>, dim3(tiles), dim3(2 * HH), lds, st, a);         \
+    }
+    if (H == 128) TSD_NB(128) else if (H == 256) TSD_NB(256) else {
+        set_error("node_bwd: hidden=%d has no MFMA instance", H);
+        return TSD_ERR_INVALID;
+    }
+#undef TSD_NB
+    TSD_LAUNCH_CHECK("node_bwd");
+    return TSD_OK;
 }
 
 struct ComboStride {  // per-checkpoint strides (blockIdx.y = checkpoint of the ensemble)

@@ -633,42 +633,45 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
     // after the loop: 3 L problems of N rows each are launch-latency bound one by one (13 + 5 us each, 21 per step).
     const bool batch_wg = (H % 128 == 0);
     const float* dh_cur = w.dh;  // d loss / d h_{l+1}
-    for (int l = L - 1; l >= 0; --l) {
+    if (batch_wg) {
+        // MFMA sizes: per block ONE filter-chain launch (launch_filter_bwd) and ONE node-chain launch (launch_node_bwd:
+        // gather + three 16-row GEMMs, the mirror image of the forward's node role) instead of 3 + 4 primitive launches
+        float *dagg = w.nA, *dagg_other = w.nB;
+        auto wt = [&](int l, size_t off) { return w.pack_t + x.R.layer0 + (size_t)l * x.R.layer_stride + off; };
+        TSD_TRY(launch_node_bwd(H, N, 1, 0, g.enc, nullptr, nullptr, w.dh, nullptr, wt(L - 1, x.R.L_lin_w),
+                                wt(L - 1, x.R.L_lin2_w), w.x2 + (size_t)(L - 1) * NH, nullptr, nullptr,
+                                w.dx2s + (size_t)(L - 1) * NH, dagg, st));
+        for (int l = L - 1; l >= 0; --l) {
+            if (Eu > 0)
+                TSD_TRY(launch_filter_bwd(H, Eu, g.enc_u, dagg, w.x1 + l * NH, w.f0 + l * EH, wt(l, x.R.L_nn2_w),
+                                          wt(l, x.R.L_nn0_w), cfg->conv_cutoff, cfg->smooth_conv, w.dWfs + l * EH,
+                                          w.df0s + l * EH, w.d_ea, st));
+            const int lp = l > 0 ? l - 1 : 0;
+            TSD_TRY(launch_node_bwd(H, N, 0, l == 0, g.enc, w.Wf + l * EH, dagg, dh_cur, wt(l, x.R.L_lin1_w),
+                                    wt(lp, x.R.L_lin_w), wt(lp, x.R.L_lin2_w), w.x2 + (size_t)lp * NH, w.dx1s + l * NH,
+                                    w.dhs + l * NH, w.dx2s + (size_t)lp * NH, dagg_other, st));
+            dh_cur = w.dhs + l * NH;
+            float* t = dagg;
+            dagg = dagg_other;
+            dagg_other = t;
+        }
+    }
+    for (int l = L - 1; l >= 0 && !batch_wg; --l) {  // sizes without MFMA instances: primitive by primitive
         const size_t o = x.R.layer0 + (size_t)l * x.R.layer_stride;
         float *f0 = w.f0 + l * EH, *fs = w.fs + l * EH, *Wf = w.Wf + l * EH;
         float* hl = w.h + l * NH;
         float *x1 = w.x1 + l * NH, *agg = w.agg + l * NH, *x2 = w.x2 + l * NH, *xs = w.xs + l * NH;
-        float *dx2 = batch_wg ? w.dx2s + l * NH : w.nB, *dx1 = batch_wg ? w.dx1s + l * NH : w.nC;
-        float* dh_next = batch_wg ? w.dhs + l * NH : w.dh;
         // h_{l+1} = h_l + lin(ssp(lin2(agg)))
-        if (batch_wg) {
-            TSD_TRY(x.dgrad(N, H, H, o + x.R.L_lin_w, dh_cur, dx2, nullptr, 1, x2));
-            TSD_TRY(x.dgrad(N, H, H, o + x.R.L_lin2_w, dx2, w.nA, nullptr));
-        } else {
-            TSD_TRY(x.lin_bwd(N, H, H, xs, o + x.R.L_lin_w, (long)(o + x.R.L_lin_b), dh_cur, dx2, false, 1, x2));
-            TSD_TRY(x.lin_bwd(N, H, H, agg, o + x.R.L_lin2_w, (long)(o + x.R.L_lin2_b), dx2, w.nA, false));  // dagg
-        }
+        TSD_TRY(x.lin_bwd(N, H, H, xs, o + x.R.L_lin_w, (long)(o + x.R.L_lin_b), w.dh, w.nB, false, 1, x2));  // dx2
+        TSD_TRY(x.lin_bwd(N, H, H, agg, o + x.R.L_lin2_w, (long)(o + x.R.L_lin2_b), w.nB, w.nA, false));     // dagg
         // agg = aggregate(x1, Wf): symmetric edge set and filter => the adjoint w.r.t. x1 is the same gather of dagg
-        TSD_TRY(tsd_cfconv_aggregate(H, N, g.enc.row_ptr, g.enc.dst, g.enc.umap, Wf, w.nA, dx1, stream));
+        TSD_TRY(tsd_cfconv_aggregate(H, N, g.enc.row_ptr, g.enc.dst, g.enc.umap, Wf, w.nA, w.nC, stream));    // dx1
         if (Eu > 0) {
-            float* dWf = batch_wg ? w.dWfs + l * EH : w.eA;
-            float* df0 = batch_wg ? w.df0s + l * EH : w.eB;
-            if (batch_wg) {
-                TSD_TRY(launch_filter_bwd(H, Eu, g.enc_u, w.nA, x1, f0, w.pack_t + o + x.R.L_nn2_w, w.pack_t + o + x.R.L_nn0_w,
-                                          cfg->conv_cutoff, cfg->smooth_conv, dWf, df0, w.d_ea, st));
-            } else {
-                TSD_TRY(launch_aggregate_bwd_filter(H, Eu, g.enc_u, w.nA, x1, dWf, 1, cfg->conv_cutoff, cfg->smooth_conv, st));
-                TSD_TRY(x.lin_bwd(Eu, H, H, fs, o + x.R.L_nn2_w, (long)(o + x.R.L_nn2_b), dWf, df0, false, 1, f0));
-                TSD_TRY(x.lin_bwd(Eu, H, H, w.ea, o + x.R.L_nn0_w, (long)(o + x.R.L_nn0_b), df0, w.d_ea, true));
-            }
+            TSD_TRY(launch_aggregate_bwd_filter(H, Eu, g.enc_u, w.nA, x1, w.eA, 1, cfg->conv_cutoff, cfg->smooth_conv, st));
+            TSD_TRY(x.lin_bwd(Eu, H, H, fs, o + x.R.L_nn2_w, (long)(o + x.R.L_nn2_b), w.eA, w.eB, false, 1, f0));  // df0
+            TSD_TRY(x.lin_bwd(Eu, H, H, w.ea, o + x.R.L_nn0_w, (long)(o + x.R.L_nn0_b), w.eB, w.d_ea, true));
         }
-        // d loss / d h_l = d loss / d h_{l+1} (residual) + dx1 W_lin1
-        if (batch_wg) {
-            TSD_TRY(x.dgrad(N, H, H, o + x.R.L_lin1_w, dx1, dh_next, dh_cur));
-            dh_cur = dh_next;
-        } else {
-            TSD_TRY(x.lin_bwd(N, H, H, hl, o + x.R.L_lin1_w, -1, dx1, w.dh, true));
-        }
+        TSD_TRY(x.lin_bwd(N, H, H, hl, o + x.R.L_lin1_w, -1, w.nC, w.dh, true));  // dh += dx1 W_lin1 (residual keeps dh)
     }
     if (batch_wg) {
         std::vector<const float*> dYs, Xs;
