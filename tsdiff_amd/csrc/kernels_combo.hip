@@ -470,11 +470,10 @@ struct NodeBwd {
     float *dx1, *dh, *dx2_prev, *dagg_prev;
 };
 template <int H>
-__global__ __launch_bounds__(2 * H) void node_bwd_kernel(NodeBwd a) {
+__device__ __forceinline__ void node_bwd_role(const NodeBwd& a, int tile, float* smem) {
     constexpr int LDA = H + 4, NT = 2 * H, CB16 = 2, C4 = H / 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* buf = smem;
-    const int n0 = blockIdx.x * TN;
+    const int n0 = tile * TN;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, q = lane >> 4, l15 = lane & 15;
     const int col0 = wave * 32;
     const int nrows = min(TN, a.N - n0);
@@ -545,27 +544,142 @@ __global__ __launch_bounds__(2 * H) void node_bwd_kernel(NodeBwd a) {
         }
     }
 }
-int launch_node_bwd(int H, int N, int first, int last, tsd_edges enc, const float* Wf, const float* dagg_in,
-                    const float* dh_up, const float* w_lin1_t, const float* w_lin_t, const float* w_lin2_t,
-                    const float* x2_prev, float* dx1, float* dh, float* dx2_prev, float* dagg_prev, hipStream_t st) {
-    if (N == 0) return TSD_OK;
+// -------------------------------------------------------------------------------------------------
+// The filter MLP's whole backward chain for one tile of 32 undirected edges (the adjoint of the filter role;
+// schnet.py:94-99 backwards):
+//   dWf = (dagg_i * x1_j + dagg_j * x1_i) * C(d)     -> global (the weight gradient of nn.2 reads it), LDS
+//   df0 = (dWf . W_nn2) * ssp'(f0)                    -> global (weight gradient of nn.0), LDS
+//   d_ea += df0 . W_nn0                               (read-modify-write of the tile's own rows: deterministic)
+// instead of aggregate_bwd_filter + two dgrad launches with dWf / df0 read back from HBM in between.
+// -------------------------------------------------------------------------------------------------
+struct FilterBwd {
+    int tiles;  // 0: no filter role
+    tsd_edges eu;
+    const float *dagg, *x1, *f0, *W2t, *W0t;
+    float cutoff;
+    int smooth;
+    float *dWf, *df0, *d_ea;
+};
+template <int H>
+__device__ __forceinline__ void filter_bwd_role(const FilterBwd& f, int tile, float* smem) {
+    constexpr int TT = 32, LDA = H + 4, NT = 2 * H, C4 = H / 4;
+    float* buf = smem;
+    float* s_c = smem + TT * LDA;
+    int* s_i = reinterpret_cast<int*>(s_c + TT);
+    int* s_j = s_i + TT;
+    const int E = *f.eu.count;
+    const int e0 = tile * TT;
+    if (e0 >= E) return;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int col0 = (tid >> 6) * 32;
+    const int nrows = min(TT, E - e0);
+    if (tid < TT) {
+        const bool v = tid < nrows;
+        s_i[tid] = v ? f.eu.src[e0 + tid] : 0;
+        s_j[tid] = v ? f.eu.dst[e0 + tid] : 0;
+        s_c[tid] = v ? cutoff_weight(f.eu.dist[e0 + tid], f.cutoff, f.smooth) : 0.0f;
+    }
+    __syncthreads();
+    {
+        constexpr int NIT = TT * C4 / NT;
+        static_assert(TT * C4 % NT == 0, "tile / block mismatch");
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < nrows) {
+                const size_t oi = (size_t)s_i[r] * H + c4 * 4, oj = (size_t)s_j[r] * H + c4 * 4;
+                const f32x4 di = *reinterpret_cast<const f32x4*>(f.dagg + oi), dj = *reinterpret_cast<const f32x4*>(f.dagg + oj);
+                const f32x4 xi = *reinterpret_cast<const f32x4*>(f.x1 + oi), xj = *reinterpret_cast<const f32x4*>(f.x1 + oj);
+                v = (di * xj + dj * xi) * s_c[r];
+                *reinterpret_cast<f32x4*>(f.dWf + (size_t)(e0 + r) * H + c4 * 4) = v;
+            }
+            *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = v;
+        }
+    }
+    __syncthreads();
+    f32x16 acc[1][1];
+    zero_acc(acc);
+    gemm_tile<1, 1, H>(buf, LDA, f.W2t, H, col0, acc);
+    __syncthreads();
+    const int col = col0 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi);
+        float v = 0.0f;
+        if (row < nrows) {
+            const size_t o = (size_t)(e0 + row) * H + col;
+            v = acc[0][0][r] * act_deriv(1, f.f0[o]);
+            f.df0[o] = v;
+        }
+        buf[row * LDA + col] = v;
+    }
+    __syncthreads();
+    zero_acc(acc);
+    gemm_tile<1, 1, H>(buf, LDA, f.W0t, H, col0, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi);
+        if (row < nrows) {
+            const size_t o = (size_t)(e0 + row) * H + col;
+            f.d_ea[o] += acc[0][0][r];
+        }
+    }
+}
+
+// One launch per block of the backward pass: workgroups [0, node_tiles) run the node chain (the critical path),
+// the rest the filter chain of the same block -- both read d loss / d agg of the block and nothing of each other.
+template <int H>
+__global__ __launch_bounds__(2 * H) void block_bwd_kernel(NodeBwd a, int node_tiles, FilterBwd f) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    if (b < node_tiles) {
+        __builtin_amdgcn_s_setprio(3);
+        node_bwd_role<H>(a, b, smem);
+    } else {
+        filter_bwd_role<H>(f, b - node_tiles, smem);
+    }
+}
+// first: the chain starts at dh (top block, no gather); last: it stops at dh_0.  filter_rows == 0: no filter role.
+int launch_block_bwd(int H, int N, int first, int last, tsd_edges enc, const float* Wf, const float* dagg_in,
+                     const float* dh_up, const float* w_lin1_t, const float* w_lin_t, const float* w_lin2_t,
+                     const float* x2_prev, float* dx1, float* dh, float* dx2_prev, float* dagg_prev, int filter_rows,
+                     tsd_edges enc_u, const float* x1, const float* f0, const float* W2t, const float* W0t, float cutoff,
+                     int smooth, float* dWf, float* df0, float* d_ea, hipStream_t st) {
     NodeBwd a{N, first, last, enc.row_ptr, enc.dst, enc.umap, Wf, dagg_in, dh_up, w_lin1_t, w_lin_t, w_lin2_t, x2_prev,
               dx1, dh, dx2_prev, dagg_prev};
-    const size_t lds = (size_t)TN * (H + 4) * 4;
-    const int tiles = (N + TN - 1) / TN;
-#define TSD_NB(HH)                                                                              \
-    {                                                                                           \
-        static DeviceOnce once;                                                                 \
-        int r = allow_lds(node_bwd_kernel<HH>, lds, once);                                      \
-        if (r) return r;                                                                        \
-        hipLaunchKernelGGL(node_bwd_kernel<HH>, dim3(tiles), dim3(2 * HH), lds, st, a);         \
+    FilterBwd f{};
+    f.tiles = (filter_rows + 31) / 32;
+    if (f.tiles) {
+        f.eu = enc_u;
+        f.dagg = dagg_in;
+        f.x1 = x1;
+        f.f0 = f0;
+        f.W2t = W2t;
+        f.W0t = W0t;
+        f.cutoff = cutoff;
+        f.smooth = smooth;
+        f.dWf = dWf;
+        f.df0 = df0;
+        f.d_ea = d_ea;
+    }
+    const int node_tiles = (N + TN - 1) / TN;
+    if (node_tiles + f.tiles == 0) return TSD_OK;
+    const size_t lds_n = (size_t)TN * (H + 4) * 4, lds_f = (size_t)(32 * (H + 4) + 32) * 4 + 2 * 32 * sizeof(int);
+    const size_t lds = lds_n > lds_f ? lds_n : lds_f;
+#define TSD_NB(HH)                                                                                              \
+    {                                                                                                           \
+        static DeviceOnce once;                                                                                 \
+        int r = allow_lds(block_bwd_kernel<HH>, lds, once);                                                     \
+        if (r) return r;                                                                                        \
+        hipLaunchKernelGGL(block_bwd_kernel<HH>, dim3(node_tiles + f.tiles), dim3(2 * HH), lds, st, a, node_tiles, f); \
     }
     if (H == 128) TSD_NB(128) else if (H == 256) TSD_NB(256) else {
-        set_error("node_bwd: hidden=%d has no MFMA instance", H);
+        set_error("block_bwd: hidden=%d has no MFMA instance", H);
         return TSD_ERR_INVALID;
     }
 #undef TSD_NB
-    TSD_LAUNCH_CHECK("node_bwd");
+    TSD_LAUNCH_CHECK("block_bwd");
     return TSD_OK;
 }
 

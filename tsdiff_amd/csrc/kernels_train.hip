@@ -521,105 +521,6 @@ int launch_aggregate_bwd_filter(int H, int capacity_u, tsd_edges enc_u, const fl
     return TSD_OK;
 }
 
-// The filter MLP's whole backward chain for one tile of 32 undirected edges (the adjoint of the filter role of
-// kernels_combo.hip; schnet.py:94-99 backwards):
-//   dWf = (dagg_i * x1_j + dagg_j * x1_i) * C(d)     -> global (the weight gradient of nn.2 reads it), LDS
-//   df0 = (dWf . W_nn2) * ssp'(f0)                    -> global (weight gradient of nn.0), LDS
-//   d_ea += df0 . W_nn0                               (read-modify-write of the tile's own rows: deterministic)
-// instead of aggregate_bwd_filter + two dgrad launches with dWf / df0 read back from HBM in between.
-template <int H>
-__global__ __launch_bounds__(2 * H) void filter_bwd_kernel(tsd_edges eu, const float* __restrict__ dagg,
-                                                          const float* __restrict__ x1, const float* __restrict__ f0,
-                                                          const float* __restrict__ W2t, const float* __restrict__ W0t,
-                                                          float cutoff, int smooth, float* __restrict__ dWf,
-                                                          float* __restrict__ df0, float* __restrict__ d_ea) {
-    constexpr int TT = 32, LDA = H + 4, NT = 2 * H, C4 = H / 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* buf = smem;
-    float* s_c = smem + TT * LDA;
-    int* s_i = reinterpret_cast<int*>(s_c + TT);
-    int* s_j = s_i + TT;
-    const int E = *eu.count;
-    const int e0 = blockIdx.x * TT;
-    if (e0 >= E) return;
-    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
-    const int col0 = (tid >> 6) * 32;
-    const int nrows = min(TT, E - e0);
-    if (tid < TT) {
-        const bool v = tid < nrows;
-        s_i[tid] = v ? eu.src[e0 + tid] : 0;
-        s_j[tid] = v ? eu.dst[e0 + tid] : 0;
-        s_c[tid] = v ? cutoff_weight(eu.dist[e0 + tid], cutoff, smooth) : 0.0f;
-    }
-    __syncthreads();
-    {
-        constexpr int NIT = TT * C4 / NT;
-        static_assert(TT * C4 % NT == 0, "tile / block mismatch");
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < nrows) {
-                const size_t oi = (size_t)s_i[r] * H + c4 * 4, oj = (size_t)s_j[r] * H + c4 * 4;
-                const f32x4 di = *reinterpret_cast<const f32x4*>(dagg + oi), dj = *reinterpret_cast<const f32x4*>(dagg + oj);
-                const f32x4 xi = *reinterpret_cast<const f32x4*>(x1 + oi), xj = *reinterpret_cast<const f32x4*>(x1 + oj);
-                v = (di * xj + dj * xi) * s_c[r];
-                *reinterpret_cast<f32x4*>(dWf + (size_t)(e0 + r) * H + c4 * 4) = v;
-            }
-            *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = v;
-        }
-    }
-    __syncthreads();
-    f32x16 acc[1][1];
-    zero_acc(acc);
-    gemm_tile<1, 1, H>(buf, LDA, W2t, H, col0, acc);
-    __syncthreads();
-    const int col = col0 + l31;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r, hi);
-        float v = 0.0f;
-        if (row < nrows) {
-            const size_t o = (size_t)(e0 + row) * H + col;
-            v = acc[0][0][r] * act_deriv(1, f0[o]);
-            df0[o] = v;
-        }
-        buf[row * LDA + col] = v;
-    }
-    __syncthreads();
-    zero_acc(acc);
-    gemm_tile<1, 1, H>(buf, LDA, W0t, H, col0, acc);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r, hi);
-        if (row < nrows) {
-            const size_t o = (size_t)(e0 + row) * H + col;
-            d_ea[o] += acc[0][0][r];
-        }
-    }
-}
-int launch_filter_bwd(int H, int rows, tsd_edges enc_u, const float* dagg, const float* x1, const float* f0,
-                      const float* W2t, const float* W0t, float cutoff, int smooth, float* dWf, float* df0, float* d_ea,
-                      hipStream_t st) {
-    if (rows == 0) return TSD_OK;
-    const size_t lds = (size_t)(32 * (H + 4) + 32) * 4 + 2 * 32 * sizeof(int);
-#define TSD_FB(HH)                                                                                                   \
-    {                                                                                                                \
-        static DeviceOnce once;                                                                                      \
-        int r = allow_lds(filter_bwd_kernel<HH>, lds, once);                                                         \
-        if (r) return r;                                                                                             \
-        hipLaunchKernelGGL(filter_bwd_kernel<HH>, dim3((rows + 31) / 32), dim3(2 * HH), lds, st, enc_u, dagg, x1, f0, \
-                           W2t, W0t, cutoff, smooth, dWf, df0, d_ea);                                                \
-    }
-    if (H == 128) TSD_FB(128) else if (H == 256) TSD_FB(256) else {
-        set_error("filter_bwd: hidden=%d has no MFMA instance", H);
-        return TSD_ERR_INVALID;
-    }
-#undef TSD_FB
-    TSD_LAUNCH_CHECK("filter_bwd");
-    return TSD_OK;
-}
-
 // p[u,:] = h[i,:] * h[j,:] for the undirected out edges (common.py:226-229 first half of h_pair)
 __global__ void pair_product_fwd_kernel(int H, tsd_edges eu, const float* __restrict__ h, float* __restrict__ p) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

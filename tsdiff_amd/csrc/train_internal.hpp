@@ -48,12 +48,11 @@ int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, c
                     float* dX, float* dW, float* db, int flags, LinEpi epi, float* scratch, size_t scratch_floats,
                     hipStream_t st);
 size_t linear_scratch_floats(int in, int out);
-int launch_filter_bwd(int H, int rows, tsd_edges enc_u, const float* dagg, const float* x1, const float* f0,
-                      const float* W2t, const float* W0t, float cutoff, int smooth, float* dWf, float* df0, float* d_ea,
-                      hipStream_t st);
-int launch_node_bwd(int H, int N, int first, int last, tsd_edges enc, const float* Wf, const float* dagg_in,
-                    const float* dh_up, const float* w_lin1_t, const float* w_lin_t, const float* w_lin2_t,
-                    const float* x2_prev, float* dx1, float* dh, float* dx2_prev, float* dagg_prev, hipStream_t st);
+int launch_block_bwd(int H, int N, int first, int last, tsd_edges enc, const float* Wf, const float* dagg_in,
+                     const float* dh_up, const float* w_lin1_t, const float* w_lin_t, const float* w_lin2_t,
+                     const float* x2_prev, float* dx1, float* dh, float* dx2_prev, float* dagg_prev, int filter_rows,
+                     tsd_edges enc_u, const float* x1, const float* f0, const float* W2t, const float* W0t, float cutoff,
+                     int smooth, float* dWf, float* df0, float* d_ea, hipStream_t st);
 int wgrad_batch_splits(int rows);
 size_t wgrad_batch_scratch_floats(int n, int rows, int in, int out);
 int launch_wgrad_batch(int n, int rows, int in, int out, const float* const* dY, const float* const* X, float* const* dW,

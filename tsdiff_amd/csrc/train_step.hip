@@ -634,22 +634,22 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
     const bool batch_wg = (H % 128 == 0);
     const float* dh_cur = w.dh;  // d loss / d h_{l+1}
     if (batch_wg) {
-        // MFMA sizes: per block ONE filter-chain launch (launch_filter_bwd) and ONE node-chain launch (launch_node_bwd:
-        // gather + three 16-row GEMMs, the mirror image of the forward's node role) instead of 3 + 4 primitive launches
+        // MFMA sizes: ONE launch per block (launch_block_bwd: the node chain -- gather + three 16-row GEMMs, the mirror
+        // image of the forward's node role -- beside the filter MLP's backward chain) instead of 4 + 3 primitive launches
         float *dagg = w.nA, *dagg_other = w.nB;
         auto wt = [&](int l, size_t off) { return w.pack_t + x.R.layer0 + (size_t)l * x.R.layer_stride + off; };
-        TSD_TRY(launch_node_bwd(H, N, 1, 0, g.enc, nullptr, nullptr, w.dh, nullptr, wt(L - 1, x.R.L_lin_w),
-                                wt(L - 1, x.R.L_lin2_w), w.x2 + (size_t)(L - 1) * NH, nullptr, nullptr,
-                                w.dx2s + (size_t)(L - 1) * NH, dagg, st));
+        const tsd_edges none{};
+        TSD_TRY(launch_block_bwd(H, N, 1, 0, g.enc, nullptr, nullptr, w.dh, nullptr, wt(L - 1, x.R.L_lin_w),
+                                 wt(L - 1, x.R.L_lin2_w), w.x2 + (size_t)(L - 1) * NH, nullptr, nullptr,
+                                 w.dx2s + (size_t)(L - 1) * NH, dagg, 0, none, nullptr, nullptr, nullptr, nullptr, 0.f, 0,
+                                 nullptr, nullptr, nullptr, st));
         for (int l = L - 1; l >= 0; --l) {
-            if (Eu > 0)
-                TSD_TRY(launch_filter_bwd(H, Eu, g.enc_u, dagg, w.x1 + l * NH, w.f0 + l * EH, wt(l, x.R.L_nn2_w),
-                                          wt(l, x.R.L_nn0_w), cfg->conv_cutoff, cfg->smooth_conv, w.dWfs + l * EH,
-                                          w.df0s + l * EH, w.d_ea, st));
             const int lp = l > 0 ? l - 1 : 0;
-            TSD_TRY(launch_node_bwd(H, N, 0, l == 0, g.enc, w.Wf + l * EH, dagg, dh_cur, wt(l, x.R.L_lin1_w),
-                                    wt(lp, x.R.L_lin_w), wt(lp, x.R.L_lin2_w), w.x2 + (size_t)lp * NH, w.dx1s + l * NH,
-                                    w.dhs + l * NH, w.dx2s + (size_t)lp * NH, dagg_other, st));
+            TSD_TRY(launch_block_bwd(H, N, 0, l == 0, g.enc, w.Wf + l * EH, dagg, dh_cur, wt(l, x.R.L_lin1_w),
+                                     wt(lp, x.R.L_lin_w), wt(lp, x.R.L_lin2_w), w.x2 + (size_t)lp * NH, w.dx1s + l * NH,
+                                     w.dhs + l * NH, w.dx2s + (size_t)lp * NH, dagg_other, Eu, g.enc_u, w.x1 + l * NH,
+                                     w.f0 + l * EH, wt(l, x.R.L_nn2_w), wt(l, x.R.L_nn0_w), cfg->conv_cutoff,
+                                     cfg->smooth_conv, w.dWfs + l * EH, w.df0s + l * EH, w.d_ea, st));
             dh_cur = w.dhs + l * NH;
             float* t = dagg;
             dagg = dagg_other;
