@@ -87,14 +87,20 @@ def make_models(cfg, seeds, dev):
     return models
 
 
-def forward_flops(E_enc, E_out, E_diff, N, L, M):
-    """(executed, reference-formulation) flops of one forward per checkpoint set (SURVEY.md 8a FLOP model, H = 256).
-    Executed: per-edge MLPs once per undirected pair (E/2), the out graph's embedding only for the edges that differ."""
-    F = ((E_enc // 2) * (131584 + 393216 + L * 262144) + E_enc * L * 512 + E_diff * (131584 + 393216)
-         + (E_out // 2) * (327936 + 256) + N * (L * 393216 + 13000)) * M
-    F_ref = (E_enc * (131584 + 393216 + L * 262144 + L * 512) + E_out * (131584 + 393216 + 327936 + 256)
-             + N * (L * 393216 + 13000)) * M
-    return F, F_ref
+def forward_work(cfg_struct, E_enc, E_out, E_diff, N):
+    """the library's own work model of one forward (tsd_forward_work, include/tsdiff_hip.h): executed flops (per-edge
+    MLPs once per undirected pair), the reference's directed formulation, per-block-launch flops, aggregate bytes"""
+    import ctypes as C
+    from tsdiff_amd import _lib
+    w = _lib.Work()
+    _lib.check(_lib.load().tsd_forward_work(C.byref(cfg_struct), N, E_enc, E_out, E_diff, C.byref(w)))
+    return w
+
+
+def forward_flops(cfg_struct, E_enc, E_out, E_diff, N, M):
+    """(executed, reference-formulation) flops of one forward per checkpoint set"""
+    w = forward_work(cfg_struct, E_enc, E_out, E_diff, N)
+    return w.flops_executed * M, w.flops_reference * M
 
 
 def sync_all(dist):
@@ -167,7 +173,7 @@ def combo_roofline(lib, db, cfg, dev, reps=40):
     # algorithmic flops of the L+1 launches of a forward, averaged per launch:
     # L x filters of one layer on the undirected list (two HxH GEMMs + C mask), L x (aggregation over the
     # directed list + three HxH GEMMs per node)
-    flops = (L * (Eu * (4.0 * H * H + H) + E_enc * 2.0 * H + N * 6.0 * H * H)) / (L + 1)
+    flops = forward_work(db.cfg, E_enc, 0, 0, N).flops_block_launch
     # the same work in SURVEY.md 8(d)'s units (filters counted once per DIRECTED edge, as the reference runs them)
     flops_survey = (L * (E_enc * (4.0 * H * H + 2.0 * H) + N * 6.0 * H * H)) / (L + 1)
     ach = flops / (k_ms * 1e-3) / 1e12
@@ -207,7 +213,7 @@ def aggregate_roofline(lib, db, H, dev, reps=20):
         ev1.record()
         torch.cuda.synchronize()
         a_ms = min(a_ms, ev0.elapsed_time(ev1) / reps)
-    a_bytes = (4.0 * H + 4) * E + 8.0 * H * N + 4
+    a_bytes = forward_work(db.cfg, E, 0, 0, N).bytes_aggregate
     gbs = a_bytes / (a_ms * 1e-3) / 1e9
     del Wd, x1, agg
     return {"kernel": "cfconv_aggregate_kernel<256>", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
@@ -274,7 +280,7 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist):
     # executed arithmetic of a step ~ 3 x the forward's dense layers (forward, dgrad, wgrad) on the undirected lists
     db = model._batches[0][2]
     L = model._cfg.num_convs
-    F, _ = forward_flops(db.enc.num_edges(), db.out.num_edges(), db.diff_u.num_edges(), db.N, L, 1)
+    F, _ = forward_flops(model._cfg, db.enc.num_edges(), db.out.num_edges(), db.diff_u.num_edges(), db.N, 1)
     model.eval()
     return dt, float(last), N, 3.0 * F
 
@@ -438,7 +444,7 @@ def main():
     roofline = combo_roofline(lib, db, cfg, dev, reps=40 if db.P < 2_000_000 else 2)
     fname = "r02_pmc_traffic.json" if args.workload == "c2" else "r02_pmc_traffic_c5.json"
     roofline["traffic"], roofline["traffic_source"] = pmc_traffic("layer_combo_kernel<256", fname)
-    F, F_ref = forward_flops(E_enc, E_out, E_diff, N, L, args.models)
+    F, F_ref = forward_flops(models[0]._cfg, E_enc, E_out, E_diff, N, args.models)
     step_s = dt / args.steps
 
     out = {
@@ -479,7 +485,7 @@ def main():
         rf5 = combo_roofline(lib, db5, cfg, dev, reps=2)
         rf5["traffic"], rf5["traffic_source"] = pmc_traffic("layer_combo_kernel<256", "r02_pmc_traffic_c5.json")
         N5 = 1024 * 64
-        F5, _ = forward_flops(db5.enc.num_edges(), db5.out.num_edges(), db5.diff_u.num_edges(), N5, L, 1)
+        F5, _ = forward_flops(models[0]._cfg, db5.enc.num_edges(), db5.out.num_edges(), db5.diff_u.num_edges(), N5, 1)
         out["c5"] = {"workload": "configs[4]: 1024 x 64-atom graphs, complete pair set, LD sampling, 1 checkpoint",
                      "steps": K5, "ms_per_step": round(dt5 / K5 * 1e3, 3), "value": round(N5 * K5 / dt5, 1),
                      "unit": "atoms*steps/s", "fwd_per_s": round(K5 / dt5, 3), "atoms": N5,
@@ -502,7 +508,7 @@ def main():
         K8 = 20
         dt8, p8 = run8.timed(K8)
         assert torch.isfinite(p8).all()
-        F8, _ = forward_flops(E_enc, E_out, E_diff, N, L, 8)
+        F8, _ = forward_flops(models[0]._cfg, E_enc, E_out, E_diff, N, 8)
         out["ensemble8"] = {"workload": "configs[2] per-GPU unit: the configs[1] batch with an 8-checkpoint ensemble "
                                         "(all checkpoints in the same launches)", "steps": K8,
                             "ms_per_step": round(dt8 / K8 * 1e3, 3), "value": round(N * K8 / dt8, 1),

@@ -29,8 +29,10 @@
  *     host synchronisation (exceptions, each documented at its declaration: the one-shot tsd_sampler_run
  *     and tsd_train_forward) and returns 0 on success or a negative TSD_ERR_* code;
  *     tsd_last_error() returns a thread-local message for the last failure;
- *   - no mutable process-global state: the only globals are that thread-local error string and
- *     per-device "kernel attributes set" bits; a process may drive several devices (the device current
+ *   - no mutable process-global state: the only globals are that thread-local error string,
+ *     per-device "kernel attributes set" bits and the roctx entry points resolved once from the process image
+ *     (the forward, sampling-loop, geometry / topology and training entry points run inside "tsd:<name>"
+ *     ranges that `rocprofv3 --marker-trace` records; absent a profiler the ranges are no-ops); a process may drive several devices (the device current
  *     at the call is used), one stream per call;
  *   - floating point is fp32 end to end (fp32 MFMA, exact-f32 FMA chains); indices at this
  *     boundary are int32 except where the reference surface hands over int64 tensors
@@ -121,6 +123,19 @@ const char* tsd_last_error(void);
 size_t tsd_raw_weight_floats(const tsd_model_cfg* cfg);
 size_t tsd_packed_weight_floats(const tsd_model_cfg* cfg);
 int tsd_pack_weights(const tsd_model_cfg* cfg, const float* raw, float* packed, void* stream);
+
+/* ---- work model (the figures every roofline fraction in bench.py is quoted against) -----------
+ * Arithmetic of ONE forward of one checkpoint for a batch with the given edge counts: `enc_edges` / `out_edges`
+ * directed edges of the encoder / output lists, `diff_pairs` undirected output pairs embedded separately. */
+typedef struct tsd_work {
+    double flops_edge_embed, flops_blocks, flops_pair_output, flops_other; /* executed: per-edge MLPs once per undirected pair */
+    double flops_executed;      /* their sum */
+    double flops_reference;     /* the reference's directed formulation of the same forward */
+    double flops_block_launch;  /* average executed flops of one of the L + 1 per-block launches */
+    double bytes_aggregate;     /* algorithmic HBM bytes of one stand-alone CFConv aggregation (tsd_cfconv_aggregate) */
+} tsd_work;
+int tsd_forward_work(const tsd_model_cfg* cfg, int32_t num_nodes, int64_t enc_edges, int64_t out_edges,
+                     int64_t diff_pairs, tsd_work* out);
 
 /* ---- topology (once per batch; pos independent) -------------------------------------------
  * graph_ptr [G+1]: node offsets; pair_base [G+1]: prefix sums of n_g*(n_g-1).

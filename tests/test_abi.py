@@ -130,3 +130,24 @@ def test_header_is_plain_c(tmp_path):
     src.write_text('#include "tsdiff_hip.h"\n' + "void* table[] = {" + ", ".join(f"(void*){n}" for n in names) + "};\n")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src),
                     "-o", str(tmp_path / "abi.o")], check=True)
+
+
+def test_forward_work_model_known_answers():
+    """tsd_forward_work (host only): the SURVEY 8(d) flop model at H = 256, L = 7 against its closed form, and the
+    aggregate's algorithmic bytes 1028 E + 2048 N + 4"""
+    import ctypes as C
+    from tsdiff_amd import _lib, engine, synth
+    lib = _lib.load()
+    cfg = engine.make_cfg(synth.DEFAULT_MODEL_CONFIG)
+    w = _lib.Work()
+    N, E_enc, E_out, E_diff, L = 1600, 26074, 24000, 1500, 7
+    _lib.check(lib.tsd_forward_work(C.byref(cfg), N, E_enc, E_out, E_diff, C.byref(w)))
+    F = ((E_enc // 2) * (131584 + 393216 + L * 262144) + E_enc * L * 512 + E_diff * (131584 + 393216)
+         + (E_out // 2) * (327936 + 256) + N * (L * 393216 + 13000))
+    F_ref = (E_enc * (131584 + 393216 + L * 262144 + L * 512) + E_out * (131584 + 393216 + 327936 + 256)
+             + N * (L * 393216 + 13000))
+    assert w.flops_executed == F and w.flops_reference == F_ref
+    assert w.flops_block_launch == (L * ((E_enc // 2) * (4.0 * 65536 + 256) + E_enc * 512.0 + N * 6.0 * 65536)) / (L + 1)
+    assert w.bytes_aggregate == 1028.0 * E_enc + 2048.0 * N + 4
+    assert w.flops_edge_embed + w.flops_blocks + w.flops_pair_output + w.flops_other == w.flops_executed
+    assert lib.tsd_forward_work(C.byref(cfg), -1, 0, 0, 0, C.byref(w)) != 0

@@ -13,6 +13,12 @@ rocprofv3 --kernel-trace --stats -d /tmp/p_c5 -o c5 -- python3 bench.py --worklo
 python3 tools/rocpd_stats.py $(db /tmp/p_c5) > gpurun_out/${TAG}_kernel_stats_c5.md
 rocprofv3 --kernel-trace --stats -d /tmp/p_tr -o tr -- python3 bench.py --workload train --steps 20 --warmup 5 > gpurun_out/${TAG}_prof_train.log 2>&1
 python3 tools/rocpd_stats.py $(db /tmp/p_tr) > gpurun_out/${TAG}_kernel_stats_train.md
+python3 tools/step_timeline.py $(db /tmp/p_tr) > gpurun_out/${TAG}_train_timeline.md
+# roctx ranges of the library's entry points (no counters in this pass)
+rocprofv3 --kernel-trace --marker-trace -d /tmp/p_mk -o mk -- python3 bench.py --steps 20 --warmup 5 --no-graph $B > gpurun_out/${TAG}_prof_markers.log 2>&1
+python3 tools/marker_summary.py $(db /tmp/p_mk) > gpurun_out/${TAG}_markers.md
+rocprofv3 --kernel-trace --marker-trace -d /tmp/p_mt -o mt -- python3 bench.py --workload train --steps 10 --warmup 3 > gpurun_out/${TAG}_prof_markers_train.log 2>&1
+python3 tools/marker_summary.py $(db /tmp/p_mt) > gpurun_out/${TAG}_markers_train.md
 # HBM traffic: separate passes per counter (MI355X_MICROARCH.md "rocprofv3 PMC slots"), kernel trace only
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_f -o f -- python3 bench.py --steps 30 --warmup 5 $B > gpurun_out/${TAG}_pmc_f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_w -o w -- python3 bench.py --steps 30 --warmup 5 $B > gpurun_out/${TAG}_pmc_w.log 2>&1
@@ -35,4 +41,4 @@ rocprofv3 --kernel-trace --pmc $SQ -d /tmp/p_sq5 -o sq -- python3 bench.py --wor
   python3 tools/pmc_kernel_table.py $(db /tmp/p_sq5) cfconv_aggregate
   echo '```'
 } > gpurun_out/${TAG}_sq_counters.md
-head -14 gpurun_out/${TAG}_kernel_stats_c2.md; head -8 gpurun_out/${TAG}_kernel_stats_c5.md; cat gpurun_out/${TAG}_pmc_traffic.md | head -8; head -30 gpurun_out/${TAG}_sq_counters.md
+cat gpurun_out/${TAG}_markers.md gpurun_out/${TAG}_markers_train.md; head -14 gpurun_out/${TAG}_kernel_stats_c2.md; head -8 gpurun_out/${TAG}_kernel_stats_c5.md; cat gpurun_out/${TAG}_pmc_traffic.md | head -8; head -30 gpurun_out/${TAG}_sq_counters.md

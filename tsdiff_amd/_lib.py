@@ -87,6 +87,12 @@ class Batch(C.Structure):
     ]
 
 
+class Work(C.Structure):
+    """tsd_work"""
+    _fields_ = [(k, C.c_double) for k in ("flops_edge_embed", "flops_blocks", "flops_pair_output", "flops_other",
+                                          "flops_executed", "flops_reference", "flops_block_launch", "bytes_aggregate")]
+
+
 class RunArgs(C.Structure):  # tsd_run_args
     _fields_ = [
         ("coefs", C.c_void_p),
@@ -154,6 +160,7 @@ SIGNATURES = {
     "tsd_train_workspace_floats": (C.c_size_t, [_CFG, C.c_int32, C.c_int32]),
     "tsd_train_forward": (C.c_int, [_CFG, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P]),
     "tsd_train_backward": (C.c_int, [_CFG, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P, _P]),
+    "tsd_forward_work": (C.c_int, [_CFG, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.POINTER(Work)]),
     "tsd_grad_norm_clip": (C.c_int, [C.c_int64, _P, C.c_float, _P, _P, _P]),
     "tsd_adam_step": (C.c_int, [C.c_int64, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int64, _P]),

@@ -1,7 +1,10 @@
 // api.hip -- the extern "C" surface of libtsdiff_hip.so (declared in include/tsdiff_hip.h) and the
 // orchestration of one score-network forward / one sampling step / the device-resident loop.
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdlib.h>
+
+#include <mutex>
 
 #include "common.hpp"
 
@@ -14,6 +17,29 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+namespace {
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)(void);
+roctx_push_fn g_roctx_push = nullptr;  // written once (call_once), read-only afterwards
+roctx_pop_fn g_roctx_pop = nullptr;
+std::once_flag g_roctx_once;
+}  // namespace
+TraceRange::TraceRange(const char* name) {
+    std::call_once(g_roctx_once, [] {
+        void* push = dlsym(RTLD_DEFAULT, "roctxRangePushA");
+        void* pop = dlsym(RTLD_DEFAULT, "roctxRangePop");
+        if (push && pop) {
+            g_roctx_push = (roctx_push_fn)push;
+            g_roctx_pop = (roctx_pop_fn)pop;
+        }
+    });
+    on = g_roctx_push != nullptr;
+    if (on) g_roctx_push(name);
+}
+TraceRange::~TraceRange() {
+    if (on) g_roctx_pop();
 }
 
 int check_hip(hipError_t e, const char* what) {
@@ -117,6 +143,7 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     const size_t H = c.hidden;
     const tsd_geometry& g = b.geo;
     int r;
+    TraceRange range("tsd:score_forward");
     if (!counts_ready) {
         if ((r = launch_geometry_count(c, N, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, g, st))) return r;
     }
@@ -232,6 +259,7 @@ size_t tsd_packed_weight_floats(const tsd_model_cfg* cfg) {
     return weight_layout(*cfg).total;
 }
 int tsd_pack_weights(const tsd_model_cfg* cfg, const float* raw, float* packed, void* stream) {
+    TraceRange range("tsd:pack_weights");
     int r = check_cfg(cfg);
     if (r) return r;
     TSD_REQUIRE(raw && packed, "null weight pointer");
@@ -243,6 +271,7 @@ int tsd_topology_build(int32_t num_nodes, int32_t num_graphs, int32_t num_pairs,
                        const int64_t* bond_type, int32_t max_order, int32_t max_graph_nodes_host,
                        int32_t* node_graph, int32_t* pair_ptr, uint16_t* pair_code, int32_t* status,
                        void* stream) {
+    TraceRange range("tsd:topology_build");
     TSD_REQUIRE(num_nodes >= 0 && num_graphs >= 0 && num_pairs >= 0 && num_bonds >= 0, "negative size");
     TSD_REQUIRE(graph_ptr && pair_base && node_graph && pair_ptr && status, "null pointer");
     TSD_REQUIRE(num_pairs == 0 || pair_code, "null pair_code");
@@ -259,6 +288,7 @@ size_t tsd_geometry_scratch_ints(int32_t num_nodes, int32_t num_pairs) {
 int tsd_geometry_build(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_graphs, int32_t num_pairs,
                        const float* pos, const int32_t* graph_ptr, const int32_t* node_graph,
                        const int32_t* pair_ptr, const uint16_t* pair_code, tsd_geometry geo, void* stream) {
+    TraceRange range("tsd:geometry_build");
     int r = check_cfg(cfg);
     if (r) return r;
     TSD_REQUIRE(pos && graph_ptr && node_graph && pair_ptr && geo.scratch, "null pointer");
@@ -274,6 +304,7 @@ int tsd_geometry_build(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_
 
 int tsd_node_embed(const tsd_model_cfg* cfg, const float* w, int32_t num_nodes, const int64_t* atom_type,
                    const int64_t* r_feat, const int64_t* p_feat, float* z, void* stream) {
+    TraceRange range("tsd:node_embed");
     int r = check_cfg(cfg);
     if (r) return r;
     return launch_node_embed(*cfg, w, num_nodes, atom_type, r_feat, p_feat, z, (hipStream_t)stream);
@@ -365,6 +396,28 @@ size_t tsd_forward_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes,
     return carve(*cfg, num_nodes, num_pairs, num_models < 1 ? 1 : num_models, nullptr).total;
 }
 
+int tsd_forward_work(const tsd_model_cfg* cfg, int32_t num_nodes, int64_t enc_edges, int64_t out_edges,
+                     int64_t diff_pairs, tsd_work* out) {
+    int r = check_cfg(cfg);
+    if (r) return r;
+    TSD_REQUIRE(out && num_nodes >= 0 && enc_edges >= 0 && out_edges >= 0 && diff_pairs >= 0, "bad argument");
+    const double H = cfg->hidden, L = cfg->num_convs, N = num_nodes;
+    const double Eu = (double)(enc_edges / 2), Ou = (double)(out_edges / 2), E = (double)enc_edges, O = (double)out_edges;
+    const double embed_row = (2 * H + 2 * H * H) + 6 * H * H;          // Linear(1,H), Linear(H,H) | edge_cat 2H->H->H
+    const double filter_row = 4 * H * H;                                // nn.0, nn.2
+    const double pair_row = 4 * H * H + H * H + H + H;                  // 2H->H, H->H/2, H/2->1, h_i * h_j
+    const double node_block = 6 * H * H;                                // lin1, lin2, lin
+    out->flops_edge_embed = (Eu + (double)diff_pairs) * embed_row;
+    out->flops_blocks = L * (Eu * filter_row + E * 2 * H + N * node_block);
+    out->flops_pair_output = Ou * pair_row;
+    out->flops_other = N * 13000.0;
+    out->flops_executed = out->flops_edge_embed + out->flops_blocks + out->flops_pair_output + out->flops_other;
+    out->flops_reference = E * (embed_row + L * (filter_row + 2 * H)) + O * (embed_row + pair_row) + N * (L * node_block + 13000.0);
+    out->flops_block_launch = L * (Eu * (filter_row + H) + E * 2 * H + N * node_block) / (L + 1);
+    out->bytes_aggregate = (4 * H + 4) * E + 8 * H * N + 4;            // stand-alone CFConv aggregation (HBM form)
+    return TSD_OK;
+}
+
 int tsd_score_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* pos, void* stream) {
     int r = check_cfg(cfg);
     if (r) return r;
@@ -402,6 +455,7 @@ int tsd_philox_normal(uint64_t seed, uint64_t offset, int64_t n_atoms, float* ou
 int tsd_sampler_plan_create(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t kind, float clip,
                             float clip_pos, float* pos, tsd_sampler_state* state, void* stream,
                             tsd_sampler_plan** plan_out) {
+    TraceRange range("tsd:sampler_plan_create");
     int r = check_cfg(cfg);
     if (r) return r;
     if ((r = check_batch(batch))) return r;
@@ -430,6 +484,7 @@ int tsd_sampler_plan_create(const tsd_model_cfg* cfg, const tsd_batch* batch, in
 
 int tsd_sampler_plan_run(tsd_sampler_plan* plan, int32_t n_steps, const tsd_run_args* args, int32_t use_graph,
                          void* stream) {
+    TraceRange range("tsd:sampler_plan_run");
     TSD_REQUIRE(plan && args, "null pointer");
     TSD_REQUIRE(n_steps >= 0, "n_steps=%d", n_steps);
     TSD_REQUIRE(n_steps == 0 || args->coefs, "null coefs");
@@ -463,6 +518,7 @@ int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t ki
                     const float* coefs, const float* noises, uint64_t seed, uint64_t offset, float clip,
                     float clip_pos, float* pos, float* traj, tsd_sampler_state* state, int32_t use_graph,
                     void* stream) {
+    TraceRange range("tsd:sampler_run");
     tsd_sampler_plan* plan = nullptr;
     int r;
     if (use_graph) {

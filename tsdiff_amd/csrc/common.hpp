@@ -17,6 +17,18 @@ using f32x16 = float __attribute__((ext_vector_type(16)));
 // error plumbing
 // ---------------------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
+
+// A named range around a library call or one of its phases, visible to `rocprofv3 --marker-trace` (and to
+// --kernel-rename): roctxRangePushA / roctxRangePop are looked up in the process image once -- rocprofv3 preloads
+// librocprofiler-sdk-roctx.so when markers are requested -- and the range is a no-op when they are absent, so the
+// library neither links nor loads a profiler.
+struct TraceRange {
+    explicit TraceRange(const char* name);
+    ~TraceRange();
+    TraceRange(const TraceRange&) = delete;
+    TraceRange& operator=(const TraceRange&) = delete;
+    bool on;
+};
 int check_hip(hipError_t e, const char* what);
 
 #define TSD_HIP(call)                                              \

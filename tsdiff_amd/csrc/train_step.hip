@@ -512,6 +512,7 @@ size_t tsd_train_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, i
 }
 
 int tsd_grad_norm_clip(int64_t n, float* grad, float max_norm, float* scratch, float* norm, void* stream) {
+    TraceRange range("tsd:grad_norm_clip");
     hipStream_t st = (hipStream_t)stream;
     TSD_REQUIRE(n >= 0 && grad && scratch && norm, "null pointer");
     hipLaunchKernelGGL(sumsq_stage1_kernel, dim3(NORM_WG), dim3(256), 0, st, n, grad, scratch);
@@ -524,6 +525,7 @@ int tsd_grad_norm_clip(int64_t n, float* grad, float max_norm, float* scratch, f
 
 int tsd_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int64_t step, void* stream) {
+    TraceRange range("tsd:adam_step");
     TSD_REQUIRE(n >= 0 && param && grad && exp_avg && exp_avg_sq && step >= 1, "bad argument");
     if (n == 0) return TSD_OK;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
@@ -537,6 +539,7 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
                       const int64_t* r_feat, const int64_t* p_feat, const float* pos0, const float* pos,
                       const float* a_graph, const int32_t* topo_status, float* workspace, size_t workspace_floats,
                       float* loss, int32_t* counts_host, void* stream) {
+    TraceRange range("tsd:train_forward");
     hipStream_t st = (hipStream_t)stream;
     TSD_REQUIRE(cfg && batch && raw && atom_type && r_feat && p_feat && pos0 && pos && a_graph && workspace && loss &&
                     counts_host, "null pointer");
@@ -556,7 +559,10 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
     const int N = x.N, H = x.H, L = x.L, F = x.F, PU = x.PU, Eu = x.Eu, Eo = x.Eo, Ed = x.Ed;
     const Work& w = x.w;
     if (N == 0) return TSD_OK;
-    TSD_TRY(pack_all(x));
+    {
+        TraceRange ph("tsd:train_forward/pack_weights");
+        TSD_TRY(pack_all(x));
+    }
     const float* W = w.pack_inf;
     // node embedding
     hipLaunchKernelGGL(feats_to_float_kernel, dim3(nblk((int64_t)N * F)), dim3(256), 0, st, (int64_t)N * F, r_feat, p_feat,
@@ -598,6 +604,7 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
 int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* raw, const int64_t* atom_type,
                        const float* pos, float* workspace, size_t workspace_floats, const int32_t* counts_host,
                        const float* dloss, float* grad, void* stream) {
+    TraceRange range("tsd:train_backward");
     hipStream_t st = (hipStream_t)stream;
     TSD_REQUIRE(dloss && grad && atom_type && pos, "null pointer");
     Ctx x;
