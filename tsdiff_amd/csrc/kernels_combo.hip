@@ -107,13 +107,12 @@ struct VRow<1> {
 // per-block launch (x = x1, the CFConv message; schnet.py:101-107) and by the backward node chain of the
 // training step (x = d loss / d agg: the same gather is the adjoint w.r.t. x1).  SAVE: rows also go to `save` [N,H].
 // -------------------------------------------------------------------------------------------------
-template <int H, bool SAVE>
+template <int H, bool SAVE, int NW = 2 * H / 64 /* waves of the workgroup */, int U = 8 /* edges in flight per wave */>
 __device__ __forceinline__ void aggregate_tile(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ dst,
                                                const int32_t* __restrict__ umap, const float* __restrict__ Wf,
                                                const float* __restrict__ x, int N, int n0, float* buf,
                                                float* __restrict__ save) {
     constexpr int LDA = H + 4;
-    constexpr int NW = 2 * H / 64;
     constexpr int RPW = TN / NW;  // rows aggregated per wave
     constexpr int V = H / 64;     // channels per lane during aggregation
     static_assert(TN % NW == 0, "");
@@ -151,7 +150,7 @@ __device__ __forceinline__ void aggregate_tile(const int32_t* __restrict__ row_p
     // no VALU work: the edge indices come by SCALAR loads (8 consecutive edges per s_load_dwordx8), the row bases
     // are SALU arithmetic, the row loads take an SGPR base + one lane-offset VGPR (inline asm: hipcc builds a
     // 64-bit VGPR address per load), which leaves the products and sums.
-    constexpr int U = 8;  // edges in flight per wave (2 x 8 row loads of H floats)
+    // U edges in flight per wave (2 x U row loads of H floats)
     typedef int i32x8 __attribute__((ext_vector_type(8)));
     typedef typename VRow<V>::type vrow;
     const unsigned lane_b = (unsigned)lane * (V * 4u);  // this lane's byte offset inside a row
@@ -180,11 +179,16 @@ __device__ __forceinline__ void aggregate_tile(const int32_t* __restrict__ row_p
             }
         }
         // one wait for the batch, naming every destination (the consumers below depend on this statement)
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]), "+v"(wv[4]), "+v"(wv[5]), "+v"(wv[6]),
-                       "+v"(wv[7]), "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]),
-                       "+v"(xv[6]), "+v"(xv[7])::"memory");
-        static_assert(U == 8, "the wait statement names 8 + 8 registers");
+        if constexpr (U == 8)
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]), "+v"(wv[4]), "+v"(wv[5]), "+v"(wv[6]),
+                           "+v"(wv[7]), "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]), "+v"(xv[4]), "+v"(xv[5]),
+                           "+v"(xv[6]), "+v"(xv[7])::"memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]), "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]),
+                           "+v"(xv[3])::"memory");
+        static_assert(U == 8 || U == 4, "the wait statement names U + U registers");
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (e + u < E1) {
@@ -859,4 +863,6 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     return TSD_OK;
 }
 
+
 }  // namespace tsd
+
