@@ -90,24 +90,55 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
+class _ZeroArena:
+    """The buffers of a batch carved from ONE zero-initialised allocation (one fill launch instead of ~20) and one
+    uninitialised one: a fresh batch per training step pays for every launch and allocation of its construction."""
+    ALIGN = 256
+    ITEM = {torch.int32: 4, torch.float32: 4, torch.int16: 2, torch.uint8: 1, torch.int64: 8}
+
+    @staticmethod
+    def need(n, dtype):
+        return (n * _ZeroArena.ITEM[dtype] + _ZeroArena.ALIGN - 1) & ~(_ZeroArena.ALIGN - 1)
+
+    def __init__(self, device, nbytes, zero=True):
+        self.buf = (torch.zeros if zero else torch.empty)(max(nbytes, 1), dtype=torch.uint8, device=device)
+        self.o = 0
+
+    def take(self, n, dtype):
+        sz = n * self.ITEM[dtype]
+        o = self.o
+        self.o = (o + sz + self.ALIGN - 1) & ~(self.ALIGN - 1)
+        if self.o > self.buf.numel():
+            raise RuntimeError("internal: zero arena undersized")
+        return self.buf[o:o + sz].view(dtype)
+
+
 class EdgeList:
     """device buffers of one extended-graph edge list (capacity = num_pairs)"""
 
-    def __init__(self, N, P, device):
-        i32 = dict(dtype=torch.int32, device=device)
-        self.count = torch.zeros(1, **i32)
-        self.row_ptr = torch.zeros(N + 1, **i32)
+    @staticmethod
+    def zero_bytes(N):
+        return _ZeroArena.need(1, torch.int32) + _ZeroArena.need(N + 1, torch.int32)
+
+    @staticmethod
+    def raw_bytes(P):
+        cap = max(P, 1) + _lib.EDGE_PAD
+        return 5 * _ZeroArena.need(cap, torch.int32) + 2 * _ZeroArena.need(cap, torch.uint8)
+
+    def __init__(self, N, P, device, arena, raw):
+        self.count = arena.take(1, torch.int32)
+        self.row_ptr = arena.take(N + 1, torch.int32)
         # entries [0, count) of the per-edge arrays are rewritten by every geometry build and nothing uses values
         # past count: no fill launches for them (a fresh batch per training step builds 35 of these).  Every array
         # carries TSD_EDGE_PAD spare entries: the node role fetches dst / umap 8 edges at a time by scalar loads.
         cap = max(P, 1) + _lib.EDGE_PAD
-        self.src = torch.empty(cap, **i32)
-        self.dst = torch.empty(cap, **i32)
-        self.dist = torch.empty(cap, dtype=torch.float32, device=device)
-        self.type_r = torch.empty(cap, dtype=torch.uint8, device=device)
-        self.type_p = torch.empty(cap, dtype=torch.uint8, device=device)
-        self.pair_id = torch.empty(cap, **i32)
-        self.umap = torch.empty(cap, **i32)
+        self.src = raw.take(cap, torch.int32)
+        self.dst = raw.take(cap, torch.int32)
+        self.dist = raw.take(cap, torch.float32)
+        self.type_r = raw.take(cap, torch.uint8)
+        self.type_p = raw.take(cap, torch.uint8)
+        self.pair_id = raw.take(cap, torch.int32)
+        self.umap = raw.take(cap, torch.int32)
 
     def struct(self):
         return Edges(*[C.c_void_p(t.data_ptr()) for t in (
@@ -154,14 +185,20 @@ class DeviceBatch:
         self.N, self.G, self.P = N, G, P
         self.max_n = int(nn_host.max()) if G else 0
         self.num_nodes_per_graph_host = nn_host
-        i32 = dict(dtype=torch.int32, device=dev)
         self.graph_ptr = torch.from_numpy(graph_ptr.astype(np.int32)).to(dev)
         self.pair_base = torch.from_numpy(pair_base.astype(np.int32)).to(dev)
-        self.node_graph = torch.zeros(max(N, 1), **i32)
-        self.pair_ptr = torch.zeros(N + 1, **i32)
-        self.pair_code = torch.zeros(max(P, 1), dtype=torch.int16, device=dev)
-        # tsd_sampler_state: [0] status flags (also the topology build's status word), [1] step counter, run args
-        self.status = torch.zeros(_lib.SAMPLER_STATE_INTS, **i32)
+        i32, f32 = torch.int32, torch.float32
+        zeros = [("node_graph", max(N, 1), i32), ("pair_ptr", N + 1, i32), ("pair_code", max(P, 1), torch.int16),
+                 # tsd_sampler_state: [0] status flags (also the topology build's status word), [1] step counter, run args
+                 ("status", _lib.SAMPLER_STATE_INTS, i32),
+                 ("attr_row", max(P // 2, 1), i32), ("pair2out", max(P, 1), i32), ("pair2u", max(2 * P, 1), i32),
+                 ("geo_scratch", int(lib.tsd_geometry_scratch_ints(N, P)), i32),
+                 ("pos_work", 3 * max(N, 1), f32),  # the loop's in-place positions
+                 ("scratch", ((P + 63) // 64) * 64 + 3 * N + 128, f32)]
+        arena = _ZeroArena(dev, sum(_ZeroArena.need(n, dt) for _, n, dt in zeros) + 5 * EdgeList.zero_bytes(N))
+        for name, n, dt in zeros:
+            setattr(self, name, arena.take(n, dt))
+        self.pos_work = self.pos_work.view(max(N, 1), 3)
         self.atom_type = atom_type.to(torch.int64).contiguous()
         self.r_feat = r_feat.to(torch.int64).contiguous()
         self.p_feat = p_feat.to(torch.int64).contiguous()
@@ -177,23 +214,18 @@ class DeviceBatch:
         self.status_pending = True
         if not defer_status:
             self.check_status()
-        self.enc = EdgeList(N, P, dev)      # directed lists: the reference's edge_index order
-        self.out = EdgeList(N, P, dev)
-        self.enc_u = EdgeList(N, P // 2, dev)  # undirected (src < dst) lists the per-edge MLPs run on
-        self.out_u = EdgeList(N, P // 2, dev)
-        self.diff_u = EdgeList(N, P // 2, dev)
-        self.attr_row = torch.zeros(max(P // 2, 1), **i32)
-        self.pair2out = torch.zeros(max(P, 1), **i32)
-        self.pair2u = torch.zeros(max(2 * P, 1), **i32)
-        self.geo_scratch = torch.zeros(lib.tsd_geometry_scratch_ints(N, P), **i32)
+        raw = _ZeroArena(dev, 2 * EdgeList.raw_bytes(P) + 3 * EdgeList.raw_bytes(P // 2), zero=False)
+        self.enc = EdgeList(N, P, dev, arena, raw)      # directed lists: the reference's edge_index order
+        self.out = EdgeList(N, P, dev, arena, raw)
+        self.enc_u = EdgeList(N, P // 2, dev, arena, raw)  # undirected (src < dst) lists the per-edge MLPs run on
+        self.out_u = EdgeList(N, P // 2, dev, arena, raw)
+        self.diff_u = EdgeList(N, P // 2, dev, arena, raw)
         self.workspace = None
         self.edge_inv = None
         self.z = None
         self._z_key = None
         self.geo_gen = 0  # bumped whenever the edge lists are rebuilt (saved training contexts check it)
-        self.pos_work = torch.zeros(max(N, 1), 3, dtype=torch.float32, device=dev)  # the loop's in-place positions
         self._plans = {}  # (kind, clip, clip_pos) -> tsd_sampler_plan* of the bound checkpoints
-        self.scratch = torch.zeros(((P + 63) // 64) * 64 + 3 * N + 128, dtype=torch.float32, device=dev)
 
     def check_status(self, word=None):
         if not self.status_pending:
