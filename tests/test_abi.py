@@ -151,3 +151,32 @@ def test_forward_work_model_known_answers():
     assert w.bytes_aggregate == 1028.0 * E_enc + 2048.0 * N + 4
     assert w.flops_edge_embed + w.flops_blocks + w.flops_pair_output + w.flops_other == w.flops_executed
     assert lib.tsd_forward_work(C.byref(cfg), -1, 0, 0, 0, C.byref(w)) != 0
+
+
+def test_entry_points_run_inside_roctx_ranges(tmp_path):
+    """the library resolves roctxRangePushA / roctxRangePop from the process image (what `rocprofv3 --marker-trace`
+    preloads) and brackets its entry points with "tsd:<name>" ranges; without those symbols the ranges are no-ops
+    (every other test).  A stand-in roctx library, preloaded into a child process, records what it is called with."""
+    import subprocess
+    import sys
+    src = tmp_path / "fake_roctx.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stdlib.h>
+static int depth = 0;
+static void note(const char* s) { FILE* f = fopen(getenv("FAKE_ROCTX_LOG"), "a"); if (f) { fprintf(f, "%s\n", s); fclose(f); } }
+int roctxRangePushA(const char* m) { char b[256]; snprintf(b, sizeof b, "push %d %s", depth, m); note(b); return depth++; }
+int roctxRangePop(void) { char b[64]; snprintf(b, sizeof b, "pop %d", --depth); note(b); return depth; }
+''')
+    so = tmp_path / "libfake_roctx.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-O1", str(src), "-o", str(so)], check=True)
+    log = tmp_path / "ranges.log"
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from tsdiff_amd import _lib, engine, synth; "
+            "lib = _lib.load(); cfg = engine.make_cfg(synth.DEFAULT_MODEL_CONFIG); "
+            "rc = lib.tsd_pack_weights(C.byref(cfg), None, None, None); print('rc', rc)" % str(ROOT))
+    env = dict(os.environ, LD_PRELOAD=str(so), FAKE_ROCTX_LOG=str(log))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "rc -" in out.stdout, out.stdout + out.stderr   # null pointers: an error code, no crash
+    lines = log.read_text().split("\n")
+    assert "push 0 tsd:pack_weights" in lines and "pop 0" in lines
+    assert sum(l.startswith("push") for l in lines) == sum(l.startswith("pop") for l in lines)

@@ -154,7 +154,10 @@ __global__ __launch_bounds__(256) void wgrad_naive_kernel(int rows, int in, int 
 // S partial [out,in] blocks are then summed in split order by wgrad_reduce_kernel (deterministic).
 // A operand = dY^T: lane (i = out, k = row) reads dYs[row][out] -- consecutive lanes, consecutive words.
 // ---------------------------------------------------------------------------------------------
-constexpr int WG_T = 32;            // rows per tile
+#ifndef TSD_WG_T
+#define TSD_WG_T 32
+#endif
+constexpr int WG_T = TSD_WG_T;      // rows per tile
 constexpr int WG_LD = 128 + 4;      // LDS row stride (floats)
 // With `bias_part` != NULL the workgroups of in-block 0 also sum their dY tile's columns (the bias gradient):
 // partial [split][out], reduced together with the weight partials.
@@ -183,11 +186,12 @@ __device__ __forceinline__ void wgrad_body(int rows, int in, int out, int rows_p
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
-    // each thread stages 2 float4 of dY and 2 float4 of X per tile: (row = idx / 32, col4 = idx % 32)
-    f32x4 py[2], px[2];
+    // each thread stages NQ float4 of dY and NQ float4 of X per tile: (row = idx / 32, col4 = idx % 32)
+    constexpr int NQ = WG_T * 32 / WG_NT;
+    f32x4 py[NQ], px[NQ];
     auto prefetch = [&](int r0) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int idx = tid + q * WG_NT, r = idx >> 5, c4 = idx & 31;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             py[q] = z;
@@ -204,7 +208,7 @@ __device__ __forceinline__ void wgrad_body(int rows, int in, int out, int rows_p
     for (int r0 = r_begin; r0 < r_end; r0 += WG_T) {
         __syncthreads();  // previous tile fully consumed
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int idx = tid + q * WG_NT, r = idx >> 5, c4 = idx & 31;
             *reinterpret_cast<f32x4*>(sY + r * WG_LD + c4 * 4) = py[q];
             *reinterpret_cast<f32x4*>(sX + r * WG_LD + c4 * 4) = px[q];
