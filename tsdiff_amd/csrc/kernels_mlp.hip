@@ -4,7 +4,7 @@
 // (H/64 waves, each wave owns 64 output columns), keeps the whole chain of dense layers of
 // that tile on chip (activations in LDS, accumulators in AGPR/VGPR) and streams the packed
 // weights from L2 with 1-KiB coalesced wave loads.  Reference call sites are cited per kernel.
-#include "common.hpp"
+#include "train_internal.hpp"
 
 namespace tsd {
 
@@ -153,6 +153,124 @@ __global__ __launch_bounds__(2 * H) void edge_embed_kernel(EdgeEmbedW w, tsd_edg
             if (ee < E) edge_attr[(size_t)ee * H + col] = acc[0][cb][r] + b;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The edge embedding's backward chain for one tile of 32 embedded edges (the adjoint of edge_embed_kernel;
+// condensenc.py:156-176, edge.py:58-68 backwards), both lists in one launch like the forward:
+//   dc0 = (d_ea . W_cat1) * swish'(c0)                    -> global (weight gradient of edge_cat.0), LDS
+//   dc  = dc0 . W_cat0  [2H]                               -> global (bond-embedding gradient)
+//   de  = dc_lo * emb[type_r] + dc_hi * emb[type_p]        -> global (weight gradient of mlp.1), LDS
+//   dl0 = (de . W_mlp1) * swish'(l0)                       -> global (weight gradient of mlp.0)
+// Weights in the dgrad layout.  The weight / embedding-table gradients are separate (row-split) launches.
+// ---------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(2 * H) void embed_bwd_kernel(EmbedBwdList la, int tiles_a, EmbedBwdList lb,
+                                                         const float* __restrict__ bond_emb,
+                                                         const float* __restrict__ W1t, const float* __restrict__ W0t,
+                                                         const float* __restrict__ Wmt) {
+    constexpr int LDA = H + 4, NT = 2 * H, C4 = H / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* buf = smem;
+    int* s_tr = reinterpret_cast<int*>(smem + T * LDA);
+    int* s_tp = s_tr + T;
+    const bool second = (int)blockIdx.x >= tiles_a;
+    const EmbedBwdList& L = second ? lb : la;
+    const int E = *L.e.count;
+    const int e0 = (second ? (int)blockIdx.x - tiles_a : (int)blockIdx.x) * T;
+    if (e0 >= E) return;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int col0 = (tid >> 6) * 32, col = col0 + l31;
+    const int nrows = min(T, E - e0);
+    if (tid < T) {
+        const bool v = tid < nrows;
+        s_tr[tid] = v ? (int)L.e.type_r[e0 + tid] : 0;
+        s_tp[tid] = v ? (int)L.e.type_p[e0 + tid] : 0;
+    }
+    {
+        constexpr int NIT = T * C4 / NT;
+        static_assert(T * C4 % NT == 0, "tile / block mismatch");
+        f32x4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+            v[it] = *reinterpret_cast<const f32x4*>(L.d_ea + (size_t)(e0 + min(r, nrows - 1)) * H + c4 * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = r < nrows ? v[it] : z;
+        }
+    }
+    __syncthreads();
+    f32x16 acc[1][1], acc2[1][1];
+    zero_acc(acc);
+    gemm_tile<1, 1, H>(buf, LDA, W1t, H, col0, acc);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi);
+        float v = 0.0f;
+        if (row < nrows) {
+            const size_t o = (size_t)(e0 + row) * H + col;
+            v = acc[0][0][r] * act_deriv(0, L.c0[o]);
+            L.dc0[o] = v;
+        }
+        buf[row * LDA + col] = v;
+    }
+    __syncthreads();
+    zero_acc(acc);
+    zero_acc(acc2);
+    gemm_tile<1, 1, H>(buf, LDA, W0t, 2 * H, col0, acc);       // d(e * emb[type_r]) columns
+    gemm_tile<1, 1, H>(buf, LDA, W0t, 2 * H, col0 + H, acc2);  // d(e * emb[type_p]) columns
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi);
+        float v = 0.0f;
+        if (row < nrows) {
+            const float lo = acc[0][0][r], hh = acc2[0][0][r];
+            L.dc[(size_t)(e0 + row) * 2 * H + col] = lo;
+            L.dc[(size_t)(e0 + row) * 2 * H + H + col] = hh;
+            v = lo * bond_emb[s_tr[row] * H + col] + hh * bond_emb[s_tp[row] * H + col];
+            L.de[(size_t)(e0 + row) * H + col] = v;
+        }
+        buf[row * LDA + col] = v;
+    }
+    __syncthreads();
+    zero_acc(acc);
+    gemm_tile<1, 1, H>(buf, LDA, Wmt, H, col0, acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi);
+        if (row < nrows) {
+            const size_t o = (size_t)(e0 + row) * H + col;
+            L.dl0[o] = acc[0][0][r] * act_deriv(0, L.l0[o]);
+        }
+    }
+}
+
+int launch_embed_bwd(int H, int rows_a, const EmbedBwdList& la, int rows_b, const EmbedBwdList& lb, const float* bond_emb,
+                     const float* W1t, const float* W0t, const float* Wmt, hipStream_t st) {
+    const int tiles_a = (rows_a + T - 1) / T, tiles_b = (rows_b + T - 1) / T;
+    if (tiles_a + tiles_b == 0) return TSD_OK;
+    const size_t lds = (size_t)(T * (H + 4)) * 4 + 2 * T * sizeof(int);
+#define TSD_EB(HH)                                                                                                  \
+    {                                                                                                               \
+        static DeviceOnce once;                                                                                     \
+        int r = allow_lds(embed_bwd_kernel<HH>, lds, once);                                                         \
+        if (r) return r;                                                                                            \
+        hipLaunchKernelGGL(embed_bwd_kernel<HH>, dim3(tiles_a + tiles_b), dim3(2 * HH), lds, st, la, tiles_a, lb,    \
+                           bond_emb, W1t, W0t, Wmt);                                                                \
+    }
+    if (H == 128) TSD_EB(128) else if (H == 256) TSD_EB(256) else {
+        set_error("embed_bwd: hidden=%d has no MFMA instance", H);
+        return TSD_ERR_INVALID;
+    }
+#undef TSD_EB
+    TSD_LAUNCH_CHECK("embed_bwd");
+    return TSD_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -48,6 +48,14 @@ int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, c
                     float* dX, float* dW, float* db, int flags, LinEpi epi, float* scratch, size_t scratch_floats,
                     hipStream_t st);
 size_t linear_scratch_floats(int in, int out);
+// one list of the edge embedding's backward chain (kernels_mlp.hip::embed_bwd_kernel): rows of [.,H] except dc [.,2H]
+struct EmbedBwdList {
+    tsd_edges e;
+    const float *d_ea, *c0, *l0;
+    float *dc0, *dc, *de, *dl0;
+};
+int launch_embed_bwd(int H, int rows_a, const EmbedBwdList& la, int rows_b, const EmbedBwdList& lb, const float* bond_emb,
+                     const float* W1t, const float* W0t, const float* Wmt, hipStream_t st);
 int launch_block_bwd(int H, int N, int first, int last, tsd_edges enc, const float* Wf, const float* dagg_in,
                      const float* dh_up, const float* w_lin1_t, const float* w_lin_t, const float* w_lin2_t,
                      const float* x2_prev, float* dx1, float* dh, float* dx2_prev, float* dagg_prev, int filter_rows,

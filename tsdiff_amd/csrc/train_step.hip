@@ -99,6 +99,7 @@ struct Work {
     float *dhs, *dx2s, *dx1s;      // [(L+1), N, H], [L, N, H], [L, N, H]: the node-level dY of every block (batched wgrad)
     float* wpart;                  // split partials of the batched wgrads (node level, then filter level)
     float *dWfs, *df0s;            // [L, PU, H] each: the filter MLP's dY of every block (batched wgrad)
+    float *e_dc0, *e_dc, *e_de, *e_dl0;  // [2 PU, H] ([2 PU, 2H] for e_dc): the edge embedding's dY, rows as `ea`
     size_t total;
 };
 
@@ -159,6 +160,10 @@ Work carve(const tsd_model_cfg& c, int N, size_t PU, float* base) {
     }
     w.dWfs = take(H % 128 == 0 ? L * PU * H : 0);
     w.df0s = take(H % 128 == 0 ? L * PU * H : 0);
+    w.e_dc0 = take(H % 128 == 0 ? 2 * PU * H : 0);
+    w.e_dc = take(H % 128 == 0 ? 2 * PU * 2 * H : 0);
+    w.e_de = take(H % 128 == 0 ? 2 * PU * H : 0);
+    w.e_dl0 = take(H % 128 == 0 ? 2 * PU * H : 0);
     w.total = o;
     return w;
 }
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(256) void emb_mul2_bwd_kernel(int rows, int H, int 
             const int a = min((int)tr[r], ET - 1), b = min((int)tp[r], ET - 1);
             const float glo = dc[(size_t)r * 2 * H + c], ghi = dc[(size_t)r * 2 * H + H + c];
             const float ev = e[(size_t)r * H + c];
-            de[(size_t)r * H + c] = glo * emb[(size_t)a * H + c] + ghi * emb[(size_t)b * H + c];
+            if (de) de[(size_t)r * H + c] = glo * emb[(size_t)a * H + c] + ghi * emb[(size_t)b * H + c];
             acc[w][a][lane] += glo * ev;  // private to (wave, lane): plain read-modify-write
             acc[w][b][lane] += ghi * ev;
         }
@@ -464,6 +469,37 @@ int embed_bwd(const Ctx& x, const tsd_edges& lst, int E, const EmbedSave& s, con
     TSD_TRY(x.lin_bwd(E, H, H, s.s0, x.R.emlp_w1, (long)x.R.emlp_b1, tB, tA, false, 0, s.l0));     // dl0
     TSD_TRY(x.lin_bwd(E, 1, H, lst.dist, x.R.emlp_w0, (long)x.R.emlp_b0, tA, nullptr, false));
     TSD_LAUNCH_CHECK("embed_bwd");
+    return TSD_OK;
+}
+
+// MFMA sizes: the dgrad chain of BOTH lists in one tile-kernel launch (launch_embed_bwd), then the weight / table
+// gradients per list from the dY it wrote.  d_ea: [2 PU, H], rows as the edge-attribute matrix.
+int embed_bwd_fused(const Ctx& x, const tsd_geometry& g, const float* d_ea) {
+    const int H = x.H, PU = x.PU;
+    const Work& w = x.w;
+    const size_t o1 = (size_t)PU * H, o2 = (size_t)PU * 2 * H;
+    const EmbedBwdList la{g.enc_u, d_ea, w.emb.c0, w.emb.l0, w.e_dc0, w.e_dc, w.e_de, w.e_dl0};
+    const EmbedBwdList lb{g.diff_u, d_ea + o1, w.emb.c0 + o1, w.emb.l0 + o1, w.e_dc0 + o1, w.e_dc + o2, w.e_de + o1, w.e_dl0 + o1};
+    TSD_TRY(launch_embed_bwd(H, x.Eu, la, x.Ed, lb, x.raw + x.R.bond_emb, w.pack_t + x.R.ecat_w1, w.pack_t + x.R.ecat_w0,
+                             w.pack_t + x.R.emlp_w1, x.st));
+    for (int k = 0; k < 2; ++k) {
+        const int E = k ? x.Ed : x.Eu;
+        if (E == 0) continue;
+        const tsd_edges& lst = k ? g.diff_u : g.enc_u;
+        const size_t r1 = k ? o1 : 0, r2 = k ? o2 : 0;
+        // weight gradients only (dX == NULL): X, dY per layer
+        TSD_TRY(x.lin_bwd(E, H, H, w.emb.s1 + r1, x.R.ecat_w1, (long)x.R.ecat_b1, d_ea + r1, nullptr, false));
+        TSD_TRY(x.lin_bwd(E, 2 * H, H, w.emb.c + r2, x.R.ecat_w0, (long)x.R.ecat_b0, w.e_dc0 + r1, nullptr, false));
+        const int chunks = (E + 255) / 256 < 512 ? (E + 255) / 256 : 512;
+        hipLaunchKernelGGL(emb_mul2_bwd_kernel, dim3((H + 63) / 64, chunks), dim3(256), 0, x.st, E, H,
+                           (E + chunks - 1) / chunks, w.emb.e + r1, x.raw + x.R.bond_emb, lst.type_r, lst.type_p,
+                           w.e_dc + r2, (float*)nullptr, w.scratch);
+        hipLaunchKernelGGL(emb_grad_reduce_kernel, dim3(nblk(ET * H)), dim3(256), 0, x.st, chunks, ET * H, w.scratch,
+                           x.grad + x.R.bond_emb);
+        TSD_TRY(x.lin_bwd(E, H, H, w.emb.s0 + r1, x.R.emlp_w1, (long)x.R.emlp_b1, w.e_de + r1, nullptr, false));
+        TSD_TRY(x.lin_bwd(E, 1, H, lst.dist, x.R.emlp_w0, (long)x.R.emlp_b0, w.e_dl0 + r1, nullptr, false));
+    }
+    TSD_LAUNCH_CHECK("embed_bwd_fused");
     return TSD_OK;
 }
 
@@ -702,8 +738,12 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
         }
     }
     const float* dz = dh_cur;  // d loss / d h_0
-    if (Eu > 0) TSD_TRY(embed_bwd(x, g.enc_u, Eu, w.emb, w.d_ea));
-    if (Ed > 0) TSD_TRY(embed_bwd(x, g.diff_u, Ed, embed_rows(w.emb, (size_t)PU, (size_t)H), w.d_ea + EH));
+    if (batch_wg) {
+        TSD_TRY(embed_bwd_fused(x, g, w.d_ea));
+    } else {
+        if (Eu > 0) TSD_TRY(embed_bwd(x, g.enc_u, Eu, w.emb, w.d_ea));
+        if (Ed > 0) TSD_TRY(embed_bwd(x, g.diff_u, Ed, embed_rows(w.emb, (size_t)PU, (size_t)H), w.d_ea + EH));
+    }
     // node embedding: dz = dh
     hipLaunchKernelGGL(node_embed_bwd_kernel, dim3(nblk((int64_t)N * (H / 2))), dim3(256), 0, st, N, H / 2, dz, w.nA,
                        w.nB);
