@@ -274,6 +274,97 @@ int launch_embed_bwd(int H, int rows_a, const EmbedBwdList& la, int rows_b, cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// The pair MLP's backward chain for one tile of 32 undirected out edges (the adjoint of pair_output_kernel;
+// common.py:226-229 backwards):
+//   dg1 = ds * w2 * swish'(g1)          [H/2]  -> global (weight gradient of layers.1), LDS
+//   dg0 = (dg1 . W1) * swish'(g0)       [H]    -> global (weight gradient of layers.0), LDS
+//   dhp = dg0 . W0                      [2H]:  left half dp -> global [rows,H] (adjoint of h_i * h_j),
+//                                               right half -> row attr_row[e] of the edge-attribute gradient
+// ---------------------------------------------------------------------------------------------
+template <int H>
+__global__ __launch_bounds__(2 * H) void pair_bwd_kernel(tsd_edges e, const int32_t* __restrict__ attr_row,
+                                                        const float* __restrict__ ds, const float* __restrict__ w2,
+                                                        const float* __restrict__ g1, const float* __restrict__ g0,
+                                                        const float* __restrict__ W1t, const float* __restrict__ W0t,
+                                                        float* __restrict__ dg1, float* __restrict__ dg0,
+                                                        float* __restrict__ dp, float* __restrict__ d_ea) {
+    constexpr int LDA = H + 4, NT = 2 * H, HH = H / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* buf = smem;
+    float* s_ds = smem + T * LDA;
+    int* s_row = reinterpret_cast<int*>(s_ds + T);
+    const int E = *e.count;
+    const int e0 = blockIdx.x * T;
+    if (e0 >= E) return;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int col0 = (tid >> 6) * 32, col = col0 + l31;
+    const int nrows = min(T, E - e0);
+    if (tid < T) {
+        const bool v = tid < nrows;
+        s_ds[tid] = v ? ds[e0 + tid] : 0.0f;
+        s_row[tid] = v ? attr_row[e0 + tid] : 0;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < T * HH; idx += NT) {
+        const int r = idx / HH, c = idx % HH;
+        float v = 0.0f;
+        if (r < nrows) {
+            const size_t o = (size_t)(e0 + r) * HH + c;
+            v = s_ds[r] * w2[c] * act_deriv(0, g1[o]);
+            dg1[o] = v;
+        }
+        buf[r * LDA + c] = v;
+    }
+    __syncthreads();
+    f32x16 acc[1][1], acc2[1][1];
+    zero_acc(acc);
+    gemm_tile<1, 1, HH>(buf, LDA, W1t, H, col0, acc);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi);
+        float v = 0.0f;
+        if (row < nrows) {
+            const size_t o = (size_t)(e0 + row) * H + col;
+            v = acc[0][0][r] * act_deriv(0, g0[o]);
+            dg0[o] = v;
+        }
+        buf[row * LDA + col] = v;
+    }
+    __syncthreads();
+    zero_acc(acc);
+    zero_acc(acc2);
+    gemm_tile<1, 1, H>(buf, LDA, W0t, 2 * H, col0, acc);
+    gemm_tile<1, 1, H>(buf, LDA, W0t, 2 * H, col0 + H, acc2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi);
+        if (row < nrows) {
+            dp[(size_t)(e0 + row) * H + col] = acc[0][0][r];
+            d_ea[(size_t)s_row[row] * H + col] = acc2[0][0][r];  // every out edge owns its attribute row
+        }
+    }
+}
+
+int launch_pair_bwd(int H, int rows, tsd_edges e, const int32_t* attr_row, const float* ds, const float* w2,
+                    const float* g1, const float* g0, const float* W1t, const float* W0t, float* dg1, float* dg0,
+                    float* dp, float* d_ea, hipStream_t st) {
+    if (rows == 0) return TSD_OK;
+    const size_t lds = (size_t)(T * (H + 4) + T) * 4 + T * sizeof(int);
+    if (H != 256) {
+        set_error("pair_bwd: hidden=%d has no MFMA instance", H);
+        return TSD_ERR_INVALID;
+    }
+    static DeviceOnce once;
+    int r = allow_lds(pair_bwd_kernel<256>, lds, once);
+    if (r) return r;
+    hipLaunchKernelGGL(pair_bwd_kernel<256>, dim3((rows + T - 1) / T), dim3(512), lds, st, e, attr_row, ds, w2, g1, g0,
+                       W1t, W0t, dg1, dg0, dp, d_ea);
+    TSD_LAUNCH_CHECK("pair_bwd");
+    return TSD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // A9 / T5 fused: W = nn2(ssp(nn0(edge_attr))) * C ; msg = x1[dst] * W ; agg[src] += msg
 // reference models/encoder/schnet.py:88-107 (CFConv.forward/message, aggr="add").
 // The reference aggregates messages x1[edge_index[0]] * W at edge_index[1]; the extended edge set

@@ -662,14 +662,25 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
     if (Eo > 0) {
         float* ds = w.d_target;  // [Eo] (d_target itself is no longer needed)
         TSD_TRY(tsd_eq_und_bwd(Eo, g.out_u, pos, w.nA, ds, stream));
-        TSD_TRY(x.lin_bwd(Eo, H / 2, 1, w.gs1, x.R.out_w2, (long)x.R.out_b2, ds, w.eB, false, 0, w.g1));   // dg1
-        TSD_TRY(x.lin_bwd(Eo, H, H / 2, w.gs0, x.R.out_w1, (long)x.R.out_b1, w.eB, w.eA, false, 0, w.g0)); // dg0
-        TSD_TRY(x.lin_bwd(Eo, 2 * H, H, w.hp, x.R.out_w0, (long)x.R.out_b0, w.eA, w.eB, false));           // dhp [Eo,2H]
-        // dp (left half) -> dh ; d edge_attr_out (right half) -> the out edges' rows of the attribute gradient
-        float* dp = w.eA;
-        hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.eB, 2 * H, dp, H);
-        hipLaunchKernelGGL(scatter_rows_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.eB + H,
-                           2 * H, g.attr_row, w.d_ea);
+        float* dp = w.eA;  // [Eo,H]
+        if (H == 256) {
+            // the three dgrads, the split of dhp and the scatter of its right half as ONE tile kernel; the weight
+            // gradients from the dY it wrote
+            float *dg1 = w.eA + (size_t)PU * H, *dg0 = w.eB;  // [Eo,H/2] behind dp, [Eo,H]
+            TSD_TRY(launch_pair_bwd(H, Eo, g.out_u, g.attr_row, ds, raw + x.R.out_w2, w.g1, w.g0, w.pack_t + x.R.out_w1,
+                                    w.pack_t + x.R.out_w0, dg1, dg0, dp, w.d_ea, st));
+            TSD_TRY(x.lin_bwd(Eo, H / 2, 1, w.gs1, x.R.out_w2, (long)x.R.out_b2, ds, nullptr, false));
+            TSD_TRY(x.lin_bwd(Eo, H, H / 2, w.gs0, x.R.out_w1, (long)x.R.out_b1, dg1, nullptr, false));
+            TSD_TRY(x.lin_bwd(Eo, 2 * H, H, w.hp, x.R.out_w0, (long)x.R.out_b0, dg0, nullptr, false));
+        } else {
+            TSD_TRY(x.lin_bwd(Eo, H / 2, 1, w.gs1, x.R.out_w2, (long)x.R.out_b2, ds, w.eB, false, 0, w.g1));   // dg1
+            TSD_TRY(x.lin_bwd(Eo, H, H / 2, w.gs0, x.R.out_w1, (long)x.R.out_b1, w.eB, w.eA, false, 0, w.g0)); // dg0
+            TSD_TRY(x.lin_bwd(Eo, 2 * H, H, w.hp, x.R.out_w0, (long)x.R.out_b0, w.eA, w.eB, false));           // dhp [Eo,2H]
+            // dp (left half) -> dh ; d edge_attr_out (right half) -> the out edges' rows of the attribute gradient
+            hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.eB, 2 * H, dp, H);
+            hipLaunchKernelGGL(scatter_rows_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.eB + H,
+                               2 * H, g.attr_row, w.d_ea);
+        }
         TSD_TRY(tsd_pair_product_bwd(N, H, g.out, dp, w.h + (size_t)L * NH, w.dh, stream));
     }
     // The node-level layers (N rows) keep their dY per block and take their weight gradients in ONE batched launch
