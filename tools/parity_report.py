@@ -48,3 +48,47 @@ print("|---|---:|---:|---:|---:|---:|")
 for r in rows:
     print(f"| {r[0]} | {r[1]} | {r[2]:.2e} | {r[3]:.2e} | {r[4]:.2e} | {r[5]:.2e} |")
 print("\nThe HIP path's distance from the fp64 truth is of the same size as the fp32 CPU evaluation's own.")
+
+# ---- training step: every parameter gradient of the fused step against the oracle's autograd (fp32 and fp64) ----
+grows = []
+for seed in range(3):
+    sd_np = synth.synth_state_dict(cfg, seed)
+    model = get_model(AttrDict(cfg))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=False)
+    model = model.to(dev).train()
+    b = synth.wb97xd3_like_batch(12, seed=300 + seed)
+    t = {k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}
+    t["pos"] = t["pos"] * 1.5
+    gen = torch.Generator().manual_seed(seed)
+    ts, pn = torch.randint(0, 5000, (12,), generator=gen), torch.randn(t["pos"].shape, generator=gen)
+    g = {k: v.to(dev) for k, v in t.items()}
+    loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"],
+                          g["num_nodes_per_graph"], 12, _time_step=ts.to(dev), _pos_noise=pn.to(dev))
+    loss.mean().backward()
+    P = dict(model.named_parameters())
+    res = {}
+    for name, dt in (("fp32", torch.float32), ("fp64", torch.float64)):
+        osd = O.to_torch_state(sd_np, dt) if dt == torch.float64 else O.to_torch_state(sd_np)
+        for v in osd.values():
+            v.requires_grad_(True)
+        ol = O.get_loss(osd, cfg, t["atom_type"], t["r_feat"], t["p_feat"], t["pos"].to(dt), t["bond_index"], t["bond_type"],
+                        t["batch"], b["num_nodes_per_graph"], ts, pn.to(dt))
+        ol.mean().backward()
+        res[name] = {k: v.grad.double().numpy() for k, v in osd.items() if v.grad is not None and k not in ("betas", "alphas")}
+    worst32 = worst64 = worst_o = 0.0
+    wk = ""
+    for k, g64 in res["fp64"].items():
+        sc = np.abs(g64).max() + 1e-300
+        h = P[k].grad.double().cpu().numpy()
+        e64 = np.abs(h - g64).max() / sc
+        if e64 > worst64:
+            worst64, wk = e64, k
+        worst32 = max(worst32, np.abs(h - res["fp32"][k]).max() / sc)
+        worst_o = max(worst_o, np.abs(res["fp32"][k] - g64).max() / sc)
+    grows.append((seed, len(res["fp64"]), worst32, worst64, worst_o, wk))
+print("\n# parameter-gradient error statistics, fused training step vs the oracle's autograd (12-graph batches)\n")
+print("| weights seed | tensors | worst tensor: max abs(HIP - oracle fp32) / max abs(ref) | worst: HIP vs oracle fp64 | "
+      "worst: oracle fp32 vs fp64 | tensor of the worst HIP-vs-fp64 error |")
+print("|---|---:|---:|---:|---:|---|")
+for r in grows:
+    print(f"| {r[0]} | {r[1]} | {r[2]:.2e} | {r[3]:.2e} | {r[4]:.2e} | `{r[5]}` |")
