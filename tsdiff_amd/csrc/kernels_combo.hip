@@ -584,50 +584,61 @@ __device__ __forceinline__ void filter_bwd_role(const FilterBwd& f, int tile, fl
         s_c[tid] = v ? cutoff_weight(f.eu.dist[e0 + tid], f.cutoff, f.smooth) : 0.0f;
     }
     __syncthreads();
-    {
+    {   // every load of a thread in flight together (rows past the end are clamped; a guarded load per iteration
+        // makes the compiler wait for each one: 4 serial L2 round trips per tile)
         constexpr int NIT = TT * C4 / NT;
         static_assert(TT * C4 % NT == 0, "tile / block mismatch");
+        f32x4 di[NIT], dj[NIT], xi[NIT], xj[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = min(idx / C4, nrows - 1), c4 = idx % C4;
+            const size_t oi = (size_t)s_i[r] * H + c4 * 4, oj = (size_t)s_j[r] * H + c4 * 4;
+            di[it] = *reinterpret_cast<const f32x4*>(f.dagg + oi);
+            dj[it] = *reinterpret_cast<const f32x4*>(f.dagg + oj);
+            xi[it] = *reinterpret_cast<const f32x4*>(f.x1 + oi);
+            xj[it] = *reinterpret_cast<const f32x4*>(f.x1 + oj);
+        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (r < nrows) {
-                const size_t oi = (size_t)s_i[r] * H + c4 * 4, oj = (size_t)s_j[r] * H + c4 * 4;
-                const f32x4 di = *reinterpret_cast<const f32x4*>(f.dagg + oi), dj = *reinterpret_cast<const f32x4*>(f.dagg + oj);
-                const f32x4 xi = *reinterpret_cast<const f32x4*>(f.x1 + oi), xj = *reinterpret_cast<const f32x4*>(f.x1 + oj);
-                v = (di * xj + dj * xi) * s_c[r];
+                v = (di[it] * xj[it] + dj[it] * xi[it]) * s_c[r];
                 *reinterpret_cast<f32x4*>(f.dWf + (size_t)(e0 + r) * H + c4 * 4) = v;
             }
             *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = v;
         }
     }
     __syncthreads();
+    const int col = col0 + l31;
+    // the pre-activations (and, below, the old attribute-gradient values) of this lane's outputs are requested
+    // BEFORE the GEMM that needs them afterwards: their latency hides under its MFMAs
+    float pre[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pre[r] = f.f0[(size_t)(e0 + min(acc_row(r, hi), nrows - 1)) * H + col];
     f32x16 acc[1][1];
     zero_acc(acc);
     gemm_tile<1, 1, H>(buf, LDA, f.W2t, H, col0, acc);
     __syncthreads();
-    const int col = col0 + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = acc_row(r, hi);
         float v = 0.0f;
         if (row < nrows) {
-            const size_t o = (size_t)(e0 + row) * H + col;
-            v = acc[0][0][r] * act_deriv(1, f.f0[o]);
-            f.df0[o] = v;
+            v = acc[0][0][r] * act_deriv(1, pre[r]);
+            f.df0[(size_t)(e0 + row) * H + col] = v;
         }
         buf[row * LDA + col] = v;
     }
     __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pre[r] = f.d_ea[(size_t)(e0 + min(acc_row(r, hi), nrows - 1)) * H + col];
     zero_acc(acc);
     gemm_tile<1, 1, H>(buf, LDA, f.W0t, H, col0, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = acc_row(r, hi);
-        if (row < nrows) {
-            const size_t o = (size_t)(e0 + row) * H + col;
-            f.d_ea[o] += acc[0][0][r];
-        }
+        if (row < nrows) f.d_ea[(size_t)(e0 + row) * H + col] = pre[r] + acc[0][0][r];
     }
 }
 
