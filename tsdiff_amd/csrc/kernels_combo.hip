@@ -482,10 +482,17 @@ __device__ __forceinline__ void node_bwd_role(const NodeBwd& a, int tile, float*
     const int col0 = wave * 32;
     const int nrows = min(TN, a.N - n0);
     f32x4 acc[CB16];
+    float pre[CB16][4];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if (!a.first) {
         aggregate_tile<H, true>(a.row_ptr, a.dst, a.umap, a.Wf, a.dagg_in, a.N, n0, buf, a.dx1);
         __syncthreads();
+        // (values the epilogues read are requested before the GEMM that precedes them, rows clamped: no guarded loads)
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                pre[cb][r] = a.dh_up[(size_t)(n0 + min(q * 4 + r, nrows - 1)) * H + col0 + cb * 16 + l15];
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) acc[cb] = zero4;
         gemm_tile16<CB16, H>(buf, LDA, a.w_lin1_t, H, col0, acc);
@@ -498,9 +505,8 @@ __device__ __forceinline__ void node_bwd_role(const NodeBwd& a, int tile, float*
                 const int row = q * 4 + r;
                 float v = 0.0f;
                 if (row < nrows) {
-                    const size_t o = (size_t)(n0 + row) * H + col;
-                    v = a.dh_up[o] + acc[cb][r];
-                    a.dh[o] = v;
+                    v = pre[cb][r] + acc[cb][r];
+                    a.dh[(size_t)(n0 + row) * H + col] = v;
                 }
                 buf[row * LDA + col] = v;
             }
@@ -516,6 +522,11 @@ __device__ __forceinline__ void node_bwd_role(const NodeBwd& a, int tile, float*
     if (a.last) return;
     __syncthreads();
 #pragma unroll
+    for (int cb = 0; cb < CB16; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            pre[cb][r] = a.x2_prev[(size_t)(n0 + min(q * 4 + r, nrows - 1)) * H + col0 + cb * 16 + l15];
+#pragma unroll
     for (int cb = 0; cb < CB16; ++cb) acc[cb] = zero4;
     gemm_tile16<CB16, H>(buf, LDA, a.w_lin_t, H, col0, acc);
     __syncthreads();
@@ -527,9 +538,8 @@ __device__ __forceinline__ void node_bwd_role(const NodeBwd& a, int tile, float*
             const int row = q * 4 + r;
             float v = 0.0f;
             if (row < nrows) {
-                const size_t o = (size_t)(n0 + row) * H + col;
-                v = acc[cb][r] * act_deriv(1, a.x2_prev[o]);
-                a.dx2_prev[o] = v;
+                v = acc[cb][r] * act_deriv(1, pre[cb][r]);
+                a.dx2_prev[(size_t)(n0 + row) * H + col] = v;
             }
             buf[row * LDA + col] = v;
         }

@@ -204,6 +204,10 @@ __global__ __launch_bounds__(2 * H) void embed_bwd_kernel(EmbedBwdList la, int t
         }
     }
     __syncthreads();
+    // (pre-activations are requested before the GEMM that precedes their use, rows clamped: no guarded loads)
+    float pre[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pre[r] = L.c0[(size_t)(e0 + min(acc_row(r, hi), nrows - 1)) * H + col];
     f32x16 acc[1][1], acc2[1][1];
     zero_acc(acc);
     gemm_tile<1, 1, H>(buf, LDA, W1t, H, col0, acc);
@@ -213,9 +217,8 @@ __global__ __launch_bounds__(2 * H) void embed_bwd_kernel(EmbedBwdList la, int t
         const int row = acc_row(r, hi);
         float v = 0.0f;
         if (row < nrows) {
-            const size_t o = (size_t)(e0 + row) * H + col;
-            v = acc[0][0][r] * act_deriv(0, L.c0[o]);
-            L.dc0[o] = v;
+            v = acc[0][0][r] * act_deriv(0, pre[r]);
+            L.dc0[(size_t)(e0 + row) * H + col] = v;
         }
         buf[row * LDA + col] = v;
     }
@@ -239,15 +242,14 @@ __global__ __launch_bounds__(2 * H) void embed_bwd_kernel(EmbedBwdList la, int t
         buf[row * LDA + col] = v;
     }
     __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pre[r] = L.l0[(size_t)(e0 + min(acc_row(r, hi), nrows - 1)) * H + col];
     zero_acc(acc);
     gemm_tile<1, 1, H>(buf, LDA, Wmt, H, col0, acc);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = acc_row(r, hi);
-        if (row < nrows) {
-            const size_t o = (size_t)(e0 + row) * H + col;
-            L.dl0[o] = acc[0][0][r] * act_deriv(0, L.l0[o]);
-        }
+        if (row < nrows) L.dl0[(size_t)(e0 + row) * H + col] = acc[0][0][r] * act_deriv(0, pre[r]);
     }
 }
 
@@ -305,17 +307,30 @@ __global__ __launch_bounds__(2 * H) void pair_bwd_kernel(tsd_edges e, const int3
         s_row[tid] = v ? attr_row[e0 + tid] : 0;
     }
     __syncthreads();
-    for (int idx = tid; idx < T * HH; idx += NT) {
-        const int r = idx / HH, c = idx % HH;
-        float v = 0.0f;
-        if (r < nrows) {
-            const size_t o = (size_t)(e0 + r) * HH + c;
-            v = s_ds[r] * w2[c] * act_deriv(0, g1[o]);
-            dg1[o] = v;
+    {   // dg1 tile: every load of a thread in flight together (rows clamped)
+        constexpr int NIT = T * HH / NT;
+        static_assert(T * HH % NT == 0, "tile / block mismatch");
+        float gv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = min(idx / HH, nrows - 1), c = idx % HH;
+            gv[it] = g1[(size_t)(e0 + r) * HH + c];
         }
-        buf[r * LDA + c] = v;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / HH, c = idx % HH;
+            float v = 0.0f;
+            if (r < nrows) {
+                v = s_ds[r] * w2[c] * act_deriv(0, gv[it]);
+                dg1[(size_t)(e0 + r) * HH + c] = v;
+            }
+            buf[r * LDA + c] = v;
+        }
     }
     __syncthreads();
+    float pre[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pre[r] = g0[(size_t)(e0 + min(acc_row(r, hi), nrows - 1)) * H + col];
     f32x16 acc[1][1], acc2[1][1];
     zero_acc(acc);
     gemm_tile<1, 1, HH>(buf, LDA, W1t, H, col0, acc);
@@ -325,9 +340,8 @@ __global__ __launch_bounds__(2 * H) void pair_bwd_kernel(tsd_edges e, const int3
         const int row = acc_row(r, hi);
         float v = 0.0f;
         if (row < nrows) {
-            const size_t o = (size_t)(e0 + row) * H + col;
-            v = acc[0][0][r] * act_deriv(0, g0[o]);
-            dg0[o] = v;
+            v = acc[0][0][r] * act_deriv(0, pre[r]);
+            dg0[(size_t)(e0 + row) * H + col] = v;
         }
         buf[row * LDA + col] = v;
     }
