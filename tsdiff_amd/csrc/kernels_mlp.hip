@@ -717,17 +717,33 @@ __global__ __launch_bounds__(2 * H) void pair_output_kernel(PairW w, tsd_edges e
         s_row[tid] = v ? (attr_row ? attr_row[e0 + tid] : e0 + tid) : 0;
     }
     __syncthreads();
-    {  // h_src * h_dst || edge_attr row -> LDS, float4 per lane, all loads of a lane independent
+    // the precomputed first-layer half of this lane's outputs is requested first: it arrives under the staging below
+    float pre_v[16];
+    if (pre) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            pre_v[r] = pre[(size_t)(e0 + min(acc_row(r, hi), nrows - 1)) * H + wave * 32 + l31];
+    }
+    {  // h_src * h_dst || edge_attr row -> LDS, float4 per lane, every load of a thread in flight together (rows past
+       // the end clamped; a guarded load per iteration makes the compiler wait for each one)
         constexpr int C4 = H / 4;
-#pragma unroll 2
-        for (int idx = tid; idx < T * C4; idx += 2 * H) {
-            const int r = idx / C4, c4 = idx % C4;
+        constexpr int NIT = T * C4 / (2 * H);
+        static_assert(T * C4 % (2 * H) == 0, "tile / block mismatch");
+        f32x4 hs[NIT], hd[NIT], bb[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 2 * H, r = min(idx / C4, nrows - 1), c4 = idx % C4;
+            hs[it] = *reinterpret_cast<const f32x4*>(h + (size_t)s_src[r] * H + c4 * 4);
+            hd[it] = *reinterpret_cast<const f32x4*>(h + (size_t)s_dst[r] * H + c4 * 4);
+            if (!pre) bb[it] = *reinterpret_cast<const f32x4*>(edge_attr + (size_t)s_row[r] * H + c4 * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 2 * H, r = idx / C4, c4 = idx % C4;
             f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
             if (r < nrows) {
-                const f32x4 hs = *reinterpret_cast<const f32x4*>(h + (size_t)s_src[r] * H + c4 * 4);
-                const f32x4 hd = *reinterpret_cast<const f32x4*>(h + (size_t)s_dst[r] * H + c4 * 4);
-                a = hs * hd;
-                if (!pre) b = *reinterpret_cast<const f32x4*>(edge_attr + (size_t)s_row[r] * H + c4 * 4);
+                a = hs[it] * hd[it];
+                if (!pre) b = bb[it];
             }
             *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = a;
             if (!pre) *reinterpret_cast<f32x4*>(buf + r * LDA + H + c4 * 4) = b;
@@ -749,10 +765,7 @@ __global__ __launch_bounds__(2 * H) void pair_output_kernel(PairW w, tsd_edges e
         const int col = col0 + l31;
         if (pre) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = acc_row(r, hi);
-                acc[0][0][r] = row < nrows ? pre[(size_t)(e0 + row) * H + col] : 0.0f;
-            }
+            for (int r = 0; r < 16; ++r) acc[0][0][r] = acc_row(r, hi) < nrows ? pre_v[r] : 0.0f;
         } else {
             zero_acc(acc);
             gemm_tile<1, 1, H>(buf + H, LDA, w.w0 + (size_t)H * H, H, col0, acc);
