@@ -842,6 +842,17 @@ int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, c
     return TSD_OK;
 }
 
+// dst[i] (+)= sum over the S partials part[s][i] in split order (S % 4 == 0): the reduction stage of every row-split
+// kernel of the training step (workgroup = 64 outputs x 4 split quarters)
+int launch_split_reduce(int64_t n, int S, const float* part, float* dst, int accumulate, hipStream_t st) {
+    if (n == 0) return TSD_OK;
+    TSD_REQUIRE(S > 0 && S % 4 == 0, "split reduce: S=%d", S);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, n, 0, S, part,
+                       (const float*)nullptr, dst, (float*)nullptr, accumulate);
+    TSD_LAUNCH_CHECK("split_reduce");
+    return TSD_OK;
+}
+
 // dW_k (+)= dY_k^T X_k (and db_k (+)= column sums of dY_k where db_k != NULL) for n equally shaped problems in two
 // launches; `part` holds n * S * (out * in + out) floats, S = wgrad_batch_splits(rows).
 int wgrad_batch_splits(int rows) { return rows >= 16384 ? 16 : 8; }

@@ -208,7 +208,7 @@ __global__ void node_embed_bwd_kernel(int N, int Hh, const float* __restrict__ d
 }
 // d atom_emb[a, c] = sum over the nodes with atom type a of dz[i, c], in node order, without atomics:
 // grid (100 embedding rows, node chunks); partial [chunk][100][Hh], summed in chunk order by the second kernel.
-constexpr int AE_CHUNKS = 16;
+constexpr int AE_CHUNKS = 64;
 __global__ void atom_emb_grad_kernel(int N, int Hh, const int64_t* __restrict__ atom, const float* __restrict__ dz,
                                      float* __restrict__ part) {
     const int a = blockIdx.x, chunk = blockIdx.y;
@@ -233,6 +233,12 @@ __global__ void atom_emb_grad_reduce_kernel(int n, const float* __restrict__ par
 // order, the four waves are combined in a fixed order into partial[chunk][ET][H], a second kernel sums the
 // chunks in order.  ET = 32 edge types: bond 1..21, 22 + hop - 1 for hop <= 7 (tsd_model_cfg orders are <= 7).
 constexpr int ET = 32;
+// row chunks of the embedding-table gradient: 16 rows per wave (the per-row LDS accumulation is a latency chain),
+// a multiple of 4 for the split reduction (chunks past the rows write zero partials)
+inline int emb_chunks(int E) {
+    const int c = (E + 63) / 64 < 512 ? (E + 63) / 64 : 512;
+    return (c + 3) & ~3;
+}
 __global__ __launch_bounds__(256) void emb_mul2_bwd_kernel(int rows, int H, int rows_per_wg,
                                                            const float* __restrict__ e, const float* __restrict__ emb,
                                                            const uint8_t* __restrict__ tr,
@@ -262,14 +268,6 @@ __global__ __launch_bounds__(256) void emb_mul2_bwd_kernel(int rows, int H, int 
         if (cc < H)
             part[((size_t)blockIdx.y * ET + ty) * H + cc] = (acc[0][ty][l] + acc[1][ty][l]) + (acc[2][ty][l] + acc[3][ty][l]);
     }
-}
-__global__ void emb_grad_reduce_kernel(int chunks, int n /* ET * H */, const float* __restrict__ part,
-                                       float* __restrict__ demb) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    float s = 0.0f;
-    for (int k = 0; k < chunks; ++k) s += part[(size_t)k * n + t];
-    demb[t] += s;
 }
 __global__ void copy2d_kernel(int64_t rows, int cols, const float* __restrict__ src, int lds_, float* __restrict__ dst,
                               int ldd) {
@@ -460,12 +458,11 @@ int embed_bwd(const Ctx& x, const tsd_edges& lst, int E, const EmbedSave& s, con
     float* tB = x.w.eB;             // [E,2H]
     TSD_TRY(x.lin_bwd(E, H, H, s.s1, x.R.ecat_w1, (long)x.R.ecat_b1, d_ea, tB, false, 0, s.c0));   // dc0
     TSD_TRY(x.lin_bwd(E, 2 * H, H, s.c, x.R.ecat_w0, (long)x.R.ecat_b0, tB, tA, false));           // dc [E,2H]
-    const int chunks = (E + 255) / 256 < 512 ? (E + 255) / 256 : 512;
+    const int chunks = emb_chunks(E);
     hipLaunchKernelGGL(emb_mul2_bwd_kernel, dim3((H + 63) / 64, chunks), dim3(256), 0, x.st, E, H,
                        (E + chunks - 1) / chunks, s.e, x.raw + x.R.bond_emb, lst.type_r, lst.type_p, tA, tB,
                        x.w.scratch);                                                                // de -> tB
-    hipLaunchKernelGGL(emb_grad_reduce_kernel, dim3(nblk(ET * H)), dim3(256), 0, x.st, chunks, ET * H, x.w.scratch,
-                       x.grad + x.R.bond_emb);  // rows [0, ET) of the [100, H] table
+    TSD_TRY(launch_split_reduce((int64_t)ET * H, chunks, x.w.scratch, x.grad + x.R.bond_emb, 1, x.st));  // rows [0, ET) of the [100, H] table
     TSD_TRY(x.lin_bwd(E, H, H, s.s0, x.R.emlp_w1, (long)x.R.emlp_b1, tB, tA, false, 0, s.l0));     // dl0
     TSD_TRY(x.lin_bwd(E, 1, H, lst.dist, x.R.emlp_w0, (long)x.R.emlp_b0, tA, nullptr, false));
     TSD_LAUNCH_CHECK("embed_bwd");
@@ -490,12 +487,11 @@ int embed_bwd_fused(const Ctx& x, const tsd_geometry& g, const float* d_ea) {
         // weight gradients only (dX == NULL): X, dY per layer
         TSD_TRY(x.lin_bwd(E, H, H, w.emb.s1 + r1, x.R.ecat_w1, (long)x.R.ecat_b1, d_ea + r1, nullptr, false));
         TSD_TRY(x.lin_bwd(E, 2 * H, H, w.emb.c + r2, x.R.ecat_w0, (long)x.R.ecat_b0, w.e_dc0 + r1, nullptr, false));
-        const int chunks = (E + 255) / 256 < 512 ? (E + 255) / 256 : 512;
+        const int chunks = emb_chunks(E);
         hipLaunchKernelGGL(emb_mul2_bwd_kernel, dim3((H + 63) / 64, chunks), dim3(256), 0, x.st, E, H,
                            (E + chunks - 1) / chunks, w.emb.e + r1, x.raw + x.R.bond_emb, lst.type_r, lst.type_p,
                            w.e_dc + r2, (float*)nullptr, w.scratch);
-        hipLaunchKernelGGL(emb_grad_reduce_kernel, dim3(nblk(ET * H)), dim3(256), 0, x.st, chunks, ET * H, w.scratch,
-                           x.grad + x.R.bond_emb);
+        TSD_TRY(launch_split_reduce((int64_t)ET * H, chunks, w.scratch, x.grad + x.R.bond_emb, 1, x.st));  // rows [0, ET) of the [100, H] table
         TSD_TRY(x.lin_bwd(E, H, H, w.emb.s0 + r1, x.R.emlp_w1, (long)x.R.emlp_b1, w.e_de + r1, nullptr, false));
         TSD_TRY(x.lin_bwd(E, 1, H, lst.dist, x.R.emlp_w0, (long)x.R.emlp_b0, w.e_dl0 + r1, nullptr, false));
     }
