@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(int rows, int in, int 
     __shared__ float sm[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int o = blockIdx.x * 64 + lane;
-    const int per = (rows + 63) / 64;
+    const int per = (rows + (int)gridDim.y - 1) / (int)gridDim.y;  // gridDim.y row chunks
     const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
     float acc[MAXIN];
 #pragma unroll
@@ -813,18 +813,20 @@ int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, c
             TSD_LAUNCH_CHECK("wgrad");
             db_done = db != nullptr;
         } else if ((in <= WS_MAX_IN || out == 1) && scratch && scratch_floats >= off_part + 64 * (size_t)out * in) {
-            // narrow layers; out == 1 is the in == 1 problem with dY and X swapped (same dW memory layout)
+            // narrow layers; out == 1 is the in == 1 problem with dY and X swapped (same dW memory layout).
+            // Every thread walks its row chunk serially (a latency chain): many rows get 256 chunks instead of 64.
             const bool swap = in > WS_MAX_IN;
             const int o2 = swap ? in : out, i2 = swap ? 1 : in;
+            const int chunks = (rows >= 8192 && scratch_floats >= off_part + 256 * (size_t)out * in) ? 256 : 64;
             float* part = scratch + off_part;
             if (i2 == 1)
-                hipLaunchKernelGGL(wgrad_small_kernel<1>, dim3((o2 + 63) / 64, 64), dim3(256), 0, st, rows, i2, o2,
+                hipLaunchKernelGGL(wgrad_small_kernel<1>, dim3((o2 + 63) / 64, chunks), dim3(256), 0, st, rows, i2, o2,
                                    swap ? X : dY, swap ? dY : X, part);
             else
-                hipLaunchKernelGGL(wgrad_small_kernel<WS_MAX_IN>, dim3((o2 + 63) / 64, 64), dim3(256), 0, st, rows, i2,
-                                   o2, swap ? X : dY, swap ? dY : X, part);
+                hipLaunchKernelGGL(wgrad_small_kernel<WS_MAX_IN>, dim3((o2 + 63) / 64, chunks), dim3(256), 0, st, rows,
+                                   i2, o2, swap ? X : dY, swap ? dY : X, part);
             const int64_t n = (int64_t)o2 * i2;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, n, 0, 64, part,
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, n, 0, chunks, part,
                                (const float*)nullptr, dW, (float*)nullptr, accW);
             TSD_LAUNCH_CHECK("wgrad_small");
         } else {
