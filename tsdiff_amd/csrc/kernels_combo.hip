@@ -708,6 +708,38 @@ int launch_block_bwd(int H, int N, int first, int last, tsd_edges enc, const flo
     return TSD_OK;
 }
 
+// out[i] = sum_{e in row i} x[dst e] * W[umap e] for every node, by the node role's gather code (tiles of TN nodes):
+// the adjoint of the pair product h_i * h_j w.r.t. h in the training step (W = d loss / d product on the undirected
+// out list, x = h; common.py:226-229 backwards)
+template <int H>
+__global__ __launch_bounds__(2 * H) void row_gather_kernel(int N, const int32_t* __restrict__ row_ptr,
+                                                           const int32_t* __restrict__ dst,
+                                                           const int32_t* __restrict__ umap, const float* __restrict__ W,
+                                                           const float* __restrict__ x, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    aggregate_tile<H, true>(row_ptr, dst, umap, W, x, N, blockIdx.x * TN, smem, out);
+}
+int launch_row_gather(int H, int N, tsd_edges e, const float* W, const float* x, float* out, hipStream_t st) {
+    if (N == 0) return TSD_OK;
+    const size_t lds = (size_t)TN * (H + 4) * 4;
+    const int tiles = (N + TN - 1) / TN;
+#define TSD_RG(HH)                                                                                              \
+    {                                                                                                           \
+        static DeviceOnce once;                                                                                 \
+        int r = allow_lds(row_gather_kernel<HH>, lds, once);                                                    \
+        if (r) return r;                                                                                        \
+        hipLaunchKernelGGL(row_gather_kernel<HH>, dim3(tiles), dim3(2 * HH), lds, st, N, e.row_ptr, e.dst, e.umap, \
+                           W, x, out);                                                                          \
+    }
+    if (H == 64) TSD_RG(64) else if (H == 128) TSD_RG(128) else if (H == 256) TSD_RG(256) else {
+        set_error("row_gather: hidden=%d unsupported", H);
+        return TSD_ERR_INVALID;
+    }
+#undef TSD_RG
+    TSD_LAUNCH_CHECK("row_gather");
+    return TSD_OK;
+}
+
 struct ComboStride {  // per-checkpoint strides (blockIdx.y = checkpoint of the ensemble)
     size_t w, nh, ea, wf, pre;
     int node_stride;  // 1: node tiles are the first workgroups; S > 1 (odd): node tile j is workgroup j * S

@@ -817,7 +817,7 @@ int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, c
             // Every thread walks its row chunk serially (a latency chain): many rows get 256 chunks instead of 64.
             const bool swap = in > WS_MAX_IN;
             const int o2 = swap ? in : out, i2 = swap ? 1 : in;
-            const int chunks = (rows >= 8192 && scratch_floats >= off_part + 256 * (size_t)out * in) ? 256 : 64;
+            const int chunks = (rows >= 2048 && scratch_floats >= off_part + 256 * (size_t)out * in) ? 256 : 64;
             float* part = scratch + off_part;
             if (i2 == 1)
                 hipLaunchKernelGGL(wgrad_small_kernel<1>, dim3((o2 + 63) / 64, chunks), dim3(256), 0, st, rows, i2, o2,

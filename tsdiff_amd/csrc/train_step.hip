@@ -677,7 +677,7 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
             hipLaunchKernelGGL(scatter_rows_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.eB + H,
                                2 * H, g.attr_row, w.d_ea);
         }
-        TSD_TRY(tsd_pair_product_bwd(N, H, g.out, dp, w.h + (size_t)L * NH, w.dh, stream));
+        TSD_TRY(launch_row_gather(H, N, g.out, dp, w.h + (size_t)L * NH, w.dh, st));  // dh_i = sum_e dp[umap e] * h[dst e]
     }
     // The node-level layers (N rows) keep their dY per block and take their weight gradients in ONE batched launch
     // after the loop: 3 L problems of N rows each are launch-latency bound one by one (13 + 5 us each, 21 per step).
