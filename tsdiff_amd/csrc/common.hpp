@@ -389,6 +389,21 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ ldsA, int ld
     gemm_tile_ring<RB, CB, K, R>(r, ldsA, lda, acc);
 }
 
+// gemm_tile in two halves: gemm_ring_start puts the first ring_depth k-blocks of B in flight (they depend on
+// nothing the kernel computes), gemm_ring_run consumes them.  A kernel starts the ring BEFORE the staging barrier /
+// the epilogue that precedes the GEMM, so that the first MFMA does not wait an L2 round trip.
+template <int CB, int K>
+__device__ __forceinline__ void gemm_ring_start(BRing<CB, ring_depth<CB>()>& r, const float* __restrict__ Bp, int nout,
+                                                int col0) {
+    const int lane = threadIdx.x & 63;
+    ring_start<CB, ring_depth<CB>(), K / 8>(r, Bp, nout, (unsigned)((lane >> 5) * nout + col0 + (lane & 31)), 2, 32);
+}
+template <int RB, int CB, int K>
+__device__ __forceinline__ void gemm_ring_run(BRing<CB, ring_depth<CB>()>& r, const float* __restrict__ ldsA, int lda,
+                                              f32x16 (&acc)[RB][CB]) {
+    gemm_tile_ring<RB, CB, K, ring_depth<CB>()>(r, ldsA, lda, acc);
+}
+
 // 16-row variant on the 16x16x4 f32 MFMA (same rate, half the rows): A lane l holds A[i = l&15][k = l>>4],
 // B lane l holds B[k = l>>4][j = l&15], C/D: col = l&15, row = (l>>4)*4 + r, r in [0,4).
 // k is permuted in groups of 16: step s of k-block kb consumes k = kb*16 + q*4 + s on lane quarter q, so a
@@ -424,6 +439,18 @@ __device__ __forceinline__ void gemm_tile16(const float* __restrict__ ldsA, int 
     BRing<CB, R> r;
     ring_start<CB, R, K / 16>(r, Bp, nout, (unsigned)((lane >> 4) * nout + col0 + (lane & 15)), 4, 16);
     gemm_tile16_ring<CB, K, R>(r, ldsA, lda, acc);
+}
+
+template <int CB, int K>
+__device__ __forceinline__ void gemm16_ring_start(BRing<CB, ring_depth<CB>()>& r, const float* __restrict__ Bp,
+                                                  int nout, int col0) {
+    const int lane = threadIdx.x & 63;
+    ring_start<CB, ring_depth<CB>(), K / 16>(r, Bp, nout, (unsigned)((lane >> 4) * nout + col0 + (lane & 15)), 4, 16);
+}
+template <int CB, int K>
+__device__ __forceinline__ void gemm16_ring_run(BRing<CB, ring_depth<CB>()>& r, const float* __restrict__ ldsA, int lda,
+                                                f32x4 (&acc)[CB]) {
+    gemm_tile16_ring<CB, K, ring_depth<CB>()>(r, ldsA, lda, acc);
 }
 
 template <int RB, int CB>

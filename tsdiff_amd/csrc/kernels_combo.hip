@@ -347,6 +347,10 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
     TSD_TRACE_ID(2);
     TSD_TRACE_AT(0);
 
+    // the first k-blocks of both GEMMs' weights are requested ahead of the barrier / epilogue that precedes them
+    // (they depend on nothing computed here): the first MFMA of a GEMM does not wait an L2 round trip
+    BRing<1, ring_depth<1>()> rg;
+    gemm_ring_start<1, H>(rg, nn0_w, H, col0);
     if (tid < T) s_c[tid] = tid < nrows ? cutoff_weight(f.e.dist[e0 + tid], f.conv_cutoff, f.smooth) : 0.0f;
     {   // edge_attr tile -> LDS with every load of a thread in flight together (rows past the end clamped)
         constexpr int NIT = T * C4 / NT;
@@ -369,7 +373,8 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
 
     f32x16 acc[1][1];
     zero_acc(acc);
-    gemm_tile<1, 1, H>(buf, LDA, nn0_w, H, col0, acc);
+    gemm_ring_run<1, 1, H>(rg, buf, LDA, acc);
+    gemm_ring_start<1, H>(rg, nn2_w, H, col0);
     TSD_TRACE_WAVE(8);
     TSD_TRACE_AT(2);
     __syncthreads();
@@ -394,7 +399,7 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
     TSD_TRACE_AT(3);
 
     zero_acc(acc);
-    gemm_tile<1, 1, H>(buf, LDA, nn2_w, H, col0, acc);
+    gemm_ring_run<1, 1, H>(rg, buf, LDA, acc);
     TSD_TRACE_WAVE(16);
     TSD_TRACE_AT(4);
     __syncthreads();
