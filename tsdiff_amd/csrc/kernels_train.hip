@@ -267,7 +267,7 @@ struct WgradOutBatch {
 __device__ __forceinline__ void wgrad_reduce_body(int64_t nW, int nB, int S, const float* __restrict__ part,
                                                   const float* __restrict__ bias_part, float* __restrict__ dW,
                                                   float* __restrict__ db, int accumulate);
-__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(int64_t nW, int nB, int S,
+__global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(int64_t nW, int nB, int S,
                                                                  const float* __restrict__ part,
                                                                  const float* __restrict__ bias_part,
                                                                  WgradOutBatch o, int accumulate) {
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(int64_t nW, int
     wgrad_reduce_body(nW, hb ? nB : 0, S, part + (size_t)k * S * nW, bias_part + (size_t)k * S * nB, o.it[k].dW,
                       o.it[k].db, accumulate);
 }
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(int64_t nW, int nB, int S, const float* __restrict__ part,
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(int64_t nW, int nB, int S, const float* __restrict__ part,
                                                            const float* __restrict__ bias_part,
                                                            float* __restrict__ dW, float* __restrict__ db,
                                                            int accumulate) {
@@ -285,10 +285,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int64_t nW, int nB, i
 __device__ __forceinline__ void wgrad_reduce_body(int64_t nW, int nB, int S, const float* __restrict__ part,
                                                   const float* __restrict__ bias_part, float* __restrict__ dW,
                                                   float* __restrict__ db, int accumulate) {
-    __shared__ float sm[4][64];
-    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    // Q = blockDim.x / 64 wave groups (4, or 16 for long split lists: the per-lane sum over S / Q partials is a
+    // latency chain); group q adds splits [q S/Q, (q+1) S/Q) in order, the groups are combined by a fixed pairwise tree
+    __shared__ float sm[16][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, Q = blockDim.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-    const int per = S / 4;
+    const int per = S / Q;
     float s = 0.0f;
     if (i < nW) {
         for (int k = q * per; k < (q + 1) * per; ++k) s += part[(size_t)k * nW + i];
@@ -298,11 +300,22 @@ __device__ __forceinline__ void wgrad_reduce_body(int64_t nW, int nB, int S, con
     sm[q][lane] = s;
     __syncthreads();
     if (q == 0) {
-        const float v = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+        float v;
+        if (Q == 16) {
+            float t[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                t[g] = (sm[4 * g][lane] + sm[4 * g + 1][lane]) + (sm[4 * g + 2][lane] + sm[4 * g + 3][lane]);
+            v = (t[0] + t[1]) + (t[2] + t[3]);
+        } else {
+            v = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+        }
         if (i < nW) dW[i] = accumulate ? dW[i] + v : v;
         else if (i < nW + nB) db[i - nW] = accumulate ? db[i - nW] + v : v;
     }
 }
+// threads of a reduce launch: 16 wave groups when the split list is long
+static inline int reduce_threads(int S) { return (S >= 64 && S % 16 == 0) ? 1024 : 256; }
 
 // wgrad of the narrow layers (Linear(1,H), Linear(25,H/2), Linear(H/2,1)): dW[o,i] = sum_r dY[r,o] X[r,i], in <= 32.
 // Same two-stage column reduction as the bias gradient with `in` accumulators per thread:
@@ -808,7 +821,7 @@ int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, c
                                part, bpart);
             const int64_t n = (int64_t)out * in;
             const int nb = db ? out : 0;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + nb + 63) / 64)), dim3(256), 0, st, n, nb, S,
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + nb + 63) / 64)), dim3(reduce_threads(S)), 0, st, n, nb, S,
                                part, bpart, dW, db, accW);
             TSD_LAUNCH_CHECK("wgrad");
             db_done = db != nullptr;
@@ -826,7 +839,7 @@ int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, c
                 hipLaunchKernelGGL(wgrad_small_kernel<WS_MAX_IN>, dim3((o2 + 63) / 64, chunks), dim3(256), 0, st, rows,
                                    i2, o2, swap ? X : dY, swap ? dY : X, part);
             const int64_t n = (int64_t)o2 * i2;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, n, 0, chunks, part,
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(reduce_threads(chunks)), 0, st, n, 0, chunks, part,
                                (const float*)nullptr, dW, (float*)nullptr, accW);
             TSD_LAUNCH_CHECK("wgrad_small");
         } else {
@@ -849,7 +862,7 @@ int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, c
 int launch_split_reduce(int64_t n, int S, const float* part, float* dst, int accumulate, hipStream_t st) {
     if (n == 0) return TSD_OK;
     TSD_REQUIRE(S > 0 && S % 4 == 0, "split reduce: S=%d", S);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, n, 0, S, part,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(reduce_threads(S)), 0, st, n, 0, S, part,
                        (const float*)nullptr, dst, (float*)nullptr, accumulate);
     TSD_LAUNCH_CHECK("split_reduce");
     return TSD_OK;

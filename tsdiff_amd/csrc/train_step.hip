@@ -234,10 +234,10 @@ __global__ void atom_emb_grad_reduce_kernel(int n, const float* __restrict__ par
 // chunks in order.  ET = 32 edge types: bond 1..21, 22 + hop - 1 for hop <= 7 (tsd_model_cfg orders are <= 7).
 constexpr int ET = 32;
 // row chunks of the embedding-table gradient: 16 rows per wave (the per-row LDS accumulation is a latency chain),
-// a multiple of 4 for the split reduction (chunks past the rows write zero partials)
+// a multiple of 16 for the split reduction (chunks past the rows write zero partials)
 inline int emb_chunks(int E) {
     const int c = (E + 63) / 64 < 512 ? (E + 63) / 64 : 512;
-    return (c + 3) & ~3;
+    return (c + 15) & ~15;
 }
 __global__ __launch_bounds__(256) void emb_mul2_bwd_kernel(int rows, int H, int rows_per_wg,
                                                            const float* __restrict__ e, const float* __restrict__ emb,
