@@ -396,7 +396,7 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
 
 /* ---- optimizer step on the flat vectors (reference train.py:144-145, utils/common.py:58-68) ---------------
  * tsd_grad_norm_clip: norm[0] = |grad|_2 (fixed-order two-stage sum, deterministic), then -- max_norm > 0 --
- * grad *= min(1, max_norm / (norm + 1e-6)), torch.nn.utils.clip_grad_norm_'s rule; scratch: 256 floats.
+ * grad *= min(1, max_norm / (norm + 1e-6)), torch.nn.utils.clip_grad_norm_'s rule; scratch: 1024 floats.
  * tsd_adam_step: torch.optim.Adam's update (no amsgrad) of all n parameters in one launch; `step` counts from 1. */
 int tsd_grad_norm_clip(int64_t n, float* grad, float max_norm, float* scratch, float* norm, void* stream);
 int tsd_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,

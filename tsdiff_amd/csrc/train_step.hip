@@ -314,7 +314,7 @@ __global__ void loss_bwd_kernel(int N, const float* __restrict__ eq, const float
 
 // ---- optimizer on the flat parameter / gradient vectors (reference train.py:144-145, utils/common.py:58-68) ----
 // |g|: fixed-order two-stage sum of squares (NORM_WG workgroups, then one), no atomics
-constexpr int NORM_WG = 256;
+constexpr int NORM_WG = 1024;
 __global__ __launch_bounds__(256) void sumsq_stage1_kernel(int64_t n, const float* __restrict__ g, float* __restrict__ part) {
     __shared__ float sm[256];
     const int64_t per = ((n + NORM_WG - 1) / NORM_WG + 3) & ~int64_t(3);
@@ -331,7 +331,9 @@ __global__ __launch_bounds__(256) void sumsq_stage1_kernel(int64_t n, const floa
 }
 __global__ __launch_bounds__(256) void sumsq_stage2_kernel(const float* __restrict__ part, float* __restrict__ norm) {
     __shared__ float sm[256];
-    sm[threadIdx.x] = threadIdx.x < NORM_WG ? part[threadIdx.x] : 0.0f;
+    float s = 0.0f;
+    for (int k = threadIdx.x; k < NORM_WG; k += 256) s += part[k];  // fixed order per thread
+    sm[threadIdx.x] = s;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];

@@ -139,10 +139,10 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=Fals
         return torch.nn.utils.clip_grad_norm_(params, max_norm, norm_type=norm_type,
                                               error_if_nonfinite=error_if_nonfinite, foreach=foreach)
     lib = _lib.load()
-    scratch = torch.empty(257, dtype=torch.float32, device=flat.device)
-    check(lib.tsd_grad_norm_clip(flat.numel(), ptr(flat), float(max_norm), ptr(scratch), ptr(scratch[256:]),
+    scratch = torch.empty(1025, dtype=torch.float32, device=flat.device)
+    check(lib.tsd_grad_norm_clip(flat.numel(), ptr(flat), float(max_norm), ptr(scratch), ptr(scratch[1024:]),
                                  stream_ptr()))
-    return scratch[256]
+    return scratch[1024]
 
 
 class Adam(torch.optim.Optimizer):
