@@ -253,13 +253,29 @@ __global__ __launch_bounds__(256) void emb_mul2_bwd_kernel(int rows, int H, int 
     __syncthreads();
     const int r0 = blockIdx.y * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
     if (c < H) {
-        for (int r = r0 + w; r < r1; r += 4) {
-            const int a = min((int)tr[r], ET - 1), b = min((int)tp[r], ET - 1);
-            const float glo = dc[(size_t)r * 2 * H + c], ghi = dc[(size_t)r * 2 * H + H + c];
-            const float ev = e[(size_t)r * H + c];
-            if (de) de[(size_t)r * H + c] = glo * emb[(size_t)a * H + c] + ghi * emb[(size_t)b * H + c];
-            acc[w][a][lane] += glo * ev;  // private to (wave, lane): plain read-modify-write
-            acc[w][b][lane] += ghi * ev;
+        // four rows of the wave per trip: their loads are in flight together (rows past the end clamped), the
+        // accumulations follow in row order
+        for (int rb = r0 + w; rb < r1; rb += 16) {
+            int a[4], b[4];
+            float glo[4], ghi[4], ev[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = min(rb + 4 * k, r1 - 1);
+                a[k] = min((int)tr[r], ET - 1);
+                b[k] = min((int)tp[r], ET - 1);
+                glo[k] = dc[(size_t)r * 2 * H + c];
+                ghi[k] = dc[(size_t)r * 2 * H + H + c];
+                ev[k] = e[(size_t)r * H + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = rb + 4 * k;
+                if (r < r1) {
+                    if (de) de[(size_t)r * H + c] = glo[k] * emb[(size_t)a[k] * H + c] + ghi[k] * emb[(size_t)b[k] * H + c];
+                    acc[w][a[k]][lane] += glo[k] * ev[k];  // private to (wave, lane): plain read-modify-write
+                    acc[w][b[k]][lane] += ghi[k] * ev[k];
+                }
+            }
         }
     }
     __syncthreads();
