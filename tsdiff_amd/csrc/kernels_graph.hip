@@ -90,15 +90,21 @@ __global__ __launch_bounds__(256) void hop_kernel(const int32_t* __restrict__ gr
     for (int level = 2; level <= max_order; ++level) {
         for (int idx = threadIdx.x; idx < nn; idx += blockDim.x) {
             const int i = idx / n, j = idx % n;
-            if (hopR[idx] == 255) {
-                bool f = false;
-                for (int k = 0; k < n && !f; ++k) f = (hopR[i * n + k] == level - 1) && (hopR[k * n + j] == 1);
-                if (f) hopR[idx] = (unsigned char)level;
-            }
-            if (hopP[idx] == 255) {
-                bool f = false;
-                for (int k = 0; k < n && !f; ++k) f = (hopP[i * n + k] == level - 1) && (hopP[k * n + j] == 1);
-                if (f) hopP[idx] = (unsigned char)level;
+            // branch-free over k (no early exit: the LDS reads of a trip pipeline instead of forming a chain of
+            // n dependent round trips; the largest graph of the batch sets the kernel's duration)
+            const bool needR = hopR[idx] == 255, needP = hopP[idx] == 255;
+            if (needR || needP) {
+                int fr = 0, fp = 0;
+                const unsigned char* rowR = hopR + i * n;
+                const unsigned char* rowP = hopP + i * n;
+#pragma unroll 8
+                for (int k = 0; k < n; ++k) {
+                    fr |= (int)(rowR[k] == level - 1) & (int)(hopR[k * n + j] == 1);
+                    fp |= (int)(rowP[k] == level - 1) & (int)(hopP[k * n + j] == 1);
+                }
+                // (entries written this level hold `level`, never `level - 1` or 1: readers of this level are unaffected)
+                if (needR && fr) hopR[idx] = (unsigned char)level;
+                if (needP && fp) hopP[idx] = (unsigned char)level;
             }
         }
         __syncthreads();
