@@ -1266,3 +1266,64 @@ def test_flat_optimizer_step_equals_torch_adam(dev, tmp_path):
     for (k, a), (_, b) in zip(ref.named_parameters(), mod.named_parameters()):
         assert_close(b.detach().cpu().numpy(), a.detach().cpu().numpy(), 3e-5, f"resumed step param {k}")
     assert float(next(iter(o_new.state.values()))["step"]) == 4.0
+
+
+@pytest.mark.parametrize("variant", ["equal_orders", "smooth_conv", "tiny_graphs", "no_pairs"])
+def test_fused_training_step_variants_equal_op_by_op(variant, dev, monkeypatch):
+    """corners of the fused training step that the default configuration does not reach, against the op-by-op
+    autograd form of the primitive kernels: encoder and output lists identical (edge_order == pred_edge_order: no
+    separately embedded edges, the second list of every two-list launch is empty); the smooth cutoff weight; graphs of
+    1, 2 and 3 atoms mixed into a batch (rows without edges, tiles of a few rows); a batch without any pair (fused step
+    alone: zero loss, zero gradients)"""
+    import copy
+    from tsdiff_amd import synth
+    cfg = copy.deepcopy(synth.small_model_config(256, 2))
+    if variant == "equal_orders":
+        cfg["pred_edge_order"] = cfg["edge_order"]
+    if variant == "smooth_conv":
+        cfg["encoder"]["smooth_conv"] = True
+    if variant in ("tiny_graphs", "no_pairs"):
+        rng = np.random.default_rng(5)
+        sizes = [1, 2, 3, 1, 9] if variant == "tiny_graphs" else [1, 1, 1]
+        graphs = []
+        for n in sizes:
+            if n >= 4:
+                bi, bt = synth._reaction_graph(rng, n)
+            else:  # a chain of single bonds, kept by the reaction (both directions, row-major order)
+                pairs = [(a, a + 1) for a in range(n - 1)]
+                ei = sorted([(a, c) for a, c in pairs] + [(c, a) for a, c in pairs])
+                bi = np.asarray(ei, np.int64).reshape(-1, 2).T.copy()
+                bt = np.full(len(ei), 1 * synth.NUM_BOND_TYPES + 1, np.int64)
+            graphs.append({"atom_type": rng.choice(np.asarray([1, 6, 7, 8], np.int64), size=n),
+                           "r_feat": synth._one_hot_feat(rng, n), "p_feat": synth._one_hot_feat(rng, n),
+                           "pos": rng.standard_normal((n, 3)).astype(np.float32), "bond_index": bi, "bond_type": bt})
+        b = synth.collate(graphs)
+    else:
+        b = synth.wb97xd3_like_batch(20, seed=11)
+    g = to_dev({k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}, dev)
+    g["pos"] = (g["pos"] * 1.5).contiguous()
+    G = int(b["num_nodes_per_graph"].shape[0])
+    gen = torch.Generator().manual_seed(7)
+    ts = torch.randint(0, 5000, (G,), generator=gen).to(dev)
+    noise = torch.randn(g["pos"].shape, generator=gen).to(dev)
+    res = {}
+    for mode in ("fused",) if variant == "no_pairs" else ("fused", "ops"):
+        monkeypatch.setenv("TSDIFF_TRAIN", mode)
+        model = make_model(cfg, 3, dev)
+        model.train()
+        loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
+                              g["batch"], g["num_nodes_per_graph"], G, _time_step=ts, _pos_noise=noise)
+        loss.mean().backward()
+        res[mode] = (loss.detach().cpu().numpy(),
+                     {k: p.grad.cpu().numpy() for k, p in model.named_parameters() if p.grad is not None})
+    if variant == "no_pairs":  # no pair, no score, no target: the loss and every gradient vanish (and nothing crashes)
+        assert np.array_equal(res["fused"][0], np.zeros_like(res["fused"][0])) and len(res["fused"][1]) >= 30
+        assert all(np.abs(v).max() == 0.0 for v in res["fused"][1].values())
+        return
+    assert_close(res["fused"][0], res["ops"][0], 2e-6, f"{variant}: loss fused vs op-by-op")
+    assert set(res["fused"][1]) == set(res["ops"][1]) and len(res["fused"][1]) >= 30
+    for k, ref in res["ops"][1].items():
+        if np.abs(ref).max() == 0.0:
+            assert np.abs(res["fused"][1][k]).max() == 0.0, f"{variant}: grad {k} must vanish"
+        else:
+            assert_close(res["fused"][1][k], ref, 3e-5, f"{variant}: grad {k} fused vs op-by-op")
