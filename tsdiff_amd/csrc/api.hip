@@ -162,8 +162,23 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     um.node_graph = b.node_graph;
     um.pair_ptr = b.pair_ptr;
     um.P = P;
+    // the filter GEMMs of block 0 ride in the embedding launch (a tile's filters need only that tile's attributes):
+    // the first per-block launch, which had no node chain to run beside them, disappears
+    const WeightLayout WL0 = weight_layout(c);
+    EmbedFuse0 f0{};
+    f0.nn0_w = W + WL0.layer0 + WL0.L_nn0_w;
+    f0.nn0_b = W + WL0.layer0 + WL0.L_nn0_b;
+    f0.nn2_w = W + WL0.layer0 + WL0.L_nn2_w;
+    f0.nn2_b = W + WL0.layer0 + WL0.L_nn2_b;
+    f0.conv_cutoff = c.conv_cutoff;
+    f0.smooth = c.smooth_conv;
+    f0.wf = w.wf;
+    f0.wf_stride = w.stride_wf;
+    // (batch-100 sizes only: measured 0.441 -> 0.435 ms/step at configs[1]; at configs[4] the longer embedding
+    // tiles lose more than the launch saves, 50.5 -> 52.8 ms/step)
+    const bool fuse_block0 = (long)((N + TSD_NODE_TILE - 1) / TSD_NODE_TILE) * M <= 256;
     if ((r = launch_edge_embed2(c, W, PU, g.enc_u, w.ea, PU, g.diff_u, w.ea + (size_t)PU * H, M, w.stride_ea, st,
-                                &um)))
+                                &um, nullptr, 0, fuse_block0 ? &f0 : nullptr)))
         return r;
     // block 0 reads z (residual input) and x1_0 = lin1_0(z) straight from the per-batch arrays -- both are
     // pos independent (computed at bind time) -- so no per-step copy of z and no lin1 launch
@@ -193,7 +208,7 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     // of the 256 CUs; with an ensemble or a large batch the launch is full and the extra role only adds work:
     // C2 0.518 -> 0.511 ms/step, C5 51.1 -> 51.6, M = 8 3.10 -> 3.13)
     const bool use_pre = (long)((N + TSD_NODE_TILE - 1) / TSD_NODE_TILE) * M <= 256;
-    for (int j = 0; j <= L; ++j) {
+    for (int j = fuse_block0 ? 1 : 0; j <= L; ++j) {  // (fused: the filters of block 0 came with the embedding launch)
         const int layer = j == 0 ? -2 : j - 1;  // node chain of this launch; its filters were written by launch j-1
         const float* wf_read = layer >= 0 ? w.wf + (size_t)(layer % w.wf_slots) * PU * H : nullptr;
         if ((r = launch_layer_combo(c, W, layer, N, g.enc, wf_read, xin, layer == 0 ? b.z : w.h, w.h, xout, 0,

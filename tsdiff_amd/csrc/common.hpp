@@ -184,11 +184,22 @@ struct PairSave {     // [capacity_u, .]
     float *g1, *gs1;  // [H/2]: second layer and its swish
 };
 
+// The filter GEMMs of interaction block 0 appended to the enc-list tiles of the edge-embedding launch (inference
+// forward: a tile's filters need only that tile's edge attributes, which are still in LDS -- one launch and one
+// read of the attribute rows less per forward).  Same arithmetic in the same order as the filter role: bit-identical.
+struct EmbedFuse0 {
+    const float *nn0_w, *nn0_b, *nn2_w, *nn2_b;  // block 0 (checkpoint m at + m * weight stride)
+    float conv_cutoff;
+    int smooth;
+    float* wf;          // filter slot of block 0 (checkpoint m at + m * wf_stride)
+    size_t wf_stride;
+};
+
 // launchers of the fused forward kernels shared by the inference forward (api.hip) and the training step
 // (train_step.hip); `save` != NULL selects the SAVE instantiation
 int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_edges ea, float* out_a, int cap_b,
                        tsd_edges eb, float* out_b, int M, size_t out_stride, hipStream_t st, const UmapRole* umap,
-                       const EmbedSave* save = nullptr, int save_b_row = 0);
+                       const EmbedSave* save = nullptr, int save_b_row = 0, const EmbedFuse0* fuse0 = nullptr);
 int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N, tsd_edges enc, const float* Wf_layer,
                        const float* x1_in, const float* h_in, float* h, float* x1_out, int layer_w0, int g_begin,
                        int g_count, int capacity_u, tsd_edges enc_u, const float* edge_attr, float* wf_base,

@@ -33,11 +33,12 @@ struct PairW {
 // the few output-graph edges that need their own embedding fill the chip together.
 // SAVE: the training step's instantiation also writes the intermediate activations (EmbedSave, row = edge-attribute
 // row: list b starts at row `save_b_row`).
-template <int H, bool SAVE>
+// FUSE0: the tiles of list a go on to the filter GEMMs of interaction block 0 (EmbedFuse0, common.hpp).
+template <int H, bool SAVE, bool FUSE0>
 __global__ __launch_bounds__(2 * H) void edge_embed_kernel(EdgeEmbedW w, tsd_edges ea_, float* __restrict__ out_a,
                                                        int tiles_a, tsd_edges eb_, float* __restrict__ out_b,
                                                        size_t wstride, size_t out_stride, int embed_tiles,
-                                                       UmapRole um, EmbedSave sv, int save_b_row) {
+                                                       UmapRole um, EmbedSave sv, int save_b_row, EmbedFuse0 f0) {
     constexpr int LDA = 2 * H + 4;
     if ((int)blockIdx.x >= embed_tiles) {  // extra role: directed-edge -> undirected-pair map (checkpoint 0 only)
         if (blockIdx.y == 0)
@@ -50,6 +51,10 @@ __global__ __launch_bounds__(2 * H) void edge_embed_kernel(EdgeEmbedW w, tsd_edg
         w.bond_emb += wo; w.w0 += wo; w.b0 += wo; w.w1 += wo; w.b1 += wo;
         w.cw0 += wo; w.cb0 += wo; w.cw1 += wo; w.cb1 += wo;
         out_a += oo; out_b += oo;
+        if constexpr (FUSE0) {
+            f0.nn0_w += wo; f0.nn0_b += wo; f0.nn2_w += wo; f0.nn2_b += wo;
+            f0.wf += (size_t)blockIdx.y * f0.wf_stride;
+        }
     }
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* buf = smem;
@@ -151,6 +156,51 @@ __global__ __launch_bounds__(2 * H) void edge_embed_kernel(EdgeEmbedW w, tsd_edg
         for (int r = 0; r < 16; ++r) {
             const int ee = e0 + acc_row(r, hi);
             if (ee < E) edge_attr[(size_t)ee * H + col] = acc[0][cb][r] + b;
+        }
+        if constexpr (FUSE0) {  // keep the attribute tile for the filter GEMMs below
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][cb][r] += b;
+        }
+    }
+    if constexpr (FUSE0) {
+        if (second) return;
+        // filter role of interaction block 0 on this tile (kernels_combo.hip::filter_role, same order of operations)
+        const int nrows = min(T, E - e0);
+        const int col = col0 + l31;
+        __syncthreads();  // every wave is done reading buf
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, hi);
+            buf[row * LDA + col] = row < nrows ? acc[0][0][r] : 0.0f;
+        }
+        __syncthreads();
+        zero_acc(acc);
+        gemm_tile<1, 1, H>(buf, LDA, f0.nn0_w, H, col0, acc);
+        __syncthreads();
+        {
+            const float b = f0.nn0_b[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) buf[acc_row(r, hi) * LDA + col] = sspf(acc[0][0][r] + b);
+        }
+        __syncthreads();
+        zero_acc(acc);
+        gemm_tile<1, 1, H>(buf, LDA, f0.nn2_w, H, col0, acc);
+        __syncthreads();
+        {
+            const float b = f0.nn2_b[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = acc_row(r, hi);
+                const float cw = row < nrows ? cutoff_weight(s_d[row], f0.conv_cutoff, f0.smooth) : 0.0f;
+                buf[row * LDA + col] = (acc[0][0][r] + b) * cw;
+            }
+        }
+        __syncthreads();
+        constexpr int C4 = H / 4;
+        for (int idx = tid; idx < nrows * C4; idx += 2 * H) {
+            const int r = idx / C4, c4 = idx % C4;
+            *reinterpret_cast<f32x4*>(f0.wf + (size_t)(e0 + r) * H + c4 * 4) =
+                *reinterpret_cast<const f32x4*>(buf + r * LDA + c4 * 4);
         }
     }
 }
@@ -857,7 +907,7 @@ static inline size_t lds_pair(int H) { return (size_t)(T * (2 * H + 4) + (H / 64
 
 int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_edges ea, float* out_a, int cap_b,
                        tsd_edges eb, float* out_b, int M, size_t out_stride, hipStream_t st, const UmapRole* umap,
-                       const EmbedSave* save, int save_b_row) {
+                       const EmbedSave* save, int save_b_row, const EmbedFuse0* fuse0) {
     const WeightLayout L = weight_layout(c);
     EdgeEmbedW w{W + L.bond_emb, W + L.emlp_w0, W + L.emlp_b0, W + L.emlp_w1, W + L.emlp_b1,
                  W + L.ecat_w0, W + L.ecat_b0, W + L.ecat_w1, W + L.ecat_b1};
@@ -869,30 +919,34 @@ int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_ed
     }
     if (tiles_a + tiles_b + um.blocks == 0) return TSD_OK;
     const size_t lds = lds_edge_embed(c.hidden);
-    if (save) {
-        TSD_DISPATCH_H(c.hidden, {
-            static DeviceOnce once; int r = allow_lds(edge_embed_kernel<HH, true>, lds, once);
-            if (r) return r;
-            hipLaunchKernelGGL((edge_embed_kernel<HH, true>), dim3(tiles_a + tiles_b + um.blocks, M), dim3(2 * HH), lds,
-                               st, w, ea, out_a, tiles_a, eb, out_b, L.total, out_stride, tiles_a + tiles_b, um, *save,
-                               save_b_row);
-        });
-    } else {
-        TSD_DISPATCH_H(c.hidden, {
-            static DeviceOnce once; int r = allow_lds(edge_embed_kernel<HH, false>, lds, once);
-            if (r) return r;
-            hipLaunchKernelGGL((edge_embed_kernel<HH, false>), dim3(tiles_a + tiles_b + um.blocks, M), dim3(2 * HH), lds,
-                               st, w, ea, out_a, tiles_a, eb, out_b, L.total, out_stride, tiles_a + tiles_b, um,
-                               EmbedSave{}, 0);
-        });
+    const dim3 grid(tiles_a + tiles_b + um.blocks, M);
+    if (save && fuse0) {
+        set_error("internal: edge_embed saves and the fused block-0 filters are exclusive");
+        return TSD_ERR_INVALID;
     }
+#define TSD_EE(HH, SV, FU, SARG, FARG)                                                                         \
+    {                                                                                                          \
+        static DeviceOnce once;                                                                                \
+        int r = allow_lds(edge_embed_kernel<HH, SV, FU>, lds, once);                                           \
+        if (r) return r;                                                                                       \
+        hipLaunchKernelGGL((edge_embed_kernel<HH, SV, FU>), grid, dim3(2 * HH), lds, st, w, ea, out_a, tiles_a, eb, \
+                           out_b, L.total, out_stride, tiles_a + tiles_b, um, SARG, save_b_row, FARG);          \
+    }
+    if (save) {
+        TSD_DISPATCH_H(c.hidden, TSD_EE(HH, true, false, *save, EmbedFuse0{}));
+    } else if (fuse0) {
+        TSD_DISPATCH_H(c.hidden, TSD_EE(HH, false, true, EmbedSave{}, *fuse0));
+    } else {
+        TSD_DISPATCH_H(c.hidden, TSD_EE(HH, false, false, EmbedSave{}, EmbedFuse0{}));
+    }
+#undef TSD_EE
     TSD_LAUNCH_CHECK("edge_embed");
     return TSD_OK;
 }
 
 int launch_edge_embed(const tsd_model_cfg& c, const float* W, int capacity, tsd_edges e, float* edge_attr,
                       hipStream_t st) {
-    return launch_edge_embed2(c, W, capacity, e, edge_attr, 0, e, edge_attr, 1, 0, st, nullptr, nullptr, 0);
+    return launch_edge_embed2(c, W, capacity, e, edge_attr, 0, e, edge_attr, 1, 0, st, nullptr, nullptr, 0, nullptr);
 }
 
 int launch_cfconv_layer(const tsd_model_cfg& c, const float* W, int layer, int capacity, tsd_edges e,
