@@ -60,3 +60,47 @@ def test_get_optimizer_mirrors_the_reference():
     torch.optim.lr_scheduler.ReduceLROnPlateau(o, factor=0.6, patience=10, min_lr=1e-6)  # utils/common.py:73-80
     with pytest.raises(NotImplementedError):
         optim.get_optimizer(SimpleNamespace(type="sgd"), net)
+
+
+def test_flatten_parameters_keeps_the_module_surface():
+    """optim.flatten_parameters on the real network (CPU: no kernel runs): the parameters become views of one flat
+    buffer in the order of the flat parameter vector, state_dict / load_state_dict / named_parameters are unchanged,
+    and an optimizer step on synthetic gradients (CPU tensors: torch's own update rule) equals torch.optim.Adam on an
+    unflattened copy"""
+    from tsdiff_amd import engine, synth
+    from tsdiff_amd.epsnet import get_model
+    from tsdiff_amd.utils import AttrDict
+    cfg = synth.small_model_config(64, 2)
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(cfg, 1).items()}
+    a, b = get_model(AttrDict(cfg)), get_model(AttrDict(cfg))
+    a.load_state_dict(sd, strict=False), b.load_state_dict(sd, strict=False)
+    keys = list(b.state_dict().keys())
+    flat = optim.flatten_parameters(b)
+    assert optim.flatten_parameters(b) is flat
+    names = engine.raw_param_names(b._cfg.num_convs)
+    P = dict(b.named_parameters())
+    assert flat.numel() == sum(P[n].numel() for n in names)
+    o = 0
+    for n in names:  # consecutive views, raw order
+        assert P[n].data_ptr() == flat.data_ptr() + 4 * o and P[n].is_contiguous()
+        o += P[n].numel()
+    assert list(b.state_dict().keys()) == keys
+    for k, v in a.state_dict().items():
+        assert torch.equal(v, b.state_dict()[k])
+    b.load_state_dict(a.state_dict())          # copies INTO the views
+    assert P[names[0]].data_ptr() == flat.data_ptr()
+    oa = torch.optim.Adam(a.parameters(), lr=1e-3, betas=(0.95, 0.999))
+    ob = optim.get_optimizer(SimpleNamespace(type="adam", lr=1e-3, weight_decay=0.0, beta1=0.95, beta2=0.999), b)
+    gen = torch.Generator().manual_seed(0)
+    for _ in range(2):
+        grads = {n: torch.randn(p.shape, generator=gen) for n, p in a.named_parameters() if p.requires_grad}
+        for m in (a, b):
+            for n, p in m.named_parameters():
+                p.grad = grads[n].clone() if n in grads else None
+        na = torch.nn.utils.clip_grad_norm_(a.parameters(), 1.0)
+        nb = optim.clip_grad_norm_(b.parameters(), 1.0)
+        assert torch.allclose(na, nb, rtol=1e-6)
+        oa.step(), ob.step()
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.allclose(p, q, rtol=1e-6, atol=1e-8), n
+    assert P[names[-1]].data_ptr() + 4 * P[names[-1]].numel() == flat.data_ptr() + 4 * flat.numel()
