@@ -65,6 +65,7 @@ extern "C" {
 #define TSD_STATUS_NAN 1           /* NaN in positions after an update (sampler.py:248-250) */
 #define TSD_STATUS_BAD_BOND 2      /* bond across graphs / self loop / index out of range */
 #define TSD_STATUS_ASYMMETRIC 4    /* bond list is not symmetric (A0 contract: both directions) */
+#define TSD_STATUS_INTERNAL 8      /* a bounded in-kernel wait of the fused step tail gave up (never expected) */
 
 typedef struct tsd_model_cfg {
     int32_t hidden;          /* config.hidden_dim == config.encoder.hidden_dim */
@@ -228,6 +229,9 @@ typedef struct tsd_batch {
     tsd_geometry geo;
     float* workspace;           /* tsd_forward_workspace_floats */
     float* edge_inv_u;          /* [M, P/2] per-checkpoint output on the undirected out list */
+    int32_t max_graph_nodes;    /* atoms of the largest graph (host knowledge), or 0 = unknown: the sampling loop then
+                                   runs its step tail as three launches instead of the fused one (<= 64-atom graphs) */
+    int32_t reserved;
 } tsd_batch;
 
 size_t tsd_forward_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs,

@@ -1256,6 +1256,19 @@ def test_flat_optimizer_step_equals_torch_adam(dev, tmp_path):
         assert float(st_t[k]["step"]) == float(st_r[k]["step"]) == 3.0
         assert_close(st_t[k]["exp_avg"].cpu().numpy(), st_r[k]["exp_avg"].cpu().numpy(), 2e-5, f"exp_avg {k}")
         assert_close(st_t[k]["exp_avg_sq"].cpu().numpy(), st_r[k]["exp_avg_sq"].cpu().numpy(), 2e-5, f"exp_avg_sq {k}")
+    # the cross-loaded torch optimizer must also STEP like the original (the flat path's shared step
+    # counter must not travel in the checkpoint -- torch would bump it once per parameter): one more step of o_t on a
+    # copy of the reference model equals the same step of o_ref
+    assert len({id(st["step"]) for st in sd["state"].values()}) == len(sd["state"])
+    ref2 = make_model(meta["cfg"], meta["seed"], dev)
+    ref2.load_state_dict(ref.state_dict())
+    ref2.train()
+    o_t2 = torch.optim.Adam(ref2.parameters(), lr=5e-4, betas=(0.95, 0.999), weight_decay=1e-3)
+    o_t2.load_state_dict(torch.load(tmp_path / "opt.pt", weights_only=False))
+    o_t2.zero_grad()
+    ref2.get_loss(*args, **kw).mean().backward()
+    o_t2.step()
+    assert all(float(st["step"]) == 4.0 for st in o_t2.state.values())
     o_new = optim.Adam(mod.parameters(), lr=5e-4, betas=(0.95, 0.999), weight_decay=1e-3)
     import copy
     o_new.load_state_dict(copy.deepcopy(o_ref.state_dict()))  # (load_state_dict keeps references to same-device tensors)
@@ -1266,6 +1279,8 @@ def test_flat_optimizer_step_equals_torch_adam(dev, tmp_path):
     for (k, a), (_, b) in zip(ref.named_parameters(), mod.named_parameters()):
         assert_close(b.detach().cpu().numpy(), a.detach().cpu().numpy(), 3e-5, f"resumed step param {k}")
     assert float(next(iter(o_new.state.values()))["step"]) == 4.0
+    for (k, a), (_, b) in zip(ref.named_parameters(), ref2.named_parameters()):  # o_ref's 4th step == o_t2's
+        assert_close(b.detach().cpu().numpy(), a.detach().cpu().numpy(), 3e-5, f"cross-loaded torch step param {k}")
 
 
 @pytest.mark.parametrize("variant", ["equal_orders", "smooth_conv", "tiny_graphs", "no_pairs"])

@@ -104,3 +104,46 @@ def test_flatten_parameters_keeps_the_module_surface():
     for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         assert torch.allclose(p, q, rtol=1e-6, atol=1e-8), n
     assert P[names[-1]].data_ptr() + 4 * P[names[-1]].numel() == flat.data_ptr() + 4 * flat.numel()
+
+
+def test_state_dict_does_not_export_the_shared_step_counter():
+    """the flat path keeps ONE step tensor per group inside self.state; state_dict() must hand every parameter its
+    own copy, or torch.optim.Adam (which keeps loaded `step` tensors as they are) bumps it once per parameter.
+    CPU: the flat state is built by hand on a flat CPU buffer (no kernel runs)."""
+    import copy
+    flat = torch.zeros(5 * 7 + 7 + 7 * 3 + 3)
+    net = _net(3)
+    o = 0
+    for p in net.parameters():
+        n = p.numel()
+        flat[o:o + n] = p.detach().reshape(-1)
+        p.data = flat[o:o + n].view(p.shape)
+        o += n
+    params = list(net.parameters())
+    opt = optim.Adam(params, lr=1e-2)
+    fs = opt._ensure_flat_state(0, params, flat)
+    assert fs is not None
+    fs[3].add_(1)  # what a flat step does to the shared counter
+    assert len({id(opt.state[p]["step"]) for p in params}) == 1  # shared inside the optimizer ...
+    sd = opt.state_dict()
+    assert len({id(st["step"]) for st in sd["state"].values()}) == len(params)  # ... not in the checkpoint
+    assert all(float(st["step"]) == 1.0 for st in sd["state"].values())
+    assert len({id(opt.state[p]["step"]) for p in params}) == 1  # and state_dict() left the live state alone
+    for loader in (copy.deepcopy, lambda x: x):
+        net2 = _net(3)
+        o2 = torch.optim.Adam(net2.parameters(), lr=1e-2)
+        o2.load_state_dict(loader(sd))
+        net2(torch.randn(4, 5)).square().mean().backward()
+        o2.step()
+        assert all(float(st["step"]) == 2.0 for st in o2.state.values())
+
+
+def test_clip_with_nonpositive_max_norm_is_torchs():
+    a, b = _net(2), _net(2)
+    x = torch.randn(6, 5)
+    for m in (a, b):
+        m(x).square().mean().backward()
+    torch.nn.utils.clip_grad_norm_(a.parameters(), 0.0)
+    optim.clip_grad_norm_(b.parameters(), 0.0)
+    for p, q in zip(a.parameters(), b.parameters()):
+        assert torch.equal(p.grad, q.grad) and float(p.grad.abs().sum()) == 0.0

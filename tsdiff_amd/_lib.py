@@ -22,6 +22,7 @@ STEP_COEFS = 8
 STATUS_NAN = 1
 STATUS_BAD_BOND = 2
 STATUS_ASYMMETRIC = 4
+STATUS_INTERNAL = 8
 
 c_i32p = C.POINTER(C.c_int32)
 c_f32p = C.POINTER(C.c_float)
@@ -84,6 +85,8 @@ class Batch(C.Structure):
         ("geo", Geometry),
         ("workspace", C.c_void_p),
         ("edge_inv_u", C.c_void_p),
+        ("max_graph_nodes", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

@@ -69,6 +69,10 @@ int launch_geometry_lists(const tsd_model_cfg&, int, int, const float*, const in
 int launch_step_post(const tsd_model_cfg&, int, int, int, int, int, const int32_t*, const int32_t*, const uint16_t*,
                      tsd_geometry, const float*, float, float, float*, tsd_sampler_state*, hipStream_t);
 int launch_set_run_args(tsd_sampler_state*, const tsd_run_args&, hipStream_t);
+bool step_tail_supported(int, int, int);
+int launch_step_tail_reset(int, tsd_geometry, hipStream_t);
+int launch_step_tail(const tsd_model_cfg&, int, int, int, int, int, int, const int32_t*, const int32_t*, const uint16_t*,
+                     tsd_geometry, const float*, float, float, float*, tsd_sampler_state*, hipStream_t);
 int launch_philox_normal(uint64_t, uint64_t, int64_t, float*, hipStream_t);
 int launch_filter_gen(const tsd_model_cfg&, const float*, int, tsd_edges, const float*, float*, int, int,
                       hipStream_t);
@@ -136,20 +140,23 @@ static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base)
 // the directed CSR list only drives the aggregation and eq_transform through `umap`.
 // counts_ready: the per-row member counts are already in geo.scratch (written by the previous step's
 // step_post_kernel); advance: device step counter bumped by the scan kernel (sampling loop only).
+// lists_ready: the five lists of `pos` are complete but for the directed -> undirected map (the fused step tail of
+// the previous step built them): no count / scan / fill launches at all.
 static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float* pos, hipStream_t st,
-                        bool counts_ready = false, int32_t* advance = nullptr) {
+                        bool counts_ready = false, int32_t* advance = nullptr, bool lists_ready = false) {
     const int N = b.num_nodes, P = b.num_pairs, M = b.num_models;
     const int PU = P / 2, L = c.num_convs;
     const size_t H = c.hidden;
     const tsd_geometry& g = b.geo;
     int r;
     TraceRange range("tsd:score_forward");
-    if (!counts_ready) {
+    if (!counts_ready && !lists_ready) {
         if ((r = launch_geometry_count(c, N, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, g, st))) return r;
     }
     // the directed-edge -> undirected-pair map is not needed before the first block launch, so it runs as an
     // extra role of the edge-embedding launch instead of a launch of its own on the critical path
-    if ((r = launch_geometry_lists(c, N, P, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, g, advance, st,
+    if (!lists_ready &&
+        (r = launch_geometry_lists(c, N, P, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, g, advance, st,
                                    true)))
         return r;
     const Workspace w = carve(c, N, P, M, b.workspace);
@@ -226,9 +233,18 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
 
 // one sampling step of the device-resident loop: lists (from the counts of the previous step's tail) ->
 // M forwards -> fused tail (mean, eq_transform, update, centre, next step's counts)
+// The fused tail (one launch: update + the NEXT step's lists) is used whenever the batch qualifies.
+static bool use_step_tail(const tsd_batch& b) {
+    return step_tail_supported(b.num_nodes, b.num_graphs, b.max_graph_nodes);
+}
 static int step_impl(const tsd_model_cfg& c, const tsd_batch& b, int kind, float clip, float clip_pos, float* pos,
                      tsd_sampler_state* state, hipStream_t st) {
     int r;
+    if (use_step_tail(b)) {
+        if ((r = forward_impl(c, b, pos, st, true, nullptr, true))) return r;
+        return launch_step_tail(c, kind, b.num_nodes, b.num_graphs, b.num_models, b.num_pairs, b.max_graph_nodes,
+                                b.graph_ptr, b.pair_ptr, b.pair_code, b.geo, b.edge_inv_u, clip, clip_pos, pos, state, st);
+    }
     if ((r = forward_impl(c, b, pos, st, true, &state->step))) return r;
     return launch_step_post(c, kind, b.num_nodes, b.num_graphs, b.num_models, b.num_pairs, b.graph_ptr, b.pair_ptr,
                             b.pair_code, b.geo, b.edge_inv_u, clip, clip_pos, pos, state, st);
@@ -508,10 +524,20 @@ int tsd_sampler_plan_run(tsd_sampler_plan* plan, int32_t n_steps, const tsd_run_
     const tsd_batch& b = plan->batch;
     int r;
     if ((r = launch_set_run_args(plan->state, *args, st))) return r;
-    // member counts of the first step's lists (later steps get them from the previous step's tail kernel)
-    if ((r = launch_geometry_count(plan->cfg, b.num_nodes, plan->pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code,
-                                   b.geo, st)))
+    if (use_step_tail(b)) {
+        // the first step's lists: the fused tail in its list-only form (epoch 1 of the run's ticket counter); every
+        // later step finds the lists its predecessor's tail built
+        TSD_REQUIRE(((int64_t)n_steps + 2) * b.num_graphs < (int64_t)1 << 31, "n_steps=%d too large for one call", n_steps);
+        if ((r = launch_step_tail_reset(b.num_graphs, b.geo, st))) return r;
+        if ((r = launch_step_tail(plan->cfg, -1, b.num_nodes, b.num_graphs, b.num_models, b.num_pairs, b.max_graph_nodes,
+                                  b.graph_ptr, b.pair_ptr, b.pair_code, b.geo, b.edge_inv_u, plan->clip, plan->clip_pos,
+                                  plan->pos, plan->state, st)))
+            return r;
+    } else if ((r = launch_geometry_count(plan->cfg, b.num_nodes, plan->pos, b.graph_ptr, b.node_graph, b.pair_ptr,
+                                          b.pair_code, b.geo, st))) {
+        // member counts of the first step's lists (later steps get them from the previous step's tail kernel)
         return r;
+    }
     for (int k = 0; k < n_steps; ++k) {
         if (use_graph) {
             TSD_HIP(hipGraphLaunch(plan->exec, st));

@@ -464,6 +464,23 @@ __device__ __forceinline__ void gemm16_ring_run(BRing<CB, ring_depth<CB>()>& r, 
     gemm_tile16_ring<CB, K, ring_depth<CB>()>(r, ldsA, lda, acc);
 }
 
+// 16-byte store of a streamed output (CFConv filter rows).  Cache policy: 1 = write-through (sc1): the bytes leave the
+// XCD's L2 as they are written instead of at the kernel's end-of-launch write-back (MI355X_MICROARCH.md price list,
+// rows boundary / publish-large); 0 = plain; 2 = non-temporal (measured slower: 0.448 ms/step).  Variant builds:
+// tools/build_variant.sh NAME "-DTSD_WF_STORE=0"
+#ifndef TSD_WF_STORE
+#define TSD_WF_STORE 1  // measured at batch 100 (tools/ab_step.py, round 3): 0.4303 vs 0.4334 ms/step with plain stores
+#endif
+__device__ __forceinline__ void store_stream16(float* p, const f32x4 v) {
+#if TSD_WF_STORE == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#elif TSD_WF_STORE == 2
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+    *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
+
 template <int RB, int CB>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[RB][CB]) {
 #pragma unroll

@@ -416,8 +416,7 @@ __device__ __forceinline__ void filter_role(const ComboFilter& f, int item, floa
     TSD_TRACE_AT(5);
     for (int idx = tid; idx < nrows * C4; idx += NT) {
         const int r = idx / C4, c4 = idx % C4;
-        *reinterpret_cast<f32x4*>(out + (size_t)(e0 + r) * H + c4 * 4) =
-            *reinterpret_cast<const f32x4*>(buf + r * LDA + c4 * 4);
+        store_stream16(out + (size_t)(e0 + r) * H + c4 * 4, *reinterpret_cast<const f32x4*>(buf + r * LDA + c4 * 4));
     }
     TSD_TRACE_AT(6);
 }

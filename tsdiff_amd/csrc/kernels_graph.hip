@@ -621,6 +621,477 @@ int launch_step_post(const tsd_model_cfg& c, int kind, int N, int G, int M, int 
     return TSD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The whole step tail in ONE launch (round 3; replaces step_post + scan + pair_fill = 25 us and two kernel
+// boundaries of a 450-us step at batch 100): one workgroup per graph does
+//   1. ensemble mean + eq_transform + clip + LD/DDPM update + NaN flag + centring   (as step_post_kernel)
+//   2. membership of the graph's ordered pairs on the NEW positions, per 64-pair chunk counts
+//   3. the graph's totals -> ONE 8-byte record {tag, enc_u, out_u, diff_u} (16 bits each: a graph has at most
+//      255*254/2 undirected pairs) stored write-through; the offsets of the graph in the five lists = the sum of
+//      the records of the graphs before it (the directed lists hold exactly twice the undirected counts of a
+//      graph: membership is symmetric), polled 64 records per sweep -- "the data is the flag" (cdna_hip_programming.md
+//      Guideline 16, R2: relaxed agent-scope 8-byte granules, no fences, bounded spins)
+//   4. stream compaction of the member pairs into the five lists of the NEXT step (as pair_fill_kernel; the pairs
+//      of a graph in pair order ARE the reference's row-major edge order), row_ptr from the first pair of each row.
+// Graph <-> workgroup by a ticket (atomicAdd), not blockIdx: every graph a workgroup waits for has been taken by a
+// workgroup that is already running, whatever the dispatch order.  ticket / G + 1 is the launch's epoch within the
+// run (tsd_sampler_plan_run zeroes the ticket and the records): epoch 1 = the list-only launch on the initial
+// positions (kind < 0), epoch k + 2 = step k, whose row of the coefficient / noise / trajectory tables it selects;
+// the record tag is the epoch's low 16 bits (a record is rewritten every launch, so a stale tag never matches).
+// Bit-identical lists and positions to the three-kernel path (tests/test_gpu_parity.py).
+// ---------------------------------------------------------------------------------------------
+constexpr int TAIL_MAX_N = 64;      // larger graphs: three-kernel path (the eq_transform terms of a graph live in LDS)
+constexpr int TAIL_MAX_G = 4096;    // every workgroup sums all records before its own: ceil(g / 64) sweeps
+constexpr int TAIL_CTL_INTS = 4;    // ticket + padding ahead of the records in geo.scratch
+constexpr unsigned TAIL_SPIN_LIMIT = 400000u;  // ~0.3 s of polling: then TSD_STATUS_INTERNAL instead of a hang
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+template <int NT>
+__global__ __launch_bounds__(NT) void step_tail_kernel(int kind, int N, int G, int M, int P,
+                                                       const int32_t* __restrict__ graph_ptr,
+                                                       const int32_t* __restrict__ pair_ptr,
+                                                       const uint16_t* __restrict__ pair_code, tsd_geometry gq,
+                                                       const float* __restrict__ inv_u, float clip, float clip_pos,
+                                                       float* __restrict__ pos, tsd_sampler_state* __restrict__ ss,
+                                                       int order_enc, int order_out, float cut2,
+                                                       int max_pairs /* LDS capacity in ordered pairs */) {
+    constexpr int NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
+    float* old_s = reinterpret_cast<float*>(tsm);          // [3 * TAIL_MAX_N]
+    float* new_s = old_s + 3 * TAIL_MAX_N;                 // [3 * TAIL_MAX_N]
+    int* ccnt = reinterpret_cast<int*>(new_s + 3 * TAIL_MAX_N);  // [NLIST][64] per-chunk member counts -> exclusive prefix
+    int* misc = ccnt + NLIST * 64;                         // [16]
+    float* terms = reinterpret_cast<float*>(misc + 16);    // [3 * max_n (max_n - 1)] u_e s_e of every ordered pair
+    uint16_t* code_s = reinterpret_cast<uint16_t*>(terms + 3 * max_pairs);  // [max_n (max_n - 1)] pair codes
+
+    // The kernel is a chain of dependent memory round trips (everything it reads was written by the kernels just
+    // before it: ~2 us each): keep the chain short -- [ticket || graph offsets of the expected graph] -> [positions,
+    // pair offset, coefficients, noise] -> [pair codes, undirected out index of every pair] -> [edge_inv gathers].
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int PU = P / 2;
+    unsigned* ticket = reinterpret_cast<unsigned*>(gq.scratch);
+    gu64* rec = (gu64*)(gq.scratch + TAIL_CTL_INTS);
+    if (tid == 0) misc[0] = (int)atomicAdd(ticket, 1u);
+    // (workgroups are dispatched in blockIdx order in practice: the ticket then equals it and these loads are used)
+    const int g_spec = (int)blockIdx.x;
+    int lo = graph_ptr[g_spec], hi = graph_ptr[g_spec + 1];
+    const tsd_run_args ra = ss->args;
+    __syncthreads();
+    const unsigned tk = (unsigned)misc[0];
+    const int g = (int)(tk % (unsigned)G);
+    const unsigned epoch = tk / (unsigned)G + 1u;
+    const unsigned long long tag = epoch & 0xffffu;
+    if (g != g_spec) {
+        lo = graph_ptr[g];
+        hi = graph_ptr[g + 1];
+    }
+    const int n = hi - lo;
+    const int nm1 = max(n - 1, 1);
+    const int npairs = n * (n - 1);
+    // row of ordered pair p = p / (n - 1) without the ~40-instruction runtime division: exact for p (n - 1) < 2^32
+    const unsigned div_magic = nm1 > 1 ? 0xFFFFFFFFu / (unsigned)nm1 + 1u : 0u;
+    auto row_of = [&](int p) { return nm1 > 1 ? (int)__umulhi((unsigned)p, div_magic) : p; };
+    int32_t* status = &ss->flags;
+    const size_t k_step = kind >= 0 ? (size_t)(epoch - 2u) : 0;
+    const float* __restrict__ coefs = ra.coefs + k_step * TSD_STEP_COEFS;
+    const float* __restrict__ noise = ra.noises ? ra.noises + k_step * 3 * (size_t)N : nullptr;
+    float* __restrict__ traj = ra.traj ? ra.traj + k_step * 3 * (size_t)N : nullptr;
+
+    // second round trip: positions, the graph's pair offset, this lane's noise row, the step's coefficients
+    const int pg0 = pair_ptr[lo];
+    float c[TSD_STEP_COEFS];
+    float zn[3] = {0.f, 0.f, 0.f};
+    if (kind >= 0 && wave == 0) {
+#pragma unroll
+        for (int k = 0; k < TSD_STEP_COEFS; ++k) c[k] = coefs[k];
+        if (noise && lane < n) {
+            zn[0] = noise[3 * (lo + lane)]; zn[1] = noise[3 * (lo + lane) + 1]; zn[2] = noise[3 * (lo + lane) + 2];
+        }
+    }
+    for (int t = tid; t < 3 * n; t += NT) old_s[t] = pos[3 * lo + t];
+    __syncthreads();
+
+    // third + fourth round trip, PB pairs per thread in flight: pair code (-> LDS, the membership tests below read
+    // it twice) and -- update launches -- the pair's undirected out edge, then its edge_inv; u_e s_e -> LDS for
+    // EVERY ordered pair (+0 for non-edges: the ordered row sums below are unchanged by adding +0)
+    constexpr int PB = NT >= 256 ? 4 : 8;
+    for (int p0 = 0; p0 < npairs; p0 += PB * NT) {
+        int code[PB], uu[PB];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int p = min(p0 + q * NT + tid, npairs - 1);
+            code[q] = pair_code[pg0 + p];
+            uu[q] = -1;
+            if (kind >= 0) {
+                const int il = row_of(p), k = p - il * nm1;
+                const int jl = k + (k >= il ? 1 : 0);
+                const int p_up = jl > il ? p : jl * nm1 + il - 1;  // the pair with src < dst
+                uu[q] = gq.pair2u[(size_t)P + pg0 + p_up];
+            }
+        }
+        float sv[PB];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            sv[q] = 0.0f;
+            if (uu[q] >= 0) {
+                float s = inv_u[uu[q]];
+                for (int m = 1; m < M; ++m) s = __fadd_rn(s, inv_u[(size_t)m * PU + uu[q]]);
+                sv[q] = s / (float)M;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int p = p0 + q * NT + tid;
+            if (p < npairs) {
+                code_s[p] = (uint16_t)code[q];
+                if (kind >= 0) {
+                    float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+                    if (uu[q] >= 0) {
+                        const int il = row_of(p), k = p - il * nm1;
+                        const int jl = k + (k >= il ? 1 : 0);
+                        const float dx = old_s[3 * il] - old_s[3 * jl], dy = old_s[3 * il + 1] - old_s[3 * jl + 1],
+                                    dz = old_s[3 * il + 2] - old_s[3 * jl + 2];
+                        // edge_length as the list build computed it (eval_pair_xyz), 1 / d as eq_transform
+                        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                        const float inv = 1.0f / sqrtf(d2);
+                        t0 = __fmul_rn(__fmul_rn(inv, dx), sv[q]);
+                        t1 = __fmul_rn(__fmul_rn(inv, dy), sv[q]);
+                        t2 = __fmul_rn(__fmul_rn(inv, dz), sv[q]);
+                    }
+                    terms[3 * p] = t0;
+                    terms[3 * p + 1] = t1;
+                    terms[3 * p + 2] = t2;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (kind >= 0) {
+        const uint64_t seed = ra.seed, ctr0 = ra.offset + k_step * (uint64_t)N;
+        if (wave == 0) {  // n <= 64: one atom per lane of wave 0 (same lane <-> atom map and sums as step_post_kernel)
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            float p[3] = {0.f, 0.f, 0.f};
+            bool bad = false;
+            const int il = lane;
+            if (il < n) {
+                const int i = lo + il;
+                p[0] = old_s[3 * il]; p[1] = old_s[3 * il + 1]; p[2] = old_s[3 * il + 2];
+                float ax = 0.f, ay = 0.f, az = 0.f;
+                const float* tr = terms + 3 * il * (n - 1);
+                for (int r = 0; r < n - 1; ++r) {  // the row's pairs in order = the row's edges in order
+                    ax = __fadd_rn(ax, tr[3 * r]);
+                    ay = __fadd_rn(ay, tr[3 * r + 1]);
+                    az = __fadd_rn(az, tr[3 * r + 2]);
+                }
+                const float v[3] = {ax + ax, ay + ay, az + az};
+                // clip_norm (sampler.py:265-268)
+                const float norm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(v[0], v[0]), __fmul_rn(v[1], v[1])), __fmul_rn(v[2], v[2])));
+                const float denom = norm > clip ? clip / norm : 1.0f;
+                if (!noise) philox_normal3(ctr0 + (uint64_t)i, seed, zn);  // sampler.py:213 randn_like, generated in place
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float eps = __fmul_rn(v[k], denom);
+                    const float nz = zn[k];
+                    float nx;
+                    if (kind == 0) {  // LD, sampler.py:238-244
+                        nx = __fadd_rn(__fadd_rn(p[k], __fmul_rn(c[0], eps) / c[1]), __fmul_rn(nz, c[2]));
+                    } else {  // DDPM, sampler.py:215-236
+                        const float e = -eps;
+                        const float pos_C = __fmul_rn(c[0], p[k]);
+                        const float pos0 = __fsub_rn(__fmul_rn(c[1], pos_C), __fmul_rn(c[2], e));
+                        const float mean = __fadd_rn(__fmul_rn(c[3], pos0), __fmul_rn(c[4], pos_C)) / c[5];
+                        nx = __fadd_rn(mean, __fmul_rn(c[6], nz)) / c[7];
+                    }
+                    bad |= (nx != nx);
+                    p[k] = nx;
+                }
+                sx = p[0]; sy = p[1]; sz = p[2];
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                sx += __shfl_xor(sx, off);
+                sy += __shfl_xor(sy, off);
+                sz += __shfl_xor(sz, off);
+            }
+            if (__ballot(bad) != 0ull && lane == 0) atomicOr(status, TSD_STATUS_NAN);
+            const float cntf = (float)max(n, 1);
+            const float mx = sx / cntf, my = sy / cntf, mz = sz / cntf;
+            if (il < n) {  // center_pos (sampler.py:260-262) + optional clamp
+                float x = p[0] - mx, y = p[1] - my, z = p[2] - mz;
+                if (clip_pos >= 0.0f) {
+                    x = fminf(fmaxf(x, -clip_pos), clip_pos);
+                    y = fminf(fmaxf(y, -clip_pos), clip_pos);
+                    z = fminf(fmaxf(z, -clip_pos), clip_pos);
+                }
+                new_s[3 * il] = x;
+                new_s[3 * il + 1] = y;
+                new_s[3 * il + 2] = z;
+                const int i = lo + il;
+                pos[3 * i] = x;
+                pos[3 * i + 1] = y;
+                pos[3 * i + 2] = z;
+                if (traj) {
+                    traj[3 * i] = x;
+                    traj[3 * i + 1] = y;
+                    traj[3 * i + 2] = z;
+                }
+            }
+        }
+        __syncthreads();
+    } else {
+        __syncthreads();
+        for (int t = tid; t < 3 * n; t += NT) new_s[t] = old_s[t];
+        __syncthreads();
+    }
+
+    // ---- membership on the new positions: per-chunk counts of the five lists (chunk = 64 consecutive ordered pairs)
+    const int nchunks = (npairs + 63) >> 6;  // <= 63 for n <= 64
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    for (int c = wave; c < nchunks; c += NW) {
+        const int p = c * 64 + lane;
+        bool m[NLIST] = {false, false, false, false, false};
+        if (p < npairs) {
+            const int il = row_of(p), k = p - il * nm1;
+            const int jl = k + (k >= il ? 1 : 0);
+            const PairEval r = eval_pair_xyz(new_s[3 * il], new_s[3 * il + 1], new_s[3 * il + 2], new_s[3 * jl],
+                                             new_s[3 * jl + 1], new_s[3 * jl + 2], code_s[p], order_enc, order_out, cut2);
+            const bool up = jl > il;
+            m[0] = r.in_enc;
+            m[1] = r.in_out;
+            m[2] = r.in_enc && up;
+            m[3] = r.in_out && up;
+            m[4] = r.needs_own_attr() && up;
+        }
+#pragma unroll
+        for (int q = 0; q < NLIST; ++q) {
+            const int cq = __popcll(__ballot(m[q]));
+            if (lane == 0) ccnt[q * 64 + c] = cq;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // exclusive prefix over the chunks (one chunk per lane), the graph's totals, its record, the look-back
+        int tot[NLIST];
+#pragma unroll
+        for (int q = 0; q < NLIST; ++q) {
+            const int x = lane < nchunks ? ccnt[q * 64 + lane] : 0;
+            int v = x;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int u = __shfl_up(v, off);
+                if (lane >= off) v += u;
+            }
+            ccnt[q * 64 + lane] = v - x;
+            tot[q] = __shfl(v, 63);
+        }
+        if (lane == 0) {
+            const unsigned long long r = tag | ((unsigned long long)tot[2] << 16) | ((unsigned long long)tot[3] << 32) |
+                                         ((unsigned long long)tot[4] << 48);
+            __hip_atomic_store(rec + g, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        int base[3] = {0, 0, 0};
+        bool gave_up = false;
+        constexpr int LB = 4;  // records per lane per sweep (their loads are in flight together): 256 graphs
+        for (int g0 = 0; g0 < g && !gave_up; g0 += 64 * LB) {
+            unsigned long long r[LB];
+#pragma unroll
+            for (int q = 0; q < LB; ++q) r[q] = tag;
+            for (unsigned spins = 0;; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < LB; ++q) {
+                    const int gg = g0 + q * 64 + lane;
+                    // (a record that has matched is not loaded again)
+                    if (gg < g && (spins == 0 || (r[q] & 0xffffull) != tag))
+                        r[q] = __hip_atomic_load(rec + gg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int q = 0; q < LB; ++q) ok &= (r[q] & 0xffffull) == tag;
+                if (__all(ok)) break;
+                if (spins > TAIL_SPIN_LIMIT) {  // (wave-uniform: the exit condition is a ballot)
+                    gave_up = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            int a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+            for (int q = 0; q < LB; ++q) {
+                if (g0 + q * 64 + lane < g) {
+                    a0 += (int)((r[q] >> 16) & 0xffffull);
+                    a1 += (int)((r[q] >> 32) & 0xffffull);
+                    a2 += (int)((r[q] >> 48) & 0xffffull);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                a0 += __shfl_xor(a0, off);
+                a1 += __shfl_xor(a1, off);
+                a2 += __shfl_xor(a2, off);
+            }
+            base[0] += a0;
+            base[1] += a1;
+            base[2] += a2;
+        }
+        if (lane == 0) {
+            if (gave_up) atomicOr(status, TSD_STATUS_INTERNAL);
+            misc[1] = 2 * base[0];  // enc
+            misc[2] = 2 * base[1];  // out
+            misc[3] = base[0];      // enc_u
+            misc[4] = base[1];      // out_u
+            misc[5] = base[2];      // diff_u
+            if (g == G - 1) {  // the last graph closes the lists
+                const int end[NLIST] = {misc[1] + tot[0], misc[2] + tot[1], misc[3] + tot[2], misc[4] + tot[3],
+                                        misc[5] + tot[4]};
+                tsd_edges* lists[NLIST] = {&gq.enc, &gq.out, &gq.enc_u, &gq.out_u, &gq.diff_u};
+#pragma unroll
+                for (int q = 0; q < NLIST; ++q) {
+                    lists[q]->row_ptr[N] = end[q];
+                    *lists[q]->count = end[q];
+                }
+                ss->step = (int32_t)epoch - 2;  // row of the step tables this launch used (-1: the list-only launch)
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- fill: the member pairs of chunk c land at base + (members in earlier chunks) + (members among lower lanes)
+    const int gbase[NLIST] = {misc[1], misc[2], misc[3], misc[4], misc[5]};
+    if (npairs == 0) {
+        if (tid < n) {  // (n == 1: a row without pairs)
+            gq.enc.row_ptr[lo + tid] = gbase[0];
+            gq.out.row_ptr[lo + tid] = gbase[1];
+            gq.enc_u.row_ptr[lo + tid] = gbase[2];
+            gq.out_u.row_ptr[lo + tid] = gbase[3];
+            gq.diff_u.row_ptr[lo + tid] = gbase[4];
+        }
+        return;
+    }
+    for (int c = wave; c < nchunks; c += NW) {
+        const int p = c * 64 + lane;
+        const bool valid = p < npairs;
+        PairEval r;
+        r.in_enc = r.in_out = false;
+        r.d = 0.f;
+        r.tr_enc = r.tp_enc = r.tr_out = r.tp_out = 0;
+        int il = 0, k = 0, jl = 0;
+        bool up = false;
+        if (valid) {
+            il = row_of(p);
+            k = p - il * nm1;
+            jl = k + (k >= il ? 1 : 0);
+            r = eval_pair_xyz(new_s[3 * il], new_s[3 * il + 1], new_s[3 * il + 2], new_s[3 * jl], new_s[3 * jl + 1],
+                              new_s[3 * jl + 2], code_s[p], order_enc, order_out, cut2);
+            up = jl > il;
+        }
+        const bool m[NLIST] = {r.in_enc, r.in_out, r.in_enc && up, r.in_out && up, valid && up && r.needs_own_attr()};
+        int at[NLIST];
+#pragma unroll
+        for (int q = 0; q < NLIST; ++q)
+            at[q] = gbase[q] + ccnt[q * 64 + c] + __popcll(__ballot(m[q]) & lower);
+        const int i = lo + il, j = lo + jl;
+        if (valid && k == 0) {  // the first pair of a row: its would-be positions are the row's offsets
+            gq.enc.row_ptr[i] = at[0];
+            gq.out.row_ptr[i] = at[1];
+            gq.enc_u.row_ptr[i] = at[2];
+            gq.out_u.row_ptr[i] = at[3];
+            gq.diff_u.row_ptr[i] = at[4];
+        }
+        if (m[0]) {
+            const int e = at[0];
+            gq.enc.src[e] = i;
+            gq.enc.dst[e] = j;
+            gq.enc.dist[e] = r.d;
+            gq.enc.type_r[e] = (uint8_t)r.tr_enc;
+            gq.enc.type_p[e] = (uint8_t)r.tp_enc;
+            gq.enc.pair_id[e] = pg0 + p;
+        }
+        if (m[1]) {
+            const int e = at[1];
+            gq.out.src[e] = i;
+            gq.out.dst[e] = j;
+            gq.out.dist[e] = r.d;
+            gq.out.type_r[e] = (uint8_t)r.tr_out;
+            gq.out.type_p[e] = (uint8_t)r.tp_out;
+            gq.out.pair_id[e] = pg0 + p;
+        }
+        if (m[2]) {
+            const int e = at[2];
+            gq.enc_u.src[e] = i;
+            gq.enc_u.dst[e] = j;
+            gq.enc_u.dist[e] = r.d;
+            gq.enc_u.type_r[e] = (uint8_t)r.tr_enc;
+            gq.enc_u.type_p[e] = (uint8_t)r.tp_enc;
+            gq.enc_u.pair_id[e] = pg0 + p;
+        }
+        if (m[3]) {
+            const int e = at[3];
+            gq.out_u.src[e] = i;
+            gq.out_u.dst[e] = j;
+            gq.out_u.dist[e] = r.d;
+            gq.out_u.type_r[e] = (uint8_t)r.tr_out;
+            gq.out_u.type_p[e] = (uint8_t)r.tp_out;
+            gq.out_u.pair_id[e] = pg0 + p;
+            gq.attr_row[e] = m[4] ? PU + at[4] : at[2];  // own embedding, or the enc_u edge's row
+        }
+        if (m[4]) {
+            const int e = at[4];
+            gq.diff_u.dist[e] = r.d;
+            gq.diff_u.type_r[e] = (uint8_t)r.tr_out;
+            gq.diff_u.type_p[e] = (uint8_t)r.tp_out;
+        }
+        if (valid) {
+            gq.pair2out[pg0 + p] = m[1] ? at[1] : -1;
+            if (up) {
+                gq.pair2u[pg0 + p] = m[2] ? at[2] : -1;
+                gq.pair2u[(size_t)P + pg0 + p] = m[3] ? at[3] : -1;
+            }
+        }
+    }
+}
+
+bool step_tail_supported(int N, int G, int max_n) {
+    return G >= 1 && N >= 1 && max_n >= 1 && max_n <= TAIL_MAX_N && G <= TAIL_MAX_G &&
+           (size_t)TAIL_CTL_INTS + 2 * (size_t)G <= geometry_scratch_ints(N, 0);
+}
+
+// zero the ticket and the records: once per run, ahead of the list-only launch (outside the captured step)
+int launch_step_tail_reset(int G, tsd_geometry g, hipStream_t st) {
+    TSD_HIP(hipMemsetAsync(g.scratch, 0, ((size_t)TAIL_CTL_INTS + 2 * (size_t)G) * sizeof(int32_t), st));
+    return TSD_OK;
+}
+
+// kind < 0: lists of `pos` only (first step of a run); kind 0 / 1: the LD / DDPM step tail, then the lists
+int launch_step_tail(const tsd_model_cfg& c, int kind, int N, int G, int M, int P, int max_n,
+                     const int32_t* graph_ptr, const int32_t* pair_ptr, const uint16_t* pair_code, tsd_geometry g,
+                     const float* inv_u, float clip, float clip_pos, float* pos, tsd_sampler_state* state,
+                     hipStream_t st) {
+    if (!step_tail_supported(N, G, max_n)) {
+        set_error("internal: fused step tail launched for an unsupported batch (N=%d G=%d max_n=%d)", N, G, max_n);
+        return TSD_ERR_INVALID;
+    }
+    const size_t fixed = (size_t)(6 * TAIL_MAX_N) * 4 + (size_t)(NLIST * 64 + 16) * 4;
+    auto lds_for = [&](int mn) { return fixed + (size_t)14 * mn * (mn - 1) + 16; };  // 3 floats + 1 u16 per ordered pair
+    const size_t lds = lds_for(max_n);
+    const int max_pairs = max_n * (max_n - 1);
+    const float cut2 = c.edge_cutoff * c.edge_cutoff;
+    if (max_n <= 12) {  // (<= 132 ordered pairs: one wave; else four waves share the pair loops)
+        hipLaunchKernelGGL(step_tail_kernel<64>, dim3(G), dim3(64), lds, st, kind, N, G, M, P, graph_ptr, pair_ptr,
+                           pair_code, g, inv_u, clip, clip_pos, pos, state, c.edge_order, c.pred_edge_order, cut2,
+                           max_pairs);
+    } else {
+        static DeviceOnce once;  // (the attribute is set once per device: ask for the largest graph's worth)
+        int r = allow_lds(step_tail_kernel<256>, lds_for(TAIL_MAX_N), once);
+        if (r) return r;
+        hipLaunchKernelGGL(step_tail_kernel<256>, dim3(G), dim3(256), lds, st, kind, N, G, M, P, graph_ptr, pair_ptr,
+                           pair_code, g, inv_u, clip, clip_pos, pos, state, c.edge_order, c.pred_edge_order, cut2,
+                           max_pairs);
+    }
+    TSD_LAUNCH_CHECK("step_tail");
+    return TSD_OK;
+}
+
 // per-call inputs of the captured step -> the device-resident state block (flags untouched); step = -1: the
 // scan kernel of every step, the first included, advances it
 __global__ void set_run_args_kernel(tsd_sampler_state* ss, tsd_run_args a) {

@@ -4,6 +4,17 @@
 
 namespace tsd {
 
+template <int V>
+struct VecOf {  // V consecutive channels of a row held by one lane
+    typedef float type __attribute__((ext_vector_type(V)));
+    static __device__ __forceinline__ float get(const type& x, int v) { return x[v]; }
+};
+template <>
+struct VecOf<1> {
+    typedef float type;
+    static __device__ __forceinline__ float get(const type& x, int) { return x; }
+};
+
 // ---------------------------------------------------------------------------------------------
 // A2: z = [Emb[atom] + Wf r_feat , Wf p_feat - Wf r_feat]      reference condensenc.py:193-198
 // ---------------------------------------------------------------------------------------------
@@ -52,44 +63,59 @@ __global__ __launch_bounds__(256) void cfconv_aggregate_kernel(int N, const int3
                                                                const float* __restrict__ x1,
                                                                float* __restrict__ out) {
     constexpr int V = H / 64;  // floats per lane: 4 (H=256), 2, 1
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    typedef typename VecOf<V>::type vrow;
+    // Row order.  Workgroups are dealt round-robin to the 8 XCDs, each with a private L2, and the rows of ONE graph
+    // gather the same x1 rows: with the identity order the 16 workgroups of a 64-atom graph land on all 8 XCDs and
+    // every L2 fetches the graph's x1 rows (r02 PMC: 4.87 GB fetched for 4.38 GB algorithmic).  The XCD-aware order
+    // (TSD_AGG_SWZ=1: XCD x takes the contiguous range [x B/8, (x+1) B/8) of 4-row groups) was measured SLOWER at
+    // configs[4] size, 785 vs 753 us per launch (tools/ab_agg.py, round 3): eight far-apart W streams cost more than
+    // the re-fetched x1 rows (11 % of the bytes) save.  Identity order kept.
+    const int B = gridDim.x, b = blockIdx.x;
+    const int per = B >> 3;
+#ifndef TSD_AGG_SWZ
+#define TSD_AGG_SWZ 0
+#endif
+#ifndef TSD_AGG_U
+#define TSD_AGG_U 8
+#endif
+    const int grp = (TSD_AGG_SWZ && b < (per << 3)) ? (b & 7) * per + (b >> 3) : b;  // (the tail that does not fill 8 XCDs: identity)
+    const int i = grp * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (wave-uniform: scalar row offsets)
     const int lane = threadIdx.x & 63;
     if (i >= N) return;
     const int e0 = row_ptr[i], e1 = row_ptr[i + 1];
     float acc[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) acc[v] = 0.0f;
-    constexpr int U = 4;
-    int e = e0;
-    for (; e + U <= e1; e += U) {
-        float w[U][V], x[U][V];
+    // The row's indices come by ONE coalesced load per 64 edges (lane l holds edge eb + l) and reach the row loads
+    // through v_readlane (wave-uniform row bases in SGPRs); then U edges = 2 U row loads in flight per wave, the last
+    // batch clamped to the row's last edge (its extra slots are loaded, not added).  The per-edge index loads of the
+    // r02 form sat between the row loads with a vmcnt(0) each (ISA), and 63-edge rows spent 3 of 18 round trips in a
+    // one-edge tail loop.
+    constexpr int U = TSD_AGG_U;
+    for (int eb = e0; eb < e1; eb += 64) {
+        const int cnt = min(64, e1 - eb);
+        const int ee = eb + min(lane, cnt - 1);
+        const int jv = dst[ee];
+        const int wv = umap ? umap[ee] : ee;
+        for (int k = 0; k < cnt; k += U) {
+            vrow w[U], x[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = dst[e + u];
-            const int we = umap ? umap[e + u] : e + u;
-            const float* wp = W + (size_t)we * H + lane * V;
-            const float* xp = x1 + (size_t)j * H + lane * V;
-            if (V == 4) {
-                const f32x4 wv = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp));
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(xp);
+            for (int u = 0; u < U; ++u) {
+                const int kk = min(k + u, cnt - 1);
+                const int j = __builtin_amdgcn_readlane(jv, kk);
+                const int we = __builtin_amdgcn_readlane(wv, kk);
+                w[u] = __builtin_nontemporal_load(reinterpret_cast<const vrow*>(W + (size_t)we * H + lane * V));
+                x[u] = *reinterpret_cast<const vrow*>(x1 + (size_t)j * H + lane * V);
+            }
 #pragma unroll
-                for (int v = 0; v < V; ++v) { w[u][v] = wv[v]; x[u][v] = xv[v]; }
-            } else {
+            for (int u = 0; u < U; ++u) {
+                if (k + u < cnt) {
 #pragma unroll
-                for (int v = 0; v < V; ++v) { w[u][v] = wp[v]; x[u][v] = xp[v]; }
+                    for (int v = 0; v < V; ++v)
+                        acc[v] = __fadd_rn(acc[v], __fmul_rn(VecOf<V>::get(x[u], v), VecOf<V>::get(w[u], v)));
+                }
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int v = 0; v < V; ++v) acc[v] = __fadd_rn(acc[v], __fmul_rn(x[u][v], w[u][v]));
-    }
-    for (; e < e1; ++e) {
-        const int j = dst[e];
-        const int we = umap ? umap[e] : e;
-#pragma unroll
-        for (int v = 0; v < V; ++v)
-            acc[v] = __fadd_rn(acc[v], __fmul_rn(x1[(size_t)j * H + lane * V + v], W[(size_t)we * H + lane * V + v]));
     }
 #pragma unroll
     for (int v = 0; v < V; ++v) out[(size_t)i * H + lane * V + v] = acc[v];

@@ -199,8 +199,7 @@ __global__ __launch_bounds__(2 * H) void edge_embed_kernel(EdgeEmbedW w, tsd_edg
         constexpr int C4 = H / 4;
         for (int idx = tid; idx < nrows * C4; idx += 2 * H) {
             const int r = idx / C4, c4 = idx % C4;
-            *reinterpret_cast<f32x4*>(f0.wf + (size_t)(e0 + r) * H + c4 * 4) =
-                *reinterpret_cast<const f32x4*>(buf + r * LDA + c4 * 4);
+            store_stream16(f0.wf + (size_t)(e0 + r) * H + c4 * 4, *reinterpret_cast<const f32x4*>(buf + r * LDA + c4 * 4));
         }
     }
 }

@@ -359,9 +359,12 @@ __global__ __launch_bounds__(256) void sumsq_stage2_kernel(const float* __restri
 }
 // g *= min(1, max_norm / (norm + 1e-6))                               torch.nn.utils.clip_grad_norm_
 __global__ void clip_scale_kernel(int64_t n, float* __restrict__ g, const float* __restrict__ norm, float max_norm) {
-    const float coef = fminf(max_norm / (norm[0] + 1e-6f), 1.0f);
+    // torch: clip_coef_clamped = clamp(max_norm / (total_norm + 1e-6), max=1.0), every gradient multiplied by it --
+    // a NaN total norm gives a NaN coefficient (torch.clamp keeps NaN) and NaN gradients.  Only the exact no-op
+    // (coef >= 1) is skipped.
+    const float coef = max_norm / (norm[0] + 1e-6f);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && coef < 1.0f) g[i] *= coef;
+    if (i < n && !(coef >= 1.0f)) g[i] *= coef;
 }
 // torch.optim.Adam (no amsgrad, minimise): g += wd p; m = lerp(m, g, 1 - b1); v = b2 v + (1 - b2) g^2;
 // p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)

@@ -4,6 +4,7 @@ torch is used for device memory (caching allocator), streams and dtype conversio
 computation of the path runs in libtsdiff_hip.so.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -81,6 +82,8 @@ def pack_weights(cfg, named_tensors, device):
 
 
 _SIDE_STREAMS = {}
+# tests / tools flip this to run the sampling loop's step tail as the three separate launches (bit-identical results)
+FUSED_STEP_TAIL = os.environ.get("TSDIFF_FUSED_TAIL", "1") != "0"
 
 
 def _side_stream(device):
@@ -275,7 +278,9 @@ class DeviceBatch:
             pair_ptr=self.pair_ptr.data_ptr(), pair_code=self.pair_code.data_ptr(),
             weights=self.weights.data_ptr(), z=self.z.data_ptr(), x1_0=self.x1_0.data_ptr(),
             geo=self.geo_struct(), workspace=self.workspace.data_ptr(),
-            edge_inv_u=self.edge_inv_u.data_ptr())
+            edge_inv_u=self.edge_inv_u.data_ptr(),
+            # 0 = "unknown": the library then runs the step tail as three launches (A/B switch for tests / tools)
+            max_graph_nodes=self.max_n if FUSED_STEP_TAIL else 0)
 
     def train_struct(self):
         """tsd_batch for the training step: topology + edge-list buffers only (no bound checkpoints)"""
@@ -347,7 +352,7 @@ class DeviceBatch:
     def sampler_plan(self, kind, clip, clip_pos):
         """the captured + instantiated hipGraph of one sampling step for the bound checkpoints; built once and
         replayed by every later dynamic_sampling call on this batch (reference loop: models/sampler.py:187-254)"""
-        key = (int(kind), float(clip), float(-1.0 if clip_pos is None else clip_pos))
+        key = (int(kind), float(clip), float(-1.0 if clip_pos is None else clip_pos), bool(FUSED_STEP_TAIL))
         plan = self._plans.get(key)
         if plan is None:
             lib = _lib.load()

@@ -128,7 +128,8 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, error_if_nonfinite=Fals
         parameters = [parameters]
     params = [p for p in parameters if p.grad is not None]
     flat = None
-    if params and float(norm_type) == 2.0 and not error_if_nonfinite:
+    # (max_norm <= 0: torch zeroes / flips the gradients; not worth a kernel variant -- torch's own path)
+    if params and float(norm_type) == 2.0 and not error_if_nonfinite and float(max_norm) > 0.0:
         key = tuple(id(p) for p in params)
         lay = _clip_layouts.get(key)
         if lay is None:
@@ -239,6 +240,16 @@ class Adam(torch.optim.Optimizer):
                               weight_decay=group["weight_decay"], eps=group["eps"], maximize=False, foreach=None,
                               capturable=False, differentiable=False, fused=None, grad_scale=None, found_inf=None,
                               has_complex=False)
+
+    def state_dict(self):
+        """torch.optim.Adam's layout.  The flat path keeps ONE step counter per group, shared by the per-parameter
+        state entries; a checkpoint must not carry that aliasing (torch.optim.Adam.load_state_dict keeps `step`
+        tensors as they are, so its step() would bump the shared counter once per parameter): every entry gets its
+        own copy of the counter here."""
+        sd = super().state_dict()
+        sd["state"] = {k: ({**st, "step": st["step"].clone()} if torch.is_tensor(st.get("step")) else dict(st))
+                       for k, st in sd["state"].items()}
+        return sd
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)

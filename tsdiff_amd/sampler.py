@@ -179,6 +179,8 @@ class EnsembleSampler(nn.Module):
                 if return_traj:
                     pos_traj += list(traj.cpu().unbind(0))
             status = int(db.status[0].item())  # the single host sync of the loop
+            if status & _lib.STATUS_INTERNAL:
+                raise _lib.TsdError("internal: a bounded wait of the fused step tail gave up (TSD_STATUS_INTERNAL)")
             if status & _lib.STATUS_NAN:
                 print("NaN detected. Please restart.")
                 raise FloatingPointError()
