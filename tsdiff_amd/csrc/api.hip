@@ -113,6 +113,10 @@ struct Workspace {
 };
 
 constexpr int WF_RING = 2;
+#ifndef TSD_FOLD
+#define TSD_FOLD 1  // the inference forward on the folded weights (common.hpp, FOLDED WEIGHTS); 0: A/B variant builds
+#endif
+constexpr bool kFold = TSD_FOLD != 0;
 
 static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base) {
     Workspace w;
@@ -173,8 +177,9 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     // the first per-block launch, which had no node chain to run beside them, disappears
     const WeightLayout WL0 = weight_layout(c);
     EmbedFuse0 f0{};
-    f0.nn0_w = W + WL0.layer0 + WL0.L_nn0_w;
-    f0.nn0_b = W + WL0.layer0 + WL0.L_nn0_b;
+    // (the inference forward runs on the FOLDED weights: the attribute rows hold s1, common.hpp)
+    f0.nn0_w = W + WL0.layer0 + (kFold ? WL0.L_nn0f_w : WL0.L_nn0_w);
+    f0.nn0_b = W + WL0.layer0 + (kFold ? WL0.L_nn0f_b : WL0.L_nn0_b);
     f0.nn2_w = W + WL0.layer0 + WL0.L_nn2_w;
     f0.nn2_b = W + WL0.layer0 + WL0.L_nn2_b;
     f0.conv_cutoff = c.conv_cutoff;
@@ -185,7 +190,7 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     // tiles lose more than the launch saves, 50.5 -> 52.8 ms/step)
     const bool fuse_block0 = (long)((N + TSD_NODE_TILE - 1) / TSD_NODE_TILE) * M <= 256;
     if ((r = launch_edge_embed2(c, W, PU, g.enc_u, w.ea, PU, g.diff_u, w.ea + (size_t)PU * H, M, w.stride_ea, st,
-                                &um, nullptr, 0, fuse_block0 ? &f0 : nullptr)))
+                                &um, nullptr, 0, fuse_block0 ? &f0 : nullptr, kFold)))
         return r;
     // block 0 reads z (residual input) and x1_0 = lin1_0(z) straight from the per-batch arrays -- both are
     // pos independent (computed at bind time) -- so no per-step copy of z and no lin1 launch
@@ -208,8 +213,8 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     pre.e = g.out_u;
     pre.edge_attr = w.ea;
     pre.attr_row = g.attr_row;
-    pre.w0b = W + WL.out_w0 + H * H;  // packed [k/4][out][k%4]: the k >= H half is contiguous
-    pre.b0 = W + WL.out_b0;
+    pre.w0b = kFold ? W + WL.out_w0f : W + WL.out_w0 + H * H;  // packed [k/4][out][k%4]: the k >= H half is contiguous
+    pre.b0 = W + (kFold ? WL.out_b0f : WL.out_b0);
     pre.out = w.pre;
     // (only when the node chain of the last block leaves most of the chip idle: at batch 100 it occupies ~100
     // of the 256 CUs; with an ensemble or a large batch the launch is full and the extra role only adds work:
@@ -220,7 +225,8 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
         const float* wf_read = layer >= 0 ? w.wf + (size_t)(layer % w.wf_slots) * PU * H : nullptr;
         if ((r = launch_layer_combo(c, W, layer, N, g.enc, wf_read, xin, layer == 0 ? b.z : w.h, w.h, xout, 0,
                                     j * tpl, j < L ? tpl : 0, PU, g.enc_u, w.ea, w.wf, w.wf_slots, M, w.stride_nh,
-                                    w.stride_ea, w.stride_wf, st, (use_pre && j == L) ? &pre : nullptr, w.stride_pre)))
+                                    w.stride_ea, w.stride_wf, st, (use_pre && j == L) ? &pre : nullptr, w.stride_pre,
+                                    nullptr, nullptr, kFold)))
             return r;
         if (layer >= 0) {
             xin = xout;
@@ -228,7 +234,7 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
         }
     }
     return launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u, M, w.stride_nh, w.stride_ea,
-                              (size_t)PU, st, use_pre ? w.pre : nullptr, w.stride_pre);
+                              (size_t)PU, st, use_pre ? w.pre : nullptr, w.stride_pre, nullptr, kFold);
 }
 
 // one sampling step of the device-resident loop: lists (from the counts of the previous step's tail) ->

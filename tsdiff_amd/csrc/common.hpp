@@ -75,10 +75,20 @@ struct WeightLayout {
     size_t ecat_w0, ecat_b0, ecat_w1, ecat_b1;
     size_t layer0, layer_stride;  // per layer: see L_* offsets below
     size_t out_w0, out_b0, out_w1, out_b1, out_w2, out_b2;
+    size_t out_w0f, out_b0f;  // folded (see below): W0[:, H:] . W_cat2 [H x H], W0[:, H:] . b_cat2 + b0
     size_t total;
     // offsets inside one layer block
     size_t L_nn0_w, L_nn0_b, L_nn2_w, L_nn2_b, L_lin1_w, L_lin2_w, L_lin2_b, L_lin_w, L_lin_b;
+    size_t L_nn0f_w, L_nn0f_b;  // folded: W_nn0 . W_cat2, W_nn0 . b_cat2 + b_nn0
 };
+// FOLDED WEIGHTS (round 3).  edge_cat.2 is a Linear whose output feeds only Linears -- nn.0 of every interaction block
+// (schnet.py:77) and the edge half of grad_dist_mlp.0 (condensenc.py:236, common.py:226-229) -- with no activation in
+// between (condensenc.py:105-115).  The inference forward therefore keeps s1 = swish(edge_cat.0(...)) as its "edge
+// attribute" and uses W' = W . W_cat2, b' = W . b_cat2 + b (products accumulated in fp64 at pack time, rounded once):
+// one H x H GEMM per embedded edge less (17 % of the embedding launch).  Same function, another fp32 association
+// (measured distance to the fp64 oracle unchanged, profiles/r03_parity_report.md); the training step and the
+// piecewise entry points (tsd_edge_embed, tsd_filter_gen, tsd_interaction_block, tsd_pair_output) keep the
+// reference's operation order.
 
 inline WeightLayout weight_layout(const tsd_model_cfg& c) {
     WeightLayout L;
@@ -108,6 +118,8 @@ inline WeightLayout weight_layout(const tsd_model_cfg& c) {
     L.L_lin2_b = ltake(H);
     L.L_lin_w = ltake(HH);
     L.L_lin_b = ltake(H);
+    L.L_nn0f_w = ltake(HH);
+    L.L_nn0f_b = ltake(H);
     L.layer_stride = lo;
     o += lo * (size_t)c.num_convs;
     L.out_w0 = take(2 * HH);
@@ -116,6 +128,8 @@ inline WeightLayout weight_layout(const tsd_model_cfg& c) {
     L.out_b1 = take(H / 2);
     L.out_w2 = take(H / 2);
     L.out_b2 = take(4);
+    L.out_w0f = take(HH);
+    L.out_b0f = take(H);
     L.total = o;
     return L;
 }
@@ -197,20 +211,22 @@ struct EmbedFuse0 {
 
 // launchers of the fused forward kernels shared by the inference forward (api.hip) and the training step
 // (train_step.hip); `save` != NULL selects the SAVE instantiation
+// fold: the "edge attribute" written is s1 = swish(edge_cat.0(...)) (consumers use the folded weights)
 int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_edges ea, float* out_a, int cap_b,
                        tsd_edges eb, float* out_b, int M, size_t out_stride, hipStream_t st, const UmapRole* umap,
-                       const EmbedSave* save = nullptr, int save_b_row = 0, const EmbedFuse0* fuse0 = nullptr);
+                       const EmbedSave* save = nullptr, int save_b_row = 0, const EmbedFuse0* fuse0 = nullptr,
+                       bool fold = false);
 int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N, tsd_edges enc, const float* Wf_layer,
                        const float* x1_in, const float* h_in, float* h, float* x1_out, int layer_w0, int g_begin,
                        int g_count, int capacity_u, tsd_edges enc_u, const float* edge_attr, float* wf_base,
                        int wf_slots, int M, size_t nh_stride, size_t ea_stride, size_t wf_stride, hipStream_t st,
                        const ComboPre* pre, size_t pre_stride, const FilterSave* fsave = nullptr,
-                       const NodeSave* nsave = nullptr);
+                       const NodeSave* nsave = nullptr, bool folded = false);
 int filter_tiles_per_layer(int capacity_u);
 int launch_pair_output(const tsd_model_cfg& c, const float* W, int capacity, tsd_edges e, const float* h,
                        const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
                        size_t ea_stride, size_t inv_stride, hipStream_t st, const float* pre, size_t pre_stride,
-                       const PairSave* save = nullptr);
+                       const PairSave* save = nullptr, bool folded = false);
 
 inline bool hidden_supported(int H) { return H == 64 || H == 128 || H == 256; }
 

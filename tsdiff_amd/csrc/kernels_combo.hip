@@ -825,7 +825,7 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
                        int layer_w0, int g_begin, int g_count,
                        int capacity_u, tsd_edges enc_u, const float* edge_attr, float* wf_base, int wf_slots, int M,
                        size_t nh_stride, size_t ea_stride, size_t wf_stride, hipStream_t st, const ComboPre* pre,
-                       size_t pre_stride, const FilterSave* fsave, const NodeSave* nsave) {
+                       size_t pre_stride, const FilterSave* fsave, const NodeSave* nsave, bool folded) {
     const WeightLayout L = weight_layout(c);
     ComboNode a{};
     a.N = N;
@@ -858,8 +858,8 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
         f.layer0 = layer_w0;
         f.Wl0 = W + L.layer0;
         f.layer_stride = L.layer_stride;
-        f.o_nn0_w = L.L_nn0_w;
-        f.o_nn0_b = L.L_nn0_b;
+        f.o_nn0_w = folded ? L.L_nn0f_w : L.L_nn0_w;  // folded: `edge_attr` holds s1 (common.hpp, FOLDED WEIGHTS)
+        f.o_nn0_b = folded ? L.L_nn0f_b : L.L_nn0_b;
         f.o_nn2_w = L.L_nn2_w;
         f.o_nn2_b = L.L_nn2_b;
         f.conv_cutoff = c.conv_cutoff;

@@ -22,6 +22,8 @@ struct NodeW {
 };
 struct PairW {
     const float *w0, *b0, *w1, *b1, *w2, *b2;
+    const float *w0e, *b0e;  // edge-attribute half of layer 0 ([H x H] packed) and the bias that goes with it: W0[:, H:]
+                             // and b0, or their folded forms when the attribute rows hold s1 (common.hpp)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -34,7 +36,9 @@ struct PairW {
 // SAVE: the training step's instantiation also writes the intermediate activations (EmbedSave, row = edge-attribute
 // row: list b starts at row `save_b_row`).
 // FUSE0: the tiles of list a go on to the filter GEMMs of interaction block 0 (EmbedFuse0, common.hpp).
-template <int H, bool SAVE, bool FUSE0>
+// FOLD: the chain stops at s1 = swish(edge_cat.0(...)), which is written as the tile's attribute rows; consumers hold
+// edge_cat.2 folded into their weights (common.hpp, FOLDED WEIGHTS).  f0's nn0 pointers are then the folded ones.
+template <int H, bool SAVE, bool FUSE0, bool FOLD>
 __global__ __launch_bounds__(2 * H) void edge_embed_kernel(EdgeEmbedW w, tsd_edges ea_, float* __restrict__ out_a,
                                                        int tiles_a, tsd_edges eb_, float* __restrict__ out_b,
                                                        size_t wstride, size_t out_stride, int embed_tiles,
@@ -146,34 +150,46 @@ __global__ __launch_bounds__(2 * H) void edge_embed_kernel(EdgeEmbedW w, tsd_edg
     }
     __syncthreads();
 
-    zero_acc(acc);
-    gemm_tile<1, 1, H>(buf, LDA, w.cw1, H, col0, acc);
-#pragma unroll
-    for (int cb = 0; cb < 1; ++cb) {
-        const int col = col0 + cb * 32 + l31;
-        const float b = w.cb1[col];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ee = e0 + acc_row(r, hi);
-            if (ee < E) edge_attr[(size_t)ee * H + col] = acc[0][cb][r] + b;
+    const int nrows = min(T, E - e0);
+    const int col = col0 + l31;
+    if constexpr (FOLD) {
+        // s1 (in LDS) IS the attribute tile: whole 1-KiB rows, float4 per lane
+        constexpr int C4 = H / 4;
+        for (int idx = tid; idx < nrows * C4; idx += 2 * H) {
+            const int r = idx / C4, c4 = idx % C4;
+            store_stream16(edge_attr + (size_t)(e0 + r) * H + c4 * 4, *reinterpret_cast<const f32x4*>(buf + r * LDA + c4 * 4));
         }
-        if constexpr (FUSE0) {  // keep the attribute tile for the filter GEMMs below
+        if constexpr (!FUSE0) return;
+        if (second) return;
+        // (rows past the end hold finite values computed from d = 0; their filter rows are never stored)
+    } else {
+        zero_acc(acc);
+        gemm_tile<1, 1, H>(buf, LDA, w.cw1, H, col0, acc);
+        {
+            const float b = w.cb1[col];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][cb][r] += b;
+            for (int r = 0; r < 16; ++r) {
+                const int ee = e0 + acc_row(r, hi);
+                if (ee < E) edge_attr[(size_t)ee * H + col] = acc[0][0][r] + b;
+            }
+            if constexpr (FUSE0) {  // keep the attribute tile for the filter GEMMs below
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][0][r] += b;
+            }
+        }
+        if constexpr (FUSE0) {
+            if (second) return;
+            __syncthreads();  // every wave is done reading buf
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = acc_row(r, hi);
+                buf[row * LDA + col] = row < nrows ? acc[0][0][r] : 0.0f;
+            }
+            __syncthreads();
         }
     }
     if constexpr (FUSE0) {
-        if (second) return;
         // filter role of interaction block 0 on this tile (kernels_combo.hip::filter_role, same order of operations)
-        const int nrows = min(T, E - e0);
-        const int col = col0 + l31;
-        __syncthreads();  // every wave is done reading buf
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = acc_row(r, hi);
-            buf[row * LDA + col] = row < nrows ? acc[0][0][r] : 0.0f;
-        }
-        __syncthreads();
         zero_acc(acc);
         gemm_tile<1, 1, H>(buf, LDA, f0.nn0_w, H, col0, acc);
         __syncthreads();
@@ -740,7 +756,7 @@ __global__ __launch_bounds__(2 * H) void pair_output_kernel(PairW w, tsd_edges e
     constexpr int NW = H / 64;   // waves of the second GEMM (H/2 columns, 32 per wave); the block has 2 NW waves
     {  // blockIdx.y = checkpoint of the ensemble
         const size_t m = blockIdx.y, wo = m * wstride;
-        w.w0 += wo; w.b0 += wo; w.w1 += wo; w.b1 += wo; w.w2 += wo; w.b2 += wo;
+        w.w0 += wo; w.b0 += wo; w.w1 += wo; w.b1 += wo; w.w2 += wo; w.b2 += wo; w.w0e += wo; w.b0e += wo;
         h += m * h_stride; edge_attr += m * ea_stride; edge_inv += m * inv_stride;
         if (pre) pre += m * pre_stride;
     }
@@ -817,8 +833,8 @@ __global__ __launch_bounds__(2 * H) void pair_output_kernel(PairW w, tsd_edges e
             for (int r = 0; r < 16; ++r) acc[0][0][r] = acc_row(r, hi) < nrows ? pre_v[r] : 0.0f;
         } else {
             zero_acc(acc);
-            gemm_tile<1, 1, H>(buf + H, LDA, w.w0 + (size_t)H * H, H, col0, acc);
-            const float b = w.b0[col];
+            gemm_tile<1, 1, H>(buf + H, LDA, w.w0e, H, col0, acc);
+            const float b = w.b0e[col];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][0][r] += b;
         }
@@ -888,6 +904,27 @@ __global__ void copy_kernel(const float* __restrict__ src, float* __restrict__ d
     if (idx < n) dst[idx] = src[idx];
 }
 
+// Folded weights (common.hpp, FOLDED WEIGHTS): Cp = pack(A . B) with A [nout x lda] (columns a0 .. a0 + mid), B [mid x nin]
+// row major, products accumulated in fp64 and rounded once; bias' = A . bb + ba likewise.
+__global__ void fold_linear_kernel(const float* __restrict__ A, int lda, int a0, const float* __restrict__ B,
+                                   const float* __restrict__ bb, const float* __restrict__ ba, int nout, int mid, int nin,
+                                   float* __restrict__ Cp, float* __restrict__ bias) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < nout * nin) {
+        const int s = idx & 3;
+        const int o = (idx >> 2) % nout;
+        const int k = ((idx >> 2) / nout) * 4 + s;
+        double acc = 0.0;
+        for (int j = 0; j < mid; ++j) acc += (double)A[(size_t)o * lda + a0 + j] * (double)B[(size_t)j * nin + k];
+        Cp[idx] = (float)acc;
+    }
+    if (idx < nout) {
+        double acc = (double)ba[idx];
+        for (int j = 0; j < mid; ++j) acc += (double)A[(size_t)idx * lda + a0 + j] * (double)bb[j];
+        bias[idx] = (float)acc;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host launchers
 // ---------------------------------------------------------------------------------------------
@@ -906,7 +943,7 @@ static inline size_t lds_pair(int H) { return (size_t)(T * (2 * H + 4) + (H / 64
 
 int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_edges ea, float* out_a, int cap_b,
                        tsd_edges eb, float* out_b, int M, size_t out_stride, hipStream_t st, const UmapRole* umap,
-                       const EmbedSave* save, int save_b_row, const EmbedFuse0* fuse0) {
+                       const EmbedSave* save, int save_b_row, const EmbedFuse0* fuse0, bool fold) {
     const WeightLayout L = weight_layout(c);
     EdgeEmbedW w{W + L.bond_emb, W + L.emlp_w0, W + L.emlp_b0, W + L.emlp_w1, W + L.emlp_b1,
                  W + L.ecat_w0, W + L.ecat_b0, W + L.ecat_w1, W + L.ecat_b1};
@@ -923,20 +960,28 @@ int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_ed
         set_error("internal: edge_embed saves and the fused block-0 filters are exclusive");
         return TSD_ERR_INVALID;
     }
-#define TSD_EE(HH, SV, FU, SARG, FARG)                                                                         \
+#define TSD_EE(HH, SV, FU, FO, SARG, FARG)                                                                     \
     {                                                                                                          \
         static DeviceOnce once;                                                                                \
-        int r = allow_lds(edge_embed_kernel<HH, SV, FU>, lds, once);                                           \
+        int r = allow_lds(edge_embed_kernel<HH, SV, FU, FO>, lds, once);                                       \
         if (r) return r;                                                                                       \
-        hipLaunchKernelGGL((edge_embed_kernel<HH, SV, FU>), grid, dim3(2 * HH), lds, st, w, ea, out_a, tiles_a, eb, \
+        hipLaunchKernelGGL((edge_embed_kernel<HH, SV, FU, FO>), grid, dim3(2 * HH), lds, st, w, ea, out_a, tiles_a, eb, \
                            out_b, L.total, out_stride, tiles_a + tiles_b, um, SARG, save_b_row, FARG);          \
     }
+    if (save && fold) {
+        set_error("internal: the saving edge embedding keeps the reference's operation order (no fold)");
+        return TSD_ERR_INVALID;
+    }
     if (save) {
-        TSD_DISPATCH_H(c.hidden, TSD_EE(HH, true, false, *save, EmbedFuse0{}));
+        TSD_DISPATCH_H(c.hidden, TSD_EE(HH, true, false, false, *save, EmbedFuse0{}));
+    } else if (fuse0 && fold) {
+        TSD_DISPATCH_H(c.hidden, TSD_EE(HH, false, true, true, EmbedSave{}, *fuse0));
     } else if (fuse0) {
-        TSD_DISPATCH_H(c.hidden, TSD_EE(HH, false, true, EmbedSave{}, *fuse0));
+        TSD_DISPATCH_H(c.hidden, TSD_EE(HH, false, true, false, EmbedSave{}, *fuse0));
+    } else if (fold) {
+        TSD_DISPATCH_H(c.hidden, TSD_EE(HH, false, false, true, EmbedSave{}, EmbedFuse0{}));
     } else {
-        TSD_DISPATCH_H(c.hidden, TSD_EE(HH, false, false, EmbedSave{}, EmbedFuse0{}));
+        TSD_DISPATCH_H(c.hidden, TSD_EE(HH, false, false, false, EmbedSave{}, EmbedFuse0{}));
     }
 #undef TSD_EE
     TSD_LAUNCH_CHECK("edge_embed");
@@ -1027,9 +1072,11 @@ int launch_node_lin1(const tsd_model_cfg& c, const float* W, int layer, int N, c
 int launch_pair_output(const tsd_model_cfg& c, const float* W, int capacity, tsd_edges e, const float* h,
                        const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
                        size_t ea_stride, size_t inv_stride, hipStream_t st, const float* pre, size_t pre_stride,
-                       const PairSave* save) {
+                       const PairSave* save, bool folded) {
     const WeightLayout L = weight_layout(c);
-    PairW w{W + L.out_w0, W + L.out_b0, W + L.out_w1, W + L.out_b1, W + L.out_w2, W + L.out_b2};
+    PairW w{W + L.out_w0, W + L.out_b0, W + L.out_w1, W + L.out_b1, W + L.out_w2, W + L.out_b2,
+            folded ? W + L.out_w0f : W + L.out_w0 + (size_t)c.hidden * c.hidden,  // packed [k/4][out][k%4]: the k >= H half is contiguous
+            folded ? W + L.out_b0f : W + L.out_b0};
     const int tiles = (capacity + T - 1) / T;
     if (tiles == 0) return TSD_OK;
     const size_t lds = lds_pair(c.hidden);
@@ -1081,6 +1128,9 @@ int launch_pack_weights(const tsd_model_cfg& c, const float* raw, float* packed,
     const int H = c.hidden, F = c.feat_dim, HH = H * H;
     const float* s = raw;
     int r;
+    const float* raw_nn0_w[64];
+    const float* raw_nn0_b[64];
+    const float *raw_w0 = nullptr, *raw_b0 = nullptr, *raw_c2w = nullptr, *raw_c2b = nullptr;
 #define CP(dst, n) { if ((r = copy_one(s, packed + (dst), (n), st))) return r; s += (n); }
 #define PK(dst, nout, nin) { if ((r = pack_one(s, packed + (dst), (nout), (nin), st))) return r; s += (size_t)(nout) * (nin); }
     CP(L.bond_emb, 100 * H);
@@ -1095,14 +1145,18 @@ int launch_pack_weights(const tsd_model_cfg& c, const float* raw, float* packed,
         PK(B + L.L_lin1_w, H, H);
         PK(B + L.L_lin2_w, H, H);
         CP(B + L.L_lin2_b, H);
+        raw_nn0_w[l] = s;
         PK(B + L.L_nn0_w, H, H);
+        raw_nn0_b[l] = s;
         CP(B + L.L_nn0_b, H);
         PK(B + L.L_nn2_w, H, H);
         CP(B + L.L_nn2_b, H);
         PK(B + L.L_lin_w, H, H);
         CP(B + L.L_lin_b, H);
     }
+    raw_w0 = s;
     PK(L.out_w0, H, 2 * H);
+    raw_b0 = s;
     CP(L.out_b0, H);
     PK(L.out_w1, H / 2, H);
     CP(L.out_b1, H / 2);
@@ -1110,8 +1164,22 @@ int launch_pack_weights(const tsd_model_cfg& c, const float* raw, float* packed,
     CP(L.out_b2, 1);
     PK(L.ecat_w0, H, 2 * H);
     CP(L.ecat_b0, H);
+    raw_c2w = s;
     PK(L.ecat_w1, H, H);
+    raw_c2b = s;
     CP(L.ecat_b1, H);
+    // folded forms: nn.0 of every block and the edge half of grad_dist_mlp.0 absorb edge_cat.2
+    {
+        const int nblk = (HH + 255) / 256;
+        for (int l = 0; l < c.num_convs; ++l) {
+            const size_t B = L.layer0 + (size_t)l * L.layer_stride;
+            hipLaunchKernelGGL(fold_linear_kernel, dim3(nblk), dim3(256), 0, st, raw_nn0_w[l], H, 0, raw_c2w, raw_c2b,
+                               raw_nn0_b[l], H, H, H, packed + B + L.L_nn0f_w, packed + B + L.L_nn0f_b);
+        }
+        hipLaunchKernelGGL(fold_linear_kernel, dim3(nblk), dim3(256), 0, st, raw_w0, 2 * H, H, raw_c2w, raw_c2b, raw_b0, H,
+                           H, H, packed + L.out_w0f, packed + L.out_b0f);
+        TSD_LAUNCH_CHECK("fold_linear");
+    }
 #undef CP
 #undef PK
     (void)HH;
