@@ -39,6 +39,9 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md:41
 PEAK_HBM_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec)
+# HBM-side bytes per launch come from the committed rocprofv3 PMC passes of this round (tools/profile_round.sh), read
+# here because counters cannot be collected inside a bench run; a missing file gives `traffic: null`
+PMC_C2, PMC_C5 = "r03_pmc_traffic.json", "r03_pmc_traffic_c5.json"
 
 
 def parse():
@@ -116,17 +119,17 @@ class SamplingRun:
     def __init__(self, sampler, g, graphs, pos_init, use_graph, seed):
         self.s, self.g, self.G, self.pos_init, self.use_graph, self.seed = sampler, g, graphs, pos_init, use_graph, seed
 
-    def run(self, n_steps):
+    def run(self, n_steps, return_traj=False):
         g = self.g
         return self.s.dynamic_sampling(
             g["atom_type"], g["r_feat"], g["p_feat"], self.pos_init, g["bond_index"], g["bond_type"], g["batch"],
             self.G, extend_order=True, n_steps=n_steps, step_lr=1e-7, clip=1000, sampling_type="ld",
-            denoise_from_time_t=n_steps, return_traj=False, use_graph=self.use_graph, seed=self.seed)
+            denoise_from_time_t=n_steps, return_traj=return_traj, use_graph=self.use_graph, seed=self.seed)
 
-    def timed(self, n_steps, dist=None):
+    def timed(self, n_steps, dist=None, return_traj=False):
         sync_all(dist)
         t0 = time.perf_counter()
-        p, _ = self.run(n_steps)
+        p, _ = self.run(n_steps, return_traj)
         sync_all(dist)
         return time.perf_counter() - t0, p
 
@@ -220,6 +223,82 @@ def aggregate_roofline(lib, db, H, dev, reps=20):
             "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "avg_launch_us": round(a_ms * 1e3, 2),
             "bytes_per_launch": a_bytes, "directed_edges": E, "nodes": N,
             "workload": "configs[4] size: W [E,256] fp32 streamed once, x1 gathered, one row-sum per node"}
+
+
+def reference_loop(sampler, g, G, pos_init, n_steps, step_lr=1e-7, clip=1000.0):
+    """The reference's own LD loop body (models/sampler.py:187-254) over this package's drop-in pieces -- what the
+    UNMODIFIED models/sampler.py executes when `EnsembleSampler.forward` and `geometry.eq_transform` are swapped in
+    (INTEGRATION.md): per step one forward() call (the reference triple comes back, one host read of the edge count),
+    eq_transform, clip_norm, randn_like, the torch update, the NaN test in a Python `if` (host sync), center_pos and
+    pos.clone().cpu() (host sync) -- every per-step host round trip of the reference kept."""
+    from tsdiff_amd.geometry import eq_transform
+    from tsdiff_amd.sampler import center_pos, clip_norm
+    sigmas = (1.0 - sampler.alphas).sqrt() / sampler.alphas.sqrt()
+    seq = range(n_steps)  # the last n_steps of the schedule, as the timed dynamic_sampling call (denoise_from_time_t)
+    pos = pos_init.clone()
+    traj = []
+    dev = pos.device
+    torch.set_grad_enabled(False)  # (the reference loop runs under torch.no_grad(), sampler.py:138)
+    for i in reversed(seq):
+        t = torch.full(size=(G,), fill_value=i, dtype=torch.long, device=dev)
+        edge_inv, edge_index, edge_length = sampler(g["atom_type"], g["r_feat"], g["p_feat"], pos, g["bond_index"],
+                                                    g["bond_type"], g["batch"], t, return_edges=True)
+        node_eq = eq_transform(edge_inv, pos, edge_index, edge_length)
+        eps_pos = clip_norm(node_eq, limit=clip)
+        noise = torch.randn_like(pos)
+        step_size = step_lr * (sigmas[i] / 0.01) ** 2
+        pos = pos + step_size * eps_pos / sigmas[i] + noise * torch.sqrt(step_size * 2)
+        if torch.isnan(pos).any():
+            raise FloatingPointError()
+        pos = center_pos(pos, g["batch"])
+        traj.append(pos.clone().cpu())
+    torch.set_grad_enabled(True)
+    return pos, traj
+
+
+def dualenc_bench(dev, graphs=100, steps=10):
+    """the legacy dual-encoder network (SURVEY 8a A17-A19, configs/geodiff_legacy/qm9_default.yml shape: H = 128,
+    6 SchNet + 4 GINE convolutions) at batch 100: forward (6-tuple) and its own LD sampler, op by op"""
+    from tsdiff_amd import synth
+    from tsdiff_amd.epsnet import get_model
+    from tsdiff_amd.utils import AttrDict
+    cfg = dict(synth.LEGACY_QM9_MODEL_CONFIG)
+    model = get_model(AttrDict(cfg))
+    shapes = [(k, v.shape) for k, v in model.state_dict().items() if not k.endswith(".eps")]
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.hash_state_dict(shapes, 3).items()}, strict=False)
+    model = model.to(dev)
+    b = synth.wb97xd3_like_batch(graphs, seed=1000)
+    at, bi, batch = (torch.from_numpy(b[k]).to(dev) for k in ("atom_type", "bond_index", "batch"))
+    bt = torch.from_numpy(synth.single_bond_types(b["bond_type"])).to(dev)
+    N = int(at.shape[0])
+    pos = torch.randn(N, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(7)) * 1.5
+    tz = torch.zeros(graphs, dtype=torch.long, device=dev)
+
+    def fwd():
+        with torch.no_grad():
+            return model(at, pos, bi, bt, batch, tz, return_edges=True)
+    for _ in range(3):
+        out = fwd()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        out = fwd()
+    torch.cuda.synchronize()
+    f_ms = (time.perf_counter() - t0) / 10 * 1e3
+    # (closed-form random weights: a small step and a tight clip keep the high-noise first steps of the schedule finite;
+    # the arithmetic per step does not depend on either)
+    kw = dict(step_lr=1e-9, clip=10.0, clip_local=10.0, sampling_type="ld", return_traj=False)
+    model.langevin_dynamics_sample(at, pos / 12.1685, bi, bt, batch, graphs, True, n_steps=2, **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    p, _ = model.langevin_dynamics_sample(at, pos / 12.1685, bi, bt, batch, graphs, True, n_steps=steps, **kw)
+    torch.cuda.synchronize()
+    s_ms = (time.perf_counter() - t0) / steps * 1e3
+    assert torch.isfinite(p).all()
+    return {"workload": "legacy dual-encoder network (qm9_default.yml shape: H=128, 6 SchNet + 4 GINE convs), batch "
+                        f"{graphs} (N={N}), op-by-op primitives (no fused path: no shipped TSDiff entry point reaches it)",
+            "edges": int(out[2].shape[1]), "forward_ms": round(f_ms, 3), "fwd_per_s": round(1e3 / f_ms, 1),
+            "ld_ms_per_step": round(s_ms, 3), "atoms_steps_per_s": round(N / (s_ms * 1e-3), 1), "ld_steps": steps}
 
 
 def pmc_traffic(name_prefix, fname):
@@ -411,6 +490,9 @@ def main():
     # warm-up: builds topology, packs weights, captures the step graph (kept by the batch), W untimed steps
     if args.warmup > 0:
         run.run(args.warmup)
+    # the same K steps straight after the driver's W warm-up steps, before the clock ramp below (reported as
+    # `cold_ms_per_step`; every rank takes part: the timed call holds barriers)
+    dt_cold, _ = run.timed(args.steps, dist) if args.workload == "c2" else (None, None)
     # clock ramp: a fresh process starts on an idle, down-clocked GPU and W may be a handful of sub-millisecond
     # steps; keep the chip busy with further UNTIMED steps until it has been under load for 150 ms (reported as
     # `clock_ramp_ms`), so that the K timed steps measure the kernels, not the power-state transition
@@ -425,6 +507,9 @@ def main():
     t1 = min(run.timed(1, dist)[0] for _ in range(3))
     steady_ms = (dt - t1) / max(args.steps - 1, 1) * 1e3
     fixed_ms = t1 * 1e3 - steady_ms
+    # the reference API's default (return_traj=True: the K x N x 3 trajectory is kept on the device and copied to the
+    # host once, after the last step)
+    dt_traj, _ = run.timed(args.steps, dist, return_traj=True)
 
     tot_atoms = torch.tensor([float(N)], device=dev)
     tmax = torch.tensor([dt], device=dev)
@@ -442,7 +527,7 @@ def main():
     db = run.db()
     E_enc, E_out, E_diff = db.enc.num_edges(), db.out.num_edges(), db.diff_u.num_edges()
     roofline = combo_roofline(lib, db, cfg, dev, reps=40 if db.P < 2_000_000 else 2)
-    fname = "r02_pmc_traffic.json" if args.workload == "c2" else "r02_pmc_traffic_c5.json"
+    fname = PMC_C2 if args.workload == "c2" else PMC_C5
     roofline["traffic"], roofline["traffic_source"] = pmc_traffic("layer_combo_kernel<256", fname)
     F, F_ref = forward_flops(models[0]._cfg, E_enc, E_out, E_diff, N, args.models)
     step_s = dt / args.steps
@@ -455,6 +540,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
         "fixed_ms_per_call": round(fixed_ms, 3), "steady_ms_per_step": round(steady_ms, 4),
+        "default_api_ms_per_step": round(dt_traj / args.steps * 1e3, 4),
+        "cold_ms_per_step": None if dt_cold is None else round(dt_cold / args.steps * 1e3, 4),
         "clock_ramp_ms": 150 if ramp_steps else 0, "clock_ramp_untimed_steps": ramp_steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
@@ -470,6 +557,16 @@ def main():
     }
 
     extras = world == 1 and args.workload == "c2" and not args.no_extras
+    if extras:
+        # the unmodified-sampler form: forward() + eq_transform + the torch update per step, all host syncs kept
+        reference_loop(sampler, g, args.graphs, pos_init, 3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reference_loop(sampler, g, args.graphs, pos_init, args.steps)
+        torch.cuda.synchronize()
+        out["reference_loop_ms_per_step"] = round((time.perf_counter() - t0) / args.steps * 1e3, 4)
+        out["reference_loop_note"] = ("models/sampler.py's own loop body over EnsembleSampler.forward + eq_transform of "
+                                      "this package (per-step host syncs of the reference kept)")
     db5 = db if args.workload == "c5" else None
     # ---- BASELINE configs[4]: 1024 x 64-atom graphs, complete pair sets (N = 65 536, E = 4 128 768)
     if extras:
@@ -483,7 +580,7 @@ def main():
         assert torch.isfinite(p5).all()
         db5 = run5.db()
         rf5 = combo_roofline(lib, db5, cfg, dev, reps=2)
-        rf5["traffic"], rf5["traffic_source"] = pmc_traffic("layer_combo_kernel<256", "r02_pmc_traffic_c5.json")
+        rf5["traffic"], rf5["traffic_source"] = pmc_traffic("layer_combo_kernel<256", PMC_C5)
         N5 = 1024 * 64
         F5, _ = forward_flops(models[0]._cfg, db5.enc.num_edges(), db5.out.num_edges(), db5.diff_u.num_edges(), N5, 1)
         out["c5"] = {"workload": "configs[4]: 1024 x 64-atom graphs, complete pair set, LD sampling, 1 checkpoint",
@@ -493,7 +590,7 @@ def main():
                      "roofline": rf5}
     if db5 is not None:
         agg = aggregate_roofline(lib, db5, H, dev)
-        agg["traffic"], agg["traffic_source"] = pmc_traffic("cfconv_aggregate_kernel<256", "r02_pmc_traffic_c5.json")
+        agg["traffic"], agg["traffic_source"] = pmc_traffic("cfconv_aggregate_kernel<256", PMC_C5)
         roofline["aggregate"] = agg
     if extras:
         out["c5"]["wall_s"] = round(time.perf_counter() - t0, 1)
@@ -526,6 +623,15 @@ def main():
                         "executed_tflops": round(tf, 2), "frac_of_fp32_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                         "final_loss": last}
 
+    if extras:
+        models[0]._batches.clear()
+        torch.cuda.empty_cache()
+        try:
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):  # (the sampler mirrors the reference's print on NaN: keep
+                out["dualenc"] = dualenc_bench(dev)        # stdout for the ONE JSON line)
+        except FloatingPointError:  # (random weights can diverge: report it, never lose the headline line)
+            out["dualenc"] = {"error": "FloatingPointError (NaN) in the legacy sampler with closed-form random weights"}
     # ---- CPU baseline: the oracle on the host cores, bounded sample of the same workload (rank 0 at N=1 only)
     out["cpu_baseline"] = None
     if not args.no_cpu_baseline and args.workload == "c2" and world == 1:

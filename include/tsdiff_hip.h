@@ -216,6 +216,42 @@ int tsd_eq_transform(int32_t num_nodes, int64_t num_edges, const float* score_d,
                      const int64_t* edge_index /* [2,E] */, const float* edge_length,
                      float* score_pos /* [N,3] */, void* stream);
 
+/* ---- static type-sorted embedding tiles (round 3; pos independent, once per batch) ----------------
+ * The edge embedding of the reference (models/encoder/edge.py:58-68 + condensenc.py:156-176) is
+ *   s1 = swish(edge_cat.0([mlp(d) * emb[type_r], mlp(d) * emb[type_p]])),   mlp(d) = W1 swish(w0 d + b0) + b1
+ * and for a FIXED (type_r, type_p) the two products and edge_cat.0 collapse into ONE H x H matrix:
+ *   s1 = swish(Wt swish(w0 d + b0) + bt),  Wt = (Wc0[:, :H] diag(emb[type_r]) + Wc0[:, H:] diag(emb[type_p])) W1.
+ * Types are topology: the undirected candidate pairs of a batch are sorted by (type_r, type_p) ONCE, cut into
+ * tiles of <= 32 pairs of one type pair, and every step's embedding launch walks these static tiles (a pair that is
+ * not an edge at this step is computed and dropped) with the per-bucket matrices of tsd_bucket_weights_build:
+ * one GEMM per embedded edge instead of three.  `enc`: every pair with the encoder-graph types; `diff`: the pairs
+ * whose output-graph types differ from them (the only ones that ever need an embedding of their own). */
+typedef struct tsd_typed_tiles {
+    int32_t num_tiles;         /* HOST value (read back once after tsd_typed_tiles_build); 0: not built */
+    int32_t num_buckets;       /* HOST value: distinct (type_r, type_p) pairs of this list */
+    const int32_t* tile_slot;  /* [num_tiles] slot of the tile's bucket in the bucket-weight arena */
+    const int32_t* tile_start; /* [num_tiles] first entry of the tile in pair / node_i / node_j */
+    const int32_t* tile_count; /* [num_tiles] 1..32 */
+    const int32_t* pair;       /* [P/2] ordered-pair index (src < dst) of the candidates, grouped by bucket */
+    const int32_t* node_i;     /* [P/2] src atom */
+    const int32_t* node_j;     /* [P/2] dst atom */
+} tsd_typed_tiles;
+/* Scratch / output sizes: pair, node_i, node_j: P/2 ints each per list; tile arrays: tsd_typed_tiles_capacity ints
+ * each per list; keys: [2][1024] ints (bucket_key of slot s of list l at keys[l * 1024 + s]: type_r * 32 + type_p);
+ * counts_dev [4] = {enc tiles, enc buckets, diff tiles, diff buckets} (device; the caller reads them back once);
+ * scratch: 8192 ints.  Diff-list slots are numbered after the enc list's (slot = enc buckets + k). */
+size_t tsd_typed_tiles_capacity(int32_t num_pairs);
+int tsd_typed_tiles_build(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs, const int32_t* graph_ptr,
+                          const int32_t* node_graph, const int32_t* pair_ptr, const uint16_t* pair_code,
+                          int32_t* enc_pair, int32_t* enc_i, int32_t* enc_j, int32_t* enc_tile /* [3][capacity] */,
+                          int32_t* diff_pair, int32_t* diff_i, int32_t* diff_j, int32_t* diff_tile /* [3][capacity] */,
+                          int32_t* keys, int32_t* counts_dev, int32_t* scratch, void* stream);
+/* Per-bucket folded matrices of ONE checkpoint: out [num_slots][H*H + H] (packed [k/4][out][k%4], then the bias),
+ * slot s from keys_dev[s] (enc slots, then diff slots: pass the concatenated key list).  fp64 accumulation. */
+size_t tsd_bucket_weights_floats(const tsd_model_cfg* cfg, int32_t num_slots);
+int tsd_bucket_weights_build(const tsd_model_cfg* cfg, const float* packed_weights, int32_t num_slots,
+                             const int32_t* keys_dev, float* out, void* stream);
+
 /* ---- whole forward for M checkpoints ---------------------------------------------------- */
 typedef struct tsd_batch {
     int32_t num_nodes, num_graphs, num_pairs, num_models;
@@ -232,6 +268,8 @@ typedef struct tsd_batch {
     int32_t max_graph_nodes;    /* atoms of the largest graph (host knowledge), or 0 = unknown: the sampling loop then
                                    runs its step tail as three launches instead of the fused one (<= 64-atom graphs) */
     int32_t reserved;
+    tsd_typed_tiles enc_tiles, diff_tiles;  /* static type-sorted embedding tiles, or num_tiles = 0: generic embedding */
+    const float* bucket_weights;            /* [M][(enc + diff buckets) * (H*H + H)] (tsd_bucket_weights_build) or NULL */
 } tsd_batch;
 
 size_t tsd_forward_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs,

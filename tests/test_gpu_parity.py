@@ -913,8 +913,9 @@ def test_piecewise_step_equals_fused_loop(dev):
 # ---------------------------------------------------------------------------------------------
 # round 2: the parity gaps of VERDICT r01 (gradients elementwise, config C5 shape, M = 8, LD at batch 100)
 # ---------------------------------------------------------------------------------------------
-def _grad_tol_check(got, ref, name, rtol=2e-4):
-    """elementwise: max|d| <= rtol * max|ref| per tensor (fp32 sums over up to ~10^4 edges in another order)"""
+def _grad_tol_check(got, ref, name, rtol=2e-5):
+    """elementwise: max|d| <= rtol * max|ref| per tensor (fp32 sums over up to ~10^4 edges in another order; measured
+    2-3e-6 on the full model, profiles/r02_parity_report.md: 2e-5 leaves one order of magnitude, not two)"""
     ref = np.asarray(ref)
     scale = float(np.abs(ref).max())
     err = float(np.abs(np.asarray(got) - ref).max())

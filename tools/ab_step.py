@@ -5,7 +5,7 @@
 
 Every configuration runs in its own child process (one library per process), the configurations interleaved over
 `rounds` rounds; prints ms/step min / median per configuration.  LIB = path of a libtsdiff_hip.so variant
-(tools/build_variant.sh) or `default`; the suffix `:tail0` runs the step tail as three launches."""
+(tools/build_variant.sh) or `default`; suffixes: `:tail0` runs the step tail as three launches, `:typed0` the generic embedding kernel."""
 import os
 import subprocess
 import sys
@@ -14,14 +14,15 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def child(workload, steps, lib, tail):
+def child(workload, steps, lib, flags):
     sys.path.insert(0, ROOT)
     import numpy as np
     import torch
     from tsdiff_amd import _lib, engine, synth
     if lib != "default":
         _lib.LIB_PATH = lib if os.path.isabs(lib) else os.path.join(ROOT, lib)
-    engine.FUSED_STEP_TAIL = tail
+    engine.FUSED_STEP_TAIL = "tail0" not in flags
+    engine.TYPED_TILES = "typed0" not in flags
     from bench import SamplingRun, make_models, to_dev
     from tsdiff_amd.sampler import EnsembleSampler
     dev = torch.device("cuda:0")
@@ -55,7 +56,7 @@ def child(workload, steps, lib, tail):
 def main():
     args = sys.argv[1:]
     if args and args[0] == "--child":
-        child(args[1], int(args[2]), args[3], args[4] == "1")
+        child(args[1], int(args[2]), args[3], args[4].split(","))
         return
     workload, steps, rounds, cfgs = "c2", 200, 3, []
     i = 0
@@ -68,14 +69,14 @@ def main():
             rounds = int(args[i + 1]); i += 2
         else:
             name, spec = args[i].split("=", 1)
-            tail = not spec.endswith(":tail0")
-            cfgs.append((name, spec.replace(":tail0", ""), tail)); i += 1
+            parts = spec.split(":")
+            cfgs.append((name, parts[0], ",".join(parts[1:]) or "-")); i += 1
     res = {c[0]: [] for c in cfgs}
     chk = {}
     for _ in range(rounds):
-        for name, lib, tail in cfgs:
-            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", workload, str(steps), lib,
-                                  "1" if tail else "0"], capture_output=True, text=True)
+        for name, lib, flags in cfgs:
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", workload, str(steps), lib, flags],
+                                 capture_output=True, text=True)
             line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
             if not line:
                 print(f"{name}: FAILED\n{out.stdout[-2000:]}\n{out.stderr[-3000:]}")

@@ -61,6 +61,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--sampling-type", default="ld")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--seed", type=int, default=2022,
+                    help="run seed (sampling.py:82 default): rank r draws its initial positions and its Langevin noise "
+                         "from the streams seeded `seed ^ r` (SURVEY 8e), so a run is reproducible for a (seed, GPU "
+                         "count) pair and no two ranks share a stream")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,13 +86,17 @@ def main():
 
     def sample_fn(shard, r):
         res = []
-        for s in range(0, len(shard), args.batch_size):  # sampling.py:169 batching
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(args.seed ^ r)  # initial positions: this rank's own stream
+        for k, s in enumerate(range(0, len(shard), args.batch_size)):  # sampling.py:169 batching
             b, npg = collate(shard[s:s + args.batch_size], dev)
-            pos_init = torch.randn(b["pos"].shape[0], 3, device=dev)  # sampling.py:190
+            pos_init = torch.randn(b["pos"].shape[0], 3, device=dev, generator=gen)  # sampling.py:190
             pos, _ = sampler.dynamic_sampling(b["atom_type"], b["r_feat"], b["p_feat"], pos_init, b["bond_index"],
                                               b["bond_type"], b["batch"], len(npg), extend_order=True,
                                               n_steps=args.steps, step_lr=1e-7, clip=1000,
-                                              sampling_type=args.sampling_type, return_traj=False)
+                                              sampling_type=args.sampling_type, return_traj=False,
+                                              # device Philox key of this (rank, batch): no overlap across either
+                                              seed=((args.seed ^ r) << 20) + k)
             res += list(torch.split(pos.cpu(), npg))  # sampling.py:218-223
         return res
 
@@ -101,6 +109,7 @@ def main():
         atoms = sum(int(g["atom_type"].shape[0]) for g in graphs)
         assert len(res) == len(graphs) and all(r.shape == g["pos"].shape for r, g in zip(res, graphs))
         print(json.dumps({"graphs": args.graphs, "atoms": atoms, "checkpoints": args.models, "gpus": world,
+                          "seed": args.seed,
                           "steps": args.steps, "seconds": round(dt, 3),
                           "atoms_steps_per_s": round(atoms * args.steps / dt, 1),
                           "checkpoint_forwards_per_s": round(

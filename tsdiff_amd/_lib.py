@@ -69,6 +69,19 @@ class Geometry(C.Structure):
     ]
 
 
+class TypedTiles(C.Structure):  # tsd_typed_tiles
+    _fields_ = [
+        ("num_tiles", C.c_int32),
+        ("num_buckets", C.c_int32),
+        ("tile_slot", C.c_void_p),
+        ("tile_start", C.c_void_p),
+        ("tile_count", C.c_void_p),
+        ("pair", C.c_void_p),
+        ("node_i", C.c_void_p),
+        ("node_j", C.c_void_p),
+    ]
+
+
 class Batch(C.Structure):
     _fields_ = [
         ("num_nodes", C.c_int32),
@@ -87,6 +100,9 @@ class Batch(C.Structure):
         ("edge_inv_u", C.c_void_p),
         ("max_graph_nodes", C.c_int32),
         ("reserved", C.c_int32),
+        ("enc_tiles", TypedTiles),
+        ("diff_tiles", TypedTiles),
+        ("bucket_weights", C.c_void_p),
     ]
 
 
@@ -179,6 +195,11 @@ SIGNATURES = {
     "tsd_sampler_run": (C.c_int, [_CFG, C.POINTER(Batch), C.c_int32, C.c_int32, _P, _P, C.c_uint64, C.c_uint64,
                                   C.c_float, C.c_float, _P, _P, _P, C.c_int32, _P]),
     "tsd_philox_normal": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int64, _P, _P]),
+    "tsd_typed_tiles_capacity": (C.c_size_t, [C.c_int32]),
+    "tsd_typed_tiles_build": (C.c_int, [_CFG, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                        _P, _P, _P]),
+    "tsd_bucket_weights_floats": (C.c_size_t, [_CFG, C.c_int32]),
+    "tsd_bucket_weights_build": (C.c_int, [_CFG, _P, C.c_int32, _P, _P, _P]),
 }
 
 _lib = None

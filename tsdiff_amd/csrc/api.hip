@@ -69,6 +69,13 @@ int launch_geometry_lists(const tsd_model_cfg&, int, int, const float*, const in
 int launch_step_post(const tsd_model_cfg&, int, int, int, int, int, const int32_t*, const int32_t*, const uint16_t*,
                      tsd_geometry, const float*, float, float, float*, tsd_sampler_state*, hipStream_t);
 int launch_set_run_args(tsd_sampler_state*, const tsd_run_args&, hipStream_t);
+size_t typed_tiles_capacity(int);
+int launch_typed_tiles_build(const tsd_model_cfg&, int, int, const int32_t*, const int32_t*, const int32_t*,
+                             const uint16_t*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*,
+                             int32_t*, int32_t*, int32_t*, int32_t*, hipStream_t);
+int launch_bucket_weights(const tsd_model_cfg&, const float*, int, const int32_t*, float*, hipStream_t);
+int launch_typed_embed(const tsd_model_cfg&, const float*, const tsd_batch&, const float*, float*, int, size_t,
+                       hipStream_t, const UmapRole*, const EmbedFuse0*);
 bool step_tail_supported(int, int, int);
 int launch_step_tail_reset(int, tsd_geometry, hipStream_t);
 int launch_step_tail(const tsd_model_cfg&, int, int, int, int, int, int, const int32_t*, const int32_t*, const uint16_t*,
@@ -98,6 +105,23 @@ static int check_cfg(const tsd_model_cfg* c) {
     return TSD_OK;
 }
 
+// Capacity: the per-edge matrices are indexed row * H with 64-bit arithmetic in the kernels, but tile and row
+// bookkeeping is 32-bit; the largest batch any kernel has been run and checked at is configs[4] (P H = 1.06e9).
+// Everything at or past 2^31 elements of one [P, H] matrix is refused up front (TSD_ERR_UNSUPPORTED) instead of
+// trusted: split the batch (graphs never interact; tsdiff_amd.distributed shards them).
+static bool capacity_ok(const tsd_model_cfg& c, int64_t N, int64_t P) {
+    const int64_t lim = (int64_t)1 << 31;
+    return P * c.hidden < lim && N * c.hidden < lim;
+}
+#define TSD_CAPACITY(c, N, P)                                                                                       \
+    do {                                                                                                            \
+        if (!capacity_ok((c), (N), (P))) {                                                                          \
+            set_error("batch too large: %lld ordered pairs x hidden %d >= 2^31 elements per edge matrix (largest "  \
+                      "verified size: 1024 x 64-atom graphs); split the batch", (long long)(P), (c).hidden);        \
+            return TSD_ERR_UNSUPPORTED;                                                                             \
+        }                                                                                                           \
+    } while (0)
+
 struct Workspace {
     // every array holds one block per checkpoint (stride_* floats apart): the M forwards of an ensemble
     // run in the SAME launches (grid.y = checkpoint), which removes the tile quantisation of batch-100
@@ -107,6 +131,7 @@ struct Workspace {
                  // launch j writes block j's filters, launch j+1 is their only reader
     float *h, *x1, *x1b;  // [M][N, H]
     float *pre;  // [M][P/2, H]: node-independent half of the pair MLP's first layer (ComboPre)
+    int32_t* ready;  // [M][node tiles] readiness flags of the last launch (pair role), zeroed by the embedding launch
     size_t stride_ea, stride_wf, stride_nh, stride_pre;
     int wf_slots;
     size_t total;
@@ -135,6 +160,7 @@ static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base)
     w.x1b = take(w.stride_nh * M);
     w.stride_pre = pad(PU * H);
     w.pre = take(w.stride_pre * M);
+    w.ready = reinterpret_cast<int32_t*>(take(pad((size_t)M * ((N + TSD_NODE_TILE - 1) / TSD_NODE_TILE))));
     w.total = o;
     return w;
 }
@@ -146,8 +172,11 @@ static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base)
 // step_post_kernel); advance: device step counter bumped by the scan kernel (sampling loop only).
 // lists_ready: the five lists of `pos` are complete but for the directed -> undirected map (the fused step tail of
 // the previous step built them): no count / scan / fill launches at all.
+// status: device word for TSD_STATUS_INTERNAL (sampling loop: the state block's flags); NULL: the pair MLP runs as its
+// own launch (no in-launch waits anywhere in the forward).
 static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float* pos, hipStream_t st,
-                        bool counts_ready = false, int32_t* advance = nullptr, bool lists_ready = false) {
+                        bool counts_ready = false, int32_t* advance = nullptr, bool lists_ready = false,
+                        int32_t* status = nullptr) {
     const int N = b.num_nodes, P = b.num_pairs, M = b.num_models;
     const int PU = P / 2, L = c.num_convs;
     const size_t H = c.hidden;
@@ -163,7 +192,6 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
         (r = launch_geometry_lists(c, N, P, pos, b.graph_ptr, b.node_graph, b.pair_ptr, b.pair_code, g, advance, st,
                                    true)))
         return r;
-    const Workspace w = carve(c, N, P, M, b.workspace);
     // one launch per interaction block: node chain of block l || filter GEMMs of block l+1;
     // all M checkpoints in the same launches (grid.y)
     const float* W = b.weights;
@@ -173,6 +201,15 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     um.node_graph = b.node_graph;
     um.pair_ptr = b.pair_ptr;
     um.P = P;
+    const Workspace w = carve(c, N, P, M, b.workspace);
+    const int node_tiles_all = (N + TSD_NODE_TILE - 1) / TSD_NODE_TILE;
+    // small forwards (the node chain of a block leaves most of the chip idle): the LAST block launch also runs the
+    // whole pair MLP behind per-node-tile readiness flags, which the embedding launch zeroes
+    const bool small_fwd = (long)node_tiles_all * M <= 256;
+    if (small_fwd) {
+        um.zero_words = w.ready;
+        um.n_zero = node_tiles_all * M;
+    }
     // the filter GEMMs of block 0 ride in the embedding launch (a tile's filters need only that tile's attributes):
     // the first per-block launch, which had no node chain to run beside them, disappears
     const WeightLayout WL0 = weight_layout(c);
@@ -188,9 +225,13 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     f0.wf_stride = w.stride_wf;
     // (batch-100 sizes only: measured 0.441 -> 0.435 ms/step at configs[1]; at configs[4] the longer embedding
     // tiles lose more than the launch saves, 50.5 -> 52.8 ms/step)
-    const bool fuse_block0 = (long)((N + TSD_NODE_TILE - 1) / TSD_NODE_TILE) * M <= 256;
-    if ((r = launch_edge_embed2(c, W, PU, g.enc_u, w.ea, PU, g.diff_u, w.ea + (size_t)PU * H, M, w.stride_ea, st,
-                                &um, nullptr, 0, fuse_block0 ? &f0 : nullptr, kFold)))
+    const bool fuse_block0 = small_fwd;
+    // static type-sorted tiles (one GEMM per embedded edge instead of three) when the batch carries them
+    const bool typed = kFold && b.enc_tiles.num_tiles > 0 && b.bucket_weights != nullptr;
+    if (typed) {
+        if ((r = launch_typed_embed(c, W, b, pos, w.ea, M, w.stride_ea, st, &um, fuse_block0 ? &f0 : nullptr))) return r;
+    } else if ((r = launch_edge_embed2(c, W, PU, g.enc_u, w.ea, PU, g.diff_u, w.ea + (size_t)PU * H, M, w.stride_ea, st,
+                                       &um, nullptr, 0, fuse_block0 ? &f0 : nullptr, kFold)))
         return r;
     // block 0 reads z (residual input) and x1_0 = lin1_0(z) straight from the per-batch arrays -- both are
     // pos independent (computed at bind time) -- so no per-step copy of z and no lin1 launch
@@ -219,7 +260,24 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     // (only when the node chain of the last block leaves most of the chip idle: at batch 100 it occupies ~100
     // of the 256 CUs; with an ensemble or a large batch the launch is full and the extra role only adds work:
     // C2 0.518 -> 0.511 ms/step, C5 51.1 -> 51.6, M = 8 3.10 -> 3.13)
-    const bool use_pre = (long)((N + TSD_NODE_TILE - 1) / TSD_NODE_TILE) * M <= 256;
+    const bool use_pre = small_fwd;
+#ifndef TSD_PAIR_ROLE
+#define TSD_PAIR_ROLE 1  // 0 (A/B variant builds): pre role + separate pair_output launch, as in round 2
+#endif
+    const bool pair_role = use_pre && TSD_PAIR_ROLE != 0 && status != nullptr;
+    if (pair_role) {
+        pre.pair = 1;
+        pre.w0a = W + WL.out_w0;
+        pre.w1 = W + WL.out_w1;
+        pre.b1 = W + WL.out_b1;
+        pre.w2 = W + WL.out_w2;
+        pre.b2 = W + WL.out_b2;
+        pre.h = w.h;
+        pre.edge_inv = b.edge_inv_u;
+        pre.ready = w.ready;
+        pre.status = status;
+        pre.inv_stride = (size_t)PU;
+    }
     for (int j = fuse_block0 ? 1 : 0; j <= L; ++j) {  // (fused: the filters of block 0 came with the embedding launch)
         const int layer = j == 0 ? -2 : j - 1;  // node chain of this launch; its filters were written by launch j-1
         const float* wf_read = layer >= 0 ? w.wf + (size_t)(layer % w.wf_slots) * PU * H : nullptr;
@@ -233,6 +291,7 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
             xout = (xout == w.x1) ? w.x1b : w.x1;
         }
     }
+    if (pair_role) return TSD_OK;  // the last block launch ran the pair MLP
     return launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u, M, w.stride_nh, w.stride_ea,
                               (size_t)PU, st, use_pre ? w.pre : nullptr, w.stride_pre, nullptr, kFold);
 }
@@ -247,11 +306,11 @@ static int step_impl(const tsd_model_cfg& c, const tsd_batch& b, int kind, float
                      tsd_sampler_state* state, hipStream_t st) {
     int r;
     if (use_step_tail(b)) {
-        if ((r = forward_impl(c, b, pos, st, true, nullptr, true))) return r;
+        if ((r = forward_impl(c, b, pos, st, true, nullptr, true, &state->flags))) return r;
         return launch_step_tail(c, kind, b.num_nodes, b.num_graphs, b.num_models, b.num_pairs, b.max_graph_nodes,
                                 b.graph_ptr, b.pair_ptr, b.pair_code, b.geo, b.edge_inv_u, clip, clip_pos, pos, state, st);
     }
-    if ((r = forward_impl(c, b, pos, st, true, &state->step))) return r;
+    if ((r = forward_impl(c, b, pos, st, true, &state->step, false, &state->flags))) return r;
     return launch_step_post(c, kind, b.num_nodes, b.num_graphs, b.num_models, b.num_pairs, b.graph_ptr, b.pair_ptr,
                             b.pair_code, b.geo, b.edge_inv_u, clip, clip_pos, pos, state, st);
 }
@@ -271,8 +330,9 @@ struct tsd_sampler_plan {
 };
 
 namespace tsd {
-static int check_batch(const tsd_batch* batch) {
+static int check_batch(const tsd_model_cfg& c, const tsd_batch* batch) {
     TSD_REQUIRE(batch != nullptr, "batch is null");
+    TSD_CAPACITY(c, batch->num_nodes, batch->num_pairs);
     TSD_REQUIRE(batch->num_models >= 1, "num_models=%d", batch->num_models);
     TSD_REQUIRE(batch->z && batch->x1_0 && batch->weights && batch->workspace && batch->edge_inv_u,
                 "null batch pointer");
@@ -316,6 +376,39 @@ int tsd_topology_build(int32_t num_nodes, int32_t num_graphs, int32_t num_pairs,
     return launch_topology(num_nodes, num_graphs, num_pairs, num_bonds, graph_ptr, pair_base, bond_index,
                            bond_type, max_order, max_graph_nodes_host, node_graph, pair_ptr, pair_code, status,
                            (hipStream_t)stream);
+}
+
+size_t tsd_typed_tiles_capacity(int32_t num_pairs) { return typed_tiles_capacity(num_pairs); }
+
+int tsd_typed_tiles_build(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs, const int32_t* graph_ptr,
+                          const int32_t* node_graph, const int32_t* pair_ptr, const uint16_t* pair_code,
+                          int32_t* enc_pair, int32_t* enc_i, int32_t* enc_j, int32_t* enc_tile, int32_t* diff_pair,
+                          int32_t* diff_i, int32_t* diff_j, int32_t* diff_tile, int32_t* keys, int32_t* counts_dev,
+                          int32_t* scratch, void* stream) {
+    TraceRange range("tsd:typed_tiles_build");
+    int r = check_cfg(cfg);
+    if (r) return r;
+    TSD_REQUIRE(graph_ptr && node_graph && pair_ptr && keys && counts_dev && scratch, "null pointer");
+    TSD_REQUIRE(num_pairs == 0 || (pair_code && enc_pair && enc_i && enc_j && enc_tile && diff_pair && diff_i &&
+                                   diff_j && diff_tile),
+                "null pointer");
+    return launch_typed_tiles_build(*cfg, num_nodes, num_pairs, graph_ptr, node_graph, pair_ptr, pair_code, enc_pair,
+                                    enc_i, enc_j, enc_tile, diff_pair, diff_i, diff_j, diff_tile, keys, counts_dev,
+                                    scratch, (hipStream_t)stream);
+}
+
+size_t tsd_bucket_weights_floats(const tsd_model_cfg* cfg, int32_t num_slots) {
+    if (check_cfg(cfg) || num_slots < 0) return 0;
+    return (size_t)num_slots * ((size_t)cfg->hidden * cfg->hidden + cfg->hidden);
+}
+
+int tsd_bucket_weights_build(const tsd_model_cfg* cfg, const float* packed_weights, int32_t num_slots,
+                             const int32_t* keys_dev, float* out, void* stream) {
+    TraceRange range("tsd:bucket_weights_build");
+    int r = check_cfg(cfg);
+    if (r) return r;
+    TSD_REQUIRE(num_slots >= 0 && (num_slots == 0 || (packed_weights && keys_dev && out)), "bad argument");
+    return launch_bucket_weights(*cfg, packed_weights, num_slots, keys_dev, out, (hipStream_t)stream);
 }
 
 size_t tsd_geometry_scratch_ints(int32_t num_nodes, int32_t num_pairs) {
@@ -430,6 +523,11 @@ int tsd_eq_transform(int32_t num_nodes, int64_t num_edges, const float* score_d,
 size_t tsd_forward_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs,
                                     int32_t num_models) {
     if (check_cfg(cfg)) return 0;
+    if (!capacity_ok(*cfg, num_nodes, num_pairs)) {
+        set_error("batch too large: %d ordered pairs x hidden %d >= 2^31 elements per edge matrix; split the batch",
+                  num_pairs, cfg->hidden);
+        return 0;
+    }
     return carve(*cfg, num_nodes, num_pairs, num_models < 1 ? 1 : num_models, nullptr).total;
 }
 
@@ -458,7 +556,7 @@ int tsd_forward_work(const tsd_model_cfg* cfg, int32_t num_nodes, int64_t enc_ed
 int tsd_score_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* pos, void* stream) {
     int r = check_cfg(cfg);
     if (r) return r;
-    if ((r = check_batch(batch))) return r;
+    if ((r = check_batch(*cfg, batch))) return r;
     TSD_REQUIRE(pos, "null pointer");
     return forward_impl(*cfg, *batch, pos, (hipStream_t)stream);
 }
@@ -495,7 +593,7 @@ int tsd_sampler_plan_create(const tsd_model_cfg* cfg, const tsd_batch* batch, in
     TraceRange range("tsd:sampler_plan_create");
     int r = check_cfg(cfg);
     if (r) return r;
-    if ((r = check_batch(batch))) return r;
+    if ((r = check_batch(*cfg, batch))) return r;
     TSD_REQUIRE(pos && state && plan_out, "null pointer");
     TSD_REQUIRE(kind == 0 || kind == 1, "kind=%d (0 = ld, 1 = ddpm)", kind);
     TSD_REQUIRE(stream != nullptr, "stream capture is illegal on the legacy default stream: pass a created stream");
@@ -572,7 +670,7 @@ int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t ki
         if ((r = tsd_sampler_plan_create(cfg, batch, kind, clip, clip_pos, pos, state, stream, &plan))) return r;
     } else {  // eager: no capture, the same kernels launched one by one
         if ((r = check_cfg(cfg))) return r;
-        if ((r = check_batch(batch))) return r;
+        if ((r = check_batch(*cfg, batch))) return r;
         TSD_REQUIRE(pos && state, "null pointer");
         TSD_REQUIRE(kind == 0 || kind == 1, "kind=%d (0 = ld, 1 = ddpm)", kind);
         plan = new tsd_sampler_plan{*cfg, *batch, kind, clip, clip_pos, pos, state, nullptr, nullptr};

@@ -86,7 +86,7 @@ struct WeightLayout {
 // between (condensenc.py:105-115).  The inference forward therefore keeps s1 = swish(edge_cat.0(...)) as its "edge
 // attribute" and uses W' = W . W_cat2, b' = W . b_cat2 + b (products accumulated in fp64 at pack time, rounded once):
 // one H x H GEMM per embedded edge less (17 % of the embedding launch).  Same function, another fp32 association
-// (measured distance to the fp64 oracle unchanged, profiles/r03_parity_report.md); the training step and the
+// (measured distance to an fp64 evaluation unchanged, profiles/r03_parity_report.md); the training step and the
 // piecewise entry points (tsd_edge_embed, tsd_filter_gen, tsd_interaction_block, tsd_pair_output) keep the
 // reference's operation order.
 
@@ -167,6 +167,8 @@ struct UmapRole {
     tsd_geometry g;
     const int32_t *graph_ptr, *node_graph, *pair_ptr;
     int P;
+    int32_t* zero_words;  // words zeroed by the role (the node-tile readiness flags of the forward's last launch), or NULL
+    int n_zero;
 };
 
 // optional third role of the per-block launch (kernels_combo.hip), filled by the forward in api.hip
@@ -176,7 +178,18 @@ struct ComboPre {
     const float* edge_attr;
     const int32_t* attr_row;  // edge_attr row of out edge e (NULL: e)
     const float *w0b, *b0;    // packed W0 rows k in [H, 2H), bias
-    float* out;               // [capacity_u, H]
+    float* out;               // [capacity_u, H]  (pre role only)
+    // ---- pair role (round 3): the WHOLE pair MLP of a tile of 32 undirected out edges inside the forward's last
+    // block launch -- the node-independent half first, then, behind per-node-tile readiness flags published by the
+    // node role of the same launch (cdna_hip_programming.md Guideline 16, R1: write-through payload, drained flag), the
+    // h_i * h_j half and the rest of pair_output_kernel.  Replaces the pre role + the pair_output launch.
+    int pair;                 // != 0: pair role (needs the fields below)
+    const float *w0a, *w1, *b1, *w2, *b2;  // packed W0 rows k in [0, H); layers 1, 2
+    const float* h;           // final node states [N, H] (written by the node role of this launch)
+    float* edge_inv;          // [capacity_u]
+    int32_t* ready;           // [M][node tiles] flags: 1 = the tile's rows of h are in memory
+    int32_t* status;          // TSD_STATUS_INTERNAL on a wait that gave up
+    size_t inv_stride;        // per-checkpoint stride of edge_inv
 };
 
 // Side outputs of the fused forward kernels for the training step (train_step.hip): the activations the

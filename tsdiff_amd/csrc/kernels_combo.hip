@@ -70,6 +70,7 @@ struct ComboNode {
     float* h;           // residual output
     float* x1_out;
     const float *lin2_w, *lin2_b, *lin_w, *lin_b, *lin1_next_w;
+    int32_t* ready;  // != NULL (last launch of a small forward): publish h write-through, then ready[tile] = 1
 };
 
 // Filter work is a flat queue of items g = layer * tiles_per_layer + tile over ALL layers (it depends on the
@@ -286,10 +287,18 @@ __device__ __forceinline__ void node_role(const ComboNode& a, int tile, float* s
                 float hn = 0.0f;
                 if (row < nrows) {
                     hn = h_res[cb][r] + (acc[cb][r] + b);
-                    a.h[(size_t)(n0 + row) * H + col] = hn;
+                    if (a.ready)  // write-through (sc1): the pair tiles of this launch read the row from other CUs
+                        __hip_atomic_store(a.h + (size_t)(n0 + row) * H + col, hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        a.h[(size_t)(n0 + row) * H + col] = hn;
                 }
                 buf[row * LDA + col] = hn;
             }
+        }
+        if (a.ready) {  // Guideline 16 R1: every storing wave drains, the workgroup meets, ONE lane raises the flag
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(a.ready + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (a.lin1_next_w == nullptr) return;
         __syncthreads();
@@ -454,6 +463,135 @@ __device__ __forceinline__ void pre_role(const ComboPre& q, int tile, float* sme
     for (int r = 0; r < 16; ++r) {
         const int row = acc_row(r, hi);
         if (row < nrows) q.out[(size_t)(e0 + row) * H + col] = acc[0][0][r] + b;
+    }
+}
+
+// "pair" role: the pair MLP of one tile of 32 undirected out edges inside the forward's LAST block launch
+// (ComboPre, common.hpp): pre = edge_attr_out . W0[:, H:]^T + b0 while the node chain of the last block is still
+// running, then -- once the node tiles that own the tile's atoms have published h -- h_i * h_j . W0[:, :H]^T on top,
+// swish, the H -> H/2 layer, swish, the dot with w2: the arithmetic of pre_role + pair_output_kernel in the same
+// order (bit-identical), without the round trip of `pre` through memory and without the pair_output launch.
+#ifndef TSD_PAIR_SLEEP
+#define TSD_PAIR_SLEEP 48  // x64 cycles between two polls of a waiting pair tile (~1.3 us)
+#endif
+constexpr unsigned PAIR_SPIN_LIMIT = 2000000u;  // ~1 s of polling: then TSD_STATUS_INTERNAL instead of a hang
+
+template <int H>
+__device__ __forceinline__ void pair_role(const ComboPre& q, int tile, int node_tiles, float* smem) {
+    constexpr int LDA = H + 4, NT = 2 * H, C4 = H / 4, NW = H / 64;
+    float* buf = smem;
+    float* s_red = smem + T * LDA;  // [NW][T]
+    int* s_src = reinterpret_cast<int*>(s_red + NW * T);
+    int* s_dst = s_src + T;
+    int* s_row = s_dst + T;
+    const int E = *q.e.count;
+    const int e0 = tile * T;
+    if (e0 >= E) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int col0 = wave * 32, col = col0 + l31;
+    const int nrows = min(T, E - e0);
+    if (tid < T) {
+        const int ee = e0 + min(tid, nrows - 1);
+        s_src[tid] = q.e.src[ee];
+        s_dst[tid] = q.e.dst[ee];
+        s_row[tid] = q.attr_row ? q.attr_row[ee] : ee;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < T * C4; idx += NT) {
+        const int r = idx / C4, c4 = idx % C4;
+        *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) =
+            *reinterpret_cast<const f32x4*>(q.edge_attr + (size_t)s_row[r] * H + c4 * 4);
+    }
+    __syncthreads();
+    f32x16 acc[1][1];
+    zero_acc(acc);
+    gemm_tile<1, 1, H>(buf, LDA, q.w0b, H, col0, acc);
+    {
+        const float b = q.b0[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] = acc_row(r, hi) < nrows ? acc[0][0][r] + b : 0.0f;
+    }
+    // wait for the node tiles that hold this tile's atoms (min .. max node id over both end points)
+    if (wave == 0) {
+        int lo = lane < T ? min(s_src[lane], s_dst[lane]) : 0x7fffffff;
+        int hn = lane < T ? max(s_src[lane], s_dst[lane]) : -1;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo = min(lo, __shfl_xor(lo, off));
+            hn = max(hn, __shfl_xor(hn, off));
+        }
+        const int t_lo = lo / TN, t_hi = hn / TN;
+        bool gave_up = false;
+        for (int t0 = t_lo; t0 <= t_hi && !gave_up; t0 += 64) {
+            const int t = t0 + lane;
+            const bool need = t <= t_hi && t < node_tiles;
+            for (unsigned spins = 0;; ++spins) {
+                const int f = need ? __hip_atomic_load(q.ready + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1;
+                if (__all(f != 0)) break;
+                if (spins > PAIR_SPIN_LIMIT) {
+                    gave_up = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(TSD_PAIR_SLEEP);
+            }
+        }
+        if (gave_up && lane == 0) atomicOr(q.status, TSD_STATUS_INTERNAL);
+    }
+    __syncthreads();  // (also: every wave is done reading buf)
+    {   // h_src * h_dst -> LDS.  The rows were written by other CUs during this launch: sc1 loads (L2, never this
+        // CU's L1, which may hold the rows' previous contents from a node tile's residual read)
+        constexpr int NIT = T * C4 / NT;
+        static_assert(T * C4 % NT == 0, "tile / block mismatch");
+        f32x4 hs[NIT], hd[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+            const float* ps = q.h + (size_t)s_src[r] * H + c4 * 4;
+            const float* pd = q.h + (size_t)s_dst[r] * H + c4 * 4;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(hs[it]) : "v"(ps) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(hd[it]) : "v"(pd) : "memory");
+        }
+        static_assert(NIT == 4, "the wait statement names 2 x 4 registers");
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(hs[0]), "+v"(hs[1]), "+v"(hs[2]), "+v"(hs[3]), "+v"(hd[0]), "+v"(hd[1]), "+v"(hd[2]), "+v"(hd[3])
+                     :: "memory");
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = r < nrows ? hs[it] * hd[it] : z;
+        }
+    }
+    __syncthreads();
+    gemm_tile<1, 1, H>(buf, LDA, q.w0a, H, col0, acc);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) buf[acc_row(r, hi) * LDA + col] = swishf(acc[0][0][r]);
+    __syncthreads();
+    if (wave < NW) {  // H -> H/2 and the final dot: the first H/64 waves
+        f32x16 a2[1][1];
+        const int c2 = wave * 32 + l31;
+        zero_acc(a2);
+        gemm_tile<1, 1, H>(buf, LDA, q.w1, H / 2, wave * 32, a2);
+        const float b = q.b1[c2], w2 = q.w2[c2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float g = a2[0][0][r] + b, sg = swishf(g);
+            float v = sg * w2;
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 1);
+            if (l31 == 0) s_red[wave * T + acc_row(r, hi)] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < nrows) {
+        float v = s_red[tid];
+#pragma unroll
+        for (int k = 1; k < NW; ++k) v += s_red[k * T + tid];
+        q.edge_inv[e0 + tid] = v + q.b2[0];
     }
 }
 
@@ -765,8 +903,15 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
         f.Wl0 += wo;
         f.edge_attr += m * sd.ea; f.wf += m * sd.wf;
         if (q.tiles) {
-            q.edge_attr += m * sd.ea; q.w0b += wo; q.b0 += wo; q.out += m * sd.pre;
+            q.edge_attr += m * sd.ea; q.w0b += wo; q.b0 += wo;
+            if (q.pair) {
+                q.w0a += wo; q.w1 += wo; q.b1 += wo; q.w2 += wo; q.b2 += wo;
+                q.h += no; q.edge_inv += m * q.inv_stride; q.ready += m * (size_t)node_tiles;
+            } else {
+                q.out += m * sd.pre;
+            }
         }
+        if (a.ready) a.ready += m * (size_t)node_tiles;
     }
     // Workgroup -> role.  Small launches (every workgroup resident at once, S = 1) put the node tiles first; large
     // ones (S > 1, odd) spread them through the grid, so that the node role's HBM-bound gather of a big batch and the
@@ -800,7 +945,10 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
     } else {
         const int item = others_before;
         if (item >= f.tiles) {
-            pre_role<H>(q, item - f.tiles, smem);
+            if (q.pair)
+                pair_role<H>(q, item - f.tiles, node_tiles, smem);
+            else
+                pre_role<H>(q, item - f.tiles, smem);
             return;
         }
         TSD_TRACE_REAL(24);
@@ -812,7 +960,8 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
 static inline size_t lds_combo(int H) {
     const size_t node = (size_t)TN * (H + 4) * 4;
     const size_t filt = (size_t)(T * (H + 4) + T) * 4;
-    return node > filt ? node : filt;
+    const size_t pair = (size_t)(T * (H + 4) + (H / 64) * T + 3 * T) * 4;  // pair role (H >= 64)
+    return node > filt ? (node > pair ? node : pair) : (filt > pair ? filt : pair);
 }
 
 int filter_tiles_per_layer(int capacity_u) { return (capacity_u + T - 1) / T; }
@@ -873,6 +1022,7 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     const int node_tiles = layer == -2 ? 0 : (N + TN - 1) / TN;
     ComboPre q{};
     if (pre && pre->tiles > 0) q = *pre;
+    if (q.pair) a.ready = q.ready;  // the node role of this launch publishes h to the pair tiles
     const int grid = node_tiles + f.tiles + q.tiles;
     if (grid == 0) return TSD_OK;
     const size_t lds = lds_combo(c.hidden);

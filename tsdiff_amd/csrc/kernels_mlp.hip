@@ -45,9 +45,11 @@ __global__ __launch_bounds__(2 * H) void edge_embed_kernel(EdgeEmbedW w, tsd_edg
                                                        UmapRole um, EmbedSave sv, int save_b_row, EmbedFuse0 f0) {
     constexpr int LDA = 2 * H + 4;
     if ((int)blockIdx.x >= embed_tiles) {  // extra role: directed-edge -> undirected-pair map (checkpoint 0 only)
-        if (blockIdx.y == 0)
-            edge_umap_body(um.g, um.graph_ptr, um.node_graph, um.pair_ptr, um.P,
-                           ((int)blockIdx.x - embed_tiles) * (2 * H) + (int)threadIdx.x);
+        if (blockIdx.y == 0) {
+            const int t = ((int)blockIdx.x - embed_tiles) * (2 * H) + (int)threadIdx.x;
+            edge_umap_body(um.g, um.graph_ptr, um.node_graph, um.pair_ptr, um.P, t);
+            if (t < um.n_zero) um.zero_words[t] = 0;  // readiness flags of the forward's last launch (api.hip)
+        }
         return;
     }
     {  // blockIdx.y = checkpoint of the ensemble: its weight arena and its output block
@@ -951,7 +953,7 @@ int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_ed
     UmapRole um{};
     if (umap && umap->P > 0) {
         um = *umap;
-        um.blocks = (um.P + 2 * c.hidden - 1) / (2 * c.hidden);
+        um.blocks = ((um.P > um.n_zero ? um.P : um.n_zero) + 2 * c.hidden - 1) / (2 * c.hidden);
     }
     if (tiles_a + tiles_b + um.blocks == 0) return TSD_OK;
     const size_t lds = lds_edge_embed(c.hidden);

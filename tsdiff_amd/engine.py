@@ -82,6 +82,9 @@ def pack_weights(cfg, named_tensors, device):
 
 
 _SIDE_STREAMS = {}
+# static type-sorted embedding tiles (kernels_typed.hip); "0" keeps the generic embedding kernel (A/B, tests)
+TYPED_TILES = os.environ.get("TSDIFF_TYPED_TILES", "1") != "0"
+MAX_TYPE_BUCKETS = 96  # (type_r, type_p) pairs per batch whose folded matrices are kept (H = 256: 25 MB per checkpoint)
 # tests / tools flip this to run the sampling loop's step tail as the three separate launches (bit-identical results)
 FUSED_STEP_TAIL = os.environ.get("TSDIFF_FUSED_TAIL", "1") != "0"
 
@@ -183,8 +186,11 @@ class DeviceBatch:
         pair_base = np.zeros(G + 1, np.int64)
         np.cumsum(nn_host * (nn_host - 1), out=pair_base[1:])
         P = int(pair_base[-1])
-        if P >= 2 ** 31 or N >= 2 ** 31:
-            raise NotImplementedError("batch too large for int32 indexing")
+        if P * cfg.hidden >= 2 ** 31 or N * cfg.hidden >= 2 ** 31:
+            # the library's own guard (api.hip capacity_ok), checked here before anything large is allocated
+            raise NotImplementedError(f"batch too large: {P} ordered pairs x hidden {cfg.hidden} >= 2^31 elements per "
+                                      "edge matrix (largest verified size: 1024 x 64-atom graphs); split the batch "
+                                      "(tsdiff_amd.distributed shards graphs)")
         self.N, self.G, self.P = N, G, P
         self.max_n = int(nn_host.max()) if G else 0
         self.num_nodes_per_graph_host = nn_host
@@ -212,11 +218,40 @@ class DeviceBatch:
         check(lib.tsd_topology_build(N, G, P, nb, ptr(self.graph_ptr), ptr(self.pair_base), ptr(bond_index),
                                      ptr(bond_type), max_order, self.max_n, ptr(self.node_graph),
                                      ptr(self.pair_ptr), ptr(self.pair_code), ptr(self.status), stream_ptr()))
+        # static type-sorted embedding tiles (inference forward: one GEMM per embedded edge instead of three,
+        # include/tsdiff_hip.h tsd_typed_tiles): built on the device behind the topology, their four counts come back
+        # with the status word in the same host read
+        self.typed = None
+        if TYPED_TILES and not defer_status and P > 0:
+            cap = int(lib.tsd_typed_tiles_capacity(P))
+            PU = P // 2
+            tt = torch.empty(6 * PU + 6 * cap + 2 * 1024 + 8192, dtype=i32, device=dev)
+            v = [tt[k * PU:(k + 1) * PU] for k in range(6)]
+            o = 6 * PU
+            enc_tile, diff_tile = tt[o:o + 3 * cap], tt[o + 3 * cap:o + 6 * cap]
+            keys = tt[o + 6 * cap:o + 6 * cap + 2048]
+            scratch = tt[o + 6 * cap + 2048:]
+            counts = self.status[12:16]  # (spare words of the state block: read back with the status word)
+            check(lib.tsd_typed_tiles_build(C.byref(cfg), N, P, ptr(self.graph_ptr), ptr(self.node_graph),
+                                            ptr(self.pair_ptr), ptr(self.pair_code), ptr(v[0]), ptr(v[1]), ptr(v[2]),
+                                            ptr(enc_tile), ptr(v[3]), ptr(v[4]), ptr(v[5]), ptr(diff_tile), ptr(keys),
+                                            ptr(counts), ptr(scratch), stream_ptr()))
+            self.typed = dict(buf=tt, cap=cap, v=v, enc_tile=enc_tile, diff_tile=diff_tile, keys=keys)
         # the topology status word needs a host read: now (one sync per batch), or -- training -- together with
         # the edge counts that tsd_train_forward reads anyway
         self.status_pending = True
         if not defer_status:
-            self.check_status()
+            words = self.status.cpu()
+            self.check_status(int(words[0]))
+            if self.typed is not None:
+                nt_e, nb_e, nt_d, nb_d = (int(x) for x in words[12:16])
+                self.status[12:16].zero_()
+                if nt_e == 0 or nb_e + nb_d > MAX_TYPE_BUCKETS:
+                    self.typed = None  # (no pairs, or an unusually rich type mix: the generic embedding kernel)
+                else:
+                    t = self.typed
+                    t.update(nt_e=nt_e, nb_e=nb_e, nt_d=nt_d, nb_d=nb_d,
+                             slot_keys=torch.cat([t["keys"][:nb_e], t["keys"][1024:1024 + nb_d]]).contiguous())
         raw = _ZeroArena(dev, 2 * EdgeList.raw_bytes(P) + 3 * EdgeList.raw_bytes(P // 2), zero=False)
         self.enc = EdgeList(N, P, dev, arena, raw)      # directed lists: the reference's edge_index order
         self.out = EdgeList(N, P, dev, arena, raw)
@@ -229,6 +264,7 @@ class DeviceBatch:
         self._z_key = None
         self.geo_gen = 0  # bumped whenever the edge lists are rebuilt (saved training contexts check it)
         self._plans = {}  # (kind, clip, clip_pos) -> tsd_sampler_plan* of the bound checkpoints
+        self._plan_streams = {}  # streams the plans were launched on (drop_plans waits for them)
 
     def check_status(self, word=None):
         if not self.status_pending:
@@ -262,6 +298,15 @@ class DeviceBatch:
         if self.workspace is None or self.workspace.numel() < nws:
             self.workspace = torch.empty(max(nws, 1), dtype=torch.float32, device=self.device)
         self.edge_inv_u = torch.zeros(M, max(self.P // 2, 1), dtype=torch.float32, device=self.device)
+        self.bucket_weights = None
+        if self.typed is not None and TYPED_TILES:
+            t = self.typed
+            ns = t["nb_e"] + t["nb_d"]
+            per = int(lib.tsd_bucket_weights_floats(C.byref(self.cfg), ns))
+            self.bucket_weights = torch.empty(M, per, dtype=torch.float32, device=self.device)
+            for m in range(M):  # folded once per (batch, checkpoint), fp64 accumulation
+                check(lib.tsd_bucket_weights_build(C.byref(self.cfg), ptr(self.weights[m]), ns, ptr(t["slot_keys"]),
+                                                   ptr(self.bucket_weights[m]), stream_ptr()))
         self.M = M
         self._z_key = key
 
@@ -280,7 +325,21 @@ class DeviceBatch:
             geo=self.geo_struct(), workspace=self.workspace.data_ptr(),
             edge_inv_u=self.edge_inv_u.data_ptr(),
             # 0 = "unknown": the library then runs the step tail as three launches (A/B switch for tests / tools)
-            max_graph_nodes=self.max_n if FUSED_STEP_TAIL else 0)
+            max_graph_nodes=self.max_n if FUSED_STEP_TAIL else 0,
+            enc_tiles=self._tiles_struct("enc"), diff_tiles=self._tiles_struct("diff"),
+            bucket_weights=None if self.bucket_weights is None else self.bucket_weights.data_ptr())
+
+    def _tiles_struct(self, which):
+        t = self.typed
+        if t is None or self.bucket_weights is None or not TYPED_TILES:
+            return _lib.TypedTiles()
+        e = which == "enc"
+        tile, cap = (t["enc_tile"] if e else t["diff_tile"]), t["cap"]
+        v = t["v"][0:3] if e else t["v"][3:6]
+        return _lib.TypedTiles(num_tiles=t["nt_e"] if e else t["nt_d"], num_buckets=t["nb_e"] if e else t["nb_d"],
+                               tile_slot=tile.data_ptr(), tile_start=tile[cap:].data_ptr(),
+                               tile_count=tile[2 * cap:].data_ptr(), pair=v[0].data_ptr(), node_i=v[1].data_ptr(),
+                               node_j=v[2].data_ptr())
 
     def train_struct(self):
         """tsd_batch for the training step: topology + edge-list buffers only (no bound checkpoints)"""
@@ -337,13 +396,18 @@ class DeviceBatch:
     def drop_plans(self):
         if not getattr(self, "_plans", None):
             return
-        torch.cuda.synchronize(self.device)  # an exec must outlive its launches
+        for s in getattr(self, "_plan_streams", {}).values():  # an exec must outlive its launches: wait for the
+            s.synchronize()                                     # streams the plans ran on (not for the whole device)
         lib = _lib.load()
         for plan in self._plans.values():
             lib.tsd_sampler_plan_destroy(plan)
         self._plans = {}
+        self._plan_streams = {}
 
     def __del__(self):
+        import sys
+        if sys is None or sys.is_finalizing():  # interpreter shutdown: the driver reclaims everything, no sync from GC
+            return
         try:
             self.drop_plans()
         except Exception:
@@ -352,7 +416,7 @@ class DeviceBatch:
     def sampler_plan(self, kind, clip, clip_pos):
         """the captured + instantiated hipGraph of one sampling step for the bound checkpoints; built once and
         replayed by every later dynamic_sampling call on this batch (reference loop: models/sampler.py:187-254)"""
-        key = (int(kind), float(clip), float(-1.0 if clip_pos is None else clip_pos), bool(FUSED_STEP_TAIL))
+        key = (int(kind), float(clip), float(-1.0 if clip_pos is None else clip_pos), bool(FUSED_STEP_TAIL), bool(TYPED_TILES))
         plan = self._plans.get(key)
         if plan is None:
             lib = _lib.load()
@@ -371,18 +435,28 @@ class DeviceBatch:
         """n = coefs.shape[0] steps on self.pos_work, asynchronous on the current stream (no host sync).
         noises None: device Philox draws keyed by (seed, offset)."""
         lib = _lib.load()
-        plan = self.sampler_plan(kind, clip, clip_pos)
         self.geo_gen += 1
+        cur = torch.cuda.current_stream(self.device)
+        if not use_graph:
+            # eager (debugging) form: the same kernels launched one by one, NO capture and no plan object -- usable
+            # when capture itself is what is being diagnosed (tsd_sampler_run's eager branch does not synchronise)
+            self.check_status()
+            b = self.struct()
+            check(lib.tsd_sampler_run(C.byref(self.cfg), C.byref(b), int(kind), int(coefs.shape[0]), ptr(coefs),
+                                      ptr(noises), int(seed), int(offset), float(clip),
+                                      float(-1.0 if clip_pos is None else clip_pos), ptr(self.pos_work), ptr(traj),
+                                      ptr(self.status), 0, C.c_void_p(cur.cuda_stream)))
+            return
+        plan = self.sampler_plan(kind, clip, clip_pos)
         args = _lib.RunArgs(coefs=coefs.data_ptr(), noises=None if noises is None else noises.data_ptr(),
                             traj=None if traj is None else traj.data_ptr(), seed=int(seed), offset=int(offset))
-        cur = torch.cuda.current_stream(self.device)
         # a graph may not be launched into the legacy default stream either: hop to the side stream
         side = _side_stream(self.device) if cur.cuda_stream == 0 else None
         run_on = side if side is not None else cur
         if side is not None:
             side.wait_stream(cur)
-        check(lib.tsd_sampler_plan_run(plan, int(coefs.shape[0]), C.byref(args), int(bool(use_graph)),
-                                       C.c_void_p(run_on.cuda_stream)))
+        self._plan_streams[run_on.cuda_stream] = run_on
+        check(lib.tsd_sampler_plan_run(plan, int(coefs.shape[0]), C.byref(args), 1, C.c_void_p(run_on.cuda_stream)))
         if side is not None:
             cur.wait_stream(side)
 

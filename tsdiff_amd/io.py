@@ -145,15 +145,19 @@ def save_checkpoint(path, config, model, optimizer, scheduler, iteration=0, avg_
 # sampling results
 # ---------------------------------------------------------------------------------------------------
 def unbatch_positions(pos_gen, batch, num_graphs):
-    """`sampling.py:218-223`: per-graph position tensors, original order (batch is ascending, so each graph is
-    one contiguous slice; identical to the reference's `pos_gen[batch == j]` mask loop)."""
-    batch = batch.detach().cpu()
-    counts = torch.bincount(batch, minlength=num_graphs).tolist()
-    if len(counts) != num_graphs:
-        raise ValueError(f"batch holds {len(counts)} graphs, num_graphs={num_graphs}")
-    pos_gen = pos_gen.detach().cpu()
-    if bool((batch[1:] < batch[:-1]).any()):  # not sorted: fall back to the literal mask loop
-        return [pos_gen[..., batch == j, :] for j in range(num_graphs)]
+    """`sampling.py:218-223`: per-graph position tensors, original order, on `pos_gen`'s device like the
+    reference's `pos_gen[batch == j]` mask loop (ids outside [0, num_graphs) are ignored like there).  `batch`
+    ascending (what `Batch.from_data_list` produces): each graph is one contiguous slice, cut with one split
+    instead of `num_graphs` mask kernels; anything else takes the literal mask loop."""
+    pos_gen = pos_gen.detach()
+    b = batch.detach().to(pos_gen.device)
+    ok = b.dtype in (torch.int64, torch.int32) and b.numel() > 0
+    if ok:
+        bl = b.long()
+        ok = bool(((bl[1:] >= bl[:-1]).all() & (bl[0] >= 0) & (bl[-1] < num_graphs)).item())
+    if not ok:
+        return [pos_gen[..., b == j, :] for j in range(num_graphs)]
+    counts = torch.bincount(bl, minlength=num_graphs).tolist()
     return list(torch.split(pos_gen, counts, dim=-2))
 
 

@@ -493,10 +493,12 @@ class FusedTrainLoss(torch.autograd.Function):
         cfg = model._cfg
         dev = pos0.device
         # parameters re-homed in one flat buffer (optim.flatten_parameters) are handed over as they lie
+        # (EVERY parameter must still be the view it was made: a re-homed one -- p.data = ..., weight tying, a partial
+        # .to() -- would otherwise train on the stale copy in the flat buffer)
+        from . import optim
         flat = getattr(model, "_flat_param", None)
-        if flat is not None and flat.device == dev and params[0].data_ptr() == flat.data_ptr() and \
-                params[-1].data_ptr() + 4 * params[-1].numel() == flat.data_ptr() + 4 * flat.numel() and \
-                sum(p.numel() for p in params) == flat.numel():
+        live = flat is not None and flat.device == dev and optim._views_of(params, flat)
+        if live:
             raw = flat.detach()
         else:
             raw = torch.cat([p.detach().reshape(-1) for p in params])
@@ -523,6 +525,10 @@ class FusedTrainLoss(torch.autograd.Function):
         db.geo_gen += 1
         model._train_ws_gen = getattr(model, "_train_ws_gen", 0) + 1
         ctx.stamp = (db.geo_gen, model._train_ws_gen)
+        # the live flat buffer is read again by backward (weights of the dgrads): an optimizer step or any other
+        # in-place update of a parameter in between would differentiate against other weights than the forward used
+        ctx.param_versions = (flat._version + sum(p._version for p in params)) if live else None
+        ctx.params = params if live else None
         ctx.used = False
         ctx.model, ctx.db, ctx.raw, ctx.ws, ctx.counts, ctx.pos = model, db, raw, ws, counts, pos_perturbed
         ctx.sizes = [p.numel() for p in params]
@@ -543,6 +549,12 @@ class FusedTrainLoss(torch.autograd.Function):
                 "get_loss / forward / sampling call ran on the same model or batch in between.  The fused training "
                 "step keeps ONE step's activations per model (reference order: get_loss, backward, step; "
                 "train.py:128-145).  Call backward first, or set TSDIFF_TRAIN=ops for the op-by-op autograd form.")
+        if ctx.param_versions is not None and \
+                ctx.param_versions != ctx.model._flat_param._version + sum(p._version for p in ctx.params):
+            raise RuntimeError(
+                "tsdiff_amd: a parameter was modified in place between get_loss and backward() (an optimizer step of "
+                "another loss?): the fused training step differentiates against the live flat parameter buffer.  "
+                "Call backward before stepping, or set TSDIFF_TRAIN=ops.")
         ctx.used = True
         grad = torch.empty_like(ctx.raw)
         dloss = _c(dloss.float()).view(-1)
