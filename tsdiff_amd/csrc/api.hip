@@ -318,6 +318,10 @@ static int step_impl(const tsd_model_cfg& c, const tsd_batch& b, int kind, float
 }  // namespace tsd
 
 // the plan: one captured + instantiated step, replayed by every call (include/tsdiff_hip.h)
+// (round 3: a second graph of TSD_PLAN_MULTI consecutive steps -- consecutive graph launches are ~9 us apart on the
+// device, kernels inside a graph are back to back -- captured on the first call that runs that many steps; every
+// per-step value comes from the device-side step counter / ticket, so a step is the same wherever it is replayed from)
+constexpr int TSD_PLAN_MULTI = 8;
 struct tsd_sampler_plan {
     tsd_model_cfg cfg;
     tsd_batch batch;
@@ -327,6 +331,8 @@ struct tsd_sampler_plan {
     tsd_sampler_state* state;
     hipGraph_t graph;
     hipGraphExec_t exec;
+    hipGraph_t graph_multi;
+    hipGraphExec_t exec_multi;
 };
 
 namespace tsd {
@@ -598,7 +604,7 @@ int tsd_sampler_plan_create(const tsd_model_cfg* cfg, const tsd_batch* batch, in
     TSD_REQUIRE(kind == 0 || kind == 1, "kind=%d (0 = ld, 1 = ddpm)", kind);
     TSD_REQUIRE(stream != nullptr, "stream capture is illegal on the legacy default stream: pass a created stream");
     hipStream_t st = (hipStream_t)stream;
-    tsd_sampler_plan* p = new tsd_sampler_plan{*cfg, *batch, kind, clip, clip_pos, pos, state, nullptr, nullptr};
+    tsd_sampler_plan* p = new tsd_sampler_plan{*cfg, *batch, kind, clip, clip_pos, pos, state, nullptr, nullptr, nullptr, nullptr};
     hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) {
         delete p;
@@ -642,7 +648,23 @@ int tsd_sampler_plan_run(tsd_sampler_plan* plan, int32_t n_steps, const tsd_run_
         // member counts of the first step's lists (later steps get them from the previous step's tail kernel)
         return r;
     }
-    for (int k = 0; k < n_steps; ++k) {
+    int k = 0;
+    if (use_graph && n_steps >= TSD_PLAN_MULTI) {
+        if (!plan->exec_multi) {  // first long call on this plan: capture TSD_PLAN_MULTI steps (nothing executes)
+            hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+            if (e != hipSuccess) return check_hip(e, "hipStreamBeginCapture");
+            for (int q = 0; q < TSD_PLAN_MULTI && r == TSD_OK; ++q)
+                r = step_impl(plan->cfg, b, plan->kind, plan->clip, plan->clip_pos, plan->pos, plan->state, st);
+            e = hipStreamEndCapture(st, &plan->graph_multi);
+            if (r == TSD_OK) r = check_hip(e, "hipStreamEndCapture");
+            if (r == TSD_OK)
+                r = check_hip(hipGraphInstantiate(&plan->exec_multi, plan->graph_multi, nullptr, nullptr, 0),
+                              "hipGraphInstantiate");
+            if (r != TSD_OK) return r;
+        }
+        for (; k + TSD_PLAN_MULTI <= n_steps; k += TSD_PLAN_MULTI) TSD_HIP(hipGraphLaunch(plan->exec_multi, st));
+    }
+    for (; k < n_steps; ++k) {
         if (use_graph) {
             TSD_HIP(hipGraphLaunch(plan->exec, st));
         } else if ((r = step_impl(plan->cfg, b, plan->kind, plan->clip, plan->clip_pos, plan->pos, plan->state, st))) {
@@ -656,6 +678,8 @@ void tsd_sampler_plan_destroy(tsd_sampler_plan* plan) {
     if (!plan) return;
     if (plan->exec) (void)hipGraphExecDestroy(plan->exec);
     if (plan->graph) (void)hipGraphDestroy(plan->graph);
+    if (plan->exec_multi) (void)hipGraphExecDestroy(plan->exec_multi);
+    if (plan->graph_multi) (void)hipGraphDestroy(plan->graph_multi);
     delete plan;
 }
 
@@ -673,7 +697,7 @@ int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t ki
         if ((r = check_batch(*cfg, batch))) return r;
         TSD_REQUIRE(pos && state, "null pointer");
         TSD_REQUIRE(kind == 0 || kind == 1, "kind=%d (0 = ld, 1 = ddpm)", kind);
-        plan = new tsd_sampler_plan{*cfg, *batch, kind, clip, clip_pos, pos, state, nullptr, nullptr};
+        plan = new tsd_sampler_plan{*cfg, *batch, kind, clip, clip_pos, pos, state, nullptr, nullptr, nullptr, nullptr};
     }
     const tsd_run_args args{coefs, noises, traj, seed, offset};
     r = tsd_sampler_plan_run(plan, n_steps, &args, use_graph, stream);
