@@ -41,7 +41,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md:41
 PEAK_HBM_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec)
 # HBM-side bytes per launch come from the committed rocprofv3 PMC passes of this round (tools/profile_round.sh), read
 # here because counters cannot be collected inside a bench run; a missing file gives `traffic: null`
-PMC_C2, PMC_C5 = "r03_pmc_traffic.json", "r03_pmc_traffic_c5.json"
+PMC_C2, PMC_C5, MFMA_BUSY = "r03_pmc_traffic.json", "r03_pmc_traffic_c5.json", "r03_mfma_busy.json"
 
 
 def parse():
@@ -193,17 +193,18 @@ def combo_roofline(lib, db, cfg, dev, reps=40):
             "algorithmic_bytes_per_launch": (Eu * 4.0 * H * 3 + 4.0 * N * H * 4 + 5 * 4.0 * H * H) * L / (L + 1)}
 
 
-def aggregate_roofline(lib, db, H, dev, reps=20):
+def aggregate_roofline(lib, cfg_struct, N, E, row_ptr, dst, H, dev, reps=20):
     """the HBM-bound form of the message pass: segmented aggregation with a materialised
-    directed filter W [E,H]: bytes = 1028 E + 2048 N + 4 (at H = 256)"""
+    directed filter W [E,H]: bytes = 1028 E + 2048 N + 4 (at H = 256).  The 4.2 GB filter is allocated from a
+    freshly emptied allocator (the caller drops the sampling workspace first): the kernel's rate depends on how
+    the buffer is laid out physically (tools/ab_agg.py: 700-800 us across processes for the same code)."""
     from tsdiff_amd import _lib
-    N, E = db.N, db.enc.num_edges()
     Wd = torch.randn(max(E, 1), H, device=dev)
     x1 = torch.randn(N, H, device=dev)
     agg = torch.empty(N, H, device=dev)
 
     def launch():
-        _lib.check(lib.tsd_cfconv_aggregate(H, N, _lib.ptr(db.enc.row_ptr), _lib.ptr(db.enc.dst), None, _lib.ptr(Wd),
+        _lib.check(lib.tsd_cfconv_aggregate(H, N, _lib.ptr(row_ptr), _lib.ptr(dst), None, _lib.ptr(Wd),
                                             _lib.ptr(x1), _lib.ptr(agg), _lib.stream_ptr()))
     for _ in range(reps):
         launch()
@@ -216,7 +217,7 @@ def aggregate_roofline(lib, db, H, dev, reps=20):
         ev1.record()
         torch.cuda.synchronize()
         a_ms = min(a_ms, ev0.elapsed_time(ev1) / reps)
-    a_bytes = forward_work(db.cfg, E, 0, 0, N).bytes_aggregate
+    a_bytes = forward_work(cfg_struct, E, 0, 0, N).bytes_aggregate
     gbs = a_bytes / (a_ms * 1e-3) / 1e9
     del Wd, x1, agg
     return {"kernel": "cfconv_aggregate_kernel<256>", "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS,
@@ -300,6 +301,30 @@ def dualenc_bench(dev, graphs=100, steps=10):
             "ld_ms_per_step": round(s_ms, 3), "atoms_steps_per_s": round(N / (s_ms * 1e-3), 1), "ld_steps": steps}
 
 
+def mfma_busy(label, kernel_prefix):
+    """MFMA-busy fraction of a kernel from the committed SQ-counter pass of this round (tools/mfma_busy.py)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", MFMA_BUSY)) as fh:
+            tab = json.load(fh)[label]
+        key = [k for k in tab if k.startswith(kernel_prefix)][0]
+        return tab[key]["mfma_busy"]
+    except Exception:
+        return None
+
+
+def train_roofline(tf, flops):
+    """the `roofline` object of the training step: whole-step executed arithmetic against the fp32 MFMA peak, plus the
+    MFMA-pipe busy fractions of its three heaviest kernels (SQ counters, profiles/)"""
+    return {"kernel": "whole training step (forward + dgrad + wgrad tile GEMMs, optimizer, host)", "bound": "mfma",
+            "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "flop_per_step": flops,
+            "note": "executed flops = 3 x the forward's (undirected formulation)",
+            "mfma_busy": {"block_bwd_kernel": mfma_busy("train", "block_bwd_kernel"),
+                          "layer_combo_kernel(save)": mfma_busy("train", "layer_combo_kernel"),
+                          "wgrad_batch_kernel": mfma_busy("train", "wgrad_batch_kernel")},
+            "mfma_busy_source": "profiles/" + MFMA_BUSY}
+
+
 def pmc_traffic(name_prefix, fname):
     """HBM-side bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_summary.py)"""
     try:
@@ -358,7 +383,7 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist):
     # executed arithmetic of a step ~ 3 x the forward's dense layers (forward, dgrad, wgrad) on the undirected lists
     db = model._batches[0][2]
     L = model._cfg.num_convs
-    F, _ = forward_flops(model._cfg, db.enc.num_edges(), db.out.num_edges(), db.diff_u.num_edges(), db.N, 1)
+    F = forward_work(model._cfg, db.enc.num_edges(), db.out.num_edges(), db.diff_u.num_edges(), db.N).flops_train_forward
     model.eval()
     return dt, float(last), N, 3.0 * F
 
@@ -380,10 +405,7 @@ def bench_train_main(args, model, dev, rank, world, dist):
             "config": {"workload": "configs[3] training step", "graphs_per_gpu": args.graphs, "atoms_per_gpu": N,
                        "parallelism": f"graph-batch data parallel over {world} GPU(s), one RCCL all-reduce of "
                                       "the flat fp32 gradient per step"},
-            "roofline": {"kernel": "whole training step (forward + dgrad + wgrad tile GEMMs, optimizer, host)",
-                         "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                         "flop_per_step": flops, "note": "executed flops = 3 x the forward's (undirected formulation)"},
+            "roofline": train_roofline(tf, flops),
             "final_loss": last}))
 
 
@@ -528,6 +550,7 @@ def main():
     roofline = combo_roofline(lib, db, cfg, dev, reps=40 if db.P < 2_000_000 else 2)
     fname = PMC_C2 if args.workload == "c2" else PMC_C5
     roofline["traffic"], roofline["traffic_source"] = pmc_traffic("layer_combo_kernel<256", fname)
+    roofline["mfma_busy"] = mfma_busy("c2" if args.workload == "c2" else "c5", "layer_combo_kernel")
     F, F_ref = forward_flops(models[0]._cfg, E_enc, E_out, E_diff, N, args.models)
     step_s = dt / args.steps
 
@@ -588,14 +611,24 @@ def main():
                      "edges_enc": db5.enc.num_edges(), "forward_tflops": round(F5 / (dt5 / K5) / 1e12, 2),
                      "roofline": rf5}
     if db5 is not None:
-        agg = aggregate_roofline(lib, db5, H, dev)
-        agg["traffic"], agg["traffic_source"] = pmc_traffic("cfconv_aggregate_kernel<256", PMC_C5)
-        roofline["aggregate"] = agg
-    if extras:
-        out["c5"]["wall_s"] = round(time.perf_counter() - t0, 1)
-        del run5, s5, db5, g5
+        # the stand-alone aggregation needs the directed CSR only: keep copies, drop the sampling state first
+        N5a, E5a = db5.N, db5.enc.num_edges()
+        rp5, dst5 = db5.enc.row_ptr.clone(), db5.enc.dst.clone()
+        cfg5 = db5.cfg
+        if extras:
+            out["c5"]["wall_s"] = round(time.perf_counter() - t0, 1)
+            del run5, s5, g5
+        db5 = None
+        if args.workload == "c5":
+            del run, db
         models[0]._batches.clear()
         torch.cuda.empty_cache()
+        agg = aggregate_roofline(lib, cfg5, N5a, E5a, rp5, dst5, H, dev)
+        agg["traffic"], agg["traffic_source"] = pmc_traffic("cfconv_aggregate_kernel<256", PMC_C5)
+        roofline["aggregate"] = agg
+        del rp5, dst5
+        torch.cuda.empty_cache()
+    if extras:
         # ---- BASELINE configs[2]'s per-GPU unit: the same 100-graph batch with an ensemble of 8 checkpoints
         m8 = (models + make_models(cfg, range(len(models), 8), dev))[:8]
         s8 = EnsembleSampler(m8)
@@ -620,7 +653,7 @@ def main():
                                     "batch every step", "steps": Kt, "ms_per_step": round(dtt / Kt * 1e3, 3),
                         "value": round(200 * Kt / dtt, 1), "unit": "graphs/s", "atoms": Nt,
                         "executed_tflops": round(tf, 2), "frac_of_fp32_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                        "final_loss": last}
+                        "roofline": train_roofline(tf, flt), "final_loss": last}
 
     if extras:
         models[0]._batches.clear()

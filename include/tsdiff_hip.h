@@ -129,11 +129,13 @@ int tsd_pack_weights(const tsd_model_cfg* cfg, const float* raw, float* packed, 
  * Arithmetic of ONE forward of one checkpoint for a batch with the given edge counts: `enc_edges` / `out_edges`
  * directed edges of the encoder / output lists, `diff_pairs` undirected output pairs embedded separately. */
 typedef struct tsd_work {
-    double flops_edge_embed, flops_blocks, flops_pair_output, flops_other; /* executed: per-edge MLPs once per undirected pair */
+    double flops_edge_embed, flops_blocks, flops_pair_output, flops_other; /* executed by the INFERENCE forward: per-edge
+                                   MLPs once per undirected pair, embedding on the type-folded matrices (tsd_typed_tiles) */
     double flops_executed;      /* their sum */
     double flops_reference;     /* the reference's directed formulation of the same forward */
     double flops_block_launch;  /* average executed flops of one of the L + 1 per-block launches */
     double bytes_aggregate;     /* algorithmic HBM bytes of one stand-alone CFConv aggregation (tsd_cfconv_aggregate) */
+    double flops_train_forward; /* executed by the TRAINING step's forward (reference operation order, undirected pairs) */
 } tsd_work;
 int tsd_forward_work(const tsd_model_cfg* cfg, int32_t num_nodes, int64_t enc_edges, int64_t out_edges,
                      int64_t diff_pairs, tsd_work* out);

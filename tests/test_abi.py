@@ -142,8 +142,11 @@ def test_forward_work_model_known_answers():
     w = _lib.Work()
     N, E_enc, E_out, E_diff, L = 1600, 26074, 24000, 1500, 7
     _lib.check(lib.tsd_forward_work(C.byref(cfg), N, E_enc, E_out, E_diff, C.byref(w)))
-    F = ((E_enc // 2) * (131584 + 393216 + L * 262144) + E_enc * L * 512 + E_diff * (131584 + 393216)
+    # inference forward: Linear(1,H) + ONE folded H x H GEMM per embedded edge (type-sorted tiles); the training
+    # forward keeps the reference's order: + edge_cat's 6 H^2 per embedded edge
+    F = ((E_enc // 2) * (131584 + L * 262144) + E_enc * L * 512 + E_diff * 131584
          + (E_out // 2) * (327936 + 256) + N * (L * 393216 + 13000))
+    assert w.flops_train_forward == F + ((E_enc // 2) + E_diff) * 393216
     F_ref = (E_enc * (131584 + 393216 + L * 262144 + L * 512) + E_out * (131584 + 393216 + 327936 + 256)
              + N * (L * 393216 + 13000))
     assert w.flops_executed == F and w.flops_reference == F_ref

@@ -14,6 +14,7 @@ python3 tools/rocpd_stats.py $(db /tmp/p_c5) > gpurun_out/${TAG}_kernel_stats_c5
 rocprofv3 --kernel-trace --stats -d /tmp/p_tr -o tr -- python3 bench.py --workload train --steps 20 --warmup 5 > gpurun_out/${TAG}_prof_train.log 2>&1
 python3 tools/rocpd_stats.py $(db /tmp/p_tr) > gpurun_out/${TAG}_kernel_stats_train.md
 python3 tools/step_timeline.py $(db /tmp/p_tr) > gpurun_out/${TAG}_train_timeline.md
+python3 tools/step_timeline.py $(db /tmp/p_c2) step_tail > gpurun_out/${TAG}_step_timeline.md
 # roctx ranges of the library's entry points (no counters in this pass)
 rocprofv3 --kernel-trace --marker-trace -d /tmp/p_mk -o mk -- python3 bench.py --steps 20 --warmup 5 --no-graph $B > gpurun_out/${TAG}_prof_markers.log 2>&1
 python3 tools/marker_summary.py $(db /tmp/p_mk) > gpurun_out/${TAG}_markers.md
@@ -30,12 +31,20 @@ python3 tools/pmc_summary.py $(db /tmp/p_f5) $(db /tmp/p_w5) gpurun_out/${TAG}_p
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAVES"
 rocprofv3 --kernel-trace --pmc $SQ -d /tmp/p_sq -o sq -- python3 bench.py --steps 30 --warmup 5 $B > gpurun_out/${TAG}_pmc_sq.log 2>&1
 rocprofv3 --kernel-trace --pmc $SQ -d /tmp/p_sq5 -o sq -- python3 bench.py --workload c5 --steps 3 --warmup 1 $B > gpurun_out/${TAG}_pmc_sq5.log 2>&1
+rocprofv3 --kernel-trace --pmc $SQ -d /tmp/p_sqt -o sq -- python3 bench.py --workload train --steps 8 --warmup 2 > gpurun_out/${TAG}_pmc_sqt.log 2>&1
+python3 tools/mfma_busy.py c2=$(db /tmp/p_sq) c5=$(db /tmp/p_sq5) train=$(db /tmp/p_sqt) > gpurun_out/${TAG}_mfma_busy.json
+{
+  echo "# SQ counters per launch of the training step (rocprofv3 --kernel-trace --pmc, one pass; MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch time x 2.4 GHz)), $TAG"
+  echo; echo '```'
+  for k in block_bwd layer_combo wgrad_batch wgrad_kernel embed_bwd edge_embed pair_output pair_bwd; do python3 tools/pmc_kernel_table.py $(db /tmp/p_sqt) $k; done
+  echo '```'
+} > gpurun_out/${TAG}_sq_counters_train.md
 {
   echo "# SQ counters per launch (rocprofv3 --kernel-trace --pmc, one pass), $TAG"
   echo; echo "## configs[1] (batch 100)"; echo '```'
   python3 tools/pmc_kernel_table.py $(db /tmp/p_sq) layer_combo
-  python3 tools/pmc_kernel_table.py $(db /tmp/p_sq) edge_embed
-  python3 tools/pmc_kernel_table.py $(db /tmp/p_sq) pair_output
+  python3 tools/pmc_kernel_table.py $(db /tmp/p_sq) typed_embed
+  python3 tools/pmc_kernel_table.py $(db /tmp/p_sq) step_tail
   echo '```'; echo; echo "## configs[4] (1024 x 64 atoms)"; echo '```'
   python3 tools/pmc_kernel_table.py $(db /tmp/p_sq5) layer_combo
   python3 tools/pmc_kernel_table.py $(db /tmp/p_sq5) cfconv_aggregate

@@ -109,7 +109,8 @@ class Batch(C.Structure):
 class Work(C.Structure):
     """tsd_work"""
     _fields_ = [(k, C.c_double) for k in ("flops_edge_embed", "flops_blocks", "flops_pair_output", "flops_other",
-                                          "flops_executed", "flops_reference", "flops_block_launch", "bytes_aggregate")]
+                                          "flops_executed", "flops_reference", "flops_block_launch", "bytes_aggregate",
+                                          "flops_train_forward")]
 
 
 class RunArgs(C.Structure):  # tsd_run_args

@@ -545,10 +545,11 @@ int tsd_forward_work(const tsd_model_cfg* cfg, int32_t num_nodes, int64_t enc_ed
     const double H = cfg->hidden, L = cfg->num_convs, N = num_nodes;
     const double Eu = (double)(enc_edges / 2), Ou = (double)(out_edges / 2), E = (double)enc_edges, O = (double)out_edges;
     const double embed_row = (2 * H + 2 * H * H) + 6 * H * H;          // Linear(1,H), Linear(H,H) | edge_cat 2H->H->H
+    const double embed_row_typed = 2 * H + 2 * H * H;                   // Linear(1,H), ONE folded H x H GEMM (typed tiles)
     const double filter_row = 4 * H * H;                                // nn.0, nn.2
     const double pair_row = 4 * H * H + H * H + H + H;                  // 2H->H, H->H/2, H/2->1, h_i * h_j
     const double node_block = 6 * H * H;                                // lin1, lin2, lin
-    out->flops_edge_embed = (Eu + (double)diff_pairs) * embed_row;
+    out->flops_edge_embed = (Eu + (double)diff_pairs) * embed_row_typed;
     out->flops_blocks = L * (Eu * filter_row + E * 2 * H + N * node_block);
     out->flops_pair_output = Ou * pair_row;
     out->flops_other = N * 13000.0;
@@ -556,6 +557,9 @@ int tsd_forward_work(const tsd_model_cfg* cfg, int32_t num_nodes, int64_t enc_ed
     out->flops_reference = E * (embed_row + L * (filter_row + 2 * H)) + O * (embed_row + pair_row) + N * (L * node_block + 13000.0);
     out->flops_block_launch = L * (Eu * (filter_row + H) + E * 2 * H + N * node_block) / (L + 1);
     out->bytes_aggregate = (4 * H + 4) * E + 8 * H * N + 4;            // stand-alone CFConv aggregation (HBM form)
+    // the training step's forward keeps the reference's operation order (no folded weights): three GEMMs more per
+    // embedded edge than the inference forward
+    out->flops_train_forward = out->flops_executed + (Eu + (double)diff_pairs) * (embed_row - embed_row_typed);
     return TSD_OK;
 }
 

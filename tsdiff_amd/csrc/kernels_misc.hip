@@ -78,7 +78,22 @@ __global__ __launch_bounds__(256) void cfconv_aggregate_kernel(int N, const int3
 #ifndef TSD_AGG_U
 #define TSD_AGG_U 8
 #endif
-    const int grp = (TSD_AGG_SWZ && b < (per << 3)) ? (b & 7) * per + (b >> 3) : b;  // (the tail that does not fill 8 XCDs: identity)
+#ifndef TSD_AGG_RUN
+#define TSD_AGG_RUN 16  // consecutive 4-row groups kept on one XCD by TSD_AGG_SWZ == 2 (16 groups = one 64-atom graph)
+#endif
+    int grp = b;
+    if (TSD_AGG_SWZ == 1 && b < (per << 3)) {
+        grp = (b & 7) * per + (b >> 3);  // XCD x takes the contiguous range [x B/8, (x+1) B/8)
+    } else if (TSD_AGG_SWZ == 2) {
+        // runs of TSD_AGG_RUN consecutive groups go to ONE XCD, consecutive runs to consecutive XCDs: the XCDs work on
+        // neighbouring graphs (one W window, as the identity order) and a graph's x1 rows are fetched by one L2
+        constexpr int RUN = TSD_AGG_RUN;
+        const int full = B / (8 * RUN) * (8 * RUN);
+        if (b < full) {
+            const int x = b & 7, r = b >> 3;
+            grp = ((r / RUN) * 8 + x) * RUN + r % RUN;
+        }
+    }
     const int i = grp * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // (wave-uniform: scalar row offsets)
     const int lane = threadIdx.x & 63;
     if (i >= N) return;
