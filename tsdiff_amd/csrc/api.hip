@@ -225,9 +225,11 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     f0.wf_stride = w.stride_wf;
     // (batch-100 sizes only: measured 0.441 -> 0.435 ms/step at configs[1]; at configs[4] the longer embedding
     // tiles lose more than the launch saves, 50.5 -> 52.8 ms/step)
-    const bool fuse_block0 = small_fwd;
     // static type-sorted tiles (one GEMM per embedded edge instead of three) when the batch carries them
     const bool typed = kFold && b.enc_tiles.num_tiles > 0 && b.bucket_weights != nullptr;
+    // ... and with the typed embedding's small LDS tile also at configs[4] sizes (42.90 -> 42.54 ms/step; the 8-checkpoint
+    // ensemble at batch 100 in between loses 0.4 %: not there)
+    const bool fuse_block0 = small_fwd || (typed && (long)node_tiles_all * M >= 2048);
     if (typed) {
         if ((r = launch_typed_embed(c, W, b, pos, w.ea, M, w.stride_ea, st, &um, fuse_block0 ? &f0 : nullptr))) return r;
     } else if ((r = launch_edge_embed2(c, W, PU, g.enc_u, w.ea, PU, g.diff_u, w.ea + (size_t)PU * H, M, w.stride_ea, st,
