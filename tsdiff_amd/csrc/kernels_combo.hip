@@ -474,10 +474,15 @@ __device__ __forceinline__ void pre_role(const ComboPre& q, int tile, float* sme
 #ifndef TSD_PAIR_SLEEP
 #define TSD_PAIR_SLEEP 48  // x64 cycles between two polls of a waiting pair tile (~1.3 us)
 #endif
+#ifndef TSD_PAIR_DEFER
+#define TSD_PAIR_DEFER 1
+#endif
 constexpr unsigned PAIR_SPIN_LIMIT = 2000000u;  // ~1 s of polling: then TSD_STATUS_INTERNAL instead of a hang
 
+// defer_pre: the node-independent GEMM runs AFTER the wait -- for the pair tiles that share a CU with a node tile (an
+// fp32 MFMA stream beside it slows the node chain's aggregation 3x, and the node chain is what everyone waits for)
 template <int H>
-__device__ __forceinline__ void pair_role(const ComboPre& q, int tile, int node_tiles, float* smem) {
+__device__ __forceinline__ void pair_role(const ComboPre& q, int tile, int node_tiles, float* smem, bool defer_pre) {
     constexpr int LDA = H + 4, NT = 2 * H, C4 = H / 4, NW = H / 64;
     float* buf = smem;
     float* s_red = smem + T * LDA;  // [NW][T]
@@ -497,20 +502,21 @@ __device__ __forceinline__ void pair_role(const ComboPre& q, int tile, int node_
         s_row[tid] = q.attr_row ? q.attr_row[ee] : ee;
     }
     __syncthreads();
-    for (int idx = tid; idx < T * C4; idx += NT) {
-        const int r = idx / C4, c4 = idx % C4;
-        *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) =
-            *reinterpret_cast<const f32x4*>(q.edge_attr + (size_t)s_row[r] * H + c4 * 4);
-    }
-    __syncthreads();
     f32x16 acc[1][1];
-    zero_acc(acc);
-    gemm_tile<1, 1, H>(buf, LDA, q.w0b, H, col0, acc);
-    {
+    auto pre_gemm = [&]() {
+        for (int idx = tid; idx < T * C4; idx += NT) {
+            const int r = idx / C4, c4 = idx % C4;
+            *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) =
+                *reinterpret_cast<const f32x4*>(q.edge_attr + (size_t)s_row[r] * H + c4 * 4);
+        }
+        __syncthreads();
+        zero_acc(acc);
+        gemm_tile<1, 1, H>(buf, LDA, q.w0b, H, col0, acc);
         const float b = q.b0[col];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][0][r] = acc_row(r, hi) < nrows ? acc[0][0][r] + b : 0.0f;
-    }
+    };
+    if (!defer_pre) pre_gemm();
     // wait for the node tiles that hold this tile's atoms (min .. max node id over both end points)
     if (wave == 0) {
         int lo = lane < T ? min(s_src[lane], s_dst[lane]) : 0x7fffffff;
@@ -538,6 +544,10 @@ __device__ __forceinline__ void pair_role(const ComboPre& q, int tile, int node_
         if (gave_up && lane == 0) atomicOr(q.status, TSD_STATUS_INTERNAL);
     }
     __syncthreads();  // (also: every wave is done reading buf)
+    if (defer_pre) {
+        pre_gemm();
+        __syncthreads();
+    }
     {   // h_src * h_dst -> LDS.  The rows were written by other CUs during this launch: sc1 loads (L2, never this
         // CU's L1, which may hold the rows' previous contents from a node tile's residual read)
         constexpr int NIT = T * C4 / NT;
@@ -946,7 +956,9 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
         const int item = others_before;
         if (item >= f.tiles) {
             if (q.pair)
-                pair_role<H>(q, item - f.tiles, node_tiles, smem);
+                // workgroups b and b + 256 of a launch share a CU (measured; a speed assumption only): these pair tiles
+                // sit beside the node tiles
+                pair_role<H>(q, item - f.tiles, node_tiles, smem, TSD_PAIR_DEFER && b >= 256 && b - 256 < node_tiles);
             else
                 pre_role<H>(q, item - f.tiles, smem);
             return;
