@@ -194,10 +194,12 @@ struct ComboPre {
 
 // Side outputs of the fused forward kernels for the training step (train_step.hip): the activations the
 // backward pass reads, written next to the inference results by the SAVE instantiations of the same kernels.
-struct EmbedSave {    // rows are edge-attribute rows: enc_u edge e -> e, k-th diff_u edge -> capacity_u + k
+struct EmbedSave {    // rows are edge-attribute rows: enc_u edge e -> e, k-th diff_u edge -> save_b_row + k
     float *l0, *s0;   // Linear(1,H)(d) and its swish                         [rows,H]
     float *e, *c;     // e = mlp(d) [rows,H]; c = [e * emb[type_r], e * emb[type_p]] [rows,2H]
     float *c0, *s1;   // edge_cat.0(c) and its swish                           [rows,H]
+    float* d;         // the row's distance                                    [rows]   (the two lists' inputs as ONE
+    uint8_t *tr, *tp; // the row's bond types                                  [rows]    row range for the wgrads)
 };
 struct FilterSave {   // per interaction block: [layer][capacity_u, H]
     float *f0, *fs;   // nn.0 output and its shifted softplus
@@ -209,6 +211,9 @@ struct PairSave {     // [capacity_u, .]
     float* hp;        // [2H]: h_i * h_j || edge_attr_out
     float *g0, *gs0;  // [H]: first layer of the pair MLP and its swish
     float *g1, *gs1;  // [H/2]: second layer and its swish
+    // attribute rows >= attr_from lie attr_shift rows lower than geo.attr_row says (the training step packs the
+    // separately embedded out edges right behind the enc_u rows: one contiguous row range for the weight gradients)
+    int attr_from = 0x7fffffff, attr_shift = 0;
 };
 
 // The filter GEMMs of interaction block 0 appended to the enc-list tiles of the edge-embedding launch (inference

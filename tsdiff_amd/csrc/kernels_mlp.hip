@@ -85,6 +85,13 @@ __global__ __launch_bounds__(2 * H) void edge_embed_kernel(EdgeEmbedW w, tsd_edg
         s_d[tid] = v ? e.dist[ee] : 0.0f;
         s_tr[tid] = v ? (int)e.type_r[ee] : 0;
         s_tp[tid] = v ? (int)e.type_p[ee] : 0;
+        if constexpr (SAVE) {
+            if (v) {
+                sv.d[srow0 + tid] = s_d[tid];
+                sv.tr[srow0 + tid] = (uint8_t)s_tr[tid];
+                sv.tp[srow0 + tid] = (uint8_t)s_tp[tid];
+            }
+        }
     }
     __syncthreads();
     {  // Linear(1,H) + swish: thread = (channel, half of the tile's rows)
@@ -356,7 +363,8 @@ __global__ __launch_bounds__(2 * H) void pair_bwd_kernel(tsd_edges e, const int3
                                                         const float* __restrict__ g1, const float* __restrict__ g0,
                                                         const float* __restrict__ W1t, const float* __restrict__ W0t,
                                                         float* __restrict__ dg1, float* __restrict__ dg0,
-                                                        float* __restrict__ dp, float* __restrict__ d_ea) {
+                                                        float* __restrict__ dp, float* __restrict__ d_ea,
+                                                        int attr_from, int attr_shift) {
     constexpr int LDA = H + 4, NT = 2 * H, HH = H / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* buf = smem;
@@ -371,7 +379,9 @@ __global__ __launch_bounds__(2 * H) void pair_bwd_kernel(tsd_edges e, const int3
     if (tid < T) {
         const bool v = tid < nrows;
         s_ds[tid] = v ? ds[e0 + tid] : 0.0f;
-        s_row[tid] = v ? attr_row[e0 + tid] : 0;
+        int row = v ? attr_row[e0 + tid] : 0;
+        if (row >= attr_from) row -= attr_shift;  // (as PairSave::attr_from / attr_shift of the forward)
+        s_row[tid] = row;
     }
     __syncthreads();
     {   // dg1 tile: every load of a thread in flight together (rows clamped)
@@ -429,7 +439,7 @@ __global__ __launch_bounds__(2 * H) void pair_bwd_kernel(tsd_edges e, const int3
 
 int launch_pair_bwd(int H, int rows, tsd_edges e, const int32_t* attr_row, const float* ds, const float* w2,
                     const float* g1, const float* g0, const float* W1t, const float* W0t, float* dg1, float* dg0,
-                    float* dp, float* d_ea, hipStream_t st) {
+                    float* dp, float* d_ea, int attr_from, int attr_shift, hipStream_t st) {
     if (rows == 0) return TSD_OK;
     const size_t lds = (size_t)(T * (H + 4) + T) * 4 + T * sizeof(int);
     if (H != 256) {
@@ -440,7 +450,7 @@ int launch_pair_bwd(int H, int rows, tsd_edges e, const int32_t* attr_row, const
     int r = allow_lds(pair_bwd_kernel<256>, lds, once);
     if (r) return r;
     hipLaunchKernelGGL(pair_bwd_kernel<256>, dim3((rows + T - 1) / T), dim3(512), lds, st, e, attr_row, ds, w2, g1, g0,
-                       W1t, W0t, dg1, dg0, dp, d_ea);
+                       W1t, W0t, dg1, dg0, dp, d_ea, attr_from, attr_shift);
     TSD_LAUNCH_CHECK("pair_bwd");
     return TSD_OK;
 }
@@ -781,7 +791,11 @@ __global__ __launch_bounds__(2 * H) void pair_output_kernel(PairW w, tsd_edges e
         const bool v = tid < nrows;
         s_src[tid] = v ? e.src[e0 + tid] : 0;
         s_dst[tid] = v ? e.dst[e0 + tid] : 0;
-        s_row[tid] = v ? (attr_row ? attr_row[e0 + tid] : e0 + tid) : 0;
+        int row = v ? (attr_row ? attr_row[e0 + tid] : e0 + tid) : 0;
+        if constexpr (SAVE) {
+            if (row >= sv.attr_from) row -= sv.attr_shift;
+        }
+        s_row[tid] = row;
     }
     __syncthreads();
     // the precomputed first-layer half of this lane's outputs is requested first: it arrives under the staging below

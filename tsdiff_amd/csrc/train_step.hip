@@ -83,7 +83,8 @@ struct Work {
     float *featR, *featP;          // [N,F] fp32 one-hot features
     float* h;                      // [(L+1), N, H]
     float *x1, *agg, *x2, *xs;     // [L, N, H] each
-    EmbedSave emb;                 // [2 PU, .]: rows [0, Eu) enc_u edges, rows [PU, PU + Ed) separately embedded out edges
+    EmbedSave emb;                 // [2 PU, .]: rows [0, Eu) enc_u edges, rows [Eu, Eu + Ed) separately embedded out edges
+                                   // (ONE row range: every weight gradient of the embedding is one problem of Eu + Ed rows)
     float* ea;                     // [2 PU, H] edge attributes, same rows (condensenc.py:156-176, edge.py:58-68)
     float *f0, *fs, *Wf;           // [L, PU, H] each
     float *hp, *g0, *gs0, *g1, *gs1, *s_u;  // pair MLP
@@ -121,6 +122,9 @@ Work carve(const tsd_model_cfg& c, int N, size_t PU, float* base) {
     w.emb.c = take(2 * PU * 2 * H);
     w.emb.c0 = take(2 * PU * H);
     w.emb.s1 = take(2 * PU * H);
+    w.emb.d = take(2 * PU);
+    w.emb.tr = reinterpret_cast<uint8_t*>(take((2 * PU + 3) / 4));
+    w.emb.tp = reinterpret_cast<uint8_t*>(take((2 * PU + 3) / 4));
     w.ea = take(2 * PU * H);
     w.f0 = take(L * PU * H);
     w.fs = take(L * PU * H);
@@ -295,13 +299,16 @@ __global__ void copy2d_kernel(int64_t rows, int cols, const float* __restrict__ 
 }
 // dst[row[r]] = src[r] for rows with distinct targets (the out edges' share of the edge-attribute gradient:
 // every out_u edge owns one row of the attribute matrix, geo.attr_row)
+// (targets >= from lie `shift` rows lower: PairSave::attr_from / attr_shift)
 __global__ void scatter_rows_kernel(int64_t rows, int cols, const float* __restrict__ src, int lds_,
-                                    const int32_t* __restrict__ row, float* __restrict__ dst) {
+                                    const int32_t* __restrict__ row, int from, int shift, float* __restrict__ dst) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= rows * cols) return;
     const int64_t r = t / cols;
     const int c = (int)(t % cols);
-    dst[(size_t)row[r] * cols + c] = src[r * lds_ + c];
+    int target = row[r];
+    if (target >= from) target -= shift;
+    dst[(size_t)target * cols + c] = src[r * lds_ + c];
 }
 // d_target[u] = (|pos0_i - pos0_j| - d_u) / sqrt(1 - a) * sqrt(a), a = alpha of the pair's graph   condensenc.py:309-318
 __global__ void d_target_kernel(tsd_edges eu, const float* __restrict__ pos0, const int32_t* __restrict__ node_graph,
@@ -313,6 +320,82 @@ __global__ void d_target_kernel(tsd_edges eu, const float* __restrict__ pos0, co
     const float d_gt = sqrtf(dx * dx + dy * dy + dz * dz);
     const float a = a_graph[node_graph[i]];
     out[u] = (d_gt - eu.dist[u]) / sqrtf(1.0f - a) * sqrtf(a);
+}
+// The loss head of the forward in ONE launch (d_target, both eq_transforms and the squared difference; thread = node):
+//   d_target_e = (|pos0_i - pos0_j| - d_e) / sqrt(1 - a) * sqrt(a)                          condensenc.py:309-318
+//   node_eq = eq_transform(s), pos_target = eq_transform(d_target)                          geometry.py:22-30
+//   loss_i = |node_eq_i - pos_target_i|^2                                                   condensenc.py:326-328
+// (a directed edge and its reverse give the same d_target: both distances are sums of the same squares)
+__global__ void loss_head_kernel(int N, tsd_edges ed, const float* __restrict__ pos, const float* __restrict__ pos0,
+                                 const int32_t* __restrict__ node_graph, const float* __restrict__ a_graph,
+                                 const float* __restrict__ s, float* __restrict__ node_eq,
+                                 float* __restrict__ pos_target, float* __restrict__ loss) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float a = a_graph[node_graph[i]];
+    const float ca = sqrtf(1.0f - a), sa = sqrtf(a);
+    const float px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
+    const float qx = pos0[3 * i], qy = pos0[3 * i + 1], qz = pos0[3 * i + 2];
+    float ax = 0.f, ay = 0.f, az = 0.f, tx = 0.f, ty = 0.f, tz = 0.f;
+    const int e1 = ed.row_ptr[i + 1];
+    for (int e = ed.row_ptr[i]; e < e1; ++e) {
+        const int j = ed.dst[e];
+        const float d = ed.dist[e];
+        const float dx = px - pos[3 * j], dy = py - pos[3 * j + 1], dz = pz - pos[3 * j + 2];
+        const float gx = qx - pos0[3 * j], gy = qy - pos0[3 * j + 1], gz = qz - pos0[3 * j + 2];
+        const float d_gt = sqrtf(gx * gx + gy * gy + gz * gz);
+        const float w = s[ed.umap[e]] / d, wt = ((d_gt - d) / ca * sa) / d;
+        ax += dx * w;
+        ay += dy * w;
+        az += dz * w;
+        tx += dx * wt;
+        ty += dy * wt;
+        tz += dz * wt;
+    }
+    const float ex = ax + ax, ey = ay + ay, ez = az + az, ux = tx + tx, uy = ty + ty, uz = tz + tz;
+    node_eq[3 * i] = ex; node_eq[3 * i + 1] = ey; node_eq[3 * i + 2] = ez;
+    pos_target[3 * i] = ux; pos_target[3 * i + 1] = uy; pos_target[3 * i + 2] = uz;
+    const float l0 = ex - ux, l1 = ey - uy, l2 = ez - uz;
+    loss[i] = l0 * l0 + l1 * l1 + l2 * l2;
+}
+// The head of the backward in ONE launch: workgroups [0, edge_blocks) take the loss gradient to the undirected pair
+// scores -- g_i = 2 (node_eq_i - pos_target_i) dloss_i, ds[u] = 2 ((pos_i - pos_j) / d_u) . (g_i - g_j) -- and the
+// remaining workgroups zero the gradient accumulators of the step (the flat parameter gradient, the attribute
+// gradient, dh when no pair writes it): six launches of the primitive form (two kernels, four memsets).
+struct ZeroRange {
+    float* p;
+    size_t n;
+};
+__global__ __launch_bounds__(256) void bwd_head_kernel(tsd_edges eu, int edge_blocks, const float* __restrict__ pos,
+                                                       const float* __restrict__ eq, const float* __restrict__ tg,
+                                                       const float* __restrict__ dloss, float* __restrict__ ds,
+                                                       ZeroRange z0, ZeroRange z1, ZeroRange z2) {
+    if ((int)blockIdx.x < edge_blocks) {
+        const int u = blockIdx.x * blockDim.x + threadIdx.x;
+        if (u >= *eu.count) return;
+        const int i = eu.src[u], j = eu.dst[u];
+        const float inv = 2.0f / eu.dist[u];
+        const float li = dloss[i], lj = dloss[j];
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float gi = 2.0f * (eq[3 * i + k] - tg[3 * i + k]) * li, gj = 2.0f * (eq[3 * j + k] - tg[3 * j + k]) * lj;
+            acc += (pos[3 * i + k] - pos[3 * j + k]) * (gi - gj);
+        }
+        ds[u] = inv * acc;
+        return;
+    }
+    const size_t gt = (size_t)((int)blockIdx.x - edge_blocks) * blockDim.x + threadIdx.x;
+    const size_t gs = (size_t)((int)gridDim.x - edge_blocks) * blockDim.x;
+    const ZeroRange z[3] = {z0, z1, z2};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const size_t n4 = z[r].n / 4;
+        f32x4* p4 = reinterpret_cast<f32x4*>(z[r].p);
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        for (size_t k = gt; k < n4; k += gs) p4[k] = zero;
+        for (size_t k = n4 * 4 + gt; k < z[r].n; k += gs) z[r].p[k] = 0.0f;
+    }
 }
 __global__ void loss_fwd_kernel(int N, const float* __restrict__ eq, const float* __restrict__ tg,
                                 float* __restrict__ loss) {
@@ -493,28 +576,26 @@ int embed_bwd(const Ctx& x, const tsd_edges& lst, int E, const EmbedSave& s, con
 // MFMA sizes: the dgrad chain of BOTH lists in one tile-kernel launch (launch_embed_bwd), then the weight / table
 // gradients per list from the dY it wrote.  d_ea: [2 PU, H], rows as the edge-attribute matrix.
 int embed_bwd_fused(const Ctx& x, const tsd_geometry& g, const float* d_ea) {
-    const int H = x.H, PU = x.PU;
+    const int H = x.H;
     const Work& w = x.w;
-    const size_t o1 = (size_t)PU * H, o2 = (size_t)PU * 2 * H;
+    const size_t o1 = (size_t)x.Eu * H, o2 = (size_t)x.Eu * 2 * H;  // first row of the second list
     const EmbedBwdList la{g.enc_u, d_ea, w.emb.c0, w.emb.l0, w.e_dc0, w.e_dc, w.e_de, w.e_dl0};
     const EmbedBwdList lb{g.diff_u, d_ea + o1, w.emb.c0 + o1, w.emb.l0 + o1, w.e_dc0 + o1, w.e_dc + o2, w.e_de + o1, w.e_dl0 + o1};
     TSD_TRY(launch_embed_bwd(H, x.Eu, la, x.Ed, lb, x.raw + x.R.bond_emb, w.pack_t + x.R.ecat_w1, w.pack_t + x.R.ecat_w0,
                              w.pack_t + x.R.emlp_w1, x.st));
-    for (int k = 0; k < 2; ++k) {
-        const int E = k ? x.Ed : x.Eu;
-        if (E == 0) continue;
-        const tsd_edges& lst = k ? g.diff_u : g.enc_u;
-        const size_t r1 = k ? o1 : 0, r2 = k ? o2 : 0;
-        // weight gradients only (dX == NULL): X, dY per layer
-        TSD_TRY(x.lin_bwd(E, H, H, w.emb.s1 + r1, x.R.ecat_w1, (long)x.R.ecat_b1, d_ea + r1, nullptr, false));
-        TSD_TRY(x.lin_bwd(E, 2 * H, H, w.emb.c + r2, x.R.ecat_w0, (long)x.R.ecat_b0, w.e_dc0 + r1, nullptr, false));
+    // weight gradients only (dX == NULL): X, dY per layer, the rows of BOTH lists as one problem (they are contiguous:
+    // the forward saved the second list's rows, distances and types right behind the first's)
+    const int E = x.Eu + x.Ed;
+    if (E > 0) {
+        TSD_TRY(x.lin_bwd(E, H, H, w.emb.s1, x.R.ecat_w1, (long)x.R.ecat_b1, d_ea, nullptr, false));
+        TSD_TRY(x.lin_bwd(E, 2 * H, H, w.emb.c, x.R.ecat_w0, (long)x.R.ecat_b0, w.e_dc0, nullptr, false));
         const int chunks = emb_chunks(E);
         hipLaunchKernelGGL(emb_mul2_bwd_kernel, dim3((H + 63) / 64, chunks), dim3(256), 0, x.st, E, H,
-                           (E + chunks - 1) / chunks, w.emb.e + r1, x.raw + x.R.bond_emb, lst.type_r, lst.type_p,
-                           w.e_dc + r2, (float*)nullptr, w.scratch);
+                           (E + chunks - 1) / chunks, w.emb.e, x.raw + x.R.bond_emb, w.emb.tr, w.emb.tp, w.e_dc,
+                           (float*)nullptr, w.scratch);
         TSD_TRY(launch_split_reduce((int64_t)ET * H, chunks, w.scratch, x.grad + x.R.bond_emb, 1, x.st));  // rows [0, ET) of the [100, H] table
-        TSD_TRY(x.lin_bwd(E, H, H, w.emb.s0 + r1, x.R.emlp_w1, (long)x.R.emlp_b1, w.e_de + r1, nullptr, false));
-        TSD_TRY(x.lin_bwd(E, 1, H, lst.dist, x.R.emlp_w0, (long)x.R.emlp_b0, w.e_dl0 + r1, nullptr, false));
+        TSD_TRY(x.lin_bwd(E, H, H, w.emb.s0, x.R.emlp_w1, (long)x.R.emlp_b1, w.e_de, nullptr, false));
+        TSD_TRY(x.lin_bwd(E, 1, H, w.emb.d, x.R.emlp_w0, (long)x.R.emlp_b0, w.e_dl0, nullptr, false));
     }
     TSD_LAUNCH_CHECK("embed_bwd_fused");
     return TSD_OK;
@@ -624,8 +705,11 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
                        raw + x.R.atom_emb, raw + x.R.atom_feat, atom_type, w.featR, w.featP, w.h);
     TSD_LAUNCH_CHECK("node_embed_raw");
     const size_t NH = (size_t)N * H, CH = (size_t)PU * H;  // strides of the per-block node / edge arrays
+    (void)F;
     // edge attributes of every undirected pair once: the enc_u rows, then the out edges that differ (geo.attr_row)
-    TSD_TRY(launch_edge_embed2(*cfg, W, Eu, g.enc_u, w.ea, Ed, g.diff_u, w.ea + CH, 1, 0, st, nullptr, &w.emb, PU));
+    // (rows [0, Eu) and [Eu, Eu + Ed) of the attribute matrix and of every saved activation: geo.attr_row numbers the
+    // second range from PU on, the pair kernels shift it down by PU - Eu)
+    TSD_TRY(launch_edge_embed2(*cfg, W, Eu, g.enc_u, w.ea, Ed, g.diff_u, w.ea + (size_t)Eu * H, 1, 0, st, nullptr, &w.emb, Eu));
     // one launch per interaction block: node chain of block l || filter GEMMs of block l+1   schnet.py:88-128, 223-224
     const int tpl = filter_tiles_per_layer(PU);
     const FilterSave fsv{w.f0, w.fs};
@@ -640,16 +724,15 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
     }
     // pair MLP on [h_i * h_j , edge_attr_out]                                       common.py:226-229
     if (Eo > 0) {
-        const PairSave psv{w.hp, w.g0, w.gs0, w.g1, w.gs1};
+        PairSave psv{w.hp, w.g0, w.gs0, w.g1, w.gs1};
+        psv.attr_from = PU;
+        psv.attr_shift = PU - Eu;
         TSD_TRY(launch_pair_output(*cfg, W, Eo, g.out_u, w.h + (size_t)L * NH, w.ea, g.attr_row, w.s_u, 1, 0, 0, 0, st,
                                    nullptr, 0, &psv));
-        hipLaunchKernelGGL(d_target_kernel, dim3(nblk(Eo)), dim3(256), 0, st, g.out_u, pos0, batch->node_graph, a_graph,
-                           w.d_target);
     }
     // loss                                                                      condensenc.py:303-328
-    TSD_TRY(tsd_eq_und_fwd(N, g.out, pos, w.s_u, w.node_eq, stream));
-    TSD_TRY(tsd_eq_und_fwd(N, g.out, pos, w.d_target, w.pos_target, stream));
-    hipLaunchKernelGGL(loss_fwd_kernel, dim3(nblk(N)), dim3(256), 0, st, N, w.node_eq, w.pos_target, loss);
+    hipLaunchKernelGGL(loss_head_kernel, dim3((N + 63) / 64), dim3(64), 0, st, N, g.out, pos, pos0, batch->node_graph,
+                       a_graph, w.s_u, w.node_eq, w.pos_target, loss);
     TSD_LAUNCH_CHECK("train_forward");
     return TSD_OK;
 }
@@ -666,26 +749,31 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
     const tsd_geometry& g = batch->geo;
     const int N = x.N, H = x.H, L = x.L, F = x.F, PU = x.PU, Eu = x.Eu, Eo = x.Eo, Ed = x.Ed;
     const Work& w = x.w;
-    TSD_HIP(hipMemsetAsync(grad, 0, x.R.total * sizeof(float), st));
-    if (N == 0) return TSD_OK;
+    if (N == 0) {
+        TSD_HIP(hipMemsetAsync(grad, 0, x.R.total * sizeof(float), st));
+        return TSD_OK;
+    }
     const size_t NH = (size_t)N * H, EH = (size_t)PU * H;  // strides of the per-block node / edge arrays
-    // loss -> node_eq -> s_u
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3(nblk(3 * (int64_t)N)), dim3(256), 0, st, N, w.node_eq, w.pos_target, dloss,
-                       w.nA);
-    TSD_HIP(hipMemsetAsync(w.dh, 0, NH * sizeof(float), st));
-    // attribute gradient of every embedded pair: rows [0, Eu) enc_u edges, rows [PU, PU + Ed) the out edges' own
-    if (Eu > 0) TSD_HIP(hipMemsetAsync(w.d_ea, 0, (size_t)Eu * H * sizeof(float), st));
-    if (Ed > 0) TSD_HIP(hipMemsetAsync(w.d_ea + EH, 0, (size_t)Ed * H * sizeof(float), st));
+    float* ds = w.d_target;  // [Eo]
+    {
+        // loss -> node_eq -> s_u, and the zero fill of the accumulators: the flat gradient (every weight gradient
+        // accumulates), the attribute gradient of every embedded pair (rows [0, Eu) enc_u edges, rows [Eu, Eu + Ed)
+        // the out edges' own), dh when there is no pair to write it
+        const int edge_blocks = (int)nblk(Eo);
+        const ZeroRange z0{grad, x.R.total}, z1{w.d_ea, (size_t)(Eu + Ed) * H}, z2{w.dh, Eo > 0 ? (size_t)0 : NH};
+        const size_t zfloats = z0.n + z1.n + z2.n;
+        const int zero_blocks = (int)std::min<size_t>(2048, (zfloats / 4 + 255) / 256 + 1);
+        hipLaunchKernelGGL(bwd_head_kernel, dim3(edge_blocks + zero_blocks), dim3(256), 0, st, g.out_u, edge_blocks, pos,
+                           w.node_eq, w.pos_target, dloss, ds, z0, z1, z2);
+    }
     if (Eo > 0) {
-        float* ds = w.d_target;  // [Eo] (d_target itself is no longer needed)
-        TSD_TRY(tsd_eq_und_bwd(Eo, g.out_u, pos, w.nA, ds, stream));
         float* dp = w.eA;  // [Eo,H]
         if (H == 256) {
             // the three dgrads, the split of dhp and the scatter of its right half as ONE tile kernel; the weight
             // gradients from the dY it wrote
             float *dg1 = w.eA + (size_t)PU * H, *dg0 = w.eB;  // [Eo,H/2] behind dp, [Eo,H]
             TSD_TRY(launch_pair_bwd(H, Eo, g.out_u, g.attr_row, ds, raw + x.R.out_w2, w.g1, w.g0, w.pack_t + x.R.out_w1,
-                                    w.pack_t + x.R.out_w0, dg1, dg0, dp, w.d_ea, st));
+                                    w.pack_t + x.R.out_w0, dg1, dg0, dp, w.d_ea, PU, PU - Eu, st));
             TSD_TRY(x.lin_bwd(Eo, H / 2, 1, w.gs1, x.R.out_w2, (long)x.R.out_b2, ds, nullptr, false));
             TSD_TRY(x.lin_bwd(Eo, H, H / 2, w.gs0, x.R.out_w1, (long)x.R.out_b1, dg1, nullptr, false));
             TSD_TRY(x.lin_bwd(Eo, 2 * H, H, w.hp, x.R.out_w0, (long)x.R.out_b0, dg0, nullptr, false));
@@ -696,7 +784,7 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
             // dp (left half) -> dh ; d edge_attr_out (right half) -> the out edges' rows of the attribute gradient
             hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.eB, 2 * H, dp, H);
             hipLaunchKernelGGL(scatter_rows_kernel, dim3(nblk((int64_t)Eo * H)), dim3(256), 0, st, (int64_t)Eo, H, w.eB + H,
-                               2 * H, g.attr_row, w.d_ea);
+                               2 * H, g.attr_row, PU, PU - Eu, w.d_ea);
         }
         TSD_TRY(launch_row_gather(H, N, g.out, dp, w.h + (size_t)L * NH, w.dh, st));  // dh_i = sum_e dp[umap e] * h[dst e]
     }
@@ -770,7 +858,7 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
         TSD_TRY(embed_bwd_fused(x, g, w.d_ea));
     } else {
         if (Eu > 0) TSD_TRY(embed_bwd(x, g.enc_u, Eu, w.emb, w.d_ea));
-        if (Ed > 0) TSD_TRY(embed_bwd(x, g.diff_u, Ed, embed_rows(w.emb, (size_t)PU, (size_t)H), w.d_ea + EH));
+        if (Ed > 0) TSD_TRY(embed_bwd(x, g.diff_u, Ed, embed_rows(w.emb, (size_t)Eu, (size_t)H), w.d_ea + (size_t)Eu * H));
     }
     // node embedding: dz = dh
     hipLaunchKernelGGL(node_embed_bwd_kernel, dim3(nblk((int64_t)N * (H / 2))), dim3(256), 0, st, N, H / 2, dz, w.nA,
