@@ -427,6 +427,14 @@ int tsd_gine_aggregate(int32_t num_nodes, int64_t num_edges, int32_t H, int32_t 
  * other host read) and must be
  * handed unchanged to tsd_train_backward, which turns dloss [N] = d(objective)/d(loss) into
  * grad [tsd_train_raw_floats], the gradient of every parameter in the layout of `raw`. */
+/* The forward diffusion of get_loss (condensenc.py:292-297) in one launch: a_graph[g] = alphas[time_step[g]],
+ * pos_perturbed[i] = pos[i] + noise[i] * sqrt(1 - a) / sqrt(a) with a = a_graph[node_graph[i]] -- the operations of
+ * the reference's expression in its order (eight elementwise / gather launches there).  time_step [G] and
+ * node_graph [N] are int64 as the reference holds them (indices outside their tables are clamped, not reported);
+ * the draws (time_step, noise) stay the caller's. */
+int tsd_diffuse_positions(int32_t num_nodes, int32_t num_graphs, int32_t num_timesteps, const float* alphas,
+                          const int64_t* time_step, const int64_t* node_graph, const float* pos, const float* noise,
+                          float* pos_perturbed /* [N,3] */, float* a_graph /* [G] */, void* stream);
 size_t tsd_train_raw_floats(const tsd_model_cfg* cfg);
 size_t tsd_train_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs);
 int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* raw, const int64_t* atom_type,

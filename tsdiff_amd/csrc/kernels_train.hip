@@ -9,6 +9,7 @@
 // All per-edge work runs on the UNDIRECTED lists (see tsd_geometry): a filter row Wf[u] / score s[u] is
 // used by both directed edges (i,j) and (j,i), so its gradient is the sum of both directions.
 #include <stdlib.h>
+#include <algorithm>
 
 #include "train_internal.hpp"
 
@@ -286,16 +287,18 @@ __device__ __forceinline__ void wgrad_reduce_body(int64_t nW, int nB, int S, con
                                                   const float* __restrict__ bias_part, float* __restrict__ dW,
                                                   float* __restrict__ db, int accumulate) {
     // Q = blockDim.x / 64 wave groups (4, or 16 for long split lists: the per-lane sum over S / Q partials is a
-    // latency chain); group q adds splits [q S/Q, (q+1) S/Q) in order, the groups are combined by a fixed pairwise tree
+    // latency chain); group q adds splits [q per, (q+1) per) in order (per = ceil(S / Q): the last groups of a split
+    // count that Q does not divide hold fewer, or none), the groups are combined by a fixed pairwise tree
     __shared__ float sm[16][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, Q = blockDim.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-    const int per = S / Q;
+    const int per = (S + Q - 1) / Q;
+    const int k0 = min(S, q * per), k1 = min(S, (q + 1) * per);
     float s = 0.0f;
     if (i < nW) {
-        for (int k = q * per; k < (q + 1) * per; ++k) s += part[(size_t)k * nW + i];
+        for (int k = k0; k < k1; ++k) s += part[(size_t)k * nW + i];
     } else if (i < nW + nB) {
-        for (int k = q * per; k < (q + 1) * per; ++k) s += bias_part[(size_t)k * nB + (i - nW)];
+        for (int k = k0; k < k1; ++k) s += bias_part[(size_t)k * nB + (i - nW)];
     }
     sm[q][lane] = s;
     __syncthreads();
@@ -315,7 +318,7 @@ __device__ __forceinline__ void wgrad_reduce_body(int64_t nW, int nB, int S, con
     }
 }
 // threads of a reduce launch: 16 wave groups when the split list is long
-static inline int reduce_threads(int S) { return (S >= 64 && S % 16 == 0) ? 1024 : 256; }
+static inline int reduce_threads(int S) { return S >= 64 ? 1024 : 256; }
 
 // wgrad of the narrow layers (Linear(1,H), Linear(25,H/2), Linear(H/2,1)): dW[o,i] = sum_r dY[r,o] X[r,i], in <= 32.
 // Same two-stage column reduction as the bias gradient with `in` accumulators per thread:
@@ -324,19 +327,22 @@ static inline int reduce_threads(int S) { return (S >= 64 && S % 16 == 0) ? 1024
 constexpr int WS_MAX_IN = 32;
 template <int MAXIN>  // 1 (the Linear(1,H) / Linear(H/2,1) layers: no wasted predicated lanes) or WS_MAX_IN
 __global__ __launch_bounds__(256) void wgrad_small_kernel(int rows, int in, int out, const float* __restrict__ dY,
-                                                          const float* __restrict__ X, float* __restrict__ part) {
+                                                          const float* __restrict__ X, float* __restrict__ part,
+                                                          float* __restrict__ bias_part /* [chunks][out] or NULL */) {
     __shared__ float sm[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int o = blockIdx.x * 64 + lane;
     const int per = (rows + (int)gridDim.y - 1) / (int)gridDim.y;  // gridDim.y row chunks
     const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
     float acc[MAXIN];
+    float bsum = 0.0f;  // the bias gradient (column sums of dY) rides along: the same rows are read anyway
 #pragma unroll
     for (int i = 0; i < MAXIN; ++i) acc[i] = 0.0f;
     if (o < out)
         for (int r = r0 + w; r < r1; r += 4) {
             const float g = dY[(size_t)r * out + o];
             const float* xr = X + (size_t)r * in;
+            bsum += g;
 #pragma unroll
             for (int i = 0; i < MAXIN; ++i)
                 if (i < in) acc[i] = fmaf(g, xr[i], acc[i]);
@@ -350,6 +356,13 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(int rows, int in, int 
             if (w == 0 && o < out)
                 part[((size_t)blockIdx.y * out + o) * in + i] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
         }
+    }
+    if (bias_part) {  // uniform
+        __syncthreads();
+        sm[w][lane] = bsum;
+        __syncthreads();
+        if (w == 0 && o < out)
+            bias_part[(size_t)blockIdx.y * out + o] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
     }
 }
 
@@ -832,16 +845,21 @@ int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, c
             const int o2 = swap ? in : out, i2 = swap ? 1 : in;
             const int chunks = (rows >= 2048 && scratch_floats >= off_part + 256 * (size_t)out * in) ? 256 : 64;
             float* part = scratch + off_part;
+            // the bias gradient in the same two launches (not in the swapped form: its "dY" is X)
+            float* bpart = nullptr;
+            if (db && !swap && scratch_floats >= off_part + (size_t)chunks * out * (in + 1)) bpart = part + (size_t)chunks * out * in;
             if (i2 == 1)
                 hipLaunchKernelGGL(wgrad_small_kernel<1>, dim3((o2 + 63) / 64, chunks), dim3(256), 0, st, rows, i2, o2,
-                                   swap ? X : dY, swap ? dY : X, part);
+                                   swap ? X : dY, swap ? dY : X, part, bpart);
             else
                 hipLaunchKernelGGL(wgrad_small_kernel<WS_MAX_IN>, dim3((o2 + 63) / 64, chunks), dim3(256), 0, st, rows,
-                                   i2, o2, swap ? X : dY, swap ? dY : X, part);
+                                   i2, o2, swap ? X : dY, swap ? dY : X, part, bpart);
             const int64_t n = (int64_t)o2 * i2;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(reduce_threads(chunks)), 0, st, n, 0, chunks, part,
-                               (const float*)nullptr, dW, (float*)nullptr, accW);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + (bpart ? out : 0) + 63) / 64)),
+                               dim3(reduce_threads(chunks)), 0, st, n, bpart ? out : 0, chunks, part, bpart, dW,
+                               bpart ? db : (float*)nullptr, accW);
             TSD_LAUNCH_CHECK("wgrad_small");
+            db_done = bpart != nullptr;
         } else {
             hipLaunchKernelGGL(wgrad_naive_kernel, dim3(out * in), dim3(256), 0, st, rows, in, out, dY, X, dW, accW);
             TSD_LAUNCH_CHECK("wgrad_naive");
@@ -869,20 +887,37 @@ int launch_split_reduce(int64_t n, int S, const float* part, float* dst, int acc
 }
 
 // dW_k (+)= dY_k^T X_k (and db_k (+)= column sums of dY_k where db_k != NULL) for n equally shaped problems in two
-// launches; `part` holds n * S * (out * in + out) floats, S = wgrad_batch_splits(rows).
-int wgrad_batch_splits(int rows) { return rows >= 16384 ? 16 : 8; }
+// launches; `part` holds wgrad_batch_scratch_floats(n, rows, in, out) floats.
+// Row splits S of a launch of m problems with `blocks` 128 x 128 output blocks each: the m * blocks * S workgroups
+// (8 waves, 71 VGPRs: up to three per CU) are all resident at once and a CU's time is its workgroup count, so S is
+// taken to fill a whole number k >= 2 of workgroups on each of the 256 CUs from below (14 filter problems: S = 9 ->
+// 504 workgroups, two per CU on 252 CUs, where S = 8 left a quarter of the CUs with one and 16 with 3.5 on average;
+// 21 node-level problems: S = 6 -> 504, where 8 gave 672 = 2.6 per CU, i.e. three).
+int wgrad_batch_splits(int m, int blocks, int rows) {
+    const int unit = m * blocks;
+    const int cap = std::max(1, std::min(64, rows / 64));
+    for (int k = 2; k <= 16; ++k) {
+        const int S = 256 * k / unit;
+        if (S >= 4) return std::min(S, cap);
+    }
+    return std::min(4, cap);
+}
 size_t wgrad_batch_scratch_floats(int n, int rows, int in, int out) {
-    return (size_t)n * wgrad_batch_splits(rows) * ((size_t)out * in + out);
+    const int blocks = (in / 128) * (out / 128);
+    size_t worst = 0;
+    for (int m = 1; m <= std::min(n, WG_BATCH_MAX); ++m)  // (a launch holds at most WG_BATCH_MAX problems)
+        worst = std::max(worst, (size_t)m * wgrad_batch_splits(m, blocks, rows));
+    return worst * ((size_t)out * in + out);
 }
 int launch_wgrad_batch(int n, int rows, int in, int out, const float* const* dY, const float* const* X, float* const* dW,
                        float* const* db, int accumulate, float* part, hipStream_t st) {
     if (n == 0) return TSD_OK;
     TSD_REQUIRE(out % 128 == 0 && in % 128 == 0 && rows > 0, "wgrad batch: shape %d x %d, %d rows", out, in, rows);
-    const int S = wgrad_batch_splits(rows);
-    const int per = ((rows + S - 1) / S + WG_T - 1) / WG_T * WG_T;
     const int64_t nW = (int64_t)out * in;
     for (int base = 0; base < n; base += WG_BATCH_MAX) {
         const int m = n - base < WG_BATCH_MAX ? n - base : WG_BATCH_MAX;
+        const int S = wgrad_batch_splits(m, (in / 128) * (out / 128), rows);
+        const int per = ((rows + S - 1) / S + WG_T - 1) / WG_T * WG_T;
         WgradBatch b;
         WgradOutBatch o;
         for (int k = 0; k < m; ++k) {
@@ -892,8 +927,8 @@ int launch_wgrad_batch(int n, int rows, int in, int out, const float* const* dY,
         float* bpart = part + (size_t)m * S * nW;
         hipLaunchKernelGGL(wgrad_batch_kernel, dim3(in / 128, out / 128, m * S), dim3(WG_NT), 0, st, rows, in, out, per,
                            S, b, part, bpart);
-        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)((nW + out + 63) / 64), m), dim3(256), 0, st, nW,
-                           out, S, part, bpart, o, accumulate);
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)((nW + out + 63) / 64), m), dim3(reduce_threads(S)),
+                           0, st, nW, out, S, part, bpart, o, accumulate);
     }
     TSD_LAUNCH_CHECK("wgrad_batch");
     return TSD_OK;

@@ -66,7 +66,7 @@ int launch_block_bwd(int H, int N, int first, int last, tsd_edges enc, const flo
                      tsd_edges enc_u, const float* x1, const float* f0, const float* W2t, const float* W0t, float cutoff,
                      int smooth, float* dWf, float* df0, float* d_ea, hipStream_t st);
 int launch_split_reduce(int64_t n, int S, const float* part, float* dst, int accumulate, hipStream_t st);
-int wgrad_batch_splits(int rows);
+int wgrad_batch_splits(int m, int blocks, int rows);
 size_t wgrad_batch_scratch_floats(int n, int rows, int in, int out);
 int launch_wgrad_batch(int n, int rows, int in, int out, const float* const* dY, const float* const* X, float* const* dW,
                        float* const* db, int accumulate, float* part, hipStream_t st);

@@ -19,6 +19,7 @@
 
 #include <vector>
 
+#include <algorithm>
 #include "train_internal.hpp"
 
 namespace tsd {
@@ -109,8 +110,8 @@ Work carve(const tsd_model_cfg& c, int N, size_t PU, float* base) {
     const size_t H = c.hidden, L = c.num_convs, F = c.feat_dim;
     size_t o = 0;
     auto take = [&](size_t n) { float* r = base ? base + o : nullptr; o += (n + 63) & ~size_t(63); return r; };
-    w.featR = take((size_t)N * F);
-    w.featP = take((size_t)N * F);
+    w.featR = take(2 * (size_t)N * F);  // [2 N, F]: reactant rows, then product rows (one weight-gradient problem)
+    w.featP = base ? w.featR + (size_t)N * F : nullptr;
     w.h = take((L + 1) * N * H);
     w.x1 = take(L * N * H);
     w.agg = take(L * N * H);
@@ -155,12 +156,13 @@ Work carve(const tsd_model_cfg& c, int N, size_t PU, float* base) {
     w.dx2s = take(L * N * H);
     w.dx1s = take(L * N * H);
     {
-        size_t a = 0, b = 0;
+        size_t a = 0, b = 0, e2 = 0;
         if (N > 0 && H % 128 == 0) {
             a = wgrad_batch_scratch_floats((int)(3 * L), N, (int)H, (int)H);
             b = PU > 0 ? wgrad_batch_scratch_floats((int)(2 * L), (int)PU, (int)H, (int)H) : 0;
+            e2 = PU > 0 ? wgrad_batch_scratch_floats(2, (int)(2 * PU), (int)H, (int)H) : 0;  // the embedding's two H x H layers
         }
-        w.wpart = take(a > b ? a : b);
+        w.wpart = take(std::max(a, std::max(b, e2)));
     }
     w.dWfs = take(H % 128 == 0 ? L * PU * H : 0);
     w.df0s = take(H % 128 == 0 ? L * PU * H : 0);
@@ -397,6 +399,19 @@ __global__ __launch_bounds__(256) void bwd_head_kernel(tsd_edges eu, int edge_bl
         for (size_t k = n4 * 4 + gt; k < z[r].n; k += gs) z[r].p[k] = 0.0f;
     }
 }
+// get_loss's forward diffusion (condensenc.py:292-297): thread = atom; the first G threads also write a_graph
+__global__ void diffuse_kernel(int N, int G, int T, const float* __restrict__ alphas, const int64_t* __restrict__ time_step,
+                               const int64_t* __restrict__ node_graph, const float* __restrict__ pos,
+                               const float* __restrict__ noise, float* __restrict__ out, float* __restrict__ a_graph) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < G) a_graph[i] = alphas[min(max(time_step[i], (int64_t)0), (int64_t)T - 1)];
+    if (i >= N) return;
+    const int64_t g = min(max(node_graph[i], (int64_t)0), (int64_t)G - 1);
+    const float a = alphas[min(max(time_step[g], (int64_t)0), (int64_t)T - 1)];
+    const float s1 = sqrtf(1.0f - a), s2 = sqrtf(a);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[3 * i + k] = pos[3 * i + k] + (noise[3 * i + k] * s1) / s2;
+}
 __global__ void loss_fwd_kernel(int N, const float* __restrict__ eq, const float* __restrict__ tg,
                                 float* __restrict__ loss) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -587,14 +602,19 @@ int embed_bwd_fused(const Ctx& x, const tsd_geometry& g, const float* d_ea) {
     // the forward saved the second list's rows, distances and types right behind the first's)
     const int E = x.Eu + x.Ed;
     if (E > 0) {
-        TSD_TRY(x.lin_bwd(E, H, H, w.emb.s1, x.R.ecat_w1, (long)x.R.ecat_b1, d_ea, nullptr, false));
+        {   // the two H x H layers (edge_cat.2, the distance MLP's second layer) share a launch
+            const float* dYs[2] = {d_ea, w.e_de};
+            const float* Xs[2] = {w.emb.s1, w.emb.s0};
+            float* dWs[2] = {x.grad + x.R.ecat_w1, x.grad + x.R.emlp_w1};
+            float* dbs[2] = {x.grad + x.R.ecat_b1, x.grad + x.R.emlp_b1};
+            TSD_TRY(launch_wgrad_batch(2, E, H, H, dYs, Xs, dWs, dbs, 1, w.wpart, x.st));
+        }
         TSD_TRY(x.lin_bwd(E, 2 * H, H, w.emb.c, x.R.ecat_w0, (long)x.R.ecat_b0, w.e_dc0, nullptr, false));
         const int chunks = emb_chunks(E);
         hipLaunchKernelGGL(emb_mul2_bwd_kernel, dim3((H + 63) / 64, chunks), dim3(256), 0, x.st, E, H,
                            (E + chunks - 1) / chunks, w.emb.e, x.raw + x.R.bond_emb, w.emb.tr, w.emb.tp, w.e_dc,
                            (float*)nullptr, w.scratch);
         TSD_TRY(launch_split_reduce((int64_t)ET * H, chunks, w.scratch, x.grad + x.R.bond_emb, 1, x.st));  // rows [0, ET) of the [100, H] table
-        TSD_TRY(x.lin_bwd(E, H, H, w.emb.s0, x.R.emlp_w1, (long)x.R.emlp_b1, w.e_de, nullptr, false));
         TSD_TRY(x.lin_bwd(E, 1, H, w.emb.d, x.R.emlp_w0, (long)x.R.emlp_b0, w.e_dl0, nullptr, false));
     }
     TSD_LAUNCH_CHECK("embed_bwd_fused");
@@ -669,6 +689,20 @@ int tsd_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, fl
     return TSD_OK;
 }
 
+int tsd_diffuse_positions(int32_t num_nodes, int32_t num_graphs, int32_t num_timesteps, const float* alphas,
+                          const int64_t* time_step, const int64_t* node_graph, const float* pos, const float* noise,
+                          float* pos_perturbed, float* a_graph, void* stream) {
+    TSD_REQUIRE(num_nodes >= 0 && num_graphs >= 0 && num_timesteps > 0, "bad sizes");
+    const int n = num_nodes > num_graphs ? num_nodes : num_graphs;
+    if (n == 0) return TSD_OK;
+    TSD_REQUIRE(alphas && time_step && a_graph && (num_nodes == 0 || (node_graph && pos && noise && pos_perturbed)),
+                "null pointer");
+    hipLaunchKernelGGL(diffuse_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, num_nodes, num_graphs,
+                       num_timesteps, alphas, time_step, node_graph, pos, noise, pos_perturbed, a_graph);
+    TSD_LAUNCH_CHECK("diffuse_positions");
+    return TSD_OK;
+}
+
 int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* raw, const int64_t* atom_type,
                       const int64_t* r_feat, const int64_t* p_feat, const float* pos0, const float* pos,
                       const float* a_graph, const int32_t* topo_status, float* workspace, size_t workspace_floats,
@@ -680,13 +714,18 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
     const tsd_geometry& g = batch->geo;
     TSD_TRY(launch_geometry(*cfg, batch->num_nodes, batch->num_graphs, batch->num_pairs, pos, batch->graph_ptr,
                             batch->node_graph, batch->pair_ptr, batch->pair_code, g, st));
-    // the edge counts size the launches of the backward pass: the one host sync of the step
-    TSD_HIP(hipMemcpyAsync(&counts_host[0], g.enc_u.count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    TSD_HIP(hipMemcpyAsync(&counts_host[1], g.out_u.count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    TSD_HIP(hipMemcpyAsync(&counts_host[3], g.diff_u.count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    counts_host[2] = 0;
-    if (topo_status) TSD_HIP(hipMemcpyAsync(&counts_host[2], topo_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    // the edge counts size the launches of the backward pass: the one host sync of the step.  They land in a pinned
+    // staging block (a device-to-host copy into pageable memory is a blocking staged copy each: four of them cost
+    // ~80 us of idle GPU per step)
+    static thread_local int32_t* pinned = nullptr;
+    if (!pinned) TSD_HIP(hipHostMalloc(reinterpret_cast<void**>(&pinned), 4 * sizeof(int32_t), hipHostMallocDefault));
+    pinned[2] = 0;
+    TSD_HIP(hipMemcpyAsync(&pinned[0], g.enc_u.count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TSD_HIP(hipMemcpyAsync(&pinned[1], g.out_u.count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    TSD_HIP(hipMemcpyAsync(&pinned[3], g.diff_u.count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (topo_status) TSD_HIP(hipMemcpyAsync(&pinned[2], topo_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     TSD_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < 4; ++k) counts_host[k] = pinned[k];
     if (counts_host[2] & (TSD_STATUS_BAD_BOND | TSD_STATUS_ASYMMETRIC)) return TSD_OK;  // the caller raises
     Ctx x;
     TSD_TRY(make_ctx(x, cfg, batch, raw, workspace, workspace_floats, counts_host, st));
@@ -861,15 +900,15 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
         if (Ed > 0) TSD_TRY(embed_bwd(x, g.diff_u, Ed, embed_rows(w.emb, (size_t)Eu, (size_t)H), w.d_ea + (size_t)Eu * H));
     }
     // node embedding: dz = dh
+    // (d(Wf r) rows then d(Wf p) rows in nA [2 N, H/2], against featR | featP [2 N, F]: atom_feat_embedding's weight
+    // gradient is one problem of 2 N rows)
     hipLaunchKernelGGL(node_embed_bwd_kernel, dim3(nblk((int64_t)N * (H / 2))), dim3(256), 0, st, N, H / 2, dz, w.nA,
-                       w.nB);
+                       w.nA + (size_t)N * (H / 2));
     hipLaunchKernelGGL(atom_emb_grad_kernel, dim3(100, AE_CHUNKS), dim3(H / 2 < 256 ? H / 2 : 256), 0, st, N, H / 2,
                        atom_type, dz, w.scratch);
     hipLaunchKernelGGL(atom_emb_grad_reduce_kernel, dim3(nblk(100 * (H / 2))), dim3(256), 0, st, 100 * (H / 2), w.scratch,
                        grad + x.R.atom_emb);
-    TSD_TRY(linear_bwd_impl(N, F, H / 2, w.featR, raw + x.R.atom_feat, nullptr, w.nA, nullptr, grad + x.R.atom_feat,
-                            nullptr, 2, LinEpi(), w.scratch, w.scratch_floats, st));
-    TSD_TRY(linear_bwd_impl(N, F, H / 2, w.featP, raw + x.R.atom_feat, nullptr, w.nB, nullptr, grad + x.R.atom_feat,
+    TSD_TRY(linear_bwd_impl(2 * N, F, H / 2, w.featR, raw + x.R.atom_feat, nullptr, w.nA, nullptr, grad + x.R.atom_feat,
                             nullptr, 2, LinEpi(), w.scratch, w.scratch_floats, st));
     TSD_LAUNCH_CHECK("train_backward");
     return TSD_OK;

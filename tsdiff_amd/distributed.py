@@ -79,10 +79,11 @@ def dp_backward(model, loss_nodes, group=None, reduce_fn=None):
     reduce = reduce_fn if reduce_fn is not None else (lambda t: _all_reduce_sum(t, group))
     # (new_full is a fill kernel: torch.tensor(x, device=cuda) would be a synchronous host-to-device copy, i.e.
     # a hidden stream sync between the forward and the backward pass)
-    stats = torch.stack([loss_nodes.detach().sum(), loss_nodes.new_full((), float(loss_nodes.shape[0]))])
+    total = loss_nodes.sum()
+    stats = torch.stack([total.detach(), loss_nodes.new_full((), float(loss_nodes.shape[0]))])
     if distributed:
         reduce(stats)
-    (loss_nodes.sum() / stats[1]).backward()
+    (total / stats[1]).backward()
     if distributed:
         params = [p for p in model.parameters() if p.requires_grad]
         flat = getattr(model, "_flat_grad", None)

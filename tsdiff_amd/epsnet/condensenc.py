@@ -203,12 +203,25 @@ class CondenseEncoderEpsNetwork(nn.Module):
             time_step = torch.cat([half_1, half_2], dim=0)[:num_graphs]
         else:
             time_step = _time_step
-        a = self.alphas.detach().index_select(0, time_step)
-        a_pos = a.index_select(0, node2graph).unsqueeze(-1)
         pos_noise = torch.randn(size=pos.size(), device=dev) if _pos_noise is None else _pos_noise
-        pos_perturbed = (pos + pos_noise * (1.0 - a_pos).sqrt() / a_pos.sqrt()).contiguous()
         training = torch.is_grad_enabled() and any(p.requires_grad for p in self.raw_params())
         fused = training and os.environ.get("TSDIFF_TRAIN", "fused") != "ops"
+        if fused and pos.is_cuda and pos.dtype == torch.float32 and pos_noise.dtype == torch.float32:
+            # the forward diffusion as one launch (tsd_diffuse_positions: the same operations in the same order)
+            from .. import _lib
+            from .._lib import check, ptr, stream_ptr
+            alphas = self.alphas.detach()
+            pos_c, noise_c = pos.detach().contiguous(), pos_noise.contiguous()
+            ts, n2g = time_step.to(torch.int64).contiguous(), node2graph.to(torch.int64).contiguous()
+            pos_perturbed = torch.empty_like(pos_c)
+            a = torch.empty(ts.shape[0], dtype=torch.float32, device=dev)
+            check(_lib.load().tsd_diffuse_positions(pos_c.shape[0], ts.shape[0], alphas.shape[0], ptr(alphas), ptr(ts),
+                                                    ptr(n2g), ptr(pos_c), ptr(noise_c), ptr(pos_perturbed), ptr(a),
+                                                    stream_ptr()))
+        else:
+            a = self.alphas.detach().index_select(0, time_step)
+            a_pos = a.index_select(0, node2graph).unsqueeze(-1)
+            pos_perturbed = (pos + pos_noise * (1.0 - a_pos).sqrt() / a_pos.sqrt()).contiguous()
         # (the fused step reads the topology status together with its edge counts: one host sync less per batch)
         db = self.device_batch(atom_type, r_feat, p_feat, bond_index, bond_type, batch, num_nodes_per_graph,
                                defer_status=fused)
