@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the c5 / ensemble8 / train sub-objects")
     ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="train workload only: the next batch's topology is built inside its get_loss (the default "
+                         "builds it on a side stream during the current step, model.prefetch_batch)")
     ap.add_argument("--reuse-batch", action="store_true",
                     help="train workload only: ONE batch for every step with its topology cached (A/B; the default "
                          "rotates 8 batches and rebuilds the topology every step like a real data loader)")
@@ -341,7 +344,7 @@ def pmc_traffic(name_prefix, fname):
 # ---------------------------------------------------------------------------------------------------
 # training step (BASELINE configs[3])
 # ---------------------------------------------------------------------------------------------------
-def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist):
+def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist, prefetch=True):
     """one training step of configs/train_config.yml per iteration: loss (get_loss), backward, RCCL gradient
     all-reduce, clip_grad_norm_, Adam.  Returns (seconds, last mean loss, atoms per batch, executed flops per step)."""
     from tsdiff_amd import synth
@@ -361,19 +364,31 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist):
     # configs/train_config.yml's optimizer block through the mirror of utils.common.get_optimizer (train.py:103)
     opt = optim.get_optimizer(SimpleNamespace(type="adam", lr=5e-4, weight_decay=0.0, beta1=0.95, beta2=0.999), model)
     counter = [0]
+    used = [None]
+
+    def topo_args(g):
+        return (g["atom_type"], g["r_feat"], g["p_feat"], g["bond_index"], g["bond_type"], g["batch"],
+                g["num_nodes_per_graph"])
 
     def step():
         g = batches[counter[0] % len(batches)]
         counter[0] += 1
-        if not reuse_batch:
-            model._batches.clear()
         opt.zero_grad()
         loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
                               g["batch"], g["num_nodes_per_graph"], graphs)
+        used[0] = model._batches[0][2]
         mean = dp_backward(model, loss)
         optim.clip_grad_norm_(model.parameters(), 3000.0)
         opt.step()
+        if not reuse_batch:
+            # the batch's cached topology is dropped: the next step's is built from scratch, either inside its get_loss
+            # or -- `prefetch` -- right here on a side stream while the GPU works on this step (a loader's prefetch)
+            model._batches.clear()
+            if prefetch:
+                model.prefetch_batch(*topo_args(batches[counter[0] % len(batches)]))
         return mean
+    if not reuse_batch:
+        model._batches.clear()
     for _ in range(warmup):
         step()
     sync_all(dist)
@@ -383,7 +398,7 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist):
     sync_all(dist)
     dt = time.perf_counter() - t0
     # executed arithmetic of a step ~ 3 x the forward's dense layers (forward, dgrad, wgrad) on the undirected lists
-    db = model._batches[0][2]
+    db = used[0]
     L = model._cfg.num_convs
     F = forward_work(model._cfg, db.enc.num_edges(), db.out.num_edges(), db.diff_u.num_edges(), db.N).flops_train_forward
     model.eval()
@@ -391,7 +406,8 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist):
 
 
 def bench_train_main(args, model, dev, rank, world, dist):
-    dt, last, N, flops = run_train(model, args.graphs, args.steps, args.warmup, args.reuse_batch, dev, rank, dist)
+    dt, last, N, flops = run_train(model, args.graphs, args.steps, args.warmup, args.reuse_batch, dev, rank, dist,
+                                   prefetch=not args.no_prefetch)
     tmax = torch.tensor([dt], device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -405,6 +421,9 @@ def bench_train_main(args, model, dev, rank, world, dist):
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[3] training step", "graphs_per_gpu": args.graphs, "atoms_per_gpu": N,
+                       "batch_topology": "one batch reused" if args.reuse_batch else
+                       ("rebuilt every step inside get_loss" if args.no_prefetch else
+                        "rebuilt every step, on a side stream during the previous step (prefetch_batch)"),
                        "parallelism": f"graph-batch data parallel over {world} GPU(s), one RCCL all-reduce of "
                                       "the flat fp32 gradient per step"},
             "roofline": train_roofline(tf, flops),
@@ -650,9 +669,11 @@ def main():
         # ---- BASELINE configs[3]: one training step at batch 200
         Kt = 10
         dtt, last, Nt, flt = run_train(models[0], 200, Kt, 3, False, dev, 0, None)
+        dtn = run_train(models[0], 200, Kt, 3, False, dev, 0, None, prefetch=False)[0]
         tf = flt / (dtt / Kt) / 1e12
         out["train"] = {"workload": "configs[3]: training step at batch 200 (get_loss + backward + clip + Adam), a new "
                                     "batch every step", "steps": Kt, "ms_per_step": round(dtt / Kt * 1e3, 3),
+                        "ms_per_step_no_prefetch": round(dtn / Kt * 1e3, 3),
                         "value": round(200 * Kt / dtt, 1), "unit": "graphs/s", "atoms": Nt,
                         "executed_tflops": round(tf, 2), "frac_of_fp32_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
                         "roofline": train_roofline(tf, flt), "final_loss": last}

@@ -275,3 +275,58 @@ def test_capacity_guard_and_largest_accepted_batch(dev):
     jl, il = dst % 64, src % 64
     rev = dst * 63 + il - (il > jl).long()
     assert torch.equal(edge_inv.view(-1)[rev], edge_inv.view(-1))
+
+
+def _param_grads(model):
+    return torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.requires_grad]).clone()
+
+
+def test_prefetched_batch_gives_the_same_training_step(dev):
+    """model.prefetch_batch builds the next batch's topology on a side stream during the current step (bench.py's
+    training loop); get_loss on the prefetched batch == get_loss that builds it itself, bit for bit
+    in the loss and in every parameter gradient, also when the GPU is busy on the main stream while it is built and
+    when the cached batch is dropped right after the step (the allocator must not hand its memory out early)"""
+    from tsdiff_amd import synth
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    model = make_model(cfg, 0, dev)
+    model.train()
+    batches = [to_dev({k2: torch.from_numpy(v) for k2, v in synth.wb97xd3_like_batch(24, seed=900 + k).items()
+                       if isinstance(v, np.ndarray)}, dev) for k in range(3)]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    draws = []
+    for g in batches:
+        t = torch.randint(0, model.num_timesteps, (24,), device=dev, generator=gen)
+        draws.append((t, torch.randn(g["pos"].shape, device=dev, generator=gen)))
+
+    def topo(g):
+        return (g["atom_type"], g["r_feat"], g["p_feat"], g["bond_index"], g["bond_type"], g["batch"], g["num_nodes_per_graph"])
+
+    def run(prefetch):
+        res = []
+        model._batches.clear()
+        busy = torch.randn(2048, 2048, device=dev)
+        for k, g in enumerate(batches):
+            model.zero_grad()
+            loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
+                                  g["batch"], g["num_nodes_per_graph"], 24, _time_step=draws[k][0], _pos_noise=draws[k][1])
+            loss.mean().backward()
+            model._batches.clear()
+            if prefetch and k + 1 < len(batches):
+                for _ in range(4):
+                    busy = busy @ busy * 1e-3  # main-stream work in flight while the side stream builds
+                db = model.prefetch_batch(*topo(batches[k + 1]))
+                assert db.ready_event is not None and model._batches[0][2] is db
+            res.append((loss.detach().clone(), _param_grads(model)))
+        torch.cuda.synchronize()
+        return res
+
+    a, b = run(False), run(True)
+    for (la, ga), (lb, gb) in zip(a, b):
+        assert torch.equal(la, lb)
+        assert torch.equal(ga, gb)
+    # a second prefetch of the same tensors is a cache hit; a CPU model / tensor is a no-op
+    model._batches.clear()
+    d1 = model.prefetch_batch(*topo(batches[0]))
+    assert model.prefetch_batch(*topo(batches[0])) is d1
+    model._batches.clear()

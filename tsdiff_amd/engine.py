@@ -263,8 +263,30 @@ class DeviceBatch:
         self.z = None
         self._z_key = None
         self.geo_gen = 0  # bumped whenever the edge lists are rebuilt (saved training contexts check it)
+        self.ready_event = None  # set by a build on a side stream (prefetch): consumers wait for it, stream to stream
         self._plans = {}  # (kind, clip, clip_pos) -> tsd_sampler_plan* of the bound checkpoints
         self._plan_streams = {}  # streams the plans were launched on (drop_plans waits for them)
+
+    def owned_tensors(self):
+        """every device tensor this object holds right now (arenas, inputs, typed-tile buffers): what a build on a
+        side stream hands to the allocator's cross-stream bookkeeping (`Tensor.record_stream`)"""
+        seen, out = set(), []
+
+        def walk(o, depth=0):
+            if torch.is_tensor(o):
+                if o.is_cuda and o.untyped_storage().data_ptr() not in seen:
+                    seen.add(o.untyped_storage().data_ptr())
+                    out.append(o)
+            elif isinstance(o, dict):
+                for v in o.values():
+                    walk(v, depth + 1)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    walk(v, depth + 1)
+            elif isinstance(o, EdgeList) and depth < 3:
+                walk(vars(o), depth + 1)
+        walk(vars(self))
+        return out
 
     def check_status(self, word=None):
         if not self.status_pending:

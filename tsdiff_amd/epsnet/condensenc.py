@@ -151,9 +151,52 @@ class CondenseEncoderEpsNetwork(nn.Module):
         key = tuple((t._cdata, t._version) for t in ts)
         for k, _, db in self._batches:
             if k == key:
+                if db.ready_event is not None:  # built ahead on the prefetch stream: order this stream behind it
+                    torch.cuda.current_stream(db.device).wait_event(db.ready_event)
+                    db.ready_event = None
                 return db
         db = engine.DeviceBatch(self._cfg, atom_type, r_feat, p_feat, bond_index, bond_type, batch,
                                 num_nodes_per_graph, defer_status=defer_status)
+        self._batches = [(key, ts, db)] + self._batches[:1]
+        return db
+
+    def prefetch_batch(self, atom_type, r_feat, p_feat, bond_index, bond_type, batch, num_nodes_per_graph=None,
+                       wait_for=None):
+        """Build the position-independent state of the NEXT training batch (graph offsets, k-hop pair codes, buffers:
+        what get_loss would build first) on a side stream, while the GPU is still busy with the current step -- the
+        role of the reference's DataLoader workers (train.py:92-101), for the part of the batch that lives on the
+        device here.  The build reads the per-graph sizes back to the host; on the side stream that read waits for
+        nothing, where inside get_loss it waits for the whole previous step and leaves the GPU idle while the host
+        builds the batch (0.3 ms of a 3.1-ms step at batch 200).  get_loss() with the same tensors then finds the
+        batch in the cache and orders its stream behind the build (an event wait on the device, no host sync).
+        Optional: get_loss builds the batch itself when this was not called.
+        The input tensors must be complete when this is called (a loader's finished copies); if they are still being
+        produced on some stream, pass that stream or an event recorded behind their producers as `wait_for`."""
+        dev = atom_type.device
+        if dev.type != "cuda":
+            return None
+        ts = (atom_type, r_feat, p_feat, bond_index, bond_type, batch)
+        key = tuple((t._cdata, t._version) for t in ts)
+        for k, _, db in self._batches:
+            if k == key:
+                return db
+        side = getattr(self, "_prefetch_stream", None)
+        if side is None or side.device != dev:
+            side = torch.cuda.Stream(device=dev)
+            self._prefetch_stream = side
+        main = torch.cuda.current_stream(dev)
+        if isinstance(wait_for, torch.cuda.Event):
+            side.wait_event(wait_for)
+        elif wait_for is not None:
+            side.wait_stream(wait_for)
+        with torch.cuda.stream(side):
+            db = engine.DeviceBatch(self._cfg, atom_type, r_feat, p_feat, bond_index, bond_type, batch,
+                                    num_nodes_per_graph, defer_status=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        for t in db.owned_tensors():  # allocated under the side stream, used (and eventually freed) under `main`
+            t.record_stream(main)
+        db.ready_event = ev
         self._batches = [(key, ts, db)] + self._batches[:1]
         return db
 
