@@ -330,3 +330,88 @@ def test_prefetched_batch_gives_the_same_training_step(dev):
     d1 = model.prefetch_batch(*topo(batches[0]))
     assert model.prefetch_batch(*topo(batches[0])) is d1
     model._batches.clear()
+
+
+def _random_reaction_batch(rng, G, n_lo, n_hi, scale):
+    """G graphs with random bond graphs (0 bonds .. ring rich, R-only / P-only / both bonds of every order),
+    1..n_hi atoms, positions at `scale` Angstrom: the topology zoo of test_random_topologies_edge_lists_bit_exact as
+    full batches (types, features) the sampler can run on"""
+    from tsdiff_amd import synth
+    graphs = []
+    for _ in range(G):
+        n = int(rng.integers(n_lo, n_hi + 1))
+        seen, bi, bt = set(), [], []
+        for _ in range(int(rng.integers(0, 3 * n)) if n > 1 else 0):
+            i, j = (int(v) for v in rng.integers(0, n, size=2))
+            if i == j or (min(i, j), max(i, j)) in seen:
+                continue
+            seen.add((min(i, j), max(i, j)))
+            r, p = int(rng.integers(0, 5)), int(rng.integers(0, 5))
+            if r == 0 and p == 0:
+                r = 1
+            bi += [(i, j), (j, i)]
+            bt += [r * 22 + p] * 2
+        ei = np.asarray(bi, dtype=np.int64).reshape(-1, 2)
+        et = np.asarray(bt, dtype=np.int64)
+        perm = np.lexsort((ei[:, 1], ei[:, 0])) if len(bi) else np.zeros(0, np.int64)
+        graphs.append({"atom_type": rng.choice(np.asarray([1, 6, 7, 8, 9], dtype=np.int64), size=n),
+                       "r_feat": synth._one_hot_feat(rng, n), "p_feat": synth._one_hot_feat(rng, n),
+                       "pos": (rng.standard_normal((n, 3)) * scale).astype(np.float32),
+                       "bond_index": ei[perm].T.copy() if len(bi) else np.zeros((2, 0), np.int64),
+                       "bond_type": et[perm]})
+    return synth.collate(graphs)
+
+
+@pytest.mark.parametrize("hidden,convs,trials", [(64, 2, 24), (256, 3, 8)])
+def test_sampling_paths_random_topologies_vs_oracle(hidden, convs, trials, dev, monkeypatch):
+    """The sampling loop as shipped (one-launch step tail with the look-back scan, type-sorted embedding tiles, pair
+    MLP inside the last block launch, folded edge_cat.2) on RANDOM topologies -- fragments without bonds, one-atom
+    graphs, ring-rich graphs, every R/P bond-type combination, radius membership changing from step to step, edge
+    orders 1..4, cutoffs from 'bonds only' to 'all pairs' -- against the pinned oracle's restatement of the
+    reference loop (4 LD steps, injected noise, every step's positions), and against the same loop with the generic
+    embedding kernel and the three-launch tail (same lists after the last step, positions within rounding)"""
+    from oracle import tsdiff_oracle as O
+    from tsdiff_amd import engine, synth
+    from tsdiff_amd.sampler import EnsembleSampler
+    from tests.util import assert_close
+    rng = np.random.default_rng(4242 + hidden)
+    n_typed = 0
+    for trial in range(trials):
+        G = int(rng.integers(1, 25))
+        b = _random_reaction_batch(rng, G, 1, int(rng.choice([6, 20, 40])), float(rng.choice([0.7, 2.0, 5.0])))
+        cfg = dict(synth.small_model_config(hidden, convs))
+        cfg.update(edge_order=int(rng.integers(1, 5)), pred_edge_order=int(rng.integers(1, 5)),
+                   edge_cutoff=float(rng.choice([0.0, 3.0, 10.0, 100.0])))
+        t = {k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}
+        g = to_dev(t, dev)
+        N = t["pos"].shape[0]
+        n_steps = 4
+        noises = torch.from_numpy(rng.standard_normal((n_steps, N, 3)).astype(np.float32))
+        tag = f"trial {trial}: G={G} N={N} orders {cfg['edge_order']}/{cfg['pred_edge_order']} cutoff {cfg['edge_cutoff']}"
+
+        def run(typed, tail):
+            monkeypatch.setattr(engine, "TYPED_TILES", typed)
+            monkeypatch.setattr(engine, "FUSED_STEP_TAIL", tail)
+            model = make_model(cfg, 2, dev)
+            ens = EnsembleSampler([model])
+            pos, traj = ens.dynamic_sampling(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"],
+                                             g["bond_type"], g["batch"], G, True, n_steps=n_steps, step_lr=1e-6, clip=1000,
+                                             sampling_type="ld", noises=noises.to(dev))
+            db = ens._bound_batch(g["atom_type"], g["r_feat"], g["p_feat"], g["bond_index"], g["bond_type"], g["batch"])
+            return pos, torch.stack(traj), db
+
+        pos, traj, db = run(True, True)
+        n_typed += db.typed is not None
+        lists = _lists_snapshot(db)
+        o_pos, o_traj = O.sample([O.to_torch_state(synth.synth_state_dict(cfg, 2))], cfg, t["atom_type"], t["r_feat"],
+                                 t["p_feat"], t["pos"], t["bond_index"], t["bond_type"], t["batch"],
+                                 b["num_nodes_per_graph"], noises, n_steps, step_lr=1e-6)
+        assert_close(traj.cpu().numpy(), torch.stack(o_traj).numpy(), 5e-5, tag + " vs oracle")
+        # the lists left by the last tail launch == a stand-alone build on the final positions (bit exact)
+        db.geometry(pos)
+        ref_lists = _lists_snapshot(db)
+        for k in lists:
+            assert np.array_equal(lists[k], ref_lists[k]), (tag, k)
+        pos_g, traj_g, _ = run(False, False)
+        assert_close(traj.cpu().numpy(), traj_g.cpu().numpy(), 2e-5, tag + " typed tiles + fused tail vs generic kernels")
+    assert n_typed >= trials // 2  # (batches without a single pair have no tiles: the generic kernel runs)
