@@ -415,3 +415,45 @@ def test_sampling_paths_random_topologies_vs_oracle(hidden, convs, trials, dev, 
         pos_g, traj_g, _ = run(False, False)
         assert_close(traj.cpu().numpy(), traj_g.cpu().numpy(), 2e-5, tag + " typed tiles + fused tail vs generic kernels")
     assert n_typed >= trials // 2  # (batches without a single pair have no tiles: the generic kernel runs)
+
+
+@pytest.mark.parametrize("hidden,convs,trials", [(64, 2, 6), (256, 2, 6)])
+def test_training_step_random_topologies_fused_vs_op_by_op_and_oracle(hidden, convs, trials, dev, monkeypatch):
+    """the fused training step on the random-topology zoo (batches without a separately embedded out edge, without
+    any out edge, with one-atom graphs, with every R/P bond combination): loss and EVERY parameter gradient against
+    the op-by-op autograd form of the primitive kernels, the loss against the pinned oracle (fp32 CPU)"""
+    from oracle import tsdiff_oracle as O
+    from tsdiff_amd import synth
+    from tests.test_gpu_parity import _grad_tol_check
+    from tests.util import assert_close
+    rng = np.random.default_rng(777 + hidden)
+    for trial in range(trials):
+        G = int(rng.integers(1, 30))
+        b = _random_reaction_batch(rng, G, 1 if trial % 2 else 2, int(rng.choice([5, 16, 40])), float(rng.choice([1.0, 2.5])))
+        cfg = dict(synth.small_model_config(hidden, convs))
+        cfg.update(edge_order=int(rng.integers(1, 5)), pred_edge_order=int(rng.integers(1, 5)),
+                   edge_cutoff=float(rng.choice([0.0, 3.0, 10.0])))
+        t = {k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}
+        g = to_dev(t, dev)
+        N = t["pos"].shape[0]
+        ts = torch.from_numpy(rng.integers(0, 5000, size=G))
+        pn = torch.from_numpy(rng.standard_normal((N, 3)).astype(np.float32))
+        tag = f"trial {trial}: G={G} N={N} orders {cfg['edge_order']}/{cfg['pred_edge_order']} cutoff {cfg['edge_cutoff']}"
+        res = {}
+        for mode in ("fused", "ops"):
+            monkeypatch.setenv("TSDIFF_TRAIN", mode)
+            model = make_model(cfg, 3, dev)
+            model.train()
+            loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
+                                  g["batch"], g["num_nodes_per_graph"], G, _time_step=ts.to(dev), _pos_noise=pn.to(dev))
+            loss.mean().backward()
+            res[mode] = (loss.detach().cpu().numpy(),
+                         {k: p.grad.cpu().numpy() for k, p in model.named_parameters() if p.grad is not None})
+        assert set(res["fused"][1]) == set(res["ops"][1]), tag
+        assert_close(res["fused"][0], res["ops"][0], 2e-6, tag + " loss fused vs op-by-op")
+        for k, ref in res["ops"][1].items():
+            _grad_tol_check(res["fused"][1][k], ref, f"{k} ({tag}, fused vs op-by-op)")
+        sd = O.to_torch_state(synth.synth_state_dict(cfg, 3))
+        o_loss = O.get_loss(sd, cfg, t["atom_type"], t["r_feat"], t["p_feat"], t["pos"], t["bond_index"], t["bond_type"],
+                            t["batch"], b["num_nodes_per_graph"], ts, pn)
+        assert_close(res["fused"][0], o_loss.detach().numpy(), 5e-5, tag + " loss vs oracle")
