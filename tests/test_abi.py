@@ -156,6 +156,24 @@ def test_forward_work_model_known_answers():
     assert lib.tsd_forward_work(C.byref(cfg), -1, 0, 0, 0, C.byref(w)) != 0
 
 
+def test_size_queries_for_every_supported_hidden_width():
+    """the host-only size queries (no GPU call): workspace / parameter-vector sizes for hidden 64, 128 and 256 --
+    widths whose halves are not MFMA shapes size their split scratch by other rules (a division by zero sat here)"""
+    import ctypes as C
+    from tsdiff_amd import _lib, engine, synth
+    lib = _lib.load()
+    prev = None
+    for hidden in (64, 128, 256):
+        cfg = engine.make_cfg(synth.small_model_config(hidden, 3))
+        raw = lib.tsd_train_raw_floats(C.byref(cfg))
+        assert raw > 3 * 3 * hidden * hidden and (prev is None or raw > prev)
+        prev = raw
+        sizes = [lib.tsd_train_workspace_floats(C.byref(cfg), N, P) for N, P in ((0, 0), (10, 90), (300, 6000), (3000, 90000))]
+        assert sizes == sorted(sizes) and sizes[1] > 0
+        assert lib.tsd_forward_workspace_floats(C.byref(cfg), 3000, 90000, 1) > 0
+        assert lib.tsd_forward_workspace_floats(C.byref(cfg), 3000, 90000, 8) > lib.tsd_forward_workspace_floats(C.byref(cfg), 3000, 90000, 1)
+
+
 def test_entry_points_run_inside_roctx_ranges(tmp_path):
     """the library resolves roctxRangePushA / roctxRangePop from the process image (what `rocprofv3 --marker-trace`
     preloads) and brackets its entry points with "tsd:<name>" ranges; without those symbols the ranges are no-ops

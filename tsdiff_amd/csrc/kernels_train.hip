@@ -328,7 +328,8 @@ constexpr int WS_MAX_IN = 32;
 template <int MAXIN>  // 1 (the Linear(1,H) / Linear(H/2,1) layers: no wasted predicated lanes) or WS_MAX_IN
 __global__ __launch_bounds__(256) void wgrad_small_kernel(int rows, int in, int out, const float* __restrict__ dY,
                                                           const float* __restrict__ X, float* __restrict__ part,
-                                                          float* __restrict__ bias_part /* [chunks][out] or NULL */) {
+                                                          float* __restrict__ bias_part /* [chunks][out] or NULL */,
+                                                          int bias_of_x /* swapped form (in == 1): [chunks] sums of X */) {
     __shared__ float sm[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int o = blockIdx.x * 64 + lane;
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(int rows, int in, int 
         for (int r = r0 + w; r < r1; r += 4) {
             const float g = dY[(size_t)r * out + o];
             const float* xr = X + (size_t)r * in;
-            bsum += g;
+            bsum += bias_of_x ? xr[0] : g;
 #pragma unroll
             for (int i = 0; i < MAXIN; ++i)
                 if (i < in) acc[i] = fmaf(g, xr[i], acc[i]);
@@ -361,8 +362,12 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(int rows, int in, int 
         __syncthreads();
         sm[w][lane] = bsum;
         __syncthreads();
-        if (w == 0 && o < out)
-            bias_part[(size_t)blockIdx.y * out + o] = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+        const float v = (sm[0][lane] + sm[1][lane]) + (sm[2][lane] + sm[3][lane]);
+        if (bias_of_x) {
+            if (w == 0 && o == 0) bias_part[blockIdx.y] = v;
+        } else if (w == 0 && o < out) {
+            bias_part[(size_t)blockIdx.y * out + o] = v;
+        }
     }
 }
 
@@ -845,18 +850,19 @@ int linear_bwd_impl(int rows, int in, int out, const float* X, const float* W, c
             const int o2 = swap ? in : out, i2 = swap ? 1 : in;
             const int chunks = (rows >= 2048 && scratch_floats >= off_part + 256 * (size_t)out * in) ? 256 : 64;
             float* part = scratch + off_part;
-            // the bias gradient in the same two launches (not in the swapped form: its "dY" is X)
+            // the bias gradient in the same two launches (swapped form: the layer's dY is the kernel's X, one column)
             float* bpart = nullptr;
-            if (db && !swap && scratch_floats >= off_part + (size_t)chunks * out * (in + 1)) bpart = part + (size_t)chunks * out * in;
+            const int nb = swap ? 1 : out;
+            if (db && scratch_floats >= off_part + (size_t)chunks * ((size_t)out * in + nb)) bpart = part + (size_t)chunks * out * in;
             if (i2 == 1)
                 hipLaunchKernelGGL(wgrad_small_kernel<1>, dim3((o2 + 63) / 64, chunks), dim3(256), 0, st, rows, i2, o2,
-                                   swap ? X : dY, swap ? dY : X, part, bpart);
+                                   swap ? X : dY, swap ? dY : X, part, bpart, swap ? 1 : 0);
             else
                 hipLaunchKernelGGL(wgrad_small_kernel<WS_MAX_IN>, dim3((o2 + 63) / 64, chunks), dim3(256), 0, st, rows,
-                                   i2, o2, swap ? X : dY, swap ? dY : X, part, bpart);
+                                   i2, o2, swap ? X : dY, swap ? dY : X, part, bpart, 0);
             const int64_t n = (int64_t)o2 * i2;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + (bpart ? out : 0) + 63) / 64)),
-                               dim3(reduce_threads(chunks)), 0, st, n, bpart ? out : 0, chunks, part, bpart, dW,
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + (bpart ? nb : 0) + 63) / 64)),
+                               dim3(reduce_threads(chunks)), 0, st, n, bpart ? nb : 0, chunks, part, bpart, dW,
                                bpart ? db : (float*)nullptr, accW);
             TSD_LAUNCH_CHECK("wgrad_small");
             db_done = bpart != nullptr;
@@ -894,8 +900,8 @@ int launch_split_reduce(int64_t n, int S, const float* part, float* dst, int acc
 // 504 workgroups, two per CU on 252 CUs, where S = 8 left a quarter of the CUs with one and 16 with 3.5 on average;
 // 21 node-level problems: S = 6 -> 504, where 8 gave 672 = 2.6 per CU, i.e. three).
 int wgrad_batch_splits(int m, int blocks, int rows) {
-    const int unit = m * blocks;
-    const int cap = std::max(1, std::min(64, rows / 64));
+    const int unit = std::max(1, m * blocks);
+    const int cap = std::max(1, std::min(128, rows / 64));
     for (int k = 2; k <= 16; ++k) {
         const int S = 256 * k / unit;
         if (S >= 4) return std::min(S, cap);

@@ -161,6 +161,7 @@ Work carve(const tsd_model_cfg& c, int N, size_t PU, float* base) {
             a = wgrad_batch_scratch_floats((int)(3 * L), N, (int)H, (int)H);
             b = PU > 0 ? wgrad_batch_scratch_floats((int)(2 * L), (int)PU, (int)H, (int)H) : 0;
             e2 = PU > 0 ? wgrad_batch_scratch_floats(2, (int)(2 * PU), (int)H, (int)H) : 0;  // the embedding's two H x H layers
+            if (PU > 0 && (H / 2) % 128 == 0) e2 = std::max(e2, wgrad_batch_scratch_floats(1, (int)PU, (int)H, (int)(H / 2)));  // pair MLP layers.1
         }
         w.wpart = take(std::max(a, std::max(b, e2)));
     }
@@ -814,7 +815,13 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
             TSD_TRY(launch_pair_bwd(H, Eo, g.out_u, g.attr_row, ds, raw + x.R.out_w2, w.g1, w.g0, w.pack_t + x.R.out_w1,
                                     w.pack_t + x.R.out_w0, dg1, dg0, dp, w.d_ea, PU, PU - Eu, st));
             TSD_TRY(x.lin_bwd(Eo, H / 2, 1, w.gs1, x.R.out_w2, (long)x.R.out_b2, ds, nullptr, false));
-            TSD_TRY(x.lin_bwd(Eo, H, H / 2, w.gs0, x.R.out_w1, (long)x.R.out_b1, dg1, nullptr, false));
+            {   // [H/2 x H]: two output blocks -- split finer than the single-problem form (128 ways: one workgroup per CU)
+                const float* dYs[1] = {dg1};
+                const float* Xs[1] = {w.gs0};
+                float* dWs[1] = {grad + x.R.out_w1};
+                float* dbs[1] = {grad + x.R.out_b1};
+                TSD_TRY(launch_wgrad_batch(1, Eo, H, H / 2, dYs, Xs, dWs, dbs, 1, w.wpart, st));
+            }
             TSD_TRY(x.lin_bwd(Eo, 2 * H, H, w.hp, x.R.out_w0, (long)x.R.out_b0, dg0, nullptr, false));
         } else {
             TSD_TRY(x.lin_bwd(Eo, H / 2, 1, w.gs1, x.R.out_w2, (long)x.R.out_b2, ds, w.eB, false, 0, w.g1));   // dg1
