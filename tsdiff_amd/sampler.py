@@ -171,14 +171,26 @@ class EnsembleSampler(nn.Module):
             pos_traj = []
             # the trajectory leaves the device in chunks of at most ~256 MB (5000 steps of config C5 are 3.9 GB)
             chunk = n if not return_traj else max(1, min(n, (64 << 20) // max(3 * N, 1)))
+            # a short trajectory (<= 16 MB: the whole of a configs[1] call up to ~800 steps) and the status word come
+            # back through pinned memory behind ONE stream synchronisation; a pageable .cpu() is a staged blocking copy
+            # each (0.05 ms per step of a 20-step call)
+            small = return_traj and chunk == n and n * N * 12 <= (16 << 20)
+            status_host = None
             for k0 in range(0, n, chunk):
                 k1 = min(n, k0 + chunk)
                 traj = torch.empty(k1 - k0, N, 3, dtype=torch.float32, device=dev) if return_traj else None
                 db.sampler_run(kind, coefs[k0:k1], None if noises is None else noises[k0:k1], seed or 0, k0 * N,
                                clip, clip_pos, traj, use_graph)
-                if return_traj:
+                if small:
+                    host = torch.empty(traj.shape, dtype=torch.float32, pin_memory=True)
+                    host.copy_(traj, non_blocking=True)
+                    status_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+                    status_host.copy_(db.status[:1], non_blocking=True)
+                    torch.cuda.current_stream(dev).synchronize()
+                    pos_traj += list(host.clone().unbind(0))  # (plain pageable tensors, as the reference returns)
+                elif return_traj:
                     pos_traj += list(traj.cpu().unbind(0))
-            status = int(db.status[0].item())  # the single host sync of the loop
+            status = int(status_host[0]) if status_host is not None else int(db.status[0].item())  # the host sync of the loop
             if status & _lib.STATUS_INTERNAL:
                 raise _lib.TsdError("internal: a bounded wait of the fused step tail gave up (TSD_STATUS_INTERNAL)")
             if status & _lib.STATUS_NAN:
