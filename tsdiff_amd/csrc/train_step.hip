@@ -79,8 +79,7 @@ RawLayout raw_layout(const tsd_model_cfg& c) {
 }
 
 struct Work {
-    // forward state (rows of the per-edge arrays by CAPACITY PU = P/2, so that the layout does not depend on the
-    // edge counts of the step)
+    // forward state (per-edge arrays sized by CAPACITY PU = P/2; per-block arrays strided by it)
     float *featR, *featP;          // [N,F] fp32 one-hot features
     float* h;                      // [(L+1), N, H]
     float *x1, *agg, *x2, *xs;     // [L, N, H] each
