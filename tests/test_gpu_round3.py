@@ -457,3 +457,32 @@ def test_training_step_random_topologies_fused_vs_op_by_op_and_oracle(hidden, co
         o_loss = O.get_loss(sd, cfg, t["atom_type"], t["r_feat"], t["p_feat"], t["pos"], t["bond_index"], t["bond_type"],
                             t["batch"], b["num_nodes_per_graph"], ts, pn)
         assert_close(res["fused"][0], o_loss.detach().numpy(), 5e-5, tag + " loss vs oracle")
+
+
+def test_diffuse_positions_equals_the_reference_expression(dev):
+    """tsd_diffuse_positions (one launch) == condensenc.py:292-297 evaluated by torch op by op, bit for bit: the
+    per-graph alphas and the perturbed positions, including graphs at both ends of the schedule"""
+    from tsdiff_amd import _lib, synth
+    from tsdiff_amd._lib import check, ptr, stream_ptr
+    lib = _lib.load()
+    model = make_model(synth.small_model_config(), 0, dev)
+    alphas = model.alphas.detach()
+    T = alphas.shape[0]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    for G, n_max in ((1, 1), (7, 30), (200, 23)):
+        nn = torch.randint(1, n_max + 1, (G,), generator=torch.Generator().manual_seed(G))
+        batch = torch.repeat_interleave(torch.arange(G), nn).to(dev)
+        N = int(nn.sum())
+        ts = torch.randint(0, T, (G,), device=dev, generator=gen)
+        ts[0], ts[-1] = 0, T - 1
+        pos = torch.randn(N, 3, device=dev, generator=gen) * 3
+        noise = torch.randn(N, 3, device=dev, generator=gen)
+        out, a = torch.empty_like(pos), torch.empty(G, device=dev)
+        check(lib.tsd_diffuse_positions(N, G, T, ptr(alphas), ptr(ts), ptr(batch), ptr(pos), ptr(noise), ptr(out), ptr(a),
+                                        stream_ptr()))
+        a_ref = alphas.index_select(0, ts)
+        a_pos = a_ref.index_select(0, batch).unsqueeze(-1)
+        ref = pos + noise * (1.0 - a_pos).sqrt() / a_pos.sqrt()
+        assert torch.equal(a, a_ref)
+        assert torch.equal(out, ref), float((out - ref).abs().max())

@@ -312,17 +312,6 @@ __global__ void scatter_rows_kernel(int64_t rows, int cols, const float* __restr
     if (target >= from) target -= shift;
     dst[(size_t)target * cols + c] = src[r * lds_ + c];
 }
-// d_target[u] = (|pos0_i - pos0_j| - d_u) / sqrt(1 - a) * sqrt(a), a = alpha of the pair's graph   condensenc.py:309-318
-__global__ void d_target_kernel(tsd_edges eu, const float* __restrict__ pos0, const int32_t* __restrict__ node_graph,
-                                const float* __restrict__ a_graph, float* __restrict__ out) {
-    const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= *eu.count) return;
-    const int i = eu.src[u], j = eu.dst[u];
-    const float dx = pos0[3 * i] - pos0[3 * j], dy = pos0[3 * i + 1] - pos0[3 * j + 1], dz = pos0[3 * i + 2] - pos0[3 * j + 2];
-    const float d_gt = sqrtf(dx * dx + dy * dy + dz * dz);
-    const float a = a_graph[node_graph[i]];
-    out[u] = (d_gt - eu.dist[u]) / sqrtf(1.0f - a) * sqrtf(a);
-}
 // The loss head of the forward in ONE launch (d_target, both eq_transforms and the squared difference; thread = node):
 //   d_target_e = (|pos0_i - pos0_j| - d_e) / sqrt(1 - a) * sqrt(a)                          condensenc.py:309-318
 //   node_eq = eq_transform(s), pos_target = eq_transform(d_target)                          geometry.py:22-30
@@ -411,19 +400,6 @@ __global__ void diffuse_kernel(int N, int G, int T, const float* __restrict__ al
     const float s1 = sqrtf(1.0f - a), s2 = sqrtf(a);
 #pragma unroll
     for (int k = 0; k < 3; ++k) out[3 * i + k] = pos[3 * i + k] + (noise[3 * i + k] * s1) / s2;
-}
-__global__ void loss_fwd_kernel(int N, const float* __restrict__ eq, const float* __restrict__ tg,
-                                float* __restrict__ loss) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const float a = eq[3 * i] - tg[3 * i], b = eq[3 * i + 1] - tg[3 * i + 1], c = eq[3 * i + 2] - tg[3 * i + 2];
-    loss[i] = a * a + b * b + c * c;
-}
-__global__ void loss_bwd_kernel(int N, const float* __restrict__ eq, const float* __restrict__ tg,
-                                const float* __restrict__ dloss, float* __restrict__ deq) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 3 * N) return;
-    deq[t] = 2.0f * (eq[t] - tg[t]) * dloss[t / 3];
 }
 
 // ---- optimizer on the flat parameter / gradient vectors (reference train.py:144-145, utils/common.py:58-68) ----

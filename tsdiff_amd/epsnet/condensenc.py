@@ -254,8 +254,11 @@ class CondenseEncoderEpsNetwork(nn.Module):
             from .. import _lib
             from .._lib import check, ptr, stream_ptr
             alphas = self.alphas.detach()
-            pos_c, noise_c = pos.detach().contiguous(), pos_noise.contiguous()
-            ts, n2g = time_step.to(torch.int64).contiguous(), node2graph.to(torch.int64).contiguous()
+            pos_c, noise_c = pos.detach().contiguous(), pos_noise.to(dev).contiguous()
+            ts = time_step.to(device=dev, dtype=torch.int64).contiguous()
+            n2g = node2graph.to(device=dev, dtype=torch.int64).contiguous()
+            if ts.shape[0] != num_graphs or n2g.shape[0] != pos_c.shape[0] or noise_c.shape != pos_c.shape:
+                raise ValueError("get_loss: time_step / batch / pos_noise do not match num_graphs / pos")
             pos_perturbed = torch.empty_like(pos_c)
             a = torch.empty(ts.shape[0], dtype=torch.float32, device=dev)
             check(_lib.load().tsd_diffuse_positions(pos_c.shape[0], ts.shape[0], alphas.shape[0], ptr(alphas), ptr(ts),
