@@ -5,6 +5,7 @@ computation of the path runs in libtsdiff_hip.so.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import torch
@@ -427,10 +428,9 @@ class DeviceBatch:
         self._plan_streams = {}
 
     def __del__(self):
-        import sys
-        if sys is None or sys.is_finalizing():  # interpreter shutdown: the driver reclaims everything, no sync from GC
-            return
         try:
+            if sys is None or sys.is_finalizing():  # interpreter shutdown: the driver reclaims everything, no sync from GC
+                return
             self.drop_plans()
         except Exception:
             pass
