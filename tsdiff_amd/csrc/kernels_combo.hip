@@ -59,6 +59,9 @@ namespace tsd {
 
 constexpr int T = TSD_EDGE_TILE;   // 32 edges per filter tile
 constexpr int TN = TSD_NODE_TILE;  // 16 nodes per node tile
+#ifndef TSD_AGG_PREFETCH
+#define TSD_AGG_PREFETCH 1
+#endif
 
 struct ComboNode {
     int mode;  // 0: aggregate + update (+ next lin1), 1: x1_out = lin1(h) only, -1: no node role
@@ -155,11 +158,26 @@ __device__ __forceinline__ void aggregate_tile(const int32_t* __restrict__ row_p
     typedef int i32x8 __attribute__((ext_vector_type(8)));
     typedef typename VRow<V>::type vrow;
     const unsigned lane_b = (unsigned)lane * (V * 4u);  // this lane's byte offset inside a row
+#if TSD_AGG_PREFETCH
+    // the indices of batch k + 1 are requested while the rows of batch k are in flight: one dependent scalar round trip
+    // less per batch of a chain of (2 + edges / U) round trips
+    i32x8 jd, ud, jn, un;
+    if (E0 < E1) {
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(jn) : "s"(dst + E0) : "memory");
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(un) : "s"(umap + E0) : "memory");
+    }
+#endif
     for (int e = E0; e < E1; e += U) {
+#if TSD_AGG_PREFETCH
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(jn), "+s"(un)::"memory");
+        jd = jn;
+        ud = un;
+#else
         i32x8 jd, ud;  // dst / umap of edges e .. e+7 (the lists carry 8 spare entries: tsdiff_hip.h)
         asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(jd) : "s"(dst + e) : "memory");
         asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(ud) : "s"(umap + e) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(jd), "+s"(ud)::"memory");
+#endif
         vrow wv[U], xv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -179,6 +197,12 @@ __device__ __forceinline__ void aggregate_tile(const int32_t* __restrict__ row_p
                 asm volatile("global_load_dword %0, %1, %2" : "=v"(xv[u]) : "v"(lane_b), "s"(xrow) : "memory");
             }
         }
+#if TSD_AGG_PREFETCH
+        if (e + U < E1) {
+            asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(jn) : "s"(dst + e + U) : "memory");
+            asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(un) : "s"(umap + e + U) : "memory");
+        }
+#endif
         // one wait for the batch, naming every destination (the consumers below depend on this statement)
         if constexpr (U == 8)
             asm volatile("s_waitcnt vmcnt(0)"
