@@ -426,7 +426,8 @@ int tsd_gine_aggregate(int32_t num_nodes, int64_t num_edges, int32_t H, int32_t 
  * output edges embedded separately (the call synchronises the stream once to read them; a fresh batch needs no
  * other host read) and must be
  * handed unchanged to tsd_train_backward, which turns dloss [N] = d(objective)/d(loss) into
- * grad [tsd_train_raw_floats], the gradient of every parameter in the layout of `raw`. */
+ * grad [tsd_train_raw_floats], the gradient of every parameter in the layout of `raw` (grad and workspace 16-byte
+ * aligned). */
 /* The forward diffusion of get_loss (condensenc.py:292-297) in one launch: a_graph[g] = alphas[time_step[g]],
  * pos_perturbed[i] = pos[i] + noise[i] * sqrt(1 - a) / sqrt(a) with a = a_graph[node_graph[i]] -- the operations of
  * the reference's expression in its order (eight elementwise / gather launches there).  time_step [G] and

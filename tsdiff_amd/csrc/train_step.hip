@@ -758,6 +758,8 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
     TraceRange range("tsd:train_backward");
     hipStream_t st = (hipStream_t)stream;
     TSD_REQUIRE(dloss && grad && atom_type && pos, "null pointer");
+    TSD_REQUIRE((reinterpret_cast<uintptr_t>(grad) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
+                "grad and workspace must be 16-byte aligned");
     Ctx x;
     TSD_TRY(make_ctx(x, cfg, batch, raw, workspace, workspace_floats, counts_host, st));
     x.grad = grad;
