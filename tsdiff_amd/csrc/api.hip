@@ -352,7 +352,7 @@ using namespace tsd;
 
 extern "C" {
 
-const char* tsd_version(void) { return "tsdiff_hip 0.2 (gfx950, fp32 MFMA)"; }
+const char* tsd_version(void) { return "tsdiff_hip 0.3 (gfx950, fp32 MFMA)"; }
 const char* tsd_last_error(void) { return g_err; }
 
 size_t tsd_raw_weight_floats(const tsd_model_cfg* cfg) {
