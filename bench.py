@@ -464,7 +464,9 @@ def cpu_baseline(args, cfg, b, pos_init):
     v, f, S, N = cpu_ld_rate(O, cfg, b, pos0, args.models, nthreads, args.cpu_steps, 15.0)
     out = {"value": round(v, 1), "unit": "atoms*steps/s", "cores": nthreads, "kind": "port", "fwd_per_s": round(f, 3),
            "sample": f"{S} LD steps of the same {args.graphs}-graph batch (N={N}), torch-CPU oracle, "
-                     f"{nthreads} of {ncpu} host cores"}
+                     f"{nthreads} of {ncpu} host cores",
+           "note": "port, faster than the literal reference: the oracle extends each graph's bond graph by a per-graph "
+                   "BFS where the reference takes dense batch-wide N x N matrix powers (models/common.py:115-202)"}
     if ncpu != nthreads:
         va, fa, Sa, _ = cpu_ld_rate(O, cfg, b, pos0, args.models, ncpu, 3, 10.0)
         out["all_cores"] = {"value": round(va, 1), "cores": ncpu, "fwd_per_s": round(fa, 3),
