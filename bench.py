@@ -325,7 +325,7 @@ def train_roofline(tf, flops):
             "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "flop_per_step": flops,
             "note": "executed flops = 3 x the forward's (undirected formulation)",
             "mfma_busy": {"block_bwd_kernel": mfma_busy("train", "block_bwd_kernel"),
-                          "layer_combo_kernel(save)": mfma_busy("train", "layer_combo_kernel"),
+                          "layer_combo_kernel(save)": mfma_busy("train", "layer_combo_kernel<256, true"),
                           "wgrad_batch_kernel": mfma_busy("train", "wgrad_batch_kernel")},
             "mfma_busy_source": "profiles/" + MFMA_BUSY}
 
@@ -572,8 +572,8 @@ def main():
     E_enc, E_out, E_diff = db.enc.num_edges(), db.out.num_edges(), db.diff_u.num_edges()
     roofline = combo_roofline(lib, db, cfg, dev, reps=40 if db.P < 2_000_000 else 2)
     fname = PMC_C2 if args.workload == "c2" else PMC_C5
-    roofline["traffic"], roofline["traffic_source"] = pmc_traffic("layer_combo_kernel<256", fname)
-    roofline["mfma_busy"] = mfma_busy("c2" if args.workload == "c2" else "c5", "layer_combo_kernel")
+    roofline["traffic"], roofline["traffic_source"] = pmc_traffic("layer_combo_kernel<256, false, false>", fname)
+    roofline["mfma_busy"] = mfma_busy("c2" if args.workload == "c2" else "c5", "layer_combo_kernel<256, false, false>")
     F, F_ref = forward_flops(models[0]._cfg, E_enc, E_out, E_diff, N, args.models)
     step_s = dt / args.steps
 
@@ -625,7 +625,7 @@ def main():
         assert torch.isfinite(p5).all()
         db5 = run5.db()
         rf5 = combo_roofline(lib, db5, cfg, dev, reps=2)
-        rf5["traffic"], rf5["traffic_source"] = pmc_traffic("layer_combo_kernel<256", PMC_C5)
+        rf5["traffic"], rf5["traffic_source"] = pmc_traffic("layer_combo_kernel<256, false, false>", PMC_C5)
         N5 = 1024 * 64
         F5, _ = forward_flops(models[0]._cfg, db5.enc.num_edges(), db5.out.num_edges(), db5.diff_u.num_edges(), N5, 1)
         out["c5"] = {"workload": "configs[4]: 1024 x 64-atom graphs, complete pair set, LD sampling, 1 checkpoint",

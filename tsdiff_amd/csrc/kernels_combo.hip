@@ -923,7 +923,10 @@ struct ComboStride {  // per-checkpoint strides (blockIdx.y = checkpoint of the 
 
 constexpr int NODE_RUN = 4;  // consecutive node tiles kept on one XCD (one 64-atom graph = 4 tiles)
 
-template <int H, bool SAVE>
+// TAIL: the instantiation of the launches that carry a third role behind the filter tiles (the pair MLP of the last
+// block launch, or the pre-GEMM of the piecewise pair output): a kernel of its own name in a profile, and the plain
+// block launches do not carry its code and registers.
+template <int H, bool SAVE, bool TAIL>
 __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int node_tiles, ComboFilter f,
                                                             ComboStride sd, ComboPre q, FilterSave fsv,
                                                             NodeSave ns TSD_TRACE_ARG) {
@@ -936,7 +939,7 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
         if (a.lin1_next_w) a.lin1_next_w += wo;
         f.Wl0 += wo;
         f.edge_attr += m * sd.ea; f.wf += m * sd.wf;
-        if (q.tiles) {
+        if (TAIL && q.tiles) {
             q.edge_attr += m * sd.ea; q.w0b += wo; q.b0 += wo;
             if (q.pair) {
                 q.w0a += wo; q.w1 += wo; q.b1 += wo; q.w2 += wo; q.b2 += wo;
@@ -979,7 +982,8 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
     } else {
         const int item = others_before;
         if (item >= f.tiles) {
-            if (q.pair)
+            if constexpr (!TAIL) return;
+            else if (q.pair)
                 // workgroups b and b + 256 of a launch share a CU (measured; a speed assumption only): these pair tiles
                 // sit beside the node tiles
                 pair_role<H>(q, item - f.tiles, node_tiles, smem, TSD_PAIR_DEFER && b >= 256 && b - 256 < node_tiles);
@@ -1074,24 +1078,20 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
 #else
 #define TSD_TRACE_HOST
 #endif
-#define TSD_COMBO(HH)                                                                                       \
-    if (save) {                                                                                             \
+#define TSD_COMBO_I(HH, SV, TL)                                                                             \
+    {                                                                                                       \
         static DeviceOnce once;                                                                             \
-        int r = allow_lds(layer_combo_kernel<HH, true>, lds, once);                                         \
+        int r = allow_lds(layer_combo_kernel<HH, SV, TL>, lds, once);                                       \
         if (r) return r;                                                                                    \
-        hipLaunchKernelGGL((layer_combo_kernel<HH, true>), dim3(grid, M), dim3(2 * HH), lds, st, a, node_tiles, f, \
-                           sd, q, fsv, nsv TSD_TRACE_HOST);                                                 \
-    } else {                                                                                                \
-        static DeviceOnce once;                                                                             \
-        int r = allow_lds(layer_combo_kernel<HH, false>, lds, once);                                        \
-        if (r) return r;                                                                                    \
-        hipLaunchKernelGGL((layer_combo_kernel<HH, false>), dim3(grid, M), dim3(2 * HH), lds, st, a, node_tiles, f, \
+        hipLaunchKernelGGL((layer_combo_kernel<HH, SV, TL>), dim3(grid, M), dim3(2 * HH), lds, st, a, node_tiles, f, \
                            sd, q, fsv, nsv TSD_TRACE_HOST);                                                 \
     }
+#define TSD_COMBO(HH)                                                                                       \
+    if (save) TSD_COMBO_I(HH, true, false) else if (q.tiles > 0) TSD_COMBO_I(HH, false, true) else TSD_COMBO_I(HH, false, false)
     const bool save = fsave != nullptr || nsave != nullptr;
     const FilterSave fsv = fsave ? *fsave : FilterSave{};
     const NodeSave nsv = nsave ? *nsave : NodeSave{};
-    if (save && ((f.tiles > 0 && !fsave) || (node_tiles > 0 && a.mode == 0 && !nsave) || M != 1)) {
+    if (save && ((f.tiles > 0 && !fsave) || (node_tiles > 0 && a.mode == 0 && !nsave) || M != 1 || q.tiles > 0)) {
         set_error("internal: the saving block launch needs both save sets and one checkpoint");
         return TSD_ERR_INVALID;
     }
@@ -1102,6 +1102,7 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
         default: set_error("hidden=%d unsupported (64/128/256)", c.hidden); return TSD_ERR_INVALID;
     }
 #undef TSD_COMBO
+#undef TSD_COMBO_I
     TSD_LAUNCH_CHECK("layer_combo");
     return TSD_OK;
 }
