@@ -34,7 +34,9 @@
  *     (the forward, sampling-loop, geometry / topology and training entry points run inside "tsd:<name>"
  *     ranges that `rocprofv3 --marker-trace` records; absent a profiler the ranges are no-ops); a process may drive several devices (the device current
  *     at the call is used), one stream per call;
- *   - floating point is fp32 end to end (fp32 MFMA, exact-f32 FMA chains); indices at this
+ *   - every tensor at this boundary is fp32; the GEMMs run on the fp32-input MFMA (exact-f32 FMA chains) or, in the
+ *     inference forward when the batch carries `weights16`, on the f16 MFMA with split operands and fp32 accumulation
+ *     (22-bit operands: the fp32 error class, see tsd_pack_weights16); indices at this
  *     boundary are int32 except where the reference surface hands over int64 tensors
  *     (bond_index, bond_type, atom_type, r_feat, p_feat);
  *   - hidden size H must be 64, 128 or 256 (reference config: 256).
@@ -66,6 +68,8 @@ extern "C" {
 #define TSD_STATUS_BAD_BOND 2      /* bond across graphs / self loop / index out of range */
 #define TSD_STATUS_ASYMMETRIC 4    /* bond list is not symmetric (A0 contract: both directions) */
 #define TSD_STATUS_INTERNAL 8      /* a bounded in-kernel wait of the fused step tail gave up (never expected) */
+#define TSD_STATUS_RANGE 16        /* split-f16 forward (tsd_batch.weights16): an activation left the f16 range
+                                      (|a| > 65504); the results of the call are invalid, rerun it with weights16 = NULL */
 
 typedef struct tsd_model_cfg {
     int32_t hidden;          /* config.hidden_dim == config.encoder.hidden_dim */
@@ -124,6 +128,12 @@ const char* tsd_last_error(void);
 size_t tsd_raw_weight_floats(const tsd_model_cfg* cfg);
 size_t tsd_packed_weight_floats(const tsd_model_cfg* cfg);
 int tsd_pack_weights(const tsd_model_cfg* cfg, const float* raw, float* packed, void* stream);
+/* The split-f16 image of a packed arena (0.4): the inference forward's tile GEMMs run on the f16 MFMA pipes (16x the
+ * fp32-input MFMA rate on gfx950) with every fp32 operand split into two f16 planes, a = hi + lo * 2^-11, three f16
+ * MFMAs per product, fp32 accumulation: 22 significant bits per operand, the same error class as the fp32 fma chain
+ * (csrc/split16.hpp; measured in profiles/).  `packed16` has tsd_packed_weight_floats floats: every dense matrix
+ * rewritten in place of its fp32 image as [k/16][plane][k%16/8][out][k%8] f16, everything else copied. */
+int tsd_pack_weights16(const tsd_model_cfg* cfg, const float* packed, float* packed16, void* stream);
 
 /* ---- work model (the figures every roofline fraction in bench.py is quoted against) -----------
  * Arithmetic of ONE forward of one checkpoint for a batch with the given edge counts: `enc_edges` / `out_edges`
@@ -253,6 +263,9 @@ int tsd_typed_tiles_build(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t n
 size_t tsd_bucket_weights_floats(const tsd_model_cfg* cfg, int32_t num_slots);
 int tsd_bucket_weights_build(const tsd_model_cfg* cfg, const float* packed_weights, int32_t num_slots,
                              const int32_t* keys_dev, float* out, void* stream);
+/* f16-plane image of a bucket arena (same size and slot layout, biases copied): see tsd_pack_weights16 */
+int tsd_bucket_weights16(const tsd_model_cfg* cfg, const float* bucket_weights, int32_t num_slots, float* out16,
+                         void* stream);
 
 /* ---- whole forward for M checkpoints ---------------------------------------------------- */
 typedef struct tsd_batch {
@@ -272,6 +285,14 @@ typedef struct tsd_batch {
     int32_t reserved;
     tsd_typed_tiles enc_tiles, diff_tiles;  /* static type-sorted embedding tiles, or num_tiles = 0: generic embedding */
     const float* bucket_weights;            /* [M][(enc + diff buckets) * (H*H + H)] (tsd_bucket_weights_build) or NULL */
+    /* ---- appended in 0.4: the split-f16 inference forward (see tsd_pack_weights16) ---- */
+    const float* weights16;                 /* [M, packed_floats] f16-plane image of `weights` (tsd_pack_weights16), or NULL:
+                                               the forward runs on the fp32-input MFMA */
+    const float* bucket_weights16;          /* [M][...] f16-plane image of `bucket_weights` (tsd_bucket_weights16); needed
+                                               with weights16 when bucket_weights is set */
+    int32_t* status;                        /* device word that receives TSD_STATUS_RANGE (sticky, OR-ed; the caller zeroes
+                                               and reads it); may be NULL: no range report.  In the sampling loop the
+                                               state block's flags word is used instead */
 } tsd_batch;
 
 size_t tsd_forward_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs,

@@ -5,7 +5,7 @@
 
 Every configuration runs in its own child process (one library per process), the configurations interleaved over
 `rounds` rounds; prints ms/step min / median per configuration.  LIB = path of a libtsdiff_hip.so variant
-(tools/build_variant.sh) or `default`; suffixes: `:tail0` runs the step tail as three launches, `:typed0` the generic embedding kernel."""
+(tools/build_variant.sh) or `default`; suffixes: `:tail0` runs the step tail as three launches, `:typed0` the generic embedding kernel, `:f32` the fp32-input MFMA forward."""
 import os
 import subprocess
 import sys
@@ -23,6 +23,8 @@ def child(workload, steps, lib, flags):
         _lib.LIB_PATH = lib if os.path.isabs(lib) else os.path.join(ROOT, lib)
     engine.FUSED_STEP_TAIL = "tail0" not in flags
     engine.TYPED_TILES = "typed0" not in flags
+    if "f32" in flags:
+        engine.GEMM = "f32"  # fp32-input MFMA instead of the split-f16 forward
     from bench import SamplingRun, make_models, to_dev
     from tsdiff_amd.sampler import EnsembleSampler
     dev = torch.device("cuda:0")

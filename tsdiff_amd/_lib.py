@@ -23,6 +23,7 @@ STATUS_NAN = 1
 STATUS_BAD_BOND = 2
 STATUS_ASYMMETRIC = 4
 STATUS_INTERNAL = 8
+STATUS_RANGE = 16  # split-f16 forward: an activation left the f16 range (the call is rerun on the fp32-MFMA kernels)
 
 c_i32p = C.POINTER(C.c_int32)
 c_f32p = C.POINTER(C.c_float)
@@ -103,6 +104,9 @@ class Batch(C.Structure):
         ("enc_tiles", TypedTiles),
         ("diff_tiles", TypedTiles),
         ("bucket_weights", C.c_void_p),
+        ("weights16", C.c_void_p),          # appended in 0.4: f16-plane arenas of the split-f16 forward, range word
+        ("bucket_weights16", C.c_void_p),
+        ("status", C.c_void_p),
     ]
 
 
@@ -202,6 +206,8 @@ SIGNATURES = {
                                         _P, _P, _P]),
     "tsd_bucket_weights_floats": (C.c_size_t, [_CFG, C.c_int32]),
     "tsd_bucket_weights_build": (C.c_int, [_CFG, _P, C.c_int32, _P, _P, _P]),
+    "tsd_pack_weights16": (C.c_int, [_CFG, _P, _P, _P]),
+    "tsd_bucket_weights16": (C.c_int, [_CFG, _P, C.c_int32, _P, _P]),
 }
 
 _lib = None

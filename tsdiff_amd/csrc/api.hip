@@ -75,7 +75,7 @@ int launch_typed_tiles_build(const tsd_model_cfg&, int, int, const int32_t*, con
                              int32_t*, int32_t*, int32_t*, int32_t*, hipStream_t);
 int launch_bucket_weights(const tsd_model_cfg&, const float*, int, const int32_t*, float*, hipStream_t);
 int launch_typed_embed(const tsd_model_cfg&, const float*, const tsd_batch&, const float*, float*, int, size_t,
-                       hipStream_t, const UmapRole*, const EmbedFuse0*);
+                       hipStream_t, const UmapRole*, const EmbedFuse0*, Prec);
 bool step_tail_supported(int, int, int);
 int launch_step_tail_reset(int, tsd_geometry, hipStream_t);
 int launch_step_tail(const tsd_model_cfg&, int, int, int, int, int, int, const int32_t*, const int32_t*, const uint16_t*,
@@ -194,7 +194,17 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
         return r;
     // one launch per interaction block: node chain of block l || filter GEMMs of block l+1;
     // all M checkpoints in the same launches (grid.y)
-    const float* W = b.weights;
+    // Arithmetic of the tile GEMMs: split-f16 operands on the f16 MFMA pipes when the batch carries the f16-plane
+    // arenas (csrc/split16.hpp; needs the typed embedding and the folded weights), else the fp32-input MFMA.  Every
+    // tensor in memory is fp32 either way.  The range word: the sampling loop's flags, else the batch's.
+    const bool typed = kFold && b.enc_tiles.num_tiles > 0 && b.bucket_weights != nullptr;
+    Prec prec{};
+    if (kFold && typed && b.weights16 != nullptr && b.bucket_weights16 != nullptr) {
+        prec.mode = PREC_H2;
+        prec.range_status = status ? status : b.status;
+    }
+    const bool h2 = prec.mode == PREC_H2;
+    const float* W = h2 ? b.weights16 : b.weights;
     UmapRole um{};
     um.g = g;
     um.graph_ptr = b.graph_ptr;
@@ -226,12 +236,11 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     // (batch-100 sizes only: measured 0.441 -> 0.435 ms/step at configs[1]; at configs[4] the longer embedding
     // tiles lose more than the launch saves, 50.5 -> 52.8 ms/step)
     // static type-sorted tiles (one GEMM per embedded edge instead of three) when the batch carries them
-    const bool typed = kFold && b.enc_tiles.num_tiles > 0 && b.bucket_weights != nullptr;
     // ... and with the typed embedding's small LDS tile also at configs[4] sizes (42.90 -> 42.54 ms/step; the 8-checkpoint
     // ensemble at batch 100 in between loses 0.4 %: not there)
     const bool fuse_block0 = small_fwd || (typed && (long)node_tiles_all * M >= 2048);
     if (typed) {
-        if ((r = launch_typed_embed(c, W, b, pos, w.ea, M, w.stride_ea, st, &um, fuse_block0 ? &f0 : nullptr))) return r;
+        if ((r = launch_typed_embed(c, W, b, pos, w.ea, M, w.stride_ea, st, &um, fuse_block0 ? &f0 : nullptr, prec))) return r;
     } else if ((r = launch_edge_embed2(c, W, PU, g.enc_u, w.ea, PU, g.diff_u, w.ea + (size_t)PU * H, M, w.stride_ea, st,
                                        &um, nullptr, 0, fuse_block0 ? &f0 : nullptr, kFold)))
         return r;
@@ -262,11 +271,12 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     // (only when the node chain of the last block leaves most of the chip idle: at batch 100 it occupies ~100
     // of the 256 CUs; with an ensemble or a large batch the launch is full and the extra role only adds work:
     // C2 0.518 -> 0.511 ms/step, C5 51.1 -> 51.6, M = 8 3.10 -> 3.13)
-    const bool use_pre = small_fwd;
+    // (the split-f16 forward has no separate pre role: its pair MLP is either the pair role or the stand-alone kernel)
 #ifndef TSD_PAIR_ROLE
 #define TSD_PAIR_ROLE 1  // 0 (A/B variant builds): pre role + separate pair_output launch, as in round 2
 #endif
-    const bool pair_role = use_pre && TSD_PAIR_ROLE != 0 && status != nullptr;
+    const bool pair_role = small_fwd && TSD_PAIR_ROLE != 0 && status != nullptr;
+    const bool use_pre = small_fwd && (pair_role || !h2);
     if (pair_role) {
         pre.pair = 1;
         pre.w0a = W + WL.out_w0;
@@ -286,7 +296,7 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
         if ((r = launch_layer_combo(c, W, layer, N, g.enc, wf_read, xin, layer == 0 ? b.z : w.h, w.h, xout, 0,
                                     j * tpl, j < L ? tpl : 0, PU, g.enc_u, w.ea, w.wf, w.wf_slots, M, w.stride_nh,
                                     w.stride_ea, w.stride_wf, st, (use_pre && j == L) ? &pre : nullptr, w.stride_pre,
-                                    nullptr, nullptr, kFold)))
+                                    nullptr, nullptr, kFold, prec)))
             return r;
         if (layer >= 0) {
             xin = xout;
@@ -295,7 +305,7 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     }
     if (pair_role) return TSD_OK;  // the last block launch ran the pair MLP
     return launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u, M, w.stride_nh, w.stride_ea,
-                              (size_t)PU, st, use_pre ? w.pre : nullptr, w.stride_pre, nullptr, kFold);
+                              (size_t)PU, st, use_pre ? w.pre : nullptr, w.stride_pre, nullptr, kFold, prec);
 }
 
 // one sampling step of the device-resident loop: lists (from the counts of the previous step's tail) ->
@@ -352,7 +362,7 @@ using namespace tsd;
 
 extern "C" {
 
-const char* tsd_version(void) { return "tsdiff_hip 0.3 (gfx950, fp32 MFMA)"; }
+const char* tsd_version(void) { return "tsdiff_hip 0.4 (gfx950; fp32 MFMA, split-f16 MFMA inference forward)"; }
 const char* tsd_last_error(void) { return g_err; }
 
 size_t tsd_raw_weight_floats(const tsd_model_cfg* cfg) {
@@ -369,6 +379,22 @@ int tsd_pack_weights(const tsd_model_cfg* cfg, const float* raw, float* packed, 
     if (r) return r;
     TSD_REQUIRE(raw && packed, "null weight pointer");
     return launch_pack_weights(*cfg, raw, packed, (hipStream_t)stream);
+}
+
+int tsd_pack_weights16(const tsd_model_cfg* cfg, const float* packed, float* packed16, void* stream) {
+    TraceRange range("tsd:pack_weights16");
+    int r = check_cfg(cfg);
+    if (r) return r;
+    TSD_REQUIRE(packed && packed16 && packed != packed16, "null / aliased weight pointer");
+    return launch_pack_weights16(*cfg, packed, packed16, (hipStream_t)stream);
+}
+
+int tsd_bucket_weights16(const tsd_model_cfg* cfg, const float* bucket_weights, int32_t num_slots, float* out16,
+                         void* stream) {
+    int r = check_cfg(cfg);
+    if (r) return r;
+    TSD_REQUIRE(num_slots >= 0 && (num_slots == 0 || (bucket_weights && out16 && bucket_weights != out16)), "bad argument");
+    return launch_bucket_weights16(*cfg, bucket_weights, num_slots, out16, (hipStream_t)stream);
 }
 
 int tsd_topology_build(int32_t num_nodes, int32_t num_graphs, int32_t num_pairs, int64_t num_bonds,

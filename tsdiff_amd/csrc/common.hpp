@@ -171,6 +171,16 @@ struct UmapRole {
     int n_zero;
 };
 
+// Arithmetic of the tile GEMMs of a launch: PREC_F32 = fp32-input MFMA (exact fp32 fma chains: training, piecewise entry
+// points, fallback), PREC_H2 = split-f16 operands on the f16 MFMA pipes (split16.hpp; the inference forward's default).
+// A PREC_H2 launch takes the f16-plane weight arena (tsd_pack_weights16) where the fp32 one is documented, and a device
+// word that receives TSD_STATUS_RANGE when an operand left the f16 range.
+enum : int { PREC_F32 = 0, PREC_H2 = 1 };
+struct Prec {
+    int mode = PREC_F32;
+    int32_t* range_status = nullptr;
+};
+
 // optional third role of the per-block launch (kernels_combo.hip), filled by the forward in api.hip
 struct ComboPre {
     int tiles;  // 0: no pre role
@@ -230,6 +240,7 @@ struct EmbedFuse0 {
 // launchers of the fused forward kernels shared by the inference forward (api.hip) and the training step
 // (train_step.hip); `save` != NULL selects the SAVE instantiation
 // fold: the "edge attribute" written is s1 = swish(edge_cat.0(...)) (consumers use the folded weights)
+// (the launchers below that take a `Prec` run their GEMMs in that arithmetic; W is then the matching arena)
 int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_edges ea, float* out_a, int cap_b,
                        tsd_edges eb, float* out_b, int M, size_t out_stride, hipStream_t st, const UmapRole* umap,
                        const EmbedSave* save = nullptr, int save_b_row = 0, const EmbedFuse0* fuse0 = nullptr,
@@ -239,12 +250,18 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
                        int g_count, int capacity_u, tsd_edges enc_u, const float* edge_attr, float* wf_base,
                        int wf_slots, int M, size_t nh_stride, size_t ea_stride, size_t wf_stride, hipStream_t st,
                        const ComboPre* pre, size_t pre_stride, const FilterSave* fsave = nullptr,
-                       const NodeSave* nsave = nullptr, bool folded = false);
+                       const NodeSave* nsave = nullptr, bool folded = false, Prec prec = Prec{});
 int filter_tiles_per_layer(int capacity_u);
 int launch_pair_output(const tsd_model_cfg& c, const float* W, int capacity, tsd_edges e, const float* h,
                        const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
                        size_t ea_stride, size_t inv_stride, hipStream_t st, const float* pre, size_t pre_stride,
-                       const PairSave* save = nullptr, bool folded = false);
+                       const PairSave* save = nullptr, bool folded = false, Prec prec = Prec{});
+
+int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity, tsd_edges e, const float* h,
+                         const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
+                         size_t ea_stride, size_t inv_stride, hipStream_t st, bool folded, int32_t* range_status);
+int launch_pack_weights16(const tsd_model_cfg& c, const float* packed, float* packed16, hipStream_t st);
+int launch_bucket_weights16(const tsd_model_cfg& c, const float* bucket, int num_slots, float* out16, hipStream_t st);
 
 inline bool hidden_supported(int H) { return H == 64 || H == 128 || H == 256; }
 
@@ -529,3 +546,5 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[RB][CB]) {
 __device__ __forceinline__ int acc_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 }  // namespace tsd
+
+#include "split16.hpp"

@@ -111,12 +111,18 @@ struct VRow<1> {
 // per-block launch (x = x1, the CFConv message; schnet.py:101-107) and by the backward node chain of the
 // training step (x = d loss / d agg: the same gather is the adjoint w.r.t. x1).  SAVE: rows also go to `save` [N,H].
 // -------------------------------------------------------------------------------------------------
-template <int H, bool SAVE, int NW = 2 * H / 64 /* waves of the workgroup */, int U = 8 /* edges in flight per wave */>
+// SPLIT: the tile goes to LDS as the two f16 planes of split16.hpp ([TN][H + 8] each, at `buf`) instead of fp32 rows;
+// *amax collects max |sum| for the range check.
+template <int H, bool SAVE, int NW = 2 * H / 64 /* waves of the workgroup */, int U = 8 /* edges in flight per wave */,
+          bool SPLIT = false>
 __device__ __forceinline__ void aggregate_tile(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ dst,
                                                const int32_t* __restrict__ umap, const float* __restrict__ Wf,
                                                const float* __restrict__ x, int N, int n0, float* buf,
-                                               float* __restrict__ save) {
+                                               float* __restrict__ save, float* amax = nullptr) {
     constexpr int LDA = H + 4;
+    constexpr int LDH = ldh_of(H);
+    const Planes pl = planes_at(buf, TN, LDH);
+    float amx = 0.0f;
     constexpr int RPW = TN / NW;  // rows aggregated per wave
     constexpr int V = H / 64;     // channels per lane during aggregation
     static_assert(TN % NW == 0, "");
@@ -136,9 +142,20 @@ __device__ __forceinline__ void aggregate_tile(const int32_t* __restrict__ row_p
 #pragma unroll
     for (int v = 0; v < V; ++v) s[v] = 0.0f;
     auto flush = [&]() {  // row rr is complete: its sums go to the LDS tile, the next row starts
+        if constexpr (SPLIT) {
+            const int off = (wave * RPW + rr) * LDH + lane * V;
+            if constexpr (V == 4) {
+                const f32x4 sv = {s[0], s[1], s[2], s[3]};
+                planes_store4(pl, off, sv, amx);
+            } else if constexpr (V == 2) {
+                planes_store2(pl, off, s[0], s[1], amx);
+            } else {
+                planes_store1(pl, off, s[0], amx);
+            }
+        }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            buf[(wave * RPW + rr) * LDA + lane * V + v] = s[v];
+            if constexpr (!SPLIT) buf[(wave * RPW + rr) * LDA + lane * V + v] = s[v];
             if constexpr (SAVE) {
                 if (first + rr < N) save[(size_t)(first + rr) * H + lane * V + v] = s[v];
             }
@@ -225,6 +242,9 @@ __device__ __forceinline__ void aggregate_tile(const int32_t* __restrict__ row_p
         }
     }
     while (rr < RPW) flush();  // the last row, and rows past it without edges (or past the last node): zeros
+    if constexpr (SPLIT) {
+        if (amax) *amax = fmaxf(*amax, amx);
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -629,6 +649,324 @@ __device__ __forceinline__ void pair_role(const ComboPre& q, int tile, int node_
     }
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// The three roles of the per-block launch on the f16 MFMA pipes (PREC_H2, split16.hpp): the same dataflow as
+// node_role / filter_role / pair_role above -- same inputs and outputs in memory (fp32), same LDS tile shapes -- with
+// every GEMM operand tile held in LDS as two f16 planes and every weight matrix read from the f16-plane arena.
+// -------------------------------------------------------------------------------------------------
+template <int H>
+__device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float* smem, int32_t* range_status) {
+    constexpr int LDH = ldh_of(H);
+    constexpr int NT = 2 * H, CB16 = 2, C4 = H / 4;
+    const Planes pl = planes_at(smem, TN, LDH);
+    const int n0 = tile * TN;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, l15 = lane & 15;
+    const int col0 = wave * 32;
+    const int nrows = min(TN, a.N - n0);
+    f32x4 accm[CB16], accx[CB16];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    float amax = 0.0f;
+    HRing<CB16, HRING16_R> rg;
+
+    float b_lin2[CB16], b_lin[CB16], h_res[CB16][4];
+    if (a.mode == 0) {
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) {
+            const int col = col0 + cb * 16 + l15;
+            b_lin2[cb] = a.lin2_b[col];
+            b_lin[cb] = a.lin_b[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = q * 4 + r;
+                h_res[cb][r] = row < nrows ? a.h_in[(size_t)(n0 + row) * H + col] : 0.0f;
+            }
+        }
+        aggregate_tile<H, false, 2 * H / 64, 8, true>(a.row_ptr, a.dst, a.umap, a.Wf, a.x1_in, a.N, n0, smem, nullptr, &amax);
+        hgemm16_ring_start<CB16, H>(rg, a.lin2_w, H, col0);  // (after the gather: its registers are the gather's)
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) accm[cb] = accx[cb] = zero4;
+        hgemm16_ring_run<CB16, H>(rg, pl, LDH, accm, accx);
+        hgemm16_ring_start<CB16, H>(rg, a.lin_w, H, col0);
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) {
+            const int col = col0 + cb * 16 + l15;
+            const float b = b_lin2[cb];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) planes_store1(pl, (q * 4 + r) * LDH + col, sspf(hval4(accm[cb], accx[cb], r) + b), amax);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) accm[cb] = accx[cb] = zero4;
+        hgemm16_ring_run<CB16, H>(rg, pl, LDH, accm, accx);
+        if (a.lin1_next_w != nullptr) hgemm16_ring_start<CB16, H>(rg, a.lin1_next_w, H, col0);
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) {
+            const int col = col0 + cb * 16 + l15;
+            const float b = b_lin[cb];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = q * 4 + r;
+                float hn = 0.0f;
+                if (row < nrows) {
+                    hn = h_res[cb][r] + (hval4(accm[cb], accx[cb], r) + b);
+                    if (a.ready)  // write-through (sc1): the pair tiles of this launch read the row from other CUs
+                        __hip_atomic_store(a.h + (size_t)(n0 + row) * H + col, hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        a.h[(size_t)(n0 + row) * H + col] = hn;
+                }
+                planes_store1(pl, row * LDH + col, hn, amax);
+            }
+        }
+        if (a.ready) {  // Guideline 16 R1: every storing wave drains, the workgroup meets, ONE lane raises the flag
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(a.ready + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (a.lin1_next_w == nullptr) {
+            range_report(amax, range_status);
+            return;
+        }
+        __syncthreads();
+    } else {
+        hgemm16_ring_start<CB16, H>(rg, a.lin1_next_w, H, col0);
+        for (int idx = tid; idx < TN * C4; idx += NT) {
+            const int r = idx / C4, c4 = idx % C4;
+            f32x4 v = zero4;
+            if (r < nrows) v = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)(n0 + r) * H + c4 * 4);
+            planes_store4(pl, r * LDH + c4 * 4, v, amax);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int cb = 0; cb < CB16; ++cb) accm[cb] = accx[cb] = zero4;
+    hgemm16_ring_run<CB16, H>(rg, pl, LDH, accm, accx);
+#pragma unroll
+    for (int cb = 0; cb < CB16; ++cb) {
+        const int col = col0 + cb * 16 + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = q * 4 + r;
+            if (row < nrows) a.x1_out[(size_t)(n0 + row) * H + col] = hval4(accm[cb], accx[cb], r);
+        }
+    }
+    range_report(amax, range_status);
+}
+
+template <int H>
+__device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, float* smem, int32_t* range_status) {
+    const int g = f.g_begin + item;
+    const int lrel = g / f.tiles_per_layer, tile = g - lrel * f.tiles_per_layer;
+    const float* Wb = f.Wl0 + (size_t)(f.layer0 + lrel) * f.layer_stride;
+    const float *nn0_w = Wb + f.o_nn0_w, *nn0_b = Wb + f.o_nn0_b, *nn2_w = Wb + f.o_nn2_w, *nn2_b = Wb + f.o_nn2_b;
+    float* out = f.wf + (size_t)(lrel % f.wf_slots) * f.wf_layer_stride;
+    constexpr int LDH = ldh_of(H), LDA = H + 4;
+    constexpr int NT = 2 * H, C4 = H / 4;
+    const Planes pl = planes_at(smem, T, LDH);
+    float* buf = smem;            // the finished filter tile as fp32 rows (over the planes: T (H + 4) <= T (H + 8) floats)
+    float* s_c = smem + T * LDH;  // (planes: 2 x T x LDH f16 = T x LDH floats)
+
+    const int E = *f.e.count;
+    const int e0 = tile * T;
+    if (e0 >= E) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int col0 = (tid >> 6) * 32, col = col0 + l31;
+    const int nrows = min(T, E - e0);
+    float amax = 0.0f;
+
+    HRing<1, HRING_R> rg;
+    hgemm_ring_start<1, H>(rg, nn0_w, H, col0);
+    if (tid < T) s_c[tid] = tid < nrows ? cutoff_weight(f.e.dist[e0 + tid], f.conv_cutoff, f.smooth) : 0.0f;
+    const float b0 = nn0_b[col], b2 = nn2_b[col];
+    {   // edge_attr tile -> LDS planes with every load of a thread in flight together (rows past the end clamped)
+        constexpr int NIT = T * C4 / NT;
+        static_assert(T * C4 % NT == 0, "tile / block mismatch");
+        f32x4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+            v[it] = *reinterpret_cast<const f32x4*>(f.edge_attr + (size_t)(e0 + min(r, nrows - 1)) * H + c4 * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            planes_store4(pl, r * LDH + c4 * 4, r < nrows ? v[it] : z, amax);
+        }
+    }
+    __syncthreads();
+
+    f32x16 accm[1][1], accx[1][1];
+    hzero(accm, accx);
+    hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
+    hgemm_ring_start<1, H>(rg, nn2_w, H, col0);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        planes_store1(pl, acc_row(r, hi) * LDH + col, sspf(hval(accm[0][0], accx[0][0], r) + b0), amax);
+    __syncthreads();
+
+    hzero(accm, accx);
+    hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi);
+        buf[row * LDA + col] = (hval(accm[0][0], accx[0][0], r) + b2) * s_c[row];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nrows * C4; idx += NT) {
+        const int r = idx / C4, c4 = idx % C4;
+        store_stream16(out + (size_t)(e0 + r) * H + c4 * 4, *reinterpret_cast<const f32x4*>(buf + r * LDA + c4 * 4));
+    }
+    range_report(amax, range_status);
+}
+
+template <int H>
+__device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int node_tiles, float* smem, bool defer_pre,
+                                            int32_t* range_status) {
+    constexpr int LDH = ldh_of(H), NT = 2 * H, C4 = H / 4, NW = H / 64;
+    const Planes pl = planes_at(smem, T, LDH);
+    float* s_red = smem + T * LDH;  // [NW][T]
+    int* s_src = reinterpret_cast<int*>(s_red + NW * T);
+    int* s_dst = s_src + T;
+    int* s_row = s_dst + T;
+    const int E = *q.e.count;
+    const int e0 = tile * T;
+    if (e0 >= E) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int col0 = wave * 32, col = col0 + l31;
+    const int nrows = min(T, E - e0);
+    float amax = 0.0f;
+    if (tid < T) {
+        const int ee = e0 + min(tid, nrows - 1);
+        s_src[tid] = q.e.src[ee];
+        s_dst[tid] = q.e.dst[ee];
+        s_row[tid] = q.attr_row ? q.attr_row[ee] : ee;
+    }
+    __syncthreads();
+    f32x16 accm[1][1], accx[1][1];
+    float pre_v[16];
+    auto pre_gemm = [&]() {
+        HRing<1, HRING_R> rg;
+        hgemm_ring_start<1, H>(rg, q.w0b, H, col0);
+        constexpr int NIT = T * C4 / NT;
+        f32x4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+            v[it] = *reinterpret_cast<const f32x4*>(q.edge_attr + (size_t)s_row[r] * H + c4 * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+            planes_store4(pl, r * LDH + c4 * 4, v[it], amax);
+        }
+        __syncthreads();
+        hzero(accm, accx);
+        hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
+        const float b = q.b0[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pre_v[r] = acc_row(r, hi) < nrows ? hval(accm[0][0], accx[0][0], r) + b : 0.0f;
+    };
+    if (!defer_pre) pre_gemm();
+    // wait for the node tiles that hold this tile's atoms (min .. max node id over both end points)
+    if (wave == 0 && q.ready != nullptr) {  // (ready == NULL: the stand-alone pair output, h is complete)
+        int lo = lane < T ? min(s_src[lane], s_dst[lane]) : 0x7fffffff;
+        int hn = lane < T ? max(s_src[lane], s_dst[lane]) : -1;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo = min(lo, __shfl_xor(lo, off));
+            hn = max(hn, __shfl_xor(hn, off));
+        }
+        const int t_lo = lo / TN, t_hi = hn / TN;
+        bool gave_up = false;
+        for (int t0 = t_lo; t0 <= t_hi && !gave_up; t0 += 64) {
+            const int t = t0 + lane;
+            const bool need = t <= t_hi && t < node_tiles;
+            for (unsigned spins = 0;; ++spins) {
+                const int f = need ? __hip_atomic_load(q.ready + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1;
+                if (__all(f != 0)) break;
+                if (spins > PAIR_SPIN_LIMIT) {
+                    gave_up = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(TSD_PAIR_SLEEP);
+            }
+        }
+        if (gave_up && lane == 0) atomicOr(q.status, TSD_STATUS_INTERNAL);
+    }
+    __syncthreads();  // (also: every wave is done reading the planes)
+    if (defer_pre) {
+        pre_gemm();
+        __syncthreads();
+    }
+    HRing<1, HRING_R> rg;
+    hgemm_ring_start<1, H>(rg, q.w0a, H, col0);
+    {   // h_src * h_dst -> LDS planes.  The rows were written by other CUs during this launch: sc1 loads
+        constexpr int NIT = T * C4 / NT;
+        static_assert(T * C4 % NT == 0, "tile / block mismatch");
+        f32x4 hs[NIT], hd[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+            const float* ps = q.h + (size_t)s_src[r] * H + c4 * 4;
+            const float* pd = q.h + (size_t)s_dst[r] * H + c4 * 4;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(hs[it]) : "v"(ps) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(hd[it]) : "v"(pd) : "memory");
+        }
+        static_assert(NIT == 4, "the wait statement names 2 x 4 registers");
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(hs[0]), "+v"(hs[1]), "+v"(hs[2]), "+v"(hs[3]), "+v"(hd[0]), "+v"(hd[1]), "+v"(hd[2]), "+v"(hd[3])
+                     :: "memory");
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            planes_store4(pl, r * LDH + c4 * 4, r < nrows ? hs[it] * hd[it] : z, amax);
+        }
+    }
+    // (the ring above was started before the sc1 loads: its loads are older, the vmcnt(0) there covers them too)
+    __syncthreads();
+    hzero(accm, accx);
+    hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        planes_store1(pl, acc_row(r, hi) * LDH + col, swishf(pre_v[r] + hval(accm[0][0], accx[0][0], r)), amax);
+    __syncthreads();
+    if (wave < NW) {  // H -> H/2 and the final dot: the first H/64 waves
+        const int c2 = wave * 32 + l31;
+        hzero(accm, accx);
+        hgemm_tile<1, 1, H>(pl, LDH, q.w1, H / 2, wave * 32, accm, accx);
+        const float b = q.b1[c2], w2 = q.w2[c2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float g = hval(accm[0][0], accx[0][0], r) + b, sg = swishf(g);
+            float v = sg * w2;
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 8);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 1);
+            if (l31 == 0) s_red[wave * T + acc_row(r, hi)] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < nrows) {
+        float v = s_red[tid];
+#pragma unroll
+        for (int k = 1; k < NW; ++k) v += s_red[k * T + tid];
+        q.edge_inv[e0 + tid] = v + q.b2[0];
+    }
+    range_report(amax, range_status);
+}
+
 // -------------------------------------------------------------------------------------------------
 // Backward node chain of the training step between two blocks, one tile of TN nodes per workgroup -- the adjoint
 // of the node role above, same shape (one gather + three 16-row GEMMs):
@@ -919,6 +1257,7 @@ int launch_row_gather(int H, int N, tsd_edges e, const float* W, const float* x,
 struct ComboStride {  // per-checkpoint strides (blockIdx.y = checkpoint of the ensemble)
     size_t w, nh, ea, wf, pre;
     int node_stride;  // 1: node tiles are the first workgroups; S > 1 (odd): node tile j is workgroup j * S
+    int32_t* range_status;  // PREC_H2 launches: device word for TSD_STATUS_RANGE (or NULL)
 };
 
 constexpr int NODE_RUN = 4;  // consecutive node tiles kept on one XCD (one 64-atom graph = 4 tiles)
@@ -926,7 +1265,9 @@ constexpr int NODE_RUN = 4;  // consecutive node tiles kept on one XCD (one 64-a
 // TAIL: the instantiation of the launches that carry a third role behind the filter tiles (the pair MLP of the last
 // block launch, or the pre-GEMM of the piecewise pair output): a kernel of its own name in a profile, and the plain
 // block launches do not carry its code and registers.
-template <int H, bool SAVE, bool TAIL>
+// PREC: PREC_F32 = fp32-input MFMA roles; PREC_H2 = the split-f16 roles (no SAVE form: the training step stays fp32,
+// and no pre role: the piecewise pair output computes both halves itself).
+template <int H, bool SAVE, bool TAIL, int PREC = PREC_F32>
 __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int node_tiles, ComboFilter f,
                                                             ComboStride sd, ComboPre q, FilterSave fsv,
                                                             NodeSave ns TSD_TRACE_ARG) {
@@ -977,30 +1318,94 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
         // they share a SIMD with
         __builtin_amdgcn_s_setprio(3);
         TSD_TRACE_REAL(24);
-        node_role<H, SAVE>(a, tile, smem, ns TSD_TRACE_PASS);
+        if constexpr (PREC == PREC_H2) node_role_h<H>(a, tile, smem, sd.range_status);
+        else node_role<H, SAVE>(a, tile, smem, ns TSD_TRACE_PASS);
         TSD_TRACE_REAL(25);
     } else {
         const int item = others_before;
         if (item >= f.tiles) {
             if constexpr (!TAIL) return;
-            else if (q.pair)
+            else if (q.pair) {
                 // workgroups b and b + 256 of a launch share a CU (measured; a speed assumption only): these pair tiles
                 // sit beside the node tiles
-                pair_role<H>(q, item - f.tiles, node_tiles, smem, TSD_PAIR_DEFER && b >= 256 && b - 256 < node_tiles);
-            else
+                const bool defer = TSD_PAIR_DEFER && b >= 256 && b - 256 < node_tiles;
+                if constexpr (PREC == PREC_H2) pair_role_h<H>(q, item - f.tiles, node_tiles, smem, defer, sd.range_status);
+                else pair_role<H>(q, item - f.tiles, node_tiles, smem, defer);
+            } else if constexpr (PREC == PREC_F32) {
                 pre_role<H>(q, item - f.tiles, smem);
+            }
             return;
         }
         TSD_TRACE_REAL(24);
-        filter_role<H, SAVE>(f, item, smem, fsv TSD_TRACE_PASS);
+        if constexpr (PREC == PREC_H2) filter_role_h<H>(f, item, smem, sd.range_status);
+        else filter_role<H, SAVE>(f, item, smem, fsv TSD_TRACE_PASS);
         TSD_TRACE_REAL(25);
     }
 }
 
-static inline size_t lds_combo(int H) {
-    const size_t node = (size_t)TN * (H + 4) * 4;
-    const size_t filt = (size_t)(T * (H + 4) + T) * 4;
-    const size_t pair = (size_t)(T * (H + 4) + (H / 64) * T + 3 * T) * 4;  // pair role (H >= 64)
+
+// The stand-alone pair output (tsd_pair_output's place in a forward that does not run it inside the last block
+// launch) on the f16 MFMA pipes: pair_role_h without the wait.
+template <int H>
+__global__ __launch_bounds__(2 * H) void pair_output_h_kernel(ComboPre q, size_t wstride, size_t h_stride, size_t ea_stride,
+                                                              int32_t* range_status) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const size_t m = blockIdx.y, wo = m * wstride;
+    q.edge_attr += m * ea_stride; q.w0b += wo; q.b0 += wo;
+    q.w0a += wo; q.w1 += wo; q.b1 += wo; q.w2 += wo; q.b2 += wo;
+    q.h += m * h_stride; q.edge_inv += m * q.inv_stride;
+    pair_role_h<H>(q, blockIdx.x, 0, smem, false, range_status);
+}
+int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity, tsd_edges e, const float* h,
+                         const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
+                         size_t ea_stride, size_t inv_stride, hipStream_t st, bool folded, int32_t* range_status) {
+    const WeightLayout L = weight_layout(c);
+    const size_t H = c.hidden;
+    const int tiles = (capacity + T - 1) / T;
+    if (tiles == 0) return TSD_OK;
+    ComboPre q{};
+    q.tiles = tiles;
+    q.e = e;
+    q.edge_attr = edge_attr;
+    q.attr_row = attr_row;
+    q.w0b = folded ? W16 + L.out_w0f : W16 + L.out_w0 + H * H;
+    q.b0 = W16 + (folded ? L.out_b0f : L.out_b0);
+    q.pair = 1;
+    q.w0a = W16 + L.out_w0;
+    q.w1 = W16 + L.out_w1;
+    q.b1 = W16 + L.out_b1;
+    q.w2 = W16 + L.out_w2;
+    q.b2 = W16 + L.out_b2;
+    q.h = h;
+    q.edge_inv = edge_inv;
+    q.ready = nullptr;
+    q.status = nullptr;
+    q.inv_stride = inv_stride;
+    const size_t lds = (size_t)(T * ldh_of(c.hidden) + (c.hidden / 64) * T + 3 * T) * 4;
+#define TSD_POH(HH)                                                                                              \
+    {                                                                                                            \
+        static DeviceOnce once;                                                                                  \
+        int r = allow_lds(pair_output_h_kernel<HH>, lds, once);                                                  \
+        if (r) return r;                                                                                         \
+        hipLaunchKernelGGL(pair_output_h_kernel<HH>, dim3(tiles, M), dim3(2 * HH), lds, st, q, L.total, h_stride, \
+                           ea_stride, range_status);                                                             \
+    }
+    switch (c.hidden) {
+        case 64: TSD_POH(64) break;
+        case 128: TSD_POH(128) break;
+        case 256: TSD_POH(256) break;
+        default: set_error("hidden=%d unsupported (64/128/256)", c.hidden); return TSD_ERR_INVALID;
+    }
+#undef TSD_POH
+    TSD_LAUNCH_CHECK("pair_output_h");
+    return TSD_OK;
+}
+
+static inline size_t lds_combo(int H, int prec) {
+    const int ld = prec == PREC_H2 ? ldh_of(H) : H + 4;  // floats per tile row (two f16 planes of H + 8 = H + 8 floats)
+    const size_t node = (size_t)TN * ld * 4;
+    const size_t filt = (size_t)(T * ld + T) * 4;
+    const size_t pair = (size_t)(T * ld + (H / 64) * T + 3 * T) * 4;  // pair role (H >= 64)
     return node > filt ? (node > pair ? node : pair) : (filt > pair ? filt : pair);
 }
 
@@ -1014,7 +1419,7 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
                        int layer_w0, int g_begin, int g_count,
                        int capacity_u, tsd_edges enc_u, const float* edge_attr, float* wf_base, int wf_slots, int M,
                        size_t nh_stride, size_t ea_stride, size_t wf_stride, hipStream_t st, const ComboPre* pre,
-                       size_t pre_stride, const FilterSave* fsave, const NodeSave* nsave, bool folded) {
+                       size_t pre_stride, const FilterSave* fsave, const NodeSave* nsave, bool folded, Prec prec) {
     const WeightLayout L = weight_layout(c);
     ComboNode a{};
     a.N = N;
@@ -1065,29 +1470,36 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     if (q.pair) a.ready = q.ready;  // the node role of this launch publishes h to the pair tiles
     const int grid = node_tiles + f.tiles + q.tiles;
     if (grid == 0) return TSD_OK;
-    const size_t lds = lds_combo(c.hidden);
+    const size_t lds = lds_combo(c.hidden, prec.mode);
     // interleave only when the launch is many chip-fulls deep (the node tiles alone over-subscribe the chip)
     int node_stride = 1;
     if (node_tiles >= 1024 && grid >= 3 * node_tiles) {
         node_stride = grid / node_tiles;
         if (node_stride % 2 == 0) --node_stride;
     }
-    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, pre_stride, node_stride};
+    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, pre_stride, node_stride, prec.range_status};
+    if (prec.mode == PREC_H2 && (fsave || nsave || (q.tiles > 0 && !q.pair))) {
+        set_error("internal: the split-f16 block launch has no saving form and no pre role");
+        return TSD_ERR_INVALID;
+    }
 #ifdef TSD_TRACE
 #define TSD_TRACE_HOST , g_tsd_trace_host
 #else
 #define TSD_TRACE_HOST
 #endif
-#define TSD_COMBO_I(HH, SV, TL)                                                                             \
+#define TSD_COMBO_I(HH, SV, TL, PR)                                                                         \
     {                                                                                                       \
         static DeviceOnce once;                                                                             \
-        int r = allow_lds(layer_combo_kernel<HH, SV, TL>, lds, once);                                       \
+        int r = allow_lds(layer_combo_kernel<HH, SV, TL, PR>, lds, once);                                   \
         if (r) return r;                                                                                    \
-        hipLaunchKernelGGL((layer_combo_kernel<HH, SV, TL>), dim3(grid, M), dim3(2 * HH), lds, st, a, node_tiles, f, \
+        hipLaunchKernelGGL((layer_combo_kernel<HH, SV, TL, PR>), dim3(grid, M), dim3(2 * HH), lds, st, a, node_tiles, f, \
                            sd, q, fsv, nsv TSD_TRACE_HOST);                                                 \
     }
 #define TSD_COMBO(HH)                                                                                       \
-    if (save) TSD_COMBO_I(HH, true, false) else if (q.tiles > 0) TSD_COMBO_I(HH, false, true) else TSD_COMBO_I(HH, false, false)
+    if (prec.mode == PREC_H2) {                                                                             \
+        if (q.tiles > 0) TSD_COMBO_I(HH, false, true, PREC_H2) else TSD_COMBO_I(HH, false, false, PREC_H2)   \
+    } else if (save) TSD_COMBO_I(HH, true, false, PREC_F32)                                                  \
+    else if (q.tiles > 0) TSD_COMBO_I(HH, false, true, PREC_F32) else TSD_COMBO_I(HH, false, false, PREC_F32)
     const bool save = fsave != nullptr || nsave != nullptr;
     const FilterSave fsv = fsave ? *fsave : FilterSave{};
     const NodeSave nsv = nsave ? *nsave : NodeSave{};

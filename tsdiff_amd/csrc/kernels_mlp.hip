@@ -1088,7 +1088,15 @@ int launch_node_lin1(const tsd_model_cfg& c, const float* W, int layer, int N, c
 int launch_pair_output(const tsd_model_cfg& c, const float* W, int capacity, tsd_edges e, const float* h,
                        const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
                        size_t ea_stride, size_t inv_stride, hipStream_t st, const float* pre, size_t pre_stride,
-                       const PairSave* save, bool folded) {
+                       const PairSave* save, bool folded, Prec prec) {
+    if (prec.mode == PREC_H2) {
+        if (save || pre) {
+            set_error("internal: the split-f16 pair output has no saving form and takes no precomputed half");
+            return TSD_ERR_INVALID;
+        }
+        return launch_pair_output_h(c, W, capacity, e, h, edge_attr, attr_row, edge_inv, M, h_stride, ea_stride, inv_stride,
+                                    st, folded, prec.range_status);
+    }
     const WeightLayout L = weight_layout(c);
     PairW w{W + L.out_w0, W + L.out_b0, W + L.out_w1, W + L.out_b1, W + L.out_w2, W + L.out_b2,
             folded ? W + L.out_w0f : W + L.out_w0 + (size_t)c.hidden * c.hidden,  // packed [k/4][out][k%4]: the k >= H half is contiguous
@@ -1129,6 +1137,59 @@ static int copy_one(const float* src, float* dst, int n, hipStream_t st) {
     hipLaunchKernelGGL(copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, dst, n);
     TSD_LAUNCH_CHECK("copy");
     return TSD_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// f16-plane image of packed matrices (split16.hpp): fp32 packed [k/4][out][k%4]  ->  [k/16][plane][k%16/8][out][k%8] f16
+// in the same bytes.  One thread per element; `count` equally shaped matrices `stride` floats apart (blockIdx.y).
+// ---------------------------------------------------------------------------------------------
+__global__ void split16_kernel(const float* __restrict__ src, float* __restrict__ dst, int nout, int nin, size_t stride) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nout * nin) return;
+    src += (size_t)blockIdx.y * stride;
+    f16* d = reinterpret_cast<f16*>(dst + (size_t)blockIdx.y * stride);
+    const int col = idx % nout, k = idx / nout;
+    const float a = src[((size_t)(k >> 2) * nout + col) * 4 + (k & 3)];
+    const f16 h = (f16)a;
+    const f16 l = (f16)((a - (float)h) * SPLIT_SCALE);
+    const int ks = k >> 4, half = (k >> 3) & 1, e = k & 7;
+    d[((((size_t)ks * 2 + 0) * 2 + half) * nout + col) * 8 + e] = h;
+    d[((((size_t)ks * 2 + 1) * 2 + half) * nout + col) * 8 + e] = l;
+}
+static int split_mats(const float* src, float* dst, int nout, int nin, int count, size_t stride, hipStream_t st) {
+    if (count <= 0) return TSD_OK;
+    if (nin % 16 != 0) {
+        set_error("internal: split16 needs K %% 16 == 0 (K = %d)", nin);
+        return TSD_ERR_INVALID;
+    }
+    const int n = nout * nin;
+    hipLaunchKernelGGL(split16_kernel, dim3((n + 255) / 256, count), dim3(256), 0, st, src, dst, nout, nin, stride);
+    TSD_LAUNCH_CHECK("split16");
+    return TSD_OK;
+}
+int launch_pack_weights16(const tsd_model_cfg& c, const float* packed, float* packed16, hipStream_t st) {
+    const WeightLayout L = weight_layout(c);
+    const int H = c.hidden;
+    int r;
+    TSD_HIP(hipMemcpyAsync(packed16, packed, L.total * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if ((r = split_mats(packed + L.emlp_w1, packed16 + L.emlp_w1, H, H, 1, 0, st))) return r;
+    if ((r = split_mats(packed + L.ecat_w0, packed16 + L.ecat_w0, H, 2 * H, 1, 0, st))) return r;
+    if ((r = split_mats(packed + L.ecat_w1, packed16 + L.ecat_w1, H, H, 1, 0, st))) return r;
+    const size_t lo[6] = {L.L_nn0_w, L.L_nn2_w, L.L_lin1_w, L.L_lin2_w, L.L_lin_w, L.L_nn0f_w};
+    for (int i = 0; i < 6; ++i)
+        if ((r = split_mats(packed + L.layer0 + lo[i], packed16 + L.layer0 + lo[i], H, H, c.num_convs, L.layer_stride, st)))
+            return r;
+    if ((r = split_mats(packed + L.out_w0, packed16 + L.out_w0, H, 2 * H, 1, 0, st))) return r;
+    if ((r = split_mats(packed + L.out_w1, packed16 + L.out_w1, H / 2, H, 1, 0, st))) return r;
+    if ((r = split_mats(packed + L.out_w0f, packed16 + L.out_w0f, H, H, 1, 0, st))) return r;
+    return TSD_OK;
+}
+int launch_bucket_weights16(const tsd_model_cfg& c, const float* bucket, int num_slots, float* out16, hipStream_t st) {
+    if (num_slots <= 0) return TSD_OK;
+    const size_t H = c.hidden, per = H * H + H;
+    TSD_HIP(hipMemcpyAsync(out16, bucket, (size_t)num_slots * per * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return split_mats(bucket, out16, c.hidden, c.hidden, num_slots, per, st);
 }
 
 size_t raw_weight_floats(const tsd_model_cfg& c) {

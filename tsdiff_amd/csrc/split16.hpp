@@ -1,0 +1,233 @@
+// split16.hpp -- the tile GEMM of the inference forward on the f16 MFMA pipes with fp32-class accuracy ("f16x2").
+//
+// gfx950 runs v_mfma_f32_32x32x16_f16 at 16x the rate of the fp32-input MFMA (MI355X_MICROARCH.md: 2.5 PFLOP/s dense
+// against 157 TFLOP/s), and has no TF32-like middle form.  Every fp32 operand is therefore SPLIT into two f16 planes
+//     a = a_hi + a_lo * 2^-11,   a_hi = f16(a),   a_lo = f16((a - a_hi) * 2^11)          (22 significant bits)
+// and a product a . b is evaluated as THREE f16 MFMAs with fp32 accumulation
+//     acc_m += a_hi b_hi ;   acc_x += a_hi b_lo + a_lo b_hi ;   result = acc_m + acc_x * 2^-11
+// (the dropped a_lo b_lo term is 2^-22 relative).  The low planes are stored scaled by 2^11, so they never reach the
+// f16 subnormal range before the value itself is below ~1e-8: the representation error is max(2^-23 |a|, ~1e-11)
+// whatever the magnitude, the accumulation is the MFMA's fp32.  Measured (tools/mfma_probe4.hip, K = 256, softplus-like
+// activations): max error against an fp64 GEMM 6.0e-7 of the result scale, an fp32 fma chain 5.0e-7 -- the same class.
+// What the split cannot represent is |a| > 65504 (f16 range): every conversion tracks max|a|, a kernel that saw a
+// larger value raises TSD_STATUS_RANGE and the host reruns the call on the fp32-MFMA kernels (tsdiff_amd/engine.py).
+//
+// Weights: tsd_pack_weights16 rewrites every dense matrix of the packed fp32 arena IN THE SAME BYTES (hi + lo planes =
+// 4 bytes per element) as  [k/16][plane][k%16 / 8][out][k%8]  f16 -- a lane's B fragment of one k-step (16 k for the
+// 32x32x16 MFMA: 8 consecutive k of one output column) is one aligned 16-byte load, a wave reads two 512-byte runs;
+// the 16x16x32 MFMA of the 16-row node tiles reads the same image (its four lane quarters take (k-step, half) pairs).
+// Biases, embeddings and narrow layers are copied verbatim, so a kernel takes ONE arena pointer in either precision.
+// The A operand lives in LDS as two planes [rows][H + 8] f16 (row stride = 4 banks mod 64: ds_read_b128 conflict-free).
+//
+// The B feed is the counted asm ring of common.hpp (R k-steps in flight per wave).
+#pragma once
+
+namespace tsd {
+
+using f16 = _Float16;
+using f16x8 = f16 __attribute__((ext_vector_type(8)));
+using f16x4 = f16 __attribute__((ext_vector_type(4)));
+using f16x2 = f16 __attribute__((ext_vector_type(2)));
+
+constexpr float SPLIT_SCALE = 2048.0f, SPLIT_INV = 1.0f / 2048.0f;
+constexpr float F16_MAX = 65504.0f;
+
+constexpr int ldh_of(int H) { return H + 8; }                                  // f16 elements per LDS row of one plane
+constexpr size_t planes_bytes(int rows, int H) { return (size_t)rows * ldh_of(H) * 2 * 2; }  // both planes
+
+struct Planes {
+    f16* hi;
+    f16* lo;
+};
+__device__ __forceinline__ Planes planes_at(void* smem, int rows, int ldh) {
+    f16* p = reinterpret_cast<f16*>(smem);
+    return Planes{p, p + rows * ldh};
+}
+
+// amax: running max |a| of everything this thread converted (range check, one v_max per element)
+__device__ __forceinline__ void split1(float a, f16& h, f16& l, float& amax) {
+    amax = fmaxf(amax, fabsf(a));
+    h = (f16)a;
+    l = (f16)((a - (float)h) * SPLIT_SCALE);
+}
+__device__ __forceinline__ void planes_store1(const Planes& p, int off, float a, float& amax) {
+    f16 h, l;
+    split1(a, h, l, amax);
+    p.hi[off] = h;
+    p.lo[off] = l;
+}
+// four consecutive elements (off a multiple of 4): one 8-byte store per plane
+__device__ __forceinline__ void planes_store4(const Planes& p, int off, const f32x4& a, float& amax) {
+    f16x4 h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f16 hh, ll;
+        split1(a[i], hh, ll, amax);
+        h[i] = hh;
+        l[i] = ll;
+    }
+    *reinterpret_cast<f16x4*>(p.hi + off) = h;
+    *reinterpret_cast<f16x4*>(p.lo + off) = l;
+}
+// two column-adjacent elements (off even): one 4-byte store per plane
+__device__ __forceinline__ void planes_store2(const Planes& p, int off, float a0, float a1, float& amax) {
+    f16x2 h, l;
+    f16 hh, ll;
+    split1(a0, hh, ll, amax);
+    h[0] = hh; l[0] = ll;
+    split1(a1, hh, ll, amax);
+    h[1] = hh; l[1] = ll;
+    *reinterpret_cast<f16x2*>(p.hi + off) = h;
+    *reinterpret_cast<f16x2*>(p.lo + off) = l;
+}
+// the range flag of a workgroup role: any thread that converted a value beyond the f16 range (or a NaN's neighbour inf)
+__device__ __forceinline__ void range_report(float amax, int32_t* status) {
+    if (status != nullptr && !(amax <= F16_MAX)) atomicOr(status, TSD_STATUS_RANGE);
+}
+
+__device__ __forceinline__ f32x16 mfma_h32(const f32x4& a, const f32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_h16(const f32x4& a, const f32x4& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// B ring: R k-steps in flight, each CB column blocks x 2 planes of one float4 (8 f16) per lane
+template <int CB, int R>
+struct HRing {
+    f32x4 b[R][CB][2];
+    const char* base;  // wave-uniform: packed matrix (+ first k-step of this GEMM)
+    unsigned voff;     // lane byte offset inside a k-step
+    int step_bytes, plane_bytes, cb_bytes;
+};
+template <int CB>
+__device__ __forceinline__ void hring_issue(f32x4 (&b)[CB][2], const char* __restrict__ sbase, unsigned voff,
+                                            int plane_bytes, int cb_bytes) {
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const char* sb = sbase + (size_t)cb * cb_bytes + (size_t)p * plane_bytes;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[cb][p]) : "v"(voff), "s"(sb) : "memory");
+        }
+}
+template <int N, int CB>
+__device__ __forceinline__ void hring_wait(f32x4 (&b)[CB][2]) {
+    static_assert(CB == 1 || CB == 2, "");
+    if constexpr (CB == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[0][0]), "+v"(b[0][1]) : "n"(N) : "memory");
+    if constexpr (CB == 2)
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) : "n"(N) : "memory");
+}
+
+constexpr int HRING_R = 4;    // k-steps in flight, 32-row GEMMs (CB = 1: 8 fragments = 32 VGPRs)
+constexpr int HRING16_R = 3;  // 32-k steps in flight, 16-row GEMMs (CB = 2: 12 fragments = 48 VGPRs)
+
+// ---- 32-row blocks: v_mfma_f32_32x32x16_f16.  A lane l: row l & 31, k = 8 (l >> 5) .. + 7 of the k-step; B lane l:
+// column l & 31, the same k; C/D as the fp32 32x32 MFMA (acc_row).  KS = K / 16 k-steps.
+template <int CB, int K>
+__device__ __forceinline__ void hgemm_ring_start(HRing<CB, HRING_R>& r, const float* __restrict__ Bp16, int nout, int col0) {
+    const int lane = threadIdx.x & 63;
+    r.base = reinterpret_cast<const char*>(Bp16);
+    r.voff = (unsigned)(((lane >> 5) * nout + col0 + (lane & 31)) * 16);
+    r.step_bytes = 64 * nout;   // 2 planes x 2 halves x nout x 16 B
+    r.plane_bytes = 32 * nout;
+    r.cb_bytes = 32 * 16;
+    constexpr int KS = K / 16;
+    static_for<0, (HRING_R < KS ? HRING_R : KS)>([&](auto i) {
+        constexpr int I = decltype(i)::value;
+        hring_issue<CB>(r.b[I], r.base + (size_t)I * r.step_bytes, r.voff, r.plane_bytes, r.cb_bytes);
+    });
+}
+template <int RB, int CB, int K>
+__device__ __forceinline__ void hgemm_ring_run(HRing<CB, HRING_R>& r, const Planes& A, int ldh, f32x16 (&accm)[RB][CB],
+                                               f32x16 (&accx)[RB][CB]) {
+    constexpr int R = HRING_R, KS = K / 16;
+    const int lane = threadIdx.x & 63;
+    const int aoff = (lane & 31) * ldh + (lane >> 5) * 8;
+    static_for<0, KS>([&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;
+        constexpr int slot = ks % R;
+        constexpr int younger = ((ks + R <= KS) ? R : KS - ks) - 1;
+        f32x4 ah[RB], al[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            ah[rb] = *reinterpret_cast<const f32x4*>(A.hi + aoff + rb * 32 * ldh + ks * 16);
+            al[rb] = *reinterpret_cast<const f32x4*>(A.lo + aoff + rb * 32 * ldh + ks * 16);
+        }
+        hring_wait<younger * CB * 2, CB>(r.b[slot]);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                accx[rb][cb] = mfma_h32(ah[rb], r.b[slot][cb][1], accx[rb][cb]);
+                accm[rb][cb] = mfma_h32(ah[rb], r.b[slot][cb][0], accm[rb][cb]);
+                accx[rb][cb] = mfma_h32(al[rb], r.b[slot][cb][0], accx[rb][cb]);
+            }
+        if constexpr (ks + R < KS)
+            hring_issue<CB>(r.b[slot], r.base + (size_t)(ks + R) * r.step_bytes, r.voff, r.plane_bytes, r.cb_bytes);
+    });
+}
+template <int RB, int CB, int K>
+__device__ __forceinline__ void hgemm_tile(const Planes& A, int ldh, const float* __restrict__ Bp16, int nout, int col0,
+                                           f32x16 (&accm)[RB][CB], f32x16 (&accx)[RB][CB]) {
+    HRing<CB, HRING_R> r;
+    hgemm_ring_start<CB, K>(r, Bp16, nout, col0);
+    hgemm_ring_run<RB, CB, K>(r, A, ldh, accm, accx);
+}
+template <int RB, int CB>
+__device__ __forceinline__ void hzero(f32x16 (&accm)[RB][CB], f32x16 (&accx)[RB][CB]) {
+    zero_acc(accm);
+    zero_acc(accx);
+}
+__device__ __forceinline__ float hval(const f32x16& m, const f32x16& x, int r) { return fmaf(x[r], SPLIT_INV, m[r]); }
+
+// ---- 16-row blocks: v_mfma_f32_16x16x32_f16 (node tiles).  A lane l: row l & 15, k = 8 (l >> 4) .. + 7 of a 32-k step;
+// B lane l: column l & 15, the same k; C/D: col = l & 15, row = (l >> 4) * 4 + r.  One 32-k step = two 16-k steps of the
+// packed image: lane quarter q takes k-step 2 s + (q >> 1), half q & 1.  CB = 16-wide column blocks of this wave.
+template <int CB, int K>
+__device__ __forceinline__ void hgemm16_ring_start(HRing<CB, HRING16_R>& r, const float* __restrict__ Bp16, int nout, int col0) {
+    const int lane = threadIdx.x & 63, q = lane >> 4;
+    r.base = reinterpret_cast<const char*>(Bp16);
+    r.voff = (unsigned)((q >> 1) * 64 * nout + ((q & 1) * nout + col0 + (lane & 15)) * 16);
+    r.step_bytes = 128 * nout;  // two 16-k steps
+    r.plane_bytes = 32 * nout;
+    r.cb_bytes = 16 * 16;
+    constexpr int KS = K / 32;
+    static_for<0, (HRING16_R < KS ? HRING16_R : KS)>([&](auto i) {
+        constexpr int I = decltype(i)::value;
+        hring_issue<CB>(r.b[I], r.base + (size_t)I * r.step_bytes, r.voff, r.plane_bytes, r.cb_bytes);
+    });
+}
+template <int CB, int K>
+__device__ __forceinline__ void hgemm16_ring_run(HRing<CB, HRING16_R>& r, const Planes& A, int ldh, f32x4 (&accm)[CB],
+                                                 f32x4 (&accx)[CB]) {
+    constexpr int R = HRING16_R, KS = K / 32;
+    const int lane = threadIdx.x & 63;
+    const int aoff = (lane & 15) * ldh + (lane >> 4) * 8;
+    static_for<0, KS>([&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;
+        constexpr int slot = ks % R;
+        constexpr int younger = ((ks + R <= KS) ? R : KS - ks) - 1;
+        const f32x4 ah = *reinterpret_cast<const f32x4*>(A.hi + aoff + ks * 32);
+        const f32x4 al = *reinterpret_cast<const f32x4*>(A.lo + aoff + ks * 32);
+        hring_wait<younger * CB * 2, CB>(r.b[slot]);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            accx[cb] = mfma_h16(ah, r.b[slot][cb][1], accx[cb]);
+            accm[cb] = mfma_h16(ah, r.b[slot][cb][0], accm[cb]);
+            accx[cb] = mfma_h16(al, r.b[slot][cb][0], accx[cb]);
+        }
+        if constexpr (ks + R < KS)
+            hring_issue<CB>(r.b[slot], r.base + (size_t)(ks + R) * r.step_bytes, r.voff, r.plane_bytes, r.cb_bytes);
+    });
+}
+template <int CB, int K>
+__device__ __forceinline__ void hgemm16_tile(const Planes& A, int ldh, const float* __restrict__ Bp16, int nout, int col0,
+                                             f32x4 (&accm)[CB], f32x4 (&accx)[CB]) {
+    HRing<CB, HRING16_R> r;
+    hgemm16_ring_start<CB, K>(r, Bp16, nout, col0);
+    hgemm16_ring_run<CB, K>(r, A, ldh, accm, accx);
+}
+__device__ __forceinline__ float hval4(const f32x4& m, const f32x4& x, int r) { return fmaf(x[r], SPLIT_INV, m[r]); }
+
+}  // namespace tsd

@@ -86,6 +86,13 @@ _SIDE_STREAMS = {}
 # static type-sorted embedding tiles (kernels_typed.hip); "0" keeps the generic embedding kernel (A/B, tests)
 TYPED_TILES = os.environ.get("TSDIFF_TYPED_TILES", "1") != "0"
 MAX_TYPE_BUCKETS = 96  # (type_r, type_p) pairs per batch whose folded matrices are kept (H = 256: 25 MB per checkpoint)
+# Arithmetic of the inference forward's tile GEMMs (csrc/split16.hpp): "h2" = split-f16 operands on the f16 MFMA pipes
+# (22-bit operands, fp32 accumulation: the fp32 error class at several times the fp32-input MFMA's rate; the default),
+# "f32" = fp32-input MFMA (exact fp32 fma chains).  A call whose activations leave the f16 range (|a| > 65504,
+# TSD_STATUS_RANGE) is rerun in "f32" by the host.  Training always runs fp32.
+GEMM = os.environ.get("TSDIFF_GEMM", "h2")
+if GEMM not in ("h2", "f32"):
+    raise ValueError(f"TSDIFF_GEMM={GEMM!r}: expected 'h2' or 'f32'")
 # tests / tools flip this to run the sampling loop's step tail as the three separate launches (bit-identical results)
 FUSED_STEP_TAIL = os.environ.get("TSDIFF_FUSED_TAIL", "1") != "0"
 
@@ -267,6 +274,7 @@ class DeviceBatch:
         self.ready_event = None  # set by a build on a side stream (prefetch): consumers wait for it, stream to stream
         self._plans = {}  # (kind, clip, clip_pos) -> tsd_sampler_plan* of the bound checkpoints
         self._plan_streams = {}  # streams the plans were launched on (drop_plans waits for them)
+        self.gemm = None  # None: the module default (GEMM); "f32" after a range fallback on this batch
 
     def owned_tensors(self):
         """every device tensor this object holds right now (arenas, inputs, typed-tile buffers): what a build on a
@@ -322,6 +330,8 @@ class DeviceBatch:
             self.workspace = torch.empty(max(nws, 1), dtype=torch.float32, device=self.device)
         self.edge_inv_u = torch.zeros(M, max(self.P // 2, 1), dtype=torch.float32, device=self.device)
         self.bucket_weights = None
+        self.weights16 = None
+        self.bucket_weights16 = None
         if self.typed is not None and TYPED_TILES:
             t = self.typed
             ns = t["nb_e"] + t["nb_d"]
@@ -330,6 +340,14 @@ class DeviceBatch:
             for m in range(M):  # folded once per (batch, checkpoint), fp64 accumulation
                 check(lib.tsd_bucket_weights_build(C.byref(self.cfg), ptr(self.weights[m]), ns, ptr(t["slot_keys"]),
                                                    ptr(self.bucket_weights[m]), stream_ptr()))
+            # the f16-plane images of both arenas (split-f16 forward: needs the typed embedding)
+            self.weights16 = torch.empty_like(self.weights)
+            self.bucket_weights16 = torch.empty_like(self.bucket_weights)
+            for m in range(M):
+                check(lib.tsd_pack_weights16(C.byref(self.cfg), ptr(self.weights[m]), ptr(self.weights16[m]),
+                                             stream_ptr()))
+                check(lib.tsd_bucket_weights16(C.byref(self.cfg), ptr(self.bucket_weights[m]), ns,
+                                               ptr(self.bucket_weights16[m]), stream_ptr()))
         self.M = M
         self._z_key = key
 
@@ -339,7 +357,13 @@ class DeviceBatch:
                         attr_row=self.attr_row.data_ptr(), pair2out=self.pair2out.data_ptr(),
                         pair2u=self.pair2u.data_ptr(), scratch=self.geo_scratch.data_ptr())
 
+    def gemm_mode(self):
+        """'h2' (split-f16 MFMA) or 'f32' for the next forward / sampling call on this batch"""
+        mode = self.gemm or GEMM
+        return mode if (mode == "h2" and self.weights16 is not None and self.bucket_weights16 is not None) else "f32"
+
     def struct(self):
+        h2 = self.gemm_mode() == "h2"
         return Batch(
             num_nodes=self.N, num_graphs=self.G, num_pairs=self.P, num_models=self.M,
             graph_ptr=self.graph_ptr.data_ptr(), node_graph=self.node_graph.data_ptr(),
@@ -350,7 +374,10 @@ class DeviceBatch:
             # 0 = "unknown": the library then runs the step tail as three launches (A/B switch for tests / tools)
             max_graph_nodes=self.max_n if FUSED_STEP_TAIL else 0,
             enc_tiles=self._tiles_struct("enc"), diff_tiles=self._tiles_struct("diff"),
-            bucket_weights=None if self.bucket_weights is None else self.bucket_weights.data_ptr())
+            bucket_weights=None if self.bucket_weights is None else self.bucket_weights.data_ptr(),
+            weights16=self.weights16.data_ptr() if h2 else None,
+            bucket_weights16=self.bucket_weights16.data_ptr() if h2 else None,
+            status=self.status.data_ptr())
 
     def _tiles_struct(self, which):
         t = self.typed
@@ -390,7 +417,31 @@ class DeviceBatch:
         pos = pos.to(torch.float32).contiguous()
         b = self.struct()
         check(lib.tsd_score_forward(C.byref(self.cfg), C.byref(b), ptr(pos), stream_ptr()))
+        self.range_pending = self.gemm_mode() == "h2"
         return pos
+
+    def forward_out_edges(self, pos):
+        """forward(pos) and the number of directed out edges, in ONE host read (the edge count and -- split-f16 forward
+        -- the range flag); a call that left the f16 range is rerun on the fp32-MFMA kernels"""
+        self.forward(pos)
+        if not self.range_pending:
+            return self.out.num_edges()
+        words = torch.stack([self.out.count[0], self.status[0]]).cpu()
+        if self.range_fallback(int(words[1])):
+            self.forward(pos)
+            return self.out.num_edges()
+        return int(words[0])
+
+    def range_fallback(self, word):
+        """True when a split-f16 call reported TSD_STATUS_RANGE: the batch is switched to the fp32-MFMA kernels (the
+        caller reruns the call).  `word`: the status word the caller has read anyway."""
+        if not (int(word) & _lib.STATUS_RANGE):
+            return False
+        self.status[:1].zero_()
+        if self.gemm_mode() != "h2":
+            raise _lib.TsdError("internal: TSD_STATUS_RANGE from an fp32 forward")
+        self.gemm = "f32"
+        return True
 
     def ensemble_mean(self):
         """directed edge_inv (reference order): mean over the checkpoints, expanded through out.umap"""
@@ -438,7 +489,8 @@ class DeviceBatch:
     def sampler_plan(self, kind, clip, clip_pos):
         """the captured + instantiated hipGraph of one sampling step for the bound checkpoints; built once and
         replayed by every later dynamic_sampling call on this batch (reference loop: models/sampler.py:187-254)"""
-        key = (int(kind), float(clip), float(-1.0 if clip_pos is None else clip_pos), bool(FUSED_STEP_TAIL), bool(TYPED_TILES))
+        key = (int(kind), float(clip), float(-1.0 if clip_pos is None else clip_pos), bool(FUSED_STEP_TAIL), bool(TYPED_TILES),
+               self.gemm_mode())
         plan = self._plans.get(key)
         if plan is None:
             lib = _lib.load()

@@ -219,9 +219,8 @@ class CondenseEncoderEpsNetwork(nn.Module):
             return edge_inv, edge_index, edge_length
         packed = self.packed_weights()
         db.bind_models([packed], key=("single", id(self), self._packed_key))
-        db.forward(pos)
+        E = db.forward_out_edges(pos)  # the one host sync (the reference's nonzero() syncs as well)
         mean = db.ensemble_mean()  # M = 1: expands the undirected result to the directed edge order
-        E = db.out.num_edges()  # the one host sync (the reference's nonzero() syncs as well)
         edge_inv = mean[:E].clone().unsqueeze(-1)
         if not return_edges:
             return edge_inv

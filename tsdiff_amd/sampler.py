@@ -44,9 +44,8 @@ class EnsembleSampler(nn.Module):
     def forward(self, atom_type, r_feat, p_feat, pos, bond_index, bond_type, batch, time_step,
                 return_edges=True, **kwargs):
         db = self._bound_batch(atom_type, r_feat, p_feat, bond_index, bond_type, batch)
-        db.forward(pos)
+        E = db.forward_out_edges(pos)
         mean = db.ensemble_mean()
-        E = db.out.num_edges()
         edge_inv = mean[:E].clone().unsqueeze(-1)
         if not return_edges:
             return edge_inv
@@ -136,6 +135,7 @@ class EnsembleSampler(nn.Module):
                 noise = kwargs.get("init_noise", None)
                 if noise is None:
                     noise = torch.randn(pos_init.size(), device=dev)
+                    kwargs["init_noise"] = noise  # (a rerun after a range fallback starts from the same draw)
                 alpha_t = self.alphas[denoise_from_time_t - 1]
                 alpha_s = self.alphas[noise_from_time_t - 1] if noise_from_time_t != 0 else 1
                 sigma = ((1.0 - (alpha_t / alpha_s)) / alpha_t).sqrt()
@@ -191,6 +191,13 @@ class EnsembleSampler(nn.Module):
                 elif return_traj:
                     pos_traj += list(traj.cpu().unbind(0))
             status = int(status_host[0]) if status_host is not None else int(db.status[0].item())  # the host sync of the loop
+            if db.range_fallback(status):
+                # split-f16 forward: an activation left the f16 range somewhere in the run -- the whole call again on the
+                # fp32-MFMA kernels (same draws: injected, or the same Philox seed)
+                kw = dict(kwargs, noises=noises, seed=seed)
+                return self.dynamic_sampling(atom_type, r_feat, p_feat, pos_init, bond_index, bond_type, batch, num_graphs,
+                                             extend_order, extend_radius, n_steps, step_lr, clip, clip_pos,
+                                             denoise_from_time_t, noise_from_time_t, **kw)
             if status & _lib.STATUS_INTERNAL:
                 raise _lib.TsdError("internal: a bounded wait of the fused step tail gave up (TSD_STATUS_INTERNAL)")
             if status & _lib.STATUS_NAN:
