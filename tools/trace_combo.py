@@ -25,10 +25,12 @@ from tsdiff_amd.sampler import EnsembleSampler  # noqa: E402
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "c2"
     fl_arg = int(sys.argv[2]) if len(sys.argv) > 2 else 3   # filter layer of the traced launch (-1: node role only)
+    h2 = (sys.argv[3] if len(sys.argv) > 3 else "h2") == "h2"  # split-f16 roles (default) or the fp32-MFMA ones
     dev = torch.device("cuda:0")
     lib = _lib.load()
     dbg = C.CDLL(_lib.LIB_PATH).tsd_debug_trace
     dbg.argtypes = [C.c_void_p]
+    C.CDLL(_lib.LIB_PATH).tsd_debug_prec(1 if h2 else 0)
     cfg = synth.DEFAULT_MODEL_CONFIG
     H, L = 256, 7
     model = make_models(cfg, [0], dev)[0]
@@ -53,7 +55,7 @@ def main():
 
     def blk(layer, fl):
         _lib.check(lib.tsd_interaction_block(
-            C.byref(db.cfg), _lib.ptr(db.weights[0]), layer, N, db.enc.struct(), _lib.ptr(wf[0]), _lib.ptr(xa),
+            C.byref(db.cfg), _lib.ptr(db.weights16[0] if h2 else db.weights[0]), layer, N, db.enc.struct(), _lib.ptr(wf[0]), _lib.ptr(xa),
             _lib.ptr(hbuf), _lib.ptr(xb), fl, PU, db.enc_u.struct(), _lib.ptr(ea), _lib.ptr(wf[1]), _lib.stream_ptr()))
     for _ in range(5):
         blk(2, fl_arg)
@@ -67,6 +69,16 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     dbg(C.c_void_p(0))
+    # the same launch 50 times back to back (no tracing): average time per launch against the traced span of one
+    for _ in range(3):
+        blk(2, fl_arg)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(50):
+        blk(2, fl_arg)
+    ev1.record()
+    torch.cuda.synchronize()
+    print(f"50 untraced launches back to back: {ev0.elapsed_time(ev1) * 1e3 / 50:.2f} us per launch")
     t = trace.cpu().numpy().reshape(grid, 32).astype(np.int64)
     role = (t[:, 31] >> 40) & 255
     hw = t[:, 31] & 0xFFFFFFFF
@@ -78,10 +90,10 @@ def main():
         if m.any():
             t[m, :31] -= t[m, 0].min()
     t0 = 0
-    ev_us = ev0.elapsed_time(ev1) * 1e3
+    ev_us = 0.0
     span = max(t[role == r][:, 6 if r == 2 else 7].max() for r in (1, 2) if (role == r).any())
     tick_us, tn = 1.0 / 2400.0, "assumed 2.4 GHz shader clock"
-    print(f"launch {ev_us:.1f} us by events; longest traced XCD span {span} ticks = {span * tick_us:.1f} us ({tn})")
+    print(f"longest traced XCD span {span} ticks = {span * tick_us:.1f} us ({tn})")
     names = {1: ["start", "aggregated", "gemm lin2", "epi+bar", "gemm lin", "epi+bar", "gemm lin1", "stored"],
              2: ["start", "A tile in LDS", "gemm nn0", "ssp+bar", "gemm nn2", "epi+bar", "stored"]}
     for r, rn in ((1, "node role"), (2, "filter role")):

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Timeline of the one-launch forward from a -DTSD_TRACE variant build (wall_clock64 stamps, 100 MHz):
+    tools/build_variant.sh mtrace "-DTSD_MEGA_TRACE" kernels_combo.hip && python tools/trace_mega.py"""
+import ctypes as C, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tsdiff_amd import _lib, synth
+_lib.LIB_PATH = os.environ.get("TSDIFF_LIB", os.path.join(ROOT, "tools", "bin", "lib_mtrace.so"))
+from bench import make_models, to_dev
+from tsdiff_amd.sampler import EnsembleSampler
+dev = torch.device("cuda:0")
+lib = _lib.load()
+dbg = C.CDLL(_lib.LIB_PATH).tsd_debug_mega_trace
+dbg.argtypes = [C.c_void_p]
+cfg = synth.DEFAULT_MODEL_CONFIG
+model = make_models(cfg, [0], dev)[0]
+g = to_dev(synth.wb97xd3_like_batch(100, seed=1000), dev)
+g["pos"] = torch.randn(g["pos"].shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1234)) * 1.5
+s = EnsembleSampler([model])
+def fwd():
+    with torch.no_grad():
+        s(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"], None)
+for _ in range(3): fwd()
+torch.cuda.synchronize()
+buf = np.zeros(8192 * 4, dtype=np.uint64)
+assert dbg(buf.ctypes.data_as(C.c_void_p)) == 0   # clear what the warm-up calls wrote
+fwd(); torch.cuda.synchronize()
+assert dbg(buf.ctypes.data_as(C.c_void_p)) == 0
+t = buf.astype(np.int64).reshape(-1, 4)
+t = t[t[:, 1] > 0]
+t0 = t[:, 1].min()
+us = lambda x: (x - t0) / 100.0
+names = {1: "embed", 2: "node", 3: "filter", 4: "pair", 0: "umap/other"}
+print(f"{len(t)} workgroups traced; launch span {us(t[:, 2].max()):.1f} us")
+for r in (1, 2, 3, 4, 0):
+    m = t[:, 0] == r
+    if not m.any(): continue
+    st, en = us(t[m, 1]), us(t[m, 2]) if r else us(t[m, 1])
+    print(f"{names[r]:10s} n={m.sum():5d} start min/med/max {st.min():7.1f} {np.median(st):7.1f} {st.max():7.1f}   end min/med/max {en.min():7.1f} {np.median(en):7.1f} {en.max():7.1f}  dur med {np.median(en - st):6.1f}")
+m = t[:, 0] == 3
+if m.any():
+    for l in range(1, 7):
+        ml = m & (t[:, 3] == l)
+        if ml.any():
+            print(f"  filter layer {l}: start med {np.median(us(t[ml, 1])):7.1f}  end med {np.median(us(t[ml, 2])):7.1f} max {us(t[ml, 2]).max():7.1f}")

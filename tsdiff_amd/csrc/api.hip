@@ -132,6 +132,9 @@ struct Workspace {
     float *h, *x1, *x1b;  // [M][N, H]
     float *pre;  // [M][P/2, H]: node-independent half of the pair MLP's first layer (ComboPre)
     int32_t* ready;  // [M][node tiles] readiness flags of the last launch (pair role), zeroed by the embedding launch
+    int32_t* ctl;    // control words of the one-launch forward (kernels_combo.hip MegaCtl), zeroed by the host per run
+    size_t ctl_words;
+    float* x1m;      // one-launch forward: [L - 1][N, H] x1 of every block (a buffer is written once per launch)
     size_t stride_ea, stride_wf, stride_nh, stride_pre;
     int wf_slots;
     size_t total;
@@ -143,6 +146,14 @@ constexpr int WF_RING = 2;
 #endif
 constexpr bool kFold = TSD_FOLD != 0;
 
+#ifndef TSD_MEGA
+#define TSD_MEGA 1  // 0 (A/B variant builds): the split-f16 forward as one launch per block
+#endif
+// shapes the one-launch forward takes: every node workgroup resident at once, one checkpoint
+static bool mega_shape(const tsd_model_cfg& c, int N, int M) {
+    return TSD_MEGA != 0 && M == 1 && N > 0 && (N + TSD_NODE_TILE - 1) / TSD_NODE_TILE <= 256 && c.num_convs <= 60;
+}
+
 static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base) {
     Workspace w;
     const size_t H = c.hidden, PU = (size_t)P / 2;
@@ -151,6 +162,8 @@ static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base)
     auto pad = [](size_t n) { return (n + 63) & ~size_t(63); };
     w.stride_ea = pad(2 * PU * H);
     w.wf_slots = c.num_convs < WF_RING ? c.num_convs : WF_RING;
+    // the one-launch forward (one checkpoint, <= 256 node tiles) keeps the filters of every block (no ring)
+    if (mega_shape(c, N, M)) w.wf_slots = c.num_convs;
     w.stride_wf = pad((size_t)w.wf_slots * PU * H);
     w.stride_nh = pad((size_t)N * H);
     w.ea = take(w.stride_ea * M);
@@ -161,6 +174,9 @@ static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base)
     w.stride_pre = pad(PU * H);
     w.pre = take(w.stride_pre * M);
     w.ready = reinterpret_cast<int32_t*>(take(pad((size_t)M * ((N + TSD_NODE_TILE - 1) / TSD_NODE_TILE))));
+    w.ctl_words = pad(mega_ctl_words(N));
+    w.ctl = reinterpret_cast<int32_t*>(take(w.ctl_words));
+    w.x1m = take(mega_shape(c, N, M) && c.num_convs > 1 ? w.stride_nh * (size_t)(c.num_convs - 1) : 0);
     w.total = o;
     return w;
 }
@@ -174,9 +190,11 @@ static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base)
 // the previous step built them): no count / scan / fill launches at all.
 // status: device word for TSD_STATUS_INTERNAL (sampling loop: the state block's flags); NULL: the pair MLP runs as its
 // own launch (no in-launch waits anywhere in the forward).
+// epoch_src / epoch_bias (sampling loop): the device word and offset that number the forwards of a run 1, 2, ... (the
+// one-launch forward's hand-off words are monotonic and zeroed once per run); NULL: a stand-alone forward zeroes them.
 static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float* pos, hipStream_t st,
                         bool counts_ready = false, int32_t* advance = nullptr, bool lists_ready = false,
-                        int32_t* status = nullptr) {
+                        int32_t* status = nullptr, const int32_t* epoch_src = nullptr, int epoch_bias = 1) {
     const int N = b.num_nodes, P = b.num_pairs, M = b.num_models;
     const int PU = P / 2, L = c.num_convs;
     const size_t H = c.hidden;
@@ -205,6 +223,7 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     }
     const bool h2 = prec.mode == PREC_H2;
     const float* W = h2 ? b.weights16 : b.weights;
+    const bool mega = h2 && mega_shape(c, N, M) && prec.range_status != nullptr && P > 0 && !(b.reserved & 1);
     UmapRole um{};
     um.g = g;
     um.graph_ptr = b.graph_ptr;
@@ -238,12 +257,23 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     // static type-sorted tiles (one GEMM per embedded edge instead of three) when the batch carries them
     // ... and with the typed embedding's small LDS tile also at configs[4] sizes (42.90 -> 42.54 ms/step; the 8-checkpoint
     // ensemble at batch 100 in between loses 0.4 %: not there)
-    const bool fuse_block0 = small_fwd || (typed && (long)node_tiles_all * M >= 2048);
+    const bool fuse_block0 = small_fwd || mega || (typed && (long)node_tiles_all * M >= 2048);
     if (typed) {
         if ((r = launch_typed_embed(c, W, b, pos, w.ea, M, w.stride_ea, st, &um, fuse_block0 ? &f0 : nullptr, prec))) return r;
     } else if ((r = launch_edge_embed2(c, W, PU, g.enc_u, w.ea, PU, g.diff_u, w.ea + (size_t)PU * H, M, w.stride_ea, st,
                                        &um, nullptr, 0, fuse_block0 ? &f0 : nullptr, kFold)))
         return r;
+    if (mega) {
+        // the L block launches and the pair MLP as ONE launch (kernels_combo.hip forward_mega_kernel): node workgroups
+        // persistent over the blocks, filter tiles, pair tiles, in-launch hand-offs instead of launch boundaries
+        if (epoch_src == nullptr) {
+            TSD_HIP(hipMemsetAsync(w.ctl, 0, w.ctl_words * sizeof(int32_t), st));
+            epoch_src = w.ctl + 32;  // (MegaCtl::LAYER0, the counter of block 0's filter tiles: never counted, stays 0)
+            epoch_bias = 1;
+        }
+        return launch_forward_mega(c, b, pos, W, w.ea, w.wf, w.h, w.x1m, w.stride_nh, w.ctl, epoch_src, epoch_bias,
+                                   prec.range_status, st);
+    }
     // block 0 reads z (residual input) and x1_0 = lin1_0(z) straight from the per-batch arrays -- both are
     // pos independent (computed at bind time) -- so no per-step copy of z and no lin1 launch
     if (w.stride_nh != (size_t)N * H) {
@@ -318,11 +348,13 @@ static int step_impl(const tsd_model_cfg& c, const tsd_batch& b, int kind, float
                      tsd_sampler_state* state, hipStream_t st) {
     int r;
     if (use_step_tail(b)) {
-        if ((r = forward_impl(c, b, pos, st, true, nullptr, true, &state->flags))) return r;
+        // (the fused tail leaves step = -1 after its list-only launch and + 1 per step: forward k of a run reads k - 2)
+        if ((r = forward_impl(c, b, pos, st, true, nullptr, true, &state->flags, &state->step, 2))) return r;
         return launch_step_tail(c, kind, b.num_nodes, b.num_graphs, b.num_models, b.num_pairs, b.max_graph_nodes,
                                 b.graph_ptr, b.pair_ptr, b.pair_code, b.geo, b.edge_inv_u, clip, clip_pos, pos, state, st);
     }
-    if ((r = forward_impl(c, b, pos, st, true, &state->step, false, &state->flags))) return r;
+    // (the scan kernel of the list build advances step from -1 before the forward: forward k of a run reads k - 1)
+    if ((r = forward_impl(c, b, pos, st, true, &state->step, false, &state->flags, &state->step, 1))) return r;
     return launch_step_post(c, kind, b.num_nodes, b.num_graphs, b.num_models, b.num_pairs, b.graph_ptr, b.pair_ptr,
                             b.pair_code, b.geo, b.edge_inv_u, clip, clip_pos, pos, state, st);
 }
@@ -517,10 +549,15 @@ int tsd_interaction_block(const tsd_model_cfg* cfg, const float* w, int32_t laye
     TSD_REQUIRE(layer < 0 || (Wf_layer && x1_in && enc.row_ptr && enc.dst && enc.umap && x1_in != x1_out),
                 "node role needs Wf_layer, x1_in != x1_out and the directed enc list");
     TSD_REQUIRE(filter_layer < 0 || (edge_attr && Wf_out && enc_u.count && enc_u.dist), "filter role: null pointer");
+    Prec prec{};
+#ifdef TSD_TRACE
+    extern int g_tsd_debug_prec;  // (kernels_combo.hip, variant builds: the traced launch in the split-f16 arithmetic)
+    prec.mode = g_tsd_debug_prec;
+#endif
     return launch_layer_combo(*cfg, w, layer, num_nodes, enc, Wf_layer, x1_in, nullptr, h, x1_out,
                               filter_layer < 0 ? 0 : filter_layer, 0,
                               filter_layer < 0 ? 0 : filter_tiles_per_layer(capacity_u), capacity_u, enc_u, edge_attr,
-                              Wf_out, 1, 1, 0, 0, 0, (hipStream_t)stream, nullptr, 0);
+                              Wf_out, 1, 1, 0, 0, 0, (hipStream_t)stream, nullptr, 0, nullptr, nullptr, false, prec);
 }
 
 int tsd_cfconv_aggregate(int32_t hidden, int32_t num_nodes, const int32_t* row_ptr, const int32_t* dst,
@@ -666,6 +703,10 @@ int tsd_sampler_plan_run(tsd_sampler_plan* plan, int32_t n_steps, const tsd_run_
     const tsd_batch& b = plan->batch;
     int r;
     if ((r = launch_set_run_args(plan->state, *args, st))) return r;
+    {   // the hand-off words of the one-launch forward count the forwards of THIS run
+        const Workspace wm = carve(plan->cfg, b.num_nodes, b.num_pairs, b.num_models, b.workspace);
+        TSD_HIP(hipMemsetAsync(wm.ctl, 0, wm.ctl_words * sizeof(int32_t), st));
+    }
     if (use_step_tail(b)) {
         // the first step's lists: the fused tail in its list-only form (epoch 1 of the run's ticket counter); every
         // later step finds the lists its predecessor's tail built

@@ -197,7 +197,8 @@ struct ComboPre {
     const float *w0a, *w1, *b1, *w2, *b2;  // packed W0 rows k in [0, H); layers 1, 2
     const float* h;           // final node states [N, H] (written by the node role of this launch)
     float* edge_inv;          // [capacity_u]
-    int32_t* ready;           // [M][node tiles] flags: 1 = the tile's rows of h are in memory
+    int32_t* ready;           // [M][node tiles] flags: >= ready_target = the tile's rows of h are in memory
+    int ready_target = 1;     // (per-block launches: flags are 0 / 1; one-launch forward: epoch * 64 + blocks)
     int32_t* status;          // TSD_STATUS_INTERNAL on a wait that gave up
     size_t inv_stride;        // per-checkpoint stride of edge_inv
 };
@@ -261,6 +262,11 @@ int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity,
                          const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
                          size_t ea_stride, size_t inv_stride, hipStream_t st, bool folded, int32_t* range_status);
 int launch_pack_weights16(const tsd_model_cfg& c, const float* packed, float* packed16, hipStream_t st);
+// the whole split-f16 forward of one checkpoint as ONE launch (kernels_combo.hip, small batches)
+int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float* pos, const float* W16, float* ea, float* wf,
+                        float* h, float* x1m, size_t x1_stride, int32_t* ctl, const int32_t* epoch_src, int epoch_bias,
+                        int32_t* status, hipStream_t st);
+size_t mega_ctl_words(int N);
 int launch_bucket_weights16(const tsd_model_cfg& c, const float* bucket, int num_slots, float* out16, hipStream_t st);
 
 inline bool hidden_supported(int H) { return H == 64 || H == 128 || H == 256; }

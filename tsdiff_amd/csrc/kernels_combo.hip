@@ -11,6 +11,7 @@
 //
 // Both roles run with 2H threads = H/32 waves, 32 output columns per wave.
 #include "train_internal.hpp"
+#include "typed_tile.hpp"
 
 // Phase timeline of the per-block launch (variant builds only: tools/build_variant.sh trace "-DTSD_TRACE";
 // tools/trace_combo.py reads it).  32 u64 slots per workgroup: [0..7] s_memtime at phase boundaries (wave 0), [8..15] / [16..23] every wave's end of its
@@ -19,6 +20,11 @@
 static unsigned long long* g_tsd_trace_host = nullptr;  // variant builds only
 extern "C" int tsd_debug_trace(void* buf) {
     g_tsd_trace_host = (unsigned long long*)buf;
+    return 0;
+}
+int g_tsd_debug_prec = 0;  // variant builds only: tsd_interaction_block runs the split-f16 roles (w = the f16-plane arena)
+extern "C" int tsd_debug_prec(int prec) {
+    g_tsd_debug_prec = prec;
     return 0;
 }
 #define TSD_TRACE_AT(slot)                                                                                      \
@@ -46,6 +52,7 @@ extern "C" int tsd_debug_trace(void* buf) {
     } while (0)
 #define TSD_TRACE_ARG , unsigned long long* trace_buf
 #define TSD_TRACE_PASS , trace_buf
+#define TSD_TRACE_NULL , nullptr
 #else
 #define TSD_TRACE_AT(slot)
 #define TSD_TRACE_WAVE(base)
@@ -53,6 +60,7 @@ extern "C" int tsd_debug_trace(void* buf) {
 #define TSD_TRACE_REAL(slot)
 #define TSD_TRACE_ARG
 #define TSD_TRACE_PASS
+#define TSD_TRACE_NULL
 #endif
 
 namespace tsd {
@@ -113,8 +121,10 @@ struct VRow<1> {
 // -------------------------------------------------------------------------------------------------
 // SPLIT: the tile goes to LDS as the two f16 planes of split16.hpp ([TN][H + 8] each, at `buf`) instead of fp32 rows;
 // *amax collects max |sum| for the range check.
+// SC1: the rows are loaded with `sc1` (from L2, never this CU's L1): the one-launch forward gathers rows that other CUs
+// wrote during the launch into buffers this CU may have read an older version of.
 template <int H, bool SAVE, int NW = 2 * H / 64 /* waves of the workgroup */, int U = 8 /* edges in flight per wave */,
-          bool SPLIT = false>
+          bool SPLIT = false, bool SC1 = false>
 __device__ __forceinline__ void aggregate_tile(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ dst,
                                                const int32_t* __restrict__ umap, const float* __restrict__ Wf,
                                                const float* __restrict__ x, int N, int n0, float* buf,
@@ -123,6 +133,11 @@ __device__ __forceinline__ void aggregate_tile(const int32_t* __restrict__ row_p
     constexpr int LDH = ldh_of(H);
     const Planes pl = planes_at(buf, TN, LDH);
     float amx = 0.0f;
+    // (the asm loads below take these through "s" operands: wave-uniform as the compiler can see it, split16.hpp)
+    dst = reinterpret_cast<const int32_t*>(uniform_ptr(dst));
+    umap = reinterpret_cast<const int32_t*>(uniform_ptr(umap));
+    Wf = reinterpret_cast<const float*>(uniform_ptr(Wf));
+    x = reinterpret_cast<const float*>(uniform_ptr(x));
     constexpr int RPW = TN / NW;  // rows aggregated per wave
     constexpr int V = H / 64;     // channels per lane during aggregation
     static_assert(TN % NW == 0, "");
@@ -203,7 +218,16 @@ __device__ __forceinline__ void aggregate_tile(const int32_t* __restrict__ row_p
             const int we = live ? ud[u] : ud[0], j = live ? jd[u] : jd[0];
             const float* wrow = Wf + (size_t)we * H;
             const float* xrow = x + (size_t)j * H;
-            if constexpr (V == 4) {
+            if constexpr (V == 4 && SC1) {
+                asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(wv[u]) : "v"(lane_b), "s"(wrow) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(xv[u]) : "v"(lane_b), "s"(xrow) : "memory");
+            } else if constexpr (V == 2 && SC1) {
+                asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(wv[u]) : "v"(lane_b), "s"(wrow) : "memory");
+                asm volatile("global_load_dwordx2 %0, %1, %2 sc1" : "=v"(xv[u]) : "v"(lane_b), "s"(xrow) : "memory");
+            } else if constexpr (SC1) {
+                asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(wv[u]) : "v"(lane_b), "s"(wrow) : "memory");
+                asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(xv[u]) : "v"(lane_b), "s"(xrow) : "memory");
+            } else if constexpr (V == 4) {
                 asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wv[u]) : "v"(lane_b), "s"(wrow) : "memory");
                 asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(xv[u]) : "v"(lane_b), "s"(xrow) : "memory");
             } else if constexpr (V == 2) {
@@ -576,8 +600,8 @@ __device__ __forceinline__ void pair_role(const ComboPre& q, int tile, int node_
             const int t = t0 + lane;
             const bool need = t <= t_hi && t < node_tiles;
             for (unsigned spins = 0;; ++spins) {
-                const int f = need ? __hip_atomic_load(q.ready + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1;
-                if (__all(f != 0)) break;
+                const int f = need ? __hip_atomic_load(q.ready + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+                if (__all(f >= q.ready_target)) break;
                 if (spins > PAIR_SPIN_LIMIT) {
                     gave_up = true;
                     break;
@@ -656,7 +680,7 @@ __device__ __forceinline__ void pair_role(const ComboPre& q, int tile, int node_
 // every GEMM operand tile held in LDS as two f16 planes and every weight matrix read from the f16-plane arena.
 // -------------------------------------------------------------------------------------------------
 template <int H>
-__device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float* smem, int32_t* range_status) {
+__device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float* smem, int32_t* range_status TSD_TRACE_ARG) {
     constexpr int LDH = ldh_of(H);
     constexpr int NT = 2 * H, CB16 = 2, C4 = H / 4;
     const Planes pl = planes_at(smem, TN, LDH);
@@ -671,6 +695,8 @@ __device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float*
     HRing<CB16, HRING16_R> rg;
 
     float b_lin2[CB16], b_lin[CB16], h_res[CB16][4];
+    TSD_TRACE_ID(1);
+    TSD_TRACE_AT(0);
     if (a.mode == 0) {
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
@@ -685,11 +711,15 @@ __device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float*
         }
         aggregate_tile<H, false, 2 * H / 64, 8, true>(a.row_ptr, a.dst, a.umap, a.Wf, a.x1_in, a.N, n0, smem, nullptr, &amax);
         hgemm16_ring_start<CB16, H>(rg, a.lin2_w, H, col0);  // (after the gather: its registers are the gather's)
+        TSD_TRACE_WAVE(16);
         __syncthreads();
+        TSD_TRACE_AT(1);
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) accm[cb] = accx[cb] = zero4;
         hgemm16_ring_run<CB16, H>(rg, pl, LDH, accm, accx);
         hgemm16_ring_start<CB16, H>(rg, a.lin_w, H, col0);
+        TSD_TRACE_WAVE(8);
+        TSD_TRACE_AT(2);
         __syncthreads();
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
@@ -699,10 +729,12 @@ __device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float*
             for (int r = 0; r < 4; ++r) planes_store1(pl, (q * 4 + r) * LDH + col, sspf(hval4(accm[cb], accx[cb], r) + b), amax);
         }
         __syncthreads();
+        TSD_TRACE_AT(3);
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) accm[cb] = accx[cb] = zero4;
         hgemm16_ring_run<CB16, H>(rg, pl, LDH, accm, accx);
         if (a.lin1_next_w != nullptr) hgemm16_ring_start<CB16, H>(rg, a.lin1_next_w, H, col0);
+        TSD_TRACE_AT(4);
         __syncthreads();
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
@@ -742,9 +774,11 @@ __device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float*
         }
         __syncthreads();
     }
+    TSD_TRACE_AT(5);
 #pragma unroll
     for (int cb = 0; cb < CB16; ++cb) accm[cb] = accx[cb] = zero4;
     hgemm16_ring_run<CB16, H>(rg, pl, LDH, accm, accx);
+    TSD_TRACE_AT(6);
 #pragma unroll
     for (int cb = 0; cb < CB16; ++cb) {
         const int col = col0 + cb * 16 + l15;
@@ -754,11 +788,12 @@ __device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float*
             if (row < nrows) a.x1_out[(size_t)(n0 + row) * H + col] = hval4(accm[cb], accx[cb], r);
         }
     }
+    TSD_TRACE_AT(7);
     range_report(amax, range_status);
 }
 
 template <int H>
-__device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, float* smem, int32_t* range_status) {
+__device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, float* smem, int32_t* range_status TSD_TRACE_ARG) {
     const int g = f.g_begin + item;
     const int lrel = g / f.tiles_per_layer, tile = g - lrel * f.tiles_per_layer;
     const float* Wb = f.Wl0 + (size_t)(f.layer0 + lrel) * f.layer_stride;
@@ -778,6 +813,8 @@ __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, fl
     const int col0 = (tid >> 6) * 32, col = col0 + l31;
     const int nrows = min(T, E - e0);
     float amax = 0.0f;
+    TSD_TRACE_ID(2);
+    TSD_TRACE_AT(0);
 
     HRing<1, HRING_R> rg;
     hgemm_ring_start<1, H>(rg, nn0_w, H, col0);
@@ -786,12 +823,14 @@ __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, fl
     {   // edge_attr tile -> LDS planes with every load of a thread in flight together (rows past the end clamped)
         constexpr int NIT = T * C4 / NT;
         static_assert(T * C4 % NT == 0, "tile / block mismatch");
-        f32x4 v[NIT];
+        static_assert(NIT == 4, "ld16_wait4 names four registers");
+        f32x4 v[NIT];  // (sc1: in the one-launch forward the rows were stored by other workgroups of this launch)
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
-            v[it] = *reinterpret_cast<const f32x4*>(f.edge_attr + (size_t)(e0 + min(r, nrows - 1)) * H + c4 * 4);
+            ld16_sc1(v[it], f.edge_attr + (size_t)(e0 + min(r, nrows - 1)) * H + c4 * 4);
         }
+        ld16_wait4(v);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
@@ -800,19 +839,25 @@ __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, fl
         }
     }
     __syncthreads();
+    TSD_TRACE_AT(1);
 
     f32x16 accm[1][1], accx[1][1];
     hzero(accm, accx);
     hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
     hgemm_ring_start<1, H>(rg, nn2_w, H, col0);
+    TSD_TRACE_WAVE(8);
+    TSD_TRACE_AT(2);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r)
         planes_store1(pl, acc_row(r, hi) * LDH + col, sspf(hval(accm[0][0], accx[0][0], r) + b0), amax);
     __syncthreads();
+    TSD_TRACE_AT(3);
 
     hzero(accm, accx);
     hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
+    TSD_TRACE_WAVE(16);
+    TSD_TRACE_AT(4);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -820,10 +865,12 @@ __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, fl
         buf[row * LDA + col] = (hval(accm[0][0], accx[0][0], r) + b2) * s_c[row];
     }
     __syncthreads();
+    TSD_TRACE_AT(5);
     for (int idx = tid; idx < nrows * C4; idx += NT) {
         const int r = idx / C4, c4 = idx % C4;
         store_stream16(out + (size_t)(e0 + r) * H + c4 * 4, *reinterpret_cast<const f32x4*>(buf + r * LDA + c4 * 4));
     }
+    TSD_TRACE_AT(6);
     range_report(amax, range_status);
 }
 
@@ -854,19 +901,21 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
     float pre_v[16];
     auto pre_gemm = [&]() {
         HRing<1, HRING_R> rg;
-        hgemm_ring_start<1, H>(rg, q.w0b, H, col0);
         constexpr int NIT = T * C4 / NT;
-        f32x4 v[NIT];
+        static_assert(NIT == 4, "ld16_wait4 names four registers");
+        f32x4 v[NIT];  // (sc1: see filter_role_h)
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
-            v[it] = *reinterpret_cast<const f32x4*>(q.edge_attr + (size_t)s_row[r] * H + c4 * 4);
+            ld16_sc1(v[it], q.edge_attr + (size_t)s_row[r] * H + c4 * 4);
         }
+        ld16_wait4(v);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
             planes_store4(pl, r * LDH + c4 * 4, v[it], amax);
         }
+        hgemm_ring_start<1, H>(rg, q.w0b, H, col0);  // (behind the staging: its registers are free now)
         __syncthreads();
         hzero(accm, accx);
         hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
@@ -890,8 +939,8 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
             const int t = t0 + lane;
             const bool need = t <= t_hi && t < node_tiles;
             for (unsigned spins = 0;; ++spins) {
-                const int f = need ? __hip_atomic_load(q.ready + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1;
-                if (__all(f != 0)) break;
+                const int f = need ? __hip_atomic_load(q.ready + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+                if (__all(f >= q.ready_target)) break;
                 if (spins > PAIR_SPIN_LIMIT) {
                     gave_up = true;
                     break;
@@ -907,7 +956,6 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
         __syncthreads();
     }
     HRing<1, HRING_R> rg;
-    hgemm_ring_start<1, H>(rg, q.w0a, H, col0);
     {   // h_src * h_dst -> LDS planes.  The rows were written by other CUs during this launch: sc1 loads
         constexpr int NIT = T * C4 / NT;
         static_assert(T * C4 % NT == 0, "tile / block mismatch");
@@ -931,7 +979,7 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
             planes_store4(pl, r * LDH + c4 * 4, r < nrows ? hs[it] * hd[it] : z, amax);
         }
     }
-    // (the ring above was started before the sc1 loads: its loads are older, the vmcnt(0) there covers them too)
+    hgemm_ring_start<1, H>(rg, q.w0a, H, col0);  // (behind the staging: its registers are free now)
     __syncthreads();
     hzero(accm, accx);
     hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
@@ -1318,7 +1366,7 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
         // they share a SIMD with
         __builtin_amdgcn_s_setprio(3);
         TSD_TRACE_REAL(24);
-        if constexpr (PREC == PREC_H2) node_role_h<H>(a, tile, smem, sd.range_status);
+        if constexpr (PREC == PREC_H2) node_role_h<H>(a, tile, smem, sd.range_status TSD_TRACE_PASS);
         else node_role<H, SAVE>(a, tile, smem, ns TSD_TRACE_PASS);
         TSD_TRACE_REAL(25);
     } else {
@@ -1337,12 +1385,14 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
             return;
         }
         TSD_TRACE_REAL(24);
-        if constexpr (PREC == PREC_H2) filter_role_h<H>(f, item, smem, sd.range_status);
+        if constexpr (PREC == PREC_H2) filter_role_h<H>(f, item, smem, sd.range_status TSD_TRACE_PASS);
         else filter_role<H, SAVE>(f, item, smem, fsv TSD_TRACE_PASS);
         TSD_TRACE_REAL(25);
     }
 }
 
+
+int filter_tiles_per_layer(int capacity_u);
 
 // The stand-alone pair output (tsd_pair_output's place in a forward that does not run it inside the last block
 // launch) on the f16 MFMA pipes: pair_role_h without the wait.
@@ -1410,6 +1460,380 @@ static inline size_t lds_combo(int H, int prec) {
 }
 
 int filter_tiles_per_layer(int capacity_u) { return (capacity_u + T - 1) / T; }
+
+// =================================================================================================
+// THE INTERACTION BLOCKS AND THE PAIR MLP AS ONE LAUNCH (split-f16 arithmetic, small batches, one checkpoint).
+//
+// With the GEMMs on the f16 MFMA pipes a per-block launch at batch 100 is 25 us of which ~7 us are the launch itself
+// (its 508 workgroups are dispatched at ~8 ns each and the kernel boundary drains and refills the chip) and ~17 us the
+// node chain, a latency chain that occupies 100 of the 256 CUs.  Here the L launches behind the embedding launch become
+// roles of one grid, ordered by blockIdx (= dispatch order):
+//   [node workgroups: ONE per node tile, persistent over all L blocks]
+//   [filter tiles of blocks 1 .. L-1, block-major]  [pair tiles]
+// (the embedding launch before it still carries the filters of block 0 and the directed -> undirected map), and the
+// launch boundaries become hand-offs (cdna_hip_programming.md Guideline 16: 16-byte write-through payload, every
+// storing wave drains, ONE lane publishes; relaxed agent-scope polls by one wave; consumers read handed-off rows with
+// sc1 loads, and no buffer is written twice within the launch -- an sc1 load is served by the XCD's L2, which would
+// keep the line of an earlier read):
+//   layer_done[l] counter, + 1 per filter tile of block l >= 1 -> node workgroups entering block l
+//   node_done[t] = epoch * 64 + (blocks tile t has published x1 / h for)
+//                -> the node tiles that hold atoms of the same graphs (block l + 1 gathers x1 rows of the whole graph),
+//                   pair tiles (final h)
+// All words are monotonic: a counter's target is epoch * count, where epoch = the number of this launch since the host
+// zeroed the block (once per run / per stand-alone forward), derived from the device-side step counter of the sampling
+// loop (it advances between two launches; graph replay freezes kernel arguments): nothing is zeroed per launch.
+// Waits are bounded (TSD_STATUS_INTERNAL instead of a hang).  No workgroup waits for one that is dispatched after it,
+// except the node workgroups among themselves and for filter tiles -- they are all resident (node tiles <= 256 is a
+// launch condition; filter tiles never wait), so in-order dispatch is enough for progress.
+// Results are bit-identical to the launch-per-block split-f16 forward (same GEMMs, same gather order).
+//
+// REGISTERS.  The kernel must fit 128 VGPRs (two resident workgroups per CU) WITHOUT an occupancy cap: under
+// __launch_bounds__(2 H, 4) the compiler spills and splits live ranges beside the asm-issued ring loads, whose
+// destination registers it believes written at the statement (measured: wrong results in one build, 3x slower tiles in
+// another).  tools/check_async_loads.py proves the absence of such accesses for the compiled binary.
+// =================================================================================================
+#ifdef TSD_MEGA_TRACE  // (variant builds: tools/trace_mega.py) 4 u64 per workgroup: role, start, end, aux
+__device__ unsigned long long g_mega_trace[8192 * 4];
+#define TSD_MEGA_T(slot, val)                                                                           \
+    do {                                                                                                \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_mega_trace[(size_t)blockIdx.x * 4 + (slot)] = (val); \
+    } while (0)
+extern "C" int tsd_debug_mega_trace(void* host_buf) {  // copies the buffer out and clears it
+    hipError_t e = hipMemcpyFromSymbol(host_buf, HIP_SYMBOL(g_mega_trace), sizeof(g_mega_trace));
+    if (e != hipSuccess) return (int)e;
+    static unsigned long long zeros[8192 * 4];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mega_trace), zeros, sizeof(zeros));
+}
+#else
+#define TSD_MEGA_T(slot, val)
+#endif
+struct MegaCtl {  // int32 words in the forward workspace
+    // one counter per 128-byte line (arrivals and polls of different blocks do not share a line / an L2 channel);
+    // LAYER0 itself (block 0 has no filter tiles in this launch) is never counted and stays 0
+    static constexpr int LAYER0 = 32, LSTRIDE = 32 /* [64 blocks] */, NODE0 = 32 + 64 * 32 /* [node tiles] */;
+};
+struct MegaArgs {
+    // roles' grid ranges
+    int n_node, n_filter, n_pair, tiles_per_layer;
+    int L, N;
+    const int32_t* epoch_src;  // device word: epoch = *epoch_src + epoch_bias (>= 1, + 1 per launch since the block was zeroed)
+    int epoch_bias;
+    int32_t* ctl;
+    int32_t* status;           // TSD_STATUS_INTERNAL / TSD_STATUS_RANGE
+    // node role
+    const int32_t *graph_ptr, *node_graph;
+    const int32_t *row_ptr, *dst, *umap;
+    const float* W;            // f16-plane arena
+    size_t layer0, layer_stride, o_lin1, o_lin2_w, o_lin2_b, o_lin_w, o_lin_b;
+    const float *z, *x1_0;
+    float *x1m, *h;            // x1m: [L - 1][N, H], x1 of block l + 1 in slot l (every buffer is written ONCE per launch)
+    size_t x1_stride;
+    const float* wf;           // filters, slot = block
+    size_t wf_layer_stride;
+    // filter role (blocks 1 .. L-1) and pair role
+    ComboFilter f;
+    ComboPre q;
+};
+
+constexpr unsigned MEGA_SPIN_LIMIT = 4000000u;
+#ifndef TSD_MEGA_POLL_SLEEP
+#define TSD_MEGA_POLL_SLEEP 12  // x64 cycles between two polls (~0.3 us): a hundred waves polling one word at full rate throttle the L2 channel it lives in
+#endif
+constexpr int MEGA_POLL_SLEEP = TSD_MEGA_POLL_SLEEP;
+
+// one wave: wait until *p >= target (monotonic word); false after the bound
+__device__ __forceinline__ bool mega_wait_ge(const int32_t* p, int target, int32_t* status) {
+    for (unsigned spins = 0;; ++spins) {
+        if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        if (spins > MEGA_SPIN_LIMIT) {
+            if ((threadIdx.x & 63) == 0) atomicOr(status, TSD_STATUS_INTERNAL);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(MEGA_POLL_SLEEP);
+    }
+}
+// one wave: wait until p[t] >= target for every t in [lo, hi]
+__device__ __forceinline__ bool mega_wait_range_ge(const int32_t* p, int lo, int hi, int target, int32_t* status) {
+    const int lane = threadIdx.x & 63;
+    for (int t0 = lo; t0 <= hi; t0 += 64) {
+        const int t = t0 + lane;
+        for (unsigned spins = 0;; ++spins) {
+            const int v = t <= hi ? __hip_atomic_load(p + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+            if (__all(v >= target)) break;
+            if (spins > MEGA_SPIN_LIMIT) {
+                if (lane == 0) atomicOr(status, TSD_STATUS_INTERNAL);
+                return false;
+            }
+            __builtin_amdgcn_s_sleep(MEGA_POLL_SLEEP);
+        }
+    }
+    return true;
+}
+// every storing wave drains, the workgroup meets, ONE lane counts (Guideline 16 R1, counter form)
+__device__ __forceinline__ void mega_arrive(int32_t* counter) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the node workgroup of tile `tile`: all L blocks (node_role_h's chain per block, h kept in registers, x1 published)
+template <int H>
+__device__ __forceinline__ void node_persist_h(const MegaArgs& A, int tile, int epoch, float* smem) {
+    constexpr int LDH = ldh_of(H), LDA = H + 4;
+    constexpr int NT = 2 * H, CB16 = 2, C4 = H / 4;
+    const Planes pl = planes_at(smem, TN, LDH);
+    float* xst = smem;  // the finished x1 tile as fp32 rows (over the planes: TN (H + 4) <= TN (H + 8) floats)
+    const int n0 = tile * TN;
+    int tid_ = threadIdx.x;
+    asm volatile("" : "+v"(tid_));  // (opaque: lane arithmetic is not hoisted above the role branch of the one-launch kernel)
+    const int tid = tid_;
+    const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, l15 = lane & 15;
+    const int col0 = wave * 32;
+    const int nrows = min(TN, A.N - n0);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    float amax = 0.0f;
+    int32_t* node_done = A.ctl + MegaCtl::NODE0;
+    // the node tiles that hold atoms of the graphs this tile's atoms belong to
+    const int g_first = A.node_graph[n0], g_last = A.node_graph[n0 + nrows - 1];
+    const int t_lo = A.graph_ptr[g_first] / TN, t_hi = (A.graph_ptr[g_last + 1] - 1) / TN;
+    // residual input of block 0: the pos-independent node embedding z
+    float h_res[CB16][4];
+#pragma unroll
+    for (int cb = 0; cb < CB16; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = q * 4 + r;
+            h_res[cb][r] = row < nrows ? A.z[(size_t)(n0 + row) * H + col0 + cb * 16 + l15] : 0.0f;
+        }
+    for (int l = 0; l < A.L; ++l) {
+        if (l > 0 && wave == 0) {
+#ifndef TSD_MEGA_NOWAIT_LAYER  // (timing experiments only: wrong results)
+            mega_wait_ge(A.ctl + MegaCtl::LAYER0 + MegaCtl::LSTRIDE * l, A.tiles_per_layer * epoch, A.status);
+#endif
+#ifndef TSD_MEGA_NOWAIT_NODE
+            mega_wait_range_ge(node_done, t_lo, t_hi, epoch * 64 + l, A.status);
+#endif
+        }
+        __syncthreads();
+        const float* Wl = A.W + A.layer0 + (size_t)l * A.layer_stride;
+        const float* x_in = l == 0 ? A.x1_0 : A.x1m + (size_t)(l - 1) * A.x1_stride;
+        float* x_out = A.x1m + (size_t)l * A.x1_stride;
+        const bool last = l + 1 == A.L;
+        HRing<CB16, HRING16_R> rg;
+        f32x4 accm[CB16], accx[CB16];
+        float b_lin2[CB16], b_lin[CB16];
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) {
+            b_lin2[cb] = Wl[A.o_lin2_b + col0 + cb * 16 + l15];
+            b_lin[cb] = Wl[A.o_lin_b + col0 + cb * 16 + l15];
+        }
+#ifdef TSD_MEGA_PLAIN_GATHER
+        constexpr bool kSc1 = false;
+#else
+        constexpr bool kSc1 = true;
+#endif
+        aggregate_tile<H, false, 2 * H / 64, 8, true, kSc1>(A.row_ptr, A.dst, A.umap, A.wf + (size_t)l * A.wf_layer_stride,
+                                                            x_in, A.N, n0, smem, nullptr, &amax);
+        hgemm16_ring_start<CB16, H>(rg, Wl + A.o_lin2_w, H, col0);
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) accm[cb] = accx[cb] = zero4;
+        hgemm16_ring_run<CB16, H>(rg, pl, LDH, accm, accx);
+        hgemm16_ring_start<CB16, H>(rg, Wl + A.o_lin_w, H, col0);
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) {
+            const int col = col0 + cb * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                planes_store1(pl, (q * 4 + r) * LDH + col, sspf(hval4(accm[cb], accx[cb], r) + b_lin2[cb]), amax);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) accm[cb] = accx[cb] = zero4;
+        hgemm16_ring_run<CB16, H>(rg, pl, LDH, accm, accx);
+        if (!last) hgemm16_ring_start<CB16, H>(rg, Wl + A.layer_stride + A.o_lin1, H, col0);
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) {
+            const int col = col0 + cb * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = q * 4 + r;
+                float hn = 0.0f;
+                if (row < nrows) {
+                    hn = h_res[cb][r] + (hval4(accm[cb], accx[cb], r) + b_lin[cb]);
+                    if (last)  // the final node states: write-through, the pair tiles read them from other CUs
+                        __hip_atomic_store(A.h + (size_t)(n0 + row) * H + col, hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                h_res[cb][r] = hn;
+                if (!last) planes_store1(pl, row * LDH + col, hn, amax);
+            }
+        }
+        if (last) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(node_done + tile, epoch * 64 + A.L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) accm[cb] = accx[cb] = zero4;
+        hgemm16_ring_run<CB16, H>(rg, pl, LDH, accm, accx);
+        __syncthreads();  // every wave is done reading the planes: the x1 tile goes over them as fp32 rows
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) {
+            const int col = col0 + cb * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xst[(q * 4 + r) * LDA + col] = hval4(accm[cb], accx[cb], r);
+        }
+        __syncthreads();
+        for (int idx = tid; idx < nrows * C4; idx += NT) {  // whole 1-KiB rows, write-through
+            const int r = idx / C4, c4 = idx % C4;
+            store_stream16(x_out + (size_t)(n0 + r) * H + c4 * 4, *reinterpret_cast<const f32x4*>(xst + r * LDA + c4 * 4));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // (also: the staging rows are free for the next block's planes)
+        if (tid == 0) __hip_atomic_store(node_done + tile, epoch * 64 + l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    range_report(amax, A.status);
+}
+
+
+template <int H>
+__global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    TSD_MEGA_T(1, wall_clock64());
+    const int epoch =  // (wave-uniform: kept in an SGPR)
+        __builtin_amdgcn_readfirstlane(__hip_atomic_load(A.epoch_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + A.epoch_bias;
+    int b = blockIdx.x;
+    if (b < A.n_node) {
+        __builtin_amdgcn_s_setprio(3);
+        node_persist_h<H>(A, b, epoch, smem);
+        TSD_MEGA_T(0, 2);
+        TSD_MEGA_T(2, wall_clock64());
+        return;
+    }
+    b -= A.n_node;
+    if (b < A.n_filter) {  // filter tiles of blocks 1 .. L-1
+        const int layer = 1 + b / A.tiles_per_layer;
+#ifndef TSD_MEGA_SKIP_FILTER  // (timing experiments only: wrong results)
+        filter_role_h<H>(A.f, b, smem, A.status TSD_TRACE_NULL);
+#endif
+        mega_arrive(A.ctl + MegaCtl::LAYER0 + MegaCtl::LSTRIDE * layer);
+        TSD_MEGA_T(0, 3);
+        TSD_MEGA_T(2, wall_clock64());
+        TSD_MEGA_T(3, (unsigned long long)layer);
+        return;
+    }
+    b -= A.n_filter;
+    if (b < A.n_pair) {
+        ComboPre q = A.q;
+        q.ready_target = epoch * 64 + A.L;
+        pair_role_h<H>(q, b, A.n_node, smem, false, A.status);
+        TSD_MEGA_T(0, 4);
+        TSD_MEGA_T(2, wall_clock64());
+    }
+}
+
+int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float* pos, const float* W16, float* ea, float* wf,
+                        float* h, float* x1m, size_t x1_stride, int32_t* ctl, const int32_t* epoch_src, int epoch_bias,
+                        int32_t* status, hipStream_t st) {
+    (void)pos;
+    const WeightLayout WL = weight_layout(c);
+    const int H = c.hidden, L = c.num_convs, N = b.num_nodes, P = b.num_pairs, PU = P / 2;
+    const tsd_geometry& g = b.geo;
+    MegaArgs A{};
+    A.L = L;
+    A.N = N;
+    A.epoch_src = epoch_src;
+    A.epoch_bias = epoch_bias;
+    A.ctl = ctl;
+    A.status = status;
+    // node role
+    A.graph_ptr = b.graph_ptr;
+    A.node_graph = b.node_graph;
+    A.row_ptr = g.enc.row_ptr;
+    A.dst = g.enc.dst;
+    A.umap = g.enc.umap;
+    A.W = W16;
+    A.layer0 = WL.layer0;
+    A.layer_stride = WL.layer_stride;
+    A.o_lin1 = WL.L_lin1_w;
+    A.o_lin2_w = WL.L_lin2_w;
+    A.o_lin2_b = WL.L_lin2_b;
+    A.o_lin_w = WL.L_lin_w;
+    A.o_lin_b = WL.L_lin_b;
+    A.z = b.z;
+    A.x1_0 = b.x1_0;
+    A.x1m = x1m;
+    A.x1_stride = x1_stride;
+    A.h = h;
+    A.wf = wf;
+    A.wf_layer_stride = (size_t)PU * H;
+    // filter role: the queue of kernels_combo's per-block launches from block 1 on, slot = block
+    A.tiles_per_layer = filter_tiles_per_layer(PU);
+    A.f.tiles = (L - 1) * A.tiles_per_layer;
+    A.f.g_begin = A.tiles_per_layer;
+    A.f.tiles_per_layer = A.tiles_per_layer;
+    A.f.layer0 = 0;
+    A.f.Wl0 = W16 + WL.layer0;
+    A.f.layer_stride = WL.layer_stride;
+    A.f.o_nn0_w = WL.L_nn0f_w;
+    A.f.o_nn0_b = WL.L_nn0f_b;
+    A.f.o_nn2_w = WL.L_nn2_w;
+    A.f.o_nn2_b = WL.L_nn2_b;
+    A.f.conv_cutoff = c.conv_cutoff;
+    A.f.smooth = c.smooth_conv;
+    A.f.e = g.enc_u;
+    A.f.edge_attr = ea;
+    A.f.wf = wf;
+    A.f.wf_layer_stride = (size_t)PU * H;
+    A.f.wf_slots = L;
+    // pair role
+    A.q.tiles = (PU + T - 1) / T;
+    A.q.e = g.out_u;
+    A.q.edge_attr = ea;
+    A.q.attr_row = g.attr_row;
+    A.q.w0b = W16 + WL.out_w0f;
+    A.q.b0 = W16 + WL.out_b0f;
+    A.q.pair = 1;
+    A.q.w0a = W16 + WL.out_w0;
+    A.q.w1 = W16 + WL.out_w1;
+    A.q.b1 = W16 + WL.out_b1;
+    A.q.w2 = W16 + WL.out_w2;
+    A.q.b2 = W16 + WL.out_b2;
+    A.q.h = h;
+    A.q.edge_inv = b.edge_inv_u;
+    A.q.ready = ctl + MegaCtl::NODE0;
+    A.q.status = status;
+    A.q.inv_stride = (size_t)PU;
+    // grid
+    A.n_node = (N + TN - 1) / TN;
+    A.n_filter = A.f.tiles;
+    A.n_pair = A.q.tiles;
+    const int grid = A.n_node + A.n_filter + A.n_pair;
+    if (grid == 0 || A.n_node == 0) return TSD_OK;
+    const size_t lds = lds_combo(H, PREC_H2);
+#define TSD_MEGA(HH)                                                                                         \
+    {                                                                                                        \
+        static DeviceOnce once;                                                                              \
+        int r = allow_lds(forward_mega_kernel<HH>, lds, once);                                               \
+        if (r) return r;                                                                                     \
+        hipLaunchKernelGGL(forward_mega_kernel<HH>, dim3(grid), dim3(2 * HH), lds, st, A);                   \
+    }
+    switch (H) {
+        case 64: TSD_MEGA(64) break;
+        case 128: TSD_MEGA(128) break;
+        case 256: TSD_MEGA(256) break;
+        default: set_error("hidden=%d unsupported (64/128/256)", H); return TSD_ERR_INVALID;
+    }
+#undef TSD_MEGA
+    TSD_LAUNCH_CHECK("forward_mega");
+    return TSD_OK;
+}
+size_t mega_ctl_words(int N) { return (size_t)MegaCtl::NODE0 + (size_t)((N + TN - 1) / TN); }
+
 
 // layer == -1: node role = lin1 of block 0 only; layer == -2: no node role.
 // Filter role: items [g_begin, g_begin + g_count) of the queue (layer_w0 + g / tiles_per_layer, g % tiles_per_layer);

@@ -44,45 +44,66 @@ __device__ __forceinline__ Planes planes_at(void* smem, int rows, int ldh) {
     return Planes{p, p + rows * ldh};
 }
 
-// amax: running max |a| of everything this thread converted (range check, one v_max per element)
-__device__ __forceinline__ void split1(float a, f16& h, f16& l, float& amax) {
-    amax = fmaxf(amax, fabsf(a));
+// amax: running max |a| of everything this thread converted (range check).  The max is an asm statement at the point of
+// the conversion: left to the compiler it is batched into v_max3 chains long after the stores, which keeps every
+// converted value alive across them (+10-15 VGPRs in the tile kernels).
+__device__ __forceinline__ void amax_upd(float& amax, float a) {
+    asm("v_max_f32 %0, %0, |%1|" : "+v"(amax) : "v"(a));
+}
+__device__ __forceinline__ void amax_upd2(float& amax, float a, float b) {
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void split1(float a, f16& h, f16& l) {
     h = (f16)a;
     l = (f16)((a - (float)h) * SPLIT_SCALE);
 }
 __device__ __forceinline__ void planes_store1(const Planes& p, int off, float a, float& amax) {
     f16 h, l;
-    split1(a, h, l, amax);
+    amax_upd(amax, a);
+    split1(a, h, l);
     p.hi[off] = h;
     p.lo[off] = l;
+}
+// two column-adjacent elements (off even): one 4-byte store per plane
+__device__ __forceinline__ void planes_store2(const Planes& p, int off, float a0, float a1, float& amax) {
+    f16x2 h, l;
+    f16 hh, ll;
+    amax_upd2(amax, a0, a1);
+    split1(a0, hh, ll);
+    h[0] = hh; l[0] = ll;
+    split1(a1, hh, ll);
+    h[1] = hh; l[1] = ll;
+    *reinterpret_cast<f16x2*>(p.hi + off) = h;
+    *reinterpret_cast<f16x2*>(p.lo + off) = l;
 }
 // four consecutive elements (off a multiple of 4): one 8-byte store per plane
 __device__ __forceinline__ void planes_store4(const Planes& p, int off, const f32x4& a, float& amax) {
     f16x4 h, l;
+    amax_upd2(amax, a[0], a[1]);
+    amax_upd2(amax, a[2], a[3]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         f16 hh, ll;
-        split1(a[i], hh, ll, amax);
+        split1(a[i], hh, ll);
         h[i] = hh;
         l[i] = ll;
     }
     *reinterpret_cast<f16x4*>(p.hi + off) = h;
     *reinterpret_cast<f16x4*>(p.lo + off) = l;
 }
-// two column-adjacent elements (off even): one 4-byte store per plane
-__device__ __forceinline__ void planes_store2(const Planes& p, int off, float a0, float a1, float& amax) {
-    f16x2 h, l;
-    f16 hh, ll;
-    split1(a0, hh, ll, amax);
-    h[0] = hh; l[0] = ll;
-    split1(a1, hh, ll, amax);
-    h[1] = hh; l[1] = ll;
-    *reinterpret_cast<f16x2*>(p.hi + off) = h;
-    *reinterpret_cast<f16x2*>(p.lo + off) = l;
-}
 // the range flag of a workgroup role: any thread that converted a value beyond the f16 range (or a NaN's neighbour inf)
 __device__ __forceinline__ void range_report(float amax, int32_t* status) {
     if (status != nullptr && !(amax <= F16_MAX)) atomicOr(status, TSD_STATUS_RANGE);
+}
+
+// 16-byte load that is served by L2, never by this CU's L1 (`sc1`): rows that another workgroup stored write-through
+// during the same launch (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 loads pair with sc1 stores).  The
+// destination counts as written at the statement: consume it behind ld16_wait4 (or any vmcnt(0) that names it).
+__device__ __forceinline__ void ld16_sc1(f32x4& v, const float* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void ld16_wait4(f32x4 (&v)[4]) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
 }
 
 __device__ __forceinline__ f32x16 mfma_h32(const f32x4& a, const f32x4& b, const f32x16& c) {
@@ -90,6 +111,14 @@ __device__ __forceinline__ f32x16 mfma_h32(const f32x4& a, const f32x4& b, const
 }
 __device__ __forceinline__ f32x4 mfma_h16(const f32x4& a, const f32x4& b, const f32x4& c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// a wave-uniform pointer as the compiler can see it (the asm loads take their base through an "s" operand: a base the
+// compiler keeps in VGPRs -- e.g. derived from a value it cannot prove uniform -- would be substituted as a VGPR pair)
+__device__ __forceinline__ const char* uniform_ptr(const void* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
 }
 
 // B ring: R k-steps in flight, each CB column blocks x 2 planes of one float4 (8 f16) per lane
@@ -119,29 +148,30 @@ __device__ __forceinline__ void hring_wait(f32x4 (&b)[CB][2]) {
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1]) : "n"(N) : "memory");
 }
 
-constexpr int HRING_R = 4;    // k-steps in flight, 32-row GEMMs (CB = 1: 8 fragments = 32 VGPRs)
+constexpr int HRING_R = 3;    // k-steps in flight, 32-row GEMMs (CB = 1: 8 fragments = 32 VGPRs)
 constexpr int HRING16_R = 3;  // 32-k steps in flight, 16-row GEMMs (CB = 2: 12 fragments = 48 VGPRs)
 
 // ---- 32-row blocks: v_mfma_f32_32x32x16_f16.  A lane l: row l & 31, k = 8 (l >> 5) .. + 7 of the k-step; B lane l:
 // column l & 31, the same k; C/D as the fp32 32x32 MFMA (acc_row).  KS = K / 16 k-steps.
-template <int CB, int K>
-__device__ __forceinline__ void hgemm_ring_start(HRing<CB, HRING_R>& r, const float* __restrict__ Bp16, int nout, int col0) {
+// (the ring depth R is the HRing's: HRING_R by default, a kernel short of registers declares a shallower one)
+template <int CB, int K, int R>
+__device__ __forceinline__ void hgemm_ring_start(HRing<CB, R>& r, const float* __restrict__ Bp16, int nout, int col0) {
     const int lane = threadIdx.x & 63;
-    r.base = reinterpret_cast<const char*>(Bp16);
+    r.base = uniform_ptr(Bp16);
     r.voff = (unsigned)(((lane >> 5) * nout + col0 + (lane & 31)) * 16);
     r.step_bytes = 64 * nout;   // 2 planes x 2 halves x nout x 16 B
     r.plane_bytes = 32 * nout;
     r.cb_bytes = 32 * 16;
     constexpr int KS = K / 16;
-    static_for<0, (HRING_R < KS ? HRING_R : KS)>([&](auto i) {
+    static_for<0, (R < KS ? R : KS)>([&](auto i) {
         constexpr int I = decltype(i)::value;
         hring_issue<CB>(r.b[I], r.base + (size_t)I * r.step_bytes, r.voff, r.plane_bytes, r.cb_bytes);
     });
 }
-template <int RB, int CB, int K>
-__device__ __forceinline__ void hgemm_ring_run(HRing<CB, HRING_R>& r, const Planes& A, int ldh, f32x16 (&accm)[RB][CB],
+template <int RB, int CB, int K, int R>
+__device__ __forceinline__ void hgemm_ring_run(HRing<CB, R>& r, const Planes& A, int ldh, f32x16 (&accm)[RB][CB],
                                                f32x16 (&accx)[RB][CB]) {
-    constexpr int R = HRING_R, KS = K / 16;
+    constexpr int KS = K / 16;
     const int lane = threadIdx.x & 63;
     const int aoff = (lane & 31) * ldh + (lane >> 5) * 8;
     static_for<0, KS>([&](auto ksc) {
@@ -187,7 +217,7 @@ __device__ __forceinline__ float hval(const f32x16& m, const f32x16& x, int r) {
 template <int CB, int K>
 __device__ __forceinline__ void hgemm16_ring_start(HRing<CB, HRING16_R>& r, const float* __restrict__ Bp16, int nout, int col0) {
     const int lane = threadIdx.x & 63, q = lane >> 4;
-    r.base = reinterpret_cast<const char*>(Bp16);
+    r.base = uniform_ptr(Bp16);
     r.voff = (unsigned)((q >> 1) * 64 * nout + ((q & 1) * nout + col0 + (lane & 15)) * 16);
     r.step_bytes = 128 * nout;  // two 16-k steps
     r.plane_bytes = 32 * nout;

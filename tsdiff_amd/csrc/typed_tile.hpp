@@ -1,0 +1,153 @@
+// typed_tile.hpp -- one tile of the type-sorted edge embedding on the f16 MFMA pipes (kernels_typed.hip) as a device
+// function: the embedding launch (typed_embed_h_kernel) and the one-launch forward (kernels_combo.hip) both run it.
+#pragma once
+#include "train_internal.hpp"
+
+namespace tsd {
+
+struct TypedList {
+    int n;  // tiles
+    const int32_t *slot, *start, *count, *pair, *ni, *nj;
+};
+struct TypedEmbedW {
+    const float *w0, *b0;    // Linear(1, H) of the distance MLP (packed arena, per checkpoint: + m * wstride)
+    const float* bucket;     // bucket arena of checkpoint 0; checkpoint m at + m * bstride
+    size_t wstride, bstride;
+};
+
+// One tile of the embedding launch on the f16 MFMA pipes (PREC_H2, split16.hpp): `w.bucket` and the block-0 filter weights come from the
+// f16-plane arenas (tsd_bucket_weights16 / tsd_pack_weights16), the operand tiles live in LDS as two f16 planes, the
+// finished rows are staged as fp32 for the 1-KiB row stores.  Inputs and outputs in memory are the fp32 ones.
+template <int H, bool FUSE0>
+__device__ __forceinline__ void typed_embed_tile_h(const TypedEmbedW& w, const TypedList& ta, const TypedList& tb, int bx,
+                                                   size_t m, const float* __restrict__ pos,
+                                                   const int32_t* __restrict__ pair2u, int P,
+                                                   const int32_t* __restrict__ attr_row, float* __restrict__ edge_attr,
+                                                   size_t out_stride, const EmbedFuse0& f0, int32_t* range_status,
+                                                   float* smem) {
+    constexpr int T = TSD_EDGE_TILE;
+    constexpr int LDA = H + 4, LDH = ldh_of(H), NT = 2 * H, C4 = H / 4;
+    const Planes pl = planes_at(smem, T, LDH);
+    float* stage = smem + T * LDH;  // fp32 rows [T][LDA]
+    float* s_d = stage + T * LDA;
+    int* s_row = reinterpret_cast<int*>(s_d + T);
+    float* s_cw = s_d + 2 * T;  // CFConv cutoff weight of the row (block-0 filters)
+    const bool second = bx >= ta.n;
+    const TypedList& tl = second ? tb : ta;
+    const int t = second ? bx - ta.n : bx;
+    const int PU = P / 2;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int col0 = (tid >> 6) * 32, col = col0 + l31;
+    const int slot = tl.slot[t], start = tl.start[t], nrows = tl.count[t];
+    const float* Wt = w.bucket + m * w.bstride + (size_t)slot * ((size_t)H * H + H);
+    const float* bt = Wt + (size_t)H * H;
+    const float *w0 = w.w0 + m * w.wstride, *b0 = w.b0 + m * w.wstride;
+    edge_attr += m * out_stride;
+    float amax = 0.0f;
+    if (tid < T) {
+        const int s = start + min(tid, nrows - 1);
+        const int p = tl.pair[s];
+        const int i = tl.ni[s], j = tl.nj[s];
+        int row = -1;
+        if (tid < nrows) {
+            if (!second) {
+                row = pair2u[p];                                  // enc_u index of the pair, -1: not an edge now
+            } else {
+                const int eo = pair2u[(size_t)P + p];             // out_u index
+                const int ar = eo >= 0 ? attr_row[eo] : -1;
+                row = ar >= PU ? ar : -1;                         // separately embedded now?
+            }
+        }
+        // edge_length exactly as the list build computes it (kernels_graph.hip::eval_pair_xyz, src = i < j = dst)
+        const float dx = pos[3 * i] - pos[3 * j], dy = pos[3 * i + 1] - pos[3 * j + 1], dz = pos[3 * i + 2] - pos[3 * j + 2];
+        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        s_d[tid] = sqrtf(d2);
+        s_row[tid] = row;
+        if constexpr (FUSE0) s_cw[tid] = tid < nrows ? cutoff_weight(sqrtf(d2), f0.conv_cutoff, f0.smooth) : 0.0f;
+    }
+    __syncthreads();
+    {   // (a tile none of whose pairs is an edge at this step: nothing to do)
+        int any = 0;
+        for (int r = 0; r < nrows; ++r) any |= s_row[r] >= 0;
+        if (!any) return;
+    }
+    // (ring of 2 k-steps: this tile kernel holds three GEMMs' worth of epilogue state and sits at the 128-VGPR line
+    // that two resident workgroups per CU need; a forced cap makes the compiler spill beside the asm-issued loads)
+    HRing<1, 2> rg;
+    const float bias_t = bt[col];
+    {   // Linear(1,H) + swish: thread = (channel pair, quarter of the tile's rows)
+        const int c = (tid % (H / 2)) * 2, r0 = (tid / (H / 2)) * (T / 4);
+        const float wa = w0[c], wb = w0[c + 1], ba = b0[c], bb = b0[c + 1];
+#pragma unroll
+        for (int r = r0; r < r0 + T / 4; ++r) {
+            const float d = s_d[r];
+            planes_store2(pl, r * LDH + c, swishf(wa * d + ba), swishf(wb * d + bb), amax);
+        }
+    }
+    hgemm_ring_start<1, H>(rg, Wt, H, col0);  // (behind the stage above: its registers are free now)
+    __syncthreads();
+    f32x16 accm[1][1], accx[1][1];
+    hzero(accm, accx);
+    hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
+    const bool fuse = FUSE0 && !second;
+    const float *nn0_w = f0.nn0_w + m * w.wstride, *nn0_b = f0.nn0_b + m * w.wstride;
+    const float *nn2_w = f0.nn2_w + m * w.wstride, *nn2_b = f0.nn2_b + m * w.wstride;
+    if constexpr (FUSE0) {
+        if (fuse) hgemm_ring_start<1, H>(rg, nn0_w, H, col0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi);
+        const float v = swishf(hval(accm[0][0], accx[0][0], r) + bias_t);
+        stage[row * LDA + col] = v;
+        if constexpr (FUSE0) {
+            if (fuse) planes_store1(pl, row * LDH + col, v, amax);
+        }
+    }
+    __syncthreads();
+    // s1 is the attribute tile: whole 1-KiB rows to the rows of the edges the pairs are at this step
+    for (int idx = tid; idx < nrows * C4; idx += NT) {
+        const int r = idx / C4, c4 = idx % C4;
+        const int row = s_row[r];
+        if (row >= 0)
+            store_stream16(edge_attr + (size_t)row * H + c4 * 4, *reinterpret_cast<const f32x4*>(stage + r * LDA + c4 * 4));
+    }
+    if constexpr (FUSE0) {
+        if (!fuse) {
+            range_report(amax, range_status);
+            return;
+        }
+        // filter role of interaction block 0 on this tile (kernels_combo.hip::filter_role_h)
+        float* wf = f0.wf + m * f0.wf_stride;
+        const float bb0 = nn0_b[col];
+        hzero(accm, accx);
+        hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
+        hgemm_ring_start<1, H>(rg, nn2_w, H, col0);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            planes_store1(pl, acc_row(r, hi) * LDH + col, sspf(hval(accm[0][0], accx[0][0], r) + bb0), amax);
+        __syncthreads();
+        const float bb2 = nn2_b[col];
+        hzero(accm, accx);
+        hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
+        // (every wave passed the barrier above after its row stores from `stage`: it may be overwritten)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, hi);
+            stage[row * LDA + col] = (hval(accm[0][0], accx[0][0], r) + bb2) * s_cw[row];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < nrows * C4; idx += NT) {
+            const int r = idx / C4, c4 = idx % C4;
+            const int row = s_row[r];
+            if (row >= 0)
+                store_stream16(wf + (size_t)row * H + c4 * 4, *reinterpret_cast<const f32x4*>(stage + r * LDA + c4 * 4));
+        }
+    }
+    range_report(amax, range_status);
+}
+
+
+}  // namespace tsd
