@@ -10,14 +10,18 @@ one batch: device-side graph build, one score-network forward per checkpoint, en
 eq_transform, clip, update, NaN flag, centring.  Workload at every N (weak scaling): BASELINE.json
 configs[1] -- a wb97xd3-like batch of 100 reaction graphs (8..23 atoms, synthetic: the real
 test_data.pkl and the trained checkpoints are LFS blobs absent from the reference tree), the full
-H=256 / 7-block condensenc network with closed-form synthetic weights, fp32, one checkpoint.
+H=256 / 7-block condensenc network with closed-form synthetic weights, fp32 tensors (tile GEMMs on the f16 MFMA with
+split operands and fp32 accumulation, csrc/split16.hpp: the fp32 error class), one checkpoint.
 Inputs are resident in HBM before the timed region; graphs shard across ranks with no data-path
 collective (each rank samples its own 100 graphs).
 
 Prints ONE JSON line on rank 0 (contract in the task statement).  Besides the headline fields:
-  roofline      -- the dominant kernel (one interaction block per launch, fp32-MFMA-bound) timed live with
-                   events, plus `aggregate`: the HBM-bound message-passing form (segmented reduce with a
-                   materialised filter) at BASELINE configs[4] size -- the >= 70 %-of-HBM target
+  roofline      -- the dominant kernel of the default (split-f16) path timed live with events: at batch-100 sizes the
+                   one-launch kernel of all interaction blocks + pair MLP (forward_mega_kernel), at configs[4] sizes one
+                   interaction block per launch; `f32_mfma`: the same for the fp32-input-MFMA path (layer_combo_kernel);
+                   `aggregate`: the HBM-bound message-passing form (segmented reduce with a materialised filter) at
+                   BASELINE configs[4] size -- the >= 70 %-of-HBM target
+  f32_mfma_ms_per_step -- the same timed call with TSDIFF_GEMM=f32 (exact-fp32 MFMA kernels, the round-2/3 path)
   cpu_baseline  -- the CPU oracle (our restatement of the reference, kind "port") on the host cores, at 32
                    threads and at os.cpu_count(), plus the configs[4] chunk protocol of BASELINE.md 5.3
   c5 / ensemble8 / train -- the other BASELINE configs this GPU runs (N = 1 only, a few steps each)
@@ -38,6 +42,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md:41
+PEAK_F16_MFMA_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md:42 (dense)
+# The inference forward's tile GEMMs run on the f16 MFMA with every fp32 operand split into two f16 planes: THREE f16
+# MFMAs per fp32-equivalent multiply-add (csrc/split16.hpp), so the roof of its fp32-equivalent (algorithmic) flop
+# rate is a third of the dense f16 peak.
+PEAK_SPLIT_F16_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec)
 # HBM-side bytes per launch come from the committed rocprofv3 PMC passes of this round (tools/profile_round.sh), read
 # here because counters cannot be collected inside a bench run; a missing file gives `traffic: null`
@@ -141,9 +150,10 @@ class SamplingRun:
         return self.s._bound_batch(g["atom_type"], g["r_feat"], g["p_feat"], g["bond_index"], g["bond_type"], g["batch"])
 
 
-def combo_roofline(lib, db, cfg, dev, reps=40):
-    """the dominant kernel: one interaction block per launch (layer_combo_kernel: node chain of block l || CFConv
-    filters of block l+1), its L+1 launches of a forward timed live with events on the launch stream"""
+def combo_roofline(lib, db, cfg, dev, reps=40, h2=False):
+    """one interaction block per launch (layer_combo_kernel: node chain of block l || CFConv filters of block l+1), its
+    L+1 launches of a forward timed live with events on the launch stream; h2: the split-f16 instantiation (the
+    default path of batches too large for the one-launch kernel), else the fp32-input-MFMA one"""
     from tsdiff_amd import _lib
     H, L = cfg["hidden_dim"], cfg["encoder"]["num_convs"]
     N, PU = db.N, db.P // 2
@@ -156,10 +166,13 @@ def combo_roofline(lib, db, cfg, dev, reps=40):
     def launch_blocks():
         """[filters 0], [node 0 || filters 1], ..., [node L-1]; block l's filters live in ring slot l % 2"""
         def blk(layer, fl, xi, xo):
-            _lib.check(lib.tsd_interaction_block(
-                C.byref(db.cfg), _lib.ptr(db.weights[0]), layer, N, db.enc.struct(),
-                _lib.ptr(wf[layer % 2]) if layer >= 0 else None, _lib.ptr(xi), _lib.ptr(hbuf), _lib.ptr(xo), fl, PU,
-                db.enc_u.struct(), _lib.ptr(ea), _lib.ptr(wf[fl % 2]) if fl >= 0 else None, _lib.stream_ptr()))
+            args = (C.byref(db.cfg), _lib.ptr(db.weights16[0] if h2 else db.weights[0]), layer, N, db.enc.struct(),
+                    _lib.ptr(wf[layer % 2]) if layer >= 0 else None, _lib.ptr(xi), _lib.ptr(hbuf), _lib.ptr(xo), fl, PU,
+                    db.enc_u.struct(), _lib.ptr(ea), _lib.ptr(wf[fl % 2]) if fl >= 0 else None)
+            if h2:
+                _lib.check(lib.tsd_interaction_block16(*args, None, _lib.stream_ptr()))
+            else:
+                _lib.check(lib.tsd_interaction_block(*args, _lib.stream_ptr()))
         blk(-2, 0, xa, xb)
         for l in range(L):
             blk(l, l + 1 if l + 1 < L else -1, xa if l % 2 == 0 else xb, xb if l % 2 == 0 else xa)
@@ -184,8 +197,11 @@ def combo_roofline(lib, db, cfg, dev, reps=40):
     flops_survey = (L * (E_enc * (4.0 * H * H + 2.0 * H) + N * 6.0 * H * H)) / (L + 1)
     ach = flops / (k_ms * 1e-3) / 1e12
     del ea, wf, xa, xb, hbuf
-    return {"kernel": "layer_combo_kernel<256>", "bound": "mfma", "achieved": round(ach, 2),
-            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+    peak = PEAK_SPLIT_F16_TFLOPS if h2 else PEAK_FP32_MFMA_TFLOPS
+    return {"kernel": "layer_combo_kernel<256, ..., split-f16>" if h2 else "layer_combo_kernel<256>", "bound": "mfma",
+            "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "peak_note": ("fp32-equivalent flops against a third of the 2500 TFLOP/s dense f16 MFMA peak: three f16 MFMAs "
+                          "per fp32 multiply-add (split operands)") if h2 else "fp32-input MFMA peak",
             "traffic": None, "avg_launch_us": round(k_ms * 1e3, 2), "undirected_edges": Eu, "directed_edges": E_enc,
             "nodes": N, "flop_per_launch": flops, "launches_per_forward": L + 1,
             "achieved_in_survey_units": round(flops_survey / (k_ms * 1e-3) / 1e12, 2),
@@ -194,6 +210,52 @@ def combo_roofline(lib, db, cfg, dev, reps=40):
             # average launch: L/(L+1) x [edge_attr read + filter write + filter read (rows of 4H bytes) + node rows
             # (h in, x1 in, x1 out, h out) + the block's 5 H x H weight matrices]
             "algorithmic_bytes_per_launch": (Eu * 4.0 * H * 3 + 4.0 * N * H * 4 + 5 * 4.0 * H * H) * L / (L + 1)}
+
+
+def mega_roofline(lib, db, cfg, pos, dev, reps=40):
+    """the dominant kernel of the default path at batch-100 sizes: forward_mega_kernel -- all L interaction blocks (node
+    workgroups persistent over the blocks, filter tiles of blocks 1..L-1) and the pair MLP in ONE launch -- re-run on the
+    state a forward left in the workspace (tsd_forward_blocks), timed live with events on the launch stream"""
+    from tsdiff_amd import _lib
+    H, L = cfg["hidden_dim"], cfg["encoder"]["num_convs"]
+    N = db.N
+    db.forward(pos)
+    E_enc, E_out, Eu = db.enc.num_edges(), db.out.num_edges(), db.enc_u.num_edges()
+    b = db.struct()
+    epoch = [0]
+
+    def launch():
+        epoch[0] += 1
+        _lib.check(lib.tsd_forward_blocks(C.byref(db.cfg), C.byref(b), epoch[0], _lib.stream_ptr()))
+    for _ in range(max(3, reps)):
+        launch()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k_ms = float("inf")
+    for _ in range(3):
+        ev0.record()
+        for _ in range(reps):
+            launch()
+        ev1.record()
+        torch.cuda.synchronize()
+        k_ms = min(k_ms, ev0.elapsed_time(ev1) / reps)
+    assert int(db.status[0].item()) & (_lib.STATUS_INTERNAL | _lib.STATUS_RANGE) == 0
+    w = forward_work(db.cfg, E_enc, E_out, 0, N)
+    # algorithmic flops of the launch: every block's node chain and aggregation, the filters of blocks 1..L-1 (block 0's
+    # ride in the embedding launch), the pair MLP
+    flops = w.flops_blocks - Eu * 4.0 * H * H + w.flops_pair_output
+    ach = flops / (k_ms * 1e-3) / 1e12
+    return {"kernel": "forward_mega_kernel<256>", "bound": "mfma", "achieved": round(ach, 2),
+            "peak": round(PEAK_SPLIT_F16_TFLOPS, 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_SPLIT_F16_TFLOPS, 4),
+            "peak_note": "fp32-equivalent (algorithmic) flops against a third of the 2500 TFLOP/s dense f16 MFMA peak: "
+                         "three f16 MFMAs per fp32 multiply-add (split operands, csrc/split16.hpp); the executed f16 "
+                         "flops are 3x `achieved` against 2500",
+            "traffic": None, "avg_launch_us": round(k_ms * 1e3, 2), "launches_per_forward": 1, "flop_per_launch": flops,
+            "undirected_edges": Eu, "directed_edges": E_enc, "nodes": N,
+            "bound_note": "a latency chain at this size, not an MFMA stream: the node workgroups (100 of 256 CUs) run "
+                          "7 dependent blocks of gather + three 16-row GEMMs; DESIGN.md section 4",
+            # edge_attr read L-1 times, L-1 filter layers written, L filter layers gathered from both end points,
+            # x1 / h rows, the weights of L blocks
+            "algorithmic_bytes_per_launch": Eu * 4.0 * H * ((L - 1) * 2 + 2 * L) + 4.0 * N * H * 3 * L + 5 * 4.0 * H * H * L}
 
 
 def aggregate_roofline(lib, cfg_struct, N, E, row_ptr, dst, H, dev, reps=20):
@@ -570,10 +632,34 @@ def main():
 
     db = run.db()
     E_enc, E_out, E_diff = db.enc.num_edges(), db.out.num_edges(), db.diff_u.num_edges()
-    roofline = combo_roofline(lib, db, cfg, dev, reps=40 if db.P < 2_000_000 else 2)
+    from tsdiff_amd import engine
+    gemm = db.gemm_mode()
+    one_launch = gemm == "h2" and engine.ONE_LAUNCH and args.models == 1 and (N + 15) // 16 <= 256
     fname = PMC_C2 if args.workload == "c2" else PMC_C5
-    roofline["traffic"], roofline["traffic_source"] = pmc_traffic("layer_combo_kernel<256, false, false>", fname)
-    roofline["mfma_busy"] = mfma_busy("c2" if args.workload == "c2" else "c5", "layer_combo_kernel<256, false, false>")
+    label = "c2" if args.workload == "c2" else "c5"
+    reps = 40 if db.P < 2_000_000 else 2
+    # the fp32-input-MFMA kernel of the same launch shape (the round-2/3 path; TSDIFF_GEMM=f32)
+    rf32 = combo_roofline(lib, db, cfg, dev, reps=reps)
+    rf32["traffic"], rf32["traffic_source"] = pmc_traffic("layer_combo_kernel<256, false, false, 0>", fname)
+    rf32["mfma_busy"] = mfma_busy(label, "layer_combo_kernel<256, false, false, 0>")
+    if one_launch:
+        roofline = mega_roofline(lib, db, cfg, pos_init, dev)
+        roofline["traffic"], roofline["traffic_source"] = pmc_traffic("forward_mega_kernel<256>", fname)
+        roofline["mfma_busy"] = mfma_busy(label, "forward_mega_kernel<256>")
+    elif gemm == "h2":
+        roofline = combo_roofline(lib, db, cfg, dev, reps=reps, h2=True)
+        roofline["traffic"], roofline["traffic_source"] = pmc_traffic("layer_combo_kernel<256, false, false, 1>", fname)
+        roofline["mfma_busy"] = mfma_busy(label, "layer_combo_kernel<256, false, false, 1>")
+    else:
+        roofline = dict(rf32)
+    roofline["f32_mfma"] = rf32
+    # the same K timed steps on the fp32-input-MFMA kernels (exact fp32 fma chains)
+    f32_ms = None
+    if gemm == "h2" and world == 1:
+        engine.GEMM = "f32"
+        run.run(max(args.warmup, 5))
+        f32_ms = min(run.timed(args.steps)[0] for _ in range(3)) / args.steps * 1e3
+        engine.GEMM = "h2"
     F, F_ref = forward_flops(models[0]._cfg, E_enc, E_out, E_diff, N, args.models)
     step_s = dt / args.steps
 
@@ -586,10 +672,15 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 4),
         "fixed_ms_per_call": round(fixed_ms, 3), "steady_ms_per_step": round(steady_ms, 4),
         "default_api_ms_per_step": round(dt_traj / args.steps * 1e3, 4),
+        "f32_mfma_ms_per_step": None if f32_ms is None else round(f32_ms, 4),
+        "gemm": ("h2: tile GEMMs on the f16 MFMA, fp32 operands split into two f16 planes (22 bits), fp32 accumulation; "
+                 "eps within 2e-6 of an fp64 evaluation (fp32 MFMA: 1e-6); the L blocks + pair MLP as one launch") if gemm == "h2"
+                else "f32: fp32-input MFMA",
         "cold_ms_per_step": None if dt_cold is None else round(dt_cold / args.steps * 1e3, 4),
         "clock_ramp_ms": 150 if ramp_steps else 0, "clock_ramp_untimed_steps": ramp_steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32 (GEMM operands as split f16 pairs on the f16 MFMA, f32 accumulate)" if gemm == "h2" else "f32",
+        "data": "synthetic",
         "config": {"workload": ("configs[1]: wb97xd3-like batch of 100 graphs, LD sampling, last K steps of the "
                                 "5000-step schedule (step_lr 1e-7, clip 1000)") if args.workload == "c2" else
                                "configs[4]: synthetic 64-atom graphs, complete intra-graph pair set, LD sampling",
@@ -624,8 +715,12 @@ def main():
         dt5, p5 = run5.timed(K5)
         assert torch.isfinite(p5).all()
         db5 = run5.db()
-        rf5 = combo_roofline(lib, db5, cfg, dev, reps=2)
-        rf5["traffic"], rf5["traffic_source"] = pmc_traffic("layer_combo_kernel<256, false, false>", PMC_C5)
+        h2_5 = db5.gemm_mode() == "h2"
+        rf5 = combo_roofline(lib, db5, cfg, dev, reps=2, h2=h2_5)
+        rf5["traffic"], rf5["traffic_source"] = pmc_traffic("layer_combo_kernel<256, false, false, %d>" % (1 if h2_5 else 0), PMC_C5)
+        rf5["mfma_busy"] = mfma_busy("c5", "layer_combo_kernel<256, false, false, %d>" % (1 if h2_5 else 0))
+        if h2_5:
+            rf5["f32_mfma"] = combo_roofline(lib, db5, cfg, dev, reps=2)
         N5 = 1024 * 64
         F5, _ = forward_flops(models[0]._cfg, db5.enc.num_edges(), db5.out.num_edges(), db5.diff_u.num_edges(), N5, 1)
         out["c5"] = {"workload": "configs[4]: 1024 x 64-atom graphs, complete pair set, LD sampling, 1 checkpoint",

@@ -210,6 +210,14 @@ int tsd_interaction_block(const tsd_model_cfg* cfg, const float* w, int32_t laye
                           int32_t filter_layer, int32_t capacity_u, tsd_edges enc_u, const float* edge_attr,
                           float* Wf_out, void* stream);
 
+/* The same launch in the split-f16 arithmetic of the inference forward (w16: tsd_pack_weights16 image; the filter role
+ * then takes edge_attr = s1 and the FOLDED nn.0 of tsd_pack_weights, as the forward does); range_status: device word
+ * for TSD_STATUS_RANGE or NULL.  Inputs and outputs are the fp32 ones. */
+int tsd_interaction_block16(const tsd_model_cfg* cfg, const float* w16, int32_t layer, int32_t num_nodes,
+                            tsd_edges enc, const float* Wf_layer, const float* x1_in, float* h, float* x1_out,
+                            int32_t filter_layer, int32_t capacity_u, tsd_edges enc_u, const float* edge_attr,
+                            float* Wf_out, int32_t* range_status, void* stream);
+
 /* h += lin(ssp(lin2(agg) )); if next_layer >= 0 also x1 = lin1_{next_layer}(h).
  * part / enc_row_ptr: only for agg produced by tsd_cfconv_layer (rows cut by tile edges); pass NULL
  * for a complete agg (tsd_cfconv_aggregate). */
@@ -300,6 +308,14 @@ size_t tsd_forward_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes,
                                     int32_t num_models);
 /* geometry + M forwards; edge_inv_u[m] valid for the first *geo.out_u.count entries. */
 int tsd_score_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* pos, void* stream);
+
+/* Measurement entry (bench.py's roofline of the dominant kernel): re-runs ONLY the one-launch kernel of the split-f16
+ * forward -- the L interaction blocks (models/encoder/schnet.py:203-225) and the pair MLP (models/common.py:226-229) --
+ * on the state the last tsd_score_forward of this batch left in the workspace (edge attributes, block-0 filters, edge
+ * lists).  `epoch` numbers the calls 1, 2, 3, ... (the hand-off words of the launch are monotonic; call 1 zeroes them).
+ * TSD_ERR_UNSUPPORTED when the batch does not take that path (no weights16 / status, several checkpoints, > 256 node
+ * tiles). */
+int tsd_forward_blocks(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t epoch, void* stream);
 
 /* mean over checkpoints in the reference's order, expanded to the directed out list:
  * edge_inv[e] = ((inv_u[0][u] + inv_u[1][u]) + ...)/M with u = out.umap[e]   -> edge_inv [P] */

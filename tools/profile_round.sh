@@ -42,6 +42,7 @@ python3 tools/mfma_busy.py c2=$(db /tmp/p_sq) c5=$(db /tmp/p_sq5) train=$(db /tm
 {
   echo "# SQ counters per launch (rocprofv3 --kernel-trace --pmc, one pass), $TAG"
   echo; echo "## configs[1] (batch 100)"; echo '```'
+  python3 tools/pmc_kernel_table.py $(db /tmp/p_sq) forward_mega
   python3 tools/pmc_kernel_table.py $(db /tmp/p_sq) layer_combo
   python3 tools/pmc_kernel_table.py $(db /tmp/p_sq) typed_embed
   python3 tools/pmc_kernel_table.py $(db /tmp/p_sq) step_tail

@@ -150,6 +150,8 @@ SIGNATURES = {
     "tsd_filter_gen": (C.c_int, [_CFG, _P, C.c_int32, Edges, _P, _P, _P]),
     "tsd_interaction_block": (C.c_int, [_CFG, _P, C.c_int32, C.c_int32, Edges, _P, _P, _P, _P, C.c_int32, C.c_int32,
                                         Edges, _P, _P, _P]),
+    "tsd_interaction_block16": (C.c_int, [_CFG, _P, C.c_int32, C.c_int32, Edges, _P, _P, _P, _P, C.c_int32, C.c_int32,
+                                          Edges, _P, _P, _P, _P]),
     "tsd_cfconv_aggregate": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "tsd_node_update": (C.c_int, [_CFG, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "tsd_pair_output": (C.c_int, [_CFG, _P, C.c_int32, Edges, _P, _P, _P, _P, _P]),
@@ -206,6 +208,7 @@ SIGNATURES = {
                                         _P, _P, _P]),
     "tsd_bucket_weights_floats": (C.c_size_t, [_CFG, C.c_int32]),
     "tsd_bucket_weights_build": (C.c_int, [_CFG, _P, C.c_int32, _P, _P, _P]),
+    "tsd_forward_blocks": (C.c_int, [_CFG, C.POINTER(Batch), C.c_int32, _P]),
     "tsd_pack_weights16": (C.c_int, [_CFG, _P, _P, _P]),
     "tsd_bucket_weights16": (C.c_int, [_CFG, _P, C.c_int32, _P, _P]),
 }

@@ -537,7 +537,7 @@ int tsd_filter_gen(const tsd_model_cfg* cfg, const float* w, int32_t capacity, t
     return launch_filter_gen(*cfg, w, capacity, edges, edge_attr, Wf, 0, cfg->num_convs, (hipStream_t)stream);
 }
 
-int tsd_interaction_block(const tsd_model_cfg* cfg, const float* w, int32_t layer, int32_t num_nodes,
+static int interaction_block_impl(int h2, int32_t* range_status, const tsd_model_cfg* cfg, const float* w, int32_t layer, int32_t num_nodes,
                           tsd_edges enc, const float* Wf_layer, const float* x1_in, float* h, float* x1_out,
                           int32_t filter_layer, int32_t capacity_u, tsd_edges enc_u, const float* edge_attr,
                           float* Wf_out, void* stream) {
@@ -550,14 +550,32 @@ int tsd_interaction_block(const tsd_model_cfg* cfg, const float* w, int32_t laye
                 "node role needs Wf_layer, x1_in != x1_out and the directed enc list");
     TSD_REQUIRE(filter_layer < 0 || (edge_attr && Wf_out && enc_u.count && enc_u.dist), "filter role: null pointer");
     Prec prec{};
+    if (h2) {
+        prec.mode = PREC_H2;
+        prec.range_status = range_status;
+    }
 #ifdef TSD_TRACE
     extern int g_tsd_debug_prec;  // (kernels_combo.hip, variant builds: the traced launch in the split-f16 arithmetic)
-    prec.mode = g_tsd_debug_prec;
+    if (g_tsd_debug_prec) prec.mode = g_tsd_debug_prec;
 #endif
     return launch_layer_combo(*cfg, w, layer, num_nodes, enc, Wf_layer, x1_in, nullptr, h, x1_out,
                               filter_layer < 0 ? 0 : filter_layer, 0,
                               filter_layer < 0 ? 0 : filter_tiles_per_layer(capacity_u), capacity_u, enc_u, edge_attr,
-                              Wf_out, 1, 1, 0, 0, 0, (hipStream_t)stream, nullptr, 0, nullptr, nullptr, false, prec);
+                              Wf_out, 1, 1, 0, 0, 0, (hipStream_t)stream, nullptr, 0, nullptr, nullptr, h2 != 0, prec);
+}
+
+int tsd_interaction_block(const tsd_model_cfg* cfg, const float* w, int32_t layer, int32_t num_nodes, tsd_edges enc,
+                          const float* Wf_layer, const float* x1_in, float* h, float* x1_out, int32_t filter_layer,
+                          int32_t capacity_u, tsd_edges enc_u, const float* edge_attr, float* Wf_out, void* stream) {
+    return interaction_block_impl(0, nullptr, cfg, w, layer, num_nodes, enc, Wf_layer, x1_in, h, x1_out, filter_layer,
+                                  capacity_u, enc_u, edge_attr, Wf_out, stream);
+}
+int tsd_interaction_block16(const tsd_model_cfg* cfg, const float* w16, int32_t layer, int32_t num_nodes, tsd_edges enc,
+                            const float* Wf_layer, const float* x1_in, float* h, float* x1_out, int32_t filter_layer,
+                            int32_t capacity_u, tsd_edges enc_u, const float* edge_attr, float* Wf_out,
+                            int32_t* range_status, void* stream) {
+    return interaction_block_impl(1, range_status, cfg, w16, layer, num_nodes, enc, Wf_layer, x1_in, h, x1_out, filter_layer,
+                                  capacity_u, enc_u, edge_attr, Wf_out, stream);
 }
 
 int tsd_cfconv_aggregate(int32_t hidden, int32_t num_nodes, const int32_t* row_ptr, const int32_t* dst,
@@ -634,6 +652,26 @@ int tsd_score_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
     if ((r = check_batch(*cfg, batch))) return r;
     TSD_REQUIRE(pos, "null pointer");
     return forward_impl(*cfg, *batch, pos, (hipStream_t)stream);
+}
+
+int tsd_forward_blocks(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t epoch, void* stream) {
+    TraceRange range("tsd:forward_blocks");
+    int r = check_cfg(cfg);
+    if (r) return r;
+    if ((r = check_batch(*cfg, batch))) return r;
+    TSD_REQUIRE(epoch >= 1, "epoch=%d (1, 2, ... since the first call)", epoch);
+    const tsd_batch& b = *batch;
+    const bool typed = kFold && b.enc_tiles.num_tiles > 0 && b.bucket_weights != nullptr;
+    if (!(typed && b.weights16 && b.bucket_weights16 && b.status && mega_shape(*cfg, b.num_nodes, b.num_models) &&
+          b.num_pairs > 0)) {
+        set_error("tsd_forward_blocks: the batch does not take the one-launch split-f16 forward");
+        return TSD_ERR_UNSUPPORTED;
+    }
+    const Workspace w = carve(*cfg, b.num_nodes, b.num_pairs, b.num_models, b.workspace);
+    hipStream_t st = (hipStream_t)stream;
+    if (epoch == 1) TSD_HIP(hipMemsetAsync(w.ctl, 0, w.ctl_words * sizeof(int32_t), st));
+    return launch_forward_mega(*cfg, b, nullptr, b.weights16, w.ea, w.wf, w.h, w.x1m, w.stride_nh, w.ctl, w.ctl + 32, epoch,
+                               b.status, st);
 }
 
 int tsd_ensemble_mean(int32_t num_models, int32_t num_pairs, tsd_edges out, const float* edge_inv_u,
