@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the c5 / ensemble8 / train sub-objects")
+    ap.add_argument("--no-f32", action="store_true",
+                    help="skip the fp32-MFMA kernels (`f32_mfma_ms_per_step`, `roofline.f32_mfma`): profiling runs that "
+                         "want the default path's kernels only")
     ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--no-prefetch", action="store_true",
@@ -639,9 +642,11 @@ def main():
     label = "c2" if args.workload == "c2" else "c5"
     reps = 40 if db.P < 2_000_000 else 2
     # the fp32-input-MFMA kernel of the same launch shape (the round-2/3 path; TSDIFF_GEMM=f32)
-    rf32 = combo_roofline(lib, db, cfg, dev, reps=reps)
-    rf32["traffic"], rf32["traffic_source"] = pmc_traffic("layer_combo_kernel<256, false, false, 0>", fname)
-    rf32["mfma_busy"] = mfma_busy(label, "layer_combo_kernel<256, false, false, 0>")
+    rf32 = None
+    if not args.no_f32 or gemm != "h2":
+        rf32 = combo_roofline(lib, db, cfg, dev, reps=reps)
+        rf32["traffic"], rf32["traffic_source"] = pmc_traffic("layer_combo_kernel<256, false, false, 0>", fname)
+        rf32["mfma_busy"] = mfma_busy(label, "layer_combo_kernel<256, false, false, 0>")
     if one_launch:
         roofline = mega_roofline(lib, db, cfg, pos_init, dev)
         roofline["traffic"], roofline["traffic_source"] = pmc_traffic("forward_mega_kernel<256>", fname)
@@ -655,7 +660,7 @@ def main():
     roofline["f32_mfma"] = rf32
     # the same K timed steps on the fp32-input-MFMA kernels (exact fp32 fma chains)
     f32_ms = None
-    if gemm == "h2" and world == 1:
+    if gemm == "h2" and world == 1 and not args.no_f32:
         engine.GEMM = "f32"
         run.run(max(args.warmup, 5))
         f32_ms = min(run.timed(args.steps)[0] for _ in range(3)) / args.steps * 1e3

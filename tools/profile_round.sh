@@ -5,10 +5,12 @@
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 db() { ls $1/*/*results.db $1/*results.db 2>/dev/null | head -1; }
-B="--no-cpu-baseline --no-extras"
+B="--no-cpu-baseline --no-extras --no-f32"
 rm -rf /tmp/p_*
 rocprofv3 --kernel-trace --stats -d /tmp/p_c2 -o c2 -- python3 bench.py --steps 200 --warmup 20 $B > gpurun_out/${TAG}_prof_c2.log 2>&1
 python3 tools/rocpd_stats.py $(db /tmp/p_c2) > gpurun_out/${TAG}_kernel_stats_c2.md
+TSDIFF_GEMM=f32 rocprofv3 --kernel-trace --stats -d /tmp/p_c2f -o c2f -- python3 bench.py --steps 200 --warmup 20 $B > gpurun_out/${TAG}_prof_c2_f32.log 2>&1
+python3 tools/rocpd_stats.py $(db /tmp/p_c2f) > gpurun_out/${TAG}_kernel_stats_c2_f32.md
 rocprofv3 --kernel-trace --stats -d /tmp/p_c5 -o c5 -- python3 bench.py --workload c5 --steps 4 --warmup 1 $B > gpurun_out/${TAG}_prof_c5.log 2>&1
 python3 tools/rocpd_stats.py $(db /tmp/p_c5) > gpurun_out/${TAG}_kernel_stats_c5.md
 rocprofv3 --kernel-trace --stats -d /tmp/p_tr -o tr -- python3 bench.py --workload train --steps 20 --warmup 5 > gpurun_out/${TAG}_prof_train.log 2>&1

@@ -1469,7 +1469,8 @@ int filter_tiles_per_layer(int capacity_u) { return (capacity_u + T - 1) / T; }
 // node chain, a latency chain that occupies 100 of the 256 CUs.  Here the L launches behind the embedding launch become
 // roles of one grid, ordered by blockIdx (= dispatch order):
 //   [node workgroups: ONE per node tile, persistent over all L blocks]
-//   [filter tiles of blocks 1 .. L-1, block-major]  [pair tiles]
+//   [filter tiles of blocks 1 .. L-1, block-major]  [pair tiles]      (the first n_node pair tiles sit at positions
+//    256 .. 256 + n_node - 1, i.e. on the node workgroups' CUs, where they sleep until the node chain is done)
 // (the embedding launch before it still carries the filters of block 0 and the directed -> undirected map), and the
 // launch boundaries become hand-offs (cdna_hip_programming.md Guideline 16: 16-byte write-through payload, every
 // storing wave drains, ONE lane publishes; relaxed agent-scope polls by one wave; consumers read handed-off rows with
@@ -1715,10 +1716,26 @@ __global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A) {
         return;
     }
     b -= A.n_node;
-    if (b < A.n_filter) {  // filter tiles of blocks 1 .. L-1
-        const int layer = 1 + b / A.tiles_per_layer;
+    // Workgroups b and b + 256 of a launch share a CU (measured; a speed assumption only).  The node workgroups took the
+    // first slot of n_node CUs; whatever is dispatched at positions 256 .. 256 + n_node - 1 becomes their neighbour.  A
+    // filter tile there costs the node chain -- the critical path of the launch -- a third of its speed (17.5 us per
+    // block alone, 23 us beside filter tiles: gather and epilogues share the CU's L1 and issue slots).  So those
+    // positions go to PAIR tiles, which only sleep until the node chain has finished (their node-independent GEMM
+    // deferred behind the wait): the node workgroups get their CUs to themselves.
+#ifndef TSD_MEGA_PARK
+#define TSD_MEGA_PARK 1
+#endif
+    const int first_filters = TSD_MEGA_PARK ? min(A.n_filter, max(0, 256 - A.n_node)) : A.n_filter;
+    const int parked = TSD_MEGA_PARK ? min(A.n_pair, A.n_node) : 0;
+    int filter_item = -1, pair_item = -1;
+    if (b < first_filters) filter_item = b;
+    else if (b < first_filters + parked) pair_item = b - first_filters;
+    else if (b < A.n_filter + parked) filter_item = b - parked;
+    else if (b < A.n_filter + A.n_pair) pair_item = b - A.n_filter;
+    if (filter_item >= 0) {  // filter tiles of blocks 1 .. L-1
+        const int layer = 1 + filter_item / A.tiles_per_layer;
 #ifndef TSD_MEGA_SKIP_FILTER  // (timing experiments only: wrong results)
-        filter_role_h<H>(A.f, b, smem, A.status TSD_TRACE_NULL);
+        filter_role_h<H>(A.f, filter_item, smem, A.status TSD_TRACE_NULL);
 #endif
         mega_arrive(A.ctl + MegaCtl::LAYER0 + MegaCtl::LSTRIDE * layer);
         TSD_MEGA_T(0, 3);
@@ -1726,11 +1743,10 @@ __global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A) {
         TSD_MEGA_T(3, (unsigned long long)layer);
         return;
     }
-    b -= A.n_filter;
-    if (b < A.n_pair) {
+    if (pair_item >= 0) {
         ComboPre q = A.q;
         q.ready_target = epoch * 64 + A.L;
-        pair_role_h<H>(q, b, A.n_node, smem, false, A.status);
+        pair_role_h<H>(q, pair_item, A.n_node, smem, /* defer_pre */ pair_item < parked, A.status);
         TSD_MEGA_T(0, 4);
         TSD_MEGA_T(2, wall_clock64());
     }
