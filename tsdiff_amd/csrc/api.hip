@@ -149,9 +149,9 @@ constexpr bool kFold = TSD_FOLD != 0;
 #ifndef TSD_MEGA
 #define TSD_MEGA 1  // 0 (A/B variant builds): the split-f16 forward as one launch per block
 #endif
-// shapes the one-launch forward takes: every node workgroup resident at once, one checkpoint
+// shapes the one-launch forward takes: every node workgroup (8 atoms each) resident at once, one checkpoint
 static bool mega_shape(const tsd_model_cfg& c, int N, int M) {
-    return TSD_MEGA != 0 && M == 1 && N > 0 && (N + TSD_NODE_TILE - 1) / TSD_NODE_TILE <= 256 && c.num_convs <= 60;
+    return TSD_MEGA != 0 && M == 1 && N > 0 && (N + mega_node_rows() - 1) / mega_node_rows() <= 256 && c.num_convs <= 60;
 }
 
 static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base) {

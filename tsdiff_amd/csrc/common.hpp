@@ -199,6 +199,7 @@ struct ComboPre {
     float* edge_inv;          // [capacity_u]
     int32_t* ready;           // [M][node tiles] flags: >= ready_target = the tile's rows of h are in memory
     int ready_target = 1;     // (per-block launches: flags are 0 / 1; one-launch forward: epoch * 64 + blocks)
+    int ready_div = TSD_NODE_TILE;  // atoms per flag (node tile rows: 16; the one-launch forward's node tiles: 8)
     int32_t* status;          // TSD_STATUS_INTERNAL on a wait that gave up
     size_t inv_stride;        // per-checkpoint stride of edge_inv
 };
@@ -267,6 +268,7 @@ int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float*
                         float* h, float* x1m, size_t x1_stride, int32_t* ctl, const int32_t* epoch_src, int epoch_bias,
                         int32_t* status, hipStream_t st);
 size_t mega_ctl_words(int N);
+int mega_node_rows();
 int launch_bucket_weights16(const tsd_model_cfg& c, const float* bucket, int num_slots, float* out16, hipStream_t st);
 
 inline bool hidden_supported(int H) { return H == 64 || H == 128 || H == 256; }

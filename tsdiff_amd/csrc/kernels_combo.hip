@@ -123,8 +123,10 @@ struct VRow<1> {
 // *amax collects max |sum| for the range check.
 // SC1: the rows are loaded with `sc1` (from L2, never this CU's L1): the one-launch forward gathers rows that other CUs
 // wrote during the launch into buffers this CU may have read an older version of.
+// TR: rows of the tile that are aggregated (default TN; the one-launch forward's node workgroups take 8: rows TR .. TN - 1
+// of the LDS tile are then not written here).
 template <int H, bool SAVE, int NW = 2 * H / 64 /* waves of the workgroup */, int U = 8 /* edges in flight per wave */,
-          bool SPLIT = false, bool SC1 = false>
+          bool SPLIT = false, bool SC1 = false, int TR = TN>
 __device__ __forceinline__ void aggregate_tile(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ dst,
                                                const int32_t* __restrict__ umap, const float* __restrict__ Wf,
                                                const float* __restrict__ x, int N, int n0, float* buf,
@@ -138,9 +140,9 @@ __device__ __forceinline__ void aggregate_tile(const int32_t* __restrict__ row_p
     umap = reinterpret_cast<const int32_t*>(uniform_ptr(umap));
     Wf = reinterpret_cast<const float*>(uniform_ptr(Wf));
     x = reinterpret_cast<const float*>(uniform_ptr(x));
-    constexpr int RPW = TN / NW;  // rows aggregated per wave
+    constexpr int RPW = TR / NW;  // rows aggregated per wave
     constexpr int V = H / 64;     // channels per lane during aggregation
-    static_assert(TN % NW == 0, "");
+    static_assert(TR % NW == 0 && TR <= TN, "");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // The RPW rows of this wave are consecutive, so their edges are ONE contiguous CSR range
     // [rp[first], rp[first + RPW]): one load of the RPW + 1 row offsets, one coalesced load of the indices per
@@ -594,7 +596,7 @@ __device__ __forceinline__ void pair_role(const ComboPre& q, int tile, int node_
             lo = min(lo, __shfl_xor(lo, off));
             hn = max(hn, __shfl_xor(hn, off));
         }
-        const int t_lo = lo / TN, t_hi = hn / TN;
+        const int t_lo = lo / q.ready_div, t_hi = hn / q.ready_div;
         bool gave_up = false;
         for (int t0 = t_lo; t0 <= t_hi && !gave_up; t0 += 64) {
             const int t = t0 + lane;
@@ -933,7 +935,7 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
             lo = min(lo, __shfl_xor(lo, off));
             hn = max(hn, __shfl_xor(hn, off));
         }
-        const int t_lo = lo / TN, t_hi = hn / TN;
+        const int t_lo = lo / q.ready_div, t_hi = hn / q.ready_div;
         bool gave_up = false;
         for (int t0 = t_lo; t0 <= t_hi && !gave_up; t0 += 64) {
             const int t = t0 + lane;
@@ -1577,26 +1579,35 @@ __device__ __forceinline__ void mega_arrive(int32_t* counter) {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// the node workgroup of tile `tile`: all L blocks (node_role_h's chain per block, h kept in registers, x1 published)
+// The node workgroup of tile `tile`: all L blocks (node_role_h's chain per block, h kept in registers, x1 published).
+// Tile rows MEGA_TR: 16 as in the per-block launches.  8 (one row per wave in the gather: two dependent round trips for
+// ~16 edges instead of four for ~32; the MFMA's other rows are free) is bit-identical and was measured SLOWER at batch
+// 100: 0.254 vs 0.223 ms/step -- 200 node workgroups leave the filter tiles 312 of the 512 slots, a layer of 408 tiles
+// then takes 1.3 rounds and the node chain waits for its filters (tools/trace_mega.py: 188 vs 157 us).
+#ifndef TSD_MEGA_TR
+#define TSD_MEGA_TR 16  // (8: built and measured, see below)
+#endif
+constexpr int MEGA_TR = TSD_MEGA_TR;
 template <int H>
 __device__ __forceinline__ void node_persist_h(const MegaArgs& A, int tile, int epoch, float* smem) {
     constexpr int LDH = ldh_of(H), LDA = H + 4;
     constexpr int NT = 2 * H, CB16 = 2, C4 = H / 4;
     const Planes pl = planes_at(smem, TN, LDH);
     float* xst = smem;  // the finished x1 tile as fp32 rows (over the planes: TN (H + 4) <= TN (H + 8) floats)
-    const int n0 = tile * TN;
+    constexpr int TR = MEGA_TR < 2 * H / 64 ? 2 * H / 64 : MEGA_TR;  // (at least one row per wave)
+    const int n0 = tile * TR;
     int tid_ = threadIdx.x;
     asm volatile("" : "+v"(tid_));  // (opaque: lane arithmetic is not hoisted above the role branch of the one-launch kernel)
     const int tid = tid_;
     const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, l15 = lane & 15;
     const int col0 = wave * 32;
-    const int nrows = min(TN, A.N - n0);
+    const int nrows = min(TR, A.N - n0);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     float amax = 0.0f;
     int32_t* node_done = A.ctl + MegaCtl::NODE0;
     // the node tiles that hold atoms of the graphs this tile's atoms belong to
     const int g_first = A.node_graph[n0], g_last = A.node_graph[n0 + nrows - 1];
-    const int t_lo = A.graph_ptr[g_first] / TN, t_hi = (A.graph_ptr[g_last + 1] - 1) / TN;
+    const int t_lo = A.graph_ptr[g_first] / TR, t_hi = (A.graph_ptr[g_last + 1] - 1) / TR;
     // residual input of block 0: the pos-independent node embedding z
     float h_res[CB16][4];
 #pragma unroll
@@ -1616,6 +1627,13 @@ __device__ __forceinline__ void node_persist_h(const MegaArgs& A, int tile, int 
 #endif
         }
         __syncthreads();
+        if constexpr (TR < TN) {  // the MFMA's rows past the tile: the gather does not write them and the x1 staging of
+            // the previous block lies over them (fp32 bits read as f16 may be inf): zero, so that they stay finite
+            for (int idx = tid; idx < (TN - TR) * (LDH / 2); idx += NT) {
+                reinterpret_cast<uint32_t*>(pl.hi + TR * LDH)[idx] = 0u;
+                reinterpret_cast<uint32_t*>(pl.lo + TR * LDH)[idx] = 0u;
+            }
+        }
         const float* Wl = A.W + A.layer0 + (size_t)l * A.layer_stride;
         const float* x_in = l == 0 ? A.x1_0 : A.x1m + (size_t)(l - 1) * A.x1_stride;
         float* x_out = A.x1m + (size_t)l * A.x1_stride;
@@ -1633,7 +1651,7 @@ __device__ __forceinline__ void node_persist_h(const MegaArgs& A, int tile, int 
 #else
         constexpr bool kSc1 = true;
 #endif
-        aggregate_tile<H, false, 2 * H / 64, 8, true, kSc1>(A.row_ptr, A.dst, A.umap, A.wf + (size_t)l * A.wf_layer_stride,
+        aggregate_tile<H, false, 2 * H / 64, 8, true, kSc1, TR>(A.row_ptr, A.dst, A.umap, A.wf + (size_t)l * A.wf_layer_stride,
                                                             x_in, A.N, n0, smem, nullptr, &amax);
         hgemm16_ring_start<CB16, H>(rg, Wl + A.o_lin2_w, H, col0);
         __syncthreads();
@@ -1725,8 +1743,12 @@ __global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A) {
 #ifndef TSD_MEGA_PARK
 #define TSD_MEGA_PARK 1
 #endif
-    const int first_filters = TSD_MEGA_PARK ? min(A.n_filter, max(0, 256 - A.n_node)) : A.n_filter;
-    const int parked = TSD_MEGA_PARK ? min(A.n_pair, A.n_node) : 0;
+    // (only while the node workgroups take at most half of the CUs: every parked tile is a slot the filter tiles lose;
+    // measured at batch 100: 0.2184 vs 0.2197 ms/step -- the node chain is slowed by the memory system's load, which
+    // stays, far more than by its CU neighbour)
+    const bool park = TSD_MEGA_PARK != 0 && A.n_node <= 128;
+    const int first_filters = park ? min(A.n_filter, 256 - A.n_node) : A.n_filter;
+    const int parked = park ? min(A.n_pair, A.n_node) : 0;
     int filter_item = -1, pair_item = -1;
     if (b < first_filters) filter_item = b;
     else if (b < first_filters + parked) pair_item = b - first_filters;
@@ -1822,10 +1844,12 @@ int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float*
     A.q.h = h;
     A.q.edge_inv = b.edge_inv_u;
     A.q.ready = ctl + MegaCtl::NODE0;
+    A.q.ready_div = MEGA_TR;
     A.q.status = status;
     A.q.inv_stride = (size_t)PU;
     // grid
-    A.n_node = (N + TN - 1) / TN;
+    constexpr int TRH = MEGA_TR;  // (H = 64 / 128 / 256: 2 / 4 / 8 waves, all <= MEGA_TR rows)
+    A.n_node = (N + TRH - 1) / TRH;
     A.n_filter = A.f.tiles;
     A.n_pair = A.q.tiles;
     const int grid = A.n_node + A.n_filter + A.n_pair;
@@ -1848,7 +1872,8 @@ int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float*
     TSD_LAUNCH_CHECK("forward_mega");
     return TSD_OK;
 }
-size_t mega_ctl_words(int N) { return (size_t)MegaCtl::NODE0 + (size_t)((N + TN - 1) / TN); }
+size_t mega_ctl_words(int N) { return (size_t)MegaCtl::NODE0 + (size_t)((N + MEGA_TR - 1) / MEGA_TR); }
+int mega_node_rows() { return MEGA_TR; }
 
 
 // layer == -1: node role = lin1 of block 0 only; layer == -2: no node role.
