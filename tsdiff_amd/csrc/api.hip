@@ -174,7 +174,7 @@ static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base)
     w.stride_pre = pad(PU * H);
     w.pre = take(w.stride_pre * M);
     w.ready = reinterpret_cast<int32_t*>(take(pad((size_t)M * ((N + TSD_NODE_TILE - 1) / TSD_NODE_TILE))));
-    w.ctl_words = pad(mega_ctl_words(N));
+    w.ctl_words = pad(mega_shape(c, N, M) ? mega_ctl_words(filter_tiles_per_layer((int)PU), c.num_convs) : 64);
     w.ctl = reinterpret_cast<int32_t*>(take(w.ctl_words));
     w.x1m = take(mega_shape(c, N, M) && c.num_convs > 1 ? w.stride_nh * (size_t)(c.num_convs - 1) : 0);
     w.total = o;
@@ -268,7 +268,7 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
         // persistent over the blocks, filter tiles, pair tiles, in-launch hand-offs instead of launch boundaries
         if (epoch_src == nullptr) {
             TSD_HIP(hipMemsetAsync(w.ctl, 0, w.ctl_words * sizeof(int32_t), st));
-            epoch_src = w.ctl + 32;  // (MegaCtl::LAYER0, the counter of block 0's filter tiles: never counted, stays 0)
+            epoch_src = w.ctl + 32;  // (MegaCtl::ZERO: a word nothing writes)
             epoch_bias = 1;
         }
         return launch_forward_mega(c, b, pos, W, w.ea, w.wf, w.h, w.x1m, w.stride_nh, w.ctl, epoch_src, epoch_bias,

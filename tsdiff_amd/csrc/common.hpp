@@ -267,7 +267,7 @@ int launch_pack_weights16(const tsd_model_cfg& c, const float* packed, float* pa
 int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float* pos, const float* W16, float* ea, float* wf,
                         float* h, float* x1m, size_t x1_stride, int32_t* ctl, const int32_t* epoch_src, int epoch_bias,
                         int32_t* status, hipStream_t st);
-size_t mega_ctl_words(int N);
+size_t mega_ctl_words(int tiles_per_layer, int L);
 int mega_node_rows();
 int launch_bucket_weights16(const tsd_model_cfg& c, const float* bucket, int num_slots, float* out16, hipStream_t st);
 

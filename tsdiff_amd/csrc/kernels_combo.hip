@@ -1478,7 +1478,10 @@ int filter_tiles_per_layer(int capacity_u) { return (capacity_u + T - 1) / T; }
 // storing wave drains, ONE lane publishes; relaxed agent-scope polls by one wave; consumers read handed-off rows with
 // sc1 loads, and no buffer is written twice within the launch -- an sc1 load is served by the XCD's L2, which would
 // keep the line of an earlier read):
-//   layer_done[l] counter, + 1 per filter tile of block l >= 1 -> node workgroups entering block l
+//   filter_done[l][f] = epoch once filter tile f of block l >= 1 has its rows in memory
+//                -> the node workgroups whose edges use rows of that tile (a graph's pairs are contiguous in the
+//                   undirected list: a node tile waits for the ~5 filter tiles [min umap / 32, max umap / 32] of its own
+//                   edges, not for the slowest of the layer's 408)
 //   node_done[t] = epoch * 64 + (blocks tile t has published x1 / h for)
 //                -> the node tiles that hold atoms of the same graphs (block l + 1 gathers x1 rows of the whole graph),
 //                   pair tiles (final h)
@@ -1511,9 +1514,9 @@ extern "C" int tsd_debug_mega_trace(void* host_buf) {  // copies the buffer out 
 #define TSD_MEGA_T(slot, val)
 #endif
 struct MegaCtl {  // int32 words in the forward workspace
-    // one counter per 128-byte line (arrivals and polls of different blocks do not share a line / an L2 channel);
-    // LAYER0 itself (block 0 has no filter tiles in this launch) is never counted and stays 0
-    static constexpr int LAYER0 = 32, LSTRIDE = 32 /* [64 blocks] */, NODE0 = 32 + 64 * 32 /* [node tiles] */;
+    // ZERO: a word nothing ever writes (epoch source of a stand-alone forward); NODE0: one word per node tile (<= 256);
+    // FILTER0: one word per filter tile of blocks 0 .. L-1 (block-major; block 0's are never written here)
+    static constexpr int ZERO = 32, NODE0 = 64, FILTER0 = 64 + 256;
 };
 struct MegaArgs {
     // roles' grid ranges
@@ -1617,10 +1620,31 @@ __device__ __forceinline__ void node_persist_h(const MegaArgs& A, int tile, int 
             const int row = q * 4 + r;
             h_res[cb][r] = row < nrows ? A.z[(size_t)(n0 + row) * H + col0 + cb * 16 + l15] : 0.0f;
         }
+    // the filter tiles this tile's edges read rows of (geometry only: the same range in every block)
+    int f_lo = 0x7fffffff, f_hi = -1;
+    if (wave == 0) {
+        const int Et0 = A.row_ptr[n0], Et1 = A.row_ptr[min(n0 + TR, A.N)];
+        int lo = 0x7fffffff, hn = -1;
+        for (int e = Et0 + lane; e < Et1; e += 64) {
+            const int u = A.umap[e];
+            lo = min(lo, u);
+            hn = max(hn, u);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo = min(lo, __shfl_xor(lo, off));
+            hn = max(hn, __shfl_xor(hn, off));
+        }
+        if (hn >= 0) {
+            f_lo = lo / T;
+            f_hi = hn / T;
+        }
+    }
     for (int l = 0; l < A.L; ++l) {
         if (l > 0 && wave == 0) {
 #ifndef TSD_MEGA_NOWAIT_LAYER  // (timing experiments only: wrong results)
-            mega_wait_ge(A.ctl + MegaCtl::LAYER0 + MegaCtl::LSTRIDE * l, A.tiles_per_layer * epoch, A.status);
+            if (f_hi >= 0)
+                mega_wait_range_ge(A.ctl + MegaCtl::FILTER0 + (size_t)l * A.tiles_per_layer, f_lo, f_hi, epoch, A.status);
 #endif
 #ifndef TSD_MEGA_NOWAIT_NODE
             mega_wait_range_ge(node_done, t_lo, t_hi, epoch * 64 + l, A.status);
@@ -1759,7 +1783,12 @@ __global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A) {
 #ifndef TSD_MEGA_SKIP_FILTER  // (timing experiments only: wrong results)
         filter_role_h<H>(A.f, filter_item, smem, A.status TSD_TRACE_NULL);
 #endif
-        mega_arrive(A.ctl + MegaCtl::LAYER0 + MegaCtl::LSTRIDE * layer);
+        // every storing wave drains, the workgroup meets, ONE lane publishes the tile (Guideline 16 R1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(A.ctl + MegaCtl::FILTER0 + filter_item + A.tiles_per_layer, epoch, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);  // (filter_item counts from block 1)
         TSD_MEGA_T(0, 3);
         TSD_MEGA_T(2, wall_clock64());
         TSD_MEGA_T(3, (unsigned long long)layer);
@@ -1872,7 +1901,7 @@ int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float*
     TSD_LAUNCH_CHECK("forward_mega");
     return TSD_OK;
 }
-size_t mega_ctl_words(int N) { return (size_t)MegaCtl::NODE0 + (size_t)((N + MEGA_TR - 1) / MEGA_TR); }
+size_t mega_ctl_words(int tiles_per_layer, int L) { return (size_t)MegaCtl::FILTER0 + (size_t)tiles_per_layer * (size_t)(L > 0 ? L : 1); }
 int mega_node_rows() { return MEGA_TR; }
 
 
