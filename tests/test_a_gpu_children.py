@@ -59,7 +59,11 @@ def test_bench_sampling_under_torchrun_one_rank():
     rec = _json_line(_torchrun(["bench.py", "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline",
                                 "--no-extras"]))
     assert rec["n_gpus"] == 1 and rec["steps"] == 5 and rec["unit"] == "atoms*steps/s" and rec["value"] > 0
-    assert rec["config"]["graphs_per_gpu"] == 100 and rec["roofline"]["kernel"].startswith("layer_combo_kernel")
+    assert rec["config"]["graphs_per_gpu"] == 100
+    # the dominant kernel of the default (split-f16) path, with the fp32-MFMA block launch beside it
+    assert rec["roofline"]["kernel"].startswith("forward_mega_kernel") and 0 < rec["roofline"]["frac"] < 1
+    assert rec["roofline"]["f32_mfma"]["kernel"].startswith("layer_combo_kernel")
+    assert rec["f32_mfma_ms_per_step"] > rec["ms_per_step"] > 0
     assert rec["cpu_baseline"] is None and "c5" not in rec
 
 
