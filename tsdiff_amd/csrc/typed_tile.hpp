@@ -71,9 +71,7 @@ __device__ __forceinline__ void typed_embed_tile_h(const TypedEmbedW& w, const T
         for (int r = 0; r < nrows; ++r) any |= s_row[r] >= 0;
         if (!any) return;
     }
-    // (ring of 2 k-steps: this tile kernel holds three GEMMs' worth of epilogue state and sits at the 128-VGPR line
-    // that two resident workgroups per CU need; a forced cap makes the compiler spill beside the asm-issued loads)
-    HRing<1, 2> rg;
+    HRing<1, HRING_R> rg;
     const float bias_t = bt[col];
     {   // Linear(1,H) + swish: thread = (channel pair, quarter of the tile's rows)
         const int c = (tid % (H / 2)) * 2, r0 = (tid / (H / 2)) * (T / 4);
