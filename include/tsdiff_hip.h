@@ -291,7 +291,8 @@ typedef struct tsd_batch {
     int32_t max_graph_nodes;    /* atoms of the largest graph (host knowledge), or 0 = unknown: the sampling loop then
                                    runs its step tail as three launches instead of the fused one (<= 64-atom graphs) */
     int32_t reserved;           /* flags; bit 0: run the forward as one launch per block even where the one-launch form
-                                   applies (A/B and cross-check switch; results are bit-identical) */
+                                   applies; bit 1: 32-row filter tiles also where a split-f16 block launch would take
+                                   64-row ones (A/B and cross-check switches; results are bit-identical) */
     tsd_typed_tiles enc_tiles, diff_tiles;  /* static type-sorted embedding tiles, or num_tiles = 0: generic embedding */
     const float* bucket_weights;            /* [M][(enc + diff buckets) * (H*H + H)] (tsd_bucket_weights_build) or NULL */
     /* ---- appended in 0.4: the split-f16 inference forward (see tsd_pack_weights16) ---- */

@@ -111,6 +111,28 @@ def test_small_configs_and_ensembles_take_the_right_path(dev, monkeypatch):
         assert_close(res["one"].cpu().numpy(), res["f32"].cpu().numpy(), RTOL, f"edge_inv, {len(seeds)} checkpoint(s)")
 
 
+def test_wide_filter_tiles_equal_narrow_ones(dev, monkeypatch):
+    """a block launch with >= 1024 filter tiles takes them as 64-row tiles (two row blocks per weight fragment): every
+    row is the same MFMA sequence as in a 32-row tile, so the forward is bit for bit the one with
+    tsd_batch.reserved bit 1 set; both within 1e-5 of the fp32-MFMA forward.  40 graphs of 63 atoms, all pairs edges:
+    78120 undirected edges = 2442 32-row tiles per block = 1220 64-row tiles + one of 40 rows"""
+    from tsdiff_amd import engine, synth
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    model = make_model(cfg, 3, dev)
+    b = synth.dense_stress_batch(40, n=63, seed=9)
+    g = to_dev({**{k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}, "num_graphs": 40}, dev)
+    set_mode = _modes(monkeypatch)
+    res = {}
+    for name, gemm, wide in (("wide", "h2", True), ("narrow", "h2", False), ("f32", "f32", True)):
+        set_mode(gemm, True)
+        monkeypatch.setattr(engine, "WIDE_FILTER_TILES", wide)
+        inv, _, _ = run_forward(model, g, dev)
+        res[name] = inv.clone()
+    assert torch.isfinite(res["wide"]).all()
+    assert torch.equal(res["wide"], res["narrow"])
+    assert_close(res["wide"].cpu().numpy(), res["f32"].cpu().numpy(), RTOL, "64-row filter tiles vs fp32 MFMA")
+
+
 def test_activation_beyond_the_f16_range_falls_back_to_fp32(dev, monkeypatch):
     """one channel of the edge attribute is pushed to 1e5 (> 65504): the split-f16 kernels raise TSD_STATUS_RANGE and
     the host reruns the call on the fp32-MFMA kernels -- same result as asking for fp32 in the first place"""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of the whole sampling step (configs[1] by default) across library variants and host switches.
 
-    python tools/ab_step.py [--workload c2|c5|ens8] [--steps 200] [--rounds 3] NAME=LIB[:tail0] ...
+    python tools/ab_step.py [--workload c2|c5|ens8|gNNN] [--steps 200] [--rounds 3] NAME=LIB[:tail0] ...
 
 Every configuration runs in its own child process (one library per process), the configurations interleaved over
 `rounds` rounds; prints ms/step min / median per configuration.  LIB = path of a libtsdiff_hip.so variant
@@ -37,8 +37,8 @@ def child(workload, steps, lib, flags):
         b = synth.dense_stress_batch(1024, n=64, seed=1000)
         G = 1024
     else:
-        b = synth.wb97xd3_like_batch(100, seed=1000)
-        G = 100
+        G = int(workload[1:]) if workload[0] == "g" else 100   # gNNN: NNN graphs of the configs[1] distribution
+        b = synth.wb97xd3_like_batch(G, seed=1000)
     g = to_dev(b, dev)
     N = g["pos"].shape[0]
     gen = torch.Generator(device=dev)

@@ -220,6 +220,7 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     if (kFold && typed && b.weights16 != nullptr && b.bucket_weights16 != nullptr) {
         prec.mode = PREC_H2;
         prec.range_status = status ? status : b.status;
+        prec.narrow_filter_tiles = (b.reserved & 2) != 0;
     }
     const bool h2 = prec.mode == PREC_H2;
     const float* W = h2 ? b.weights16 : b.weights;

@@ -179,6 +179,7 @@ enum : int { PREC_F32 = 0, PREC_H2 = 1 };
 struct Prec {
     int mode = PREC_F32;
     int32_t* range_status = nullptr;
+    bool narrow_filter_tiles = false;  // 32-row filter tiles also where a launch would take 64-row ones (tsd_batch.reserved bit 1)
 };
 
 // optional third role of the per-block launch (kernels_combo.hip), filled by the forward in api.hip

@@ -794,8 +794,11 @@ __device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float*
     range_report(amax, range_status);
 }
 
-template <int H>
+// RB = 32-row blocks of one tile: 1 in the small launches (more, shorter tiles), 2 where a launch is many chip-fulls
+// of filter tiles (a weight fragment from the ring then feeds two row blocks: the tile is bound by the weight feed).
+template <int H, int RB>
 __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, float* smem, int32_t* range_status TSD_TRACE_ARG) {
+    constexpr int TT = T * RB;
     const int g = f.g_begin + item;
     const int lrel = g / f.tiles_per_layer, tile = g - lrel * f.tiles_per_layer;
     const float* Wb = f.Wl0 + (size_t)(f.layer0 + lrel) * f.layer_stride;
@@ -803,69 +806,74 @@ __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, fl
     float* out = f.wf + (size_t)(lrel % f.wf_slots) * f.wf_layer_stride;
     constexpr int LDH = ldh_of(H), LDA = H + 4;
     constexpr int NT = 2 * H, C4 = H / 4;
-    const Planes pl = planes_at(smem, T, LDH);
-    float* buf = smem;            // the finished filter tile as fp32 rows (over the planes: T (H + 4) <= T (H + 8) floats)
-    float* s_c = smem + T * LDH;  // (planes: 2 x T x LDH f16 = T x LDH floats)
+    const Planes pl = planes_at(smem, TT, LDH);
+    float* buf = smem;             // the finished filter tile as fp32 rows (over the planes: TT (H + 4) <= TT (H + 8) floats)
+    float* s_c = smem + TT * LDH;  // (planes: 2 x TT x LDH f16 = TT x LDH floats)
 
     const int E = *f.e.count;
-    const int e0 = tile * T;
+    const int e0 = tile * TT;
     if (e0 >= E) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int col0 = (tid >> 6) * 32, col = col0 + l31;
-    const int nrows = min(T, E - e0);
+    const int nrows = min(TT, E - e0);
     float amax = 0.0f;
     TSD_TRACE_ID(2);
     TSD_TRACE_AT(0);
 
     HRing<1, HRING_R> rg;
     hgemm_ring_start<1, H>(rg, nn0_w, H, col0);
-    if (tid < T) s_c[tid] = tid < nrows ? cutoff_weight(f.e.dist[e0 + tid], f.conv_cutoff, f.smooth) : 0.0f;
+    for (int r = tid; r < TT; r += NT) s_c[r] = r < nrows ? cutoff_weight(f.e.dist[e0 + r], f.conv_cutoff, f.smooth) : 0.0f;
     const float b0 = nn0_b[col], b2 = nn2_b[col];
     {   // edge_attr tile -> LDS planes with every load of a thread in flight together (rows past the end clamped)
-        constexpr int NIT = T * C4 / NT;
-        static_assert(T * C4 % NT == 0, "tile / block mismatch");
-        static_assert(NIT == 4, "ld16_wait4 names four registers");
-        f32x4 v[NIT];  // (sc1: in the one-launch forward the rows were stored by other workgroups of this launch)
+        constexpr int NIT = TT * C4 / NT;
+        static_assert(TT * C4 % NT == 0, "tile / block mismatch");
+        static_assert(NIT == 4 * RB, "ld16_wait4 names four registers");
+        f32x4 v[RB][4];  // (sc1: in the one-launch forward the rows were stored by other workgroups of this launch)
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
-            ld16_sc1(v[it], f.edge_attr + (size_t)(e0 + min(r, nrows - 1)) * H + c4 * 4);
+            ld16_sc1(v[it / 4][it % 4], f.edge_attr + (size_t)(e0 + min(r, nrows - 1)) * H + c4 * 4);
         }
-        ld16_wait4(v);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) ld16_wait4(v[rb]);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            planes_store4(pl, r * LDH + c4 * 4, r < nrows ? v[it] : z, amax);
+            planes_store4(pl, r * LDH + c4 * 4, r < nrows ? v[it / 4][it % 4] : z, amax);
         }
     }
     __syncthreads();
     TSD_TRACE_AT(1);
 
-    f32x16 accm[1][1], accx[1][1];
+    f32x16 accm[RB][1], accx[RB][1];
     hzero(accm, accx);
-    hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
+    hgemm_ring_run<RB, 1, H>(rg, pl, LDH, accm, accx);
     hgemm_ring_start<1, H>(rg, nn2_w, H, col0);
     TSD_TRACE_WAVE(8);
     TSD_TRACE_AT(2);
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-        planes_store1(pl, acc_row(r, hi) * LDH + col, sspf(hval(accm[0][0], accx[0][0], r) + b0), amax);
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            planes_store1(pl, (rb * T + acc_row(r, hi)) * LDH + col, sspf(hval(accm[rb][0], accx[rb][0], r) + b0), amax);
     __syncthreads();
     TSD_TRACE_AT(3);
 
     hzero(accm, accx);
-    hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
+    hgemm_ring_run<RB, 1, H>(rg, pl, LDH, accm, accx);
     TSD_TRACE_WAVE(16);
     TSD_TRACE_AT(4);
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r, hi);
-        buf[row * LDA + col] = (hval(accm[0][0], accx[0][0], r) + b2) * s_c[row];
-    }
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rb * T + acc_row(r, hi);
+            buf[row * LDA + col] = (hval(accm[rb][0], accx[rb][0], r) + b2) * s_c[row];
+        }
     __syncthreads();
     TSD_TRACE_AT(5);
     for (int idx = tid; idx < nrows * C4; idx += NT) {
@@ -1310,6 +1318,9 @@ struct ComboStride {  // per-checkpoint strides (blockIdx.y = checkpoint of the 
     int32_t* range_status;  // PREC_H2 launches: device word for TSD_STATUS_RANGE (or NULL)
 };
 
+#ifndef TSD_FILTER_WIDE_MIN
+#define TSD_FILTER_WIDE_MIN 1024  // filter tiles (x checkpoints) of a block launch from which they are 64 rows; 0: never
+#endif
 constexpr int NODE_RUN = 4;  // consecutive node tiles kept on one XCD (one 64-atom graph = 4 tiles)
 
 // TAIL: the instantiation of the launches that carry a third role behind the filter tiles (the pair MLP of the last
@@ -1317,7 +1328,8 @@ constexpr int NODE_RUN = 4;  // consecutive node tiles kept on one XCD (one 64-a
 // block launches do not carry its code and registers.
 // PREC: PREC_F32 = fp32-input MFMA roles; PREC_H2 = the split-f16 roles (no SAVE form: the training step stays fp32,
 // and no pre role: the piecewise pair output computes both halves itself).
-template <int H, bool SAVE, bool TAIL, int PREC = PREC_F32>
+// FRB: 32-row blocks per filter tile of the split-f16 filter role (filter_role_h).
+template <int H, bool SAVE, bool TAIL, int PREC = PREC_F32, int FRB = 1>
 __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int node_tiles, ComboFilter f,
                                                             ComboStride sd, ComboPre q, FilterSave fsv,
                                                             NodeSave ns TSD_TRACE_ARG) {
@@ -1387,7 +1399,7 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
             return;
         }
         TSD_TRACE_REAL(24);
-        if constexpr (PREC == PREC_H2) filter_role_h<H>(f, item, smem, sd.range_status TSD_TRACE_PASS);
+        if constexpr (PREC == PREC_H2) filter_role_h<H, FRB>(f, item, smem, sd.range_status TSD_TRACE_PASS);
         else filter_role<H, SAVE>(f, item, smem, fsv TSD_TRACE_PASS);
         TSD_TRACE_REAL(25);
     }
@@ -1453,10 +1465,10 @@ int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity,
     return TSD_OK;
 }
 
-static inline size_t lds_combo(int H, int prec) {
+static inline size_t lds_combo(int H, int prec, int frb = 1) {
     const int ld = prec == PREC_H2 ? ldh_of(H) : H + 4;  // floats per tile row (two f16 planes of H + 8 = H + 8 floats)
     const size_t node = (size_t)TN * ld * 4;
-    const size_t filt = (size_t)(T * ld + T) * 4;
+    const size_t filt = (size_t)(T * ld + T) * 4 * frb;
     const size_t pair = (size_t)(T * ld + (H / 64) * T + 3 * T) * 4;  // pair role (H >= 64)
     return node > filt ? (node > pair ? node : pair) : (filt > pair ? filt : pair);
 }
@@ -1781,7 +1793,7 @@ __global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A) {
     if (filter_item >= 0) {  // filter tiles of blocks 1 .. L-1
         const int layer = 1 + filter_item / A.tiles_per_layer;
 #ifndef TSD_MEGA_SKIP_FILTER  // (timing experiments only: wrong results)
-        filter_role_h<H>(A.f, filter_item, smem, A.status TSD_TRACE_NULL);
+        filter_role_h<H, 1>(A.f, filter_item, smem, A.status TSD_TRACE_NULL);
 #endif
         // every storing wave drains, the workgroup meets, ONE lane publishes the tile (Guideline 16 R1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1962,9 +1974,20 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     ComboPre q{};
     if (pre && pre->tiles > 0) q = *pre;
     if (q.pair) a.ready = q.ready;  // the node role of this launch publishes h to the pair tiles
+    // Whole layers of filter tiles, many chip-fulls of them (big batches / ensembles): 64-row tiles.  A weight fragment
+    // of the ring then feeds two row blocks, and the launch is bound by that feed.
+    int frb = 1;
+    if (prec.mode == PREC_H2 && !prec.narrow_filter_tiles && f.tiles > 0 && q.tiles == 0 && TSD_FILTER_WIDE_MIN > 0 && f.tiles % f.tiles_per_layer == 0 &&
+        f.g_begin % f.tiles_per_layer == 0 && (long)f.tiles * M >= TSD_FILTER_WIDE_MIN) {
+        const int tpl2 = (capacity_u + 2 * T - 1) / (2 * T);
+        f.g_begin = f.g_begin / f.tiles_per_layer * tpl2;
+        f.tiles = f.tiles / f.tiles_per_layer * tpl2;
+        f.tiles_per_layer = tpl2;
+        frb = 2;
+    }
     const int grid = node_tiles + f.tiles + q.tiles;
     if (grid == 0) return TSD_OK;
-    const size_t lds = lds_combo(c.hidden, prec.mode);
+    const size_t lds = lds_combo(c.hidden, prec.mode, frb);
     // interleave only when the launch is many chip-fulls deep (the node tiles alone over-subscribe the chip)
     int node_stride = 1;
     if (node_tiles >= 1024 && grid >= 3 * node_tiles) {
@@ -1981,19 +2004,21 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
 #else
 #define TSD_TRACE_HOST
 #endif
-#define TSD_COMBO_I(HH, SV, TL, PR)                                                                         \
+#define TSD_COMBO_I(HH, SV, TL, PR, FR)                                                                     \
     {                                                                                                       \
         static DeviceOnce once;                                                                             \
-        int r = allow_lds(layer_combo_kernel<HH, SV, TL, PR>, lds, once);                                   \
+        int r = allow_lds(layer_combo_kernel<HH, SV, TL, PR, FR>, lds, once);                               \
         if (r) return r;                                                                                    \
-        hipLaunchKernelGGL((layer_combo_kernel<HH, SV, TL, PR>), dim3(grid, M), dim3(2 * HH), lds, st, a, node_tiles, f, \
+        hipLaunchKernelGGL((layer_combo_kernel<HH, SV, TL, PR, FR>), dim3(grid, M), dim3(2 * HH), lds, st, a, node_tiles, f, \
                            sd, q, fsv, nsv TSD_TRACE_HOST);                                                 \
     }
 #define TSD_COMBO(HH)                                                                                       \
     if (prec.mode == PREC_H2) {                                                                             \
-        if (q.tiles > 0) TSD_COMBO_I(HH, false, true, PREC_H2) else TSD_COMBO_I(HH, false, false, PREC_H2)   \
-    } else if (save) TSD_COMBO_I(HH, true, false, PREC_F32)                                                  \
-    else if (q.tiles > 0) TSD_COMBO_I(HH, false, true, PREC_F32) else TSD_COMBO_I(HH, false, false, PREC_F32)
+        if (q.tiles > 0) TSD_COMBO_I(HH, false, true, PREC_H2, 1)                                           \
+        else if (frb == 2) TSD_COMBO_I(HH, false, false, PREC_H2, 2)                                        \
+        else TSD_COMBO_I(HH, false, false, PREC_H2, 1)                                                      \
+    } else if (save) TSD_COMBO_I(HH, true, false, PREC_F32, 1)                                              \
+    else if (q.tiles > 0) TSD_COMBO_I(HH, false, true, PREC_F32, 1) else TSD_COMBO_I(HH, false, false, PREC_F32, 1)
     const bool save = fsave != nullptr || nsave != nullptr;
     const FilterSave fsv = fsave ? *fsave : FilterSave{};
     const NodeSave nsv = nsave ? *nsave : NodeSave{};

@@ -95,6 +95,7 @@ if GEMM not in ("h2", "f32"):
     raise ValueError(f"TSDIFF_GEMM={GEMM!r}: expected 'h2' or 'f32'")
 # the split-f16 forward of a small batch as ONE launch (kernels_combo.hip forward_mega_kernel); "0": one launch per block
 ONE_LAUNCH = os.environ.get("TSDIFF_ONE_LAUNCH", "1") != "0"
+WIDE_FILTER_TILES = os.environ.get("TSDIFF_WIDE_FILTER_TILES", "1") != "0"  # 0: tsd_batch.reserved bit 1 (cross-check switch)
 # tests / tools flip this to run the sampling loop's step tail as the three separate launches (bit-identical results)
 FUSED_STEP_TAIL = os.environ.get("TSDIFF_FUSED_TAIL", "1") != "0"
 
@@ -375,7 +376,7 @@ class DeviceBatch:
             edge_inv_u=self.edge_inv_u.data_ptr(),
             # 0 = "unknown": the library then runs the step tail as three launches (A/B switch for tests / tools)
             max_graph_nodes=self.max_n if FUSED_STEP_TAIL else 0,
-            reserved=0 if ONE_LAUNCH else 1,
+            reserved=(0 if ONE_LAUNCH else 1) | (0 if WIDE_FILTER_TILES else 2),
             enc_tiles=self._tiles_struct("enc"), diff_tiles=self._tiles_struct("diff"),
             bucket_weights=None if self.bucket_weights is None else self.bucket_weights.data_ptr(),
             weights16=self.weights16.data_ptr() if h2 else None,
@@ -493,7 +494,7 @@ class DeviceBatch:
         """the captured + instantiated hipGraph of one sampling step for the bound checkpoints; built once and
         replayed by every later dynamic_sampling call on this batch (reference loop: models/sampler.py:187-254)"""
         key = (int(kind), float(clip), float(-1.0 if clip_pos is None else clip_pos), bool(FUSED_STEP_TAIL), bool(TYPED_TILES),
-               self.gemm_mode(), bool(ONE_LAUNCH))
+               self.gemm_mode(), bool(ONE_LAUNCH), bool(WIDE_FILTER_TILES))
         plan = self._plans.get(key)
         if plan is None:
             lib = _lib.load()
