@@ -111,3 +111,37 @@ def test_the_built_kernels_pass():
         import pytest
         pytest.skip("no kernel listings (run `make -C tsdiff_amd/csrc`)")
     assert chk.main(files) == 0
+
+
+def test_a_block_reached_only_from_before_the_loads_is_clean(tmp_path):
+    # if (c) { loads } else { the compiler zero-fills the same registers }: the else block never sees the loads
+    body = """
+\ts_cbranch_scc1 .LBB0_2
+\t;;#ASMSTART
+\tglobal_load_dwordx4 v[10:13], v1, s[2:3]
+\t;;#ASMEND
+\ts_branch .LBB0_3
+.LBB0_2:
+\tv_mov_b32_e32 v10, 0
+.LBB0_3:
+\t;;#ASMSTART
+\ts_waitcnt vmcnt(0)
+\t;;#ASMEND
+\tv_mov_b32_e32 v40, v10
+"""
+    assert run(body, tmp_path) == 0
+
+
+def test_a_path_that_skips_the_wait_is_reported(tmp_path):
+    body = """
+\t;;#ASMSTART
+\tglobal_load_dwordx4 v[10:13], v1, s[2:3]
+\t;;#ASMEND
+\ts_cbranch_scc1 .LBB0_2
+\t;;#ASMSTART
+\ts_waitcnt vmcnt(0)
+\t;;#ASMEND
+.LBB0_2:
+\tv_mov_b32_e32 v40, v10
+"""
+    assert run(body, tmp_path) == 1

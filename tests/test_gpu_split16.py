@@ -111,6 +111,28 @@ def test_small_configs_and_ensembles_take_the_right_path(dev, monkeypatch):
         assert_close(res["one"].cpu().numpy(), res["f32"].cpu().numpy(), RTOL, f"edge_inv, {len(seeds)} checkpoint(s)")
 
 
+@pytest.mark.parametrize("n,graphs", [(40, 5), (64, 3)])
+def test_one_launch_gather_paths(n, graphs, dev, monkeypatch):
+    """the node workgroups of the one-launch forward gather x from an LDS copy of their graphs' rows when those are at
+    most 60 (aggregate through xl_gather), from L2 otherwise: 40-atom graphs give tiles of both kinds in one launch
+    (a tile inside one graph: 40 rows; across two: 80), 64-atom graphs only the second kind.  Both are bit for bit the
+    forward of one launch per block"""
+    from tsdiff_amd import synth
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    model = make_model(cfg, 1, dev)
+    b = synth.dense_stress_batch(graphs, n=n, seed=21)
+    g = to_dev({**{k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}, "num_graphs": graphs}, dev)
+    set_mode = _modes(monkeypatch)
+    res = {}
+    for name, gemm, one in (("one", "h2", True), ("per_block", "h2", False), ("f32", "f32", True)):
+        set_mode(gemm, one)
+        inv, _, _ = run_forward(model, g, dev)
+        res[name] = inv.clone()
+    assert torch.isfinite(res["one"]).all()
+    assert torch.equal(res["one"], res["per_block"])
+    assert_close(res["one"].cpu().numpy(), res["f32"].cpu().numpy(), RTOL, "one-launch forward vs fp32 MFMA")
+
+
 def test_wide_filter_tiles_equal_narrow_ones(dev, monkeypatch):
     """a block launch with >= 1024 filter tiles takes them as 64-row tiles (two row blocks per weight fragment): every
     row is the same MFMA sequence as in a 32-row tile, so the forward is bit for bit the one with

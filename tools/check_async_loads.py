@@ -6,11 +6,10 @@ counted `s_waitcnt vmcnt(N)` statements (csrc/common.hpp, csrc/split16.hpp); the
 batch.  For the compiler an asm output is written AT the statement, so nothing in the language stops it from copying,
 spilling or re-using such a register between the load and its wait -- it does so only under register pressure (a
 `__launch_bounds__` occupancy cap), silently, and the kernel then computes with stale fragments.  This script proves
-the absence of that for the BINARY: it walks every kernel in text order, keeps the hardware's vmcnt FIFO (every vector
-memory instruction counts; loads return in order, stores in order, the two classes not with respect to each other),
-and reports any instruction that names a destination register of an asm-issued load that a preceding wait has not
-covered.  The walk is linear (branches are not followed): conservative inside straight-line tile code, which is where
-the rings live.
+the absence of that for the BINARY: it walks every kernel in text order with the hardware's vmcnt rule (loads return
+in order among loads; stores only add to the outstanding count), carries the set of in-flight registers along forward
+branches to their labels, and reports any instruction that names a destination register of an asm-issued load that a
+preceding wait has not covered on some path.
 
     python tools/check_async_loads.py file.s [...]        exit code 1 on a violation
 """
@@ -33,23 +32,39 @@ def regs_of(text):
     return out
 
 
+LABEL = re.compile(r"^(\.LBB\d+_\d+):")
+BRANCH = re.compile(r"^\s*(s_branch|s_cbranch_\w+)\s+(\.LBB\d+_\d+)")
+
+
+def merge(a, b):
+    """two states reaching one label: a register is in flight if it is on either path; `younger` (the loads issued
+    after it -- what a counted wait is measured against) is the smaller of the two"""
+    if a is None:
+        return None if b is None else dict(b)
+    if b is None:
+        return dict(a)
+    out = dict(a)
+    for r, (line, y) in b.items():
+        out[r] = (line, min(y, out[r][1])) if r in out else (line, y)
+    return out
+
+
 def check_kernel(name, lines):
-    """`maybe`: the vector memory operations that MAY still be outstanding, in issue order; `out_max`: an upper bound
-    of the hardware counter.  A wait vmcnt(n) leaves at most n outstanding, so at least len(maybe) - n of them are back:
-    loads return in order among loads, stores among stores, so the oldest (that many - number of the other class)
-    entries of each class are certainly back."""
-    maybe = []     # [is_load, frozenset(dest regs) for an asm-issued load or None, line]
-    out_max = 0
-    hot = {}       # register -> line of the asm load that has it in flight
+    """`hot`: register -> (line of the asm load that has it in flight, number of vector memory LOADS issued after that
+    load).  Loads return in order among loads, so behind `s_waitcnt vmcnt(n)` -- at most n operations outstanding --
+    a load with at least n younger loads is back (were it outstanding, so were they: more than n); stores only add to
+    the outstanding count, so they never make a load look complete.
+    Control flow: forward branches carry the state to their label, where it is merged with the fall-through state
+    (a path that skips a wait keeps its loads in flight; a block reached only by a branch from before the loads has
+    none); code behind an unconditional branch is unreachable until the next label.  `s_cbranch_execz/execnz` only skip
+    lane-masked code and carry nothing: the walk goes through the skipped code (its conditions are correlated with the
+    later ones in ways a merge would lose -- a wait inside `if (last)` and the `if (last && tid == 0)` behind it).
+    Backward branches are not followed: the tile code never carries an asm load over a loop edge, and the loop body is checked on its first pass."""
+    hot = {}
+    pending = {}   # label -> state carried by forward branches
+    seen = set()
     in_asm = False
     bad = []
-
-    def retire(entries):
-        for e in entries:
-            if e[1]:
-                for r in e[1]:
-                    hot.pop(r, None)
-
     for no, raw in lines:
         st = raw.strip()
         if st.startswith(";;#ASMSTART"):
@@ -58,38 +73,45 @@ def check_kernel(name, lines):
         if st.startswith(";;#ASMEND"):
             in_asm = False
             continue
+        lab = LABEL.match(st)
+        if lab:
+            seen.add(lab.group(1))
+            hot = merge(hot, pending.pop(lab.group(1), None))
+            if hot is None:
+                hot = {}   # (reached by a backward branch only: a loop header behind an unconditional branch)
+            continue
         line = raw.split(";", 1)[0].strip()
         if not line or line.startswith(".") or line.endswith(":"):
+            continue
+        if hot is None:
+            continue       # unreachable
+        br = BRANCH.match(line)
+        if br and br.group(1) in ("s_cbranch_execz", "s_cbranch_execnz"):
+            continue       # a skip over lane-masked code: walking through that code is the conservative reading
+        if br:
+            if br.group(2) not in seen:
+                pending[br.group(2)] = merge(pending.get(br.group(2)), hot)
+            if br.group(1) == "s_branch":
+                hot = None
+            continue
+        if line.startswith("s_endpgm"):
+            hot = None
             continue
         w = WAIT.search(line)
         if w:
             n = int(w.group(1))
-            out_max = min(out_max, n)
-            must = len(maybe) - out_max
-            if must > 0:
-                loads = [e for e in maybe if e[0]]
-                stores = [e for e in maybe if not e[0]]
-                gl = max(0, must - len(stores))   # loads certainly back
-                gs = max(0, must - len(loads))    # stores certainly back
-                gone = loads[:gl] + stores[:gs]
-                retire(gone)
-                ids = {id(e) for e in gone}
-                maybe = [e for e in maybe if id(e) not in ids]
+            hot = {r: v for r, v in hot.items() if v[1] < n}
             continue
         used = regs_of(line)
         clash = used & hot.keys()
         if clash:
-            bad.append((no, raw.strip(), sorted(clash), sorted({hot[r] for r in clash})))
-        if VMEM.match(line) is not None:
-            is_load = "_load" in line.split()[0]
-            dest = None
-            if in_asm and is_load:
+            bad.append((no, raw.strip(), sorted(clash), sorted({hot[r][0] for r in clash})))
+        if VMEM.match(line) is not None and "_load" in line.split()[0]:
+            hot = {r: (l, y + 1) for r, (l, y) in hot.items()}
+            if in_asm:
                 first = line.split(None, 1)[1].split(",")[0]
-                dest = frozenset(regs_of(first))
-                for r in dest:
-                    hot[r] = no
-            maybe.append([is_load, dest, no])
-            out_max += 1
+                for r in regs_of(first):
+                    hot[r] = (no, 0)
     return bad
 
 

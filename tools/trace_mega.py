@@ -44,3 +44,26 @@ if m.any():
         ml = m & (t[:, 3] == l)
         if ml.any():
             print(f"  filter layer {l}: start med {np.median(us(t[ml, 1])):7.1f}  end med {np.median(us(t[ml, 2])):7.1f} max {us(t[ml, 2]).max():7.1f}")
+# phase stamps of the node workgroups (variant builds with TSD_MEGA_P_MASK): [tile][block][phase], 100 MHz wall clock
+try:
+    dph = C.CDLL(_lib.LIB_PATH).tsd_debug_mega_phase
+    dph.argtypes = [C.c_void_p]
+    pb = np.zeros(256 * 8 * 8, dtype=np.uint64)
+    assert dph(pb.ctypes.data_as(C.c_void_p)) == 0
+    ph = pb.astype(np.int64).reshape(256, 8, 8)
+    nt = int((ph[:, 0, 1] > 0).sum()) or int((ph[:, 1, 1] > 0).sum())
+    names_p = ["block start", "flags seen", "gathered", "lin2 + barrier", "ssp epilogue", "lin + barrier", "h epilogue + lin1", "x1 published"]
+    print(f"node workgroups with stamps: {nt}; per block, medians over tiles (us since the launch's first stamp)")
+    for l in range(7):
+        row = ph[:nt, l, :]
+        have = [p for p in range(8) if (row[:, p] > 0).all()]
+        if not have:
+            continue
+        txt = "  ".join(f"{names_p[p]} {np.median(us(row[:, p])):6.1f}" for p in have)
+        print(f"  block {l}: {txt}")
+        if len(have) >= 2:
+            d = "  ".join(f"{names_p[b]}-{names_p[a]}: med {np.median((row[:, b] - row[:, a]) / 100.0):5.2f} max {((row[:, b] - row[:, a]) / 100.0).max():5.2f}"
+                          for a, b in zip(have[:-1], have[1:]))
+            print(f"           {d}")
+except AttributeError:
+    pass

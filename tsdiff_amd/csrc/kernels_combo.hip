@@ -274,6 +274,141 @@ __device__ __forceinline__ void aggregate_tile(const int32_t* __restrict__ row_p
 }
 
 // -------------------------------------------------------------------------------------------------
+// The same aggregation for the node workgroups of the one-launch forward (H = 256, split planes, rows stored by other
+// workgroups of the launch), wrapped around the wait for the neighbour tiles (`wait_for_x`, which ends with a barrier).
+// Traced (tools/trace_mega.py): every dependent round trip of the gather is 1.5-2 us there -- the rows were stored
+// write-through by other CUs and come from beyond the XCD's L2 -- and aggregate_tile makes five or six of them behind
+// the wait (row offsets, indices, four batches of 8 edges = 16 row loads).  Here:
+//   1. BEFORE the wait (the filters of the block are complete): row offsets, indices, and the filter rows of the wave's
+//      first 8 edges -- all of it depends on the geometry only.
+//   2. behind the wait: the columns a tile gathers x at are the atoms of the graphs its own atoms belong to, rows
+//      [xbase, xbase + nloc) of x, a few dozen at molecule sizes, each wanted by up to TN rows of the tile: they are
+//      copied to LDS (`xs`) by LDS-DMA, one round trip, no registers.  The per-edge loads are then the filter rows
+//      alone -- half the bytes through the CU's L2 port -- and
+//   3. with the 64 row registers of a wave all on filter rows the remaining edges take one round trip per 16.
+// Two round trips behind the wait for up to 24 edges per wave, three for up to 40.  Sums as in aggregate_tile: per
+// row, in edge order, product rounded then added -- bit-identical.  Every wave of the workgroup calls it.
+// (Variants that did not fit 128 VGPRs without an occupancy cap, i.e. two workgroups per CU: 16 edges requested before
+// the wait; x rows and 16 filter rows in ONE round trip behind it; the next batch's indices requested early.)
+// -------------------------------------------------------------------------------------------------
+constexpr int XS_ROWS = 60;  // rows of x the LDS copy holds (a 16-row tile between two 23-atom graphs: 16 + 2 * 22)
+typedef int xl_i32x8 __attribute__((ext_vector_type(8)));
+template <int H, int NW, int TR, class WaitFn>
+__device__ __forceinline__ void xl_gather(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ dst,
+                                          const int32_t* __restrict__ umap, const float* __restrict__ Wf,
+                                          const float* __restrict__ x, int xbase, int nloc, float* xs, int N, int n0,
+                                          float* buf, float& amax, WaitFn&& wait_for_x) {
+    static_assert(H == 256, "one 16-byte load per lane and row");
+    constexpr int V = 4, U = 8, LDH = ldh_of(H), RPW = TR / NW, C4 = H / 4;
+    static_assert(TR % NW == 0 && TR <= TN, "");
+    const Planes pl = planes_at(buf, TN, LDH);
+    dst = reinterpret_cast<const int32_t*>(uniform_ptr(dst));
+    umap = reinterpret_cast<const int32_t*>(uniform_ptr(umap));
+    Wf = reinterpret_cast<const float*>(uniform_ptr(Wf));
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const unsigned lane_b = (unsigned)lane * (V * 4u);
+    const int first = n0 + wave * RPW;
+    static_assert(RPW == 2, "the row offsets of a wave are three scalars");
+    int E0, Em, E1;  // edges of the wave's first row: [E0, Em), of its second: [Em, E1)
+    {
+        const int rpv = row_ptr[min(first + min(lane, RPW), N)];  // lanes 0 .. RPW: row offsets of this wave's rows
+        E0 = __builtin_amdgcn_readlane(rpv, 0), Em = __builtin_amdgcn_readlane(rpv, 1), E1 = __builtin_amdgcn_readlane(rpv, 2);
+    }
+    // step 1 (before the wait for the x rows): the filter rows of the wave's first 8 edges -- indices and row loads
+    // depend on the geometry only.  (8, not 16: with 64 row registers held across the wait the kernel does not fit the
+    // 128 VGPRs of two workgroups per CU.)  The index lists carry 8 spare entries (tsdiff_hip.h); slots past the range
+    // re-read slot 0 and are not added.
+    f32x4 w0[U];
+    xl_i32x8 ja;  // their x columns
+    if (E0 < E1) {
+        xl_i32x8 ua;
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(ua) : "s"(umap + E0) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ua)::"memory");
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int we = E0 + u < E1 ? ua[u] : ua[0];
+            asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(w0[u]) : "v"(lane_b), "s"(Wf + (size_t)we * H) : "memory");
+        }
+    }
+    wait_for_x();  // (ends with a barrier)
+    if (E0 < E1) asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(ja) : "s"(dst + E0) : "memory");
+    {   // step 2: the rows of x -> LDS by LDS-DMA (one 1-KiB row per wave instruction, no registers: the row registers
+        // of step 1 are in flight); `sc1` as every load of rows another CU stored during this launch.  The wait also
+        // covers the filter rows of step 1.
+        static_assert(XS_ROWS <= 8 * NW, "eight rows per wave");
+        const char* xg = reinterpret_cast<const char*>(x + (size_t)xbase * H) + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = wave + i * NW;
+            if (r < nloc)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xg + (size_t)r * (H * 4)),
+                                                 (__attribute__((address_space(3))) void*)(xs + (size_t)r * H), 16, 0, 16 /* sc1 */);
+        }
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w0[3]), "+v"(w0[4]), "+v"(w0[5]), "+v"(w0[6]), "+v"(w0[7])::"memory");
+    }
+    int rr = 0;
+    int row_end = Em;
+    float s[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) s[v] = 0.0f;
+    auto flush = [&]() {
+        const f32x4 sv = {s[0], s[1], s[2], s[3]};
+        planes_store4(pl, (wave * RPW + rr) * LDH + lane * V, sv, amax);
+#pragma unroll
+        for (int v = 0; v < V; ++v) s[v] = 0.0f;
+        ++rr;
+        row_end = E1;  // (rr >= 1: the second row, or past it)
+    };
+    auto consume = [&](const f32x4 (&w)[U], const xl_i32x8& jd, int e) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (e + u < E1) {
+                while (e + u >= row_end) flush();  // (also steps over rows without edges)
+                const f32x4 xr = *reinterpret_cast<const f32x4*>(xs + (size_t)(jd[u] - xbase) * H + lane * V);
+#pragma unroll
+                for (int v = 0; v < V; ++v) s[v] = __fadd_rn(s[v], __fmul_rn(xr[v], w[u][v]));
+            }
+        }
+    };
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(ja)::"memory");
+    __syncthreads();  // the LDS copy of x is complete
+    if (E0 < E1) consume(w0, ja, E0);
+    // step 3: the remaining edges, 16 per round trip (two groups of 8: a group is only requested when its first edge is
+    // inside the range)
+    for (int e = E0 + U; e < E1; e += 2 * U) {
+        const bool two = e + U < E1;
+        xl_i32x8 jd0, ud0, jd1, ud1;
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(jd0) : "s"(dst + e) : "memory");
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(ud0) : "s"(umap + e) : "memory");
+        if (two) {
+            asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(jd1) : "s"(dst + e + U) : "memory");
+            asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(ud1) : "s"(umap + e + U) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(jd0), "+s"(ud0), "+s"(jd1), "+s"(ud1)::"memory");
+        f32x4 wa[U], wb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int we = e + u < E1 ? ud0[u] : ud0[0];
+            asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(wa[u]) : "v"(lane_b), "s"(Wf + (size_t)we * H) : "memory");
+        }
+        if (two) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int we = e + U + u < E1 ? ud1[u] : ud1[0];
+                asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(wb[u]) : "v"(lane_b), "s"(Wf + (size_t)we * H) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(wa[0]), "+v"(wa[1]), "+v"(wa[2]), "+v"(wa[3]), "+v"(wa[4]), "+v"(wa[5]), "+v"(wa[6]), "+v"(wa[7]),
+                       "+v"(wb[0]), "+v"(wb[1]), "+v"(wb[2]), "+v"(wb[3]), "+v"(wb[4]), "+v"(wb[5]), "+v"(wb[6]), "+v"(wb[7])::"memory");
+        consume(wa, jd0, e);
+        if (two) consume(wb, jd1, e + U);
+    }
+    while (rr < RPW) flush();  // the last row, and rows past it without edges (or past the last node): zeros
+}
+
+// -------------------------------------------------------------------------------------------------
 // node role: agg[i] = sum_{e in row i} x1[dst e] * Wf[umap e]  (edge order, product rounded then added:
 // bit-identical to a sequential scatter_add), then the three dense layers of tsd_node_update.
 // reference schnet.py:101-107 (message/aggregate), :103 (lin2), :123-127, :223-224
@@ -1522,8 +1657,21 @@ extern "C" int tsd_debug_mega_trace(void* host_buf) {  // copies the buffer out 
     static unsigned long long zeros[8192 * 4];
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_mega_trace), zeros, sizeof(zeros));
 }
+// phase stamps of the node workgroups: [tile][block][phase] (wall clock, 100 MHz)
+#ifndef TSD_MEGA_P_MASK
+#define TSD_MEGA_P_MASK 255  // (every stamp costs scalar registers: a build that must stay at 128 VGPRs takes fewer)
+#endif
+__device__ unsigned long long g_mega_phase[256 * 8 * 8];
+#define TSD_MEGA_P(tile, l, ph)                                                                                 \
+    do {                                                                                                        \
+        if (TSD_MEGA_P_MASK >> (ph) & 1 && threadIdx.x == 0 && (tile) < 256 && (l) < 8) g_mega_phase[((size_t)(tile) * 8 + (l)) * 8 + (ph)] = wall_clock64(); \
+    } while (0)
+extern "C" int tsd_debug_mega_phase(void* host_buf) {
+    return (int)hipMemcpyFromSymbol(host_buf, HIP_SYMBOL(g_mega_phase), sizeof(g_mega_phase));
+}
 #else
 #define TSD_MEGA_T(slot, val)
+#define TSD_MEGA_P(tile, l, ph)
 #endif
 struct MegaCtl {  // int32 words in the forward workspace
     // ZERO: a word nothing ever writes (epoch source of a stand-alone forward); NODE0: one word per node tile (<= 256);
@@ -1554,6 +1702,9 @@ struct MegaArgs {
 };
 
 constexpr unsigned MEGA_SPIN_LIMIT = 4000000u;
+#ifndef TSD_MEGA_XLDS
+#define TSD_MEGA_XLDS 1  // the node workgroups gather x from an LDS copy of their graphs' rows (aggregate_tile_xl); 0: from L2
+#endif
 #ifndef TSD_MEGA_POLL_SLEEP
 #define TSD_MEGA_POLL_SLEEP 12  // x64 cycles between two polls (~0.3 us): a hundred waves polling one word at full rate throttle the L2 channel it lives in
 #endif
@@ -1622,7 +1773,10 @@ __device__ __forceinline__ void node_persist_h(const MegaArgs& A, int tile, int 
     int32_t* node_done = A.ctl + MegaCtl::NODE0;
     // the node tiles that hold atoms of the graphs this tile's atoms belong to
     const int g_first = A.node_graph[n0], g_last = A.node_graph[n0 + nrows - 1];
-    const int t_lo = A.graph_ptr[g_first] / TR, t_hi = (A.graph_ptr[g_last + 1] - 1) / TR;
+    // the atoms of those graphs (workgroup-uniform values the compiler would keep in vector registers)
+    const int x_base = __builtin_amdgcn_readfirstlane(A.graph_ptr[g_first]);
+    const int x_nloc = __builtin_amdgcn_readfirstlane(A.graph_ptr[g_last + 1]) - x_base;
+    const int t_lo = x_base / TR, t_hi = (x_base + x_nloc - 1) / TR;
     // residual input of block 0: the pos-independent node embedding z
     float h_res[CB16][4];
 #pragma unroll
@@ -1652,43 +1806,63 @@ __device__ __forceinline__ void node_persist_h(const MegaArgs& A, int tile, int 
             f_hi = hn / T;
         }
     }
+    bool use_xl = false;
+    if constexpr (H == 256 && TR == TN && TSD_MEGA_XLDS) use_xl = x_nloc <= XS_ROWS;  // (workgroup-uniform)
     for (int l = 0; l < A.L; ++l) {
-        if (l > 0 && wave == 0) {
-#ifndef TSD_MEGA_NOWAIT_LAYER  // (timing experiments only: wrong results)
-            if (f_hi >= 0)
-                mega_wait_range_ge(A.ctl + MegaCtl::FILTER0 + (size_t)l * A.tiles_per_layer, f_lo, f_hi, epoch, A.status);
-#endif
-#ifndef TSD_MEGA_NOWAIT_NODE
-            mega_wait_range_ge(node_done, t_lo, t_hi, epoch * 64 + l, A.status);
-#endif
-        }
-        __syncthreads();
-        if constexpr (TR < TN) {  // the MFMA's rows past the tile: the gather does not write them and the x1 staging of
-            // the previous block lies over them (fp32 bits read as f16 may be inf): zero, so that they stay finite
-            for (int idx = tid; idx < (TN - TR) * (LDH / 2); idx += NT) {
-                reinterpret_cast<uint32_t*>(pl.hi + TR * LDH)[idx] = 0u;
-                reinterpret_cast<uint32_t*>(pl.lo + TR * LDH)[idx] = 0u;
-            }
-        }
+        TSD_MEGA_P(tile, l, 0);
         const float* Wl = A.W + A.layer0 + (size_t)l * A.layer_stride;
         const float* x_in = l == 0 ? A.x1_0 : A.x1m + (size_t)(l - 1) * A.x1_stride;
         float* x_out = A.x1m + (size_t)l * A.x1_stride;
+        const float* wf_l = A.wf + (size_t)l * A.wf_layer_stride;
         const bool last = l + 1 == A.L;
         HRing<CB16, HRING16_R> rg;
         f32x4 accm[CB16], accx[CB16];
-        float b_lin2[CB16], b_lin[CB16];
+        if (use_xl) {
+            // the filters of this block first (complete long before the neighbours' x rows as a rule): the first
+            // edges' filter rows of every wave are in flight while wave 0 waits for the node tiles
+            if (l > 0 && wave == 0 && f_hi >= 0)
+                mega_wait_range_ge(A.ctl + MegaCtl::FILTER0 + (size_t)l * A.tiles_per_layer, f_lo, f_hi, epoch, A.status);
+            __syncthreads();
+            if constexpr (H == 256)
+                xl_gather<H, 2 * H / 64, TR>(A.row_ptr, A.dst, A.umap, wf_l, x_in, x_base, x_nloc, smem + TN * LDH, A.N, n0, smem,
+                                             amax, [&]() {
+                                                 if (l > 0 && wave == 0) mega_wait_range_ge(node_done, t_lo, t_hi, epoch * 64 + l, A.status);
+                                                 __syncthreads();
+                                                 TSD_MEGA_P(tile, l, 1);
+                                             });
+        } else {
+            if (l > 0 && wave == 0) {
+#ifndef TSD_MEGA_NOWAIT_LAYER  // (timing experiments only: wrong results)
+                if (f_hi >= 0)
+                    mega_wait_range_ge(A.ctl + MegaCtl::FILTER0 + (size_t)l * A.tiles_per_layer, f_lo, f_hi, epoch, A.status);
+#endif
+#ifndef TSD_MEGA_NOWAIT_NODE
+                mega_wait_range_ge(node_done, t_lo, t_hi, epoch * 64 + l, A.status);
+#endif
+            }
+            __syncthreads();
+            TSD_MEGA_P(tile, l, 1);
+            if constexpr (TR < TN) {  // the MFMA's rows past the tile: the gather does not write them and the x1 staging of
+                // the previous block lies over them (fp32 bits read as f16 may be inf): zero, so that they stay finite
+                for (int idx = tid; idx < (TN - TR) * (LDH / 2); idx += NT) {
+                    reinterpret_cast<uint32_t*>(pl.hi + TR * LDH)[idx] = 0u;
+                    reinterpret_cast<uint32_t*>(pl.lo + TR * LDH)[idx] = 0u;
+                }
+            }
+#ifdef TSD_MEGA_PLAIN_GATHER
+            constexpr bool kSc1 = false;
+#else
+            constexpr bool kSc1 = true;
+#endif
+            aggregate_tile<H, false, 2 * H / 64, 8, true, kSc1, TR>(A.row_ptr, A.dst, A.umap, wf_l, x_in, A.N, n0, smem, nullptr, &amax);
+        }
+        TSD_MEGA_P(tile, l, 2);
+        float b_lin2[CB16], b_lin[CB16];  // (requested behind the gather: they arrive under the first GEMM)
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
             b_lin2[cb] = Wl[A.o_lin2_b + col0 + cb * 16 + l15];
             b_lin[cb] = Wl[A.o_lin_b + col0 + cb * 16 + l15];
         }
-#ifdef TSD_MEGA_PLAIN_GATHER
-        constexpr bool kSc1 = false;
-#else
-        constexpr bool kSc1 = true;
-#endif
-        aggregate_tile<H, false, 2 * H / 64, 8, true, kSc1, TR>(A.row_ptr, A.dst, A.umap, A.wf + (size_t)l * A.wf_layer_stride,
-                                                            x_in, A.N, n0, smem, nullptr, &amax);
         hgemm16_ring_start<CB16, H>(rg, Wl + A.o_lin2_w, H, col0);
         __syncthreads();
 #pragma unroll
@@ -1696,6 +1870,7 @@ __device__ __forceinline__ void node_persist_h(const MegaArgs& A, int tile, int 
         hgemm16_ring_run<CB16, H>(rg, pl, LDH, accm, accx);
         hgemm16_ring_start<CB16, H>(rg, Wl + A.o_lin_w, H, col0);
         __syncthreads();
+        TSD_MEGA_P(tile, l, 3);
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
             const int col = col0 + cb * 16 + l15;
@@ -1706,9 +1881,11 @@ __device__ __forceinline__ void node_persist_h(const MegaArgs& A, int tile, int 
         __syncthreads();
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) accm[cb] = accx[cb] = zero4;
+        TSD_MEGA_P(tile, l, 4);
         hgemm16_ring_run<CB16, H>(rg, pl, LDH, accm, accx);
         if (!last) hgemm16_ring_start<CB16, H>(rg, Wl + A.layer_stride + A.o_lin1, H, col0);
         __syncthreads();
+        TSD_MEGA_P(tile, l, 5);
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
             const int col = col0 + cb * 16 + l15;
@@ -1736,6 +1913,7 @@ __device__ __forceinline__ void node_persist_h(const MegaArgs& A, int tile, int 
         for (int cb = 0; cb < CB16; ++cb) accm[cb] = accx[cb] = zero4;
         hgemm16_ring_run<CB16, H>(rg, pl, LDH, accm, accx);
         __syncthreads();  // every wave is done reading the planes: the x1 tile goes over them as fp32 rows
+        TSD_MEGA_P(tile, l, 6);
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
             const int col = col0 + cb * 16 + l15;
@@ -1750,6 +1928,7 @@ __device__ __forceinline__ void node_persist_h(const MegaArgs& A, int tile, int 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // (also: the staging rows are free for the next block's planes)
         if (tid == 0) __hip_atomic_store(node_done + tile, epoch * 64 + l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        TSD_MEGA_P(tile, l, 7);
     }
     range_report(amax, A.status);
 }
@@ -1895,7 +2074,9 @@ int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float*
     A.n_pair = A.q.tiles;
     const int grid = A.n_node + A.n_filter + A.n_pair;
     if (grid == 0 || A.n_node == 0) return TSD_OK;
-    const size_t lds = lds_combo(H, PREC_H2);
+    size_t lds = lds_combo(H, PREC_H2);
+    if (H == 256 && MEGA_TR == TN && TSD_MEGA_XLDS)  // the node workgroups' LDS copy of x (aggregate_tile_xl) behind their planes
+        lds = std::max(lds, (size_t)(TN * ldh_of(256) + XS_ROWS * 256) * 4);
 #define TSD_MEGA(HH)                                                                                         \
     {                                                                                                        \
         static DeviceOnce once;                                                                              \
