@@ -5,7 +5,9 @@ import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tsdiff_amd import engine, synth
+from tsdiff_amd import _lib, engine, synth
+if os.environ.get("TSDIFF_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["TSDIFF_LIB"])  # (a variant build: tools/build_variant.sh)
 from tsdiff_amd.epsnet import get_model
 from tsdiff_amd.utils import AttrDict
 dev = torch.device("cuda:0")

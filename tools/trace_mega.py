@@ -43,7 +43,9 @@ if m.any():
     for l in range(1, 7):
         ml = m & (t[:, 3] == l)
         if ml.any():
-            print(f"  filter layer {l}: start med {np.median(us(t[ml, 1])):7.1f}  end med {np.median(us(t[ml, 2])):7.1f} max {us(t[ml, 2]).max():7.1f}")
+            en = us(t[ml, 2])
+            print(f"  filter layer {l}: start med {np.median(us(t[ml, 1])):7.1f}  end med {np.median(en):7.1f}  p90 {np.percentile(en, 90):7.1f}  "
+                  f"p99 {np.percentile(en, 99):7.1f}  max {en.max():7.1f}")
 # phase stamps of the node workgroups (variant builds with TSD_MEGA_P_MASK): [tile][block][phase], 100 MHz wall clock
 try:
     dph = C.CDLL(_lib.LIB_PATH).tsd_debug_mega_phase
@@ -67,3 +69,9 @@ try:
             print(f"           {d}")
 except AttributeError:
     pass
+# how many workgroups of each role are running at a time (start/end stamps)
+span = us(t[:, 2].max())
+print("running workgroups over time (node / filter / pair):")
+for x in np.arange(5.0, span, 10.0):
+    c = [int(((us(t[:, 1]) <= x) & (us(t[:, 2]) > x) & (t[:, 0] == r)).sum()) for r in (2, 3, 4)]
+    print(f"  t = {x:5.0f} us: {c[0]:4d} {c[1]:4d} {c[2]:4d}   (sum {sum(c)})")
