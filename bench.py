@@ -637,7 +637,7 @@ def main():
     E_enc, E_out, E_diff = db.enc.num_edges(), db.out.num_edges(), db.diff_u.num_edges()
     from tsdiff_amd import engine
     gemm = db.gemm_mode()
-    one_launch = gemm == "h2" and engine.ONE_LAUNCH and args.models == 1 and (N + 15) // 16 <= 256
+    one_launch = gemm == "h2" and engine.OPTIONS.one_launch and args.models == 1 and (N + 15) // 16 <= 256
     fname = PMC_C2 if args.workload == "c2" else PMC_C5
     label = "c2" if args.workload == "c2" else "c5"
     reps = 40 if db.P < 2_000_000 else 2
@@ -661,10 +661,10 @@ def main():
     # the same K timed steps on the fp32-input-MFMA kernels (exact fp32 fma chains)
     f32_ms = None
     if gemm == "h2" and world == 1 and not args.no_f32:
-        engine.GEMM = "f32"
+        engine.OPTIONS.gemm = "f32"
         run.run(max(args.warmup, 5))
         f32_ms = min(run.timed(args.steps)[0] for _ in range(3)) / args.steps * 1e3
-        engine.GEMM = "h2"
+        engine.OPTIONS.gemm = "h2"
     F, F_ref = forward_flops(models[0]._cfg, E_enc, E_out, E_diff, N, args.models)
     step_s = dt / args.steps
 

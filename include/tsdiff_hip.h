@@ -67,7 +67,10 @@ extern "C" {
 #define TSD_STATUS_NAN 1           /* NaN in positions after an update (sampler.py:248-250) */
 #define TSD_STATUS_BAD_BOND 2      /* bond across graphs / self loop / index out of range */
 #define TSD_STATUS_ASYMMETRIC 4    /* bond list is not symmetric (A0 contract: both directions) */
-#define TSD_STATUS_INTERNAL 8      /* a bounded in-kernel wait of the fused step tail gave up (never expected) */
+#define TSD_STATUS_INTERNAL 8      /* a bounded in-kernel wait (fused step tail, one-launch forward) gave up -- e.g. another
+                                      tenant of the GPU held the workgroup slots the waited-for tiles needed; the results
+                                      of the call are invalid: rerun it with tsd_batch.reserved bit 0 set and
+                                      max_graph_nodes = 0 (forms without in-kernel waits; the Python host does) */
 #define TSD_STATUS_RANGE 16        /* split-f16 forward (tsd_batch.weights16): an activation left the f16 range
                                       (|a| > 65504); the results of the call are invalid, rerun it with weights16 = NULL */
 
@@ -291,8 +294,13 @@ typedef struct tsd_batch {
     int32_t max_graph_nodes;    /* atoms of the largest graph (host knowledge), or 0 = unknown: the sampling loop then
                                    runs its step tail as three launches instead of the fused one (<= 64-atom graphs) */
     int32_t reserved;           /* flags; bit 0: run the forward as one launch per block even where the one-launch form
-                                   applies; bit 1: 32-row filter tiles also where a split-f16 block launch would take
-                                   64-row ones (A/B and cross-check switches; results are bit-identical) */
+                                   applies (also what a caller sets after a TSD_STATUS_INTERNAL report: that form has no
+                                   in-kernel waits); bit 1: 32-row filter tiles also where a split-f16 block launch would
+                                   take 64-row ones (A/B and cross-check switches; results are bit-identical); bit 2: no
+                                   fused per-unit encoder (kernels_unit.hip) where it would apply: one launch per block
+                                   with materialised filters instead (same function, another summation order);
+                                   bit 3 (tests only): fault injection -- the one-launch forward skips its last filter
+                                   tile, so that one bounded wait gives up and TSD_STATUS_INTERNAL is reported */
     tsd_typed_tiles enc_tiles, diff_tiles;  /* static type-sorted embedding tiles, or num_tiles = 0: generic embedding */
     const float* bucket_weights;            /* [M][(enc + diff buckets) * (H*H + H)] (tsd_bucket_weights_build) or NULL */
     /* ---- appended in 0.4: the split-f16 inference forward (see tsd_pack_weights16) ---- */

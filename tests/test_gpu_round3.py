@@ -45,7 +45,7 @@ def _lists_snapshot(db):
 
 def _set_tail(monkeypatch, on):
     from tsdiff_amd import engine
-    monkeypatch.setattr(engine, "FUSED_STEP_TAIL", bool(on))
+    monkeypatch.setattr(engine.OPTIONS, "fused_step_tail", bool(on))
 
 
 @pytest.mark.parametrize("case", ["small", "ensemble2_ddpm", "sigma_far", "dense64"])
@@ -390,8 +390,8 @@ def test_sampling_paths_random_topologies_vs_oracle(hidden, convs, trials, dev, 
         tag = f"trial {trial}: G={G} N={N} orders {cfg['edge_order']}/{cfg['pred_edge_order']} cutoff {cfg['edge_cutoff']}"
 
         def run(typed, tail):
-            monkeypatch.setattr(engine, "TYPED_TILES", typed)
-            monkeypatch.setattr(engine, "FUSED_STEP_TAIL", tail)
+            monkeypatch.setattr(engine.OPTIONS, "typed_tiles", typed)
+            monkeypatch.setattr(engine.OPTIONS, "fused_step_tail", tail)
             model = make_model(cfg, 2, dev)
             ens = EnsembleSampler([model])
             pos, traj = ens.dynamic_sampling(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"],

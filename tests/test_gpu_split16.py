@@ -26,8 +26,8 @@ def _modes(monkeypatch):
     from tsdiff_amd import engine
 
     def set_mode(gemm, one_launch):
-        monkeypatch.setattr(engine, "GEMM", gemm)
-        monkeypatch.setattr(engine, "ONE_LAUNCH", one_launch)
+        monkeypatch.setattr(engine.OPTIONS, "gemm", gemm)
+        monkeypatch.setattr(engine.OPTIONS, "one_launch", one_launch)
     return set_mode
 
 
@@ -147,7 +147,7 @@ def test_wide_filter_tiles_equal_narrow_ones(dev, monkeypatch):
     res = {}
     for name, gemm, wide in (("wide", "h2", True), ("narrow", "h2", False), ("f32", "f32", True)):
         set_mode(gemm, True)
-        monkeypatch.setattr(engine, "WIDE_FILTER_TILES", wide)
+        monkeypatch.setattr(engine.OPTIONS, "wide_filter_tiles", wide)
         inv, _, _ = run_forward(model, g, dev)
         res[name] = inv.clone()
     assert torch.isfinite(res["wide"]).all()

@@ -21,12 +21,12 @@ def child(workload, steps, lib, flags):
     from tsdiff_amd import _lib, engine, synth
     if lib != "default":
         _lib.LIB_PATH = lib if os.path.isabs(lib) else os.path.join(ROOT, lib)
-    engine.FUSED_STEP_TAIL = "tail0" not in flags
-    engine.TYPED_TILES = "typed0" not in flags
+    engine.OPTIONS.fused_step_tail = "tail0" not in flags
+    engine.OPTIONS.typed_tiles = "typed0" not in flags
     if "perblock" in flags:
-        engine.ONE_LAUNCH = False  # the split-f16 forward as one launch per block
+        engine.OPTIONS.one_launch = False  # the split-f16 forward as one launch per block
     if "f32" in flags:
-        engine.GEMM = "f32"  # fp32-input MFMA instead of the split-f16 forward
+        engine.OPTIONS.gemm = "f32"  # fp32-input MFMA instead of the split-f16 forward
     from bench import SamplingRun, make_models, to_dev
     from tsdiff_amd.sampler import EnsembleSampler
     dev = torch.device("cuda:0")

@@ -38,7 +38,7 @@ for seed in range(nseeds):
     g = {k: v.to(dev) for k, v in t.items()}
     res = {}
     for mode in ("h2", "f32"):
-        engine.GEMM = mode
+        engine.OPTIONS.gemm = mode
         with torch.no_grad():
             inv, ei, el = model(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
                                 g["batch"], torch.zeros(24, dtype=torch.long, device=dev))
@@ -65,7 +65,7 @@ pos0 = torch.randn(N, 3, device=dev, generator=gen) * 1.5
 noises = torch.randn(20, N, 3, device=dev, generator=gen)
 out = {}
 for mode in ("h2", "f32"):
-    engine.GEMM = mode
+    engine.OPTIONS.gemm = mode
     sampler = EnsembleSampler(models)
     pos, traj = sampler.dynamic_sampling(g["atom_type"], g["r_feat"], g["p_feat"], pos0, g["bond_index"], g["bond_type"],
                                          g["batch"], 100, extend_order=True, n_steps=20, step_lr=1e-7, clip=1000,

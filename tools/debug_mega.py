@@ -22,7 +22,7 @@ H, L = 256, 7
 def pad(n): return (n + 63) & ~63
 out = {}
 for one in (False, True):
-    engine.ONE_LAUNCH = one
+    engine.OPTIONS.one_launch = one
     with torch.no_grad():
         inv, ei, el = model(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"], torch.zeros(G, dtype=torch.long, device=dev))
     db = model._batches[0][2]

@@ -149,9 +149,14 @@ constexpr bool kFold = TSD_FOLD != 0;
 #ifndef TSD_MEGA
 #define TSD_MEGA 1  // 0 (A/B variant builds): the split-f16 forward as one launch per block
 #endif
-// shapes the one-launch forward takes: every node workgroup (8 atoms each) resident at once, one checkpoint
-static bool mega_shape(const tsd_model_cfg& c, int N, int M) {
-    return TSD_MEGA != 0 && M == 1 && N > 0 && (N + mega_node_rows() - 1) / mega_node_rows() <= 256 && c.num_convs <= 60;
+// Shapes the one-launch forward takes: one checkpoint, every node workgroup resident at once on at most HALF of the
+// device's slots for that kernel (occupancy x compute units, queried per device: 512 on a whole MI355X, less on a
+// partitioned or smaller part), and a filter arena of all L blocks (no ring) that stays small.
+static bool mega_shape(const tsd_model_cfg& c, int N, int P, int M) {
+    if (TSD_MEGA == 0 || M != 1 || N <= 0 || c.num_convs > 60) return false;
+    const int node_wgs = (N + mega_node_rows() - 1) / mega_node_rows();
+    if (2 * node_wgs > mega_slots(c.hidden)) return false;
+    return (size_t)(P / 2) * c.hidden * c.num_convs * sizeof(float) <= ((size_t)2 << 30);
 }
 
 static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base) {
@@ -163,7 +168,7 @@ static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base)
     w.stride_ea = pad(2 * PU * H);
     w.wf_slots = c.num_convs < WF_RING ? c.num_convs : WF_RING;
     // the one-launch forward (one checkpoint, <= 256 node tiles) keeps the filters of every block (no ring)
-    if (mega_shape(c, N, M)) w.wf_slots = c.num_convs;
+    if (mega_shape(c, N, P, M)) w.wf_slots = c.num_convs;
     w.stride_wf = pad((size_t)w.wf_slots * PU * H);
     w.stride_nh = pad((size_t)N * H);
     w.ea = take(w.stride_ea * M);
@@ -174,9 +179,9 @@ static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base)
     w.stride_pre = pad(PU * H);
     w.pre = take(w.stride_pre * M);
     w.ready = reinterpret_cast<int32_t*>(take(pad((size_t)M * ((N + TSD_NODE_TILE - 1) / TSD_NODE_TILE))));
-    w.ctl_words = pad(mega_shape(c, N, M) ? mega_ctl_words(filter_tiles_per_layer((int)PU), c.num_convs) : 64);
+    w.ctl_words = pad(mega_shape(c, N, P, M) ? mega_ctl_words(filter_tiles_per_layer((int)PU), c.num_convs) : 64);
     w.ctl = reinterpret_cast<int32_t*>(take(w.ctl_words));
-    w.x1m = take(mega_shape(c, N, M) && c.num_convs > 1 ? w.stride_nh * (size_t)(c.num_convs - 1) : 0);
+    w.x1m = take(mega_shape(c, N, P, M) && c.num_convs > 1 ? w.stride_nh * (size_t)(c.num_convs - 1) : 0);
     w.total = o;
     return w;
 }
@@ -224,7 +229,7 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     }
     const bool h2 = prec.mode == PREC_H2;
     const float* W = h2 ? b.weights16 : b.weights;
-    const bool mega = h2 && mega_shape(c, N, M) && prec.range_status != nullptr && P > 0 && !(b.reserved & 1);
+    const bool mega = h2 && mega_shape(c, N, P, M) && prec.range_status != nullptr && P > 0 && !(b.reserved & 1);
     UmapRole um{};
     um.g = g;
     um.graph_ptr = b.graph_ptr;
@@ -663,7 +668,7 @@ int tsd_forward_blocks(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t
     TSD_REQUIRE(epoch >= 1, "epoch=%d (1, 2, ... since the first call)", epoch);
     const tsd_batch& b = *batch;
     const bool typed = kFold && b.enc_tiles.num_tiles > 0 && b.bucket_weights != nullptr;
-    if (!(typed && b.weights16 && b.bucket_weights16 && b.status && mega_shape(*cfg, b.num_nodes, b.num_models) &&
+    if (!(typed && b.weights16 && b.bucket_weights16 && b.status && mega_shape(*cfg, b.num_nodes, b.num_pairs, b.num_models) &&
           b.num_pairs > 0)) {
         set_error("tsd_forward_blocks: the batch does not take the one-launch split-f16 forward");
         return TSD_ERR_UNSUPPORTED;

@@ -270,6 +270,7 @@ int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float*
                         int32_t* status, hipStream_t st);
 size_t mega_ctl_words(int tiles_per_layer, int L);
 int mega_node_rows();
+int mega_slots(int H);  // resident workgroup slots of the one-launch kernel on the current device (0: unknown)
 int launch_bucket_weights16(const tsd_model_cfg& c, const float* bucket, int num_slots, float* out16, hipStream_t st);
 
 inline bool hidden_supported(int H) { return H == 64 || H == 128 || H == 256; }

@@ -739,7 +739,10 @@ __device__ __forceinline__ void pair_role(const ComboPre& q, int tile, int node_
             for (unsigned spins = 0;; ++spins) {
                 const int f = need ? __hip_atomic_load(q.ready + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
                 if (__all(f >= q.ready_target)) break;
-                if (spins > PAIR_SPIN_LIMIT) {
+                // (a launch in which another wait has already given up unwinds quickly: see mega_wait_failed)
+                if (spins > PAIR_SPIN_LIMIT ||
+                    ((spins & 1023u) == 1023u &&
+                     (__hip_atomic_load(q.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & TSD_STATUS_INTERNAL))) {
                     gave_up = true;
                     break;
                 }
@@ -1086,7 +1089,10 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
             for (unsigned spins = 0;; ++spins) {
                 const int f = need ? __hip_atomic_load(q.ready + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
                 if (__all(f >= q.ready_target)) break;
-                if (spins > PAIR_SPIN_LIMIT) {
+                // (a launch in which another wait has already given up unwinds quickly: see mega_wait_failed)
+                if (spins > PAIR_SPIN_LIMIT ||
+                    ((spins & 1023u) == 1023u &&
+                     (__hip_atomic_load(q.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & TSD_STATUS_INTERNAL))) {
                     gave_up = true;
                     break;
                 }
@@ -1682,6 +1688,7 @@ struct MegaArgs {
     // roles' grid ranges
     int n_node, n_filter, n_pair, tiles_per_layer;
     int L, N;
+    int half_slots;            // half of the device's resident-workgroup slots for this kernel (mega_slots() / 2: 256 on a whole MI355X)
     const int32_t* epoch_src;  // device word: epoch = *epoch_src + epoch_bias (>= 1, + 1 per launch since the block was zeroed)
     int epoch_bias;
     int32_t* ctl;
@@ -1711,11 +1718,22 @@ constexpr unsigned MEGA_SPIN_LIMIT = 4000000u;
 constexpr int MEGA_POLL_SLEEP = TSD_MEGA_POLL_SLEEP;
 
 // one wave: wait until *p >= target (monotonic word); false after the bound
+// (a launch in which one wait has given up unwinds quickly: every MEGA_ABORT_POLLS polls a waiting wave looks at the
+// status word, and a wait that finds TSD_STATUS_INTERNAL there gives up as well -- the results of such a launch are void,
+// the host reruns the forward as one launch per block)
+constexpr unsigned MEGA_ABORT_POLLS = 256u;
+__device__ __forceinline__ bool mega_wait_failed(unsigned spins, int32_t* status) {
+    if (spins > MEGA_SPIN_LIMIT) {
+        if ((threadIdx.x & 63) == 0) atomicOr(status, TSD_STATUS_INTERNAL);
+        return true;
+    }
+    return (spins & (MEGA_ABORT_POLLS - 1)) == MEGA_ABORT_POLLS - 1 &&
+           (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & TSD_STATUS_INTERNAL) != 0;
+}
 __device__ __forceinline__ bool mega_wait_ge(const int32_t* p, int target, int32_t* status) {
     for (unsigned spins = 0;; ++spins) {
         if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
-        if (spins > MEGA_SPIN_LIMIT) {
-            if ((threadIdx.x & 63) == 0) atomicOr(status, TSD_STATUS_INTERNAL);
+        if (mega_wait_failed(spins, status)) {
             return false;
         }
         __builtin_amdgcn_s_sleep(MEGA_POLL_SLEEP);
@@ -1729,10 +1747,7 @@ __device__ __forceinline__ bool mega_wait_range_ge(const int32_t* p, int lo, int
         for (unsigned spins = 0;; ++spins) {
             const int v = t <= hi ? __hip_atomic_load(p + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
             if (__all(v >= target)) break;
-            if (spins > MEGA_SPIN_LIMIT) {
-                if (lane == 0) atomicOr(status, TSD_STATUS_INTERNAL);
-                return false;
-            }
+            if (mega_wait_failed(spins, status)) return false;
             __builtin_amdgcn_s_sleep(MEGA_POLL_SLEEP);
         }
     }
@@ -1961,8 +1976,8 @@ __global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A) {
     // (only while the node workgroups take at most half of the CUs: every parked tile is a slot the filter tiles lose;
     // measured at batch 100: 0.2184 vs 0.2197 ms/step -- the node chain is slowed by the memory system's load, which
     // stays, far more than by its CU neighbour)
-    const bool park = TSD_MEGA_PARK != 0 && A.n_node <= 128;
-    const int first_filters = park ? min(A.n_filter, 256 - A.n_node) : A.n_filter;
+    const bool park = TSD_MEGA_PARK != 0 && 2 * A.n_node <= A.half_slots;
+    const int first_filters = park ? min(A.n_filter, A.half_slots - A.n_node) : A.n_filter;
     const int parked = park ? min(A.n_pair, A.n_node) : 0;
     int filter_item = -1, pair_item = -1;
     if (b < first_filters) filter_item = b;
@@ -1994,6 +2009,47 @@ __global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A) {
     }
 }
 
+// Resident-workgroup slots of the one-launch kernel on the current device: occupancy of the kernel (its LDS and
+// registers) x compute units, queried once per device.  The launch condition (api.hip mega_shape) keeps the node
+// workgroups -- which wait for workgroups dispatched after them -- within HALF of these slots, so that on a partitioned
+// or smaller part the filter tiles they wait for always find a free slot.  (A second tenant on the same GPU can still
+// hold slots: that is what the bounded waits and the host's per-block rerun are for.)
+static size_t mega_lds_bytes(int H) {
+    size_t lds = lds_combo(H, PREC_H2);
+    if (H == 256 && MEGA_TR == TN && TSD_MEGA_XLDS)  // the node workgroups' LDS copy of x (xl_gather) behind their planes
+        lds = std::max(lds, (size_t)(TN * ldh_of(256) + XS_ROWS * 256) * 4);
+    return lds;
+}
+int mega_slots(int H) {
+    static std::atomic<int> cache[3][64];
+    const int hi = H == 64 ? 0 : (H == 128 ? 1 : 2);
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) return 0;
+    d &= 63;
+    int v = cache[hi][d].load();
+    if (v > 0) return v;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) != hipSuccess) return 0;
+    int per_cu = 0;
+    const size_t lds = mega_lds_bytes(H);
+    hipError_t e = hipErrorInvalidValue;
+#define TSD_OCC(HH)                                                                                             \
+    {                                                                                                           \
+        if (lds > 48 * 1024)                                                                                    \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(forward_mega_kernel<HH>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, forward_mega_kernel<HH>, 2 * HH, lds);        \
+    }
+    if (H == 64) TSD_OCC(64) else if (H == 128) TSD_OCC(128) else if (H == 256) TSD_OCC(256)
+#undef TSD_OCC
+    if (e != hipSuccess || per_cu <= 0) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    v = per_cu * prop.multiProcessorCount;
+    cache[hi][d].store(v);
+    return v;
+}
 int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float* pos, const float* W16, float* ea, float* wf,
                         float* h, float* x1m, size_t x1_stride, int32_t* ctl, const int32_t* epoch_src, int epoch_bias,
                         int32_t* status, hipStream_t st) {
@@ -2072,11 +2128,17 @@ int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float*
     A.n_node = (N + TRH - 1) / TRH;
     A.n_filter = A.f.tiles;
     A.n_pair = A.q.tiles;
+    A.half_slots = mega_slots(H) / 2;
+    if (A.n_node > A.half_slots) {
+        set_error("internal: %d node workgroups on a device with %d resident slots", A.n_node, 2 * A.half_slots);
+        return TSD_ERR_INVALID;
+    }
+    // (tests, tsd_batch.reserved bit 3: the last filter tile of the last block is never run, so the node workgroup that
+    // reads its rows waits until the bound -- the TSD_STATUS_INTERNAL path end to end)
+    if ((b.reserved & 8) && A.n_filter > 0) --A.n_filter;
     const int grid = A.n_node + A.n_filter + A.n_pair;
     if (grid == 0 || A.n_node == 0) return TSD_OK;
-    size_t lds = lds_combo(H, PREC_H2);
-    if (H == 256 && MEGA_TR == TN && TSD_MEGA_XLDS)  // the node workgroups' LDS copy of x (aggregate_tile_xl) behind their planes
-        lds = std::max(lds, (size_t)(TN * ldh_of(256) + XS_ROWS * 256) * 4);
+    const size_t lds = mega_lds_bytes(H);
 #define TSD_MEGA(HH)                                                                                         \
     {                                                                                                        \
         static DeviceOnce once;                                                                              \

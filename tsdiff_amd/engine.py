@@ -83,21 +83,10 @@ def pack_weights(cfg, named_tensors, device):
 
 
 _SIDE_STREAMS = {}
-# static type-sorted embedding tiles (kernels_typed.hip); "0" keeps the generic embedding kernel (A/B, tests)
-TYPED_TILES = os.environ.get("TSDIFF_TYPED_TILES", "1") != "0"
 MAX_TYPE_BUCKETS = 96  # (type_r, type_p) pairs per batch whose folded matrices are kept (H = 256: 25 MB per checkpoint)
-# Arithmetic of the inference forward's tile GEMMs (csrc/split16.hpp): "h2" = split-f16 operands on the f16 MFMA pipes
-# (22-bit operands, fp32 accumulation: the fp32 error class at several times the fp32-input MFMA's rate; the default),
-# "f32" = fp32-input MFMA (exact fp32 fma chains).  A call whose activations leave the f16 range (|a| > 65504,
-# TSD_STATUS_RANGE) is rerun in "f32" by the host.  Training always runs fp32.
-GEMM = os.environ.get("TSDIFF_GEMM", "h2")
-if GEMM not in ("h2", "f32"):
-    raise ValueError(f"TSDIFF_GEMM={GEMM!r}: expected 'h2' or 'f32'")
-# the split-f16 forward of a small batch as ONE launch (kernels_combo.hip forward_mega_kernel); "0": one launch per block
-ONE_LAUNCH = os.environ.get("TSDIFF_ONE_LAUNCH", "1") != "0"
-WIDE_FILTER_TILES = os.environ.get("TSDIFF_WIDE_FILTER_TILES", "1") != "0"  # 0: tsd_batch.reserved bit 1 (cross-check switch)
-# tests / tools flip this to run the sampling loop's step tail as the three separate launches (bit-identical results)
-FUSED_STEP_TAIL = os.environ.get("TSDIFF_FUSED_TAIL", "1") != "0"
+# the A/B and cross-check switches of the host side (arithmetic of the tile GEMMs, typed embedding tiles, one-launch
+# forward, filter tile width, fused step tail, fused encoder) live in tsdiff_amd.options, documented there
+from .options import OPTIONS  # noqa: E402
 
 
 def _side_stream(device):
@@ -211,6 +200,7 @@ class DeviceBatch:
         zeros = [("node_graph", max(N, 1), i32), ("pair_ptr", N + 1, i32), ("pair_code", max(P, 1), torch.int16),
                  # tsd_sampler_state: [0] status flags (also the topology build's status word), [1] step counter, run args
                  ("status", _lib.SAMPLER_STATE_INTS, i32),
+                 ("typed_counts", 4, i32),  # tsd_typed_tiles_build's four counts (read back with the status word)
                  ("attr_row", max(P // 2, 1), i32), ("pair2out", max(P, 1), i32), ("pair2u", max(2 * P, 1), i32),
                  ("geo_scratch", int(lib.tsd_geometry_scratch_ints(N, P)), i32),
                  ("pos_work", 3 * max(N, 1), f32),  # the loop's in-place positions
@@ -233,7 +223,7 @@ class DeviceBatch:
         # include/tsdiff_hip.h tsd_typed_tiles): built on the device behind the topology, their four counts come back
         # with the status word in the same host read
         self.typed = None
-        if TYPED_TILES and not defer_status and P > 0:
+        if OPTIONS.typed_tiles and not defer_status and P > 0:
             cap = int(lib.tsd_typed_tiles_capacity(P))
             PU = P // 2
             tt = torch.empty(6 * PU + 6 * cap + 2 * 1024 + 8192, dtype=i32, device=dev)
@@ -242,7 +232,7 @@ class DeviceBatch:
             enc_tile, diff_tile = tt[o:o + 3 * cap], tt[o + 3 * cap:o + 6 * cap]
             keys = tt[o + 6 * cap:o + 6 * cap + 2048]
             scratch = tt[o + 6 * cap + 2048:]
-            counts = self.status[12:16]  # (spare words of the state block: read back with the status word)
+            counts = self.typed_counts
             check(lib.tsd_typed_tiles_build(C.byref(cfg), N, P, ptr(self.graph_ptr), ptr(self.node_graph),
                                             ptr(self.pair_ptr), ptr(self.pair_code), ptr(v[0]), ptr(v[1]), ptr(v[2]),
                                             ptr(enc_tile), ptr(v[3]), ptr(v[4]), ptr(v[5]), ptr(diff_tile), ptr(keys),
@@ -252,11 +242,10 @@ class DeviceBatch:
         # the edge counts that tsd_train_forward reads anyway
         self.status_pending = True
         if not defer_status:
-            words = self.status.cpu()
+            words = torch.cat([self.status[:1], self.typed_counts]).cpu()  # ONE host read per batch
             self.check_status(int(words[0]))
             if self.typed is not None:
-                nt_e, nb_e, nt_d, nb_d = (int(x) for x in words[12:16])
-                self.status[12:16].zero_()
+                nt_e, nb_e, nt_d, nb_d = (int(x) for x in words[1:5])
                 if nt_e == 0 or nb_e + nb_d > MAX_TYPE_BUCKETS:
                     self.typed = None  # (no pairs, or an unusually rich type mix: the generic embedding kernel)
                 else:
@@ -277,7 +266,9 @@ class DeviceBatch:
         self.ready_event = None  # set by a build on a side stream (prefetch): consumers wait for it, stream to stream
         self._plans = {}  # (kind, clip, clip_pos) -> tsd_sampler_plan* of the bound checkpoints
         self._plan_streams = {}  # streams the plans were launched on (drop_plans waits for them)
-        self.gemm = None  # None: the module default (GEMM); "f32" after a range fallback on this batch
+        self.gemm = None  # None: OPTIONS.gemm; "f32" after a range fallback on this batch
+        self.per_block = False  # True after an in-launch wait of the one-launch forward gave up on this batch
+        self.test_flags = 0     # extra tsd_batch.reserved bits (tests: bit 3 = fault injection in the one-launch forward)
 
     def owned_tensors(self):
         """every device tensor this object holds right now (arenas, inputs, typed-tile buffers): what a build on a
@@ -335,7 +326,7 @@ class DeviceBatch:
         self.bucket_weights = None
         self.weights16 = None
         self.bucket_weights16 = None
-        if self.typed is not None and TYPED_TILES:
+        if self.typed is not None and OPTIONS.typed_tiles:
             t = self.typed
             ns = t["nb_e"] + t["nb_d"]
             per = int(lib.tsd_bucket_weights_floats(C.byref(self.cfg), ns))
@@ -362,7 +353,7 @@ class DeviceBatch:
 
     def gemm_mode(self):
         """'h2' (split-f16 MFMA) or 'f32' for the next forward / sampling call on this batch"""
-        mode = self.gemm or GEMM
+        mode = self.gemm or OPTIONS.gemm
         return mode if (mode == "h2" and self.weights16 is not None and self.bucket_weights16 is not None) else "f32"
 
     def struct(self):
@@ -375,8 +366,8 @@ class DeviceBatch:
             geo=self.geo_struct(), workspace=self.workspace.data_ptr(),
             edge_inv_u=self.edge_inv_u.data_ptr(),
             # 0 = "unknown": the library then runs the step tail as three launches (A/B switch for tests / tools)
-            max_graph_nodes=self.max_n if FUSED_STEP_TAIL else 0,
-            reserved=(0 if ONE_LAUNCH else 1) | (0 if WIDE_FILTER_TILES else 2),
+            max_graph_nodes=self.max_n if (OPTIONS.fused_step_tail and not self.per_block) else 0,
+            reserved=self.reserved_flags(),
             enc_tiles=self._tiles_struct("enc"), diff_tiles=self._tiles_struct("diff"),
             bucket_weights=None if self.bucket_weights is None else self.bucket_weights.data_ptr(),
             weights16=self.weights16.data_ptr() if h2 else None,
@@ -385,7 +376,7 @@ class DeviceBatch:
 
     def _tiles_struct(self, which):
         t = self.typed
-        if t is None or self.bucket_weights is None or not TYPED_TILES:
+        if t is None or self.bucket_weights is None or not OPTIONS.typed_tiles:
             return _lib.TypedTiles()
         e = which == "enc"
         tile, cap = (t["enc_tile"] if e else t["diff_tile"]), t["cap"]
@@ -421,31 +412,50 @@ class DeviceBatch:
         pos = pos.to(torch.float32).contiguous()
         b = self.struct()
         check(lib.tsd_score_forward(C.byref(self.cfg), C.byref(b), ptr(pos), stream_ptr()))
-        self.range_pending = self.gemm_mode() == "h2"
         return pos
 
-    def forward_out_edges(self, pos):
-        """forward(pos) and the number of directed out edges, in ONE host read (the edge count and -- split-f16 forward
-        -- the range flag); a call that left the f16 range is rerun on the fp32-MFMA kernels"""
-        self.forward(pos)
-        if not self.range_pending:
-            return self.out.num_edges()
-        words = torch.stack([self.out.count[0], self.status[0]]).cpu()
-        if self.range_fallback(int(words[1])):
-            self.forward(pos)
-            return self.out.num_edges()
-        return int(words[0])
+    def reserved_flags(self):
+        """tsd_batch.reserved (include/tsdiff_hip.h): bit 0 one launch per block, bit 1 narrow filter tiles, bit 2 no
+        fused encoder; test bits"""
+        return ((0 if (OPTIONS.one_launch and not self.per_block) else 1) | (0 if OPTIONS.wide_filter_tiles else 2) |
+                (0 if OPTIONS.fused_encoder else 4) | self.test_flags)
 
-    def range_fallback(self, word):
-        """True when a split-f16 call reported TSD_STATUS_RANGE: the batch is switched to the fp32-MFMA kernels (the
-        caller reruns the call).  `word`: the status word the caller has read anyway."""
-        if not (int(word) & _lib.STATUS_RANGE):
+    def forward_out_edges(self, pos):
+        """forward(pos) and the number of directed out edges, in ONE host read (the edge count and the status word).
+        A split-f16 call that left the f16 range is rerun on the fp32-MFMA kernels; a one-launch forward in which a
+        bounded in-kernel wait gave up (TSD_STATUS_INTERNAL: e.g. another tenant held the GPU's workgroup slots) is
+        rerun as one launch per block -- bit-identical, no in-kernel waits."""
+        for _ in range(3):
+            self.forward(pos)
+            words = torch.stack([self.out.count[0], self.status[0]]).cpu()
+            if not self.status_fallback(int(words[1])):
+                return int(words[0])
+        raise _lib.TsdError("internal: the forward kept reporting status %d" % int(words[1]))
+
+    def status_fallback(self, word):
+        """The status word of a finished forward / sampling call: False if the results stand.  True: the batch has been
+        switched to the form that cannot fail that way and the caller reruns the call -- TSD_STATUS_RANGE (split-f16
+        arithmetic left the f16 range) -> fp32-MFMA kernels; TSD_STATUS_INTERNAL (a bounded wait inside the one-launch
+        forward or the fused step tail gave up) -> one launch per block / three-launch tail.  The bits are cleared."""
+        word = int(word)
+        if not (word & (_lib.STATUS_RANGE | _lib.STATUS_INTERNAL)):
             return False
         self.status[:1].zero_()
-        if self.gemm_mode() != "h2":
-            raise _lib.TsdError("internal: TSD_STATUS_RANGE from an fp32 forward")
-        self.gemm = "f32"
+        if word & _lib.STATUS_INTERNAL:
+            if self.per_block:
+                raise _lib.TsdError("internal: a bounded in-kernel wait gave up (TSD_STATUS_INTERNAL) in the "
+                                    "launch-per-block form")
+            self.per_block = True
+            self.drop_plans()
+        if word & _lib.STATUS_RANGE:
+            if self.gemm_mode() != "h2":
+                raise _lib.TsdError("internal: TSD_STATUS_RANGE from an fp32 forward")
+            self.gemm = "f32"
         return True
+
+    def range_fallback(self, word):
+        """(kept for callers of the round-3 name) see status_fallback"""
+        return self.status_fallback(word)
 
     def ensemble_mean(self):
         """directed edge_inv (reference order): mean over the checkpoints, expanded through out.umap"""
@@ -493,8 +503,9 @@ class DeviceBatch:
     def sampler_plan(self, kind, clip, clip_pos):
         """the captured + instantiated hipGraph of one sampling step for the bound checkpoints; built once and
         replayed by every later dynamic_sampling call on this batch (reference loop: models/sampler.py:187-254)"""
-        key = (int(kind), float(clip), float(-1.0 if clip_pos is None else clip_pos), bool(FUSED_STEP_TAIL), bool(TYPED_TILES),
-               self.gemm_mode(), bool(ONE_LAUNCH), bool(WIDE_FILTER_TILES))
+        key = (int(kind), float(clip), float(-1.0 if clip_pos is None else clip_pos),
+               bool(OPTIONS.fused_step_tail and not self.per_block),
+               bool(OPTIONS.typed_tiles), self.gemm_mode(), self.reserved_flags())
         plan = self._plans.get(key)
         if plan is None:
             lib = _lib.load()

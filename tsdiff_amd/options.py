@@ -1,0 +1,48 @@
+"""The switches of the host side, in ONE documented object.
+
+Every switch selects between forms that compute the same function (bit-identical unless noted); they exist for
+cross-check tests and A/B measurements, a user of the package never needs them.  The defaults can be overridden once,
+at import, by `TSDIFF_*` environment variables (read here and nowhere else); tests and tools flip the attributes of
+`tsdiff_amd.options.OPTIONS` (e.g. `monkeypatch.setattr(OPTIONS, "one_launch", False)`), which every later call sees.
+
+| attribute          | env variable              | default | meaning |
+|--------------------|---------------------------|---------|---------|
+| gemm               | TSDIFF_GEMM               | "h2"    | arithmetic of the inference forward's tile GEMMs: "h2" = split-f16 operands on the f16 MFMA pipes (22-bit operands, fp32 accumulation; csrc/split16.hpp), "f32" = fp32-input MFMA.  NOT bit-identical (1e-6 of the tensor scale apart).  A call that leaves the f16 range reruns in "f32" by itself |
+| typed_tiles        | TSDIFF_TYPED_TILES        | True    | edge embedding on static type-sorted tiles with per-type folded matrices (kernels_typed.hip); False: the generic embedding kernel (and, since the split-f16 forward needs the typed tiles, fp32 arithmetic) |
+| one_launch         | TSDIFF_ONE_LAUNCH         | True    | small batches: the L interaction blocks + pair MLP as ONE launch (forward_mega_kernel); False: one launch per block |
+| wide_filter_tiles  | TSDIFF_WIDE_FILTER_TILES  | True    | 64-row filter tiles where a block launch is many chip-fulls deep; False: 32-row tiles everywhere |
+| fused_step_tail    | TSDIFF_FUSED_TAIL         | True    | sampling loop: update + next step's edge lists as one launch; False: three launches |
+| fused_encoder      | TSDIFF_FUSED_ENCODER      | True    | chip-full launches (big batches, ensembles): the whole SchNet encoder as ONE launch of per-unit workgroups that never write the CFConv filters to memory (kernels_unit.hip); False: one launch per block with materialised filters.  NOT bit-identical with that form (another summation order: 1e-6 of the tensor scale apart), deterministic run to run |
+"""
+import os
+from dataclasses import dataclass
+
+
+def _flag(name, default=True):
+    v = os.environ.get(name)
+    return default if v is None else v != "0"
+
+
+@dataclass
+class Options:
+    gemm: str = "h2"
+    typed_tiles: bool = True
+    one_launch: bool = True
+    wide_filter_tiles: bool = True
+    fused_step_tail: bool = True
+    fused_encoder: bool = True
+
+    @classmethod
+    def from_env(cls):
+        o = cls(gemm=os.environ.get("TSDIFF_GEMM", "h2"), typed_tiles=_flag("TSDIFF_TYPED_TILES"),
+                one_launch=_flag("TSDIFF_ONE_LAUNCH"), wide_filter_tiles=_flag("TSDIFF_WIDE_FILTER_TILES"),
+                fused_step_tail=_flag("TSDIFF_FUSED_TAIL"), fused_encoder=_flag("TSDIFF_FUSED_ENCODER"))
+        o.validate()
+        return o
+
+    def validate(self):
+        if self.gemm not in ("h2", "f32"):
+            raise ValueError(f"TSDIFF_GEMM={self.gemm!r}: expected 'h2' or 'f32'")
+
+
+OPTIONS = Options.from_env()

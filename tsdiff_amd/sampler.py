@@ -191,15 +191,15 @@ class EnsembleSampler(nn.Module):
                 elif return_traj:
                     pos_traj += list(traj.cpu().unbind(0))
             status = int(status_host[0]) if status_host is not None else int(db.status[0].item())  # the host sync of the loop
-            if db.range_fallback(status):
-                # split-f16 forward: an activation left the f16 range somewhere in the run -- the whole call again on the
-                # fp32-MFMA kernels (same draws: injected, or the same Philox seed)
+            if db.status_fallback(status):
+                # the whole call again, same draws (injected, or the same Philox seed), in the form that cannot fail
+                # that way: an activation left the f16 range -> fp32-MFMA kernels; a bounded in-kernel wait of the
+                # one-launch forward / the fused step tail gave up (e.g. a second tenant held the GPU's workgroup
+                # slots) -> one launch per block and the three-launch tail (bit-identical forms without in-kernel waits)
                 kw = dict(kwargs, noises=noises, seed=seed)
                 return self.dynamic_sampling(atom_type, r_feat, p_feat, pos_init, bond_index, bond_type, batch, num_graphs,
                                              extend_order, extend_radius, n_steps, step_lr, clip, clip_pos,
                                              denoise_from_time_t, noise_from_time_t, **kw)
-            if status & _lib.STATUS_INTERNAL:
-                raise _lib.TsdError("internal: a bounded wait of the fused step tail gave up (TSD_STATUS_INTERNAL)")
             if status & _lib.STATUS_NAN:
                 print("NaN detected. Please restart.")
                 raise FloatingPointError()
