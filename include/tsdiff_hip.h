@@ -61,6 +61,7 @@ extern "C" {
 #define TSD_NODE_TILE 16         /* nodes per workgroup tile of the per-node kernels */
 #define TSD_EDGE_PAD 8           /* spare entries every tsd_edges array must carry past its capacity */
 #define TSD_MAX_GRAPH_NODES 255  /* two u8 hop matrices of n*n must fit in the 160 KiB LDS */
+#define TSD_UNIT_MAX_NODES 64    /* atoms of one unit of the fused encoder (its x1 rows live in LDS) */
 #define TSD_NUM_BOND_TYPES 22    /* len(rdkit BondType.names), reference utils/chem.py:21 */
 
 /* status word bits (device int32 written by kernels, read by the caller when it chooses) */
@@ -298,7 +299,8 @@ typedef struct tsd_batch {
                                    in-kernel waits); bit 1: 32-row filter tiles also where a split-f16 block launch would
                                    take 64-row ones (A/B and cross-check switches; results are bit-identical); bit 2: no
                                    fused per-unit encoder (kernels_unit.hip) where it would apply: one launch per block
-                                   with materialised filters instead (same function, another summation order);
+                                   with materialised filters instead (bit-identical results); bit 4: the fused
+                                   encoder also where the one-launch form would apply (tests, A/B);
                                    bit 3 (tests only): fault injection -- the one-launch forward skips its last filter
                                    tile, so that one bounded wait gives up and TSD_STATUS_INTERNAL is reported */
     tsd_typed_tiles enc_tiles, diff_tiles;  /* static type-sorted embedding tiles, or num_tiles = 0: generic embedding */
@@ -311,10 +313,24 @@ typedef struct tsd_batch {
     int32_t* status;                        /* device word that receives TSD_STATUS_RANGE (sticky, OR-ed; the caller zeroes
                                                and reads it); may be NULL: no range report.  In the sampling loop the
                                                state block's flags word is used instead */
+    /* ---- appended in 0.5: the fused per-unit encoder (csrc/kernels_unit.hip) ---- */
+    const int32_t* unit_node;               /* [num_units + 1] node offsets of the UNITS of the batch: consecutive runs of whole
+                                               graphs with at most TSD_UNIT_MAX_NODES atoms each, covering [0, N) (host
+                                               knowledge: graphs never interact, so any such partition is valid; the Python
+                                               host balances it by pair count).  NULL: no fused encoder */
+    int32_t num_units;
+    int32_t reserved2;
 } tsd_batch;
 
 size_t tsd_forward_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs,
                                     int32_t num_models);
+/* Where a forward leaves its intermediates inside `workspace` (tests, debugging tools, integrators that want the
+ * node states): float offsets out[0..4] = edge attributes [M][P, H], CFConv filter slots [M][slots, P/2, H], node states h
+ * [M][N, H] (the encoder's output), the two x1 buffers; out[5] = per-checkpoint stride of the [N, H] arrays, out[6] =
+ * number of filter slots, out[7] = tsd_forward_workspace_floats.  Same device as the forward (the layout of small
+ * batches depends on the device's workgroup slots). */
+int tsd_forward_workspace_layout(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs, int32_t num_models,
+                                 size_t* out /* [8] host */);
 /* geometry + M forwards; edge_inv_u[m] valid for the first *geo.out_u.count entries. */
 int tsd_score_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* pos, void* stream);
 
@@ -325,6 +341,15 @@ int tsd_score_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
  * TSD_ERR_UNSUPPORTED when the batch does not take that path (no weights16 / status, several checkpoints, > 256 node
  * tiles). */
 int tsd_forward_blocks(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t epoch, void* stream);
+
+/* Measurement / cross-check entry of the fused per-unit encoder (csrc/kernels_unit.hip; models/encoder/schnet.py:74-128,
+ * 203-225): runs interaction blocks [l_begin, l_end) of every bound checkpoint as ONE launch -- one workgroup per unit
+ * (tsd_batch.unit_node) computes the CFConv filters of its pairs tile by tile, accumulates both end points' messages in
+ * registers and runs the node chain on its <= 64 rows; the filters are never written to memory -- on the attribute rows
+ * and edge lists the last tsd_score_forward of this batch left in the workspace.  l_begin = 0 starts from z / x1_0;
+ * a later start reads h and x1 of block l_begin from the workspace (what a run that ended at l_begin left there).
+ * TSD_ERR_UNSUPPORTED when the batch does not take that path (no weights16 / unit partition, hidden != 256). */
+int tsd_forward_encoder(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t l_begin, int32_t l_end, void* stream);
 
 /* mean over checkpoints in the reference's order, expanded to the directed out list:
  * edge_inv[e] = ((inv_u[0][u] + inv_u[1][u]) + ...)/M with u = out.umap[e]   -> edge_inv [P] */

@@ -5,7 +5,7 @@
 
 Every configuration runs in its own child process (one library per process), the configurations interleaved over
 `rounds` rounds; prints ms/step min / median per configuration.  LIB = path of a libtsdiff_hip.so variant
-(tools/build_variant.sh) or `default`; suffixes: `:tail0` runs the step tail as three launches, `:typed0` the generic embedding kernel, `:f32` the fp32-input MFMA forward."""
+(tools/build_variant.sh) or `default`; suffixes: `:tail0` runs the step tail as three launches, `:typed0` the generic embedding kernel, `:f32` the fp32-input MFMA forward, `:fused0` / `:fused1` without / always with the fused per-unit encoder."""
 import os
 import subprocess
 import sys
@@ -27,6 +27,10 @@ def child(workload, steps, lib, flags):
         engine.OPTIONS.one_launch = False  # the split-f16 forward as one launch per block
     if "f32" in flags:
         engine.OPTIONS.gemm = "f32"  # fp32-input MFMA instead of the split-f16 forward
+    if "fused0" in flags:
+        engine.OPTIONS.fused_encoder = False  # materialised filters (one launch per block) where the fused encoder applies
+    if "fused1" in flags:
+        engine.OPTIONS.fused_encoder = "force"  # the fused per-unit encoder also where the one-launch form applies
     from bench import SamplingRun, make_models, to_dev
     from tsdiff_amd.sampler import EnsembleSampler
     dev = torch.device("cuda:0")

@@ -18,6 +18,7 @@ TSD_ERR_NAN = -4
 EDGE_TILE = 32
 EDGE_PAD = 8  # TSD_EDGE_PAD: spare entries every tsd_edges array carries past its capacity
 MAX_GRAPH_NODES = 255
+UNIT_MAX_NODES = 64  # TSD_UNIT_MAX_NODES
 STEP_COEFS = 8
 STATUS_NAN = 1
 STATUS_BAD_BOND = 2
@@ -107,6 +108,9 @@ class Batch(C.Structure):
         ("weights16", C.c_void_p),          # appended in 0.4: f16-plane arenas of the split-f16 forward, range word
         ("bucket_weights16", C.c_void_p),
         ("status", C.c_void_p),
+        ("unit_node", C.c_void_p),          # appended in 0.5: unit partition of the fused per-unit encoder
+        ("num_units", C.c_int32),
+        ("reserved2", C.c_int32),
     ]
 
 
@@ -209,6 +213,8 @@ SIGNATURES = {
     "tsd_bucket_weights_floats": (C.c_size_t, [_CFG, C.c_int32]),
     "tsd_bucket_weights_build": (C.c_int, [_CFG, _P, C.c_int32, _P, _P, _P]),
     "tsd_forward_blocks": (C.c_int, [_CFG, C.POINTER(Batch), C.c_int32, _P]),
+    "tsd_forward_encoder": (C.c_int, [_CFG, C.POINTER(Batch), C.c_int32, C.c_int32, _P]),
+    "tsd_forward_workspace_layout": (C.c_int, [_CFG, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "tsd_pack_weights16": (C.c_int, [_CFG, _P, _P, _P]),
     "tsd_bucket_weights16": (C.c_int, [_CFG, _P, C.c_int32, _P, _P]),
 }

@@ -229,7 +229,15 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     }
     const bool h2 = prec.mode == PREC_H2;
     const float* W = h2 ? b.weights16 : b.weights;
-    const bool mega = h2 && mega_shape(c, N, P, M) && prec.range_status != nullptr && P > 0 && !(b.reserved & 1);
+    // The fused per-unit encoder (kernels_unit.hip: all L blocks in one launch, the CFConv filters never written to memory)
+    // where a launch fills the chip -- ensembles, batches past the one-launch form's size -- and the batch carries its
+    // unit partition (every graph <= TSD_UNIT_MAX_NODES atoms); tsd_batch.reserved bit 2 switches it off, bit 4 asks for
+    // it also where the one-launch form would apply (tests, A/B).  Same bits as the materialising forms.
+    const bool fused_ok = h2 && unit_encoder_supported(c) && b.unit_node != nullptr && b.num_units > 0 && P > 0 &&
+                          !(b.reserved & 4);
+    const bool mega_ok = h2 && mega_shape(c, N, P, M) && prec.range_status != nullptr && P > 0 && !(b.reserved & 1);
+    const bool fused = fused_ok && (!mega_ok || (b.reserved & 16));
+    const bool mega = mega_ok && !fused;
     UmapRole um{};
     um.g = g;
     um.graph_ptr = b.graph_ptr;
@@ -263,7 +271,7 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     // static type-sorted tiles (one GEMM per embedded edge instead of three) when the batch carries them
     // ... and with the typed embedding's small LDS tile also at configs[4] sizes (42.90 -> 42.54 ms/step; the 8-checkpoint
     // ensemble at batch 100 in between loses 0.4 %: not there)
-    const bool fuse_block0 = small_fwd || mega || (typed && (long)node_tiles_all * M >= 2048);
+    const bool fuse_block0 = !fused && (small_fwd || mega || (typed && (long)node_tiles_all * M >= 2048));
     if (typed) {
         if ((r = launch_typed_embed(c, W, b, pos, w.ea, M, w.stride_ea, st, &um, fuse_block0 ? &f0 : nullptr, prec))) return r;
     } else if ((r = launch_edge_embed2(c, W, PU, g.enc_u, w.ea, PU, g.diff_u, w.ea + (size_t)PU * H, M, w.stride_ea, st,
@@ -279,6 +287,13 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
         }
         return launch_forward_mega(c, b, pos, W, w.ea, w.wf, w.h, w.x1m, w.stride_nh, w.ctl, epoch_src, epoch_bias,
                                    prec.range_status, st);
+    }
+    if (fused) {
+        // embedding launch (attribute rows) -> the whole encoder as one launch -> pair MLP launch
+        if ((r = launch_unit_encoder(c, b, W, w.ea, w.stride_ea, w.h, w.stride_nh, 0, L, nullptr, prec.range_status, st)))
+            return r;
+        return launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u, M, w.stride_nh, w.stride_ea,
+                                  (size_t)PU, st, nullptr, w.stride_pre, nullptr, kFold, prec);
     }
     // block 0 reads z (residual input) and x1_0 = lin1_0(z) straight from the per-batch arrays -- both are
     // pos independent (computed at bind time) -- so no per-step copy of z and no lin1 launch
@@ -400,7 +415,7 @@ using namespace tsd;
 
 extern "C" {
 
-const char* tsd_version(void) { return "tsdiff_hip 0.4 (gfx950; fp32 MFMA, split-f16 MFMA inference forward)"; }
+const char* tsd_version(void) { return "tsdiff_hip 0.5 (gfx950; fp32 MFMA, split-f16 MFMA inference forward, fused per-unit encoder)"; }
 const char* tsd_last_error(void) { return g_err; }
 
 size_t tsd_raw_weight_floats(const tsd_model_cfg* cfg) {
@@ -626,6 +641,25 @@ size_t tsd_forward_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes,
     return carve(*cfg, num_nodes, num_pairs, num_models < 1 ? 1 : num_models, nullptr).total;
 }
 
+int tsd_forward_workspace_layout(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs, int32_t num_models,
+                                 size_t* out) {
+    int r = check_cfg(cfg);
+    if (r) return r;
+    TSD_REQUIRE(out != nullptr && num_nodes >= 0 && num_pairs >= 0, "bad argument");
+    TSD_CAPACITY(*cfg, num_nodes, num_pairs);
+    float* base = reinterpret_cast<float*>(sizeof(float));  // (carve only does pointer arithmetic)
+    const Workspace w = carve(*cfg, num_nodes, num_pairs, num_models < 1 ? 1 : num_models, base);
+    out[0] = (size_t)(w.ea - base);
+    out[1] = (size_t)(w.wf - base);
+    out[2] = (size_t)(w.h - base);
+    out[3] = (size_t)(w.x1 - base);
+    out[4] = (size_t)(w.x1b - base);
+    out[5] = w.stride_nh;
+    out[6] = (size_t)w.wf_slots;
+    out[7] = w.total;
+    return TSD_OK;
+}
+
 int tsd_forward_work(const tsd_model_cfg* cfg, int32_t num_nodes, int64_t enc_edges, int64_t out_edges,
                      int64_t diff_pairs, tsd_work* out) {
     int r = check_cfg(cfg);
@@ -678,6 +712,25 @@ int tsd_forward_blocks(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t
     if (epoch == 1) TSD_HIP(hipMemsetAsync(w.ctl, 0, w.ctl_words * sizeof(int32_t), st));
     return launch_forward_mega(*cfg, b, nullptr, b.weights16, w.ea, w.wf, w.h, w.x1m, w.stride_nh, w.ctl, w.ctl + 32, epoch,
                                b.status, st);
+}
+
+int tsd_forward_encoder(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t l_begin, int32_t l_end, void* stream) {
+    TraceRange range("tsd:forward_encoder");
+    int r = check_cfg(cfg);
+    if (r) return r;
+    if ((r = check_batch(*cfg, batch))) return r;
+    const tsd_batch& b = *batch;
+    const bool typed = kFold && b.enc_tiles.num_tiles > 0 && b.bucket_weights != nullptr;
+    if (!(typed && b.weights16 && b.bucket_weights16 && b.status && unit_encoder_supported(*cfg) && b.unit_node &&
+          b.num_units > 0 && b.num_pairs > 0)) {
+        set_error("tsd_forward_encoder: the batch does not take the fused per-unit encoder");
+        return TSD_ERR_UNSUPPORTED;
+    }
+    TSD_REQUIRE(l_begin >= 0 && l_begin < l_end && l_end <= cfg->num_convs, "blocks [%d, %d) outside [0, %d)", l_begin,
+                l_end, cfg->num_convs);
+    const Workspace w = carve(*cfg, b.num_nodes, b.num_pairs, b.num_models, b.workspace);
+    return launch_unit_encoder(*cfg, b, b.weights16, w.ea, w.stride_ea, w.h, w.stride_nh, l_begin, l_end, w.x1, b.status,
+                               (hipStream_t)stream);
 }
 
 int tsd_ensemble_mean(int32_t num_models, int32_t num_pairs, tsd_edges out, const float* edge_inv_u,

@@ -262,6 +262,8 @@ class DeviceBatch:
         self.edge_inv = None
         self.z = None
         self._z_key = None
+        self.unit_node = None   # unit partition of the fused per-unit encoder (built at bind time: depends on M)
+        self._units_for = None
         self.geo_gen = 0  # bumped whenever the edge lists are rebuilt (saved training contexts check it)
         self.ready_event = None  # set by a build on a side stream (prefetch): consumers wait for it, stream to stream
         self._plans = {}  # (kind, clip, clip_pos) -> tsd_sampler_plan* of the bound checkpoints
@@ -344,6 +346,19 @@ class DeviceBatch:
                                                ptr(self.bucket_weights16[m]), stream_ptr()))
         self.M = M
         self._z_key = key
+        self.build_units(M)
+
+    def build_units(self, M):
+        """the unit partition of the fused per-unit encoder for M bound checkpoints (host knowledge, pos independent)"""
+        if self._units_for == M:
+            return
+        self._units_for = M
+        self.unit_node = None
+        if self.G == 0 or self.max_n > _lib.UNIT_MAX_NODES or self.P == 0:
+            return
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        bounds = partition_units(self.num_nodes_per_graph_host, M, cus)
+        self.unit_node = torch.from_numpy(bounds.astype(np.int32)).to(self.device)
 
     def geo_struct(self):
         return Geometry(enc=self.enc.struct(), out=self.out.struct(), enc_u=self.enc_u.struct(),
@@ -372,7 +387,9 @@ class DeviceBatch:
             bucket_weights=None if self.bucket_weights is None else self.bucket_weights.data_ptr(),
             weights16=self.weights16.data_ptr() if h2 else None,
             bucket_weights16=self.bucket_weights16.data_ptr() if h2 else None,
-            status=self.status.data_ptr())
+            status=self.status.data_ptr(),
+            unit_node=None if self.unit_node is None else self.unit_node.data_ptr(),
+            num_units=0 if self.unit_node is None else int(self.unit_node.numel()) - 1)
 
     def _tiles_struct(self, which):
         t = self.typed
@@ -417,8 +434,9 @@ class DeviceBatch:
     def reserved_flags(self):
         """tsd_batch.reserved (include/tsdiff_hip.h): bit 0 one launch per block, bit 1 narrow filter tiles, bit 2 no
         fused encoder; test bits"""
+        fe = OPTIONS.fused_encoder
         return ((0 if (OPTIONS.one_launch and not self.per_block) else 1) | (0 if OPTIONS.wide_filter_tiles else 2) |
-                (0 if OPTIONS.fused_encoder else 4) | self.test_flags)
+                (0 if fe else 4) | (16 if fe == "force" else 0) | self.test_flags)
 
     def forward_out_edges(self, pos):
         """forward(pos) and the number of directed out edges, in ONE host read (the edge count and the status word).
@@ -548,6 +566,58 @@ class DeviceBatch:
         check(lib.tsd_sampler_plan_run(plan, int(coefs.shape[0]), C.byref(args), 1, C.c_void_p(run_on.cuda_stream)))
         if side is not None:
             cur.wait_stream(side)
+
+
+def partition_units(nodes_per_graph, num_models, num_cus, max_nodes=_lib.UNIT_MAX_NODES):
+    """Node offsets [U + 1] of the units of the fused per-unit encoder (csrc/kernels_unit.hip): consecutive runs of
+    whole graphs, at most `max_nodes` atoms each.  One workgroup owns a unit on a CU of its own, its time is ~ the number
+    of 64-pair filter tiles of the unit, and the U x M workgroups of a launch are dealt to the CUs in order; so the runs
+    are cut at a cap on the pair count, and the cap is the one of a few candidates (1, 2, 3, 4, 6, 8 rounds of
+    workgroups per CU) with the smallest simulated makespan.  Pure host arithmetic on the graph sizes."""
+    n = np.asarray(nodes_per_graph, dtype=np.int64)
+    pairs = n * (n - 1) // 2
+    G = int(n.shape[0])
+    total = int(pairs.sum())
+
+    def cut(cap):
+        bounds, atoms, acc = [0], 0, 0
+        node = 0
+        for g in range(G):
+            if atoms > 0 and (atoms + n[g] > max_nodes or acc + pairs[g] > cap):
+                bounds.append(node)
+                atoms, acc = 0, 0
+            atoms += int(n[g])
+            acc += int(pairs[g])
+            node += int(n[g])
+        bounds.append(node)
+        return np.asarray(bounds, dtype=np.int64)
+
+    def makespan(bounds):
+        # tiles per unit (+ a node-chain term), workgroups dealt to the least loaded CU in dispatch order
+        first = np.searchsorted(np.cumsum(n), bounds[1:], side="left")  # graphs per unit via node offsets
+        gsum = np.concatenate([[0], np.cumsum(pairs)])
+        gi = np.concatenate([[0], first + 1])
+        gi = np.minimum(gi, G)
+        up = gsum[gi[1:]] - gsum[gi[:-1]]
+        cost = np.ceil(up / 64.0) + 1.0
+        cost = np.tile(cost, num_models)
+        load = np.zeros(num_cus)
+        for c in cost:
+            k = int(np.argmin(load))
+            load[k] += c
+        return float(load.max())
+
+    best = None
+    for rounds in (1, 2, 3, 4, 6, 8):
+        units_wanted = max(1, (num_cus * rounds) // max(num_models, 1))
+        cap = max(int(np.ceil(total / units_wanted)), int(pairs.max()) if G else 1, 1)
+        b = cut(cap)
+        ms = makespan(b) if len(b) - 1 <= 4096 else float(len(b))
+        if best is None or ms < best[0] - 1e-9:
+            best = (ms, b)
+        if len(b) - 1 >= G:
+            break
+    return best[1]
 
 
 def eq_transform(score_d, pos, edge_index, edge_length):
