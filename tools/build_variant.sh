@@ -10,7 +10,7 @@ SRC=$ROOT/tsdiff_amd/csrc
 OUT=$ROOT/tools/bin/obj_$NAME
 mkdir -p $OUT
 OBJS=""
-for f in api kernels_mlp kernels_combo kernels_graph kernels_misc kernels_typed kernels_train train_step; do
+for f in api kernels_mlp kernels_combo kernels_unit kernels_graph kernels_misc kernels_typed kernels_train train_step; do
   if echo " $TUS " | grep -q " $f.hip "; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=on $FLAGS -c $SRC/$f.hip -o $OUT/$f.o &
     OBJS="$OBJS $OUT/$f.o"

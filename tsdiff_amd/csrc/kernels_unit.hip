@@ -23,10 +23,9 @@
 // size), the node chain runs node_role_h's 16-row MFMAs on four row blocks.  So the encoder's h is BIT-IDENTICAL to the
 // launch-per-block and one-launch split-f16 forwards (tests/test_gpu_round4.py asserts torch.equal).
 //
-// Row ownership in the accumulation: wave w = (column half w >> 2, row class w & 3) holds agg[rows = class + 4 k][its 128
-// columns, 2 per lane].  A tile's pairs that touch row r are found by ONE ballot over the lanes' (i, j) (lane p holds
-// pair p), and walked in ascending p, four at a time (their eight 8-byte LDS reads in flight together; the adds stay in
-// order).  No dynamic register index, no atomics.
+// Row ownership in the accumulation: wave w holds agg of the rows r with r % 8 == w (4 columns per lane, agg[r / 8]: a
+// uniform dynamic index into eight 4-vectors, s_set_gpr_idx moves).  No atomics; the two tile forms are described at
+// `blk` in the kernel.
 #include "common.hpp"
 
 namespace tsd {
@@ -34,11 +33,12 @@ namespace tsd {
 constexpr int UT = 64;         // undirected pairs per filter tile (two 32-row MFMA blocks)
 constexpr int UNA = 64;        // atoms per unit (TSD_UNIT_MAX_NODES)
 constexpr int UE_MAX = 2016;   // undirected pairs per unit: one complete 64-atom graph
-constexpr int UE_PAD = 2048;
+constexpr int U_ROWS = 36 * 64;  // tile rows of a unit: 31.5 list tiles, or 36 block tiles (8 blocks: 8 * 9 / 2)
 
 struct UnitArgs {
     int L, N, num_units;
     const int32_t* unit_node;  // [num_units + 1] node offsets
+    const int32_t *node_graph, *pair_ptr, *pair2u;  // topology / geometry tables (block mode: tile row -> pair of the list)
     tsd_edges eu;              // undirected encoder list (row_ptr, src, dst, dist)
     const float* W;            // f16-plane weight arena of checkpoint 0 (checkpoint m at + m * w_stride)
     size_t w_stride;
@@ -59,7 +59,7 @@ struct UnitArgs {
 // sequence per output element)
 template <int RB16, int CB, int K>
 __device__ __forceinline__ void hgemm16_ring_run_rb(HRing<CB, HRING16_R>& r, const Planes& A, int ldh, f32x4 (&accm)[RB16][CB],
-                                                    f32x4 (&accx)[RB16][CB]) {
+                                                    f32x4 (&accx)[RB16][CB], int nrb /* row blocks that hold rows (uniform) */) {
     constexpr int R = HRING16_R, KS = K / 32;
     const int lane = threadIdx.x & 63;
     const int aoff = (lane & 15) * ldh + (lane >> 4) * 8;
@@ -69,18 +69,21 @@ __device__ __forceinline__ void hgemm16_ring_run_rb(HRing<CB, HRING16_R>& r, con
         constexpr int younger = ((ks + R <= KS) ? R : KS - ks) - 1;
         f32x4 ah[RB16], al[RB16];
 #pragma unroll
-        for (int rb = 0; rb < RB16; ++rb) {
-            ah[rb] = *reinterpret_cast<const f32x4*>(A.hi + aoff + rb * 16 * ldh + ks * 32);
-            al[rb] = *reinterpret_cast<const f32x4*>(A.lo + aoff + rb * 16 * ldh + ks * 32);
-        }
+        for (int rb = 0; rb < RB16; ++rb)
+            if (rb < nrb) {
+                ah[rb] = *reinterpret_cast<const f32x4*>(A.hi + aoff + rb * 16 * ldh + ks * 32);
+                al[rb] = *reinterpret_cast<const f32x4*>(A.lo + aoff + rb * 16 * ldh + ks * 32);
+            }
         hring_wait<younger * CB * 2, CB>(r.b[slot]);
 #pragma unroll
         for (int rb = 0; rb < RB16; ++rb)
+            if (rb < nrb) {
 #pragma unroll
-            for (int cb = 0; cb < CB; ++cb) {
-                accx[rb][cb] = mfma_h16(ah[rb], r.b[slot][cb][1], accx[rb][cb]);
-                accm[rb][cb] = mfma_h16(ah[rb], r.b[slot][cb][0], accm[rb][cb]);
-                accx[rb][cb] = mfma_h16(al[rb], r.b[slot][cb][0], accx[rb][cb]);
+                for (int cb = 0; cb < CB; ++cb) {
+                    accx[rb][cb] = mfma_h16(ah[rb], r.b[slot][cb][1], accx[rb][cb]);
+                    accm[rb][cb] = mfma_h16(ah[rb], r.b[slot][cb][0], accm[rb][cb]);
+                    accx[rb][cb] = mfma_h16(al[rb], r.b[slot][cb][0], accx[rb][cb]);
+                }
             }
         if constexpr (ks + R < KS)
             hring_issue<CB>(r.b[slot], r.base + (size_t)(ks + R) * r.step_bytes, r.voff, r.plane_bytes, r.cb_bytes);
@@ -88,6 +91,26 @@ __device__ __forceinline__ void hgemm16_ring_run_rb(HRing<CB, HRING16_R>& r, con
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Phase trace (variant builds only: tools/build_variant.sh utrace "-DTSD_UNIT_TRACE" kernels_unit.hip; tools/trace_unit.py):
+// per workgroup the shader-clock cycles wave 0 spent in each phase, summed over tiles and blocks.
+// slots: 0 convert, 1 GEMM nn.0, 2 ssp, 3 GEMM nn.2 (+ prefetch issue), 4 filter tile -> LDS, 5 accumulate, 6 node chain,
+// 7 staging, 8 tiles x blocks, 9 total
+#ifdef TSD_UNIT_TRACE
+__device__ unsigned long long g_unit_trace[4096 * 16];
+extern "C" int tsd_debug_unit_trace(void* host_buf) {
+    return (int)hipMemcpyFromSymbol(host_buf, HIP_SYMBOL(g_unit_trace), sizeof(g_unit_trace));
+}
+#define UTRACE_DECL unsigned long long ut_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ut_t = __builtin_amdgcn_s_memtime(); const unsigned long long ut_t0 = ut_t;
+#define UTRACE(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ut_acc[slot] += n_ - ut_t; ut_t = n_; } while (0)
+#define UTRACE_COUNT(slot) do { ut_acc[slot] += 1; } while (0)
+#define UTRACE_FLUSH do { ut_acc[9] = __builtin_amdgcn_s_memtime() - ut_t0; if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) { for (int i_ = 0; i_ < 10; ++i_) g_unit_trace[(size_t)blockIdx.x * 16 + i_] = ut_acc[i_]; } } while (0)
+#else
+#define UTRACE_DECL
+#define UTRACE(slot)
+#define UTRACE_COUNT(slot)
+#define UTRACE_FLUSH
+#endif
 
 // A copy of a lane value the compiler must treat as new: the address arithmetic that hangs off it is recomputed where
 // it is used (a few VALU instructions per phase) instead of being hoisted out of the block and tile loops as hundreds
@@ -99,15 +122,16 @@ __device__ __forceinline__ int opaque(int x) {
 
 template <int H>
 __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
-    static_assert(H == 256, "the unit encoder is built for hidden 256 (8 waves: 2 column halves x 4 row classes)");
+    static_assert(H == 256, "the unit encoder is built for hidden 256 (8 waves)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int LDH = ldh_of(H), LDA = H + 4, NT = 2 * H, C4 = H / 4;
     constexpr int NIT = UT * C4 / NT;  // float4 loads per thread and attribute tile (8)
     constexpr int RB16 = UNA / 16, CB16 = 2;
     float* x1s = smem;                               // [UNA][H] fp32
     float* tile = x1s + UNA * H;                     // planes (UT x LDH floats) / fp32 filter tile [UT][LDA]
-    float* s_c = tile + UT * LDH;                    // [UE_PAD] cutoff weights of the unit's pairs
-    uint16_t* s_ij = reinterpret_cast<uint16_t*>(s_c + UE_PAD);  // [UE_PAD] local (i | j << 8)
+    float* s_c = tile + UT * LDH;                    // [U_ROWS] cutoff weight per tile row (list mode: row = local pair index)
+    uint16_t* s_u = reinterpret_cast<uint16_t*>(s_c + U_ROWS);  // [U_ROWS] list mode: local (i | j << 8) of the pair;
+                                                                // block mode: local pair index of the tile row, 0xffff: none
     const Planes pl = planes_at(tile, UT, LDH);
     float* buf = tile;
 
@@ -125,21 +149,58 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
     const float* ea = A.ea + m * A.ea_stride + (size_t)e0 * H;
     float* hm = A.h + m * A.nh_stride;
     float amax = 0.0f;
+    UTRACE_DECL
 
-    // ---- per-unit staging: cutoff weights and local end points of the pairs, x1 of block l_begin ----
-    for (int e = tid; e < ne; e += NT) {
-        s_c[e] = cutoff_weight(A.eu.dist[e0 + e], A.conv_cutoff, A.smooth);
-        s_ij[e] = (uint16_t)((A.eu.src[e0 + e] - n0) | ((A.eu.dst[e0 + e] - n0) << 8));
+    // BLOCK MODE (a unit that is ONE graph of more than 32 atoms): tiles are 8 x 8 blocks (I, J), I <= J, of the atom-pair
+    // matrix in the order (0,0) (0,1) .. (0,nb-1) (1,1) .. -- row a * 8 + b of a tile is the pair (I*8 + a, J*8 + b), a pair
+    // that is no edge (i >= j on the diagonal, beyond the cutoff, past the graph) is a zero row with cutoff weight 0, so
+    // its messages are +-0 and change nothing.  Every row of agg still meets its partners in ascending order (blocks
+    // 0 .. K-1 as the J side of tiles (I, K), then the diagonal, then the I side of (K, J)): the same bits as list order.
+    // What it buys: a tile's 128 messages are 16 per wave at fixed LDS addresses (wave w adds the 8 partners of row
+    // J*8 + w, then of row I*8 + w), where a list tile of a dense graph is one 64-long dependent chain on one row.
+    // LIST MODE (everything else): tiles of 64 consecutive pairs of the unit's slice of the undirected list.
+    const bool blk = na > 32 && A.node_graph[n0] == A.node_graph[n1 - 1];
+    const int nb = (na + 7) >> 3;
+    const int ntile = blk ? nb * (nb + 1) / 2 : (ne + UT - 1) / UT;
+
+    // ---- per-unit staging: cutoff weights and end points / pair indices of the tile rows, x1 of block l_begin ----
+    if (blk) {
+        const int gpair = A.pair_ptr[n0];  // (ordered pair k of atom i: the k-th OTHER atom of the graph)
+        for (int idx = tid; idx < ntile * UT; idx += NT) {
+            int tt = idx >> 6, I = 0;
+            while (tt >= nb - I) {
+                tt -= nb - I;
+                ++I;
+            }
+            const int J = I + tt, pr = idx & 63;
+            const int i = I * 8 + (pr >> 3), j = J * 8 + (pr & 7);
+            int loc = -1;
+            if (i < j && j < na) {
+                const int uu = A.pair2u[A.pair_ptr[n0 + i] + j - 1];
+                (void)gpair;
+                if (uu >= e0 && uu < e1) loc = uu - e0;
+            }
+            s_u[idx] = (uint16_t)(loc < 0 ? 0xffff : loc);
+            s_c[idx] = loc < 0 ? 0.0f : cutoff_weight(A.eu.dist[e0 + loc], A.conv_cutoff, A.smooth);
+        }
+    } else {
+        for (int e = tid; e < ne; e += NT) {
+            s_c[e] = cutoff_weight(A.eu.dist[e0 + e], A.conv_cutoff, A.smooth);
+            s_u[e] = (uint16_t)((A.eu.src[e0 + e] - n0) | ((A.eu.dst[e0 + e] - n0) << 8));
+        }
     }
     {
         const float* x_in = (A.l_begin == 0 ? A.x1_0 : A.x1_io) + m * A.nh_stride + (size_t)n0 * H;
-        for (int idx = tid; idx < na * C4; idx += NT)
-            *reinterpret_cast<f32x4*>(x1s + idx * 4) = *reinterpret_cast<const f32x4*>(x_in + idx * 4);
+        const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
+        for (int idx = tid; idx < UNA * C4; idx += NT)  // (rows past the unit: zeros -- block mode multiplies them by +-0)
+            *reinterpret_cast<f32x4*>(x1s + idx * 4) = idx < na * C4 ? *reinterpret_cast<const f32x4*>(x_in + idx * 4) : zz;
     }
-    const int ntile = (ne + UT - 1) / UT;
+    __syncthreads();
+    const int nrb = (na + 15) >> 4;  // 16-row blocks of the node chain that hold atoms
 
-    // accumulation geometry of a wave: 128 columns (2 per lane), rows = class + 4 k;  GEMM geometry: 32 output columns
-    // per wave (every phase derives its lane geometry from an opaque copy of the thread index: see opaque())
+    // accumulation geometry of a wave -- list mode: 128 columns (2 per lane), rows = class + 4 k; block mode: row w of
+    // every 8-atom block, 4 columns per lane;  GEMM geometry: 32 output columns per wave (every phase derives its lane
+    // geometry from an opaque copy of the thread index: see opaque())
 #define TSD_UNIT_GEOM                                                         \
     const int tq = opaque(tid);                                               \
     const int wave = tq >> 6, lane = tq & 63;                                 \
@@ -152,35 +213,61 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
     for (int l = A.l_begin; l < A.l_end; ++l) {
         const float* Wl = Wm + A.layer0 + (size_t)l * A.layer_stride;
         const float *nn0_w = Wl + A.o_nn0_w, *nn2_w = Wl + A.o_nn2_w;
-        f32x2 agg[16];
+        // agg of the unit's atoms, 32 registers per lane: agg[k < 8] = row k * 8 + wave, columns 4 lane .. + 3
+        // (one array of eight 4-vectors in both modes: a whole-vector access with a uniform dynamic index compiles to
+        // s_set_gpr_idx moves; a float[32] with scalar dynamic indices went to scratch memory)
+        f32x4 agg[8];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) agg[k] = f32x2{0.0f, 0.0f};
-        f32x4 v[NIT];  // the attribute rows of the next tile (row = wave + 8 it, one 1-KiB row per wave-load)
+        for (int k = 0; k < 8; ++k) agg[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float b0, b2;  // (loaded here, not in the tile loop: a global load there waits behind the prefetch in vmcnt order)
+        {
+            TSD_UNIT_GEOM
+            b0 = Wl[A.o_nn0_b + col];
+            b2 = Wl[A.o_nn2_b + col];
+        }
+        f32x4 v[NIT];  // the attribute rows of the next tile (tile row = wave + 8 it, one 1-KiB row per wave-load)
+        unsigned vlive = 0;  // bit it: row `it` of v is a pair (else the tile row is zeros)
         auto fetch = [&](int t) {
             TSD_UNIT_GEOM
-            const int nr = min(UT, ne - t * UT);
+            vlive = 0;
+            if (blk) {
+                unsigned uu[NIT];
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int r = wave + it * (NT / 64);
-                v[it] = *reinterpret_cast<const f32x4*>(ea + (size_t)(t * UT + min(r, nr - 1)) * H + lane * 4);
+                for (int it = 0; it < NIT; ++it) uu[it] = s_u[t * UT + wave + it * (NT / 64)];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    vlive |= (uu[it] != 0xffffu ? 1u : 0u) << it;
+                    v[it] = *reinterpret_cast<const f32x4*>(ea + (size_t)(uu[it] == 0xffffu ? 0u : uu[it]) * H + lane * 4);
+                }
+            } else {
+                const int nr = min(UT, ne - t * UT);
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int r = wave + it * (NT / 64);
+                    vlive |= (r < nr ? 1u : 0u) << it;
+                    v[it] = *reinterpret_cast<const f32x4*>(ea + (size_t)(t * UT + min(r, nr - 1)) * H + lane * 4);
+                }
             }
         };
         if (ntile > 0) fetch(0);
+        UTRACE(7);
+        int tI = 0, tJ = 0;  // block mode: the tile's blocks (uniform counters)
         for (int t = 0; t < ntile; ++t) {
-            const int nrows = min(UT, ne - t * UT);
+            const int nrows = blk ? UT : min(UT, ne - t * UT);
             HRing<1, HRING_R> rg;
             f32x16 accm[2][1], accx[2][1];
-            {   // (a) attribute tile -> planes (rows past the end: zeros)
+            {   // (a) attribute tile -> planes (rows that are no pair: zeros)
                 TSD_UNIT_GEOM
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int r = wave + it * (NT / 64);
                     const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
-                    planes_store4(pl, r * LDH + lane * 4, r < nrows ? v[it] : zz, amax);
+                    planes_store4(pl, r * LDH + lane * 4, (vlive >> it & 1u) ? v[it] : zz, amax);
                 }
                 hgemm_ring_start<1, H>(rg, nn0_w, H, col0);
             }
             __syncthreads();
+            UTRACE(0);
             {   // (b) GEMM nn.0
                 TSD_UNIT_GEOM
                 hzero(accm, accx);
@@ -188,47 +275,105 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
                 hgemm_ring_start<1, H>(rg, nn2_w, H, col0);
             }
             __syncthreads();
-            {   // (c) shifted softplus -> planes
-                TSD_UNIT_GEOM
-                const float b0 = Wl[A.o_nn0_b + col];
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        planes_store1(pl, (rb * 32 + acc_row(r, hi)) * LDH + col, sspf(hval(accm[rb][0], accx[rb][0], r) + b0), amax);
-            }
-            __syncthreads();
-            {   // (d) GEMM nn.2
-                hzero(accm, accx);
-                hgemm_ring_run<2, 1, H>(rg, pl, LDH, accm, accx);
-            }
-            // (e) the next tile's attribute rows: in flight under the epilogue and the accumulation
+            UTRACE(1);
+            // (e) the NEXT tile's attribute rows are requested here: the loads are issued under the VALU work of the
+            // epilogue (64 KB through the CU's address path is ~1000 cycles of issue) and have the whole epilogue to come
+            // back in -- they are older than every refill of GEMM nn.2's weight ring, whose counted waits (in-order
+            // return) would otherwise stall on an HBM round trip; the ring's first three k-steps were issued before them
             if (t + 1 < ntile) fetch(t + 1);
-            __syncthreads();
-            {   // (f) W = (nn.2 + b) * C as fp32 rows over the planes
+            {   // (c) shifted softplus -> planes (one base per plane, the 32 rows of a lane at constant offsets from it)
                 TSD_UNIT_GEOM
-                const float b2 = Wl[A.o_nn2_b + col];
+                f16* hb = pl.hi + opaque(4 * hi * LDH + col);
+                f16* lb = pl.lo + opaque(4 * hi * LDH + col);
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int row = rb * 32 + acc_row(r, hi);
-                        buf[row * LDA + col] = (hval(accm[rb][0], accx[rb][0], r) + b2) * s_c[min(t * UT + row, UE_PAD - 1)];
+                        const float y = sspf(hval(accm[rb][0], accx[rb][0], r) + b0);
+                        f16 yh, yl;
+                        amax_upd(amax, y);
+                        split1(y, yh, yl);
+                        hb[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = yh;
+                        lb[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = yl;
                     }
             }
             __syncthreads();
-            {   // (g) messages of both end points into agg, pairs in list order per row
+            UTRACE(2);
+            {   // (d) GEMM nn.2
+                hzero(accm, accx);
+                hgemm_ring_run<2, 1, H>(rg, pl, LDH, accm, accx);
+            }
+            __syncthreads();
+            UTRACE(3);
+            {   // (f) W = (nn.2 + b) * C as fp32 rows over the planes (the cutoff weights of four consecutive rows by one
+                // 16-byte LDS read, all of a row block's up front: stores to `buf` and loads of `s_c` would otherwise be
+                // kept in program order, one LDS round trip per element)
                 TSD_UNIT_GEOM
-                const unsigned ijv = lane < nrows ? (unsigned)s_ij[t * UT + lane] : 0xffffu;
+                float* wb = buf + opaque(4 * hi * LDA + col);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    f32x4 cw[4];
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) cw[g4] = *reinterpret_cast<const f32x4*>(s_c + t * UT + rb * 32 + 8 * g4 + 4 * hi);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        wb[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LDA] = (hval(accm[rb][0], accx[rb][0], r) + b2) * cw[r >> 2][r & 3];
+                }
+            }
+            __syncthreads();
+            UTRACE(4);
+            if (blk) {   // (g) block mode: wave w adds the 8 partners of row J*8 + w (J side), then of row I*8 + w (I side)
+                TSD_UNIT_GEOM
+                const float* wrow = buf + lane * 4;
+                const float* xrow = x1s + lane * 4;
+                f32x4 wv[8], xv[8];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    wv[a] = *reinterpret_cast<const f32x4*>(wrow + (a * 8 + wave) * LDA);
+                    xv[a] = *reinterpret_cast<const f32x4*>(xrow + (tI * 8 + a) * H);
+                }
+                {
+                    f32x4 a4 = agg[tJ];
+#pragma unroll
+                    for (int a = 0; a < 8; ++a)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) a4[s] = __fadd_rn(a4[s], __fmul_rn(xv[a][s], wv[a][s]));
+                    agg[tJ] = a4;
+                }
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    wv[b] = *reinterpret_cast<const f32x4*>(wrow + (wave * 8 + b) * LDA);
+                    xv[b] = *reinterpret_cast<const f32x4*>(xrow + (tJ * 8 + b) * H);
+                }
+                {
+                    f32x4 a4 = agg[tI];
+#pragma unroll
+                    for (int b = 0; b < 8; ++b)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) a4[s] = __fadd_rn(a4[s], __fmul_rn(xv[b][s], wv[b][s]));
+                    agg[tI] = a4;
+                }
+                if (++tJ == nb) {
+                    ++tI;
+                    tJ = tI;
+                }
+            } else {   // (g) list mode: wave w owns the rows r with r % 8 == w (agg[r / 8], 4 columns per lane).  A row's
+                // partners below it come from pairs (i, r) -- the row is the pair's j -- and precede, in list order, its
+                // partners above it, pairs (r, j): the wave walks its j-side pairs of the tile in ascending order, then
+                // its i-side pairs -- every row meets its partners in ascending order.  Four pairs per round: their
+                // eight 16-byte LDS reads are in flight together, the adds stay in order.
+                TSD_UNIT_GEOM
+                const unsigned ijv = lane < nrows ? (unsigned)s_u[t * UT + lane] : 0xffffu;
                 const int iv = (int)(ijv & 255u), jv = (int)(ijv >> 8);
-                const float* bufc = buf + acol;
-                const float* x1c = x1s + acol;
-                static_for<0, 16>([&](auto kc) {
-                    constexpr int k = decltype(kc)::value;
-                    const int r = cls + 4 * k;
-                    unsigned long long msk = __ballot(iv == r || jv == r);
+                const float* wrow = buf + lane * 4;
+                const float* xrow = x1s + lane * 4;
+                const int wq = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const int rowv = side == 0 ? jv : iv, othv = side == 0 ? iv : jv;
+                    unsigned long long msk = __ballot(lane < nrows && (rowv & 7) == wq);
                     while (msk) {
-                        int p[4];
+                        int p[4], row[4], oth[4];
                         bool ok[4];
                         p[0] = (int)__builtin_ctzll(msk);
                         ok[0] = true;
@@ -239,27 +384,31 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
                             p[s] = ok[s] ? (int)__builtin_ctzll(msk) : p[s - 1];  // (a slot past the end re-reads the last pair)
                             if (ok[s]) msk &= msk - 1ull;
                         }
-                        f32x2 wv[4], xv[4];
+                        f32x4 wv[4], xv[4];
 #pragma unroll
                         for (int s = 0; s < 4; ++s) {
-                            const int ip = __builtin_amdgcn_readlane(iv, p[s]), jp = __builtin_amdgcn_readlane(jv, p[s]);
-                            const int other = ip == r ? jp : ip;
-                            wv[s] = *reinterpret_cast<const f32x2*>(bufc + p[s] * LDA);
-                            xv[s] = *reinterpret_cast<const f32x2*>(x1c + other * H);
+                            row[s] = __builtin_amdgcn_readlane(rowv, p[s]);
+                            oth[s] = __builtin_amdgcn_readlane(othv, p[s]);
+                            wv[s] = *reinterpret_cast<const f32x4*>(wrow + p[s] * LDA);
+                            xv[s] = *reinterpret_cast<const f32x4*>(xrow + oth[s] * H);
                         }
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
                             if (ok[s]) {
-                                agg[k][0] = __fadd_rn(agg[k][0], __fmul_rn(xv[s][0], wv[s][0]));
-                                agg[k][1] = __fadd_rn(agg[k][1], __fmul_rn(xv[s][1], wv[s][1]));
+                                f32x4 a4 = agg[row[s] >> 3];
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) a4[c] = __fadd_rn(a4[c], __fmul_rn(xv[s][c], wv[s][c]));
+                                agg[row[s] >> 3] = a4;
                             }
                     }
-                });
+                }
             }
             __syncthreads();  // (every wave is done with the fp32 tile: the next tile's planes go over it)
+            UTRACE(5);
+            UTRACE_COUNT(8);
         }
 
-        // ---- node chain of block l on the unit's rows (node_role_h's arithmetic on four 16-row blocks) ----
+        // ---- node chain of block l on the unit's rows (node_role_h's arithmetic on up to four 16-row blocks) ----
         const bool last = l + 1 == A.L;
         HRing<CB16, HRING16_R> rn;
         f32x4 am[RB16][CB16], ax[RB16][CB16];
@@ -273,14 +422,14 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
         {
             TSD_UNIT_GEOM
 #pragma unroll
-            for (int k = 0; k < 16; ++k) planes_store2(pl, (cls + 4 * k) * LDH + acol, agg[k][0], agg[k][1], amax);
+            for (int k = 0; k < 8; ++k) planes_store4(pl, (k * 8 + wave) * LDH + lane * 4, agg[k], amax);
             hgemm16_ring_start<CB16, H>(rn, Wl + A.o_lin2_w, H, col0);
         }
         __syncthreads();
         {
             TSD_UNIT_GEOM
             zero_n();
-            hgemm16_ring_run_rb<RB16, CB16, H>(rn, pl, LDH, am, ax);
+            hgemm16_ring_run_rb<RB16, CB16, H>(rn, pl, LDH, am, ax, nrb);
             hgemm16_ring_start<CB16, H>(rn, Wl + A.o_lin_w, H, col0);
         }
         __syncthreads();
@@ -291,17 +440,19 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
                 const float b = Wl[A.o_lin2_b + col0 + cb * 16 + l15];
 #pragma unroll
                 for (int rb = 0; rb < RB16; ++rb)
+                    if (rb < nrb) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        planes_store1(pl, (rb * 16 + q * 4 + r) * LDH + col0 + cb * 16 + l15,
-                                      sspf(hval4(am[rb][cb], ax[rb][cb], r) + b), amax);
+                        for (int r = 0; r < 4; ++r)
+                            planes_store1(pl, (rb * 16 + q * 4 + r) * LDH + col0 + cb * 16 + l15,
+                                          sspf(hval4(am[rb][cb], ax[rb][cb], r) + b), amax);
+                    }
             }
         }
         __syncthreads();
         {
             TSD_UNIT_GEOM
             zero_n();
-            hgemm16_ring_run_rb<RB16, CB16, H>(rn, pl, LDH, am, ax);
+            hgemm16_ring_run_rb<RB16, CB16, H>(rn, pl, LDH, am, ax, nrb);
             if (!last) hgemm16_ring_start<CB16, H>(rn, Wl + A.layer_stride + A.o_lin1, H, col0);
         }
         __syncthreads();
@@ -314,36 +465,44 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
                 const float b = Wl[A.o_lin_b + c];
 #pragma unroll
                 for (int rb = 0; rb < RB16; ++rb)
+                    if (rb < nrb) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = rb * 16 + q * 4 + r;
-                        float hn = 0.0f;
-                        if (row < na) {
-                            hn = h_in[(size_t)row * H + c] + (hval4(am[rb][cb], ax[rb][cb], r) + b);
-                            hm[(size_t)(n0 + row) * H + c] = hn;
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = rb * 16 + q * 4 + r;
+                            float hn = 0.0f;
+                            if (row < na) {
+                                hn = h_in[(size_t)row * H + c] + (hval4(am[rb][cb], ax[rb][cb], r) + b);
+                                hm[(size_t)(n0 + row) * H + c] = hn;
+                            }
+                            if (!last) planes_store1(pl, row * LDH + c, hn, amax);
                         }
-                        if (!last) planes_store1(pl, row * LDH + c, hn, amax);
                     }
             }
         }
-        if (last) break;
+        if (last) {
+            UTRACE(6);
+            break;
+        }
         // (the stores of h are younger than the ring of lin1 issued above: they only make its counted waits conservative)
         __syncthreads();
         {
             TSD_UNIT_GEOM
             zero_n();
-            hgemm16_ring_run_rb<RB16, CB16, H>(rn, pl, LDH, am, ax);
+            hgemm16_ring_run_rb<RB16, CB16, H>(rn, pl, LDH, am, ax, nrb);
             // x1 of the next block: straight into the LDS copy (every wave is past its reads of the old x1: the
-            // barriers of the node chain lie between)
+            // barriers of the node chain lie between); row blocks without atoms keep their zeros
 #pragma unroll
             for (int rb = 0; rb < RB16; ++rb)
+                if (rb < nrb) {
 #pragma unroll
-                for (int cb = 0; cb < CB16; ++cb)
+                    for (int cb = 0; cb < CB16; ++cb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        x1s[(rb * 16 + q * 4 + r) * H + col0 + cb * 16 + l15] = hval4(am[rb][cb], ax[rb][cb], r);
+                        for (int r = 0; r < 4; ++r)
+                            x1s[(rb * 16 + q * 4 + r) * H + col0 + cb * 16 + l15] = hval4(am[rb][cb], ax[rb][cb], r);
+                }
         }
         __syncthreads();
+        UTRACE(6);
     }
 #undef TSD_UNIT_GEOM
     if (A.l_end < A.L && A.x1_io != nullptr) {  // a partial run hands x1 of block l_end to the next launch
@@ -352,10 +511,11 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
             *reinterpret_cast<f32x4*>(x_out + idx * 4) = *reinterpret_cast<const f32x4*>(x1s + idx * 4);
     }
     range_report(amax, A.status);
+    UTRACE_FLUSH;
 }
 
 size_t unit_encoder_lds(int H) {
-    return ((size_t)UNA * H + (size_t)UT * ldh_of(H) + UE_PAD) * 4 + (size_t)UE_PAD * 2;
+    return ((size_t)UNA * H + (size_t)UT * ldh_of(H) + U_ROWS) * 4 + (size_t)U_ROWS * 2;
 }
 
 bool unit_encoder_supported(const tsd_model_cfg& c) { return c.hidden == 256; }
@@ -372,6 +532,9 @@ int launch_unit_encoder(const tsd_model_cfg& c, const tsd_batch& b, const float*
     A.N = b.num_nodes;
     A.num_units = b.num_units;
     A.unit_node = b.unit_node;
+    A.node_graph = b.node_graph;
+    A.pair_ptr = b.pair_ptr;
+    A.pair2u = b.geo.pair2u;
     A.eu = b.geo.enc_u;
     A.W = W16;
     A.w_stride = WL.total;
