@@ -319,7 +319,10 @@ typedef struct tsd_batch {
                                                knowledge: graphs never interact, so any such partition is valid; the Python
                                                host balances it by pair count).  NULL: no fused encoder */
     int32_t num_units;
-    int32_t reserved2;
+    int32_t reserved2;                      /* flags; bit 0: every unit is ONE graph (host knowledge; true whenever every graph has
+                                               more than TSD_UNIT_MAX_NODES / 2 atoms): the fused encoder then runs its
+                                               ping-pong form (two teams of four waves per workgroup, 8 x 8 atom-block tiles);
+                                               a unit that breaks the promise reports TSD_STATUS_INTERNAL */
 } tsd_batch;
 
 size_t tsd_forward_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs,

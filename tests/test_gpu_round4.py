@@ -128,7 +128,8 @@ def _forms(monkeypatch):
     def set_form(form):
         monkeypatch.setattr(engine.OPTIONS, "gemm", "h2")
         monkeypatch.setattr(engine.OPTIONS, "one_launch", form == "one_launch")
-        monkeypatch.setattr(engine.OPTIONS, "fused_encoder", "force" if form == "fused" else False)
+        monkeypatch.setattr(engine.OPTIONS, "fused_encoder", "force" if form.startswith("fused") else False)
+        monkeypatch.setattr(engine.OPTIONS, "pingpong", form != "fused_nopp")
     return set_form
 
 
@@ -204,14 +205,16 @@ def test_fused_encoder_config_c5_shape_and_partial_runs(dev, monkeypatch):
                                t["p_feat"], t["pos"], t["bond_index"], t["bond_type"], b["num_nodes_per_graph"])
     set_form = _forms(monkeypatch)
     res = {}
-    for form in ("per_block", "fused"):
+    for form in ("per_block", "fused_nopp", "fused"):   # (fused: the ping-pong form -- every unit is one 64-atom graph)
         set_form(form)
         model = make_model(cfg, 1, dev)
         inv, ei, _ = run_forward(model, g, dev)
         assert torch.equal(ei.cpu(), o_ei)
         assert_close(inv.cpu().numpy(), o_inv.numpy(), RTOL, f"edge_inv (C5 shape, {form})")
         res[form] = inv.clone()
+        assert _db(model).units_single_graph
     assert torch.equal(res["fused"], res["per_block"])
+    assert torch.equal(res["fused_nopp"], res["per_block"])
     # the encoder alone, whole and in two parts, on the state the forward left in the workspace
     lib = _lib.load()
     db = _db(model)
@@ -228,3 +231,32 @@ def test_fused_encoder_config_c5_shape_and_partial_runs(dev, monkeypatch):
     _lib.check(lib.tsd_forward_encoder(C.byref(db.cfg), C.byref(bs), 0, 3, _lib.stream_ptr()))
     _lib.check(lib.tsd_forward_encoder(C.byref(db.cfg), C.byref(bs), 3, L, _lib.stream_ptr()))
     assert torch.equal(h_now(), whole) and bool(torch.isfinite(whole).all()) and float(whole.abs().max()) > 0
+
+
+@pytest.mark.parametrize("n,graphs,cut", [(37, 5, 10.0), (50, 3, 10.0), (64, 2, 4.0), (33, 4, 3.0)])
+def test_fused_encoder_block_tiles_on_ragged_and_sparse_graphs(n, graphs, cut, dev, monkeypatch):
+    """the 8 x 8 atom-block tiles of the fused encoder (both forms) on graphs whose atom count is no multiple of 8 and,
+    with a short radius cutoff, on graphs where most atom pairs are NOT edges (zero rows inside the tiles): bit-identical
+    to the launch-per-block form, and against the oracle"""
+    from oracle import tsdiff_oracle as O
+    from tsdiff_amd import synth
+    cfg = dict(synth.DEFAULT_MODEL_CONFIG)
+    cfg["edge_cutoff"] = cut
+    cfg["encoder"] = dict(cfg["encoder"], cutoff=cut)
+    b = synth.dense_stress_batch(graphs, n=n, seed=3)
+    t = {k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}
+    g = to_dev({**t, "num_graphs": graphs}, dev)
+    o_inv, o_ei, _ = O.forward(O.to_torch_state(synth.synth_state_dict(cfg, 2)), cfg, t["atom_type"], t["r_feat"],
+                               t["p_feat"], t["pos"], t["bond_index"], t["bond_type"], b["num_nodes_per_graph"])
+    set_form = _forms(monkeypatch)
+    res = {}
+    for form in ("per_block", "fused_nopp", "fused"):
+        set_form(form)
+        model = make_model(cfg, 2, dev)
+        inv, ei, _ = run_forward(model, g, dev)
+        assert torch.equal(ei.cpu(), o_ei)
+        assert_close(inv.cpu().numpy(), o_inv.numpy(), RTOL, f"edge_inv (n = {n}, cutoff {cut}, {form})")
+        res[form] = inv.clone()
+    if cut < 10.0:
+        assert ei.shape[1] < graphs * n * (n - 1), "the short cutoff was meant to drop pairs"
+    assert torch.equal(res["fused"], res["per_block"]) and torch.equal(res["fused_nopp"], res["per_block"])

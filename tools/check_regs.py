@@ -22,6 +22,7 @@ BUDGET = [
     (r"layer_combo_kernelILi256ELb0ELb[01]ELi1E", 128, 0),  # split-f16 block launches (all filter-tile widths)
     (r"pair_output_h_kernelILi256E", 128, 0),
     (r"unit_encoder_kernelILi256E", 256, 0),
+    (r"unit_encoder_pp_kernelILi256E", 256, 0),
 ]
 
 
@@ -63,8 +64,9 @@ def main(paths):
                       f"{rec.get('sgpr_spill_count', 0)} SGPR spills  {name[:90]}")
                 if not ok:
                     bad += 1
-    missing = [pat for pat, n in seen.items() if n == 0 and not pat.startswith("unit_encoder") or
-               (n == 0 and pat.startswith("unit_encoder") and any("kernels_unit" in p for p in paths))]
+    unit = any("kernels_unit" in p for p in paths)
+    others = any("kernels_combo" in p for p in paths)
+    missing = [pat for pat, n in seen.items() if n == 0 and (unit if pat.startswith("unit_encoder") else others)]
     for pat in missing:
         print(f"check_regs: FAIL no compiled kernel matches {pat!r} (renamed? update tools/check_regs.py)")
     return 1 if bad or missing else 0

@@ -39,6 +39,20 @@ fwd(); torch.cuda.synchronize()
 assert dbg(buf.ctypes.data_as(C.c_void_p)) == 0
 t = buf.astype(np.int64).reshape(-1, 16)
 t = t[t[:, 9] > 0]
+pp = os.environ.get("TSDIFF_PINGPONG", "1") != "0" and workload == "c5"
+if pp:
+    # ping-pong form: rows alternate team 0 / team 1; slots: 0 GEMM nn.0, 1 ssp, 2 GEMM nn.2, 3 filter tile -> LDS, 4 accumulate
+    # (+ fetch), 5 next planes, 6 node chain, 7 idle / waiting for the slot (team skew, barriers of the other team)
+    nm = ["GEMM nn.0 (3 parts)", "ssp epilogue (3 parts)", "GEMM nn.2 (3 parts)", "filter tile -> LDS", "accumulate + fetch",
+          "next planes + ring start", "node chain", "between cycles"]
+    for team in (0, 1):
+        tt = t[team::2]
+        tl = np.maximum(tt[:, 8], 1)
+        print(f"team {team}: {len(tt)} workgroups, total cycles median {np.median(tt[:, 9]):.0f} = {np.median(tt[:, 9]) / clk if False else np.median(tt[:, 9]) / 2400:.1f} us at 2.4 GHz, tiles x blocks {np.median(tt[:, 8]):.0f}")
+        for i, n in enumerate(nm):
+            per = tt[:, i] / (tl if i != 6 else cfg["encoder"]["num_convs"])
+            print(f"  {n:28s} {np.median(per):9.0f} cycles per {'tile' if i != 6 else 'block'}   share {np.median(tt[:, i] / tt[:, 9]):6.1%}")
+    sys.exit(0)
 names = ["convert attr -> planes", "GEMM nn.0", "ssp epilogue", "GEMM nn.2 + prefetch", "filter tile -> LDS", "accumulate", "node chain", "staging"]
 clk = 2.4e3  # cycles per us at 2.4 GHz (nominal; the effective clock is lower under load)
 print(f"{len(t)} workgroups; total cycles per workgroup median {np.median(t[:, 9]):.0f} = {np.median(t[:, 9]) / clk:.1f} us at 2.4 GHz; "

@@ -263,6 +263,7 @@ class DeviceBatch:
         self.z = None
         self._z_key = None
         self.unit_node = None   # unit partition of the fused per-unit encoder (built at bind time: depends on M)
+        self.units_single_graph = False
         self._units_for = None
         self.geo_gen = 0  # bumped whenever the edge lists are rebuilt (saved training contexts check it)
         self.ready_event = None  # set by a build on a side stream (prefetch): consumers wait for it, stream to stream
@@ -359,6 +360,9 @@ class DeviceBatch:
         cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         bounds = partition_units(self.num_nodes_per_graph_host, M, cus)
         self.unit_node = torch.from_numpy(bounds.astype(np.int32)).to(self.device)
+        # every unit one graph (certain when every graph has more than half a unit's atoms): the ping-pong form applies
+        self.units_single_graph = bool(len(bounds) - 1 == self.G and
+                                       int(self.num_nodes_per_graph_host.min()) > _lib.UNIT_MAX_NODES // 2)
 
     def geo_struct(self):
         return Geometry(enc=self.enc.struct(), out=self.out.struct(), enc_u=self.enc_u.struct(),
@@ -389,7 +393,8 @@ class DeviceBatch:
             bucket_weights16=self.bucket_weights16.data_ptr() if h2 else None,
             status=self.status.data_ptr(),
             unit_node=None if self.unit_node is None else self.unit_node.data_ptr(),
-            num_units=0 if self.unit_node is None else int(self.unit_node.numel()) - 1)
+            num_units=0 if self.unit_node is None else int(self.unit_node.numel()) - 1,
+            reserved2=1 if (self.unit_node is not None and self.units_single_graph and OPTIONS.pingpong) else 0)
 
     def _tiles_struct(self, which):
         t = self.typed
@@ -523,7 +528,7 @@ class DeviceBatch:
         replayed by every later dynamic_sampling call on this batch (reference loop: models/sampler.py:187-254)"""
         key = (int(kind), float(clip), float(-1.0 if clip_pos is None else clip_pos),
                bool(OPTIONS.fused_step_tail and not self.per_block),
-               bool(OPTIONS.typed_tiles), self.gemm_mode(), self.reserved_flags())
+               bool(OPTIONS.typed_tiles), self.gemm_mode(), self.reserved_flags(), bool(OPTIONS.pingpong))
         plan = self._plans.get(key)
         if plan is None:
             lib = _lib.load()
