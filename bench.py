@@ -50,7 +50,7 @@ PEAK_SPLIT_F16_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec)
 # HBM-side bytes per launch come from the committed rocprofv3 PMC passes of this round (tools/profile_round.sh), read
 # here because counters cannot be collected inside a bench run; a missing file gives `traffic: null`
-PMC_C2, PMC_C5, MFMA_BUSY = "r03_pmc_traffic.json", "r03_pmc_traffic_c5.json", "r03_mfma_busy.json"
+PMC_C2, PMC_C5, MFMA_BUSY = "r04_pmc_traffic.json", "r04_pmc_traffic_c5.json", "r04_mfma_busy.json"
 
 
 def parse():
@@ -259,6 +259,58 @@ def mega_roofline(lib, db, cfg, pos, dev, reps=40):
             # edge_attr read L-1 times, L-1 filter layers written, L filter layers gathered from both end points,
             # x1 / h rows, the weights of L blocks
             "algorithmic_bytes_per_launch": Eu * 4.0 * H * ((L - 1) * 2 + 2 * L) + 4.0 * N * H * 3 * L + 5 * 4.0 * H * H * L}
+
+
+def takes_fused_encoder(db):
+    """the batch runs the fused per-unit encoder (csrc/kernels_unit.hip) in its forward: split-f16 arithmetic, a unit
+    partition, and the host's policy (tsdiff_amd.engine.DeviceBatch.reserved_flags)"""
+    return db.gemm_mode() == "h2" and db.unit_node is not None and not (db.reserved_flags() & 4) and \
+        (bool(db.reserved_flags() & 16) or db.M > 1 or (db.N + 15) // 16 > 256)
+
+
+def encoder_roofline(lib, db, cfg, pos, dev, reps=4):
+    """the dominant kernel where a launch fills the chip with dense graphs (BASELINE configs[4]): unit_encoder_kernel --
+    ALL L interaction blocks in one launch, one workgroup per unit (64-atom graph) that computes its CFConv filters tile by
+    tile and consumes them on the CU (never written to memory) -- re-run on the state a forward left in the workspace
+    (tsd_forward_encoder), timed live with events on the launch stream"""
+    from tsdiff_amd import _lib
+    H, L = cfg["hidden_dim"], cfg["encoder"]["num_convs"]
+    N = db.N
+    db.forward(pos)
+    E_enc, Eu = db.enc.num_edges(), db.enc_u.num_edges()
+    b = db.struct()
+
+    def launch():
+        _lib.check(lib.tsd_forward_encoder(C.byref(db.cfg), C.byref(b), 0, L, _lib.stream_ptr()))
+    for _ in range(max(2, reps)):
+        launch()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k_ms = float("inf")
+    for _ in range(3):
+        ev0.record()
+        for _ in range(reps):
+            launch()
+        ev1.record()
+        torch.cuda.synchronize()
+        k_ms = min(k_ms, ev0.elapsed_time(ev1) / reps)
+    assert int(db.status[0].item()) & (_lib.STATUS_INTERNAL | _lib.STATUS_RANGE) == 0
+    w = forward_work(db.cfg, E_enc, 0, 0, N)
+    flops = w.flops_blocks * db.M  # every block's filters (once per undirected pair), messages and node chain
+    ach = flops / (k_ms * 1e-3) / 1e12
+    # algorithmic bytes: the attribute rows once per block (the only per-edge stream: the filters stay on the CU), the
+    # node rows (z / h in and out per block, x1_0), the weights of L blocks per workgroup from L2 (not counted)
+    abytes = (Eu * 4.0 * H * L + 4.0 * N * H * (2 * L + 1)) * db.M
+    return {"kernel": "unit_encoder_pp_kernel<256>" if (b.reserved2 & 1) else "unit_encoder_kernel<256>", "bound": "mfma",
+            "achieved": round(ach, 2), "peak": round(PEAK_SPLIT_F16_TFLOPS, 1), "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_SPLIT_F16_TFLOPS, 4),
+            "peak_note": "fp32-equivalent (algorithmic) flops against a third of the 2500 TFLOP/s dense f16 MFMA peak: "
+                         "three f16 MFMAs per fp32 multiply-add (split operands, csrc/split16.hpp)",
+            "traffic": None, "avg_launch_us": round(k_ms * 1e3, 2), "launches_per_forward": 1, "blocks_per_launch": L,
+            "flop_per_launch": flops, "undirected_edges": Eu, "directed_edges": E_enc, "nodes": N, "units": int(b.num_units),
+            "algorithmic_bytes_per_launch": abytes,
+            "hbm_frac_of_8TBs": round(abytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+            "note": "one launch = the whole SchNet encoder; per interaction block: avg_launch_us / blocks_per_launch, "
+                    "traffic / blocks_per_launch"}
 
 
 def aggregate_roofline(lib, cfg_struct, N, E, row_ptr, dst, H, dev, reps=20):
@@ -647,7 +699,11 @@ def main():
         rf32 = combo_roofline(lib, db, cfg, dev, reps=reps)
         rf32["traffic"], rf32["traffic_source"] = pmc_traffic("layer_combo_kernel<256, false, false, 0>", fname)
         rf32["mfma_busy"] = mfma_busy(label, "layer_combo_kernel<256, false, false, 0>")
-    if one_launch:
+    if takes_fused_encoder(db):
+        roofline = encoder_roofline(lib, db, cfg, pos_init, dev)
+        roofline["traffic"], roofline["traffic_source"] = pmc_traffic(roofline["kernel"], fname)
+        roofline["mfma_busy"] = mfma_busy(label, roofline["kernel"])
+    elif one_launch:
         roofline = mega_roofline(lib, db, cfg, pos_init, dev)
         roofline["traffic"], roofline["traffic_source"] = pmc_traffic("forward_mega_kernel<256>", fname)
         roofline["mfma_busy"] = mfma_busy(label, "forward_mega_kernel<256>")
@@ -721,9 +777,17 @@ def main():
         assert torch.isfinite(p5).all()
         db5 = run5.db()
         h2_5 = db5.gemm_mode() == "h2"
-        rf5 = combo_roofline(lib, db5, cfg, dev, reps=2, h2=h2_5)
-        rf5["traffic"], rf5["traffic_source"] = pmc_traffic("layer_combo_kernel<256, false, false, %d>" % (1 if h2_5 else 0), PMC_C5)
-        rf5["mfma_busy"] = mfma_busy("c5", "layer_combo_kernel<256, false, false, %d>" % (1 if h2_5 else 0))
+        if takes_fused_encoder(db5):
+            rf5 = encoder_roofline(lib, db5, cfg, g5["pos"].clone(), dev)
+            rf5["traffic"], rf5["traffic_source"] = pmc_traffic(rf5["kernel"], PMC_C5)
+            rf5["mfma_busy"] = mfma_busy("c5", rf5["kernel"])
+            # the materialising form of the same blocks (one launch per block, filters written once and read twice)
+            rf5["materialised"] = combo_roofline(lib, db5, cfg, dev, reps=2, h2=True)
+            rf5["materialised"]["traffic"], _ = pmc_traffic("layer_combo_kernel<256, false, false, 1>", PMC_C5)
+        else:
+            rf5 = combo_roofline(lib, db5, cfg, dev, reps=2, h2=h2_5)
+            rf5["traffic"], rf5["traffic_source"] = pmc_traffic("layer_combo_kernel<256, false, false, %d>" % (1 if h2_5 else 0), PMC_C5)
+            rf5["mfma_busy"] = mfma_busy("c5", "layer_combo_kernel<256, false, false, %d>" % (1 if h2_5 else 0))
         if h2_5:
             rf5["f32_mfma"] = combo_roofline(lib, db5, cfg, dev, reps=2)
         N5 = 1024 * 64

@@ -22,7 +22,9 @@ BUDGET = [
     (r"layer_combo_kernelILi256ELb0ELb[01]ELi1E", 128, 0),  # split-f16 block launches (all filter-tile widths)
     (r"pair_output_h_kernelILi256E", 128, 0),
     (r"unit_encoder_kernelILi256E", 256, 0),
-    (r"unit_encoder_pp_kernelILi256E", 256, 0),
+    # sixteen waves per workgroup: 128 registers; a few loop-invariant values of the per-block prologue may sit in scratch
+    # (six scratch instructions per block, none inside the tile cycle)
+    (r"unit_encoder_pp_kernelILi256E", 128, 64),
 ]
 
 
@@ -59,7 +61,7 @@ def main(paths):
                 v = rec.get("vgpr_count", 0)
                 scr = rec.get("private_segment_fixed_size", 0)
                 spill = rec.get("vgpr_spill_count", 0)
-                ok = v <= vmax and scr <= smax and spill == 0
+                ok = v <= vmax and scr <= smax and (spill == 0 or smax > 0)
                 print(f"check_regs: {'ok  ' if ok else 'FAIL'} {v:3d}/{vmax} VGPRs, scratch {scr} B, "
                       f"{rec.get('sgpr_spill_count', 0)} SGPR spills  {name[:90]}")
                 if not ok:

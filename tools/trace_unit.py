@@ -39,7 +39,7 @@ fwd(); torch.cuda.synchronize()
 assert dbg(buf.ctypes.data_as(C.c_void_p)) == 0
 t = buf.astype(np.int64).reshape(-1, 16)
 t = t[t[:, 9] > 0]
-pp = os.environ.get("TSDIFF_PINGPONG", "1") != "0" and workload == "c5"
+pp = os.environ.get("TSDIFF_PINGPONG", "0") != "0" and workload == "c5"
 if pp:
     # ping-pong form: rows alternate team 0 / team 1; slots: 0 GEMM nn.0, 1 ssp, 2 GEMM nn.2, 3 filter tile -> LDS, 4 accumulate
     # (+ fetch), 5 next planes, 6 node chain, 7 idle / waiting for the slot (team skew, barriers of the other team)

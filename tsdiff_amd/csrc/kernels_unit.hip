@@ -108,7 +108,7 @@ extern "C" int tsd_debug_unit_trace(void* host_buf) {
 #define UTRACE_COUNT(slot) do { ut_acc[slot] += 1; } while (0)
 #define UTRACE_FLUSH do { ut_acc[9] = __builtin_amdgcn_s_memtime() - ut_t0; if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) { for (int i_ = 0; i_ < 10; ++i_) g_unit_trace[(size_t)blockIdx.x * 16 + i_] = ut_acc[i_]; } } while (0)
 // ping-pong form: team 0's wave 0 in row 2 b, team 1's wave 4 in row 2 b + 1 (b < 2048)
-#define UTRACE_FLUSH_PP do { ut_acc[9] = __builtin_amdgcn_s_memtime() - ut_t0; if ((threadIdx.x & 255) == 0 && blockIdx.y == 0 && blockIdx.x < 2048) { for (int i_ = 0; i_ < 10; ++i_) g_unit_trace[((size_t)blockIdx.x * 2 + (threadIdx.x >> 8)) * 16 + i_] = ut_acc[i_]; } } while (0)
+#define UTRACE_FLUSH_PP do { ut_acc[9] = __builtin_amdgcn_s_memtime() - ut_t0; if ((threadIdx.x & 511) == 0 && blockIdx.y == 0 && blockIdx.x < 2048) { for (int i_ = 0; i_ < 10; ++i_) g_unit_trace[((size_t)blockIdx.x * 2 + (threadIdx.x >> 9)) * 16 + i_] = ut_acc[i_]; } } while (0)
 #else
 #define UTRACE_DECL
 #define UTRACE(slot)
@@ -524,8 +524,8 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
 //
 // In the kernel above all eight waves walk the phases of one tile together: the MFMA pipes idle through the three
 // VALU / LDS phases (conversion, ssp, filter tile + accumulation: 47 % of a tile's cycles, tools/trace_unit.py) and the
-// VALU idles through the two GEMMs.  Here the workgroup is two TEAMS of four waves -- waves w and w + 4 share a SIMD,
-// so each team has one wave on every SIMD -- with a tile buffer each; team 0 takes the even tiles, team 1 the odd ones,
+// VALU idles through the two GEMMs.  Here the workgroup is SIXTEEN waves (128 VGPRs each), two TEAMS of eight -- two waves of
+// each team on every SIMD -- with a tile buffer each; team 0 takes the even tiles, team 1 the odd ones,
 // one slot (a quarter of a tile's cycle) apart:
 //
 //      slot     team 0                     team 1
@@ -577,14 +577,13 @@ __device__ __forceinline__ void hgemm_ring_run_part(HRing<CB, R>& r, const Plane
     });
 }
 
-constexpr int PP_R = 2;  // k-steps of the weight ring in flight (CB = 2: 2 x 2 x 2 fragments = 32 registers)
 
 template <int H>
-__global__ __launch_bounds__(2 * H) void unit_encoder_pp_kernel(UnitArgs A) {
-    static_assert(H == 256, "the unit encoder is built for hidden 256 (two teams of four waves)");
+__global__ __launch_bounds__(4 * H) void unit_encoder_pp_kernel(UnitArgs A) {
+    static_assert(H == 256, "the unit encoder is built for hidden 256 (two teams of eight waves)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int LDH = ldh_of(H), LDA = H + 4, NT = 2 * H, C4 = H / 4;
-    constexpr int RB16 = UNA / 16, CB16 = 2;
+    constexpr int LDH = ldh_of(H), LDA = H + 4, NT = 4 * H, C4 = H / 4;
+    constexpr int RB16 = UNA / 16, CB16 = 1;  // (node chain: sixteen waves x 16 columns)
     constexpr int KS = H / 16;
     float* tile0 = smem;                             // team 0: planes / fp32 filter tile
     float* tile1 = tile0 + UT * LDH;                 // team 1
@@ -634,12 +633,12 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_pp_kernel(UnitArgs A) {
 #define TSD_PP_GEOM                                                           \
     const int tq = opaque(tid);                                               \
     const int wave = tq >> 6, lane = tq & 63;                                 \
-    const int tw = wave & 3;                                                  \
+    const int tw = wave & 7;                                                  \
     const int hi = lane >> 5, l31 = lane & 31;                                \
-    const int col0 = tw * 64;                                                 \
+    const int col0 = tw * 32;                                                 \
     (void)tw; (void)hi; (void)l31; (void)col0; (void)wave;
 
-    const int team = __builtin_amdgcn_readfirstlane(tid >> 8);  // 0: waves 0-3, 1: waves 4-7 (uniform per wave)
+    const int team = __builtin_amdgcn_readfirstlane(tid >> 9);  // 0: waves 0-7, 1: waves 8-15 (uniform per wave)
     float* tile = team == 0 ? tile0 : tile1;
     const Planes pl = planes_at(tile, UT, LDH);
     float* buf = tile;
@@ -653,33 +652,28 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_pp_kernel(UnitArgs A) {
             const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
             for (int idx = tid; idx < na * C4; idx += NT) *reinterpret_cast<f32x4*>(G + idx * 4) = zz;
         }
-        float b0[2], b2[2];
+        float b0, b2;
         {
             TSD_PP_GEOM
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                b0[cb] = Wl[A.o_nn0_b + col0 + cb * 32 + l31];
-                b2[cb] = Wl[A.o_nn2_b + col0 + cb * 32 + l31];
-            }
+            b0 = Wl[A.o_nn0_b + col0 + l31];
+            b2 = Wl[A.o_nn2_b + col0 + l31];
         }
-        HRing<2, PP_R> rg;
         if (nt_team > 0) {   // the team's first tile: attribute rows -> planes, first k-steps of nn.0's weights
             TSD_PP_GEOM
-            constexpr int NITP = UT / 4;
+            constexpr int NITP = UT / 8;
             f32x4 v[NITP];
             unsigned uu[NITP];
 #pragma unroll
-            for (int it = 0; it < NITP; ++it) uu[it] = s_u[team * UT + tw + it * 4];
+            for (int it = 0; it < NITP; ++it) uu[it] = s_u[team * UT + tw + it * 8];
 #pragma unroll
             for (int it = 0; it < NITP; ++it)
                 v[it] = *reinterpret_cast<const f32x4*>(ea + (size_t)(uu[it] == 0xffffu ? 0u : uu[it]) * H + lane * 4);
 #pragma unroll
             for (int it = 0; it < NITP; ++it) {
                 const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
-                planes_store4(pl, (tw + it * 4) * LDH + lane * 4, uu[it] != 0xffffu ? v[it] : zz, amax);
+                planes_store4(pl, (tw + it * 8) * LDH + lane * 4, uu[it] != 0xffffu ? v[it] : zz, amax);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            hgemm_ring_start<2, H>(rg, nn0_w, H, col0);
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -714,66 +708,75 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_pp_kernel(UnitArgs A) {
                 for (int i = 0; i < 12; ++i) __builtin_amdgcn_s_barrier();
                 continue;
             }
-            f32x16 accm[2][2], accx[2][2];
+            f32x16 accm[2][1], accx[2][1];
             UTRACE(7);
             // a GEMM's k-steps in three parts 4 | 5 | 7, cut roughly where the other team's steps end (`filter | accumulate |
             // planes`, or the three parts of the ssp epilogue, sized to match).  ONE split for every GEMM: two code paths
             // that both consume the weight ring make the compiler copy ring registers at the branch while their loads are
             // in flight (tools/check_async_loads.py caught it).
-            auto gemm3 = [&]() {
-                hzero(accm, accx);
-                hgemm_ring_run_part<2, 2, H, 0, 4>(rg, pl, LDH, accm, accx);
-                __builtin_amdgcn_s_barrier();
-                hgemm_ring_run_part<2, 2, H, 4, 9>(rg, pl, LDH, accm, accx);
-                __builtin_amdgcn_s_barrier();
-                hgemm_ring_run_part<2, 2, H, 9, KS>(rg, pl, LDH, accm, accx);
-            };
-            {   // ---- slot 0: GEMM nn.0 in three parts
-                gemm3();
+            auto gemm3 = [&](const float* wmat) {
+                // (the weight ring goes up HERE, not before the barrier that ends the previous slot: with 128 registers per
+                // wave a ring that is live across the loop edge is what the allocator spills -- while its loads are in flight)
+                HRing<1, HRING_R> rg;
                 {
                     TSD_PP_GEOM
-                    hgemm_ring_start<2, H>(rg, nn2_w, H, col0);
+                    hgemm_ring_start<1, H>(rg, wmat, H, col0);
                 }
+                hzero(accm, accx);
+                hgemm_ring_run_part<2, 1, H, 0, 4>(rg, pl, LDH, accm, accx);
+                __builtin_amdgcn_s_barrier();
+                hgemm_ring_run_part<2, 1, H, 4, 9>(rg, pl, LDH, accm, accx);
+                __builtin_amdgcn_s_barrier();
+                hgemm_ring_run_part<2, 1, H, 9, KS>(rg, pl, LDH, accm, accx);
+            };
+            {   // ---- slot 0: GEMM nn.0 in three parts
+                __builtin_amdgcn_s_setprio(0);
+                gemm3(nn0_w);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
             UTRACE(0);
             {   // ---- slot 1: shifted softplus -> planes, in three parts
+                // (the VALU-side slots run at raised priority: a GEMM wave needs one issue slot per 32-cycle MFMA, the epilogue
+                // waves need them all -- at equal priority the older wave wins the SIMD's issue port)
+                __builtin_amdgcn_s_setprio(2);
                 TSD_PP_GEOM
                 f16* hb = pl.hi + opaque(4 * hi * LDH + col0 + l31);
                 f16* lb = pl.lo + opaque(4 * hi * LDH + col0 + l31);
-                auto elem = [&](auto ec) {   // element e of the lane's 64: accumulator block (rb, cb) = e / 16, register e % 16
-                    constexpr int e = decltype(ec)::value, rb = e >> 5, cb = (e >> 4) & 1, r = e & 15;
-                    const float y = sspf(hval(accm[rb][cb], accx[rb][cb], r) + b0[cb]);
+                auto elem = [&](auto ec) {   // element e of the lane's 32: row block e / 16, accumulator register e % 16
+                    constexpr int e = decltype(ec)::value, rb = e >> 4, r = e & 15;
+                    const float y = sspf(hval(accm[rb][0], accx[rb][0], r) + b0);
                     f16 yh, yl;
                     amax_upd(amax, y);
                     split1(y, yh, yl);
-                    hb[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LDH + cb * 32] = yh;
-                    lb[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LDH + cb * 32] = yl;
+                    hb[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = yh;
+                    lb[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = yl;
                 };
                 // (the planes are free: every wave of the team left GEMM nn.0 at the barrier that ended its slot)
-                static_for<0, 16>(elem);
+                static_for<0, 8>(elem);
                 __builtin_amdgcn_s_barrier();
-                static_for<16, 36>(elem);
+                static_for<8, 18>(elem);
                 __builtin_amdgcn_s_barrier();
-                static_for<36, 64>(elem);
+                static_for<18, 32>(elem);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
             UTRACE(1);
             {   // ---- slot 2: GEMM nn.2 in three parts
-                gemm3();
+                __builtin_amdgcn_s_setprio(0);
+                gemm3(nn2_w);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
             UTRACE(2);
             {   // ---- slot 3: filter tile -> LDS | accumulate | next tile's planes
+                __builtin_amdgcn_s_setprio(2);
                 const bool more = k + 1 < nt_team;
                 const bool diag = tI == tJ;
                 const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
-                // accumulate step, side 0 (the pair's j side: rows tw, tw + 4 of block J, partners = block I): its x rows are
-                // requested HERE, before the filter-tile step, and land under it
-                f32x4 xv0[8], a4[2];
+                // accumulate step, side 0 (the pair's j side: row tw of block J, partners = block I): its x rows are requested
+                // HERE, before the filter-tile step, and land under it
+                f32x4 xv0[8], a4;
                 {
                     TSD_PP_GEOM
 #pragma unroll
@@ -782,95 +785,80 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_pp_kernel(UnitArgs A) {
                         xv0[p] = at < na ? *reinterpret_cast<const f32x4*>(xin + (size_t)at * H + lane * 4) : zz;
                     }
                 }
-                {   // W = (nn.2 + b) * C as fp32 rows over the planes
+                {   // W = (nn.2 + b) * C as fp32 rows over the planes (four rows at a time, pinned: the attribute rows above
+                    // must stay in their registers -- a spilled one would wait for its load)
                     TSD_PP_GEOM
                     float* wb = buf + opaque(4 * hi * LDA + col0 + l31);
 #pragma unroll
-                    for (int rb = 0; rb < 2; ++rb) {
-                        f32x4 cw[4];
+                    for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) cw[g4] = *reinterpret_cast<const f32x4*>(s_c + t * UT + rb * 32 + 8 * g4 + 4 * hi);
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            const f32x4 cw = *reinterpret_cast<const f32x4*>(s_c + t * UT + rb * 32 + 8 * g4 + 4 * hi);
 #pragma unroll
-                        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r)
-                                wb[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LDA + cb * 32] =
-                                    (hval(accm[rb][cb], accx[rb][cb], r) + b2[cb]) * cw[r >> 2][r & 3];
-                    }
+                            for (int r3 = 0; r3 < 4; ++r3)
+                                wb[(rb * 32 + r3 + 8 * g4) * LDA] = (hval(accm[rb][0], accx[rb][0], g4 * 4 + r3) + b2) * cw[r3];
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 UTRACE(3);
-                // the attribute rows of the team's next tile (registers: the accumulators are dead from here on)
-                constexpr int NITP = UT / 4;
+                // the attribute rows of the team's next tile (requested at the END of the accumulate step: with 128 registers per
+                // wave there is no room for them beside the accumulators of the filter-tile step or beside both sides' x rows
+                // -- tried: the compiler waits for the loads and spills them; their HBM latency shows in the planes step)
+                constexpr int NITP = UT / 8;
                 f32x4 v[NITP];
                 unsigned vlive = 0;
-                {   // accumulate: wave tw of the team adds the partners of rows tw and tw + 4 of block J (the pair's j side),
+                {   // accumulate: wave tw of the team adds the partners of row tw of block J (the pair's j side),
                     // then of block I (its i side): read-modify-write of those rows' agg in memory.  Side 1's loads are
                     // requested before side 0's arithmetic.  (Both sides' rows and the next tile's attribute rows in
                     // registers at once do not fit 256 VGPRs: the allocator then spills the weight ring.)
                     TSD_PP_GEOM
                     const float* wrow = buf + lane * 4;
-                    f32x4 xv1[8], b4[2];
-#pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {
-                        const int at = tJ * 8 + tw + 4 * rr;
-                        a4[rr] = at < na ? *reinterpret_cast<const f32x4*>(G + (size_t)at * H + lane * 4) : zz;
+                    f32x4 xv1[8], b4;
+                    {
+                        const int at = tJ * 8 + tw;
+                        a4 = at < na ? *reinterpret_cast<const f32x4*>(G + (size_t)at * H + lane * 4) : zz;
                     }
 #pragma unroll
                     for (int p = 0; p < 8; ++p) {
                         const int at = tJ * 8 + p;
                         xv1[p] = at < na ? *reinterpret_cast<const f32x4*>(xin + (size_t)at * H + lane * 4) : zz;
                     }
-#pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {
-                        const int at = tI * 8 + tw + 4 * rr;
-                        b4[rr] = (at < na && !diag) ? *reinterpret_cast<const f32x4*>(G + (size_t)at * H + lane * 4) : zz;
+                    {
+                        const int at = tI * 8 + tw;
+                        b4 = (at < na && !diag) ? *reinterpret_cast<const f32x4*>(G + (size_t)at * H + lane * 4) : zz;
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {   // j side: tile row (p, rl) = p * 8 + rl
-                        const int rl = tw + 4 * rr;
+                    for (int p = 0; p < 8; ++p) {   // j side: tile row (p, tw) = p * 8 + tw
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + (p * 8 + tw) * LDA);
 #pragma unroll
-                        for (int p = 0; p < 8; ++p) {
-                            const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + (p * 8 + rl) * LDA);
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) a4[rr][c] = __fadd_rn(a4[rr][c], __fmul_rn(xv0[p][c], wv[c]));
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+                        for (int c = 0; c < 4; ++c) a4[c] = __fadd_rn(a4[c], __fmul_rn(xv0[p][c], wv[c]));
                     }
-                    if (diag) {   // a diagonal tile: the same rows take their i side on top (partners below the row, then above)
-                        b4[0] = a4[0];
-                        b4[1] = a4[1];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (diag) {   // a diagonal tile: the same row takes its i side on top (partners below the row, then above)
+                        b4 = a4;
                     } else {
-#pragma unroll
-                        for (int rr = 0; rr < 2; ++rr) {
-                            const int at = tJ * 8 + tw + 4 * rr;
-                            if (at < na) *reinterpret_cast<f32x4*>(G + (size_t)at * H + lane * 4) = a4[rr];
-                        }
+                        const int at = tJ * 8 + tw;
+                        if (at < na) *reinterpret_cast<f32x4*>(G + (size_t)at * H + lane * 4) = a4;
                     }
 #pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {   // i side: tile row (rl, p) = rl * 8 + p
-                        const int rl = tw + 4 * rr;
+                    for (int p = 0; p < 8; ++p) {   // i side: tile row (tw, p) = tw * 8 + p
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + (tw * 8 + p) * LDA);
 #pragma unroll
-                        for (int p = 0; p < 8; ++p) {
-                            const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + (rl * 8 + p) * LDA);
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) b4[rr][c] = __fadd_rn(b4[rr][c], __fmul_rn(xv1[p][c], wv[c]));
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+                        for (int c = 0; c < 4; ++c) b4[c] = __fadd_rn(b4[c], __fmul_rn(xv1[p][c], wv[c]));
                     }
-#pragma unroll
-                    for (int rr = 0; rr < 2; ++rr) {
-                        const int at = tI * 8 + tw + 4 * rr;
-                        if (at < na) *reinterpret_cast<f32x4*>(G + (size_t)at * H + lane * 4) = b4[rr];
+                    __builtin_amdgcn_sched_barrier(0);
+                    {
+                        const int at = tI * 8 + tw;
+                        if (at < na) *reinterpret_cast<f32x4*>(G + (size_t)at * H + lane * 4) = b4;
                     }
-                    // the next tile's attribute rows (requested only now, and pinned here: see above)
                     __builtin_amdgcn_sched_barrier(0);
                     if (more) {
                         unsigned uu[NITP];
 #pragma unroll
-                        for (int it = 0; it < NITP; ++it) uu[it] = s_u[(t + 2) * UT + tw + it * 4];
+                        for (int it = 0; it < NITP; ++it) uu[it] = s_u[(t + 2) * UT + tw + it * 8];
 #pragma unroll
                         for (int it = 0; it < NITP; ++it) {
                             vlive |= (uu[it] != 0xffffu ? 1u : 0u) << it;
@@ -891,10 +879,9 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_pp_kernel(UnitArgs A) {
 #pragma unroll
                     for (int it = 0; it < NITP; ++it) {
                         const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
-                        planes_store4(pl, (tw + it * 4) * LDH + lane * 4, (vlive >> it & 1u) ? v[it] : zz, amax);
+                        planes_store4(pl, (tw + it * 8) * LDH + lane * 4, (vlive >> it & 1u) ? v[it] : zz, amax);
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (more) hgemm_ring_start<2, H>(rg, nn0_w, H, col0);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -927,14 +914,14 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_pp_kernel(UnitArgs A) {
 #define TSD_PPN_GEOM                                                      \
     const int tq = opaque(tid);                                           \
     const int wave = tq >> 6, lane = tq & 63;                             \
-    const int col0 = wave * 32;                                           \
+    const int col0 = wave * 16;                                           \
     const int q = lane >> 4, l15 = lane & 15;                             \
     (void)q; (void)l15; (void)col0;
             {
                 TSD_PPN_GEOM
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    const int at = kk * 8 + wave;
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int at = kk * 16 + wave;
                     const f32x4 a4 = at < na ? *reinterpret_cast<const f32x4*>(G + (size_t)at * H + lane * 4) : zero4;
                     planes_store4(pn, at * LDH + lane * 4, a4, amax);
                 }
@@ -1088,7 +1075,7 @@ int launch_unit_encoder(const tsd_model_cfg& c, const tsd_batch& b, const float*
         static DeviceOnce once;
         int r = allow_lds(unit_encoder_pp_kernel<256>, lds, once);
         if (r) return r;
-        hipLaunchKernelGGL(unit_encoder_pp_kernel<256>, dim3(b.num_units, b.num_models), dim3(512), lds, st, A);
+        hipLaunchKernelGGL(unit_encoder_pp_kernel<256>, dim3(b.num_units, b.num_models), dim3(1024), lds, st, A);
         TSD_LAUNCH_CHECK("unit_encoder_pp");
         return TSD_OK;
     }

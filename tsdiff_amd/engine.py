@@ -439,9 +439,13 @@ class DeviceBatch:
     def reserved_flags(self):
         """tsd_batch.reserved (include/tsdiff_hip.h): bit 0 one launch per block, bit 1 narrow filter tiles, bit 2 no
         fused encoder; test bits"""
+        # the fused per-unit encoder: on by itself where it wins -- every unit one graph of more than 32 atoms (8 x 8
+        # atom-block tiles; BASELINE configs[4]: -12 % step time) -- and off for small-molecule batches, where the
+        # materialised forms keep two workgroups per CU busy and measure faster (DESIGN.md 4c); "force": everywhere
         fe = OPTIONS.fused_encoder
+        fused_on = fe == "force" or (bool(fe) and self.units_single_graph and not self.per_block)
         return ((0 if (OPTIONS.one_launch and not self.per_block) else 1) | (0 if OPTIONS.wide_filter_tiles else 2) |
-                (0 if fe else 4) | (16 if fe == "force" else 0) | self.test_flags)
+                (0 if fused_on else 4) | (16 if fe == "force" else 0) | self.test_flags)
 
     def forward_out_edges(self, pos):
         """forward(pos) and the number of directed out edges, in ONE host read (the edge count and the status word).

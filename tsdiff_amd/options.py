@@ -13,7 +13,7 @@ at import, by `TSDIFF_*` environment variables (read here and nowhere else); tes
 | wide_filter_tiles  | TSDIFF_WIDE_FILTER_TILES  | True    | 64-row filter tiles where a block launch is many chip-fulls deep; False: 32-row tiles everywhere |
 | fused_step_tail    | TSDIFF_FUSED_TAIL         | True    | sampling loop: update + next step's edge lists as one launch; False: three launches |
 | fused_encoder      | TSDIFF_FUSED_ENCODER      | True    | chip-full launches (big batches, ensembles): the whole SchNet encoder as ONE launch of per-unit workgroups that never write the CFConv filters to memory (kernels_unit.hip); False: one launch per block with materialised filters; "force": also where the one-launch form would apply.  Bit-identical (the messages are added in the directed list's order) |
-| pingpong           | TSDIFF_PINGPONG           | True    | fused encoder on units that are single graphs of > 32 atoms: two teams of four waves per workgroup, one on the matrix pipes while the other runs the VALU / LDS phases of its tile (unit_encoder_pp_kernel); False: all eight waves walk one tile's phases together.  Bit-identical |
+| pingpong           | TSDIFF_PINGPONG           | False   | fused encoder on units that are single graphs of > 32 atoms: sixteen waves per workgroup in two teams, one on the matrix pipes while the other runs the VALU / LDS phases of its tile (unit_encoder_pp_kernel); False: eight waves walk one tile's phases together.  Bit-identical; measured equal within 1 % at configs[4], so the simpler form is the default |
 """
 import os
 from dataclasses import dataclass
@@ -32,14 +32,14 @@ class Options:
     wide_filter_tiles: bool = True
     fused_step_tail: bool = True
     fused_encoder: bool = True
-    pingpong: bool = True
+    pingpong: bool = False
 
     @classmethod
     def from_env(cls):
         o = cls(gemm=os.environ.get("TSDIFF_GEMM", "h2"), typed_tiles=_flag("TSDIFF_TYPED_TILES"),
                 one_launch=_flag("TSDIFF_ONE_LAUNCH"), wide_filter_tiles=_flag("TSDIFF_WIDE_FILTER_TILES"),
                 fused_step_tail=_flag("TSDIFF_FUSED_TAIL"), fused_encoder=_flag("TSDIFF_FUSED_ENCODER"),
-                pingpong=_flag("TSDIFF_PINGPONG"))
+                pingpong=_flag("TSDIFF_PINGPONG", False))
         o.validate()
         return o
 
