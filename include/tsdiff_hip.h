@@ -139,6 +139,15 @@ int tsd_pack_weights(const tsd_model_cfg* cfg, const float* raw, float* packed, 
  * rewritten in place of its fp32 image as [k/16][plane][k%16/8][out][k%8] f16, everything else copied. */
 int tsd_pack_weights16(const tsd_model_cfg* cfg, const float* packed, float* packed16, void* stream);
 
+/* Pre-flight of a weight arena for the split-f16 arithmetic (a real checkpoint before its first forward): over
+ * `num_floats` floats -- the packed arena of tsd_pack_weights, which holds the folded matrices the forward multiplies with,
+ * or a bucket arena of tsd_bucket_weights_build -- out8 (DEVICE, 8 floats) receives [0] max |w|, [1] the number of
+ * non-zero weights below 2^-14 = 6.1e-5 (their high plane is an f16 subnormal: the operand keeps an absolute precision of
+ * ~1.5e-11 instead of 22 bits -- harmless in small numbers, a reason to run `weights16 = NULL` if a whole layer sits
+ * there), [2] the number beyond the f16 range 65504 (the forward would report TSD_STATUS_RANGE at once), [3] num_floats.
+ * Activations cannot be pre-flighted: the forward tracks their range itself (TSD_STATUS_RANGE). */
+int tsd_weights16_preflight(const float* weights, size_t num_floats, float* out8 /* device [8] */, void* stream);
+
 /* ---- work model (the figures every roofline fraction in bench.py is quoted against) -----------
  * Arithmetic of ONE forward of one checkpoint for a batch with the given edge counts: `enc_edges` / `out_edges`
  * directed edges of the encoder / output lists, `diff_pairs` undirected output pairs embedded separately. */

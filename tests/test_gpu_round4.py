@@ -260,3 +260,108 @@ def test_fused_encoder_block_tiles_on_ragged_and_sparse_graphs(n, graphs, cut, d
     if cut < 10.0:
         assert ei.shape[1] < graphs * n * (n - 1), "the short cutoff was meant to drop pairs"
     assert torch.equal(res["fused"], res["per_block"]) and torch.equal(res["fused_nopp"], res["per_block"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the split-f16 arithmetic away from torch-default magnitudes
+# ---------------------------------------------------------------------------------------------------------------------
+SWEEP = [("default", 256, 7, 1.0, False, (0.7, 9.0)), ("weights x 0.1", 256, 7, 0.1, False, (0.7, 9.0)),
+         ("weights x 2", 256, 7, 2.0, False, (0.7, 9.0)), ("heavy tail", 256, 7, 1.0, True, (0.7, 9.0)),
+         ("compact", 256, 7, 1.0, False, (0.3, 1.0)), ("stretched", 256, 7, 1.0, False, (4.0, 12.0)),
+         ("hidden 128", 128, 4, 1.0, False, (0.7, 9.0)), ("hidden 64 x 0.1", 64, 3, 0.1, False, (0.7, 9.0))]
+
+
+@pytest.mark.parametrize("case", SWEEP, ids=[c[0] for c in SWEEP])
+def test_split_f16_sweep_vs_fp64(case, dev):
+    """weight scale, weight distribution, hidden size, geometry scale: per tensor the split-f16 forward is as close to an
+    fp64 evaluation as the fp32-MFMA forward (e_h2 <= max(1.5 e_f32, 1e-6)), also on the 1 % smallest entries (absolute
+    error over the tensor scale); a case that leaves the f16 range is rerun in fp32 by itself (then both are that path)"""
+    from tools.split_f16_sweep import config_for, run_case, scaled_state_dict
+    name, H, L, ws, heavy, (lo, hi) = case
+    cfg = config_for(H, L)
+    r = run_case(cfg, scaled_state_dict(cfg, 3, ws, heavy), 40, 1000, lo, hi, dev)
+    assert r["finite"], "the fp64 reference itself is not finite: not a usable case"
+    print(name, r)
+    assert r["e_h2"] <= max(1.5 * r["e_f32"], 1e-6), r
+    assert r["small_h2"] <= max(2.0 * r["small_f32"], 1e-6), r
+    assert r["preflight"]["beyond_f16_range"] == 0
+
+
+@pytest.mark.parametrize("role,param,index", [("embedding", "edge_cat.0.bias", 5), ("filter", "encoder.interactions.1.conv.nn.0.bias", 3),
+                                               ("node", "encoder.interactions.0.conv.lin2.bias", 7),
+                                               ("pair", "grad_dist_mlp.layers.0.bias", 2)])
+def test_range_flag_trips_in_every_role(role, param, index, dev, monkeypatch):
+    """an activation beyond 65504 produced in the embedding tile, a filter tile, the node chain or the pair MLP: each role
+    reports TSD_STATUS_RANGE, the call is rerun on the fp32-MFMA kernels and equals an fp32 call; for the forms of the
+    forward that have these roles as separate kernels / as roles of one launch / inside the fused encoder"""
+    from tsdiff_amd import engine, synth
+    from tsdiff_amd.epsnet import get_model
+    from tsdiff_amd.utils import AttrDict
+    cfg = synth.small_model_config(256, 2)  # (two blocks: 1e5 injected into the full 7-block model overflows fp32 itself)
+
+    def build():
+        sd = synth.synth_state_dict(cfg, 7)
+        sd[param] = sd[param].copy()
+        sd[param][index] = 1.0e5
+        m = get_model(AttrDict(cfg))
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        return m.to(dev)
+    _, _, g = _batch(6, 2, dev)
+    monkeypatch.setattr(engine.OPTIONS, "gemm", "f32")
+    ref, _, _ = run_forward(build(), g, dev)
+    assert torch.isfinite(ref).all()
+    for form in ("one_launch", "per_block", "fused"):
+        monkeypatch.setattr(engine.OPTIONS, "gemm", "h2")
+        monkeypatch.setattr(engine.OPTIONS, "one_launch", form == "one_launch")
+        monkeypatch.setattr(engine.OPTIONS, "fused_encoder", "force" if form == "fused" else False)
+        model = build()
+        inv, _, _ = run_forward(model, g, dev)
+        db = _db(model)
+        assert db.gemm == "f32", f"{role}: the range flag did not trip in the {form} form"
+        assert torch.equal(inv, ref), (role, form)
+
+
+def test_operands_in_the_f16_subnormal_band(dev, monkeypatch):
+    """GEMM A operands between 1e-6 and 6e-5 (below the f16 normal range: the high plane is a subnormal, the value is
+    carried by the scaled low plane with an ABSOLUTE precision of ~1.5e-11): the attribute rows of every edge are pushed
+    there by a 2e-5 scale on edge_cat.0, compensated in edge_cat.2 (so the network's function and output scale stay put).
+    Left alone the split-f16 arithmetic lands 1.4e-5 from the fp64 evaluation there (measured, round 4: outside
+    north_star's 1e-5).  The conversion sites therefore watch the LOW side of the range too (split16.hpp site_close): a
+    tile whose attribute rows are tiny throughout reports TSD_STATUS_RANGE and the call is rerun on the fp32-MFMA
+    kernels -- in every form of the forward -- and the result is the fp32 forward's, 1e-6 from fp64."""
+    from oracle import tsdiff_oracle as O
+    from tsdiff_amd import engine, synth
+    from tsdiff_amd.epsnet import get_model
+    from tsdiff_amd.utils import AttrDict
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    sc = 2.0e-5
+    sd = {k: v.copy() for k, v in synth.synth_state_dict(cfg, 3).items()}
+    sd["edge_cat.0.weight"] *= np.float32(sc)
+    sd["edge_cat.0.bias"] *= np.float32(sc)
+    sd["edge_cat.2.weight"] *= np.float32(2.0 / sc)  # (swish(x) ~ x / 2 for small x)
+    b, t, g = _batch(30, 5, dev)
+    o64 = O.forward(O.to_torch_state(sd, torch.float64), cfg, t["atom_type"], t["r_feat"], t["p_feat"], t["pos"].double(),
+                    t["bond_index"], t["bond_type"], b["num_nodes_per_graph"])[0].numpy()
+
+    def build():
+        m = get_model(AttrDict(cfg))
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        return m.to(dev)
+    monkeypatch.setattr(engine.OPTIONS, "gemm", "f32")
+    ref, _, _ = run_forward(build(), g, dev)
+    e_f32 = rel_err(ref.cpu().numpy(), o64)
+    assert e_f32 <= 5e-6, e_f32
+    for form in ("one_launch", "per_block", "fused"):
+        monkeypatch.setattr(engine.OPTIONS, "gemm", "h2")
+        monkeypatch.setattr(engine.OPTIONS, "one_launch", form == "one_launch")
+        monkeypatch.setattr(engine.OPTIONS, "fused_encoder", "force" if form == "fused" else False)
+        m = build()
+        inv, _, _ = run_forward(m, g, dev)
+        assert _db(m).gemm == "f32", f"tiny attribute rows were not noticed in the {form} form"
+        assert torch.equal(inv, ref)
+    # a healthy checkpoint does not trip the low side (no false positive on the default weights)
+    monkeypatch.setattr(engine.OPTIONS, "fused_encoder", False)
+    monkeypatch.setattr(engine.OPTIONS, "one_launch", True)
+    h = make_model(cfg, 3, dev)
+    run_forward(h, g, dev)
+    assert _db(h).gemm is None and _db(h).gemm_mode() == "h2"

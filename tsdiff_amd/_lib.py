@@ -214,6 +214,7 @@ SIGNATURES = {
     "tsd_bucket_weights_build": (C.c_int, [_CFG, _P, C.c_int32, _P, _P, _P]),
     "tsd_forward_blocks": (C.c_int, [_CFG, C.POINTER(Batch), C.c_int32, _P]),
     "tsd_forward_encoder": (C.c_int, [_CFG, C.POINTER(Batch), C.c_int32, C.c_int32, _P]),
+    "tsd_weights16_preflight": (C.c_int, [_P, C.c_size_t, _P, _P]),
     "tsd_forward_workspace_layout": (C.c_int, [_CFG, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_size_t)]),
     "tsd_pack_weights16": (C.c_int, [_CFG, _P, _P, _P]),
     "tsd_bucket_weights16": (C.c_int, [_CFG, _P, C.c_int32, _P, _P]),

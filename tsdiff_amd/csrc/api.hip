@@ -445,6 +445,11 @@ int tsd_pack_weights16(const tsd_model_cfg* cfg, const float* packed, float* pac
     return launch_pack_weights16(*cfg, packed, packed16, (hipStream_t)stream);
 }
 
+int tsd_weights16_preflight(const float* weights, size_t num_floats, float* out8, void* stream) {
+    TSD_REQUIRE(out8 != nullptr && (num_floats == 0 || weights != nullptr), "null pointer");
+    return launch_weights_preflight(weights, num_floats, out8, (hipStream_t)stream);
+}
+
 int tsd_bucket_weights16(const tsd_model_cfg* cfg, const float* bucket_weights, int32_t num_slots, float* out16,
                          void* stream) {
     int r = check_cfg(cfg);

@@ -406,6 +406,8 @@ __device__ __forceinline__ void xl_gather(const int32_t* __restrict__ row_ptr, c
         if (two) consume(wb, jd1, e + U);
     }
     while (rr < RPW) flush();  // the last row, and rows past it without edges (or past the last node): zeros
+    // (no low-side site check here -- split16.hpp site_close: the one-launch kernel has no register to spare; the
+    // attribute rows that feed these filters are checked where the filter tiles convert them)
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -906,12 +908,14 @@ __device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float*
         __syncthreads();
     } else {
         hgemm16_ring_start<CB16, H>(rg, a.lin1_next_w, H, col0);
+        float site_m = 0.0f;
         for (int idx = tid; idx < TN * C4; idx += NT) {
             const int r = idx / C4, c4 = idx % C4;
             f32x4 v = zero4;
             if (r < nrows) v = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)(n0 + r) * H + c4 * 4);
-            planes_store4(pl, r * LDH + c4 * 4, v, amax);
+            planes_store4(pl, r * LDH + c4 * 4, v, site_m);
         }
+        site_close(amax, site_m);
         __syncthreads();
     }
     TSD_TRACE_AT(5);
@@ -968,6 +972,7 @@ __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, fl
         static_assert(TT * C4 % NT == 0, "tile / block mismatch");
         static_assert(NIT == 4 * RB, "ld16_wait4 names four registers");
         f32x4 v[RB][4];  // (sc1: in the one-launch forward the rows were stored by other workgroups of this launch)
+        float site_m = 0.0f;  // (max |a| of one conversion site: split16.hpp site_close)
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
@@ -979,8 +984,9 @@ __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, fl
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            planes_store4(pl, r * LDH + c4 * 4, r < nrows ? v[it / 4][it % 4] : z, amax);
+            planes_store4(pl, r * LDH + c4 * 4, r < nrows ? v[it / 4][it % 4] : z, site_m);
         }
+        site_close(amax, site_m);
     }
     __syncthreads();
     TSD_TRACE_AT(1);
@@ -1052,6 +1058,7 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
         constexpr int NIT = T * C4 / NT;
         static_assert(NIT == 4, "ld16_wait4 names four registers");
         f32x4 v[NIT];  // (sc1: see filter_role_h)
+        float site_m = 0.0f;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
@@ -1061,8 +1068,9 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
-            planes_store4(pl, r * LDH + c4 * 4, v[it], amax);
+            planes_store4(pl, r * LDH + c4 * 4, v[it], site_m);
         }
+        site_close(amax, site_m);
         hgemm_ring_start<1, H>(rg, q.w0b, H, col0);  // (behind the staging: its registers are free now)
         __syncthreads();
         hzero(accm, accx);

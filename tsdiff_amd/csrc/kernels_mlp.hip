@@ -1185,6 +1185,47 @@ int launch_pack_weights16(const tsd_model_cfg& c, const float* packed, float* pa
     if ((r = split_mats(packed + L.out_w0f, packed16 + L.out_w0f, H, H, 1, 0, st))) return r;
     return TSD_OK;
 }
+// Pre-flight of a weight arena for the split-f16 arithmetic: over n floats, out[0] = max |w|, out[1] = number of non-zero
+// weights below 2^-14 (the f16 normal range: their hi plane is subnormal, the value keeps ~1.5e-11 absolute precision
+// instead of 22 bits), out[2] = number beyond 65504 (not representable: the forward would report TSD_STATUS_RANGE),
+// out[3] = n.  One workgroup-level reduction per block, atomics on four words (max on the non-negative bit pattern).
+__global__ void weights_preflight_kernel(const float* __restrict__ w, size_t n, float* __restrict__ out) {
+    float mx = 0.0f;
+    unsigned small = 0, big = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float a = fabsf(w[i]);
+        mx = fmaxf(mx, a);
+        small += (a != 0.0f && a < 6.103515625e-05f) ? 1u : 0u;
+        big += (!(a <= F16_MAX)) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, off));
+        small += __shfl_xor(small, off);
+        big += __shfl_xor(big, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(mx));
+        atomicAdd(reinterpret_cast<unsigned*>(out) + 4, small);
+        atomicAdd(reinterpret_cast<unsigned*>(out) + 5, big);
+    }
+}
+__global__ void weights_preflight_finish(float* out, size_t n) {
+    const unsigned* c = reinterpret_cast<const unsigned*>(out) + 4;
+    out[1] = (float)c[0];
+    out[2] = (float)c[1];
+    out[3] = (float)n;
+}
+int launch_weights_preflight(const float* w, size_t n, float* out8, hipStream_t st) {
+    TSD_HIP(hipMemsetAsync(out8, 0, 8 * sizeof(float), st));
+    if (n > 0) {
+        hipLaunchKernelGGL(weights_preflight_kernel, dim3(256), dim3(256), 0, st, w, n, out8);
+        TSD_LAUNCH_CHECK("weights_preflight");
+    }
+    hipLaunchKernelGGL(weights_preflight_finish, dim3(1), dim3(1), 0, st, out8, n);
+    TSD_LAUNCH_CHECK("weights_preflight_finish");
+    return TSD_OK;
+}
 int launch_bucket_weights16(const tsd_model_cfg& c, const float* bucket, int num_slots, float* out16, hipStream_t st) {
     if (num_slots <= 0) return TSD_OK;
     const size_t H = c.hidden, per = H * H + H;

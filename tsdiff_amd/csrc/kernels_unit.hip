@@ -263,12 +263,14 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
             f32x16 accm[2][1], accx[2][1];
             {   // (a) attribute tile -> planes (rows that are no pair: zeros)
                 TSD_UNIT_GEOM
+                float site_m = 0.0f;  // (max |a| of this conversion site: split16.hpp site_close)
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     const int r = wave + it * (NT / 64);
                     const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
-                    planes_store4(pl, r * LDH + lane * 4, (vlive >> it & 1u) ? v[it] : zz, amax);
+                    planes_store4(pl, r * LDH + lane * 4, (vlive >> it & 1u) ? v[it] : zz, site_m);
                 }
+                site_close(amax, site_m);
                 hgemm_ring_start<1, H>(rg, nn0_w, H, col0);
             }
             __syncthreads();
@@ -426,8 +428,10 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
         };
         {
             TSD_UNIT_GEOM
+            float site_m = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) planes_store4(pl, (k * 8 + wave) * LDH + lane * 4, agg[k], amax);
+            for (int k = 0; k < 8; ++k) planes_store4(pl, (k * 8 + wave) * LDH + lane * 4, agg[k], site_m);
+            site_close(amax, site_m);
             hgemm16_ring_start<CB16, H>(rn, Wl + A.o_lin2_w, H, col0);
         }
         __syncthreads();
@@ -663,6 +667,7 @@ __global__ __launch_bounds__(4 * H) void unit_encoder_pp_kernel(UnitArgs A) {
             constexpr int NITP = UT / 8;
             f32x4 v[NITP];
             unsigned uu[NITP];
+            float site_m = 0.0f;
 #pragma unroll
             for (int it = 0; it < NITP; ++it) uu[it] = s_u[team * UT + tw + it * 8];
 #pragma unroll
@@ -671,8 +676,9 @@ __global__ __launch_bounds__(4 * H) void unit_encoder_pp_kernel(UnitArgs A) {
 #pragma unroll
             for (int it = 0; it < NITP; ++it) {
                 const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
-                planes_store4(pl, (tw + it * 8) * LDH + lane * 4, uu[it] != 0xffffu ? v[it] : zz, amax);
+                planes_store4(pl, (tw + it * 8) * LDH + lane * 4, uu[it] != 0xffffu ? v[it] : zz, site_m);
             }
+            site_close(amax, site_m);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -876,11 +882,13 @@ __global__ __launch_bounds__(4 * H) void unit_encoder_pp_kernel(UnitArgs A) {
                 {   // v -> planes of the team's buffer; then, every older global access of the wave complete (the agg stores
                     // above are what the other team's next accumulate step reads), the first k-steps of nn.0's weights
                     TSD_PP_GEOM
+                    float site_m = 0.0f;
 #pragma unroll
                     for (int it = 0; it < NITP; ++it) {
                         const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
-                        planes_store4(pl, (tw + it * 8) * LDH + lane * 4, (vlive >> it & 1u) ? v[it] : zz, amax);
+                        planes_store4(pl, (tw + it * 8) * LDH + lane * 4, (vlive >> it & 1u) ? v[it] : zz, site_m);
                     }
+                    site_close(amax, site_m);
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -919,12 +927,14 @@ __global__ __launch_bounds__(4 * H) void unit_encoder_pp_kernel(UnitArgs A) {
     (void)q; (void)l15; (void)col0;
             {
                 TSD_PPN_GEOM
+                float site_m = 0.0f;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const int at = kk * 16 + wave;
                     const f32x4 a4 = at < na ? *reinterpret_cast<const f32x4*>(G + (size_t)at * H + lane * 4) : zero4;
-                    planes_store4(pn, at * LDH + lane * 4, a4, amax);
+                    planes_store4(pn, at * LDH + lane * 4, a4, site_m);
                 }
+                site_close(amax, site_m);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 hgemm16_ring_start<CB16, H>(rn, Wl + A.o_lin2_w, H, col0);
             }

@@ -91,6 +91,24 @@ __device__ __forceinline__ void planes_store4(const Planes& p, int off, const f3
     *reinterpret_cast<f16x4*>(p.hi + off) = h;
     *reinterpret_cast<f16x4*>(p.lo + off) = l;
 }
+// LOW side of the range.  An operand below 2^-14 has a subnormal high plane; its value is then carried by the scaled low
+// plane with an ABSOLUTE precision of 2^-36 = 1.5e-11 instead of 22 relative bits, i.e. worse than fp32's 2^-24 relative
+// below |a| = 2^-12 = 2.4e-4.  Single such elements do not matter (their absolute error drowns in the sum); a tensor whose
+// values are ALL that small does -- measured: attribute rows at 1e-5 followed by 1e5-scale weights put edge_inv 1.4e-5
+// from the fp64 evaluation (tests/test_gpu_round4.py).  So every conversion SITE (one tensor of one tile) keeps its own
+// max |a| `m` of the elements this thread converts and closes with site_close: the site's max goes into the role's
+// running max, and a site whose non-zero values all lie below 2^-12 turns that max into +inf, i.e. the role reports
+// TSD_STATUS_RANGE and the host reruns the call on the fp32-MFMA kernels.  Sites are the conversions in which a thread
+// holds SEVERAL CHANNELS of several rows (attribute rows, aggregates, h copies, h_i * h_j: 4 consecutive channels x 2-8
+// rows per thread): what matters is a ROW of the A operand that is tiny throughout, and a thread that sees nothing but
+// tiny values across channels and rows is the cheap witness of it.  The column-wise epilogue sites (one channel per
+// thread: ssp / swish outputs) keep the plain running max -- a single dead channel is harmless there (its absolute error
+// drowns in the row sums) and must not switch the arithmetic.  Exact zeros -- rows past the end of a list, atoms without
+// neighbours -- are not counted.
+constexpr float SPLIT_LOW = 2.44140625e-04f;  // 2^-12
+__device__ __forceinline__ void site_close(float& amax, float m) {
+    amax = fmaxf(amax, (m > 0.0f && m < SPLIT_LOW) ? __builtin_inff() : m);
+}
 // the range flag of a workgroup role: any thread that converted a value beyond the f16 range (or a NaN's neighbour inf)
 __device__ __forceinline__ void range_report(float amax, int32_t* status) {
     if (status != nullptr && !(amax <= F16_MAX)) atomicOr(status, TSD_STATUS_RANGE);

@@ -477,6 +477,11 @@ class DeviceBatch:
         if word & _lib.STATUS_RANGE:
             if self.gemm_mode() != "h2":
                 raise _lib.TsdError("internal: TSD_STATUS_RANGE from an fp32 forward")
+            import warnings
+            warnings.warn("tsdiff_amd: an activation left the range the split-f16 arithmetic covers (|a| > 65504, or a tile "
+                          "of operands entirely below 2^-12); this batch now runs on the fp32-input MFMA kernels (same "
+                          "results, about half the speed).  model.preflight_split_f16() reports how the weights sit.",
+                          RuntimeWarning, stacklevel=3)
             self.gemm = "f32"
         return True
 

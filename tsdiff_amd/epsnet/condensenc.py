@@ -143,6 +143,19 @@ class CondenseEncoderEpsNetwork(nn.Module):
             self._packed_key = key
         return self._packed
 
+    def preflight_split_f16(self):
+        """How this checkpoint's weights sit in the f16 range of the split-f16 arithmetic (tsd_weights16_preflight over the
+        packed arena, folded matrices included): {'max_abs', 'below_f16_normal' (non-zero |w| < 2^-14: absolute instead
+        of 22-bit relative precision), 'beyond_f16_range' (> 65504: the forward would fall back to fp32 at once), 'count'}.
+        One small kernel and one host read; call it once after load_state_dict."""
+        import ctypes as C
+        from .. import _lib
+        packed = self.packed_weights()
+        out = torch.zeros(8, dtype=torch.float32, device=packed.device)
+        _lib.check(_lib.load().tsd_weights16_preflight(_lib.ptr(packed), packed.numel(), _lib.ptr(out), _lib.stream_ptr()))
+        o = out.cpu()
+        return {"max_abs": float(o[0]), "below_f16_normal": int(o[1]), "beyond_f16_range": int(o[2]), "count": int(o[3])}
+
     def device_batch(self, atom_type, r_feat, p_feat, bond_index, bond_type, batch, num_nodes_per_graph=None,
                      defer_status=False):
         # cache of the last two batches, keyed on the identity (TensorImpl) and version of the input tensors; the
