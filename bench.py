@@ -494,7 +494,7 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist, prefet
         loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
                               g["batch"], g["num_nodes_per_graph"], graphs)
         used[0] = model._batches[0][2]
-        mean = dp_backward(model, loss)
+        mean = dp_backward(model, loss, always_reduce=dist is not None)  # (one rank under torch.distributed.run: RCCL still runs)
         optim.clip_grad_norm_(model.parameters(), 3000.0)
         opt.step()
         if not reuse_batch:

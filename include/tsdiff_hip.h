@@ -531,6 +531,16 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
                        const float* pos, float* workspace, size_t workspace_floats, const int32_t* counts_host,
                        const float* dloss, float* grad, void* stream);
 
+/* The same call for a data-parallel caller (reference train.py:138-145 on N GPUs): `blocks_done_event` (a hipEvent_t,
+ * or NULL) is recorded on `stream` as soon as every gradient of the interaction blocks is final -- the contiguous range
+ * tsd_train_grad_buckets reports ({offset, count, total} floats of the flat gradient: 83 % of it for the shipped config) --
+ * so that their all-reduce can start on another stream beside the embedding's backward chain; the rest of the vector is
+ * final when the call's last kernel is. */
+int tsd_train_grad_buckets(const tsd_model_cfg* cfg, size_t* out /* [3] host */);
+int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* raw, const int64_t* atom_type,
+                        const float* pos, float* workspace, size_t workspace_floats, const int32_t* counts_host,
+                        const float* dloss, float* grad, void* blocks_done_event, void* stream);
+
 /* ---- optimizer step on the flat vectors (reference train.py:144-145, utils/common.py:58-68) ---------------
  * tsd_grad_norm_clip: norm[0] = |grad|_2 (fixed-order two-stage sum, deterministic), then -- max_norm > 0 --
  * grad *= min(1, max_norm / (norm + 1e-6)), torch.nn.utils.clip_grad_norm_'s rule; scratch: 1024 floats.

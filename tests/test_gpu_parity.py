@@ -1194,7 +1194,10 @@ def test_dp_backward_flat_gradient_path_on_the_real_model(dev):
     loss = model.get_loss(*args, **kw)
     mean = dp_backward(model, loss, reduce_fn=twice)
     n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
-    assert model._last_reduce == "flat-in-place" and calls == [2, n_params]   # 2 scalars, then ONE flat buffer
+    # 2 scalars, then the ONE flat buffer in three ranges: the interaction blocks' gradients early (beside the rest of the
+    # backward pass, on a side stream), then head and tail
+    assert model._last_reduce == "flat-in-place, blocks early" and calls[0] == 2 and len(calls) == 4
+    assert sum(calls[1:]) == n_params and calls[1] == max(calls[1:])
     assert abs(float(mean) - float(loss.mean())) < 1e-6 * abs(float(loss.mean()))
     # sum over "two ranks" of d(sum loss_r / 2N)/dp = d(mean loss)/dp: identical to the single-process gradient
     for k, p in model.named_parameters():

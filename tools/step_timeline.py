@@ -14,7 +14,8 @@ def main(path, marker="pair_count"):
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     gx = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols else None)
     wx = "workgroup_x" if "workgroup_x" in cols else ("workgroup_size_x" if "workgroup_size_x" in cols else None)
-    sel = "name, start, end" + (f", {gx}" if gx else ", 0") + (f", {wx}" if wx else ", 1")
+    qx = next((c_ for c_ in ("stream_id", "queue_id", "stream", "queue") if c_ in cols), None)  # the HIP stream of a launch
+    sel = "name, start, end" + (f", {gx}" if gx else ", 0") + (f", {wx}" if wx else ", 1") + (f", {qx}" if qx else ", 0")
     rows = c.execute(f"select {sel} from kernels order by start").fetchall()
     marks = [i for i, r in enumerate(rows) if marker in r[0]]
     if len(marks) < 2:
@@ -25,11 +26,13 @@ def main(path, marker="pair_count"):
     prev_end = t0
     print(f"# one step of `{path.split('/')[-1]}`: {b - a} launches, {(rows[b][1] - t0) / 1e3:.1f} us "
           f"(kernel time {sum(r[2] - r[1] for r in rows[a:b]) / 1e3:.1f} us)\n")
-    print("| # | start us | dur us | gap us | workgroups | kernel |")
-    print("|---:|---:|---:|---:|---:|---|")
-    for k, (n, s, e, g, w) in enumerate(rows[a:b]):
+    print("| # | start us | dur us | gap us | workgroups | stream | kernel |")
+    print("|---:|---:|---:|---:|---:|---:|---|")
+    streams = {}
+    for k, (n, s, e, g, w, q) in enumerate(rows[a:b]):
         n = n if len(n) < 100 else n[:97] + "..."
-        print(f"| {k} | {(s - t0) / 1e3:.1f} | {(e - s) / 1e3:.1f} | {(s - prev_end) / 1e3:.1f} | {g // max(w, 1)} | `{n}` |")
+        sid = streams.setdefault(q, len(streams))
+        print(f"| {k} | {(s - t0) / 1e3:.1f} | {(e - s) / 1e3:.1f} | {(s - prev_end) / 1e3:.1f} | {g // max(w, 1)} | {sid} | `{n}` |")
         prev_end = max(prev_end, e)
 
 

@@ -191,6 +191,8 @@ SIGNATURES = {
     "tsd_train_workspace_floats": (C.c_size_t, [_CFG, C.c_int32, C.c_int32]),
     "tsd_train_forward": (C.c_int, [_CFG, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P]),
     "tsd_train_backward": (C.c_int, [_CFG, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P, _P]),
+    "tsd_train_backward2": (C.c_int, [_CFG, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P, _P, _P]),
+    "tsd_train_grad_buckets": (C.c_int, [_CFG, C.POINTER(C.c_size_t)]),
     "tsd_forward_work": (C.c_int, [_CFG, C.c_int32, C.c_int64, C.c_int64, C.c_int64, C.POINTER(Work)]),
     "tsd_grad_norm_clip": (C.c_int, [C.c_int64, _P, C.c_float, _P, _P, _P]),
     "tsd_adam_step": (C.c_int, [C.c_int64, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,

@@ -752,9 +752,25 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
     return TSD_OK;
 }
 
+int tsd_train_grad_buckets(const tsd_model_cfg* cfg, size_t* out) {
+    TSD_REQUIRE(cfg != nullptr && out != nullptr, "null pointer");
+    const RawLayout R = raw_layout(*cfg);
+    out[0] = R.layer0;
+    out[1] = R.layer_stride * (size_t)cfg->num_convs;
+    out[2] = R.total;
+    return TSD_OK;
+}
+
 int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* raw, const int64_t* atom_type,
                        const float* pos, float* workspace, size_t workspace_floats, const int32_t* counts_host,
                        const float* dloss, float* grad, void* stream) {
+    return tsd_train_backward2(cfg, batch, raw, atom_type, pos, workspace, workspace_floats, counts_host, dloss, grad, nullptr,
+                               stream);
+}
+
+int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* raw, const int64_t* atom_type,
+                        const float* pos, float* workspace, size_t workspace_floats, const int32_t* counts_host,
+                        const float* dloss, float* grad, void* blocks_done_event, void* stream) {
     TraceRange range("tsd:train_backward");
     hipStream_t st = (hipStream_t)stream;
     TSD_REQUIRE(dloss && grad && atom_type && pos, "null pointer");
@@ -876,6 +892,10 @@ int tsd_train_backward(const tsd_model_cfg* cfg, const tsd_batch* batch, const f
             TSD_TRY(launch_wgrad_batch((int)dYs.size(), Eu, H, H, dYs.data(), Xs.data(), dWs.data(), dbs.data(), 1, w.wpart, st));
         }
     }
+    // every gradient of the interaction blocks (tsd_train_grad_buckets: 83 % of the flat vector) is final here: a
+    // data-parallel caller starts their all-reduce on another stream behind this event, beside the embedding's backward
+    // chain and the node-embedding gradients below
+    if (blocks_done_event != nullptr) TSD_HIP(hipEventRecord((hipEvent_t)blocks_done_event, st));
     const float* dz = dh_cur;  // d loss / d h_0
     if (batch_wg) {
         TSD_TRY(embed_bwd_fused(x, g, w.d_ea));

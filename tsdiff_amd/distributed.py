@@ -61,7 +61,7 @@ def _all_reduce_sum(t, group=None):
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
-def dp_backward(model, loss_nodes, group=None, reduce_fn=None):
+def dp_backward(model, loss_nodes, group=None, reduce_fn=None, always_reduce=False):
     """Backward of the reference's `loss.mean()` (train.py:140-143) over the GLOBAL batch.
 
     `loss_nodes` is this rank's (N_r, 1) per-node loss.  The reference averages over all nodes of the
@@ -74,8 +74,15 @@ def dp_backward(model, loss_nodes, group=None, reduce_fn=None):
 
     `reduce_fn(tensor)` replaces the in-place sum all-reduce (tests: a reducer that emulates a second rank
     exercises the flat-gradient path of the real model on one GPU); with it the reduction runs whether or not
-    a process group exists."""
-    distributed = reduce_fn is not None or (dist.is_initialized() and dist.get_world_size(group) > 1)
+    a process group exists.  `always_reduce`: run the collectives on a one-rank group too (bench.py under
+    `torch.distributed.run --nproc-per-node 1`: the timeline of the overlap below on a 1-GPU lease).
+
+    OVERLAP.  The fused training step's backward (one C call) reports, through an event, the moment the gradients of
+    the interaction blocks are final -- one contiguous range of the flat vector, 83 % of it; their all-reduce starts
+    right there on a side stream and runs beside the rest of the backward pass (the embedding's backward chain, the
+    node-embedding gradients); the two remaining ranges (head and tail of the vector) are reduced when the backward has
+    finished.  Three collectives per step in a fixed order on every rank."""
+    distributed = reduce_fn is not None or (dist.is_initialized() and (always_reduce or dist.get_world_size(group) > 1))
     reduce = reduce_fn if reduce_fn is not None else (lambda t: _all_reduce_sum(t, group))
     # (new_full is a fill kernel: torch.tensor(x, device=cuda) would be a synchronous host-to-device copy, i.e.
     # a hidden stream sync between the forward and the backward pass)
@@ -83,7 +90,11 @@ def dp_backward(model, loss_nodes, group=None, reduce_fn=None):
     stats = torch.stack([total.detach(), loss_nodes.new_full((), float(loss_nodes.shape[0]))])
     if distributed:
         reduce(stats)
-    (total / stats[1]).backward()
+    model._dp_early_reduce = reduce if distributed else None
+    try:
+        (total / stats[1]).backward()
+    finally:
+        model._dp_early_reduce = None
     if distributed:
         params = [p for p in model.parameters() if p.requires_grad]
         flat = getattr(model, "_flat_grad", None)
@@ -91,8 +102,19 @@ def dp_backward(model, loss_nodes, group=None, reduce_fn=None):
                                     flat.untyped_storage().data_ptr() for p in params) and \
                 sum(p.numel() for p in params) == flat.numel():
             # the fused training step hands out views of ONE flat gradient buffer: reduce it in place
-            reduce(flat)
-            model._last_reduce = "flat-in-place"
+            early = getattr(model, "_dp_early_done", None)
+            if early is not None:  # the blocks' range is already on its way on the side stream: head and tail now
+                side, off, cnt = early
+                if off > 0:
+                    reduce(flat[:off])
+                if off + cnt < flat.numel():
+                    reduce(flat[off + cnt:])
+                torch.cuda.current_stream(flat.device).wait_stream(side)
+                model._dp_early_done = None
+                model._last_reduce = "flat-in-place, blocks early"
+            else:
+                reduce(flat)
+                model._last_reduce = "flat-in-place"
         else:
             for p in params:
                 if p.grad is None:

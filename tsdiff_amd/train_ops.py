@@ -559,8 +559,29 @@ class FusedTrainLoss(torch.autograd.Function):
         grad = torch.empty_like(ctx.raw)
         dloss = _c(dloss.float()).view(-1)
         b = db.train_struct()
-        check(lib.tsd_train_backward(C.byref(cfg), C.byref(b), ptr(ctx.raw), ptr(db.atom_type), ptr(ctx.pos),
-                                     ptr(ctx.ws), ctx.ws.numel(), ctx.counts, ptr(dloss), ptr(grad), stream_ptr()))
+        # data-parallel step (distributed.dp_backward set `_dp_early_reduce`): the interaction blocks' gradients -- one
+        # contiguous range, 83 % of the vector -- are final long before the call's last kernel; the library records an
+        # event there and their all-reduce starts on a side stream beside the embedding's backward chain
+        early = getattr(ctx.model, "_dp_early_reduce", None)
+        ev = None
+        if early is not None:
+            ev = torch.cuda.Event()
+            ev.record()  # (creates the hipEvent_t; the library records it again where the bucket is complete)
+        check(lib.tsd_train_backward2(C.byref(cfg), C.byref(b), ptr(ctx.raw), ptr(db.atom_type), ptr(ctx.pos),
+                                      ptr(ctx.ws), ctx.ws.numel(), ctx.counts, ptr(dloss), ptr(grad),
+                                      C.c_void_p(ev.cuda_event) if ev is not None else None, stream_ptr()))
+        ctx.model._dp_early_done = None
+        if early is not None:
+            lay = (C.c_size_t * 3)()
+            check(lib.tsd_train_grad_buckets(C.byref(cfg), lay))
+            off, cnt = int(lay[0]), int(lay[1])
+            from .engine import _side_stream
+            side = _side_stream(grad.device)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                early(grad[off:off + cnt])
+            grad.record_stream(side)
+            ctx.model._dp_early_done = (side, off, cnt)
         views = [g.view(s) for g, s in zip(grad.split(ctx.sizes), ctx.shapes)]  # views of ONE flat buffer
         ctx.model._flat_grad = grad  # (distributed.dp_backward all-reduces it in place)
         return (None, None, None, None, None) + tuple(views)
