@@ -2,7 +2,7 @@
 # All profile artefacts of a round in one gpurun call:   gpurun -- 'bash tools/profile_round.sh r02'
 # Writes gpurun_out/<tag>_*: kernel-trace stats (c2, c5, train), HBM traffic PMC passes (c2, c5: FETCH_SIZE and
 # WRITE_SIZE in separate passes), SQ issue/stall/MFMA-busy counters (c2, c5; MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch time x clock)).  Copy what is to be judged to profiles/.
-TAG=${1:-r02}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 db() { ls $1/*/*results.db $1/*results.db 2>/dev/null | head -1; }
 B="--no-cpu-baseline --no-extras --no-f32"
@@ -49,7 +49,10 @@ python3 tools/mfma_busy.py c2=$(db /tmp/p_sq) c5=$(db /tmp/p_sq5) train=$(db /tm
   python3 tools/pmc_kernel_table.py $(db /tmp/p_sq) typed_embed
   python3 tools/pmc_kernel_table.py $(db /tmp/p_sq) step_tail
   echo '```'; echo; echo "## configs[4] (1024 x 64 atoms)"; echo '```'
+  python3 tools/pmc_kernel_table.py $(db /tmp/p_sq5) unit_encoder
   python3 tools/pmc_kernel_table.py $(db /tmp/p_sq5) layer_combo
+  python3 tools/pmc_kernel_table.py $(db /tmp/p_sq5) pair_output
+  python3 tools/pmc_kernel_table.py $(db /tmp/p_sq5) typed_embed
   python3 tools/pmc_kernel_table.py $(db /tmp/p_sq5) cfconv_aggregate
   echo '```'
 } > gpurun_out/${TAG}_sq_counters.md
