@@ -582,16 +582,20 @@ __device__ __forceinline__ void hgemm_ring_run_part(HRing<CB, R>& r, const Plane
 }
 
 
-template <int H>
-__global__ __launch_bounds__(4 * H) void unit_encoder_pp_kernel(UnitArgs A) {
-    static_assert(H == 256, "the unit encoder is built for hidden 256 (two teams of eight waves)");
+// TEAMS = 2: the lock-step form described above (1024 threads).  TEAMS = 1: ONE team per workgroup (512 threads, 128 VGPRs,
+// 80 KB of LDS), so that TWO workgroups -- two units -- share a CU and the hardware interleaves their phases instruction by
+// instruction (a team that waits for its x / agg rows or its attribute fetch does not hold a barrier the other one needs).
+template <int H, int TEAMS>
+__global__ __launch_bounds__(TEAMS * 2 * H, TEAMS == 1 ? 4 : 2) void unit_encoder_pp_kernel(UnitArgs A) {
+    static_assert(H == 256 && (TEAMS == 1 || TEAMS == 2), "the unit encoder is built for hidden 256 (teams of eight waves)");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int LDH = ldh_of(H), LDA = H + 4, NT = 4 * H, C4 = H / 4;
-    constexpr int RB16 = UNA / 16, CB16 = 1;  // (node chain: sixteen waves x 16 columns)
+    constexpr int LDH = ldh_of(H), LDA = H + 4, NT = TEAMS * 2 * H, C4 = H / 4, NW = NT / 64;
+    constexpr int RB16 = UNA / 16, CB16 = 1;  // (node chain: 16 columns per wave and pass)
+    constexpr int NPASS = H / (NW * 16);      // column passes of the node chain's GEMMs (16 waves: 1, 8 waves: 2)
     constexpr int KS = H / 16;
     float* tile0 = smem;                             // team 0: planes / fp32 filter tile
-    float* tile1 = tile0 + UT * LDH;                 // team 1
-    float* s_c = tile1 + UT * LDH;                   // [U_ROWS] cutoff weight per tile row
+    float* tile1 = tile0 + (TEAMS - 1) * UT * LDH;   // team 1 (TEAMS = 1: the same buffer)
+    float* s_c = tile0 + TEAMS * UT * LDH;                   // [U_ROWS] cutoff weight per tile row
     uint16_t* s_u = reinterpret_cast<uint16_t*>(s_c + U_ROWS);  // [U_ROWS] local pair index of the tile row, 0xffff: none
 
     const int u = blockIdx.x;
@@ -646,7 +650,7 @@ __global__ __launch_bounds__(4 * H) void unit_encoder_pp_kernel(UnitArgs A) {
     float* tile = team == 0 ? tile0 : tile1;
     const Planes pl = planes_at(tile, UT, LDH);
     float* buf = tile;
-    const int nt_team = (ntile - team + 1) >> 1;  // tiles of this team: t = 2 k + team
+    const int nt_team = (ntile - team + TEAMS - 1) / TEAMS;  // tiles of this team: t = TEAMS k + team
 
     for (int l = A.l_begin; l < A.l_end; ++l) {
         const float* Wl = Wm + A.layer0 + (size_t)l * A.layer_stride;
@@ -690,9 +694,9 @@ __global__ __launch_bounds__(4 * H) void unit_encoder_pp_kernel(UnitArgs A) {
             tJ = 1;
             if (tJ == nb) { tI = 1; tJ = 1; }
         }
-        auto next_tile = [&]() {  // two tiles on
+        auto next_tile = [&]() {  // TEAMS tiles on
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
+            for (int s2 = 0; s2 < TEAMS; ++s2)
                 if (++tJ == nb) {
                     ++tI;
                     tJ = tI;
@@ -701,14 +705,18 @@ __global__ __launch_bounds__(4 * H) void unit_encoder_pp_kernel(UnitArgs A) {
         // Team 1 runs one slot behind team 0: it idles through one slot first, team 0 through one at the end; in between
         // both walk whole tile cycles (GEMM nn.0 | ssp | GEMM nn.2 | filter, accumulate, next planes), three barriers per
         // slot, the same number of barriers in every wave.
-        const int ncyc = (ntile + 1) >> 1;
-        if (team == 1) {
+        const int ncyc = (ntile + TEAMS - 1) / TEAMS;
+        if (TEAMS == 2 && team == 1) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_barrier();
         }
+        // (the barriers INSIDE a GEMM / the ssp epilogue exist for the other team's steps: none with one team)
+        auto mid_barrier = [&]() {
+            if constexpr (TEAMS == 2) __builtin_amdgcn_s_barrier();
+        };
         for (int k = 0; k < ncyc; ++k) {
-            const int t = 2 * k + team;
+            const int t = TEAMS * k + team;
             if (k >= nt_team) {   // (team 1 when the tile count is odd)
 #pragma unroll
                 for (int i = 0; i < 12; ++i) __builtin_amdgcn_s_barrier();
@@ -730,9 +738,9 @@ __global__ __launch_bounds__(4 * H) void unit_encoder_pp_kernel(UnitArgs A) {
                 }
                 hzero(accm, accx);
                 hgemm_ring_run_part<2, 1, H, 0, 4>(rg, pl, LDH, accm, accx);
-                __builtin_amdgcn_s_barrier();
+                mid_barrier();
                 hgemm_ring_run_part<2, 1, H, 4, 9>(rg, pl, LDH, accm, accx);
-                __builtin_amdgcn_s_barrier();
+                mid_barrier();
                 hgemm_ring_run_part<2, 1, H, 9, KS>(rg, pl, LDH, accm, accx);
             };
             {   // ---- slot 0: GEMM nn.0 in three parts
@@ -760,9 +768,9 @@ __global__ __launch_bounds__(4 * H) void unit_encoder_pp_kernel(UnitArgs A) {
                 };
                 // (the planes are free: every wave of the team left GEMM nn.0 at the barrier that ended its slot)
                 static_for<0, 8>(elem);
-                __builtin_amdgcn_s_barrier();
+                mid_barrier();
                 static_for<8, 18>(elem);
-                __builtin_amdgcn_s_barrier();
+                mid_barrier();
                 static_for<18, 32>(elem);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -777,7 +785,7 @@ __global__ __launch_bounds__(4 * H) void unit_encoder_pp_kernel(UnitArgs A) {
             UTRACE(2);
             {   // ---- slot 3: filter tile -> LDS | accumulate | next tile's planes
                 __builtin_amdgcn_s_setprio(2);
-                const bool more = k + 1 < nt_team;
+                const bool more = k + 1 < nt_team;  // (the team's next tile: t + TEAMS)
                 const bool diag = tI == tJ;
                 const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
                 // accumulate step, side 0 (the pair's j side: row tw of block J, partners = block I): its x rows are requested
@@ -864,7 +872,7 @@ __global__ __launch_bounds__(4 * H) void unit_encoder_pp_kernel(UnitArgs A) {
                     if (more) {
                         unsigned uu[NITP];
 #pragma unroll
-                        for (int it = 0; it < NITP; ++it) uu[it] = s_u[(t + 2) * UT + tw + it * 8];
+                        for (int it = 0; it < NITP; ++it) uu[it] = s_u[(t + TEAMS) * UT + tw + it * 8];
 #pragma unroll
                         for (int it = 0; it < NITP; ++it) {
                             vlive |= (uu[it] != 0xffffu ? 1u : 0u) << it;
@@ -897,7 +905,7 @@ __global__ __launch_bounds__(4 * H) void unit_encoder_pp_kernel(UnitArgs A) {
                 UTRACE_COUNT(8);
             }
         }
-        if (team == 0) {
+        if (TEAMS == 2 && team == 0) {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_s_barrier();
@@ -906,75 +914,76 @@ __global__ __launch_bounds__(4 * H) void unit_encoder_pp_kernel(UnitArgs A) {
         // the barrier that ended its slot)
         __syncthreads();
 
-        // ---- node chain of block l (all eight waves; the arithmetic of the kernel above) on team 0's buffer ----
+        // ---- node chain of block l (all waves; the arithmetic of the kernel above) on team 0's buffer.  A wave owns 16 output
+        // columns per pass (16 waves: one pass; 8 waves: two -- with 32 columns per wave the accumulators of four row blocks
+        // do not fit 128 registers); a pass leaves its results as combined values (hval4) until every wave is done reading
+        // the planes the epilogue overwrites ----
         {
             const Planes pn = planes_at(tile0, UT, LDH);
             const bool last = l + 1 == A.L;
-            HRing<CB16, HRING16_R> rn;
-            f32x4 am[RB16][CB16], ax[RB16][CB16];
-            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-            auto zero_n = [&]() {
-#pragma unroll
-                for (int rb = 0; rb < RB16; ++rb)
-#pragma unroll
-                    for (int cb = 0; cb < CB16; ++cb) am[rb][cb] = ax[rb][cb] = zero4;
-            };
+            float vals[NPASS][RB16][4];
 #define TSD_PPN_GEOM                                                      \
     const int tq = opaque(tid);                                           \
     const int wave = tq >> 6, lane = tq & 63;                             \
-    const int col0 = wave * 16;                                           \
     const int q = lane >> 4, l15 = lane & 15;                             \
-    (void)q; (void)l15; (void)col0;
+    (void)q; (void)l15; (void)wave;
+            auto gemm_n = [&](const float* wmat) {  // vals = planes x wmat^T, this wave's columns of every pass
+                TSD_PPN_GEOM
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    HRing<CB16, HRING16_R> rn;
+                    f32x4 am[RB16][CB16], ax[RB16][CB16];
+                    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                    hgemm16_ring_start<CB16, H>(rn, wmat, H, (wave * NPASS + ps) * 16);
+#pragma unroll
+                    for (int rb = 0; rb < RB16; ++rb) am[rb][0] = ax[rb][0] = zero4;
+                    hgemm16_ring_run_rb<RB16, CB16, H>(rn, pn, LDH, am, ax, nrb);
+#pragma unroll
+                    for (int rb = 0; rb < RB16; ++rb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vals[ps][rb][r] = hval4(am[rb][0], ax[rb][0], r);
+                }
+            };
             {
                 TSD_PPN_GEOM
+                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
                 float site_m = 0.0f;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int at = kk * 16 + wave;
+                for (int kk = 0; kk < UNA / NW; ++kk) {
+                    const int at = kk * NW + wave;
                     const f32x4 a4 = at < na ? *reinterpret_cast<const f32x4*>(G + (size_t)at * H + lane * 4) : zero4;
                     planes_store4(pn, at * LDH + lane * 4, a4, site_m);
                 }
                 site_close(amax, site_m);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                hgemm16_ring_start<CB16, H>(rn, Wl + A.o_lin2_w, H, col0);
             }
             __syncthreads();
-            {
-                TSD_PPN_GEOM
-                zero_n();
-                hgemm16_ring_run_rb<RB16, CB16, H>(rn, pn, LDH, am, ax, nrb);
-                hgemm16_ring_start<CB16, H>(rn, Wl + A.o_lin_w, H, col0);
-            }
+            gemm_n(Wl + A.o_lin2_w);
             __syncthreads();
             {
                 TSD_PPN_GEOM
 #pragma unroll
-                for (int cb = 0; cb < CB16; ++cb) {
-                    const float b = Wl[A.o_lin2_b + col0 + cb * 16 + l15];
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int c = (wave * NPASS + ps) * 16 + l15;
+                    const float b = Wl[A.o_lin2_b + c];
 #pragma unroll
                     for (int rb = 0; rb < RB16; ++rb)
                         if (rb < nrb) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
-                                planes_store1(pn, (rb * 16 + q * 4 + r) * LDH + col0 + cb * 16 + l15,
-                                              sspf(hval4(am[rb][cb], ax[rb][cb], r) + b), amax);
+                                planes_store1(pn, (rb * 16 + q * 4 + r) * LDH + c, sspf(vals[ps][rb][r] + b), amax);
                         }
                 }
             }
             __syncthreads();
-            {
-                TSD_PPN_GEOM
-                zero_n();
-                hgemm16_ring_run_rb<RB16, CB16, H>(rn, pn, LDH, am, ax, nrb);
-                if (!last) hgemm16_ring_start<CB16, H>(rn, Wl + A.layer_stride + A.o_lin1, H, col0);
-            }
+            gemm_n(Wl + A.o_lin_w);
             __syncthreads();
             {
                 TSD_PPN_GEOM
                 const float* h_in = (l == 0 ? A.z + m * A.nh_stride : hm) + (size_t)n0 * H;
 #pragma unroll
-                for (int cb = 0; cb < CB16; ++cb) {
-                    const int c = col0 + cb * 16 + l15;
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int c = (wave * NPASS + ps) * 16 + l15;
                     const float b = Wl[A.o_lin_b + c];
 #pragma unroll
                     for (int rb = 0; rb < RB16; ++rb)
@@ -984,35 +993,35 @@ __global__ __launch_bounds__(4 * H) void unit_encoder_pp_kernel(UnitArgs A) {
                                 const int row = rb * 16 + q * 4 + r;
                                 float hn = 0.0f;
                                 if (row < na) {
-                                    hn = h_in[(size_t)row * H + c] + (hval4(am[rb][cb], ax[rb][cb], r) + b);
+                                    hn = h_in[(size_t)row * H + c] + (vals[ps][rb][r] + b);
                                     hm[(size_t)(n0 + row) * H + c] = hn;
                                 }
                                 if (!last) planes_store1(pn, row * LDH + c, hn, amax);
                             }
                         }
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             if (last) {
                 UTRACE(6);
                 break;
             }
             __syncthreads();
+            gemm_n(Wl + A.layer_stride + A.o_lin1);
             {
                 TSD_PPN_GEOM
-                zero_n();
-                hgemm16_ring_run_rb<RB16, CB16, H>(rn, pn, LDH, am, ax, nrb);
                 // x1 of the next block: to memory (the accumulate steps of the next block read it from there)
 #pragma unroll
-                for (int rb = 0; rb < RB16; ++rb)
-                    if (rb < nrb) {
+                for (int ps = 0; ps < NPASS; ++ps)
 #pragma unroll
-                        for (int cb = 0; cb < CB16; ++cb)
+                    for (int rb = 0; rb < RB16; ++rb)
+                        if (rb < nrb) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int row = rb * 16 + q * 4 + r;
-                                if (row < na) X[(size_t)row * H + col0 + cb * 16 + l15] = hval4(am[rb][cb], ax[rb][cb], r);
+                                if (row < na) X[(size_t)row * H + (wave * NPASS + ps) * 16 + l15] = vals[ps][rb][r];
                             }
-                    }
+                        }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             __syncthreads();
@@ -1025,7 +1034,7 @@ __global__ __launch_bounds__(4 * H) void unit_encoder_pp_kernel(UnitArgs A) {
     UTRACE_FLUSH_PP;
 }
 
-size_t unit_encoder_pp_lds(int H) { return ((size_t)2 * UT * ldh_of(H) + U_ROWS) * 4 + (size_t)U_ROWS * 2; }
+size_t unit_encoder_pp_lds(int H, int teams) { return ((size_t)teams * UT * ldh_of(H) + U_ROWS) * 4 + (size_t)U_ROWS * 2; }
 
 size_t unit_encoder_lds(int H) {
     return ((size_t)UNA * H + (size_t)UT * ldh_of(H) + U_ROWS) * 4 + (size_t)U_ROWS * 2;
@@ -1034,7 +1043,7 @@ size_t unit_encoder_lds(int H) {
 bool unit_encoder_supported(const tsd_model_cfg& c) { return c.hidden == 256; }
 
 int launch_unit_encoder(const tsd_model_cfg& c, const tsd_batch& b, const float* W16, const float* ea, size_t ea_stride,
-                        float* h, size_t nh_stride, int l_begin, int l_end, float* x1_io, float* agg_io, bool pingpong,
+                        float* h, size_t nh_stride, int l_begin, int l_end, float* x1_io, float* agg_io, int pingpong,
                         int32_t* status, hipStream_t st) {
     if (!unit_encoder_supported(c) || b.unit_node == nullptr || b.num_units <= 0) {
         set_error("internal: the fused encoder needs hidden 256 and the batch's unit partition");
@@ -1076,16 +1085,23 @@ int launch_unit_encoder(const tsd_model_cfg& c, const tsd_batch& b, const float*
     A.x1_io = x1_io;
     A.agg_io = agg_io;
     A.status = status;
-    if (pingpong) {  // (every unit one graph of more than 32 atoms: the caller's knowledge)
+    if (pingpong != 0) {  // (every unit ONE graph: the caller's knowledge)  1: two independent workgroups per CU; 2: lock-step teams
         if (x1_io == nullptr || agg_io == nullptr) {
-            set_error("internal: the ping-pong encoder needs its x1 / agg rows");
+            set_error("internal: this form of the encoder needs its x1 / agg rows");
             return TSD_ERR_INVALID;
         }
-        const size_t lds = unit_encoder_pp_lds(c.hidden);
-        static DeviceOnce once;
-        int r = allow_lds(unit_encoder_pp_kernel<256>, lds, once);
-        if (r) return r;
-        hipLaunchKernelGGL(unit_encoder_pp_kernel<256>, dim3(b.num_units, b.num_models), dim3(1024), lds, st, A);
+        const size_t lds = unit_encoder_pp_lds(c.hidden, pingpong);
+        if (pingpong == 1) {
+            static DeviceOnce once;
+            int r = allow_lds(unit_encoder_pp_kernel<256, 1>, lds, once);
+            if (r) return r;
+            hipLaunchKernelGGL((unit_encoder_pp_kernel<256, 1>), dim3(b.num_units, b.num_models), dim3(512), lds, st, A);
+        } else {
+            static DeviceOnce once;
+            int r = allow_lds(unit_encoder_pp_kernel<256, 2>, lds, once);
+            if (r) return r;
+            hipLaunchKernelGGL((unit_encoder_pp_kernel<256, 2>), dim3(b.num_units, b.num_models), dim3(1024), lds, st, A);
+        }
         TSD_LAUNCH_CHECK("unit_encoder_pp");
         return TSD_OK;
     }

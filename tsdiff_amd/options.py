@@ -13,7 +13,7 @@ at import, by `TSDIFF_*` environment variables (read here and nowhere else); tes
 | wide_filter_tiles  | TSDIFF_WIDE_FILTER_TILES  | True    | 64-row filter tiles where a block launch is many chip-fulls deep; False: 32-row tiles everywhere |
 | fused_step_tail    | TSDIFF_FUSED_TAIL         | True    | sampling loop: update + next step's edge lists as one launch; False: three launches |
 | fused_encoder      | TSDIFF_FUSED_ENCODER      | True    | chip-full launches (big batches, ensembles): the whole SchNet encoder as ONE launch of per-unit workgroups that never write the CFConv filters to memory (kernels_unit.hip); False: one launch per block with materialised filters; "force": also where the one-launch form would apply.  Bit-identical (the messages are added in the directed list's order) |
-| pingpong           | TSDIFF_PINGPONG           | False   | fused encoder on units that are single graphs of > 32 atoms: sixteen waves per workgroup in two teams, one on the matrix pipes while the other runs the VALU / LDS phases of its tile (unit_encoder_pp_kernel); False: eight waves walk one tile's phases together.  Bit-identical; measured equal within 1 % at configs[4], so the simpler form is the default |
+| pingpong           | TSDIFF_PINGPONG           | False   | form of the fused encoder on units that are single graphs of > 32 atoms: False = eight waves own a CU and walk one tile's phases together (unit_encoder_kernel); "solo" = block tiles with x1 / agg in memory at 128 VGPRs / 80 KB: two units per CU, interleaved by the hardware; "teams" = the same in lock step, two teams of eight waves in one workgroup, one on the matrix pipes while the other runs its VALU / LDS steps (unit_encoder_pp_kernel).  Bit-identical; measurements in DESIGN.md 4c |
 """
 import os
 from dataclasses import dataclass
@@ -32,14 +32,15 @@ class Options:
     wide_filter_tiles: bool = True
     fused_step_tail: bool = True
     fused_encoder: bool = True
-    pingpong: bool = False
+    pingpong: object = False
 
     @classmethod
     def from_env(cls):
         o = cls(gemm=os.environ.get("TSDIFF_GEMM", "h2"), typed_tiles=_flag("TSDIFF_TYPED_TILES"),
                 one_launch=_flag("TSDIFF_ONE_LAUNCH"), wide_filter_tiles=_flag("TSDIFF_WIDE_FILTER_TILES"),
                 fused_step_tail=_flag("TSDIFF_FUSED_TAIL"), fused_encoder=_flag("TSDIFF_FUSED_ENCODER"),
-                pingpong=_flag("TSDIFF_PINGPONG", False))
+                pingpong={"0": False, "solo": "solo", "teams": "teams", "1": "teams"}.get(
+                    os.environ.get("TSDIFF_PINGPONG", "0"), False))
         o.validate()
         return o
 
