@@ -3,7 +3,7 @@ import numpy as np, torch
 ROOT = "/root/repo"
 sys.path.insert(0, ROOT)
 from tsdiff_amd import _lib, engine, synth
-_lib.LIB_PATH = os.path.join(ROOT, "tools", "bin", "lib_utrace.so")
+_lib.LIB_PATH = os.environ.get("TSDIFF_LIB", os.path.join(ROOT, "tools", "bin", "lib_utrace.so"))
 from bench import make_models, to_dev
 from tsdiff_amd.sampler import EnsembleSampler
 dev = torch.device("cuda:0")

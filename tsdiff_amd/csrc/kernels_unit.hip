@@ -137,6 +137,7 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
     float* s_c = tile + UT * LDH;                    // [U_ROWS] cutoff weight per tile row (list mode: row = local pair index)
     uint16_t* s_u = reinterpret_cast<uint16_t*>(s_c + U_ROWS);  // [U_ROWS] list mode: local (i | j << 8) of the pair;
                                                                 // block mode: local pair index of the tile row, 0xffff: none
+    uint16_t* s_tile = s_u + U_ROWS;                 // [64] block mode: blocks (I * 16 + J) of tile t
     const Planes pl = planes_at(tile, UT, LDH);
     float* buf = tile;
 
@@ -170,7 +171,6 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
 
     // ---- per-unit staging: cutoff weights and end points / pair indices of the tile rows, x1 of block l_begin ----
     if (blk) {
-        const int gpair = A.pair_ptr[n0];  // (ordered pair k of atom i: the k-th OTHER atom of the graph)
         for (int idx = tid; idx < ntile * UT; idx += NT) {
             int tt = idx >> 6, I = 0;
             while (tt >= nb - I) {
@@ -178,15 +178,27 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
                 ++I;
             }
             const int J = I + tt, pr = idx & 63;
-            const int i = I * 8 + (pr >> 3), j = J * 8 + (pr & 7);
+            int a = pr >> 3, b = pr & 7;
+            bool row_ok = true;
+            if (I == J) {   // a DIAGONAL tile is 32 rows: the 28 pairs a < b of the block in the order (0,1) .. (0,7) (1,2) ..
+                row_ok = pr < 28;
+                int q = pr;
+                a = 0;
+                while (row_ok && q >= 7 - a) {
+                    q -= 7 - a;
+                    ++a;
+                }
+                b = a + 1 + q;
+            }
+            const int i = I * 8 + a, j = J * 8 + b;
             int loc = -1;
-            if (i < j && j < na) {
+            if (row_ok && i < j && j < na) {
                 const int uu = A.pair2u[A.pair_ptr[n0 + i] + j - 1];
-                (void)gpair;
                 if (uu >= e0 && uu < e1) loc = uu - e0;
             }
             s_u[idx] = (uint16_t)(loc < 0 ? 0xffff : loc);
             s_c[idx] = loc < 0 ? 0.0f : cutoff_weight(A.eu.dist[e0 + loc], A.conv_cutoff, A.smooth);
+            if (pr == 0) s_tile[idx >> 6] = (uint16_t)(I * 16 + J);
         }
     } else {
         for (int e = tid; e < ne; e += NT) {
@@ -236,13 +248,16 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
             TSD_UNIT_GEOM
             vlive = 0;
             if (blk) {
+                const unsigned ij = s_tile[t];
+                const int nit = (ij >> 4) == (ij & 15u) ? NIT / 2 : NIT;  // (a diagonal tile: 32 rows)
                 unsigned uu[NIT];
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) uu[it] = s_u[t * UT + wave + it * (NT / 64)];
+                for (int it = 0; it < NIT; ++it) uu[it] = it < nit ? (unsigned)s_u[t * UT + wave + it * (NT / 64)] : 0xffffu;
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
                     vlive |= (uu[it] != 0xffffu ? 1u : 0u) << it;
-                    v[it] = *reinterpret_cast<const f32x4*>(ea + (size_t)(uu[it] == 0xffffu ? 0u : uu[it]) * H + lane * 4);
+                    if (it < nit)
+                        v[it] = *reinterpret_cast<const f32x4*>(ea + (size_t)(uu[it] == 0xffffu ? 0u : uu[it]) * H + lane * 4);
                 }
             } else {
                 const int nr = min(UT, ne - t * UT);
@@ -256,80 +271,122 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
         };
         if (ntile > 0) fetch(0);
         UTRACE(7);
-        int tI = 0, tJ = 0;  // block mode: the tile's blocks (uniform counters)
         for (int t = 0; t < ntile; ++t) {
             const int nrows = blk ? UT : min(UT, ne - t * UT);
-            HRing<1, HRING_R> rg;
+            const unsigned tij = blk ? (unsigned)s_tile[t] : 1u;
+            const int tI = (int)(tij >> 4), tJ = (int)(tij & 15u);  // block mode: the tile's blocks
+            const bool diag = blk && tI == tJ;                      // ... a diagonal tile: 32 rows (28 pairs)
             f32x16 accm[2][1], accx[2][1];
-            {   // (a) attribute tile -> planes (rows that are no pair: zeros)
-                TSD_UNIT_GEOM
-                float site_m = 0.0f;  // (max |a| of this conversion site: split16.hpp site_close)
+            // phases (a) .. (f) on RB 32-row blocks (2: a full tile; 1: a diagonal tile of block mode)
+            auto phases = [&](auto rbc) {
+                constexpr int RB = decltype(rbc)::value;
+                HRing<1, HRING_R> rg;
+                {   // (a) attribute tile -> planes (rows that are no pair: zeros)
+                    TSD_UNIT_GEOM
+                    float site_m = 0.0f;  // (max |a| of this conversion site: split16.hpp site_close)
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int r = wave + it * (NT / 64);
-                    const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
-                    planes_store4(pl, r * LDH + lane * 4, (vlive >> it & 1u) ? v[it] : zz, site_m);
-                }
-                site_close(amax, site_m);
-                hgemm_ring_start<1, H>(rg, nn0_w, H, col0);
-            }
-            __syncthreads();
-            UTRACE(0);
-            {   // (b) GEMM nn.0
-                TSD_UNIT_GEOM
-                hzero(accm, accx);
-                hgemm_ring_run<2, 1, H>(rg, pl, LDH, accm, accx);
-                hgemm_ring_start<1, H>(rg, nn2_w, H, col0);
-            }
-            __syncthreads();
-            UTRACE(1);
-            // (e) the NEXT tile's attribute rows are requested here: the loads are issued under the VALU work of the
-            // epilogue (64 KB through the CU's address path is ~1000 cycles of issue) and have the whole epilogue to come
-            // back in -- they are older than every refill of GEMM nn.2's weight ring, whose counted waits (in-order
-            // return) would otherwise stall on an HBM round trip; the ring's first three k-steps were issued before them
-            if (t + 1 < ntile) fetch(t + 1);
-            {   // (c) shifted softplus -> planes (one base per plane, the 32 rows of a lane at constant offsets from it)
-                TSD_UNIT_GEOM
-                f16* hb = pl.hi + opaque(4 * hi * LDH + col);
-                f16* lb = pl.lo + opaque(4 * hi * LDH + col);
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float y = sspf(hval(accm[rb][0], accx[rb][0], r) + b0);
-                        f16 yh, yl;
-                        amax_upd(amax, y);
-                        split1(y, yh, yl);
-                        hb[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = yh;
-                        lb[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = yl;
+                    for (int it = 0; it < NIT * RB / 2; ++it) {
+                        const int r = wave + it * (NT / 64);
+                        const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
+                        planes_store4(pl, r * LDH + lane * 4, (vlive >> it & 1u) ? v[it] : zz, site_m);
                     }
-            }
-            __syncthreads();
-            UTRACE(2);
-            {   // (d) GEMM nn.2
-                hzero(accm, accx);
-                hgemm_ring_run<2, 1, H>(rg, pl, LDH, accm, accx);
-            }
-            __syncthreads();
-            UTRACE(3);
-            {   // (f) W = (nn.2 + b) * C as fp32 rows over the planes (the cutoff weights of four consecutive rows by one
-                // 16-byte LDS read, all of a row block's up front: stores to `buf` and loads of `s_c` would otherwise be
-                // kept in program order, one LDS round trip per element)
-                TSD_UNIT_GEOM
-                float* wb = buf + opaque(4 * hi * LDA + col);
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) {
-                    f32x4 cw[4];
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) cw[g4] = *reinterpret_cast<const f32x4*>(s_c + t * UT + rb * 32 + 8 * g4 + 4 * hi);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        wb[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LDA] = (hval(accm[rb][0], accx[rb][0], r) + b2) * cw[r >> 2][r & 3];
+                    site_close(amax, site_m);
+                    hgemm_ring_start<1, H>(rg, nn0_w, H, col0);
+#ifdef TSD_UNIT_WFAKE  // (timing experiment, wrong results: every k-step reads the same 2 KB per wave -- weights from L1)
+                    rg.step_bytes = 0;
+#endif
                 }
-            }
-            __syncthreads();
-            UTRACE(4);
-            if (blk) {   // (g) block mode: wave w adds the 8 partners of row J*8 + w (J side), then of row I*8 + w (I side)
+                __syncthreads();
+                UTRACE(0);
+                f32x16(&am)[RB][1] = reinterpret_cast<f32x16(&)[RB][1]>(accm);
+                f32x16(&ax)[RB][1] = reinterpret_cast<f32x16(&)[RB][1]>(accx);
+                {   // (b) GEMM nn.0
+                    TSD_UNIT_GEOM
+                    hzero(am, ax);
+                    hgemm_ring_run<RB, 1, H>(rg, pl, LDH, am, ax);
+                    hgemm_ring_start<1, H>(rg, nn2_w, H, col0);
+#ifdef TSD_UNIT_WFAKE
+                    rg.step_bytes = 0;
+#endif
+                }
+                __syncthreads();
+                UTRACE(1);
+                // (e) the NEXT tile's attribute rows are requested here: the loads are issued under the VALU work of the
+                // epilogue (64 KB through the CU's address path is ~1000 cycles of issue) and have the whole epilogue to
+                // come back in -- they are older than every refill of GEMM nn.2's weight ring, whose counted waits
+                // (in-order return) would otherwise stall on an HBM round trip; the ring's first three k-steps were
+                // issued before them
+                if (t + 1 < ntile) fetch(t + 1);
+                {   // (c) shifted softplus -> planes (one base per plane, the rows of a lane at constant offsets from it)
+                    TSD_UNIT_GEOM
+                    f16* hb = pl.hi + opaque(4 * hi * LDH + col);
+                    f16* lb = pl.lo + opaque(4 * hi * LDH + col);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float y = sspf(hval(am[rb][0], ax[rb][0], r) + b0);
+                            f16 yh, yl;
+                            amax_upd(amax, y);
+                            split1(y, yh, yl);
+                            hb[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = yh;
+                            lb[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = yl;
+                        }
+                }
+                __syncthreads();
+                UTRACE(2);
+                {   // (d) GEMM nn.2
+                    hzero(am, ax);
+                    hgemm_ring_run<RB, 1, H>(rg, pl, LDH, am, ax);
+                }
+                __syncthreads();
+                UTRACE(3);
+                {   // (f) W = (nn.2 + b) * C as fp32 rows over the planes (the cutoff weights of four consecutive rows by one
+                    // 16-byte LDS read, all of a row block's up front: stores to `buf` and loads of `s_c` would otherwise be
+                    // kept in program order, one LDS round trip per element)
+                    TSD_UNIT_GEOM
+                    float* wb = buf + opaque(4 * hi * LDA + col);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) {
+                        f32x4 cw[4];
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) cw[g4] = *reinterpret_cast<const f32x4*>(s_c + t * UT + rb * 32 + 8 * g4 + 4 * hi);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            wb[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LDA] = (hval(am[rb][0], ax[rb][0], r) + b2) * cw[r >> 2][r & 3];
+                    }
+                }
+                __syncthreads();
+                UTRACE(4);
+            };
+            if (diag) phases(IntC<1>{});
+            else phases(IntC<2>{});
+            if (diag) {   // (g) a diagonal tile: row w of the block takes its partners below it (tile rows (a, w), a < w), then above
+                TSD_UNIT_GEOM
+                const float* wrow = buf + lane * 4;
+                const float* xrow = x1s + (tI * 8) * H + lane * 4;
+                const int wq = __builtin_amdgcn_readfirstlane(wave);
+                f32x4 a4 = agg[tI];
+#pragma unroll
+                for (int a = 0; a < 7; ++a)
+                    if (a < wq) {   // pair (a, w): tile row a (15 - a) / 2 + (w - a - 1)
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + (a * (15 - a) / 2 + (wq - a - 1)) * LDA);
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + a * H);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) a4[c] = __fadd_rn(a4[c], __fmul_rn(xv[c], wv[c]));
+                    }
+                const int off_w = wq * (15 - wq) / 2 - wq - 1;
+#pragma unroll
+                for (int b = 1; b < 8; ++b)
+                    if (b > wq) {   // pair (w, b): tile row w (15 - w) / 2 + (b - w - 1)
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + (off_w + b) * LDA);
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(xrow + b * H);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) a4[c] = __fadd_rn(a4[c], __fmul_rn(xv[c], wv[c]));
+                    }
+                agg[tI] = a4;
+            } else
+            if (blk) {   // (g) block mode, I < J: wave w adds the 8 partners of row J*8 + w (J side), then of row I*8 + w (I side)
                 TSD_UNIT_GEOM
                 const float* wrow = buf + lane * 4;
                 const float* xrow = x1s + lane * 4;
@@ -359,10 +416,6 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
 #pragma unroll
                         for (int s = 0; s < 4; ++s) a4[s] = __fadd_rn(a4[s], __fmul_rn(xv[b][s], wv[b][s]));
                     agg[tI] = a4;
-                }
-                if (++tJ == nb) {
-                    ++tI;
-                    tJ = tI;
                 }
             } else {   // (g) list mode: wave w owns the rows r with r % 8 == w (agg[r / 8], 4 columns per lane).  A row's
                 // partners below it come from pairs (i, r) -- the row is the pair's j -- and precede, in list order, its
@@ -1037,7 +1090,7 @@ __global__ __launch_bounds__(TEAMS * 2 * H, TEAMS == 1 ? 4 : 2) void unit_encode
 size_t unit_encoder_pp_lds(int H, int teams) { return ((size_t)teams * UT * ldh_of(H) + U_ROWS) * 4 + (size_t)U_ROWS * 2; }
 
 size_t unit_encoder_lds(int H) {
-    return ((size_t)UNA * H + (size_t)UT * ldh_of(H) + U_ROWS) * 4 + (size_t)U_ROWS * 2;
+    return ((size_t)UNA * H + (size_t)UT * ldh_of(H) + U_ROWS) * 4 + (size_t)U_ROWS * 2 + 64 * 2;
 }
 
 bool unit_encoder_supported(const tsd_model_cfg& c) { return c.hidden == 256; }
