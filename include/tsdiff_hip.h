@@ -56,6 +56,9 @@ extern "C" {
 #define TSD_ERR_HIP (-2)         /* a HIP runtime call failed; see tsd_last_error() */
 #define TSD_ERR_UNSUPPORTED (-3) /* e.g. a graph with more than TSD_MAX_GRAPH_NODES atoms */
 #define TSD_ERR_NAN (-4)         /* reported through status words, mapped to FloatingPointError */
+#define TSD_ERR_RANGE (-5)       /* tsd_train_backward2 of a split-f16 step (tsd_batch.reserved bit 5) whose forward raised
+                                    TSD_STATUS_RANGE: nothing was launched; run tsd_train_forward again without the bit
+                                    (same workspace, same loss buffer), then the backward */
 
 #define TSD_EDGE_TILE 32         /* edges per workgroup tile of every per-edge kernel */
 #define TSD_NODE_TILE 16         /* nodes per workgroup tile of the per-node kernels */

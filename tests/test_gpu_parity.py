@@ -11,6 +11,8 @@ import numpy as np
 import pytest
 import torch
 
+from tsdiff_amd.options import OPTIONS
+
 from tests.util import assert_close, batch_inputs, load_golden
 
 pytestmark = pytest.mark.gpu
@@ -470,7 +472,7 @@ def test_fused_training_step_equals_op_by_op(dev, monkeypatch):
         noise = torch.randn_like(g["pos"])
         res = {}
         for mode in ("fused", "ops"):
-            monkeypatch.setenv("TSDIFF_TRAIN", mode)
+            monkeypatch.setattr(OPTIONS, "train", mode)
             model = make_model(cfg, 1, dev)
             model.train()
             loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
@@ -481,7 +483,7 @@ def test_fused_training_step_equals_op_by_op(dev, monkeypatch):
                          {k: p.grad.cpu().numpy() for k, p in model.named_parameters() if p.grad is not None})
         assert_close(res["fused"][0], res["ops"][0], 2e-6, "loss fused vs op-by-op")
         # the fused step has no atomics: a second evaluation gives bit-identical gradients
-        monkeypatch.setenv("TSDIFF_TRAIN", "fused")
+        monkeypatch.setattr(OPTIONS, "train", "fused")
         model = make_model(cfg, 1, dev)
         model.train()
         loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
@@ -927,7 +929,7 @@ def _grad_tol_check(got, ref, name, rtol=2e-5):
 def test_every_gradient_elementwise_vs_reference_golden(mode, dev, monkeypatch):
     """loss.mean().backward() of the reference (train.py:140-143): EVERY parameter gradient, element by element,
     against the unchanged reference's autograd (golden grads_synth_b4_small) -- both training paths"""
-    monkeypatch.setenv("TSDIFF_TRAIN", mode)
+    monkeypatch.setattr(OPTIONS, "train", mode)
     d, meta = load_golden("grads_synth_b4_small")
     g = to_dev(batch_inputs(d), dev)
     model = make_model(meta["cfg"], meta["seed"], dev)
@@ -1327,7 +1329,7 @@ def test_fused_training_step_variants_equal_op_by_op(variant, dev, monkeypatch):
     noise = torch.randn(g["pos"].shape, generator=gen).to(dev)
     res = {}
     for mode in ("fused",) if variant == "no_pairs" else ("fused", "ops"):
-        monkeypatch.setenv("TSDIFF_TRAIN", mode)
+        monkeypatch.setattr(OPTIONS, "train", mode)
         model = make_model(cfg, 3, dev)
         model.train()
         loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],

@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 import torch
 
+from tsdiff_amd.options import OPTIONS
+
 from tests.test_gpu_parity import _dense_batch, _sample, _sampling_setup, make_model, to_dev
 
 pytestmark = pytest.mark.gpu
@@ -155,7 +157,7 @@ def test_training_step_batch200_full_model(dev, monkeypatch):
     pn = torch.randn(t["pos"].shape, generator=gen)
     res = {}
     for mode in ("fused", "ops", "fused2"):
-        monkeypatch.setenv("TSDIFF_TRAIN", "ops" if mode == "ops" else "fused")
+        monkeypatch.setattr(OPTIONS, "train", "ops" if mode == "ops" else "fused")
         model = make_model(cfg, 1, dev)
         model.train()
         loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
@@ -441,7 +443,7 @@ def test_training_step_random_topologies_fused_vs_op_by_op_and_oracle(hidden, co
         tag = f"trial {trial}: G={G} N={N} orders {cfg['edge_order']}/{cfg['pred_edge_order']} cutoff {cfg['edge_cutoff']}"
         res = {}
         for mode in ("fused", "ops"):
-            monkeypatch.setenv("TSDIFF_TRAIN", mode)
+            monkeypatch.setattr(OPTIONS, "train", mode)
             model = make_model(cfg, 3, dev)
             model.train()
             loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],

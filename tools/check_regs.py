@@ -21,6 +21,8 @@ BUDGET = [
     (r"typed_embed_h_kernelILi256E", 128, 0),
     (r"layer_combo_kernelILi256ELb0ELb[01]ELi1E", 128, 0),  # split-f16 block launches (all filter-tile widths)
     (r"pair_output_h_kernelILi256E", 128, 0),
+    (r"layer_combo_kernelILi256ELb1ELb0ELi1ELi1E", 128, 0),  # split-f16 block launch of the training step (saving form)
+    (r"block_bwd_kernelILi256E", 128, 0),                    # backward block launch, fp32 and split-f16 filter chains
     (r"unit_encoder_kernelILi256E", 256, 0),
     # sixteen waves per workgroup: 128 registers; a few loop-invariant values of the per-block prologue may sit in scratch
     # (six scratch instructions per block, none inside the tile cycle)

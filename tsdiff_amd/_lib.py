@@ -14,6 +14,7 @@ TSD_ERR_INVALID = -1
 TSD_ERR_HIP = -2
 TSD_ERR_UNSUPPORTED = -3
 TSD_ERR_NAN = -4
+TSD_ERR_RANGE = -5
 
 EDGE_TILE = 32
 EDGE_PAD = 8  # TSD_EDGE_PAD: spare entries every tsd_edges array carries past its capacity

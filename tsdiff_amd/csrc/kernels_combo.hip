@@ -821,8 +821,9 @@ __device__ __forceinline__ void pair_role(const ComboPre& q, int tile, int node_
 // node_role / filter_role / pair_role above -- same inputs and outputs in memory (fp32), same LDS tile shapes -- with
 // every GEMM operand tile held in LDS as two f16 planes and every weight matrix read from the f16-plane arena.
 // -------------------------------------------------------------------------------------------------
-template <int H>
-__device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float* smem, int32_t* range_status TSD_TRACE_ARG) {
+template <int H, bool SAVE = false>
+__device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float* smem, int32_t* range_status,
+                                            const NodeSave& ns TSD_TRACE_ARG) {
     constexpr int LDH = ldh_of(H);
     constexpr int NT = 2 * H, CB16 = 2, C4 = H / 4;
     const Planes pl = planes_at(smem, TN, LDH);
@@ -851,7 +852,8 @@ __device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float*
                 h_res[cb][r] = row < nrows ? a.h_in[(size_t)(n0 + row) * H + col] : 0.0f;
             }
         }
-        aggregate_tile<H, false, 2 * H / 64, 8, true>(a.row_ptr, a.dst, a.umap, a.Wf, a.x1_in, a.N, n0, smem, nullptr, &amax);
+        aggregate_tile<H, SAVE, 2 * H / 64, 8, true>(a.row_ptr, a.dst, a.umap, a.Wf, a.x1_in, a.N, n0, smem,
+                                                      SAVE ? ns.agg : nullptr, &amax);
         hgemm16_ring_start<CB16, H>(rg, a.lin2_w, H, col0);  // (after the gather: its registers are the gather's)
         TSD_TRACE_WAVE(16);
         __syncthreads();
@@ -868,7 +870,16 @@ __device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float*
             const int col = col0 + cb * 16 + l15;
             const float b = b_lin2[cb];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) planes_store1(pl, (q * 4 + r) * LDH + col, sspf(hval4(accm[cb], accx[cb], r) + b), amax);
+            for (int r = 0; r < 4; ++r) {
+                const float v = hval4(accm[cb], accx[cb], r) + b, sv = sspf(v);
+                planes_store1(pl, (q * 4 + r) * LDH + col, sv, amax);
+                if constexpr (SAVE) {  // (the training step keeps the pre-activation and the activation: as node_role)
+                    if (q * 4 + r < nrows) {
+                        ns.x2[(size_t)(n0 + q * 4 + r) * H + col] = v;
+                        ns.xs[(size_t)(n0 + q * 4 + r) * H + col] = sv;
+                    }
+                }
+            }
         }
         __syncthreads();
         TSD_TRACE_AT(3);
@@ -938,8 +949,9 @@ __device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float*
 
 // RB = 32-row blocks of one tile: 1 in the small launches (more, shorter tiles), 2 where a launch is many chip-fulls
 // of filter tiles (a weight fragment from the ring then feeds two row blocks: the tile is bound by the weight feed).
-template <int H, int RB>
-__device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, float* smem, int32_t* range_status TSD_TRACE_ARG) {
+template <int H, int RB, bool SAVE = false>
+__device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, float* smem, int32_t* range_status,
+                                              const FilterSave& fsv TSD_TRACE_ARG) {
     constexpr int TT = T * RB;
     const int g = f.g_begin + item;
     const int lrel = g / f.tiles_per_layer, tile = g - lrel * f.tiles_per_layer;
@@ -1001,8 +1013,18 @@ __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, fl
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            planes_store1(pl, (rb * T + acc_row(r, hi)) * LDH + col, sspf(hval(accm[rb][0], accx[rb][0], r) + b0), amax);
+        for (int r = 0; r < 16; ++r) {
+            const int row = rb * T + acc_row(r, hi);
+            const float v = hval(accm[rb][0], accx[rb][0], r) + b0, sv = sspf(v);
+            planes_store1(pl, row * LDH + col, sv, amax);
+            if constexpr (SAVE) {  // the training step keeps every block's filters and activations: slot = block
+                if (row < nrows) {
+                    const size_t o = (size_t)lrel * f.wf_layer_stride + (size_t)(e0 + row) * H + col;
+                    fsv.f0[o] = v;
+                    fsv.fs[o] = sv;
+                }
+            }
+        }
     __syncthreads();
     TSD_TRACE_AT(3);
 
@@ -1294,6 +1316,7 @@ struct FilterBwd {
     float cutoff;
     int smooth;
     float *dWf, *df0, *d_ea;
+    float* amax;  // split-f16 form: [2] running max |dWf|, max |df0| of the block (non-negative floats, atomicMax), or NULL
 };
 template <int H>
 __device__ __forceinline__ void filter_bwd_role(const FilterBwd& f, int tile, float* smem) {
@@ -1373,9 +1396,140 @@ __device__ __forceinline__ void filter_bwd_role(const FilterBwd& f, int tile, fl
     }
 }
 
+// The same chain on the f16 MFMA pipes (split16.hpp, GRADIENT operands): the dWf tile is converted row by row scaled to
+// [1, 2) (a row is held by ONE wave during staging: the row max is a wave reduction), df0 with one scale per tile (its
+// rows are spread over the waves: the tile max goes through LDS beside the barrier the planes need anyway); W2t16 / W0t16
+// are the f16-plane images of the dgrad matrices (pack mode 4).  The running maxima of dWf and df0 (true values) go to
+// amax[0] (as a power-of-two floor: within a factor 2) / amax[1]: the batched weight-gradient launch scales its dY operands by them.
+template <int H>
+__device__ __forceinline__ void filter_bwd_role_h(const FilterBwd& f, int tile, float* smem) {
+    constexpr int TT = 32, LDH = ldh_of(H), NT = 2 * H, C4 = H / 4, NW = NT / 64;
+    const Planes pl = planes_at(smem, TT, LDH);
+    float* s_c = smem + TT * LDH;
+    float* s_inv = s_c + TT;    // [TT] 2^e of the dWf rows
+    float* s_wmax = s_inv + TT; // [NW] per-wave max of the df0 tile
+    int* s_i = reinterpret_cast<int*>(s_wmax + NW);
+    int* s_j = s_i + TT;
+    const int E = *f.eu.count;
+    const int e0 = tile * TT;
+    if (e0 >= E) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int col0 = wave * 32;
+    const int nrows = min(TT, E - e0);
+    if (tid < TT) {
+        const bool v = tid < nrows;
+        s_i[tid] = v ? f.eu.src[e0 + tid] : 0;
+        s_j[tid] = v ? f.eu.dst[e0 + tid] : 0;
+        s_c[tid] = v ? cutoff_weight(f.eu.dist[e0 + tid], f.cutoff, f.smooth) : 0.0f;
+    }
+    __syncthreads();
+    float dummy = 0.0f;
+    {
+        constexpr int NIT = TT * C4 / NT;
+        static_assert(TT * C4 % NT == 0 && (C4 == 64 || C4 == 32), "a row is held by one wave (or half of one)");
+        // (two halves: all sixteen row loads of a thread in flight together hold 64 registers beside the conversion's own)
+        constexpr int HB = NIT;  // (NIT / 2: two halves, 32 registers less in flight)
+        static_assert(NIT % HB == 0, "");
+#pragma unroll
+        for (int h0 = 0; h0 < NIT; h0 += HB) {
+            f32x4 di[HB], dj[HB], xi[HB], xj[HB];
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const int idx = tid + (h0 + k) * NT, r = min(idx / C4, nrows - 1), c4 = idx % C4;
+                const size_t oi = (size_t)s_i[r] * H + c4 * 4, oj = (size_t)s_j[r] * H + c4 * 4;
+                di[k] = *reinterpret_cast<const f32x4*>(f.dagg + oi);
+                dj[k] = *reinterpret_cast<const f32x4*>(f.dagg + oj);
+                xi[k] = *reinterpret_cast<const f32x4*>(f.x1 + oi);
+                xj[k] = *reinterpret_cast<const f32x4*>(f.x1 + oj);
+            }
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const int idx = tid + (h0 + k) * NT, r = idx / C4, c4 = idx % C4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (r < nrows) {
+                    v = (di[k] * xj[k] + dj[k] * xi[k]) * s_c[r];
+                    *reinterpret_cast<f32x4*>(f.dWf + (size_t)(e0 + r) * H + c4 * 4) = v;
+                }
+                float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                m = C4 == 64 ? max64(m) : max32(m);  // the row's max
+                float inv;
+                const float sc = pow2_scale(m, inv);
+                if (c4 == 0) s_inv[r] = inv;
+                planes_store4(pl, r * LDH + c4 * 4, v * sc, dummy);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const int col = col0 + l31;
+    float pre[16];
+    __syncthreads();
+    f32x16 accm[1][1], accx[1][1];
+    hzero(accm, accx);
+    hgemm_tile<1, 1, H, true>(pl, LDH, f.W2t, H, col0, accm, accx);
+    // (the pre-activations, and below the old attribute-gradient values, are read BEHIND the GEMM that precedes their
+    // use: sixteen values held across the MFMA stream put the kernel over the 128-register line of two workgroups
+    // per CU, whose interleaving hides this latency anyway)
+    // (tile base pointers are wave-uniform: SGPR base + one 32-bit lane offset per row, shared by the four accesses below)
+    const float* f0 = f.f0 + (size_t)e0 * H;
+    float* df0 = f.df0 + (size_t)e0 * H;
+    float* d_ea = f.d_ea + (size_t)e0 * H;
+    unsigned off[16];  // bytes: SGPR base + 32-bit lane offset
+    int hi_p = hi;     // (through an asm statement: the offsets and the loads stay behind the GEMM's asm statements)
+    asm volatile("" : "+v"(hi_p));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) off[r] = (unsigned)(min(acc_row(r, hi_p), nrows - 1) * H + col) * 4u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pre[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(f0) + off[r]);
+    float v0[16], m0 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi);
+        v0[r] = 0.0f;
+        if (row < nrows) {
+            v0[r] = hval(accm[0][0], accx[0][0], r) * s_inv[row] * act_deriv(1, pre[r]);
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(df0) + off[r]) = v0[r];
+        }
+        m0 = fmaxf(m0, fabsf(v0[r]));
+    }
+    m0 = max64(m0);
+    if (lane == 0) s_wmax[wave] = m0;
+    __syncthreads();  // (every wave is done reading the planes, the wave maxima are in place)
+    float tmax = s_wmax[0];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) tmax = fmaxf(tmax, s_wmax[k]);
+    float inv2;
+    const float sc2 = pow2_scale(tmax, inv2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) planes_store1(pl, acc_row(r, hi) * LDH + col, v0[r] * sc2, dummy);
+    __syncthreads();
+    hzero(accm, accx);
+    hgemm_tile<1, 1, H, true>(pl, LDH, f.W0t, H, col0, accm, accx);
+    hi_p = hi;
+    asm volatile("" : "+v"(hi_p));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) off[r] = (unsigned)(min(acc_row(r, hi_p), nrows - 1) * H + col) * 4u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pre[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(d_ea) + off[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi);
+        if (row < nrows) *reinterpret_cast<float*>(reinterpret_cast<char*>(d_ea) + off[r]) = pre[r] + hval(accm[0][0], accx[0][0], r) * inv2;
+    }
+    if (f.amax != nullptr) {
+        // (dWf: the rows' power-of-two floors 2^e <= max |row| < 2^(e+1) -- the consumer allows for the factor)
+        if (wave == 0) {
+            const float m = max32(lane < TT && lane < nrows ? s_inv[lane] : 0.0f);
+            if (lane == 0 && m > 0.0f) atomic_amax(f.amax, m);
+        }
+        if (tid == 64) atomic_amax(f.amax + 1, tmax);
+    }
+}
+
 // One launch per block of the backward pass: workgroups [0, node_tiles) run the node chain (the critical path),
 // the rest the filter chain of the same block -- both read d loss / d agg of the block and nothing of each other.
-template <int H>
+// PREC_H2: the filter chain on the f16 MFMA pipes (W2t / W0t are f16-plane images); the node chain stays fp32 (16-row
+// tiles bound by the weight feed, the same bytes in either form)
+template <int H, int PREC = PREC_F32>
 __global__ __launch_bounds__(2 * H) void block_bwd_kernel(NodeBwd a, int node_tiles, FilterBwd f) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
@@ -1383,7 +1537,8 @@ __global__ __launch_bounds__(2 * H) void block_bwd_kernel(NodeBwd a, int node_ti
         __builtin_amdgcn_s_setprio(3);
         node_bwd_role<H>(a, b, smem);
     } else {
-        filter_bwd_role<H>(f, b - node_tiles, smem);
+        if constexpr (PREC == PREC_H2) filter_bwd_role_h<H>(f, b - node_tiles, smem);
+        else filter_bwd_role<H>(f, b - node_tiles, smem);
     }
 }
 // first: the chain starts at dh (top block, no gather); last: it stops at dh_0.  filter_rows == 0: no filter role.
@@ -1391,7 +1546,7 @@ int launch_block_bwd(int H, int N, int first, int last, tsd_edges enc, const flo
                      const float* dh_up, const float* w_lin1_t, const float* w_lin_t, const float* w_lin2_t,
                      const float* x2_prev, float* dx1, float* dh, float* dx2_prev, float* dagg_prev, int filter_rows,
                      tsd_edges enc_u, const float* x1, const float* f0, const float* W2t, const float* W0t, float cutoff,
-                     int smooth, float* dWf, float* df0, float* d_ea, hipStream_t st) {
+                     int smooth, float* dWf, float* df0, float* d_ea, hipStream_t st, float* amax_h2) {
     NodeBwd a{N, first, last, enc.row_ptr, enc.dst, enc.umap, Wf, dagg_in, dh_up, w_lin1_t, w_lin_t, w_lin2_t, x2_prev,
               dx1, dh, dx2_prev, dagg_prev};
     FilterBwd f{};
@@ -1408,17 +1563,21 @@ int launch_block_bwd(int H, int N, int first, int last, tsd_edges enc, const flo
         f.dWf = dWf;
         f.df0 = df0;
         f.d_ea = d_ea;
+        f.amax = amax_h2;
     }
     const int node_tiles = (N + TN - 1) / TN;
     if (node_tiles + f.tiles == 0) return TSD_OK;
+    const bool h2 = amax_h2 != nullptr;  // (then W2t / W0t are f16-plane images)
     const size_t lds_n = (size_t)TN * (H + 4) * 4, lds_f = (size_t)(32 * (H + 4) + 32) * 4 + 2 * 32 * sizeof(int);
-    const size_t lds = lds_n > lds_f ? lds_n : lds_f;
+    const size_t lds_h = (size_t)(32 * ldh_of(H) + 3 * 32) * 4 + 2 * 32 * sizeof(int);
+    const size_t lds = std::max(lds_n, h2 ? lds_h : lds_f);
 #define TSD_NB(HH)                                                                                              \
     {                                                                                                           \
-        static DeviceOnce once;                                                                                 \
-        int r = allow_lds(block_bwd_kernel<HH>, lds, once);                                                     \
+        static DeviceOnce once, once_h;                                                                         \
+        int r = h2 ? allow_lds(block_bwd_kernel<HH, PREC_H2>, lds, once_h) : allow_lds(block_bwd_kernel<HH>, lds, once); \
         if (r) return r;                                                                                        \
-        hipLaunchKernelGGL(block_bwd_kernel<HH>, dim3(node_tiles + f.tiles), dim3(2 * HH), lds, st, a, node_tiles, f); \
+        if (h2) hipLaunchKernelGGL((block_bwd_kernel<HH, PREC_H2>), dim3(node_tiles + f.tiles), dim3(2 * HH), lds, st, a, node_tiles, f); \
+        else hipLaunchKernelGGL(block_bwd_kernel<HH>, dim3(node_tiles + f.tiles), dim3(2 * HH), lds, st, a, node_tiles, f); \
     }
     if (H == 128) TSD_NB(128) else if (H == 256) TSD_NB(256) else {
         set_error("block_bwd: hidden=%d has no MFMA instance", H);
@@ -1475,7 +1634,7 @@ constexpr int NODE_RUN = 4;  // consecutive node tiles kept on one XCD (one 64-a
 // TAIL: the instantiation of the launches that carry a third role behind the filter tiles (the pair MLP of the last
 // block launch, or the pre-GEMM of the piecewise pair output): a kernel of its own name in a profile, and the plain
 // block launches do not carry its code and registers.
-// PREC: PREC_F32 = fp32-input MFMA roles; PREC_H2 = the split-f16 roles (no SAVE form: the training step stays fp32,
+// PREC: PREC_F32 = fp32-input MFMA roles; PREC_H2 = the split-f16 roles (SAVE form: the training step's block launches,
 // and no pre role: the piecewise pair output computes both halves itself).
 // FRB: 32-row blocks per filter tile of the split-f16 filter role (filter_role_h).
 template <int H, bool SAVE, bool TAIL, int PREC = PREC_F32, int FRB = 1>
@@ -1529,7 +1688,7 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
         // they share a SIMD with
         __builtin_amdgcn_s_setprio(3);
         TSD_TRACE_REAL(24);
-        if constexpr (PREC == PREC_H2) node_role_h<H>(a, tile, smem, sd.range_status TSD_TRACE_PASS);
+        if constexpr (PREC == PREC_H2) node_role_h<H, SAVE>(a, tile, smem, sd.range_status, ns TSD_TRACE_PASS);
         else node_role<H, SAVE>(a, tile, smem, ns TSD_TRACE_PASS);
         TSD_TRACE_REAL(25);
     } else {
@@ -1548,7 +1707,7 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
             return;
         }
         TSD_TRACE_REAL(24);
-        if constexpr (PREC == PREC_H2) filter_role_h<H, FRB>(f, item, smem, sd.range_status TSD_TRACE_PASS);
+        if constexpr (PREC == PREC_H2) filter_role_h<H, FRB, SAVE>(f, item, smem, sd.range_status, fsv TSD_TRACE_PASS);
         else filter_role<H, SAVE>(f, item, smem, fsv TSD_TRACE_PASS);
         TSD_TRACE_REAL(25);
     }
@@ -1995,7 +2154,7 @@ __global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A) {
     if (filter_item >= 0) {  // filter tiles of blocks 1 .. L-1
         const int layer = 1 + filter_item / A.tiles_per_layer;
 #ifndef TSD_MEGA_SKIP_FILTER  // (timing experiments only: wrong results)
-        filter_role_h<H, 1>(A.f, filter_item, smem, A.status TSD_TRACE_NULL);
+        filter_role_h<H, 1>(A.f, filter_item, smem, A.status, FilterSave{} TSD_TRACE_NULL);
 #endif
         // every storing wave drains, the workgroup meets, ONE lane publishes the tile (Guideline 16 R1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2228,7 +2387,8 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     // Whole layers of filter tiles, many chip-fulls of them (big batches / ensembles): 64-row tiles.  A weight fragment
     // of the ring then feeds two row blocks, and the launch is bound by that feed.
     int frb = 1;
-    if (prec.mode == PREC_H2 && !prec.narrow_filter_tiles && f.tiles > 0 && q.tiles == 0 && TSD_FILTER_WIDE_MIN > 0 && f.tiles % f.tiles_per_layer == 0 &&
+    // (the saving form keeps 32-row tiles: with two row blocks AND the saves it does not fit two workgroups per CU)
+    if (prec.mode == PREC_H2 && !prec.narrow_filter_tiles && !fsave && f.tiles > 0 && q.tiles == 0 && TSD_FILTER_WIDE_MIN > 0 && f.tiles % f.tiles_per_layer == 0 &&
         f.g_begin % f.tiles_per_layer == 0 && (long)f.tiles * M >= TSD_FILTER_WIDE_MIN) {
         const int tpl2 = (capacity_u + 2 * T - 1) / (2 * T);
         f.g_begin = f.g_begin / f.tiles_per_layer * tpl2;
@@ -2246,8 +2406,8 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
         if (node_stride % 2 == 0) --node_stride;
     }
     const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, pre_stride, node_stride, prec.range_status};
-    if (prec.mode == PREC_H2 && (fsave || nsave || (q.tiles > 0 && !q.pair))) {
-        set_error("internal: the split-f16 block launch has no saving form and no pre role");
+    if (prec.mode == PREC_H2 && q.tiles > 0 && !q.pair) {
+        set_error("internal: the split-f16 block launch has no pre role");
         return TSD_ERR_INVALID;
     }
 #ifdef TSD_TRACE
@@ -2265,7 +2425,8 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     }
 #define TSD_COMBO(HH)                                                                                       \
     if (prec.mode == PREC_H2) {                                                                             \
-        if (q.tiles > 0) TSD_COMBO_I(HH, false, true, PREC_H2, 1)                                           \
+        if (save) TSD_COMBO_I(HH, true, false, PREC_H2, 1)                                                  \
+        else if (q.tiles > 0) TSD_COMBO_I(HH, false, true, PREC_H2, 1)                                      \
         else if (frb == 2) TSD_COMBO_I(HH, false, false, PREC_H2, 2)                                        \
         else TSD_COMBO_I(HH, false, false, PREC_H2, 1)                                                      \
     } else if (save) TSD_COMBO_I(HH, true, false, PREC_F32, 1)                                              \

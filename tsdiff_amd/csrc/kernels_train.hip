@@ -12,6 +12,7 @@
 #include <algorithm>
 
 #include "train_internal.hpp"
+#include "split16.hpp"
 
 namespace tsd {
 
@@ -389,6 +390,19 @@ __global__ void pack_batch_kernel(PackBatch b) {
         for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < ncols; idx += gridDim.x * blockDim.x) Bp[idx] = M[idx];
         return;
     }
+    if (b.transposed[it] >= 3) {  // 3 / 4: the forward / dgrad matrix as the f16 planes of split16.hpp (split16_kernel's layout)
+        f16* __restrict__ d = reinterpret_cast<f16*>(Bp);
+        for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < ncols * kdim; idx += gridDim.x * blockDim.x) {
+            const int col = idx % ncols, k = idx / ncols;
+            const float a = b.transposed[it] == 4 ? M[(size_t)k * ncols + col] : M[(size_t)col * kdim + k];
+            const f16 h = (f16)a;
+            const f16 l = (f16)((a - (float)h) * SPLIT_SCALE);
+            const int ks = k >> 4, half = (k >> 3) & 1, e = k & 7;
+            d[((((size_t)ks * 2 + 0) * 2 + half) * ncols + col) * 8 + e] = h;
+            d[((((size_t)ks * 2 + 1) * 2 + half) * ncols + col) * 8 + e] = l;
+        }
+        return;
+    }
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < ncols * kdim; idx += gridDim.x * blockDim.x) {
         const int s = idx & 3;
         const int n = (idx >> 2) % ncols;
@@ -411,8 +425,9 @@ int launch_pack_items(int n, const PackItem* items, hipStream_t st) {
                 b.ncols[k] = it.out;
                 b.kdim[k] = 1;
             } else {
-                b.ncols[k] = it.mode ? it.in : it.out;  // forward: B[k = in][n = out]; dgrad: B[k = out][n = in]
-                b.kdim[k] = it.mode ? it.out : it.in;
+                const bool tr = it.mode == 1 || it.mode == 4;
+                b.ncols[k] = tr ? it.in : it.out;  // forward: B[k = in][n = out]; dgrad: B[k = out][n = in]
+                b.kdim[k] = tr ? it.out : it.in;
             }
             const int sz = it.mode == 2 ? it.out : it.out * it.in;
             biggest = sz > biggest ? sz : biggest;

@@ -109,6 +109,34 @@ constexpr float SPLIT_LOW = 2.44140625e-04f;  // 2^-12
 __device__ __forceinline__ void site_close(float& amax, float m) {
     amax = fmaxf(amax, (m > 0.0f && m < SPLIT_LOW) ? __builtin_inff() : m);
 }
+// GRADIENT operands (training step).  Gradients sit wherever the loss scale puts them (1e-3 .. 1e-9 at batch 200), far
+// below the band in which the split keeps 22 bits.  A dgrad is row-wise linear, so a gradient tile is converted as
+// a * s with s = 2^-e (e = exponent of the tile's or row's max |a|: the scaled max lies in [1, 2)) and the product is
+// multiplied by 1 / s = 2^e afterwards -- both exact.  No value can leave the f16 range (the flag is not needed), and an
+// element 2^-13 below the tile's max still carries 22 bits.  m == 0 (an all-zero tile): s = 1.
+__device__ __forceinline__ float pow2_scale(float m, float& inv) {
+    unsigned b = __float_as_uint(m) & 0x7f800000u;
+    b = b > 0x7e000000u ? 0x7e000000u : b;  // (|a| >= 2^125: not a gradient; keeps 254 - E a normal exponent)
+    inv = b ? __uint_as_float(b) : 1.0f;
+    return b ? __uint_as_float(0x7f000000u - b) : 1.0f;
+}
+// max over aligned groups of 32 lanes (ds_swizzle: no index registers, unlike the ds_bpermute behind __shfl_xor), and over
+// the wave (uniform result)
+__device__ __forceinline__ float max32(float m) {
+#define TSD_SWZ(k) m = fmaxf(m, __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(m), ((k) << 10) | 0x1f)))
+    TSD_SWZ(16); TSD_SWZ(8); TSD_SWZ(4); TSD_SWZ(2); TSD_SWZ(1);
+#undef TSD_SWZ
+    return m;
+}
+__device__ __forceinline__ float max64(float m) {
+    m = max32(m);
+    return fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 0)),
+                 __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 32)));
+}
+__device__ __forceinline__ void atomic_amax(float* slot, float m) {  // max of non-negative floats: their bit patterns order
+    atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(m));
+}
+
 // the range flag of a workgroup role: any thread that converted a value beyond the f16 range (or a NaN's neighbour inf)
 __device__ __forceinline__ void range_report(float amax, int32_t* status) {
     if (status != nullptr && !(amax <= F16_MAX)) atomicOr(status, TSD_STATUS_RANGE);
@@ -186,7 +214,11 @@ __device__ __forceinline__ void hgemm_ring_start(HRing<CB, R>& r, const float* _
         hring_issue<CB>(r.b[I], r.base + (size_t)I * r.step_bytes, r.voff, r.plane_bytes, r.cb_bytes);
     });
 }
-template <int RB, int CB, int K, int R>
+// PIN: the LDS address of every k-step passes through an asm statement, which orders that step's A reads behind the
+// previous step's counted wait.  Left free, the compiler hoists the LDS reads of the last k-steps over the whole unrolled
+// loop into registers of their own (+30 VGPRs in the tail of a GEMM: the backward filter chain then loses the second
+// workgroup of its CU).
+template <int RB, int CB, int K, bool PIN = false, int R>
 __device__ __forceinline__ void hgemm_ring_run(HRing<CB, R>& r, const Planes& A, int ldh, f32x16 (&accm)[RB][CB],
                                                f32x16 (&accx)[RB][CB]) {
     constexpr int KS = K / 16;
@@ -197,10 +229,12 @@ __device__ __forceinline__ void hgemm_ring_run(HRing<CB, R>& r, const Planes& A,
         constexpr int slot = ks % R;
         constexpr int younger = ((ks + R <= KS) ? R : KS - ks) - 1;
         f32x4 ah[RB], al[RB];
+        int ao = aoff;
+        if constexpr (PIN) asm volatile("" : "+v"(ao));
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
-            ah[rb] = *reinterpret_cast<const f32x4*>(A.hi + aoff + rb * 32 * ldh + ks * 16);
-            al[rb] = *reinterpret_cast<const f32x4*>(A.lo + aoff + rb * 32 * ldh + ks * 16);
+            ah[rb] = *reinterpret_cast<const f32x4*>(A.hi + ao + rb * 32 * ldh + ks * 16);
+            al[rb] = *reinterpret_cast<const f32x4*>(A.lo + ao + rb * 32 * ldh + ks * 16);
         }
         hring_wait<younger * CB * 2, CB>(r.b[slot]);
 #pragma unroll
@@ -213,14 +247,15 @@ __device__ __forceinline__ void hgemm_ring_run(HRing<CB, R>& r, const Planes& A,
             }
         if constexpr (ks + R < KS)
             hring_issue<CB>(r.b[slot], r.base + (size_t)(ks + R) * r.step_bytes, r.voff, r.plane_bytes, r.cb_bytes);
+        if constexpr (PIN) asm volatile("" : "+v"(accx[RB - 1][CB - 1]));  // (... and the step's MFMAs ahead of the next step's reads)
     });
 }
-template <int RB, int CB, int K>
+template <int RB, int CB, int K, bool PIN = false>
 __device__ __forceinline__ void hgemm_tile(const Planes& A, int ldh, const float* __restrict__ Bp16, int nout, int col0,
                                            f32x16 (&accm)[RB][CB], f32x16 (&accx)[RB][CB]) {
     HRing<CB, HRING_R> r;
     hgemm_ring_start<CB, K>(r, Bp16, nout, col0);
-    hgemm_ring_run<RB, CB, K>(r, A, ldh, accm, accx);
+    hgemm_ring_run<RB, CB, K, PIN>(r, A, ldh, accm, accx);
 }
 template <int RB, int CB>
 __device__ __forceinline__ void hzero(f32x16 (&accm)[RB][CB], f32x16 (&accx)[RB][CB]) {

@@ -64,7 +64,7 @@ int launch_block_bwd(int H, int N, int first, int last, tsd_edges enc, const flo
                      const float* dh_up, const float* w_lin1_t, const float* w_lin_t, const float* w_lin2_t,
                      const float* x2_prev, float* dx1, float* dh, float* dx2_prev, float* dagg_prev, int filter_rows,
                      tsd_edges enc_u, const float* x1, const float* f0, const float* W2t, const float* W0t, float cutoff,
-                     int smooth, float* dWf, float* df0, float* d_ea, hipStream_t st);
+                     int smooth, float* dWf, float* df0, float* d_ea, hipStream_t st, float* amax_h2 = nullptr);
 int launch_split_reduce(int64_t n, int S, const float* part, float* dst, int accumulate, hipStream_t st);
 int wgrad_batch_splits(int m, int blocks, int rows);
 size_t wgrad_batch_scratch_floats(int n, int rows, int in, int out);
@@ -72,7 +72,8 @@ int launch_wgrad_batch(int n, int rows, int in, int out, const float* const* dY,
                        float* const* db, int accumulate, float* part, hipStream_t st);
 
 // the optimizer rewrites every weight every step: all layout conversions of a step in a few launches.
-// mode 0: W [out,in] -> forward MFMA layout [in/4][out][in%4]; 1: dgrad layout (W^T); 2: copy of `out` floats
+// mode 0: W [out,in] -> forward MFMA layout [in/4][out][in%4]; 1: dgrad layout (W^T); 2: copy of `out` floats;
+// 3 / 4: the forward / dgrad matrix as f16 planes (split16.hpp, the layout of tsd_pack_weights16; in, out multiples of 16)
 struct PackItem {
     const float* src;
     float* dst;

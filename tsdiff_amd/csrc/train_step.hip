@@ -91,6 +91,9 @@ struct Work {
     float *node_eq, *pos_target, *d_target;
     float* pack_inf;               // packed weights, layout of tsd_pack_weights (the fused forward kernels)
     float* pack_t;                 // dgrad layouts of the dense weights, offsets = raw offsets
+    float* pack16;                 // f16-plane image of pack_inf (tsd_pack_weights16): the split-f16 block launches
+    float* pack_t16;               // f16-plane images of the filter MLPs' dgrad matrices, offsets = raw offsets
+    float* amax;                   // [L][2] running max |dWf|, |df0| per block (split-f16 backward: the wgrad's dY scales)
     float* scratch;                // linear scratch
     size_t scratch_floats;
     // backward temporaries
@@ -141,6 +144,9 @@ Work carve(const tsd_model_cfg& c, int N, size_t PU, float* base) {
     const RawLayout R = raw_layout(c);
     w.pack_inf = take(weight_layout(c).total);
     w.pack_t = take(R.total);
+    w.pack16 = take(weight_layout(c).total);
+    w.pack_t16 = take(R.total);
+    w.amax = take(2 * L);
     w.scratch_floats = linear_scratch_floats((int)(2 * H), (int)H);
     if (w.scratch_floats < (size_t)512 * 32 * H) w.scratch_floats = (size_t)512 * 32 * H;  // embedding-gradient partials
     w.scratch = take(w.scratch_floats);
@@ -503,17 +509,26 @@ struct Ctx {
 
 // Every layout conversion of the step in two launches: the packed arena the fused forward kernels read
 // (layout of tsd_pack_weights) and the dgrad layouts of the dense weights (offsets of the raw vector).
-int pack_all(const Ctx& x) {
+int pack_all(const Ctx& x, bool h2) {
     const int H = x.H, L = x.L;
     const WeightLayout I = weight_layout(*x.c);
     const RawLayout& R = x.R;
     std::vector<PackItem> it;
     it.reserve(128);
     float* D = x.w.pack_inf;
-    auto cp = [&](size_t dst, size_t src, int n) { it.push_back({x.raw + src, D + dst, n, 1, 2}); };
-    auto pk = [&](size_t dst, size_t src, int out, int in) {
+    // h2: the interaction blocks' matrices and biases also as the f16-plane arena of the split-f16 block launches
+    // (same offsets as the fp32 arena: tsd_pack_weights16's image of these ranges), in the same launch
+    float* D16 = x.w.pack16;
+    bool blocks = false;
+    auto cp = [&](size_t dst, size_t src, int n) {
+        it.push_back({x.raw + src, D + dst, n, 1, 2});
+        if (h2 && blocks) it.push_back({x.raw + src, D16 + dst, n, 1, 2});
+    };
+    auto pk = [&](size_t dst, size_t src, int out, int in, bool t16 = false) {
         it.push_back({x.raw + src, D + dst, out, in, 0});
         if (x.packed(out, in)) it.push_back({x.raw + src, x.w.pack_t + src, out, in, 1});
+        if (h2 && blocks) it.push_back({x.raw + src, D16 + dst, out, in, 3});
+        if (h2 && t16) it.push_back({x.raw + src, x.w.pack_t16 + src, out, in, 4});
     };
     cp(I.bond_emb, R.bond_emb, 100 * H);
     cp(I.emlp_w0, R.emlp_w0, H);
@@ -524,18 +539,20 @@ int pack_all(const Ctx& x) {
     cp(I.ecat_b0, R.ecat_b0, H);
     pk(I.ecat_w1, R.ecat_w1, H, H);
     cp(I.ecat_b1, R.ecat_b1, H);
+    blocks = true;
     for (int l = 0; l < L; ++l) {
         const size_t i = I.layer0 + (size_t)l * I.layer_stride, r = R.layer0 + (size_t)l * R.layer_stride;
         pk(i + I.L_lin1_w, r + R.L_lin1_w, H, H);
         pk(i + I.L_lin2_w, r + R.L_lin2_w, H, H);
         cp(i + I.L_lin2_b, r + R.L_lin2_b, H);
-        pk(i + I.L_nn0_w, r + R.L_nn0_w, H, H);
+        pk(i + I.L_nn0_w, r + R.L_nn0_w, H, H, true);
         cp(i + I.L_nn0_b, r + R.L_nn0_b, H);
-        pk(i + I.L_nn2_w, r + R.L_nn2_w, H, H);
+        pk(i + I.L_nn2_w, r + R.L_nn2_w, H, H, true);
         cp(i + I.L_nn2_b, r + R.L_nn2_b, H);
         pk(i + I.L_lin_w, r + R.L_lin_w, H, H);
         cp(i + I.L_lin_b, r + R.L_lin_b, H);
     }
+    blocks = false;
     pk(I.out_w0, R.out_w0, H, 2 * H);
     cp(I.out_b0, R.out_b0, H);
     pk(I.out_w1, R.out_w1, H / 2, H);
@@ -710,9 +727,17 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
     if (N == 0) return TSD_OK;
     {
         TraceRange ph("tsd:train_forward/pack_weights");
-        TSD_TRY(pack_all(x));
+        TSD_TRY(pack_all(x, (batch->reserved & 32) != 0 && batch->status != nullptr));
     }
     const float* W = w.pack_inf;
+    // tsd_batch.reserved bit 5: the interaction blocks on the f16 MFMA pipes (split-f16 operands, split16.hpp; fp32
+    // accumulation and fp32 saved activations), range flag in tsd_batch.status as in the inference forward
+    const bool h2 = (batch->reserved & 32) != 0 && batch->status != nullptr;
+    Prec prec;
+    if (h2) {
+        prec.mode = PREC_H2;
+        prec.range_status = batch->status;
+    }
     // node embedding
     hipLaunchKernelGGL(feats_to_float_kernel, dim3(nblk((int64_t)N * F)), dim3(256), 0, st, (int64_t)N * F, r_feat, p_feat,
                        w.featR, w.featP);
@@ -732,10 +757,10 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
         const int layer = j - 1;  // -1: x1_0 = lin1_0(h_0) only
         const int lc = layer < 0 ? 0 : layer;
         const NodeSave nsv{w.agg + lc * NH, w.x2 + lc * NH, w.xs + lc * NH};
-        TSD_TRY(launch_layer_combo(*cfg, W, layer, N, g.enc, w.Wf + lc * CH, w.x1 + lc * NH, w.h + lc * NH,
+        TSD_TRY(launch_layer_combo(*cfg, h2 ? w.pack16 : W, layer, N, g.enc, w.Wf + lc * CH, w.x1 + lc * NH, w.h + lc * NH,
                                    w.h + (size_t)(layer + 1) * NH, layer + 1 < L ? w.x1 + (size_t)(layer + 1) * NH : w.nA,
                                    0, j * tpl, j < L ? tpl : 0, PU, g.enc_u, w.ea, w.Wf, L, 1, 0, 0, 0, st, nullptr, 0,
-                                   &fsv, &nsv));
+                                   &fsv, &nsv, false, prec));
     }
     // pair MLP on [h_i * h_j , edge_attr_out]                                       common.py:226-229
     if (Eo > 0) {
@@ -776,6 +801,20 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
     TSD_REQUIRE(dloss && grad && atom_type && pos, "null pointer");
     TSD_REQUIRE((reinterpret_cast<uintptr_t>(grad) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
                 "grad and workspace must be 16-byte aligned");
+    const bool h2 = batch && (batch->reserved & 32) != 0 && batch->status != nullptr;
+    if (h2) {
+        // The forward of this step ran on split-f16 operands: its range flag decides whether the saved activations can be
+        // differentiated.  One 4-byte read behind the forward's last kernel, from C++ so that the first backward launch
+        // follows the answer by microseconds (the host is ahead of the GPU here: it only waits for the forward to end)
+        static thread_local int32_t* pinned = nullptr;
+        if (!pinned) TSD_HIP(hipHostMalloc(reinterpret_cast<void**>(&pinned), sizeof(int32_t), hipHostMallocDefault));
+        TSD_HIP(hipMemcpyAsync(pinned, batch->status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        TSD_HIP(hipStreamSynchronize(st));
+        if (*pinned & TSD_STATUS_RANGE) {
+            set_error("split-f16 training step: an activation of the forward left the f16 range (TSD_STATUS_RANGE)");
+            return TSD_ERR_RANGE;
+        }
+    }
     Ctx x;
     TSD_TRY(make_ctx(x, cfg, batch, raw, workspace, workspace_floats, counts_host, st));
     x.grad = grad;
@@ -836,6 +875,8 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
         // image of the forward's node role -- beside the filter MLP's backward chain) instead of 4 + 3 primitive launches
         float *dagg = w.nA, *dagg_other = w.nB;
         auto wt = [&](int l, size_t off) { return w.pack_t + x.R.layer0 + (size_t)l * x.R.layer_stride + off; };
+        auto wt16 = [&](int l, size_t off) { return w.pack_t16 + x.R.layer0 + (size_t)l * x.R.layer_stride + off; };
+        if (h2) TSD_HIP(hipMemsetAsync(w.amax, 0, 2 * (size_t)L * sizeof(float), st));
         const tsd_edges none{};
         TSD_TRY(launch_block_bwd(H, N, 1, 0, g.enc, nullptr, nullptr, w.dh, nullptr, wt(L - 1, x.R.L_lin_w),
                                  wt(L - 1, x.R.L_lin2_w), w.x2 + (size_t)(L - 1) * NH, nullptr, nullptr,
@@ -846,8 +887,10 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
             TSD_TRY(launch_block_bwd(H, N, 0, l == 0, g.enc, w.Wf + l * EH, dagg, dh_cur, wt(l, x.R.L_lin1_w),
                                      wt(lp, x.R.L_lin_w), wt(lp, x.R.L_lin2_w), w.x2 + (size_t)lp * NH, w.dx1s + l * NH,
                                      w.dhs + l * NH, w.dx2s + (size_t)lp * NH, dagg_other, Eu, g.enc_u, w.x1 + l * NH,
-                                     w.f0 + l * EH, wt(l, x.R.L_nn2_w), wt(l, x.R.L_nn0_w), cfg->conv_cutoff,
-                                     cfg->smooth_conv, w.dWfs + l * EH, w.df0s + l * EH, w.d_ea, st));
+                                     w.f0 + l * EH, h2 ? wt16(l, x.R.L_nn2_w) : wt(l, x.R.L_nn2_w),
+                                     h2 ? wt16(l, x.R.L_nn0_w) : wt(l, x.R.L_nn0_w), cfg->conv_cutoff,
+                                     cfg->smooth_conv, w.dWfs + l * EH, w.df0s + l * EH, w.d_ea, st,
+                                     h2 ? w.amax + 2 * l : nullptr));
             dh_cur = w.dhs + l * NH;
             float* t = dagg;
             dagg = dagg_other;

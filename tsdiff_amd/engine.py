@@ -416,9 +416,11 @@ class DeviceBatch:
                                tile_count=tile[2 * cap:].data_ptr(), pair=v[0].data_ptr(), node_i=v[1].data_ptr(),
                                node_j=v[2].data_ptr())
 
-    def train_struct(self):
-        """tsd_batch for the training step: topology + edge-list buffers only (no bound checkpoints)"""
+    def train_struct(self, h2=False):
+        """tsd_batch for the training step: topology + edge-list buffers only (no bound checkpoints).  h2: the step's
+        tile GEMMs on the f16 MFMA pipes (tsd_batch.reserved bit 5), range flag in the batch's status word"""
         return Batch(
+            reserved=32 if h2 else 0, status=self.status.data_ptr(),
             num_nodes=self.N, num_graphs=self.G, num_pairs=self.P, num_models=0,
             graph_ptr=self.graph_ptr.data_ptr(), node_graph=self.node_graph.data_ptr(),
             pair_ptr=self.pair_ptr.data_ptr(), pair_code=self.pair_code.data_ptr(),

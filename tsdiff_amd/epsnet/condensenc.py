@@ -6,13 +6,13 @@ signatures and return conventions (condensenc.py:241-328) -- but every computati
 libtsdiff_hip.so on the MI355X.  The `nn.Module` children below only HOLD parameters under the
 reference's names; their own `forward` is never used.
 """
-import os
 
 import numpy as np
 import torch
 from torch import nn
 
 from .. import engine
+from ..options import OPTIONS
 
 NUM_BOND_TYPES = 22  # reference utils/chem.py:21
 
@@ -260,7 +260,7 @@ class CondenseEncoderEpsNetwork(nn.Module):
             time_step = _time_step
         pos_noise = torch.randn(size=pos.size(), device=dev) if _pos_noise is None else _pos_noise
         training = torch.is_grad_enabled() and any(p.requires_grad for p in self.raw_params())
-        fused = training and os.environ.get("TSDIFF_TRAIN", "fused") != "ops"
+        fused = training and OPTIONS.train != "ops"
         if fused and pos.is_cuda and pos.dtype == torch.float32 and pos_noise.dtype == torch.float32:
             # the forward diffusion as one launch (tsd_diffuse_positions: the same operations in the same order)
             from .. import _lib

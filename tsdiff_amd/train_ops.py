@@ -18,6 +18,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from .options import OPTIONS
 from ._lib import check, ptr, stream_ptr
 
 
@@ -512,7 +513,8 @@ class FusedTrainLoss(torch.autograd.Function):
             model._train_ws = None  # release before growing
             ws = torch.empty(max(int(nws * 1.15), 1), dtype=torch.float32, device=dev)
             model._train_ws = ws
-        b = db.train_struct()
+        h2 = OPTIONS.train_gemm == "h2" and not getattr(model, "_train_f32", False)
+        b = db.train_struct(h2)
         counts = (C.c_int32 * 4)()  # undirected edge counts of the two lists, topology status word, separately embedded out edges
         loss = torch.empty(db.N, 1, dtype=torch.float32, device=dev)
         pos0, pos_perturbed, a_graph = _c(pos0.float()), _c(pos_perturbed.float()), _c(a_graph.float())
@@ -533,6 +535,9 @@ class FusedTrainLoss(torch.autograd.Function):
         ctx.model, ctx.db, ctx.raw, ctx.ws, ctx.counts, ctx.pos = model, db, raw, ws, counts, pos_perturbed
         ctx.sizes = [p.numel() for p in params]
         ctx.shapes = [p.shape for p in params]
+        ctx.h2 = h2
+        if h2:  # what a recomputation of this forward in fp32 needs (backward: range flag)
+            ctx.fwd_in, ctx.loss = (pos0, a_graph), loss
         return loss
 
     @staticmethod
@@ -558,7 +563,6 @@ class FusedTrainLoss(torch.autograd.Function):
         ctx.used = True
         grad = torch.empty_like(ctx.raw)
         dloss = _c(dloss.float()).view(-1)
-        b = db.train_struct()
         # data-parallel step (distributed.dp_backward set `_dp_early_reduce`): the interaction blocks' gradients -- one
         # contiguous range, 83 % of the vector -- are final long before the call's last kernel; the library records an
         # event there and their all-reduce starts on a side stream beside the embedding's backward chain
@@ -567,9 +571,29 @@ class FusedTrainLoss(torch.autograd.Function):
         if early is not None:
             ev = torch.cuda.Event()
             ev.record()  # (creates the hipEvent_t; the library records it again where the bucket is complete)
-        check(lib.tsd_train_backward2(C.byref(cfg), C.byref(b), ptr(ctx.raw), ptr(db.atom_type), ptr(ctx.pos),
-                                      ptr(ctx.ws), ctx.ws.numel(), ctx.counts, ptr(dloss), ptr(grad),
-                                      C.c_void_p(ev.cuda_event) if ev is not None else None, stream_ptr()))
+
+        def run(h2):
+            b = db.train_struct(h2)
+            return lib.tsd_train_backward2(C.byref(cfg), C.byref(b), ptr(ctx.raw), ptr(db.atom_type), ptr(ctx.pos),
+                                           ptr(ctx.ws), ctx.ws.numel(), ctx.counts, ptr(dloss), ptr(grad),
+                                           C.c_void_p(ev.cuda_event) if ev is not None else None, stream_ptr())
+        code = run(ctx.h2)
+        if code == _lib.TSD_ERR_RANGE:
+            # an activation of the split-f16 forward left the f16 range (the library read the flag behind the forward's
+            # last kernel and launched nothing): the forward is recomputed on the fp32-input MFMA kernels INTO THE SAME loss
+            # tensor (scalars the caller derived from it before backward() are stale for this one step), the backward runs
+            # in fp32, and the model trains in fp32 from here on
+            import warnings
+            warnings.warn("tsdiff_amd: an activation left the range the split-f16 training arithmetic covers; this step was "
+                          "recomputed and the model now trains on the fp32-input MFMA kernels", RuntimeWarning, stacklevel=2)
+            db.status[:1].zero_()
+            ctx.model._train_f32 = True
+            pos0, a_graph = ctx.fwd_in
+            check(lib.tsd_train_forward(C.byref(cfg), C.byref(db.train_struct(False)), ptr(ctx.raw), ptr(db.atom_type),
+                                        ptr(db.r_feat), ptr(db.p_feat), ptr(pos0), ptr(ctx.pos), ptr(a_graph), None,
+                                        ptr(ctx.ws), ctx.ws.numel(), ptr(ctx.loss), ctx.counts, stream_ptr()))
+            code = run(False)
+        check(code)
         ctx.model._dp_early_done = None
         if early is not None:
             lay = (C.c_size_t * 3)()
