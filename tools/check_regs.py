@@ -24,6 +24,7 @@ BUDGET = [
     (r"layer_combo_kernelILi256ELb1ELb0ELi1ELi1E", 128, 0),  # split-f16 block launch of the training step (saving form)
     (r"block_bwd_kernelILi256E", 128, 0),                    # backward block launch, fp32 and split-f16 filter chains
     (r"unit_encoder_kernelILi256E", 256, 0),
+    (r"wgrad_h2_batch_kernel", 256, 0),  # four waves per workgroup, two workgroups per CU
     # sixteen waves per workgroup: 128 registers; a few loop-invariant values of the per-block prologue may sit in scratch
     # (six scratch instructions per block, none inside the tile cycle)
     (r"unit_encoder_pp_kernelILi256E", 128, 64),

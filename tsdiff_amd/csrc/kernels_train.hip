@@ -257,6 +257,145 @@ __global__ __launch_bounds__(WG_NT) void wgrad_batch_kernel(int rows, int in, in
     wgrad_body(rows, in, out, rows_per_split, split, b.it[item].dY, b.it[item].X, part + (size_t)item * S * out * in,
                bias_part ? bias_part + (size_t)item * S * out : nullptr, sY, sX);
 }
+// ---------------------------------------------------------------------------------------------
+// The same batched weight gradient on the f16 MFMA pipes (split16.hpp, GRADIENT operands): dW = (s dY)^T X / s with
+// s = 2^-e from the running max of the dY tensor that its producer kept (filter_bwd_role_h: amax slots, one per tensor;
+// X are saved forward activations, already inside the f16 range when the step's forward raised no flag).
+// Both operands are contracted over ROWS, i.e. an MFMA lane needs 8 consecutive rows of one column: a thread loads one
+// column of 8 consecutive rows (eight coalesced dword loads per wave row), converts, and writes ONE 16-byte LDS store
+// per plane into a column-major tile [plane][128 cols][KT + 8 rows] f16 (column stride 80 B: ds_read/write_b128 conflict
+// free).  Workgroup = 4 waves on one 128 x 128 output block, wave (g, c) owns 64 x 64 = 2 x 2 MFMA blocks (two
+// accumulator sets: 128 VGPRs), 2 workgroups per CU.  The next tile's 32 loads per thread are in flight under the MFMAs.
+// Launch: 1-D grid; the (in/128) x (out/128) blocks of one (item, split) share their dY / X columns pairwise, so they
+// are placed on ONE XCD (ids 8 apart) to meet in its L2 -- otherwise every tensor is read from HBM twice, which is what
+// bounds this launch (0.6 GB of operands at batch 200 against 40 GFLOP).
+// ---------------------------------------------------------------------------------------------
+constexpr int WH_KT = 32, WH_LDK = WH_KT + 8, WH_NT = 256;
+struct WgradItemH {
+    const float *dY, *X;
+    const float* amax;  // max |dY| of the tensor as its producer saw it (within a factor 2 below is fine), or NULL: scale 1
+};
+struct WgradBatchH {
+    WgradItemH it[WG_BATCH_MAX];
+};
+__global__ __launch_bounds__(WH_NT, 2) void wgrad_h2_batch_kernel(int rows, int in, int out, int rows_per_split, int S, int Z,
+                                                               WgradBatchH b, float* __restrict__ part,
+                                                               float* __restrict__ bias_part) {
+    __shared__ __attribute__((aligned(16))) f16 sY[2 * 128 * WH_LDK];
+    __shared__ __attribute__((aligned(16))) f16 sX[2 * 128 * WH_LDK];
+    __shared__ float s_b[WH_NT];
+    const int nbx = in / 128, nby = out / 128, q = nbx * nby;
+    const int id = blockIdx.x, slot = id >> 3;
+    const int z = (slot / q) * 8 + (id & 7), blk = slot % q;
+    if (z >= Z) return;
+    const int bx = blk % nbx, by = blk / nbx;
+    const int item = z / S, split = z - item * S;
+    const float* __restrict__ dY = b.it[item].dY;
+    const float* __restrict__ X = b.it[item].X;
+    float inv = 1.0f, sc = 1.0f;
+    if (b.it[item].amax != nullptr) sc = pow2_scale(*b.it[item].amax, inv);
+    part += (size_t)item * S * out * in;
+    const int in0 = bx * 128, out0 = by * 128;
+    const int r_begin = split * rows_per_split, r_end = min(rows, r_begin + rows_per_split);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wo = (wave >> 1) * 64, wi = (wave & 1) * 64;
+    // staging: this thread's column and (wave-uniform) 8-row group 0 / 1 of each 16 rows.  Row bases are scalar, the
+    // lane offset is one 32-bit register for all 32 loads of a tile
+    const int col = tid & 127, rg = __builtin_amdgcn_readfirstlane(tid >> 7);
+    f32x16 accm[2][2], accx[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accm[a][c][r] = accx[a][c][r] = 0.0f;
+    constexpr int NQ = WH_KT / 16;  // 8-row units of this thread per tile and tensor
+    float py[NQ][8], px[NQ][8];
+    // (buffer loads: scalar resource + scalar row offset + one lane offset register; rows past r_end read as zero)
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dY), 0, r_end * out * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, r_end * in * 4, 0x00020000);
+    const int yoff = (out0 + col) * 4, xoff = (in0 + col) * 4;
+    auto prefetch = [&](int r0) {
+#pragma unroll
+        for (int u = 0; u < NQ; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = r0 + u * 16 + rg * 8 + j;
+                py[u][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, yoff, r * out * 4, 0));
+                px[u][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, xoff, r * in * 4, 0));
+            }
+    };
+    const bool do_bias = bias_part != nullptr && bx == 0;
+    float bsum = 0.0f;
+    if (r_begin < r_end) prefetch(r_begin);
+    const int aoff = l31 * WH_LDK + hi * 8;
+    for (int r0 = r_begin; r0 < r_end; r0 += WH_KT) {
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            f16x8 yh, yl, xh, xl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f16 h, l;
+                if (do_bias) bsum += py[u][j];
+                split1(py[u][j] * sc, h, l);
+                yh[j] = h; yl[j] = l;
+                split1(px[u][j], h, l);
+                xh[j] = h; xl[j] = l;
+            }
+            const int o = col * WH_LDK + u * 16 + rg * 8;
+            *reinterpret_cast<f16x8*>(sY + o) = yh;
+            *reinterpret_cast<f16x8*>(sY + 128 * WH_LDK + o) = yl;
+            *reinterpret_cast<f16x8*>(sX + o) = xh;
+            *reinterpret_cast<f16x8*>(sX + 128 * WH_LDK + o) = xl;
+        }
+        __syncthreads();
+        if (r0 + WH_KT < r_end) prefetch(r0 + WH_KT);
+#pragma unroll
+        for (int ks = 0; ks < WH_KT / 16; ++ks) {
+            f32x4 ah[2], al[2], bh[2], bl[2];
+            int ao = aoff;
+            asm volatile("" : "+v"(ao));  // (one k-step's fragments at a time: left free, both steps' reads are hoisted)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                ah[a] = *reinterpret_cast<const f32x4*>(sY + (wo + a * 32) * WH_LDK + ao + ks * 16);
+                al[a] = *reinterpret_cast<const f32x4*>(sY + 128 * WH_LDK + (wo + a * 32) * WH_LDK + ao + ks * 16);
+                bh[a] = *reinterpret_cast<const f32x4*>(sX + (wi + a * 32) * WH_LDK + ao + ks * 16);
+                bl[a] = *reinterpret_cast<const f32x4*>(sX + 128 * WH_LDK + (wi + a * 32) * WH_LDK + ao + ks * 16);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    accx[a][c] = mfma_h32(ah[a], bl[c], accx[a][c]);
+                    accm[a][c] = mfma_h32(ah[a], bh[c], accm[a][c]);
+                    accx[a][c] = mfma_h32(al[a], bh[c], accx[a][c]);
+                }
+        }
+    }
+    // (buffer stores: one lane offset register, the 64 block / row offsets are scalar)
+    float* P = part + (size_t)split * out * in;
+    const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(P, 0, out * in * 4, 0x00020000);
+    const int wou = __builtin_amdgcn_readfirstlane(out0 + wo), wiu = __builtin_amdgcn_readfirstlane(in0 + wi);
+    const int poff = (hi * 4 * in + l31) * 4;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = wou + a * 32 + (r >> 2) * 8 + (r & 3), i = wiu + c * 32;  // (acc_row(r, hi) = that + 4 hi)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(hval(accm[a][c], accx[a][c], r) * inv), rp, poff,
+                                                      (o * in + i) * 4, 0);
+                if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);  // (eight values at a time leave the accumulator file)
+            }
+    if (do_bias) {  // the two row groups of a column
+        s_b[tid] = bsum;
+        __syncthreads();
+        if (tid < 128) bias_part[((size_t)item * S + split) * out + out0 + tid] = s_b[tid] + s_b[tid + 128];
+    }
+}
+
 // sums the S split partials in a fixed order: workgroup = 64 consecutive outputs x 4 split quarters
 // (wave q adds splits [q S/4, (q+1) S/4) in order, then ((q0 + q1) + (q2 + q3))).  The weight partials
 // [S][nW] and the bias partials [S][nB] (nB may be 0) are reduced by the same launch.
@@ -931,7 +1070,7 @@ size_t wgrad_batch_scratch_floats(int n, int rows, int in, int out) {
     return worst * ((size_t)out * in + out);
 }
 int launch_wgrad_batch(int n, int rows, int in, int out, const float* const* dY, const float* const* X, float* const* dW,
-                       float* const* db, int accumulate, float* part, hipStream_t st) {
+                       float* const* db, int accumulate, float* part, hipStream_t st, const float* const* amax_h2) {
     if (n == 0) return TSD_OK;
     TSD_REQUIRE(out % 128 == 0 && in % 128 == 0 && rows > 0, "wgrad batch: shape %d x %d, %d rows", out, in, rows);
     const int64_t nW = (int64_t)out * in;
@@ -946,6 +1085,14 @@ int launch_wgrad_batch(int n, int rows, int in, int out, const float* const* dY,
             o.it[k] = WgradOut{dW[base + k], db ? db[base + k] : nullptr};
         }
         float* bpart = part + (size_t)m * S * nW;
+        if (amax_h2 != nullptr) {  // split-f16 form (amax_h2[k]: the dY tensor's running max, or NULL entries: unscaled)
+            static_assert(WG_T == WH_KT, "the split sizes are shared with the fp32 form");
+            WgradBatchH bh;
+            for (int k = 0; k < m; ++k) bh.it[k] = WgradItemH{dY[base + k], X[base + k], amax_h2[base + k]};
+            const int Z = m * S, q = (in / 128) * (out / 128);
+            hipLaunchKernelGGL(wgrad_h2_batch_kernel, dim3((unsigned)((Z + 7) / 8 * 8 * q)), dim3(WH_NT), 0, st, rows, in, out,
+                               per, S, Z, bh, part, bpart);
+        } else
         hipLaunchKernelGGL(wgrad_batch_kernel, dim3(in / 128, out / 128, m * S), dim3(WG_NT), 0, st, rows, in, out, per,
                            S, b, part, bpart);
         hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)((nW + out + 63) / 64), m), dim3(reduce_threads(S)),

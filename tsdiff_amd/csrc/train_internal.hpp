@@ -69,7 +69,8 @@ int launch_split_reduce(int64_t n, int S, const float* part, float* dst, int acc
 int wgrad_batch_splits(int m, int blocks, int rows);
 size_t wgrad_batch_scratch_floats(int n, int rows, int in, int out);
 int launch_wgrad_batch(int n, int rows, int in, int out, const float* const* dY, const float* const* X, float* const* dW,
-                       float* const* db, int accumulate, float* part, hipStream_t st);
+                       float* const* db, int accumulate, float* part, hipStream_t st,
+                       const float* const* amax_h2 = nullptr);
 
 // the optimizer rewrites every weight every step: all layout conversions of a step in a few launches.
 // mode 0: W [out,in] -> forward MFMA layout [in/4][out][in%4]; 1: dgrad layout (W^T); 2: copy of `out` floats;

@@ -927,12 +927,17 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
         TSD_TRY(launch_wgrad_batch((int)dYs.size(), N, H, H, dYs.data(), Xs.data(), dWs.data(), dbs.data(), 1, w.wpart, st));
         if (Eu > 0) {  // the filter MLPs of all blocks: 2 L problems of Eu rows
             dYs.clear(), Xs.clear(), dWs.clear(), dbs.clear();
+            std::vector<const float*> amx;
             for (int l = 0; l < L; ++l) {
                 const size_t o = x.R.layer0 + (size_t)l * x.R.layer_stride;
                 dYs.push_back(w.dWfs + l * EH); Xs.push_back(w.fs + l * EH); dWs.push_back(grad + o + x.R.L_nn2_w); dbs.push_back(grad + o + x.R.L_nn2_b);
                 dYs.push_back(w.df0s + l * EH); Xs.push_back(w.ea);          dWs.push_back(grad + o + x.R.L_nn0_w); dbs.push_back(grad + o + x.R.L_nn0_b);
+                amx.push_back(w.amax + 2 * l);
+                amx.push_back(w.amax + 2 * l + 1);
             }
-            TSD_TRY(launch_wgrad_batch((int)dYs.size(), Eu, H, H, dYs.data(), Xs.data(), dWs.data(), dbs.data(), 1, w.wpart, st));
+            // (split-f16 step: fs / ea passed the forward's range check, the dY tensors carry their block launch's maxima)
+            TSD_TRY(launch_wgrad_batch((int)dYs.size(), Eu, H, H, dYs.data(), Xs.data(), dWs.data(), dbs.data(), 1, w.wpart, st,
+                                       h2 ? amx.data() : nullptr));
         }
     }
     // every gradient of the interaction blocks (tsd_train_grad_buckets: 83 % of the flat vector) is final here: a
