@@ -366,3 +366,84 @@ def test_operands_in_the_f16_subnormal_band(dev, monkeypatch):
     h = make_model(cfg, 3, dev)
     run_forward(h, g, dev)
     assert _db(h).gemm is None and _db(h).gemm_mode() == "h2"
+
+
+# ---------------------------------------------------------------------------------------------
+# The training step on split-f16 operands (OPTIONS.train_gemm = "h2": saving forms of the block launches, backward filter
+# chain and the filter MLPs' batched weight gradients with gradient operands scaled by powers of two)
+# ---------------------------------------------------------------------------------------------
+def _train_case(dev, graphs=12, seed=31):
+    from tsdiff_amd import synth
+    b = synth.wb97xd3_like_batch(graphs, seed=seed)
+    t = {k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}
+    t["pos"] = t["pos"] * 1.5
+    gen = torch.Generator().manual_seed(3)
+    ts = torch.randint(0, 5000, (graphs,), generator=gen)
+    pn = torch.randn(t["pos"].shape, generator=gen)
+    return to_dev(t, dev), ts.to(dev), pn.to(dev), graphs
+
+
+def _train_step_grads(model, g, ts, pn, G, mode, monkeypatch, loss_scale=1.0):
+    from tsdiff_amd.options import OPTIONS
+    monkeypatch.setattr(OPTIONS, "train_gemm", mode)
+    model._train_f32 = False
+    model.train()
+    model.zero_grad(set_to_none=True)
+    loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
+                          g["batch"], g["num_nodes_per_graph"], G, _time_step=ts, _pos_noise=pn)
+    (loss.mean() * loss_scale).backward()
+    torch.cuda.synchronize()
+    return loss.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("loss_scale", [1.0, 1e-12, 1e9])
+def test_train_split_f16_matches_fp32(loss_scale, dev, monkeypatch):
+    """every parameter gradient of one training step in split-f16 arithmetic against the fp32-MFMA step: max|d| <= 5e-6
+    of each tensor's scale (measured 7e-7) -- also with the loss scaled by 1e-12 / 1e9, i.e. with every gradient operand
+    far outside the band in which an UNSCALED f16 split keeps its bits (the dgrad tiles and the dY tensors of the weight
+    gradients are scaled by exact powers of two: split16.hpp, GRADIENT operands)"""
+    from tsdiff_amd import synth
+    model = make_model(synth.DEFAULT_MODEL_CONFIG, 2, dev)
+    g, ts, pn, G = _train_case(dev)
+    lf, gf = _train_step_grads(model, g, ts, pn, G, "f32", monkeypatch, loss_scale)
+    lh, gh = _train_step_grads(model, g, ts, pn, G, "h2", monkeypatch, loss_scale)
+    assert not getattr(model, "_train_f32", False), "the split-f16 step fell back to fp32"
+    assert float((lh - lf).abs().max()) <= 2e-6 * float(lf.abs().max())
+    assert len(gf) == 7 + 9 * 7 + 6 + 4
+    differs = 0
+    for k, ref in gf.items():
+        scale = float(ref.abs().max())
+        err = float((gh[k] - ref).abs().max())
+        assert np.isfinite(err) and err <= 5e-6 * max(scale, 1e-30), f"{k}: {err:.3e} vs scale {scale:.3e}"
+        differs += int(err > 0)
+    assert differs > 40  # (the two runs really took different kernels)
+
+
+def test_train_split_f16_range_fallback(dev, monkeypatch):
+    """an activation beyond the f16 range inside the split-f16 training forward: tsd_train_backward2 returns TSD_ERR_RANGE
+    before launching anything, the host recomputes the forward on the fp32 kernels into the same loss tensor, runs the fp32
+    backward and keeps the model in fp32 -- loss and gradients are then BIT-identical to a step that ran in fp32 from the
+    start"""
+    from tsdiff_amd import synth
+    model = make_model(synth.DEFAULT_MODEL_CONFIG, 2, dev)
+    with torch.no_grad():
+        model.encoder.interactions[3].conv.lin2.bias.add_(3.0e5)  # x2 of block 3 ~ 3e5: ssp(x2) leaves the f16 range
+    g, ts, pn, G = _train_case(dev)
+    lf, gf = _train_step_grads(model, g, ts, pn, G, "f32", monkeypatch)
+    assert np.isfinite(float(lf.abs().max()))
+    with pytest.warns(RuntimeWarning, match="split-f16 training"):
+        lh, gh = _train_step_grads(model, g, ts, pn, G, "h2", monkeypatch)
+    assert model._train_f32 is True
+    assert torch.equal(lh, lf)
+    for k, ref in gf.items():
+        assert torch.equal(gh[k], ref), k
+    # the next step runs in fp32 without a warning
+    import warnings
+    from tsdiff_amd.options import OPTIONS
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        model.zero_grad(set_to_none=True)
+        loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
+                              g["batch"], g["num_nodes_per_graph"], G, _time_step=ts, _pos_noise=pn)
+        loss.mean().backward()
+    assert OPTIONS.train_gemm == "h2" and torch.equal(loss.detach(), lf)

@@ -1400,7 +1400,7 @@ __device__ __forceinline__ void filter_bwd_role(const FilterBwd& f, int tile, fl
 // [1, 2) (a row is held by ONE wave during staging: the row max is a wave reduction), df0 with one scale per tile (its
 // rows are spread over the waves: the tile max goes through LDS beside the barrier the planes need anyway); W2t16 / W0t16
 // are the f16-plane images of the dgrad matrices (pack mode 4).  The running maxima of dWf and df0 (true values) go to
-// amax[0] (as a power-of-two floor: within a factor 2) / amax[1]: the batched weight-gradient launch scales its dY operands by them.
+// amax[0] / amax[1]: the batched weight-gradient launch scales its dY operands by them.
 template <int H>
 __device__ __forceinline__ void filter_bwd_role_h(const FilterBwd& f, int tile, float* smem) {
     constexpr int TT = 32, LDH = ldh_of(H), NT = 2 * H, C4 = H / 4, NW = NT / 64;
@@ -1408,7 +1408,8 @@ __device__ __forceinline__ void filter_bwd_role_h(const FilterBwd& f, int tile, 
     float* s_c = smem + TT * LDH;
     float* s_inv = s_c + TT;    // [TT] 2^e of the dWf rows
     float* s_wmax = s_inv + TT; // [NW] per-wave max of the df0 tile
-    int* s_i = reinterpret_cast<int*>(s_wmax + NW);
+    float* s_rmax = s_wmax + NW; // [TT] max |dWf| of the rows
+    int* s_i = reinterpret_cast<int*>(s_rmax + TT);
     int* s_j = s_i + TT;
     const int E = *f.eu.count;
     const int e0 = tile * TT;
@@ -1454,7 +1455,10 @@ __device__ __forceinline__ void filter_bwd_role_h(const FilterBwd& f, int tile, 
                 m = C4 == 64 ? max64(m) : max32(m);  // the row's max
                 float inv;
                 const float sc = pow2_scale(m, inv);
-                if (c4 == 0) s_inv[r] = inv;
+                if (c4 == 0) {
+                    s_inv[r] = inv;
+                    s_rmax[r] = m;
+                }
                 planes_store4(pl, r * LDH + c4 * 4, v * sc, dummy);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1516,9 +1520,8 @@ __device__ __forceinline__ void filter_bwd_role_h(const FilterBwd& f, int tile, 
         if (row < nrows) *reinterpret_cast<float*>(reinterpret_cast<char*>(d_ea) + off[r]) = pre[r] + hval(accm[0][0], accx[0][0], r) * inv2;
     }
     if (f.amax != nullptr) {
-        // (dWf: the rows' power-of-two floors 2^e <= max |row| < 2^(e+1) -- the consumer allows for the factor)
         if (wave == 0) {
-            const float m = max32(lane < TT && lane < nrows ? s_inv[lane] : 0.0f);
+            const float m = max32(lane < TT && lane < nrows ? s_rmax[lane] : 0.0f);
             if (lane == 0 && m > 0.0f) atomic_amax(f.amax, m);
         }
         if (tid == 64) atomic_amax(f.amax + 1, tmax);
@@ -1569,7 +1572,7 @@ int launch_block_bwd(int H, int N, int first, int last, tsd_edges enc, const flo
     if (node_tiles + f.tiles == 0) return TSD_OK;
     const bool h2 = amax_h2 != nullptr;  // (then W2t / W0t are f16-plane images)
     const size_t lds_n = (size_t)TN * (H + 4) * 4, lds_f = (size_t)(32 * (H + 4) + 32) * 4 + 2 * 32 * sizeof(int);
-    const size_t lds_h = (size_t)(32 * ldh_of(H) + 3 * 32) * 4 + 2 * 32 * sizeof(int);
+    const size_t lds_h = (size_t)(32 * ldh_of(H) + 4 * 32) * 4 + 2 * 32 * sizeof(int);
     const size_t lds = std::max(lds_n, h2 ? lds_h : lds_f);
 #define TSD_NB(HH)                                                                                              \
     {                                                                                                           \

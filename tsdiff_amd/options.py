@@ -15,7 +15,7 @@ at import, by `TSDIFF_*` environment variables (read here and nowhere else); tes
 | fused_encoder      | TSDIFF_FUSED_ENCODER      | True    | chip-full launches (big batches, ensembles): the whole SchNet encoder as ONE launch of per-unit workgroups that never write the CFConv filters to memory (kernels_unit.hip); False: one launch per block with materialised filters; "force": also where the one-launch form would apply.  Bit-identical (the messages are added in the directed list's order) |
 | pingpong           | TSDIFF_PINGPONG           | False   | form of the fused encoder on units that are single graphs of > 32 atoms: False = eight waves own a CU and walk one tile's phases together (unit_encoder_kernel); "solo" = block tiles with x1 / agg in memory at 128 VGPRs / 80 KB: two units per CU, interleaved by the hardware; "teams" = the same in lock step, two teams of eight waves in one workgroup, one on the matrix pipes while the other runs its VALU / LDS steps (unit_encoder_pp_kernel).  Bit-identical; measurements in DESIGN.md 4c |
 | train              | TSDIFF_TRAIN              | "fused" | training step: "fused" = forward + loss and the whole backward as two library calls (csrc/train_step.hip), "ops" = one autograd node per operation (same kernels; the cross-check) |
-| train_gemm         | TSDIFF_TRAIN_GEMM         | "f32"   | arithmetic of the fused training step's tile GEMMs: "f32" = fp32-input MFMA, "h2" = split-f16 operands (gradient operands scaled by a power of two per tensor).  A step whose activations leave the f16 range is recomputed in "f32" |
+| train_gemm         | TSDIFF_TRAIN_GEMM         | "h2"    | arithmetic of the fused training step's tile GEMMs: "f32" = fp32-input MFMA, "h2" = split-f16 operands (gradient operands scaled by a power of two per tensor).  A step whose activations leave the f16 range is recomputed in "f32" |
 """
 import os
 from dataclasses import dataclass
@@ -36,7 +36,7 @@ class Options:
     fused_encoder: bool = True
     pingpong: object = False
     train: str = "fused"
-    train_gemm: str = "f32"
+    train_gemm: str = "h2"
 
     @classmethod
     def from_env(cls):
@@ -45,7 +45,7 @@ class Options:
                 fused_step_tail=_flag("TSDIFF_FUSED_TAIL"), fused_encoder=_flag("TSDIFF_FUSED_ENCODER"),
                 pingpong={"0": False, "solo": "solo", "teams": "teams", "1": "teams"}.get(
                     os.environ.get("TSDIFF_PINGPONG", "0"), False),
-                train=os.environ.get("TSDIFF_TRAIN", "fused"), train_gemm=os.environ.get("TSDIFF_TRAIN_GEMM", "f32"))
+                train=os.environ.get("TSDIFF_TRAIN", "fused"), train_gemm=os.environ.get("TSDIFF_TRAIN_GEMM", "h2"))
         o.validate()
         return o
 
