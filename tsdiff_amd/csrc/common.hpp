@@ -262,7 +262,8 @@ int launch_pair_output(const tsd_model_cfg& c, const float* W, int capacity, tsd
 
 int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity, tsd_edges e, const float* h,
                          const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
-                         size_t ea_stride, size_t inv_stride, hipStream_t st, bool folded, int32_t* range_status);
+                         size_t ea_stride, size_t inv_stride, hipStream_t st, bool folded, int32_t* range_status,
+                         const PairSave* save = nullptr);
 int launch_pack_weights16(const tsd_model_cfg& c, const float* packed, float* packed16, hipStream_t st);
 int launch_weights_preflight(const float* w, size_t n, float* out8, hipStream_t st);
 // the whole split-f16 forward of one checkpoint as ONE launch (kernels_combo.hip, small batches)

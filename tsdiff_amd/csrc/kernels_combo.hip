@@ -1050,9 +1050,10 @@ __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, fl
     range_report(amax, range_status);
 }
 
-template <int H>
+// SAVE (training step): the tile's inputs and pre-/post-activations also go to `sv` (as pair_output_kernel<H, true>).
+template <int H, bool SAVE = false>
 __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int node_tiles, float* smem, bool defer_pre,
-                                            int32_t* range_status) {
+                                            int32_t* range_status, const PairSave& sv = PairSave{}) {
     constexpr int LDH = ldh_of(H), NT = 2 * H, C4 = H / 4, NW = H / 64;
     const Planes pl = planes_at(smem, T, LDH);
     float* s_red = smem + T * LDH;  // [NW][T]
@@ -1070,7 +1071,11 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
         const int ee = e0 + min(tid, nrows - 1);
         s_src[tid] = q.e.src[ee];
         s_dst[tid] = q.e.dst[ee];
-        s_row[tid] = q.attr_row ? q.attr_row[ee] : ee;
+        int row = q.attr_row ? q.attr_row[ee] : ee;
+        if constexpr (SAVE) {
+            if (row >= sv.attr_from) row -= sv.attr_shift;
+        }
+        s_row[tid] = row;
     }
     __syncthreads();
     f32x16 accm[1][1], accx[1][1];
@@ -1091,6 +1096,9 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
             planes_store4(pl, r * LDH + c4 * 4, v[it], site_m);
+            if constexpr (SAVE) {
+                if (r < nrows) *reinterpret_cast<f32x4*>(sv.hp + (size_t)(e0 + r) * 2 * H + H + c4 * 4) = v[it];
+            }
         }
         site_close(amax, site_m);
         hgemm_ring_start<1, H>(rg, q.w0b, H, col0);  // (behind the staging: its registers are free now)
@@ -1158,6 +1166,9 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
             const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             planes_store4(pl, r * LDH + c4 * 4, r < nrows ? hs[it] * hd[it] : z, amax);
+            if constexpr (SAVE) {
+                if (r < nrows) *reinterpret_cast<f32x4*>(sv.hp + (size_t)(e0 + r) * 2 * H + c4 * 4) = hs[it] * hd[it];
+            }
         }
     }
     hgemm_ring_start<1, H>(rg, q.w0a, H, col0);  // (behind the staging: its registers are free now)
@@ -1166,8 +1177,17 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
     hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-        planes_store1(pl, acc_row(r, hi) * LDH + col, swishf(pre_v[r] + hval(accm[0][0], accx[0][0], r)), amax);
+    for (int r = 0; r < 16; ++r) {
+        const float v = pre_v[r] + hval(accm[0][0], accx[0][0], r), sg = swishf(v);
+        planes_store1(pl, acc_row(r, hi) * LDH + col, sg, amax);
+        if constexpr (SAVE) {
+            const int row = acc_row(r, hi);
+            if (row < nrows) {
+                sv.g0[(size_t)(e0 + row) * H + col] = v;
+                sv.gs0[(size_t)(e0 + row) * H + col] = sg;
+            }
+        }
+    }
     __syncthreads();
     if (wave < NW) {  // H -> H/2 and the final dot: the first H/64 waves
         const int c2 = wave * 32 + l31;
@@ -1177,6 +1197,13 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float g = hval(accm[0][0], accx[0][0], r) + b, sg = swishf(g);
+            if constexpr (SAVE) {
+                const int row = acc_row(r, hi);
+                if (row < nrows) {
+                    sv.g1[(size_t)(e0 + row) * (H / 2) + c2] = g;
+                    sv.gs1[(size_t)(e0 + row) * (H / 2) + c2] = sg;
+                }
+            }
             float v = sg * w2;
             v += __shfl_xor(v, 16);
             v += __shfl_xor(v, 8);
@@ -1721,19 +1748,20 @@ int filter_tiles_per_layer(int capacity_u);
 
 // The stand-alone pair output (tsd_pair_output's place in a forward that does not run it inside the last block
 // launch) on the f16 MFMA pipes: pair_role_h without the wait.
-template <int H>
+template <int H, bool SAVE = false>
 __global__ __launch_bounds__(2 * H) void pair_output_h_kernel(ComboPre q, size_t wstride, size_t h_stride, size_t ea_stride,
-                                                              int32_t* range_status) {
+                                                              int32_t* range_status, PairSave sv) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const size_t m = blockIdx.y, wo = m * wstride;
     q.edge_attr += m * ea_stride; q.w0b += wo; q.b0 += wo;
     q.w0a += wo; q.w1 += wo; q.b1 += wo; q.w2 += wo; q.b2 += wo;
     q.h += m * h_stride; q.edge_inv += m * q.inv_stride;
-    pair_role_h<H>(q, blockIdx.x, 0, smem, false, range_status);
+    pair_role_h<H, SAVE>(q, blockIdx.x, 0, smem, false, range_status, sv);
 }
 int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity, tsd_edges e, const float* h,
                          const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
-                         size_t ea_stride, size_t inv_stride, hipStream_t st, bool folded, int32_t* range_status) {
+                         size_t ea_stride, size_t inv_stride, hipStream_t st, bool folded, int32_t* range_status,
+                         const PairSave* save) {
     const WeightLayout L = weight_layout(c);
     const size_t H = c.hidden;
     const int tiles = (capacity + T - 1) / T;
@@ -1757,13 +1785,19 @@ int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity,
     q.status = nullptr;
     q.inv_stride = inv_stride;
     const size_t lds = (size_t)(T * ldh_of(c.hidden) + (c.hidden / 64) * T + 3 * T) * 4;
+    if (save && (folded || M != 1)) {
+        set_error("internal: the saving pair output takes the unfolded first layer of one checkpoint");
+        return TSD_ERR_INVALID;
+    }
 #define TSD_POH(HH)                                                                                              \
     {                                                                                                            \
-        static DeviceOnce once;                                                                                  \
-        int r = allow_lds(pair_output_h_kernel<HH>, lds, once);                                                  \
+        static DeviceOnce once, once_s;                                                                          \
+        int r = save ? allow_lds(pair_output_h_kernel<HH, true>, lds, once_s) : allow_lds(pair_output_h_kernel<HH>, lds, once); \
         if (r) return r;                                                                                         \
-        hipLaunchKernelGGL(pair_output_h_kernel<HH>, dim3(tiles, M), dim3(2 * HH), lds, st, q, L.total, h_stride, \
-                           ea_stride, range_status);                                                             \
+        if (save) hipLaunchKernelGGL((pair_output_h_kernel<HH, true>), dim3(tiles, M), dim3(2 * HH), lds, st, q, L.total, h_stride, \
+                           ea_stride, range_status, *save);                                                      \
+        else hipLaunchKernelGGL(pair_output_h_kernel<HH>, dim3(tiles, M), dim3(2 * HH), lds, st, q, L.total, h_stride, \
+                           ea_stride, range_status, PairSave{});                                                 \
     }
     switch (c.hidden) {
         case 64: TSD_POH(64) break;

@@ -5,6 +5,7 @@
 // that tile on chip (activations in LDS, accumulators in AGPR/VGPR) and streams the packed
 // weights from L2 with 1-KiB coalesced wave loads.  Reference call sites are cited per kernel.
 #include "train_internal.hpp"
+#include "split16.hpp"
 
 namespace tsd {
 
@@ -437,14 +438,151 @@ __global__ __launch_bounds__(2 * H) void pair_bwd_kernel(tsd_edges e, const int3
     }
 }
 
+// The same chain on the f16 MFMA pipes (split16.hpp, GRADIENT operands; W1t / W0t: f16-plane images of the dgrad
+// matrices).  dg1 rows are scaled by 2^-e of the bound |ds| max|w2| 1.1 >= max |row| (swish' <= 1.0999: no reduction
+// needed), dg0 by the tile's max (through LDS beside the barrier the planes need).  amax[0] / amax[1]: running max of
+// |dg1| / |dg0| for the weight-gradient launches.
+template <int H>
+__global__ __launch_bounds__(2 * H) void pair_bwd_h_kernel(tsd_edges e, const int32_t* __restrict__ attr_row,
+                                                          const float* __restrict__ ds, const float* __restrict__ w2,
+                                                          const float* __restrict__ g1, const float* __restrict__ g0,
+                                                          const float* __restrict__ W1t, const float* __restrict__ W0t,
+                                                          float* __restrict__ dg1, float* __restrict__ dg0,
+                                                          float* __restrict__ dp, float* __restrict__ d_ea,
+                                                          int attr_from, int attr_shift, float* __restrict__ amax) {
+    constexpr int LDH = ldh_of(H), NT = 2 * H, HH = H / 2, NW = NT / 64;
+    static_assert(HH == 128, "the w2 max below reads two values per lane");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Planes pl = planes_at(smem, T, LDH);
+    float* s_ds = smem + T * LDH;
+    float* s_sc = s_ds + T;    // [T] 2^-e of the dg1 rows
+    float* s_inv = s_sc + T;   // [T] 2^e
+    float* s_wmax = s_inv + T; // [NW]
+    int* s_row = reinterpret_cast<int*>(s_wmax + NW);
+    const int E = *e.count;
+    const int e0 = blockIdx.x * T;
+    if (e0 >= E) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int col0 = wave * 32, col = col0 + l31;
+    const int nrows = min(T, E - e0);
+    const float w2m = max64(fmaxf(fabsf(w2[lane]), fabsf(w2[lane + 64])));
+    if (tid < T) {
+        const bool v = tid < nrows;
+        const float d = v ? ds[e0 + tid] : 0.0f;
+        s_ds[tid] = d;
+        float inv;
+        s_sc[tid] = pow2_scale(fabsf(d) * w2m * 1.1f, inv);
+        s_inv[tid] = inv;
+        int row = v ? attr_row[e0 + tid] : 0;
+        if (row >= attr_from) row -= attr_shift;
+        s_row[tid] = row;
+    }
+    __syncthreads();
+    float dummy = 0.0f, m1 = 0.0f;
+    {
+        constexpr int NIT = T * HH / NT;
+        static_assert(T * HH % NT == 0, "tile / block mismatch");
+        float gv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = min(idx / HH, nrows - 1), c = idx % HH;
+            gv[it] = g1[(size_t)(e0 + r) * HH + c];
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / HH, c = idx % HH;
+            float v = 0.0f;
+            if (r < nrows) {
+                v = s_ds[r] * w2[c] * act_deriv(0, gv[it]);
+                dg1[(size_t)(e0 + r) * HH + c] = v;
+            }
+            amax_upd(m1, v);
+            planes_store1(pl, r * LDH + c, v * s_sc[r], dummy);
+        }
+    }
+    __syncthreads();
+    f32x16 accm[1][1], accx[1][1];
+    hzero(accm, accx);
+    hgemm_tile<1, 1, HH, true>(pl, LDH, W1t, H, col0, accm, accx);
+    // (tile base pointers are wave-uniform: SGPR base + one 32-bit lane offset per row; computed behind the GEMM's asm
+    // statements -- held across the MFMA stream the values cost the second workgroup of the CU, see filter_bwd_role_h)
+    const float* g0t = g0 + (size_t)e0 * H;
+    float* dg0t = dg0 + (size_t)e0 * H;
+    float* dpt = dp + (size_t)e0 * H;
+    unsigned off[16];
+    int hi_p = hi;
+    asm volatile("" : "+v"(hi_p));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) off[r] = (unsigned)(min(acc_row(r, hi_p), nrows - 1) * H + col) * 4u;
+    float pre[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pre[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(g0t) + off[r]);
+    float v0[16], m0 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi);
+        v0[r] = 0.0f;
+        if (row < nrows) {
+            v0[r] = hval(accm[0][0], accx[0][0], r) * s_inv[row] * act_deriv(0, pre[r]);
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(dg0t) + off[r]) = v0[r];
+        }
+        m0 = fmaxf(m0, fabsf(v0[r]));
+    }
+    m0 = max64(m0);
+    if (lane == 0) s_wmax[wave] = m0;
+    __syncthreads();  // (every wave is done reading the planes, the wave maxima are in place)
+    float tmax = s_wmax[0];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) tmax = fmaxf(tmax, s_wmax[k]);
+    float inv2;
+    const float sc2 = pow2_scale(tmax, inv2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) planes_store1(pl, acc_row(r, hi) * LDH + col, v0[r] * sc2, dummy);
+    __syncthreads();
+    hzero(accm, accx);
+    hgemm_tile<1, 1, H, true>(pl, LDH, W0t, 2 * H, col0, accm, accx);
+    hi_p = hi;
+    asm volatile("" : "+v"(hi_p));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi_p);
+        if (row < nrows) *reinterpret_cast<float*>(reinterpret_cast<char*>(dpt) + (unsigned)(row * H + col) * 4u) =
+            hval(accm[0][0], accx[0][0], r) * inv2;
+    }
+    hzero(accm, accx);
+    hgemm_tile<1, 1, H, true>(pl, LDH, W0t, 2 * H, col0 + H, accm, accx);
+    hi_p = hi;
+    asm volatile("" : "+v"(hi_p));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi_p);
+        if (row < nrows) d_ea[(size_t)s_row[row] * H + col] = hval(accm[0][0], accx[0][0], r) * inv2;  // every out edge owns its attribute row
+    }
+    if (amax != nullptr) {
+        m1 = max64(m1);
+        if (lane == 0) atomic_amax(amax, m1);
+        if (tid == 64) atomic_amax(amax + 1, tmax);
+    }
+}
+
 int launch_pair_bwd(int H, int rows, tsd_edges e, const int32_t* attr_row, const float* ds, const float* w2,
                     const float* g1, const float* g0, const float* W1t, const float* W0t, float* dg1, float* dg0,
-                    float* dp, float* d_ea, int attr_from, int attr_shift, hipStream_t st) {
+                    float* dp, float* d_ea, int attr_from, int attr_shift, hipStream_t st, float* amax_h2) {
     if (rows == 0) return TSD_OK;
     const size_t lds = (size_t)(T * (H + 4) + T) * 4 + T * sizeof(int);
     if (H != 256) {
         set_error("pair_bwd: hidden=%d has no MFMA instance", H);
         return TSD_ERR_INVALID;
+    }
+    if (amax_h2 != nullptr) {  // split-f16 form: W1t / W0t are f16-plane images
+        const size_t lds_h = (size_t)(T * ldh_of(H) + 3 * T + 8) * 4 + T * sizeof(int);
+        static DeviceOnce once_h;
+        int r = allow_lds(pair_bwd_h_kernel<256>, lds_h, once_h);
+        if (r) return r;
+        hipLaunchKernelGGL(pair_bwd_h_kernel<256>, dim3((rows + T - 1) / T), dim3(512), lds_h, st, e, attr_row, ds, w2, g1, g0,
+                           W1t, W0t, dg1, dg0, dp, d_ea, attr_from, attr_shift, amax_h2);
+        TSD_LAUNCH_CHECK("pair_bwd_h");
+        return TSD_OK;
     }
     static DeviceOnce once;
     int r = allow_lds(pair_bwd_kernel<256>, lds, once);
@@ -1090,12 +1228,12 @@ int launch_pair_output(const tsd_model_cfg& c, const float* W, int capacity, tsd
                        size_t ea_stride, size_t inv_stride, hipStream_t st, const float* pre, size_t pre_stride,
                        const PairSave* save, bool folded, Prec prec) {
     if (prec.mode == PREC_H2) {
-        if (save || pre) {
-            set_error("internal: the split-f16 pair output has no saving form and takes no precomputed half");
+        if (pre) {
+            set_error("internal: the split-f16 pair output takes no precomputed half");
             return TSD_ERR_INVALID;
         }
         return launch_pair_output_h(c, W, capacity, e, h, edge_attr, attr_row, edge_inv, M, h_stride, ea_stride, inv_stride,
-                                    st, folded, prec.range_status);
+                                    st, folded, prec.range_status, save);
     }
     const WeightLayout L = weight_layout(c);
     PairW w{W + L.out_w0, W + L.out_b0, W + L.out_w1, W + L.out_b1, W + L.out_w2, W + L.out_b2,

@@ -58,7 +58,7 @@ int launch_embed_bwd(int H, int rows_a, const EmbedBwdList& la, int rows_b, cons
                      const float* W1t, const float* W0t, const float* Wmt, hipStream_t st);
 int launch_pair_bwd(int H, int rows, tsd_edges e, const int32_t* attr_row, const float* ds, const float* w2,
                     const float* g1, const float* g0, const float* W1t, const float* W0t, float* dg1, float* dg0,
-                    float* dp, float* d_ea, int attr_from, int attr_shift, hipStream_t st);
+                    float* dp, float* d_ea, int attr_from, int attr_shift, hipStream_t st, float* amax_h2 = nullptr);
 int launch_row_gather(int H, int N, tsd_edges e, const float* W, const float* x, float* out, hipStream_t st);
 int launch_block_bwd(int H, int N, int first, int last, tsd_edges enc, const float* Wf, const float* dagg_in,
                      const float* dh_up, const float* w_lin1_t, const float* w_lin_t, const float* w_lin2_t,

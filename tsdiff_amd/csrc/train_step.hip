@@ -93,7 +93,8 @@ struct Work {
     float* pack_t;                 // dgrad layouts of the dense weights, offsets = raw offsets
     float* pack16;                 // f16-plane image of pack_inf (tsd_pack_weights16): the split-f16 block launches
     float* pack_t16;               // f16-plane images of the filter MLPs' dgrad matrices, offsets = raw offsets
-    float* amax;                   // [L][2] running max |dWf|, |df0| per block (split-f16 backward: the wgrad's dY scales)
+    float* amax;                   // [L][2] running max |dWf|, |df0| per block, then [2] |dg1|, |dg0| of the pair MLP
+                                   // (split-f16 backward: the dY scales of the weight-gradient launches)
     float* scratch;                // linear scratch
     size_t scratch_floats;
     // backward temporaries
@@ -146,7 +147,7 @@ Work carve(const tsd_model_cfg& c, int N, size_t PU, float* base) {
     w.pack_t = take(R.total);
     w.pack16 = take(weight_layout(c).total);
     w.pack_t16 = take(R.total);
-    w.amax = take(2 * L);
+    w.amax = take(2 * L + 2);
     w.scratch_floats = linear_scratch_floats((int)(2 * H), (int)H);
     if (w.scratch_floats < (size_t)512 * 32 * H) w.scratch_floats = (size_t)512 * 32 * H;  // embedding-gradient partials
     w.scratch = take(w.scratch_floats);
@@ -167,6 +168,7 @@ Work carve(const tsd_model_cfg& c, int N, size_t PU, float* base) {
             b = PU > 0 ? wgrad_batch_scratch_floats((int)(2 * L), (int)PU, (int)H, (int)H) : 0;
             e2 = PU > 0 ? wgrad_batch_scratch_floats(2, (int)(2 * PU), (int)H, (int)H) : 0;  // the embedding's two H x H layers
             if (PU > 0 && (H / 2) % 128 == 0) e2 = std::max(e2, wgrad_batch_scratch_floats(1, (int)PU, (int)H, (int)(H / 2)));  // pair MLP layers.1
+            if (PU > 0) e2 = std::max(e2, wgrad_batch_scratch_floats(1, (int)PU, (int)(2 * H), (int)H));  // pair MLP layers.0 (split-f16 step)
         }
         w.wpart = take(std::max(a, std::max(b, e2)));
     }
@@ -552,13 +554,14 @@ int pack_all(const Ctx& x, bool h2) {
         pk(i + I.L_lin_w, r + R.L_lin_w, H, H);
         cp(i + I.L_lin_b, r + R.L_lin_b, H);
     }
-    blocks = false;
-    pk(I.out_w0, R.out_w0, H, 2 * H);
+    // (the pair MLP as the blocks: forward planes in the f16 arena; dgrad planes below)
+    pk(I.out_w0, R.out_w0, H, 2 * H, true);
     cp(I.out_b0, R.out_b0, H);
-    pk(I.out_w1, R.out_w1, H / 2, H);
+    pk(I.out_w1, R.out_w1, H / 2, H, true);
     cp(I.out_b1, R.out_b1, H / 2);
     cp(I.out_w2, R.out_w2, H / 2);
     cp(I.out_b2, R.out_b2, 1);
+    blocks = false;
     return launch_pack_items((int)it.size(), it.data(), x.st);
 }
 
@@ -767,8 +770,8 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
         PairSave psv{w.hp, w.g0, w.gs0, w.g1, w.gs1};
         psv.attr_from = PU;
         psv.attr_shift = PU - Eu;
-        TSD_TRY(launch_pair_output(*cfg, W, Eo, g.out_u, w.h + (size_t)L * NH, w.ea, g.attr_row, w.s_u, 1, 0, 0, 0, st,
-                                   nullptr, 0, &psv));
+        TSD_TRY(launch_pair_output(*cfg, h2 ? w.pack16 : W, Eo, g.out_u, w.h + (size_t)L * NH, w.ea, g.attr_row, w.s_u, 1,
+                                   0, 0, 0, st, nullptr, 0, &psv, false, prec));
     }
     // loss                                                                      condensenc.py:303-328
     hipLaunchKernelGGL(loss_head_kernel, dim3((N + 63) / 64), dim3(64), 0, st, N, g.out, pos, pos0, batch->node_graph,
@@ -844,17 +847,32 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
             // the three dgrads, the split of dhp and the scatter of its right half as ONE tile kernel; the weight
             // gradients from the dY it wrote
             float *dg1 = w.eA + (size_t)PU * H, *dg0 = w.eB;  // [Eo,H/2] behind dp, [Eo,H]
-            TSD_TRY(launch_pair_bwd(H, Eo, g.out_u, g.attr_row, ds, raw + x.R.out_w2, w.g1, w.g0, w.pack_t + x.R.out_w1,
-                                    w.pack_t + x.R.out_w0, dg1, dg0, dp, w.d_ea, PU, PU - Eu, st));
+            // (split-f16 step: the chain on f16 MFMA, the weight gradients with dY scaled by the maxima it kept; their X --
+            // gs0, hp -- passed the range check of the split-f16 forward's pair tiles)
+            float* pamax = w.amax + 2 * L;
+            if (h2) TSD_HIP(hipMemsetAsync(w.amax, 0, (2 * (size_t)L + 2) * sizeof(float), st));
+            TSD_TRY(launch_pair_bwd(H, Eo, g.out_u, g.attr_row, ds, raw + x.R.out_w2, w.g1, w.g0,
+                                    (h2 ? w.pack_t16 : w.pack_t) + x.R.out_w1, (h2 ? w.pack_t16 : w.pack_t) + x.R.out_w0, dg1,
+                                    dg0, dp, w.d_ea, PU, PU - Eu, st, h2 ? pamax : nullptr));
             TSD_TRY(x.lin_bwd(Eo, H / 2, 1, w.gs1, x.R.out_w2, (long)x.R.out_b2, ds, nullptr, false));
             {   // [H/2 x H]: two output blocks -- split finer than the single-problem form (128 ways: one workgroup per CU)
                 const float* dYs[1] = {dg1};
                 const float* Xs[1] = {w.gs0};
                 float* dWs[1] = {grad + x.R.out_w1};
                 float* dbs[1] = {grad + x.R.out_b1};
-                TSD_TRY(launch_wgrad_batch(1, Eo, H, H / 2, dYs, Xs, dWs, dbs, 1, w.wpart, st));
+                const float* am[1] = {pamax};
+                TSD_TRY(launch_wgrad_batch(1, Eo, H, H / 2, dYs, Xs, dWs, dbs, 1, w.wpart, st, h2 ? am : nullptr));
             }
-            TSD_TRY(x.lin_bwd(Eo, 2 * H, H, w.hp, x.R.out_w0, (long)x.R.out_b0, dg0, nullptr, false));
+            if (h2) {
+                const float* dYs[1] = {dg0};
+                const float* Xs[1] = {w.hp};
+                float* dWs[1] = {grad + x.R.out_w0};
+                float* dbs[1] = {grad + x.R.out_b0};
+                const float* am[1] = {pamax + 1};
+                TSD_TRY(launch_wgrad_batch(1, Eo, 2 * H, H, dYs, Xs, dWs, dbs, 1, w.wpart, st, am));
+            } else {
+                TSD_TRY(x.lin_bwd(Eo, 2 * H, H, w.hp, x.R.out_w0, (long)x.R.out_b0, dg0, nullptr, false));
+            }
         } else {
             TSD_TRY(x.lin_bwd(Eo, H / 2, 1, w.gs1, x.R.out_w2, (long)x.R.out_b2, ds, w.eB, false, 0, w.g1));   // dg1
             TSD_TRY(x.lin_bwd(Eo, H, H / 2, w.gs0, x.R.out_w1, (long)x.R.out_b1, w.eB, w.eA, false, 0, w.g0)); // dg0
@@ -876,7 +894,7 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
         float *dagg = w.nA, *dagg_other = w.nB;
         auto wt = [&](int l, size_t off) { return w.pack_t + x.R.layer0 + (size_t)l * x.R.layer_stride + off; };
         auto wt16 = [&](int l, size_t off) { return w.pack_t16 + x.R.layer0 + (size_t)l * x.R.layer_stride + off; };
-        if (h2) TSD_HIP(hipMemsetAsync(w.amax, 0, 2 * (size_t)L * sizeof(float), st));
+        if (h2 && Eo == 0) TSD_HIP(hipMemsetAsync(w.amax, 0, (2 * (size_t)L + 2) * sizeof(float), st));
         const tsd_edges none{};
         TSD_TRY(launch_block_bwd(H, N, 1, 0, g.enc, nullptr, nullptr, w.dh, nullptr, wt(L - 1, x.R.L_lin_w),
                                  wt(L - 1, x.R.L_lin2_w), w.x2 + (size_t)(L - 1) * NH, nullptr, nullptr,
