@@ -260,6 +260,9 @@ int launch_pair_output(const tsd_model_cfg& c, const float* W, int capacity, tsd
                        size_t ea_stride, size_t inv_stride, hipStream_t st, const float* pre, size_t pre_stride,
                        const PairSave* save = nullptr, bool folded = false, Prec prec = Prec{});
 
+int launch_edge_embed_save_h(const tsd_model_cfg& c, const float* W16, int cap_a, tsd_edges ea, float* out_a, int cap_b,
+                             tsd_edges eb, float* out_b, hipStream_t st, const EmbedSave& save, int save_b_row,
+                             int32_t* range_status);
 int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity, tsd_edges e, const float* h,
                          const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
                          size_t ea_stride, size_t inv_stride, hipStream_t st, bool folded, int32_t* range_status,

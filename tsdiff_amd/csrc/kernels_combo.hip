@@ -1428,6 +1428,9 @@ __device__ __forceinline__ void filter_bwd_role(const FilterBwd& f, int tile, fl
 // rows are spread over the waves: the tile max goes through LDS beside the barrier the planes need anyway); W2t16 / W0t16
 // are the f16-plane images of the dgrad matrices (pack mode 4).  The running maxima of dWf and df0 (true values) go to
 // amax[0] / amax[1]: the batched weight-gradient launch scales its dY operands by them.
+#ifndef TSD_FBWD_RING
+#define TSD_FBWD_RING 5  // weight k-steps in flight per wave of the backward filter chain
+#endif
 template <int H>
 __device__ __forceinline__ void filter_bwd_role_h(const FilterBwd& f, int tile, float* smem) {
     constexpr int TT = 32, LDH = ldh_of(H), NT = 2 * H, C4 = H / 4, NW = NT / 64;
@@ -1496,7 +1499,7 @@ __device__ __forceinline__ void filter_bwd_role_h(const FilterBwd& f, int tile, 
     __syncthreads();
     f32x16 accm[1][1], accx[1][1];
     hzero(accm, accx);
-    hgemm_tile<1, 1, H, true>(pl, LDH, f.W2t, H, col0, accm, accx);
+    hgemm_tile<1, 1, H, true, TSD_FBWD_RING>(pl, LDH, f.W2t, H, col0, accm, accx);
     // (the pre-activations, and below the old attribute-gradient values, are read BEHIND the GEMM that precedes their
     // use: sixteen values held across the MFMA stream put the kernel over the 128-register line of two workgroups
     // per CU, whose interleaving hides this latency anyway)
@@ -1534,7 +1537,7 @@ __device__ __forceinline__ void filter_bwd_role_h(const FilterBwd& f, int tile, 
     for (int r = 0; r < 16; ++r) planes_store1(pl, acc_row(r, hi) * LDH + col, v0[r] * sc2, dummy);
     __syncthreads();
     hzero(accm, accx);
-    hgemm_tile<1, 1, H, true>(pl, LDH, f.W0t, H, col0, accm, accx);
+    hgemm_tile<1, 1, H, true, TSD_FBWD_RING>(pl, LDH, f.W0t, H, col0, accm, accx);
     hi_p = hi;
     asm volatile("" : "+v"(hi_p));
 #pragma unroll

@@ -438,6 +438,12 @@ __global__ __launch_bounds__(2 * H) void pair_bwd_kernel(tsd_edges e, const int3
     }
 }
 
+#ifndef TSD_BWD_PIN
+#define TSD_BWD_PIN false
+#endif
+#ifndef TSD_BWD_RING
+#define TSD_BWD_RING 3  // weight k-steps in flight per wave in the backward tile chains (they have the registers)
+#endif
 // The same chain on the f16 MFMA pipes (split16.hpp, GRADIENT operands; W1t / W0t: f16-plane images of the dgrad
 // matrices).  dg1 rows are scaled by 2^-e of the bound |ds| max|w2| 1.1 >= max |row| (swish' <= 1.0999: no reduction
 // needed), dg0 by the tile's max (through LDS beside the barrier the planes need).  amax[0] / amax[1]: running max of
@@ -503,7 +509,7 @@ __global__ __launch_bounds__(2 * H) void pair_bwd_h_kernel(tsd_edges e, const in
     __syncthreads();
     f32x16 accm[1][1], accx[1][1];
     hzero(accm, accx);
-    hgemm_tile<1, 1, HH, true>(pl, LDH, W1t, H, col0, accm, accx);
+    hgemm_tile<1, 1, HH, TSD_BWD_PIN, TSD_BWD_RING>(pl, LDH, W1t, H, col0, accm, accx);
     // (tile base pointers are wave-uniform: SGPR base + one 32-bit lane offset per row; computed behind the GEMM's asm
     // statements -- held across the MFMA stream the values cost the second workgroup of the CU, see filter_bwd_role_h)
     const float* g0t = g0 + (size_t)e0 * H;
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(2 * H) void pair_bwd_h_kernel(tsd_edges e, const in
     for (int r = 0; r < 16; ++r) planes_store1(pl, acc_row(r, hi) * LDH + col, v0[r] * sc2, dummy);
     __syncthreads();
     hzero(accm, accx);
-    hgemm_tile<1, 1, H, true>(pl, LDH, W0t, 2 * H, col0, accm, accx);
+    hgemm_tile<1, 1, H, TSD_BWD_PIN, TSD_BWD_RING>(pl, LDH, W0t, 2 * H, col0, accm, accx);
     hi_p = hi;
     asm volatile("" : "+v"(hi_p));
 #pragma unroll
@@ -550,7 +556,7 @@ __global__ __launch_bounds__(2 * H) void pair_bwd_h_kernel(tsd_edges e, const in
             hval(accm[0][0], accx[0][0], r) * inv2;
     }
     hzero(accm, accx);
-    hgemm_tile<1, 1, H, true>(pl, LDH, W0t, 2 * H, col0 + H, accm, accx);
+    hgemm_tile<1, 1, H, TSD_BWD_PIN, TSD_BWD_RING>(pl, LDH, W0t, 2 * H, col0 + H, accm, accx);
     hi_p = hi;
     asm volatile("" : "+v"(hi_p));
 #pragma unroll
@@ -558,9 +564,17 @@ __global__ __launch_bounds__(2 * H) void pair_bwd_h_kernel(tsd_edges e, const in
         const int row = acc_row(r, hi_p);
         if (row < nrows) d_ea[(size_t)s_row[row] * H + col] = hval(accm[0][0], accx[0][0], r) * inv2;  // every out edge owns its attribute row
     }
-    if (amax != nullptr) {
+    if (amax != nullptr) {  // one (conditional) atomic per tile and word
         m1 = max64(m1);
-        if (lane == 0) atomic_amax(amax, m1);
+        __syncthreads();
+        if (lane == 0) s_wmax[wave] = m1;
+        __syncthreads();
+        if (tid == 0) {
+            float t = s_wmax[0];
+#pragma unroll
+            for (int k = 1; k < NW; ++k) t = fmaxf(t, s_wmax[k]);
+            atomic_amax(amax, t);
+        }
         if (tid == 64) atomic_amax(amax + 1, tmax);
     }
 }
@@ -1094,6 +1108,130 @@ static inline size_t lds_pair(int H) { return (size_t)(T * (2 * H + 4) + (H / 64
         case 256: { constexpr int HH = 256; __VA_ARGS__; } break;   \
         default: set_error("hidden=%d unsupported (64/128/256)", H_); return TSD_ERR_INVALID; \
     }
+
+// The saving edge embedding of the training step on the f16 MFMA pipes (split16.hpp): the same chain in the reference's
+// operation order (no fold), every GEMM operand tile as two f16 planes in LDS ([T][2H + 8] each), the dense matrices
+// from the f16-plane arena, fp32 accumulation, fp32 results and saves.  Every conversion feeds the role's running max:
+// the workgroup raises TSD_STATUS_RANGE when a value left the f16 range (the step is then recomputed in fp32).
+template <int H>
+__global__ __launch_bounds__(2 * H) void edge_embed_save_h_kernel(EdgeEmbedW w, tsd_edges ea_, float* __restrict__ out_a,
+                                                                  int tiles_a, tsd_edges eb_, float* __restrict__ out_b,
+                                                                  EmbedSave sv, int save_b_row, int32_t* range_status) {
+    constexpr int LDH = ldh_of(2 * H);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Planes pl = planes_at(smem, T, LDH);
+    float* s_d = smem + T * LDH;
+    int* s_tr = reinterpret_cast<int*>(s_d + T);
+    int* s_tp = s_tr + T;
+    const bool second = (int)blockIdx.x >= tiles_a;
+    const tsd_edges& e = second ? eb_ : ea_;
+    float* __restrict__ edge_attr = second ? out_b : out_a;
+    const int E = *e.count;
+    const int e0 = (second ? (int)blockIdx.x - tiles_a : (int)blockIdx.x) * T;
+    if (e0 >= E) return;
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int col0 = (tid >> 6) * 32, col = col0 + l31;
+    const int nrows = min(T, E - e0);
+    const size_t srow0 = (size_t)(second ? save_b_row : 0) + e0;
+    float amax = 0.0f;
+    if (tid < T) {
+        const int ee = e0 + tid;
+        const bool v = ee < E;
+        s_d[tid] = v ? e.dist[ee] : 0.0f;
+        s_tr[tid] = v ? (int)e.type_r[ee] : 0;
+        s_tp[tid] = v ? (int)e.type_p[ee] : 0;
+        if (v) {
+            sv.d[srow0 + tid] = s_d[tid];
+            sv.tr[srow0 + tid] = (uint8_t)s_tr[tid];
+            sv.tp[srow0 + tid] = (uint8_t)s_tp[tid];
+        }
+    }
+    __syncthreads();
+    {  // Linear(1,H) + swish: thread = (channel, half of the tile's rows)
+        const int c = tid % H, r0 = (tid / H) * (T / 2);
+        const float w0 = w.w0[c], b0 = w.b0[c];
+#pragma unroll 8
+        for (int r = r0; r < r0 + T / 2; ++r) {
+            const float l = w0 * s_d[r] + b0, sl = swishf(l);
+            planes_store1(pl, r * LDH + c, sl, amax);
+            if (r < nrows) {
+                sv.l0[(srow0 + r) * H + c] = l;
+                sv.s0[(srow0 + r) * H + c] = sl;
+            }
+        }
+    }
+    __syncthreads();
+    f32x16 accm[1][1], accx[1][1];
+    hzero(accm, accx);
+    hgemm_tile<1, 1, H, true>(pl, LDH, w.w1, H, col0, accm, accx);
+    __syncthreads();
+    {
+        const float b = w.b1[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, hi);
+            const float v = hval(accm[0][0], accx[0][0], r) + b;
+            const float vr = v * w.bond_emb[s_tr[row] * H + col], vp = v * w.bond_emb[s_tp[row] * H + col];
+            planes_store1(pl, row * LDH + col, vr, amax);
+            planes_store1(pl, row * LDH + H + col, vp, amax);
+            if (row < nrows) {
+                sv.e[(srow0 + row) * H + col] = v;
+                sv.c[(srow0 + row) * 2 * H + col] = vr;
+                sv.c[(srow0 + row) * 2 * H + H + col] = vp;
+            }
+        }
+    }
+    __syncthreads();
+    hzero(accm, accx);
+    hgemm_tile<1, 1, 2 * H, true>(pl, LDH, w.cw0, H, col0, accm, accx);
+    __syncthreads();
+    {
+        const float b = w.cb0[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, hi);
+            const float v = hval(accm[0][0], accx[0][0], r) + b, s1 = swishf(v);
+            planes_store1(pl, row * LDH + col, s1, amax);
+            if (row < nrows) {
+                sv.c0[(srow0 + row) * H + col] = v;
+                sv.s1[(srow0 + row) * H + col] = s1;
+            }
+        }
+    }
+    __syncthreads();
+    hzero(accm, accx);
+    hgemm_tile<1, 1, H, true>(pl, LDH, w.cw1, H, col0, accm, accx);
+    {
+        const float b = w.cb1[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = acc_row(r, hi);
+            if (row < nrows) edge_attr[(size_t)(e0 + row) * H + col] = hval(accm[0][0], accx[0][0], r) + b;
+        }
+    }
+    range_report(amax, range_status);
+}
+int launch_edge_embed_save_h(const tsd_model_cfg& c, const float* W16, int cap_a, tsd_edges ea, float* out_a, int cap_b,
+                             tsd_edges eb, float* out_b, hipStream_t st, const EmbedSave& save, int save_b_row,
+                             int32_t* range_status) {
+    const WeightLayout L = weight_layout(c);
+    EdgeEmbedW w{W16 + L.bond_emb, W16 + L.emlp_w0, W16 + L.emlp_b0, W16 + L.emlp_w1, W16 + L.emlp_b1,
+                 W16 + L.ecat_w0, W16 + L.ecat_b0, W16 + L.ecat_w1, W16 + L.ecat_b1};
+    const int tiles_a = (cap_a + T - 1) / T, tiles_b = (cap_b + T - 1) / T;
+    if (tiles_a + tiles_b == 0) return TSD_OK;
+    if (c.hidden != 256) {
+        set_error("edge_embed_save_h: hidden=%d has no split-f16 instance", c.hidden);
+        return TSD_ERR_INVALID;
+    }
+    const size_t lds = (size_t)(T * ldh_of(2 * 256) + T) * 4 + 2 * T * sizeof(int);
+    static DeviceOnce once;
+    int r = allow_lds(edge_embed_save_h_kernel<256>, lds, once);
+    if (r) return r;
+    hipLaunchKernelGGL(edge_embed_save_h_kernel<256>, dim3(tiles_a + tiles_b), dim3(512), lds, st, w, ea, out_a, tiles_a, eb,
+                       out_b, save, save_b_row, range_status);
+    TSD_LAUNCH_CHECK("edge_embed_save_h");
+    return TSD_OK;
+}
 
 int launch_edge_embed2(const tsd_model_cfg& c, const float* W, int cap_a, tsd_edges ea, float* out_a, int cap_b,
                        tsd_edges eb, float* out_b, int M, size_t out_stride, hipStream_t st, const UmapRole* umap,

@@ -133,8 +133,13 @@ __device__ __forceinline__ float max64(float m) {
     return fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 0)),
                  __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 32)));
 }
-__device__ __forceinline__ void atomic_amax(float* slot, float m) {  // max of non-negative floats: their bit patterns order
-    atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(m));
+// max of non-negative floats (their bit patterns order).  The slot is READ first and the atomic issued only by a caller
+// that raises it: thousands of workgroups hitting one L2 line with read-modify-writes serialise there (measured: nine
+// atomics per tile on two words made an 85 us kernel out of a 40 us one).
+__device__ __forceinline__ void atomic_amax(float* slot, float m) {
+    unsigned* p = reinterpret_cast<unsigned*>(slot);
+    const unsigned b = __float_as_uint(m);
+    if (b > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, b);
 }
 
 // the range flag of a workgroup role: any thread that converted a value beyond the f16 range (or a NaN's neighbour inf)
@@ -250,10 +255,10 @@ __device__ __forceinline__ void hgemm_ring_run(HRing<CB, R>& r, const Planes& A,
         if constexpr (PIN) asm volatile("" : "+v"(accx[RB - 1][CB - 1]));  // (... and the step's MFMAs ahead of the next step's reads)
     });
 }
-template <int RB, int CB, int K, bool PIN = false>
+template <int RB, int CB, int K, bool PIN = false, int R = HRING_R>
 __device__ __forceinline__ void hgemm_tile(const Planes& A, int ldh, const float* __restrict__ Bp16, int nout, int col0,
                                            f32x16 (&accm)[RB][CB], f32x16 (&accx)[RB][CB]) {
-    HRing<CB, HRING_R> r;
+    HRing<CB, R> r;
     hgemm_ring_start<CB, K>(r, Bp16, nout, col0);
     hgemm_ring_run<RB, CB, K, PIN>(r, A, ldh, accm, accx);
 }

@@ -521,7 +521,7 @@ int pack_all(const Ctx& x, bool h2) {
     // h2: the interaction blocks' matrices and biases also as the f16-plane arena of the split-f16 block launches
     // (same offsets as the fp32 arena: tsd_pack_weights16's image of these ranges), in the same launch
     float* D16 = x.w.pack16;
-    bool blocks = false;
+    bool blocks = true;  // (every matrix and vector of the forward also goes to the f16 arena)
     auto cp = [&](size_t dst, size_t src, int n) {
         it.push_back({x.raw + src, D + dst, n, 1, 2});
         if (h2 && blocks) it.push_back({x.raw + src, D16 + dst, n, 1, 2});
@@ -541,7 +541,6 @@ int pack_all(const Ctx& x, bool h2) {
     cp(I.ecat_b0, R.ecat_b0, H);
     pk(I.ecat_w1, R.ecat_w1, H, H);
     cp(I.ecat_b1, R.ecat_b1, H);
-    blocks = true;
     for (int l = 0; l < L; ++l) {
         const size_t i = I.layer0 + (size_t)l * I.layer_stride, r = R.layer0 + (size_t)l * R.layer_stride;
         pk(i + I.L_lin1_w, r + R.L_lin1_w, H, H);
@@ -561,7 +560,6 @@ int pack_all(const Ctx& x, bool h2) {
     cp(I.out_b1, R.out_b1, H / 2);
     cp(I.out_w2, R.out_w2, H / 2);
     cp(I.out_b2, R.out_b2, 1);
-    blocks = false;
     return launch_pack_items((int)it.size(), it.data(), x.st);
 }
 
@@ -752,7 +750,12 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
     // edge attributes of every undirected pair once: the enc_u rows, then the out edges that differ (geo.attr_row)
     // (rows [0, Eu) and [Eu, Eu + Ed) of the attribute matrix and of every saved activation: geo.attr_row numbers the
     // second range from PU on, the pair kernels shift it down by PU - Eu)
-    TSD_TRY(launch_edge_embed2(*cfg, W, Eu, g.enc_u, w.ea, Ed, g.diff_u, w.ea + (size_t)Eu * H, 1, 0, st, nullptr, &w.emb, Eu));
+    if (h2 && H == 256) {
+        TSD_TRY(launch_edge_embed_save_h(*cfg, w.pack16, Eu, g.enc_u, w.ea, Ed, g.diff_u, w.ea + (size_t)Eu * H, st, w.emb, Eu,
+                                         batch->status));
+    } else {
+        TSD_TRY(launch_edge_embed2(*cfg, W, Eu, g.enc_u, w.ea, Ed, g.diff_u, w.ea + (size_t)Eu * H, 1, 0, st, nullptr, &w.emb, Eu));
+    }
     // one launch per interaction block: node chain of block l || filter GEMMs of block l+1   schnet.py:88-128, 223-224
     const int tpl = filter_tiles_per_layer(PU);
     const FilterSave fsv{w.f0, w.fs};
