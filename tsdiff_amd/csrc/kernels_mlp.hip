@@ -328,10 +328,185 @@ __global__ __launch_bounds__(2 * H) void embed_bwd_kernel(EmbedBwdList la, int t
     }
 }
 
+// The same chain on the f16 MFMA pipes (split16.hpp, GRADIENT operands; W1t / W0t / Wmt: f16-plane images of the dgrad
+// matrices).  The d_ea rows are scaled row by row (a row is staged by ONE wave), dc0 and de by their tile's max.
+// amax[0..2]: running max of |d_ea|, |dc0|, |de| for the weight-gradient launches.
+template <int H>
+__global__ __launch_bounds__(2 * H) void embed_bwd_h_kernel(EmbedBwdList la, int tiles_a, EmbedBwdList lb,
+                                                           const float* __restrict__ bond_emb,
+                                                           const float* __restrict__ W1t, const float* __restrict__ W0t,
+                                                           const float* __restrict__ Wmt, float* __restrict__ amax) {
+    constexpr int LDH = ldh_of(H), NT = 2 * H, C4 = H / 4, NW = NT / 64;
+    static_assert(C4 == 64, "a row is staged by one wave");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Planes pl = planes_at(smem, T, LDH);
+    float* s_inv = smem + T * LDH;  // [T] 2^e of the d_ea rows
+    float* s_rmax = s_inv + T;      // [T] max |d_ea| of the rows
+    float* s_wmax = s_rmax + T;     // [NW]
+    int* s_tr = reinterpret_cast<int*>(s_wmax + NW);
+    int* s_tp = s_tr + T;
+    const bool second = (int)blockIdx.x >= tiles_a;
+    const EmbedBwdList& L = second ? lb : la;
+    const int E = *L.e.count;
+    const int e0 = (second ? (int)blockIdx.x - tiles_a : (int)blockIdx.x) * T;
+    if (e0 >= E) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int col0 = wave * 32, col = col0 + l31;
+    const int nrows = min(T, E - e0);
+    if (tid < T) {
+        const bool v = tid < nrows;
+        s_tr[tid] = v ? (int)L.e.type_r[e0 + tid] : 0;
+        s_tp[tid] = v ? (int)L.e.type_p[e0 + tid] : 0;
+    }
+    float dummy = 0.0f;
+    {
+        constexpr int NIT = T * C4 / NT;
+        static_assert(T * C4 % NT == 0, "tile / block mismatch");
+        f32x4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+            v[it] = *reinterpret_cast<const f32x4*>(L.d_ea + (size_t)(e0 + min(r, nrows - 1)) * H + c4 * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 a = r < nrows ? v[it] : z;
+            const float m = max64(fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))));  // the row's max
+            float inv;
+            const float sc = pow2_scale(m, inv);
+            if (c4 == 0) {
+                s_inv[r] = inv;
+                s_rmax[r] = m;
+            }
+            planes_store4(pl, r * LDH + c4 * 4, a * sc, dummy);
+        }
+    }
+    __syncthreads();
+    f32x16 accm[1][1], accx[1][1];
+    hzero(accm, accx);
+    hgemm_tile<1, 1, H>(pl, LDH, W1t, H, col0, accm, accx);
+    // (SGPR tile bases + 32-bit lane offsets, computed behind the GEMM's asm statements: see filter_bwd_role_h)
+    unsigned off[16];
+    int hi_p = hi;
+    asm volatile("" : "+v"(hi_p));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) off[r] = (unsigned)(min(acc_row(r, hi_p), nrows - 1) * H + col) * 4u;
+    auto at = [](const float* base, unsigned o) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + o); };
+    auto atw = [](float* base, unsigned o) { return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + o); };
+    const float* c0t = L.c0 + (size_t)e0 * H;
+    float* dc0t = L.dc0 + (size_t)e0 * H;
+    float pre[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pre[r] = *at(c0t, off[r]);
+    float v0[16], m0 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi);
+        v0[r] = 0.0f;
+        if (row < nrows) {
+            v0[r] = hval(accm[0][0], accx[0][0], r) * s_inv[row] * act_deriv(0, pre[r]);
+            *atw(dc0t, off[r]) = v0[r];
+        }
+        m0 = fmaxf(m0, fabsf(v0[r]));
+    }
+    m0 = max64(m0);
+    if (lane == 0) s_wmax[wave] = m0;
+    __syncthreads();  // (every wave is done reading the planes, the wave maxima are in place)
+    float tmax1 = s_wmax[0];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) tmax1 = fmaxf(tmax1, s_wmax[k]);
+    float inv2;
+    const float sc2 = pow2_scale(tmax1, inv2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) planes_store1(pl, acc_row(r, hi) * LDH + col, v0[r] * sc2, dummy);
+    __syncthreads();
+    hzero(accm, accx);
+    hgemm_tile<1, 1, H>(pl, LDH, W0t, 2 * H, col0, accm, accx);  // d(e * emb[type_r]) columns
+    float* dct = L.dc + (size_t)e0 * 2 * H;
+    hi_p = hi;
+    asm volatile("" : "+v"(hi_p));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi_p);
+        v0[r] = hval(accm[0][0], accx[0][0], r) * inv2;
+        if (row < nrows) *atw(dct, (unsigned)(row * 2 * H + col) * 4u) = v0[r];
+    }
+    hzero(accm, accx);
+    hgemm_tile<1, 1, H>(pl, LDH, W0t, 2 * H, col0 + H, accm, accx);  // d(e * emb[type_p]) columns
+    float* det = L.de + (size_t)e0 * H;
+    hi_p = hi;
+    asm volatile("" : "+v"(hi_p));
+    m0 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi_p);
+        const float hh = hval(accm[0][0], accx[0][0], r) * inv2;
+        float v = 0.0f;
+        if (row < nrows) {
+            *atw(dct, (unsigned)(row * 2 * H + H + col) * 4u) = hh;
+            v = v0[r] * bond_emb[s_tr[row] * H + col] + hh * bond_emb[s_tp[row] * H + col];
+            *atw(det, (unsigned)(row * H + col) * 4u) = v;
+        }
+        v0[r] = v;
+        m0 = fmaxf(m0, fabsf(v));
+    }
+    m0 = max64(m0);
+    __syncthreads();  // (the planes and the wave maxima of the previous stage are consumed)
+    if (lane == 0) s_wmax[wave] = m0;
+    __syncthreads();
+    float tmax2 = s_wmax[0];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) tmax2 = fmaxf(tmax2, s_wmax[k]);
+    float inv3;
+    const float sc3 = pow2_scale(tmax2, inv3);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) planes_store1(pl, acc_row(r, hi) * LDH + col, v0[r] * sc3, dummy);
+    __syncthreads();
+    hzero(accm, accx);
+    hgemm_tile<1, 1, H>(pl, LDH, Wmt, H, col0, accm, accx);
+    const float* l0t = L.l0 + (size_t)e0 * H;
+    float* dl0t = L.dl0 + (size_t)e0 * H;
+    hi_p = hi;
+    asm volatile("" : "+v"(hi_p));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) off[r] = (unsigned)(min(acc_row(r, hi_p), nrows - 1) * H + col) * 4u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pre[r] = *at(l0t, off[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, hi);
+        if (row < nrows) *atw(dl0t, off[r]) = hval(accm[0][0], accx[0][0], r) * inv3 * act_deriv(0, pre[r]);
+    }
+    if (amax != nullptr) {  // one (conditional) atomic per tile and word
+        if (wave == 0) {
+            const float m = max32(lane < nrows && lane < T ? s_rmax[lane] : 0.0f);
+            if (lane == 0) atomic_amax(amax, m);
+        }
+        if (tid == 64) atomic_amax(amax + 1, tmax1);
+        if (tid == 128) atomic_amax(amax + 2, tmax2);
+    }
+}
+
 int launch_embed_bwd(int H, int rows_a, const EmbedBwdList& la, int rows_b, const EmbedBwdList& lb, const float* bond_emb,
-                     const float* W1t, const float* W0t, const float* Wmt, hipStream_t st) {
+                     const float* W1t, const float* W0t, const float* Wmt, hipStream_t st, float* amax_h2) {
     const int tiles_a = (rows_a + T - 1) / T, tiles_b = (rows_b + T - 1) / T;
     if (tiles_a + tiles_b == 0) return TSD_OK;
+    if (amax_h2 != nullptr) {  // split-f16 form: W1t / W0t / Wmt are f16-plane images
+        if (H != 256) {
+            set_error("embed_bwd: hidden=%d has no split-f16 instance", H);
+            return TSD_ERR_INVALID;
+        }
+        const size_t lds_h = (size_t)(T * ldh_of(256) + 2 * T + 8) * 4 + 2 * T * sizeof(int);
+        static DeviceOnce once_h;
+        int r = allow_lds(embed_bwd_h_kernel<256>, lds_h, once_h);
+        if (r) return r;
+        hipLaunchKernelGGL(embed_bwd_h_kernel<256>, dim3(tiles_a + tiles_b), dim3(512), lds_h, st, la, tiles_a, lb, bond_emb,
+                           W1t, W0t, Wmt, amax_h2);
+        TSD_LAUNCH_CHECK("embed_bwd_h");
+        return TSD_OK;
+    }
     const size_t lds = (size_t)(T * (H + 4)) * 4 + 2 * T * sizeof(int);
 #define TSD_EB(HH)                                                                                                  \
     {                                                                                                               \

@@ -55,7 +55,7 @@ struct EmbedBwdList {
     float *dc0, *dc, *de, *dl0;
 };
 int launch_embed_bwd(int H, int rows_a, const EmbedBwdList& la, int rows_b, const EmbedBwdList& lb, const float* bond_emb,
-                     const float* W1t, const float* W0t, const float* Wmt, hipStream_t st);
+                     const float* W1t, const float* W0t, const float* Wmt, hipStream_t st, float* amax_h2 = nullptr);
 int launch_pair_bwd(int H, int rows, tsd_edges e, const int32_t* attr_row, const float* ds, const float* w2,
                     const float* g1, const float* g0, const float* W1t, const float* W0t, float* dg1, float* dg0,
                     float* dp, float* d_ea, int attr_from, int attr_shift, hipStream_t st, float* amax_h2 = nullptr);

@@ -93,7 +93,8 @@ struct Work {
     float* pack_t;                 // dgrad layouts of the dense weights, offsets = raw offsets
     float* pack16;                 // f16-plane image of pack_inf (tsd_pack_weights16): the split-f16 block launches
     float* pack_t16;               // f16-plane images of the filter MLPs' dgrad matrices, offsets = raw offsets
-    float* amax;                   // [L][2] running max |dWf|, |df0| per block, then [2] |dg1|, |dg0| of the pair MLP
+    float* amax;                   // [L][2] running max |dWf|, |df0| per block, then [2] |dg1|, |dg0| of the pair MLP, then
+                                   // [3] |d_ea|, |dc0|, |de| of the edge embedding
                                    // (split-f16 backward: the dY scales of the weight-gradient launches)
     float* scratch;                // linear scratch
     size_t scratch_floats;
@@ -147,7 +148,7 @@ Work carve(const tsd_model_cfg& c, int N, size_t PU, float* base) {
     w.pack_t = take(R.total);
     w.pack16 = take(weight_layout(c).total);
     w.pack_t16 = take(R.total);
-    w.amax = take(2 * L + 2);
+    w.amax = take(2 * L + 2 + 3);
     w.scratch_floats = linear_scratch_floats((int)(2 * H), (int)H);
     if (w.scratch_floats < (size_t)512 * 32 * H) w.scratch_floats = (size_t)512 * 32 * H;  // embedding-gradient partials
     w.scratch = take(w.scratch_floats);
@@ -168,7 +169,7 @@ Work carve(const tsd_model_cfg& c, int N, size_t PU, float* base) {
             b = PU > 0 ? wgrad_batch_scratch_floats((int)(2 * L), (int)PU, (int)H, (int)H) : 0;
             e2 = PU > 0 ? wgrad_batch_scratch_floats(2, (int)(2 * PU), (int)H, (int)H) : 0;  // the embedding's two H x H layers
             if (PU > 0 && (H / 2) % 128 == 0) e2 = std::max(e2, wgrad_batch_scratch_floats(1, (int)PU, (int)H, (int)(H / 2)));  // pair MLP layers.1
-            if (PU > 0) e2 = std::max(e2, wgrad_batch_scratch_floats(1, (int)PU, (int)(2 * H), (int)H));  // pair MLP layers.0 (split-f16 step)
+            if (PU > 0) e2 = std::max(e2, wgrad_batch_scratch_floats(1, (int)(2 * PU), (int)(2 * H), (int)H));  // pair MLP layers.0, edge_cat.0 (split-f16 step)
         }
         w.wpart = take(std::max(a, std::max(b, e2)));
     }
@@ -535,11 +536,11 @@ int pack_all(const Ctx& x, bool h2) {
     cp(I.bond_emb, R.bond_emb, 100 * H);
     cp(I.emlp_w0, R.emlp_w0, H);
     cp(I.emlp_b0, R.emlp_b0, H);
-    pk(I.emlp_w1, R.emlp_w1, H, H);
+    pk(I.emlp_w1, R.emlp_w1, H, H, true);
     cp(I.emlp_b1, R.emlp_b1, H);
-    pk(I.ecat_w0, R.ecat_w0, H, 2 * H);
+    pk(I.ecat_w0, R.ecat_w0, H, 2 * H, true);
     cp(I.ecat_b0, R.ecat_b0, H);
-    pk(I.ecat_w1, R.ecat_w1, H, H);
+    pk(I.ecat_w1, R.ecat_w1, H, H, true);
     cp(I.ecat_b1, R.ecat_b1, H);
     for (int l = 0; l < L; ++l) {
         const size_t i = I.layer0 + (size_t)l * I.layer_stride, r = R.layer0 + (size_t)l * R.layer_stride;
@@ -584,14 +585,18 @@ int embed_bwd(const Ctx& x, const tsd_edges& lst, int E, const EmbedSave& s, con
 
 // MFMA sizes: the dgrad chain of BOTH lists in one tile-kernel launch (launch_embed_bwd), then the weight / table
 // gradients per list from the dY it wrote.  d_ea: [2 PU, H], rows as the edge-attribute matrix.
-int embed_bwd_fused(const Ctx& x, const tsd_geometry& g, const float* d_ea) {
+int embed_bwd_fused(const Ctx& x, const tsd_geometry& g, const float* d_ea, bool h2) {
     const int H = x.H;
     const Work& w = x.w;
     const size_t o1 = (size_t)x.Eu * H, o2 = (size_t)x.Eu * 2 * H;  // first row of the second list
     const EmbedBwdList la{g.enc_u, d_ea, w.emb.c0, w.emb.l0, w.e_dc0, w.e_dc, w.e_de, w.e_dl0};
     const EmbedBwdList lb{g.diff_u, d_ea + o1, w.emb.c0 + o1, w.emb.l0 + o1, w.e_dc0 + o1, w.e_dc + o2, w.e_de + o1, w.e_dl0 + o1};
-    TSD_TRY(launch_embed_bwd(H, x.Eu, la, x.Ed, lb, x.raw + x.R.bond_emb, w.pack_t + x.R.ecat_w1, w.pack_t + x.R.ecat_w0,
-                             w.pack_t + x.R.emlp_w1, x.st));
+    // (split-f16 step: the chain on f16 MFMA; its three dY tensors keep their maxima in amax[2 L + 2 ..] for the weight
+    // gradients below, whose X -- s1, s0, c -- passed the range check of the split-f16 forward's embedding tiles)
+    const float* Wt = h2 ? w.pack_t16 : w.pack_t;
+    float* eamax = w.amax + 2 * x.L + 2;
+    TSD_TRY(launch_embed_bwd(H, x.Eu, la, x.Ed, lb, x.raw + x.R.bond_emb, Wt + x.R.ecat_w1, Wt + x.R.ecat_w0,
+                             Wt + x.R.emlp_w1, x.st, h2 ? eamax : nullptr));
     // weight gradients only (dX == NULL): X, dY per layer, the rows of BOTH lists as one problem (they are contiguous:
     // the forward saved the second list's rows, distances and types right behind the first's)
     const int E = x.Eu + x.Ed;
@@ -601,9 +606,19 @@ int embed_bwd_fused(const Ctx& x, const tsd_geometry& g, const float* d_ea) {
             const float* Xs[2] = {w.emb.s1, w.emb.s0};
             float* dWs[2] = {x.grad + x.R.ecat_w1, x.grad + x.R.emlp_w1};
             float* dbs[2] = {x.grad + x.R.ecat_b1, x.grad + x.R.emlp_b1};
-            TSD_TRY(launch_wgrad_batch(2, E, H, H, dYs, Xs, dWs, dbs, 1, w.wpart, x.st));
+            const float* am[2] = {eamax, eamax + 2};
+            TSD_TRY(launch_wgrad_batch(2, E, H, H, dYs, Xs, dWs, dbs, 1, w.wpart, x.st, h2 ? am : nullptr));
         }
-        TSD_TRY(x.lin_bwd(E, 2 * H, H, w.emb.c, x.R.ecat_w0, (long)x.R.ecat_b0, w.e_dc0, nullptr, false));
+        if (h2) {
+            const float* dYs[1] = {w.e_dc0};
+            const float* Xs[1] = {w.emb.c};
+            float* dWs[1] = {x.grad + x.R.ecat_w0};
+            float* dbs[1] = {x.grad + x.R.ecat_b0};
+            const float* am[1] = {eamax + 1};
+            TSD_TRY(launch_wgrad_batch(1, E, 2 * H, H, dYs, Xs, dWs, dbs, 1, w.wpart, x.st, am));
+        } else {
+            TSD_TRY(x.lin_bwd(E, 2 * H, H, w.emb.c, x.R.ecat_w0, (long)x.R.ecat_b0, w.e_dc0, nullptr, false));
+        }
         const int chunks = emb_chunks(E);
         hipLaunchKernelGGL(emb_mul2_bwd_kernel, dim3((H + 63) / 64, chunks), dim3(256), 0, x.st, E, H,
                            (E + chunks - 1) / chunks, w.emb.e, x.raw + x.R.bond_emb, w.emb.tr, w.emb.tp, w.e_dc,
@@ -853,7 +868,7 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
             // (split-f16 step: the chain on f16 MFMA, the weight gradients with dY scaled by the maxima it kept; their X --
             // gs0, hp -- passed the range check of the split-f16 forward's pair tiles)
             float* pamax = w.amax + 2 * L;
-            if (h2) TSD_HIP(hipMemsetAsync(w.amax, 0, (2 * (size_t)L + 2) * sizeof(float), st));
+            if (h2) TSD_HIP(hipMemsetAsync(w.amax, 0, (2 * (size_t)L + 5) * sizeof(float), st));
             TSD_TRY(launch_pair_bwd(H, Eo, g.out_u, g.attr_row, ds, raw + x.R.out_w2, w.g1, w.g0,
                                     (h2 ? w.pack_t16 : w.pack_t) + x.R.out_w1, (h2 ? w.pack_t16 : w.pack_t) + x.R.out_w0, dg1,
                                     dg0, dp, w.d_ea, PU, PU - Eu, st, h2 ? pamax : nullptr));
@@ -897,7 +912,7 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
         float *dagg = w.nA, *dagg_other = w.nB;
         auto wt = [&](int l, size_t off) { return w.pack_t + x.R.layer0 + (size_t)l * x.R.layer_stride + off; };
         auto wt16 = [&](int l, size_t off) { return w.pack_t16 + x.R.layer0 + (size_t)l * x.R.layer_stride + off; };
-        if (h2 && Eo == 0) TSD_HIP(hipMemsetAsync(w.amax, 0, (2 * (size_t)L + 2) * sizeof(float), st));
+        if (h2 && Eo == 0) TSD_HIP(hipMemsetAsync(w.amax, 0, (2 * (size_t)L + 5) * sizeof(float), st));
         const tsd_edges none{};
         TSD_TRY(launch_block_bwd(H, N, 1, 0, g.enc, nullptr, nullptr, w.dh, nullptr, wt(L - 1, x.R.L_lin_w),
                                  wt(L - 1, x.R.L_lin2_w), w.x2 + (size_t)(L - 1) * NH, nullptr, nullptr,
@@ -967,7 +982,7 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
     if (blocks_done_event != nullptr) TSD_HIP(hipEventRecord((hipEvent_t)blocks_done_event, st));
     const float* dz = dh_cur;  // d loss / d h_0
     if (batch_wg) {
-        TSD_TRY(embed_bwd_fused(x, g, w.d_ea));
+        TSD_TRY(embed_bwd_fused(x, g, w.d_ea, h2));
     } else {
         if (Eu > 0) TSD_TRY(embed_bwd(x, g.enc_u, Eu, w.emb, w.d_ea));
         if (Ed > 0) TSD_TRY(embed_bwd(x, g.diff_u, Ed, embed_rows(w.emb, (size_t)Eu, (size_t)H), w.d_ea + (size_t)Eu * H));
