@@ -530,15 +530,29 @@ __global__ void pack_batch_kernel(PackBatch b) {
         return;
     }
     if (b.transposed[it] >= 3) {  // 3 / 4: the forward / dgrad matrix as the f16 planes of split16.hpp (split16_kernel's layout)
-        f16* __restrict__ d = reinterpret_cast<f16*>(Bp);
-        for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < ncols * kdim; idx += gridDim.x * blockDim.x) {
-            const int col = idx % ncols, k = idx / ncols;
-            const float a = b.transposed[it] == 4 ? M[(size_t)k * ncols + col] : M[(size_t)col * kdim + k];
-            const f16 h = (f16)a;
-            const f16 l = (f16)((a - (float)h) * SPLIT_SCALE);
-            const int ks = k >> 4, half = (k >> 3) & 1, e = k & 7;
-            d[((((size_t)ks * 2 + 0) * 2 + half) * ncols + col) * 8 + e] = h;
-            d[((((size_t)ks * 2 + 1) * 2 + half) * ncols + col) * 8 + e] = l;
+        // one thread = 8 consecutive k of one column: a 32-byte run of a source row (3) or eight coalesced words (4) in,
+        // one 16-byte store per plane out
+        f16x8* __restrict__ d = reinterpret_cast<f16x8*>(Bp);
+        const bool tr = b.transposed[it] == 4;
+        for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < ncols * (kdim / 8); u += gridDim.x * blockDim.x) {
+            const int col = u % ncols, kg = u / ncols, k0 = kg * 8;
+            float a[8];
+            if (tr) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = M[(size_t)(k0 + j) * ncols + col];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = M[(size_t)col * kdim + k0 + j];  // (a parameter tensor is only 4-byte aligned)
+            }
+            f16x8 h, l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                h[j] = (f16)a[j];
+                l[j] = (f16)((a[j] - (float)h[j]) * SPLIT_SCALE);
+            }
+            const int ks = kg >> 1, half = kg & 1;
+            d[(((size_t)ks * 2 + 0) * 2 + half) * ncols + col] = h;
+            d[(((size_t)ks * 2 + 1) * 2 + half) * ncols + col] = l;
         }
         return;
     }
