@@ -434,17 +434,36 @@ def mfma_busy(label, kernel_prefix):
         return None
 
 
+def train_arith():
+    """'h2' (split-f16 operands, OPTIONS.train_gemm) or 'f32' -- the arithmetic of the training step's tile GEMMs"""
+    from tsdiff_amd.options import OPTIONS
+    return OPTIONS.train_gemm
+
+
+def train_dtype():
+    return ("f32 (GEMM operands as split f16 pairs on the f16 MFMA, gradient operands scaled by powers of two, f32 accumulate; "
+            "f32 saved activations)") if train_arith() == "h2" else "f32"
+
+
 def train_roofline(tf, flops):
-    """the `roofline` object of the training step: whole-step executed arithmetic against the fp32 MFMA peak, plus the
-    MFMA-pipe busy fractions of its three heaviest kernels (SQ counters, profiles/)"""
+    """the `roofline` object of the training step: whole-step executed arithmetic against the MFMA peak of its arithmetic
+    (fp32-input MFMA, or the f16 MFMA / 3 for split-f16 operands), plus the MFMA-pipe busy fractions of its heaviest kernels
+    (SQ counters, profiles/)"""
+    h2 = train_arith() == "h2"
+    peak = PEAK_SPLIT_F16_TFLOPS if h2 else PEAK_FP32_MFMA_TFLOPS
+    busy = ({"block_bwd_kernel": mfma_busy("train", "block_bwd_kernel"),
+             "layer_combo_kernel(save)": mfma_busy("train", "layer_combo_kernel<256, true"),
+             "wgrad_h2_batch_kernel": mfma_busy("train", "wgrad_h2_batch_kernel")} if h2 else
+            {"block_bwd_kernel": mfma_busy("train", "block_bwd_kernel"),
+             "layer_combo_kernel(save)": mfma_busy("train", "layer_combo_kernel<256, true"),
+             "wgrad_batch_kernel": mfma_busy("train", "wgrad_batch_kernel")})
     return {"kernel": "whole training step (forward + dgrad + wgrad tile GEMMs, optimizer, host)", "bound": "mfma",
-            "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None, "flop_per_step": flops,
-            "note": "executed flops = 3 x the forward's (undirected formulation)",
-            "mfma_busy": {"block_bwd_kernel": mfma_busy("train", "block_bwd_kernel"),
-                          "layer_combo_kernel(save)": mfma_busy("train", "layer_combo_kernel<256, true"),
-                          "wgrad_batch_kernel": mfma_busy("train", "wgrad_batch_kernel")},
-            "mfma_busy_source": "profiles/" + MFMA_BUSY}
+            "arithmetic": "split-f16 (three f16 MFMAs per product)" if h2 else "fp32-input MFMA",
+            "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(tf / peak, 4), "traffic": None, "flop_per_step": flops,
+            "note": "executed flops = 3 x the forward's (undirected formulation); the step also moves ~4 GB of saved "
+                    "activations and gradients per batch of 200 through HBM (DESIGN.md 5): about half its time at 8 TB/s",
+            "mfma_busy": busy, "mfma_busy_source": "profiles/" + MFMA_BUSY}
 
 
 def pmc_traffic(name_prefix, fname):
@@ -506,6 +525,12 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist, prefet
         return mean
     if not reuse_batch:
         model._batches.clear()
+    # A full (generation-2) collection of a process that has imported torch walks ~10^6 objects: 70-80 ms, i.e. 35 training
+    # steps, whenever the allocation counters trip it (measured: once per ~dozen steps of this loop).  What exists now is
+    # long-lived: it goes to the permanent generation, later collections look at the loop's own garbage only.
+    import gc
+    gc.collect()
+    gc.freeze()
     for _ in range(warmup):
         step()
     sync_all(dist)
@@ -536,7 +561,7 @@ def bench_train_main(args, model, dev, rank, world, dist):
             "value": round(world * args.graphs * args.steps / dt, 1), "unit": "graphs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": train_dtype(), "data": "synthetic",
             "config": {"workload": "configs[3] training step", "graphs_per_gpu": args.graphs, "atoms_per_gpu": N,
                        "batch_topology": "one batch reused" if args.reuse_batch else
                        ("rebuilt every step inside get_loss" if args.no_prefetch else
@@ -841,7 +866,7 @@ def main():
                                     "batch every step", "steps": Kt, "ms_per_step": round(dtt / Kt * 1e3, 3),
                         "ms_per_step_no_prefetch": round(dtn / Kt * 1e3, 3),
                         "value": round(200 * Kt / dtt, 1), "unit": "graphs/s", "atoms": Nt,
-                        "executed_tflops": round(tf, 2), "frac_of_fp32_peak": round(tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                        "executed_tflops": round(tf, 2), "dtype": train_dtype(),
                         "roofline": train_roofline(tf, flt), "final_loss": last}
 
     if extras:

@@ -314,7 +314,12 @@ typedef struct tsd_batch {
                                    with materialised filters instead (bit-identical results); bit 4: the fused
                                    encoder also where the one-launch form would apply (tests, A/B);
                                    bit 3 (tests only): fault injection -- the one-launch forward skips its last filter
-                                   tile, so that one bounded wait gives up and TSD_STATUS_INTERNAL is reported */
+                                   tile, so that one bounded wait gives up and TSD_STATUS_INTERNAL is reported;
+                                   bit 5 (tsd_train_forward / tsd_train_backward2, hidden = 256, `status` set): the training
+                                   step's tile GEMMs on split-f16 operands -- gradient operands scaled by exact powers of
+                                   two, fp32 accumulation and saved activations; the forward raises TSD_STATUS_RANGE in
+                                   `status` when an activation left the f16 range, tsd_train_backward2 then returns
+                                   TSD_ERR_RANGE.  Pass the same bit to both calls of a step */
     tsd_typed_tiles enc_tiles, diff_tiles;  /* static type-sorted embedding tiles, or num_tiles = 0: generic embedding */
     const float* bucket_weights;            /* [M][(enc + diff buckets) * (H*H + H)] (tsd_bucket_weights_build) or NULL */
     /* ---- appended in 0.4: the split-f16 inference forward (see tsd_pack_weights16) ---- */

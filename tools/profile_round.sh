@@ -29,6 +29,9 @@ python3 tools/pmc_summary.py $(db /tmp/p_f) $(db /tmp/p_w) gpurun_out/${TAG}_pmc
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_f5 -o f -- python3 bench.py --workload c5 --steps 3 --warmup 1 $B > gpurun_out/${TAG}_pmc_f5.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_w5 -o w -- python3 bench.py --workload c5 --steps 3 --warmup 1 $B > gpurun_out/${TAG}_pmc_w5.log 2>&1
 python3 tools/pmc_summary.py $(db /tmp/p_f5) $(db /tmp/p_w5) gpurun_out/${TAG}_pmc_traffic_c5 > /dev/null
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/p_ft -o f -- python3 bench.py --workload train --steps 8 --warmup 3 > gpurun_out/${TAG}_pmc_ft.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/p_wt -o w -- python3 bench.py --workload train --steps 8 --warmup 3 > gpurun_out/${TAG}_pmc_wt.log 2>&1
+python3 tools/pmc_summary.py $(db /tmp/p_ft) $(db /tmp/p_wt) gpurun_out/${TAG}_pmc_traffic_train > /dev/null
 # SQ counters of the hot kernels (one pass), plus the effective clock (GRBM)
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_WAVES"
 rocprofv3 --kernel-trace --pmc $SQ -d /tmp/p_sq -o sq -- python3 bench.py --steps 30 --warmup 5 $B > gpurun_out/${TAG}_pmc_sq.log 2>&1

@@ -635,6 +635,12 @@ EmbedSave embed_rows(const EmbedSave& s, size_t row, size_t H) {
     return EmbedSave{s.l0 + row * H, s.s0 + row * H, s.e + row * H, s.c + row * 2 * H, s.c0 + row * H, s.s1 + row * H};
 }
 
+// tsd_batch.reserved bit 5 asks for the split-f16 step; its tile kernels exist for the shipped width (hidden = 256), any other
+// width runs the fp32-MFMA step whatever the bit says
+bool train_h2(const tsd_model_cfg* cfg, const tsd_batch* b) {
+    return cfg && b && (b->reserved & 32) != 0 && b->status != nullptr && cfg->hidden == 256;
+}
+
 int make_ctx(Ctx& x, const tsd_model_cfg* cfg, const tsd_batch* b, const float* raw, float* ws, size_t ws_floats,
              const int32_t* counts_host, hipStream_t st) {
     TSD_REQUIRE(cfg && b && raw && ws && counts_host, "null pointer");
@@ -743,12 +749,12 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
     if (N == 0) return TSD_OK;
     {
         TraceRange ph("tsd:train_forward/pack_weights");
-        TSD_TRY(pack_all(x, (batch->reserved & 32) != 0 && batch->status != nullptr));
+        TSD_TRY(pack_all(x, train_h2(cfg, batch)));
     }
     const float* W = w.pack_inf;
     // tsd_batch.reserved bit 5: the interaction blocks on the f16 MFMA pipes (split-f16 operands, split16.hpp; fp32
     // accumulation and fp32 saved activations), range flag in tsd_batch.status as in the inference forward
-    const bool h2 = (batch->reserved & 32) != 0 && batch->status != nullptr;
+    const bool h2 = train_h2(cfg, batch);
     Prec prec;
     if (h2) {
         prec.mode = PREC_H2;
@@ -765,7 +771,7 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
     // edge attributes of every undirected pair once: the enc_u rows, then the out edges that differ (geo.attr_row)
     // (rows [0, Eu) and [Eu, Eu + Ed) of the attribute matrix and of every saved activation: geo.attr_row numbers the
     // second range from PU on, the pair kernels shift it down by PU - Eu)
-    if (h2 && H == 256) {
+    if (h2) {
         TSD_TRY(launch_edge_embed_save_h(*cfg, w.pack16, Eu, g.enc_u, w.ea, Ed, g.diff_u, w.ea + (size_t)Eu * H, st, w.emb, Eu,
                                          batch->status));
     } else {
@@ -822,7 +828,7 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
     TSD_REQUIRE(dloss && grad && atom_type && pos, "null pointer");
     TSD_REQUIRE((reinterpret_cast<uintptr_t>(grad) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
                 "grad and workspace must be 16-byte aligned");
-    const bool h2 = batch && (batch->reserved & 32) != 0 && batch->status != nullptr;
+    const bool h2 = train_h2(cfg, batch);
     if (h2) {
         // The forward of this step ran on split-f16 operands: its range flag decides whether the saved activations can be
         // differentiated.  One 4-byte read behind the forward's last kernel, from C++ so that the first backward launch
