@@ -1242,8 +1242,11 @@ struct NodeBwd {
     const float *w_lin_t, *w_lin2_t; // block l-1
     const float *x2_prev;            // block l-1 pre-activation
     float *dx1, *dh, *dx2_prev, *dagg_prev;
+    NodeAmax am;                     // split-f16 step: running maxima of what this chain writes (or NULL pointers)
 };
-template <int H>
+// AMAX: the tile's max |dh_up| (first), |dx1|, |dh|, |dx2_prev| go to a.am (the node-level weight gradients scale their dY
+// operands by them: split16.hpp, GRADIENT operands) -- one conditional atomic per tile and word
+template <int H, bool AMAX = false>
 __device__ __forceinline__ void node_bwd_role(const NodeBwd& a, int tile, float* smem) {
     constexpr int LDA = H + 4, NT = 2 * H, CB16 = 2, C4 = H / 4;
     float* buf = smem;
@@ -1254,9 +1257,39 @@ __device__ __forceinline__ void node_bwd_role(const NodeBwd& a, int tile, float*
     f32x4 acc[CB16];
     float pre[CB16][4];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    float m_in = 0.0f, m_dx1 = 0.0f, m_dh = 0.0f, m_dx2 = 0.0f;
+    auto flush = [&]() {  // (before every return of the role)
+        if constexpr (AMAX) {
+            float* s_m = smem + TN * LDA;  // [4][NT / 64] behind the tile
+            constexpr int NWV = NT / 64;
+            m_in = max64(m_in), m_dx1 = max64(m_dx1), m_dh = max64(m_dh), m_dx2 = max64(m_dx2);
+            __syncthreads();
+            if (lane == 0) {
+                s_m[wave] = m_in;
+                s_m[NWV + wave] = m_dx1;
+                s_m[2 * NWV + wave] = m_dh;
+                s_m[3 * NWV + wave] = m_dx2;
+            }
+            __syncthreads();
+            if (tid < 4) {
+                float* slot = tid == 0 ? a.am.in : tid == 1 ? a.am.dx1 : tid == 2 ? a.am.dh : a.am.dx2;
+                float t = s_m[tid * NWV];
+#pragma unroll
+                for (int k = 1; k < NWV; ++k) t = fmaxf(t, s_m[tid * NWV + k]);
+                if (slot != nullptr && t > 0.0f) atomic_amax(slot, t);
+            }
+        }
+    };
     if (!a.first) {
         aggregate_tile<H, true>(a.row_ptr, a.dst, a.umap, a.Wf, a.dagg_in, a.N, n0, buf, a.dx1);
         __syncthreads();
+        if constexpr (AMAX) {  // the aggregated dx1 tile (rows past N are zero)
+            for (int idx = tid; idx < TN * C4; idx += NT) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(buf + (idx / C4) * LDA + (idx % C4) * 4);
+                amax_upd2(m_dx1, v[0], v[1]);
+                amax_upd2(m_dx1, v[2], v[3]);
+            }
+        }
         // (values the epilogues read are requested before the GEMM that precedes them, rows clamped: no guarded loads)
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb)
@@ -1278,6 +1311,7 @@ __device__ __forceinline__ void node_bwd_role(const NodeBwd& a, int tile, float*
                     v = pre[cb][r] + acc[cb][r];
                     a.dh[(size_t)(n0 + row) * H + col] = v;
                 }
+                if constexpr (AMAX) amax_upd(m_dh, v);
                 buf[row * LDA + col] = v;
             }
         }
@@ -1286,10 +1320,17 @@ __device__ __forceinline__ void node_bwd_role(const NodeBwd& a, int tile, float*
             const int r = idx / C4, c4 = idx % C4;
             f32x4 v = zero4;
             if (r < nrows) v = *reinterpret_cast<const f32x4*>(a.dh_up + (size_t)(n0 + r) * H + c4 * 4);
+            if constexpr (AMAX) {
+                amax_upd2(m_in, v[0], v[1]);
+                amax_upd2(m_in, v[2], v[3]);
+            }
             *reinterpret_cast<f32x4*>(buf + r * LDA + c4 * 4) = v;
         }
     }
-    if (a.last) return;
+    if (a.last) {
+        flush();
+        return;
+    }
     __syncthreads();
 #pragma unroll
     for (int cb = 0; cb < CB16; ++cb)
@@ -1311,6 +1352,7 @@ __device__ __forceinline__ void node_bwd_role(const NodeBwd& a, int tile, float*
                 v = acc[cb][r] * act_deriv(1, pre[cb][r]);
                 a.dx2_prev[(size_t)(n0 + row) * H + col] = v;
             }
+            if constexpr (AMAX) amax_upd(m_dx2, v);
             buf[row * LDA + col] = v;
         }
     }
@@ -1327,6 +1369,7 @@ __device__ __forceinline__ void node_bwd_role(const NodeBwd& a, int tile, float*
             if (row < nrows) a.dagg_prev[(size_t)(n0 + row) * H + col] = acc[cb][r];
         }
     }
+    flush();
 }
 // -------------------------------------------------------------------------------------------------
 // The filter MLP's whole backward chain for one tile of 32 undirected edges (the adjoint of the filter role;
@@ -1568,7 +1611,7 @@ __global__ __launch_bounds__(2 * H) void block_bwd_kernel(NodeBwd a, int node_ti
     const int b = blockIdx.x;
     if (b < node_tiles) {
         __builtin_amdgcn_s_setprio(3);
-        node_bwd_role<H>(a, b, smem);
+        node_bwd_role<H, PREC == PREC_H2>(a, b, smem);
     } else {
         if constexpr (PREC == PREC_H2) filter_bwd_role_h<H>(f, b - node_tiles, smem);
         else filter_bwd_role<H>(f, b - node_tiles, smem);
@@ -1579,9 +1622,9 @@ int launch_block_bwd(int H, int N, int first, int last, tsd_edges enc, const flo
                      const float* dh_up, const float* w_lin1_t, const float* w_lin_t, const float* w_lin2_t,
                      const float* x2_prev, float* dx1, float* dh, float* dx2_prev, float* dagg_prev, int filter_rows,
                      tsd_edges enc_u, const float* x1, const float* f0, const float* W2t, const float* W0t, float cutoff,
-                     int smooth, float* dWf, float* df0, float* d_ea, hipStream_t st, float* amax_h2) {
+                     int smooth, float* dWf, float* df0, float* d_ea, hipStream_t st, float* amax_h2, NodeAmax node_amax) {
     NodeBwd a{N, first, last, enc.row_ptr, enc.dst, enc.umap, Wf, dagg_in, dh_up, w_lin1_t, w_lin_t, w_lin2_t, x2_prev,
-              dx1, dh, dx2_prev, dagg_prev};
+              dx1, dh, dx2_prev, dagg_prev, node_amax};
     FilterBwd f{};
     f.tiles = (filter_rows + 31) / 32;
     if (f.tiles) {
@@ -1600,8 +1643,9 @@ int launch_block_bwd(int H, int N, int first, int last, tsd_edges enc, const flo
     }
     const int node_tiles = (N + TN - 1) / TN;
     if (node_tiles + f.tiles == 0) return TSD_OK;
-    const bool h2 = amax_h2 != nullptr;  // (then W2t / W0t are f16-plane images)
-    const size_t lds_n = (size_t)TN * (H + 4) * 4, lds_f = (size_t)(32 * (H + 4) + 32) * 4 + 2 * 32 * sizeof(int);
+    // (h2: W2t / W0t are f16-plane images; the top launch of a split-f16 step has no filter role but keeps the node maxima)
+    const bool h2 = amax_h2 != nullptr || node_amax.in != nullptr || node_amax.dh != nullptr || node_amax.dx2 != nullptr;
+    const size_t lds_n = (size_t)TN * (H + 4) * 4 + 4 * 8 * 4, lds_f = (size_t)(32 * (H + 4) + 32) * 4 + 2 * 32 * sizeof(int);
     const size_t lds_h = (size_t)(32 * ldh_of(H) + 4 * 32) * 4 + 2 * 32 * sizeof(int);
     const size_t lds = std::max(lds_n, h2 ? lds_h : lds_f);
 #define TSD_NB(HH)                                                                                              \

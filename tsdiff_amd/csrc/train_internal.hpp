@@ -60,11 +60,15 @@ int launch_pair_bwd(int H, int rows, tsd_edges e, const int32_t* attr_row, const
                     const float* g1, const float* g0, const float* W1t, const float* W0t, float* dg1, float* dg0,
                     float* dp, float* d_ea, int attr_from, int attr_shift, hipStream_t st, float* amax_h2 = nullptr);
 int launch_row_gather(int H, int N, tsd_edges e, const float* W, const float* x, float* out, hipStream_t st);
+struct NodeAmax {  // device words (non-negative floats, atomic max) or NULL
+    float *in = nullptr, *dx1 = nullptr, *dh = nullptr, *dx2 = nullptr;
+};
 int launch_block_bwd(int H, int N, int first, int last, tsd_edges enc, const float* Wf, const float* dagg_in,
                      const float* dh_up, const float* w_lin1_t, const float* w_lin_t, const float* w_lin2_t,
                      const float* x2_prev, float* dx1, float* dh, float* dx2_prev, float* dagg_prev, int filter_rows,
                      tsd_edges enc_u, const float* x1, const float* f0, const float* W2t, const float* W0t, float cutoff,
-                     int smooth, float* dWf, float* df0, float* d_ea, hipStream_t st, float* amax_h2 = nullptr);
+                     int smooth, float* dWf, float* df0, float* d_ea, hipStream_t st, float* amax_h2 = nullptr,
+                     NodeAmax node_amax = NodeAmax{});
 int launch_split_reduce(int64_t n, int S, const float* part, float* dst, int accumulate, hipStream_t st);
 int wgrad_batch_splits(int m, int blocks, int rows);
 size_t wgrad_batch_scratch_floats(int n, int rows, int in, int out);

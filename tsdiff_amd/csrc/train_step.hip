@@ -94,7 +94,8 @@ struct Work {
     float* pack16;                 // f16-plane image of pack_inf (tsd_pack_weights16): the split-f16 block launches
     float* pack_t16;               // f16-plane images of the filter MLPs' dgrad matrices, offsets = raw offsets
     float* amax;                   // [L][2] running max |dWf|, |df0| per block, then [2] |dg1|, |dg0| of the pair MLP, then
-                                   // [3] |d_ea|, |dc0|, |de| of the edge embedding
+                                   // [3] |d_ea|, |dc0|, |de| of the edge embedding, then the node chain's: [1] |dh_L|, [L] |dh_l|,
+                                   // [L] |dx2_l|, [L] |dx1_l|
                                    // (split-f16 backward: the dY scales of the weight-gradient launches)
     float* scratch;                // linear scratch
     size_t scratch_floats;
@@ -148,7 +149,7 @@ Work carve(const tsd_model_cfg& c, int N, size_t PU, float* base) {
     w.pack_t = take(R.total);
     w.pack16 = take(weight_layout(c).total);
     w.pack_t16 = take(R.total);
-    w.amax = take(2 * L + 2 + 3);
+    w.amax = take(2 * L + 2 + 3 + 1 + 3 * L);
     w.scratch_floats = linear_scratch_floats((int)(2 * H), (int)H);
     if (w.scratch_floats < (size_t)512 * 32 * H) w.scratch_floats = (size_t)512 * 32 * H;  // embedding-gradient partials
     w.scratch = take(w.scratch_floats);
@@ -874,7 +875,7 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
             // (split-f16 step: the chain on f16 MFMA, the weight gradients with dY scaled by the maxima it kept; their X --
             // gs0, hp -- passed the range check of the split-f16 forward's pair tiles)
             float* pamax = w.amax + 2 * L;
-            if (h2) TSD_HIP(hipMemsetAsync(w.amax, 0, (2 * (size_t)L + 5) * sizeof(float), st));
+            if (h2) TSD_HIP(hipMemsetAsync(w.amax, 0, (5 * (size_t)L + 6) * sizeof(float), st));
             TSD_TRY(launch_pair_bwd(H, Eo, g.out_u, g.attr_row, ds, raw + x.R.out_w2, w.g1, w.g0,
                                     (h2 ? w.pack_t16 : w.pack_t) + x.R.out_w1, (h2 ? w.pack_t16 : w.pack_t) + x.R.out_w0, dg1,
                                     dg0, dp, w.d_ea, PU, PU - Eu, st, h2 ? pamax : nullptr));
@@ -918,12 +919,23 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
         float *dagg = w.nA, *dagg_other = w.nB;
         auto wt = [&](int l, size_t off) { return w.pack_t + x.R.layer0 + (size_t)l * x.R.layer_stride + off; };
         auto wt16 = [&](int l, size_t off) { return w.pack_t16 + x.R.layer0 + (size_t)l * x.R.layer_stride + off; };
-        if (h2 && Eo == 0) TSD_HIP(hipMemsetAsync(w.amax, 0, (2 * (size_t)L + 5) * sizeof(float), st));
+        if (h2 && Eo == 0) TSD_HIP(hipMemsetAsync(w.amax, 0, (5 * (size_t)L + 6) * sizeof(float), st));
         const tsd_edges none{};
+        // (split-f16 step: the node chain keeps the running maxima of its dY tensors for the node-level weight gradients)
+        float* namax = w.amax + 2 * L + 5;  // [0] dh_L, [1 + l] dh_l, [1 + L + l] dx2_l, [1 + 2 L + l] dx1_l
+        auto nam = [&](int l_dx1, int l_dh, int l_dx2, bool top) {
+            NodeAmax m;
+            if (!h2) return m;
+            if (top) m.in = namax;
+            if (l_dx1 >= 0) m.dx1 = namax + 1 + 2 * L + l_dx1;
+            if (l_dh >= 0) m.dh = namax + 1 + l_dh;
+            if (l_dx2 >= 0) m.dx2 = namax + 1 + L + l_dx2;
+            return m;
+        };
         TSD_TRY(launch_block_bwd(H, N, 1, 0, g.enc, nullptr, nullptr, w.dh, nullptr, wt(L - 1, x.R.L_lin_w),
                                  wt(L - 1, x.R.L_lin2_w), w.x2 + (size_t)(L - 1) * NH, nullptr, nullptr,
                                  w.dx2s + (size_t)(L - 1) * NH, dagg, 0, none, nullptr, nullptr, nullptr, nullptr, 0.f, 0,
-                                 nullptr, nullptr, nullptr, st));
+                                 nullptr, nullptr, nullptr, st, nullptr, nam(-1, -1, L - 1, true)));
         for (int l = L - 1; l >= 0; --l) {
             const int lp = l > 0 ? l - 1 : 0;
             TSD_TRY(launch_block_bwd(H, N, 0, l == 0, g.enc, w.Wf + l * EH, dagg, dh_cur, wt(l, x.R.L_lin1_w),
@@ -932,7 +944,7 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
                                      w.f0 + l * EH, h2 ? wt16(l, x.R.L_nn2_w) : wt(l, x.R.L_nn2_w),
                                      h2 ? wt16(l, x.R.L_nn0_w) : wt(l, x.R.L_nn0_w), cfg->conv_cutoff,
                                      cfg->smooth_conv, w.dWfs + l * EH, w.df0s + l * EH, w.d_ea, st,
-                                     h2 ? w.amax + 2 * l : nullptr));
+                                     h2 ? w.amax + 2 * l : nullptr, nam(l, l, l > 0 ? l - 1 : -1, false)));
             dh_cur = w.dhs + l * NH;
             float* t = dagg;
             dagg = dagg_other;
@@ -966,7 +978,15 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
             dYs.push_back(w.dx2s + l * NH);    Xs.push_back(w.agg + l * NH); dWs.push_back(grad + o + x.R.L_lin2_w); dbs.push_back(grad + o + x.R.L_lin2_b);
             dYs.push_back(w.dx1s + l * NH);    Xs.push_back(w.h + l * NH);   dWs.push_back(grad + o + x.R.L_lin1_w); dbs.push_back(nullptr);
         }
-        TSD_TRY(launch_wgrad_batch((int)dYs.size(), N, H, H, dYs.data(), Xs.data(), dWs.data(), dbs.data(), 1, w.wpart, st));
+        std::vector<const float*> namx;
+        for (int l = 0; l < L; ++l) {  // (order as above: dh_{l+1}, dx2_l, dx1_l; xs / agg / h passed the forward's range check)
+            const float* na = w.amax + 2 * L + 5;
+            namx.push_back(l == L - 1 ? na : na + 1 + (l + 1));
+            namx.push_back(na + 1 + L + l);
+            namx.push_back(na + 1 + 2 * L + l);
+        }
+        TSD_TRY(launch_wgrad_batch((int)dYs.size(), N, H, H, dYs.data(), Xs.data(), dWs.data(), dbs.data(), 1, w.wpart, st,
+                                   h2 ? namx.data() : nullptr));
         if (Eu > 0) {  // the filter MLPs of all blocks: 2 L problems of Eu rows
             dYs.clear(), Xs.clear(), dWs.clear(), dbs.clear();
             std::vector<const float*> amx;
