@@ -447,3 +447,36 @@ def test_train_split_f16_range_fallback(dev, monkeypatch):
                               g["batch"], g["num_nodes_per_graph"], G, _time_step=ts, _pos_noise=pn)
         loss.mean().backward()
     assert OPTIONS.train_gemm == "h2" and torch.equal(loss.detach(), lf)
+
+
+def test_train_split_f16_edge_cases(dev, monkeypatch):
+    """the split-f16 step on degenerate batches of the production width: a one-atom graph + an edge-less graph + a bonded
+    triple (partial tiles everywhere), and a batch with NO edge at all (every tile kernel and weight-gradient launch sees
+    zero rows) -- finite, and equal to the fp32 step within the split-f16 tolerance"""
+    from tsdiff_amd import synth
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    model = make_model(cfg, 4, dev)
+    F = cfg["feat_dim"]
+    atom = torch.tensor([6, 1, 1, 6, 1, 8], device=dev)
+    feat = torch.zeros(6, F, dtype=torch.long, device=dev)
+    pos = torch.tensor([[0, 0, 0], [0, 0, 0], [50., 0, 0], [0, 0, 0], [1., 0, 0], [0, 1.2, 0]], device=dev)
+    batch = torch.tensor([0, 1, 1, 2, 2, 2], device=dev)
+    nn_ = torch.tensor([1, 2, 3], device=dev)
+    ts = torch.tensor([100, 2500, 4000], device=dev)
+    pn = torch.randn(6, 3, generator=torch.Generator().manual_seed(1)).to(dev) * 0.01
+    cases = {"bonded triple": (torch.tensor([[3, 4, 3, 5], [4, 3, 5, 3]], device=dev), torch.tensor([23, 23, 22, 22], device=dev)),
+             "no edges": (torch.zeros(2, 0, dtype=torch.long, device=dev), torch.zeros(0, dtype=torch.long, device=dev))}
+    for name, (bi, bt) in cases.items():
+        p = pos.clone()
+        if name == "no edges":
+            p[3:] = torch.tensor([[0., 0, 0], [60., 0, 0], [0, 70., 0]], device=dev)
+        g = {"atom_type": atom, "r_feat": feat, "p_feat": feat, "pos": p, "bond_index": bi, "bond_type": bt, "batch": batch,
+             "num_nodes_per_graph": nn_}
+        lf, gf = _train_step_grads(model, g, ts, pn, 3, "f32", monkeypatch)
+        lh, gh = _train_step_grads(model, g, ts, pn, 3, "h2", monkeypatch)
+        assert not getattr(model, "_train_f32", False), name
+        assert torch.isfinite(lh).all() and float((lh - lf).abs().max()) <= 2e-6 * max(float(lf.abs().max()), 1e-30), name
+        for k, ref in gf.items():
+            assert torch.isfinite(gh[k]).all(), (name, k)
+            scale = float(ref.abs().max())
+            assert float((gh[k] - ref).abs().max()) <= 5e-6 * scale + 1e-30, (name, k)
