@@ -319,7 +319,9 @@ typedef struct tsd_batch {
                                    step's tile GEMMs on split-f16 operands -- gradient operands scaled by exact powers of
                                    two, fp32 accumulation and saved activations; the forward raises TSD_STATUS_RANGE in
                                    `status` when an activation left the f16 range, tsd_train_backward2 then returns
-                                   TSD_ERR_RANGE.  Pass the same bit to both calls of a step */
+                                   TSD_ERR_RANGE.  Pass the same bit to both calls of a step; bit 6 (with bit 5): the
+                                   backward keeps its small gradient launches (embedding tables, narrow layers) on the
+                                   caller's stream instead of the library's side stream (A/B switch, same results) */
     tsd_typed_tiles enc_tiles, diff_tiles;  /* static type-sorted embedding tiles, or num_tiles = 0: generic embedding */
     const float* bucket_weights;            /* [M][(enc + diff buckets) * (H*H + H)] (tsd_bucket_weights_build) or NULL */
     /* ---- appended in 0.4: the split-f16 inference forward (see tsd_pack_weights16) ---- */

@@ -480,3 +480,20 @@ def test_train_split_f16_edge_cases(dev, monkeypatch):
             assert torch.isfinite(gh[k]).all(), (name, k)
             scale = float(ref.abs().max())
             assert float((gh[k] - ref).abs().max()) <= 5e-6 * scale + 1e-30, (name, k)
+
+
+def test_train_side_lane_is_bit_identical(dev, monkeypatch):
+    """the split-f16 backward with its small gradient launches on the library's side stream (default) and on the caller's
+    stream: the same kernels in another schedule -- bit-identical loss and gradients, three steps in a row each"""
+    from tsdiff_amd import synth
+    from tsdiff_amd.options import OPTIONS
+    model = make_model(synth.DEFAULT_MODEL_CONFIG, 2, dev)
+    g, ts, pn, G = _train_case(dev, graphs=24, seed=9)
+    res = {}
+    for lane in (True, False):
+        monkeypatch.setattr(OPTIONS, "train_side_lane", lane)
+        for _ in range(3):
+            res[lane] = _train_step_grads(model, g, ts, pn, G, "h2", monkeypatch)
+    assert torch.equal(res[True][0], res[False][0])
+    for k, ref in res[False][1].items():
+        assert torch.equal(res[True][1][k], ref), k

@@ -98,6 +98,7 @@ struct Work {
                                    // [L] |dx2_l|, [L] |dx1_l|
                                    // (split-f16 backward: the dY scales of the weight-gradient launches)
     float* scratch;                // linear scratch
+    float* scratch2;               // the same again for the side lane of the split-f16 backward (small gradient kernels)
     size_t scratch_floats;
     // backward temporaries
     float *eA, *eB;                // [PU, 2H] each
@@ -153,6 +154,7 @@ Work carve(const tsd_model_cfg& c, int N, size_t PU, float* base) {
     w.scratch_floats = linear_scratch_floats((int)(2 * H), (int)H);
     if (w.scratch_floats < (size_t)512 * 32 * H) w.scratch_floats = (size_t)512 * 32 * H;  // embedding-gradient partials
     w.scratch = take(w.scratch_floats);
+    w.scratch2 = take(w.scratch_floats);
     w.eA = take(PU * 2 * H);
     w.eB = take(PU * 2 * H);
     w.d_ea = take(2 * PU * H);
@@ -467,6 +469,10 @@ __global__ void adam_kernel(int64_t n, float* __restrict__ p, const float* __res
     p[i] = pi - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
 }
 
+struct SideLane {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, fork2 = nullptr, join = nullptr;
+};
 struct Ctx {
     const tsd_model_cfg* c;
     const tsd_batch* b;
@@ -586,7 +592,7 @@ int embed_bwd(const Ctx& x, const tsd_edges& lst, int E, const EmbedSave& s, con
 
 // MFMA sizes: the dgrad chain of BOTH lists in one tile-kernel launch (launch_embed_bwd), then the weight / table
 // gradients per list from the dY it wrote.  d_ea: [2 PU, H], rows as the edge-attribute matrix.
-int embed_bwd_fused(const Ctx& x, const tsd_geometry& g, const float* d_ea, bool h2) {
+int embed_bwd_fused(const Ctx& x, const tsd_geometry& g, const float* d_ea, bool h2, SideLane* side = nullptr) {
     const int H = x.H;
     const Work& w = x.w;
     const size_t o1 = (size_t)x.Eu * H, o2 = (size_t)x.Eu * 2 * H;  // first row of the second list
@@ -598,6 +604,10 @@ int embed_bwd_fused(const Ctx& x, const tsd_geometry& g, const float* d_ea, bool
     float* eamax = w.amax + 2 * x.L + 2;
     TSD_TRY(launch_embed_bwd(H, x.Eu, la, x.Ed, lb, x.raw + x.R.bond_emb, Wt + x.R.ecat_w1, Wt + x.R.ecat_w0,
                              Wt + x.R.emlp_w1, x.st, h2 ? eamax : nullptr));
+    if (side != nullptr) {
+        TSD_HIP(hipEventRecord(side->fork2, x.st));
+        TSD_HIP(hipStreamWaitEvent(side->s, side->fork2, 0));
+    }
     // weight gradients only (dX == NULL): X, dY per layer, the rows of BOTH lists as one problem (they are contiguous:
     // the forward saved the second list's rows, distances and types right behind the first's)
     const int E = x.Eu + x.Ed;
@@ -620,12 +630,18 @@ int embed_bwd_fused(const Ctx& x, const tsd_geometry& g, const float* d_ea, bool
         } else {
             TSD_TRY(x.lin_bwd(E, 2 * H, H, w.emb.c, x.R.ecat_w0, (long)x.R.ecat_b0, w.e_dc0, nullptr, false));
         }
+        // (side lane: the table / narrow-layer gradients only read what the chain kernel above wrote)
+        Ctx xs = x;
+        if (side != nullptr) {
+            xs.st = side->s;
+            xs.w.scratch = w.scratch2;
+        }
         const int chunks = emb_chunks(E);
-        hipLaunchKernelGGL(emb_mul2_bwd_kernel, dim3((H + 63) / 64, chunks), dim3(256), 0, x.st, E, H,
+        hipLaunchKernelGGL(emb_mul2_bwd_kernel, dim3((H + 63) / 64, chunks), dim3(256), 0, xs.st, E, H,
                            (E + chunks - 1) / chunks, w.emb.e, x.raw + x.R.bond_emb, w.emb.tr, w.emb.tp, w.e_dc,
-                           (float*)nullptr, w.scratch);
-        TSD_TRY(launch_split_reduce((int64_t)ET * H, chunks, w.scratch, x.grad + x.R.bond_emb, 1, x.st));  // rows [0, ET) of the [100, H] table
-        TSD_TRY(x.lin_bwd(E, 1, H, w.emb.d, x.R.emlp_w0, (long)x.R.emlp_b0, w.e_dl0, nullptr, false));
+                           (float*)nullptr, xs.w.scratch);
+        TSD_TRY(launch_split_reduce((int64_t)ET * H, chunks, xs.w.scratch, x.grad + x.R.bond_emb, 1, xs.st));  // rows [0, ET) of the [100, H] table
+        TSD_TRY(xs.lin_bwd(E, 1, H, w.emb.d, x.R.emlp_w0, (long)x.R.emlp_b0, w.e_dl0, nullptr, false));
     }
     TSD_LAUNCH_CHECK("embed_bwd_fused");
     return TSD_OK;
@@ -634,6 +650,40 @@ int embed_bwd_fused(const Ctx& x, const tsd_geometry& g, const float* d_ea, bool
 // the save arrays of the edge embedding from row `row` on
 EmbedSave embed_rows(const EmbedSave& s, size_t row, size_t H) {
     return EmbedSave{s.l0 + row * H, s.s0 + row * H, s.e + row * H, s.c + row * 2 * H, s.c0 + row * H, s.s1 + row * H};
+}
+
+// node embedding: dz = d loss / d h_0
+// (d(Wf r) rows then d(Wf p) rows in nA [2 N, H/2], against featR | featP [2 N, F]: atom_feat_embedding's weight
+// gradient is one problem of 2 N rows)
+int node_embed_grads(const Ctx& x, const float* dz, const int64_t* atom_type, hipStream_t st, float* scratch) {
+    const Work& w = x.w;
+    const int N = x.N, H = x.H, F = x.F;
+    hipLaunchKernelGGL(node_embed_bwd_kernel, dim3(nblk((int64_t)N * (H / 2))), dim3(256), 0, st, N, H / 2, dz, w.nA,
+                       w.nA + (size_t)N * (H / 2));
+    hipLaunchKernelGGL(atom_emb_grad_kernel, dim3(100, AE_CHUNKS), dim3(H / 2 < 256 ? H / 2 : 256), 0, st, N, H / 2,
+                       atom_type, dz, scratch);
+    hipLaunchKernelGGL(atom_emb_grad_reduce_kernel, dim3(nblk(100 * (H / 2))), dim3(256), 0, st, 100 * (H / 2), scratch,
+                       x.grad + x.R.atom_emb);
+    return linear_bwd_impl(2 * N, F, H / 2, w.featR, x.raw + x.R.atom_feat, nullptr, w.nA, nullptr, x.grad + x.R.atom_feat,
+                           nullptr, 2, LinEpi(), scratch, w.scratch_floats, st);
+}
+
+// A second stream of the library's own for the backward's small, latency-bound gradient launches (embedding tables, narrow
+// layers: nine launches of a few workgroups each, ~115 us one behind the other): forked where their inputs are final, they
+// run beside the batched weight-gradient launches of the caller's stream and join it before the call returns.
+int side_lane(SideLane** out) {
+    static thread_local SideLane lanes[16];
+    int dev = 0;
+    TSD_HIP(hipGetDevice(&dev));
+    SideLane& l = lanes[dev & 15];
+    if (l.s == nullptr) {
+        TSD_HIP(hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking));
+        TSD_HIP(hipEventCreateWithFlags(&l.fork, hipEventDisableTiming));
+        TSD_HIP(hipEventCreateWithFlags(&l.fork2, hipEventDisableTiming));
+        TSD_HIP(hipEventCreateWithFlags(&l.join, hipEventDisableTiming));
+    }
+    *out = &l;
+    return TSD_OK;
 }
 
 // tsd_batch.reserved bit 5 asks for the split-f16 step; its tile kernels exist for the shipped width (hidden = 256), any other
@@ -968,6 +1018,15 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
         }
         TSD_TRY(x.lin_bwd(N, H, H, hl, o + x.R.L_lin1_w, -1, w.nC, w.dh, true));  // dh += dx1 W_lin1 (residual keeps dh)
     }
+    // split-f16 step: the node-embedding gradients need only dh_0, which is final here -- they go to the side lane, beside the
+    // batched weight-gradient launches below (nA / nB are free again, the lane has its own scratch)
+    SideLane* side = nullptr;
+    if (h2 && batch_wg && !(batch->reserved & 64)) {
+        TSD_TRY(side_lane(&side));
+        TSD_HIP(hipEventRecord(side->fork, st));
+        TSD_HIP(hipStreamWaitEvent(side->s, side->fork, 0));
+        TSD_TRY(node_embed_grads(x, dh_cur, atom_type, side->s, w.scratch2));
+    }
     if (batch_wg) {
         std::vector<const float*> dYs, Xs;
         std::vector<float*> dWs, dbs;
@@ -1008,7 +1067,7 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
     if (blocks_done_event != nullptr) TSD_HIP(hipEventRecord((hipEvent_t)blocks_done_event, st));
     const float* dz = dh_cur;  // d loss / d h_0
     if (batch_wg) {
-        TSD_TRY(embed_bwd_fused(x, g, w.d_ea, h2));
+        TSD_TRY(embed_bwd_fused(x, g, w.d_ea, h2, side));
     } else {
         if (Eu > 0) TSD_TRY(embed_bwd(x, g.enc_u, Eu, w.emb, w.d_ea));
         if (Ed > 0) TSD_TRY(embed_bwd(x, g.diff_u, Ed, embed_rows(w.emb, (size_t)Eu, (size_t)H), w.d_ea + (size_t)Eu * H));
@@ -1016,14 +1075,11 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
     // node embedding: dz = dh
     // (d(Wf r) rows then d(Wf p) rows in nA [2 N, H/2], against featR | featP [2 N, F]: atom_feat_embedding's weight
     // gradient is one problem of 2 N rows)
-    hipLaunchKernelGGL(node_embed_bwd_kernel, dim3(nblk((int64_t)N * (H / 2))), dim3(256), 0, st, N, H / 2, dz, w.nA,
-                       w.nA + (size_t)N * (H / 2));
-    hipLaunchKernelGGL(atom_emb_grad_kernel, dim3(100, AE_CHUNKS), dim3(H / 2 < 256 ? H / 2 : 256), 0, st, N, H / 2,
-                       atom_type, dz, w.scratch);
-    hipLaunchKernelGGL(atom_emb_grad_reduce_kernel, dim3(nblk(100 * (H / 2))), dim3(256), 0, st, 100 * (H / 2), w.scratch,
-                       grad + x.R.atom_emb);
-    TSD_TRY(linear_bwd_impl(2 * N, F, H / 2, w.featR, raw + x.R.atom_feat, nullptr, w.nA, nullptr, grad + x.R.atom_feat,
-                            nullptr, 2, LinEpi(), w.scratch, w.scratch_floats, st));
+    if (side == nullptr) TSD_TRY(node_embed_grads(x, dz, atom_type, st, w.scratch));
+    if (side != nullptr) {  // the caller's stream continues behind the side lane's last launch
+        TSD_HIP(hipEventRecord(side->join, side->s));
+        TSD_HIP(hipStreamWaitEvent(st, side->join, 0));
+    }
     TSD_LAUNCH_CHECK("train_backward");
     return TSD_OK;
 }

@@ -420,7 +420,7 @@ class DeviceBatch:
         """tsd_batch for the training step: topology + edge-list buffers only (no bound checkpoints).  h2: the step's
         tile GEMMs on the f16 MFMA pipes (tsd_batch.reserved bit 5), range flag in the batch's status word"""
         return Batch(
-            reserved=32 if h2 else 0, status=self.status.data_ptr(),
+            reserved=(32 | (0 if OPTIONS.train_side_lane else 64)) if h2 else 0, status=self.status.data_ptr(),
             num_nodes=self.N, num_graphs=self.G, num_pairs=self.P, num_models=0,
             graph_ptr=self.graph_ptr.data_ptr(), node_graph=self.node_graph.data_ptr(),
             pair_ptr=self.pair_ptr.data_ptr(), pair_code=self.pair_code.data_ptr(),
