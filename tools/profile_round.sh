@@ -41,7 +41,7 @@ python3 tools/mfma_busy.py c2=$(db /tmp/p_sq) c5=$(db /tmp/p_sq5) train=$(db /tm
 {
   echo "# SQ counters per launch of the training step (rocprofv3 --kernel-trace --pmc, one pass; MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch time x 2.4 GHz)), $TAG"
   echo; echo '```'
-  for k in block_bwd layer_combo wgrad_batch wgrad_kernel embed_bwd edge_embed pair_output pair_bwd; do python3 tools/pmc_kernel_table.py $(db /tmp/p_sqt) $k; done
+  for k in block_bwd layer_combo wgrad_h2 wgrad_batch wgrad_kernel embed_bwd edge_embed pair_output pair_bwd; do python3 tools/pmc_kernel_table.py $(db /tmp/p_sqt) $k; done
   echo '```'
 } > gpurun_out/${TAG}_sq_counters_train.md
 {
