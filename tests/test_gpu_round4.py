@@ -497,3 +497,48 @@ def test_train_side_lane_is_bit_identical(dev, monkeypatch):
     assert torch.equal(res[True][0], res[False][0])
     for k, ref in res[False][1].items():
         assert torch.equal(res[True][1][k], ref), k
+
+
+def test_train_split_f16_batch200_vs_oracle(dev):
+    """BASELINE configs[3] at its full size (200 graphs, ~3000 atoms, production network) in the default split-f16
+    arithmetic: loss and EVERY parameter gradient, element by element, against the pinned oracle's autograd on the host
+    (max|d| <= 2e-5 of each tensor's scale -- the bar of the fp32 step)"""
+    from oracle import tsdiff_oracle as O
+    from tsdiff_amd import synth
+    from tsdiff_amd.options import OPTIONS
+    assert OPTIONS.train_gemm == "h2"
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    G = 200
+    b = synth.wb97xd3_like_batch(G, seed=2000)
+    t = {k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}
+    t["pos"] = t["pos"] * 1.5
+    gen = torch.Generator().manual_seed(11)
+    ts = torch.randint(0, 5000, (G,), generator=gen)
+    pn = torch.randn(t["pos"].shape, generator=gen)
+    model = make_model(cfg, 2, dev)
+    model.train()
+    model.zero_grad()
+    g = to_dev(t, dev)
+    loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"],
+                          g["num_nodes_per_graph"], G, _time_step=ts.to(dev), _pos_noise=pn.to(dev))
+    loss.mean().backward()
+    assert not getattr(model, "_train_f32", False)
+    osd = O.to_torch_state(synth.synth_state_dict(cfg, 2))
+    for v in osd.values():
+        v.requires_grad_(True)
+    o_loss = O.get_loss(osd, cfg, t["atom_type"], t["r_feat"], t["p_feat"], t["pos"], t["bond_index"], t["bond_type"],
+                        t["batch"], t["num_nodes_per_graph"].numpy(), ts, pn)
+    o_loss.mean().backward()
+    assert_close(loss.detach().cpu().numpy(), o_loss.detach().numpy(), 5e-5, "loss at batch 200")
+    P = dict(model.named_parameters())
+    n, worst = 0, 0.0
+    for k, v in osd.items():
+        if v.grad is None or k in ("betas", "alphas"):
+            continue
+        ref = v.grad.numpy()
+        err = float(np.abs(P[k].grad.cpu().numpy() - ref).max()) / max(float(np.abs(ref).max()), 1e-30)
+        worst = max(worst, err)
+        assert err <= 2e-5, f"d loss / d {k}: {err:.3e} of the tensor's scale"
+        n += 1
+    assert n == 7 + 9 * 7 + 6 + 4
+    print(f"worst gradient deviation from the oracle at batch 200: {worst:.2e}")
