@@ -324,13 +324,26 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
 #pragma unroll
                     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float y = sspf(hval(am[rb][0], ax[rb][0], r) + b0);
-                            f16 yh, yl;
-                            amax_upd(amax, y);
-                            split1(y, yh, yl);
-                            hb[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = yh;
-                            lb[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = yl;
+                        for (int r = 0; r < 16; r += 2) {
+                            // two rows at a time: the adds / multiplies of the pair are packed fp32 instructions
+                            // (v_pk_fma / v_pk_add / v_pk_mul_f32: the accumulator registers of rows r, r + 1 are adjacent)
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+                            const f32x2 m2 = {am[rb][0][r], am[rb][0][r + 1]}, x2 = {ax[rb][0][r], ax[rb][0][r + 1]};
+                            const f32x2 v = x2 * SPLIT_INV + m2 + b0;
+                            const f32x2 t = {fast_exp(-fabsf(v[0])), fast_exp(-fabsf(v[1]))};
+                            const f32x2 t1 = t + 1.0f;
+                            const f32x2 lg = {__builtin_amdgcn_logf(t1[0]), __builtin_amdgcn_logf(t1[1])};
+                            const f32x2 mx = {fmaxf(v[0], 0.0f), fmaxf(v[1], 0.0f)};
+                            const f32x2 l2 = lg * 0.69314718055994530942f;  // (its own statement: not contracted, as in sspf)
+                            const f32x2 y2 = (mx + l2) - 0.69314718055994530942f;
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                f16 yh, yl;
+                                amax_upd(amax, y2[k]);
+                                split1(y2[k], yh, yl);
+                                hb[(rb * 32 + ((r + k) & 3) + 8 * ((r + k) >> 2)) * LDH] = yh;
+                                lb[(rb * 32 + ((r + k) & 3) + 8 * ((r + k) >> 2)) * LDH] = yl;
+                            }
                         }
                 }
                 __syncthreads();
