@@ -39,7 +39,7 @@ def child(workload, steps, lib, flags):
     from tsdiff_amd.sampler import EnsembleSampler
     dev = torch.device("cuda:0")
     cfg = synth.DEFAULT_MODEL_CONFIG
-    M = 8 if workload == "ens8" else 1
+    M = int(workload[3:]) if workload.startswith("ens") else 1  # ensN: N checkpoints on the configs[1] batch
     models = make_models(cfg, range(M), dev)
     if workload == "c5":
         b = synth.dense_stress_batch(1024, n=64, seed=1000)
