@@ -34,4 +34,4 @@ pr = cProfile.Profile(); pr.enable()
 for i in range(20): step(i)
 torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats('tottime').print_stats(45)
+pstats.Stats(pr).sort_stats('cumulative').print_stats(60)

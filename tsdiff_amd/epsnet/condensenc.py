@@ -122,6 +122,19 @@ class CondenseEncoderEpsNetwork(nn.Module):
     def _weight_tensors(self):
         return dict(zip(engine.raw_param_names(self._cfg.num_convs), self.raw_params()))
 
+    def parameters(self, recurse=True):
+        """nn.Module.parameters, from a cached list: the reference's loop calls `clip_grad_norm_(model.parameters(), …)`
+        every step (train.py:144) and the generic generator walks the module tree for it (~0.25 ms of a 2 ms step whose
+        length is its host side).  The module tree of this class is fixed after __init__; nn.Module._apply and
+        load_state_dict keep the Parameter objects."""
+        if not recurse:
+            return super().parameters(recurse=False)
+        lst = self.__dict__.get("_param_list_cache")
+        if lst is None:
+            lst = list(super().parameters(recurse=True))
+            self.__dict__["_param_list_cache"] = lst
+        return iter(lst)
+
     def raw_params(self):
         """the trainable tensors in the order of the flat parameter vector (engine.raw_param_names); cached: walking
         the module tree costs ~0.4 ms, once per training step otherwise.  nn.Module._apply (.to / .cuda / .float)
