@@ -23,6 +23,9 @@ BUDGET = [
     (r"pair_output_h_kernelILi256E", 128, 0),
     (r"layer_combo_kernelILi256ELb1ELb0ELi1ELi1E", 128, 0),  # split-f16 block launch of the training step (saving form)
     (r"block_bwd_kernelILi256E", 128, 0),                    # backward block launch, fp32 and split-f16 filter chains
+    (r"pair_bwd_h_kernelILi256E", 128, 0),                   # split-f16 training step: the other tile kernels
+    (r"embed_bwd_h_kernelILi256E", 128, 0),
+    (r"edge_embed_save_h_kernelILi256E", 128, 0),
     (r"unit_encoder_kernelILi256E", 256, 0),
     (r"wgrad_h2_batch_kernel", 256, 0),  # four waves per workgroup, two workgroups per CU
     # sixteen waves per workgroup: 128 registers; a few loop-invariant values of the per-block prologue may sit in scratch
