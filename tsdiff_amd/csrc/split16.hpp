@@ -200,7 +200,10 @@ __device__ __forceinline__ void hring_wait(f32x4 (&b)[CB][2]) {
 }
 
 constexpr int HRING_R = 3;    // k-steps in flight, 32-row GEMMs (CB = 1: 8 fragments = 32 VGPRs)
-constexpr int HRING16_R = 3;  // 32-k steps in flight, 16-row GEMMs (CB = 2: 12 fragments = 48 VGPRs)
+#ifndef TSD_HRING16_R
+#define TSD_HRING16_R 3
+#endif
+constexpr int HRING16_R = TSD_HRING16_R;  // 32-k steps in flight, 16-row GEMMs (CB = 2: 12 fragments = 48 VGPRs)
 
 // ---- 32-row blocks: v_mfma_f32_32x32x16_f16.  A lane l: row l & 31, k = 8 (l >> 5) .. + 7 of the k-step; B lane l:
 // column l & 31, the same k; C/D as the fp32 32x32 MFMA (acc_row).  KS = K / 16 k-steps.
