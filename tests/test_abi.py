@@ -201,3 +201,27 @@ int roctxRangePop(void) { char b[64]; snprintf(b, sizeof b, "pop %d", --depth); 
     lines = log.read_text().split("\n")
     assert "push 0 tsd:pack_weights" in lines and "pop 0" in lines
     assert sum(l.startswith("push") for l in lines) == sum(l.startswith("pop") for l in lines)
+
+
+def test_options_object(monkeypatch):
+    """tsdiff_amd.options: ONE object, defaults = the fast paths, TSDIFF_* environment variables read once at import
+    (Options.from_env), bad values refused"""
+    from tsdiff_amd import options
+    o = options.Options()
+    assert (o.gemm, o.train, o.train_gemm, o.train_side_lane, o.one_launch, o.fused_encoder) == ("h2", "fused", "h2", True, True, True)
+    monkeypatch.setenv("TSDIFF_TRAIN_GEMM", "f32")
+    monkeypatch.setenv("TSDIFF_TRAIN_SIDE_LANE", "0")
+    monkeypatch.setenv("TSDIFF_PINGPONG", "solo")
+    e = options.Options.from_env()
+    assert e.train_gemm == "f32" and e.train_side_lane is False and e.pingpong == "solo" and e.gemm == "h2"
+    monkeypatch.setenv("TSDIFF_TRAIN_GEMM", "bf16")
+    with pytest.raises(ValueError):
+        options.Options.from_env()
+    monkeypatch.setenv("TSDIFF_TRAIN_GEMM", "h2")
+    monkeypatch.setenv("TSDIFF_TRAIN", "eager")
+    with pytest.raises(ValueError):
+        options.Options.from_env()
+    # the documented table lists every field
+    doc = options.__doc__
+    for f in options.Options.__dataclass_fields__:
+        assert f"| {f} " in doc, f
