@@ -1210,6 +1210,46 @@ def test_dp_backward_flat_gradient_path_on_the_real_model(dev):
     torch.optim.Adam(model.parameters(), lr=5e-4, betas=(0.95, 0.999)).step()   # train.py:144-145 on the reduced gradient
 
 
+def test_dp_backward_with_existing_grads_reduces_once(dev):
+    """the same with a .grad ALREADY present on every parameter (zero_grad(set_to_none=False), then micro-batch
+    accumulation): AccumulateGrad adds into the existing tensors, so the early side-stream all-reduce of the blocks' range
+    must not be armed (it would race with the accumulation and the gather-scatter branch would reduce that range a second
+    time) -- every gradient is reduced exactly ONCE: p.grad = 2 x the single-process gradient's step contribution"""
+    from tsdiff_amd.distributed import dp_backward
+    d, meta = load_golden("loss_synth_b4_small")
+    g = to_dev(batch_inputs(d), dev)
+    kw = dict(_time_step=torch.from_numpy(d["time_step"]).to(dev), _pos_noise=torch.from_numpy(d["pos_noise"]).to(dev))
+    args = (g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"],
+            g["num_nodes_per_graph"], g["num_graphs"])
+    ref = make_model(meta["cfg"], meta["seed"], dev)
+    ref.train()
+    ref.get_loss(*args, **kw).mean().backward()
+    ref_grads = {k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None}
+
+    model = make_model(meta["cfg"], meta["seed"], dev)
+    model.train()
+    model.get_loss(*args, **kw).mean().backward()   # gives every parameter a .grad
+    model.zero_grad(set_to_none=False)              # ... which stays, zeroed
+    calls = []
+
+    def twice(t):
+        calls.append(t.numel())
+        t.mul_(2.0)
+    dp_backward(model, model.get_loss(*args, **kw), reduce_fn=twice)
+    assert model._last_reduce == "gather-scatter" and len(calls) == 2 and getattr(model, "_dp_early_done", None) is None
+    for k, p in model.named_parameters():
+        if k in ref_grads:   # (x2 by the emulated second rank, /2 by the doubled normaliser)
+            assert torch.allclose(p.grad, ref_grads[k], rtol=1e-6, atol=1e-12), k
+    # accumulation of a second micro-batch on top: AccumulateGrad adds this rank's g / 2 to the g already there, the
+    # reducer doubles the sum once (as any all-reduce after accumulation would): 2 x (g + g / 2) = 3 g
+    calls.clear()
+    dp_backward(model, model.get_loss(*args, **kw), reduce_fn=twice)
+    assert model._last_reduce == "gather-scatter" and len(calls) == 2
+    for k, p in model.named_parameters():
+        if k in ref_grads:
+            assert torch.allclose(p.grad, 3.0 * ref_grads[k], rtol=1e-5, atol=1e-12), k
+
+
 def test_flat_optimizer_step_equals_torch_adam(dev, tmp_path):
     """tsdiff_amd.optim (train.py:103,144-145 on the flat vectors): clip_grad_norm_ + Adam over the fused step's flat
     gradient against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam on an identical model, three steps (the clip

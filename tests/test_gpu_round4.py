@@ -383,10 +383,11 @@ def _train_case(dev, graphs=12, seed=31):
     return to_dev(t, dev), ts.to(dev), pn.to(dev), graphs
 
 
-def _train_step_grads(model, g, ts, pn, G, mode, monkeypatch, loss_scale=1.0):
+def _train_step_grads(model, g, ts, pn, G, mode, monkeypatch, loss_scale=1.0, keep_mode=False):
     from tsdiff_amd.options import OPTIONS
     monkeypatch.setattr(OPTIONS, "train_gemm", mode)
-    model._train_f32 = False
+    if not keep_mode:
+        model._train_f32 = False
     model.train()
     model.zero_grad(set_to_none=True)
     loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
@@ -421,25 +422,32 @@ def test_train_split_f16_matches_fp32(loss_scale, dev, monkeypatch):
 
 def test_train_split_f16_range_fallback(dev, monkeypatch):
     """an activation beyond the f16 range inside the split-f16 training forward: tsd_train_backward2 returns TSD_ERR_RANGE
-    before launching anything, the host recomputes the forward on the fp32 kernels into the same loss tensor, runs the fp32
-    backward and keeps the model in fp32 -- loss and gradients are then BIT-identical to a step that ran in fp32 from the
-    start"""
+    before launching anything, the host recomputes the forward on the fp32 kernels into the same loss tensor and runs the
+    fp32 backward -- loss and gradients are then BIT-identical to a step that ran in fp32 from the start.  The fallback is
+    PER STEP (round 5): the next step tries split-f16 again (and trips again on this model), the trips are counted, and
+    only OPTIONS.train_fallback_latch trips in a row latch the model to fp32"""
     from tsdiff_amd import synth
+    from tsdiff_amd.options import OPTIONS
     model = make_model(synth.DEFAULT_MODEL_CONFIG, 2, dev)
     with torch.no_grad():
         model.encoder.interactions[3].conv.lin2.bias.add_(3.0e5)  # x2 of block 3 ~ 3e5: ssp(x2) leaves the f16 range
     g, ts, pn, G = _train_case(dev)
     lf, gf = _train_step_grads(model, g, ts, pn, G, "f32", monkeypatch)
     assert np.isfinite(float(lf.abs().max()))
-    with pytest.warns(RuntimeWarning, match="split-f16 training"):
+    monkeypatch.setattr(OPTIONS, "train_fallback_latch", 3)
+    for trip in (1, 2):
+        with pytest.warns(RuntimeWarning, match="split-f16 training"):
+            lh, gh = _train_step_grads(model, g, ts, pn, G, "h2", monkeypatch)
+        assert not getattr(model, "_train_f32", False)  # not sticky
+        assert model._h2_range_trips == trip and model._h2_range_run == trip
+        assert torch.equal(lh, lf)
+        for k, ref in gf.items():
+            assert torch.equal(gh[k], ref), k
+    # the third trip in a row latches: warning says so, and the step after it runs in fp32 without a warning
+    with pytest.warns(RuntimeWarning, match="now trains in fp32"):
         lh, gh = _train_step_grads(model, g, ts, pn, G, "h2", monkeypatch)
-    assert model._train_f32 is True
-    assert torch.equal(lh, lf)
-    for k, ref in gf.items():
-        assert torch.equal(gh[k], ref), k
-    # the next step runs in fp32 without a warning
+    assert model._train_f32 is True and torch.equal(lh, lf)
     import warnings
-    from tsdiff_amd.options import OPTIONS
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         model.zero_grad(set_to_none=True)
@@ -447,6 +455,11 @@ def test_train_split_f16_range_fallback(dev, monkeypatch):
                               g["batch"], g["num_nodes_per_graph"], G, _time_step=ts, _pos_noise=pn)
         loss.mean().backward()
     assert OPTIONS.train_gemm == "h2" and torch.equal(loss.detach(), lf)
+    # a step inside the range resets the run counter (another model: same code path)
+    ok = make_model(synth.DEFAULT_MODEL_CONFIG, 2, dev)
+    ok._h2_range_run = 2
+    _train_step_grads(ok, g, ts, pn, G, "h2", monkeypatch)
+    assert ok._h2_range_run == 0 and not getattr(ok, "_train_f32", False)
 
 
 def test_train_split_f16_edge_cases(dev, monkeypatch):

@@ -65,6 +65,9 @@ extern "C" int tsd_debug_prec(int prec) {
 
 namespace tsd {
 
+#ifndef TSD_FILTER_TRANS
+#define TSD_FILTER_TRANS 1  // transposed accumulators in the split-f16 tile roles (0: the round-4 layout; A/B builds)
+#endif
 constexpr int T = TSD_EDGE_TILE;   // 32 edges per filter tile
 constexpr int TN = TSD_NODE_TILE;  // 16 nodes per node tile
 #ifndef TSD_AGG_PREFETCH
@@ -963,6 +966,12 @@ __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, fl
     const Planes pl = planes_at(smem, TT, LDH);
     float* buf = smem;             // the finished filter tile as fp32 rows (over the planes: TT (H + 4) <= TT (H + 8) floats)
     float* s_c = smem + TT * LDH;  // (planes: 2 x TT x LDH f16 = TT x LDH floats)
+    // TRANSPOSED ACCUMULATORS (split16.hpp hgemm_ring_run<..., TRANS>; inference tiles): a lane holds four runs of four
+    // consecutive channels of ONE tile row -- 8-byte plane stores, 16-byte filter-tile stores, one cutoff weight per lane;
+    // the 16 channels' biases come from LDS.  The saving form keeps the plain layout (its side stores are row-contiguous
+    // per wave that way).  Bit-identical either way.
+    constexpr bool TR = !SAVE && TSD_FILTER_TRANS != 0;
+    float* s_bias = s_c + TT;      // [2][H] nn.0 / nn.2 biases (TR)
 
     const int E = *f.e.count;
     const int e0 = tile * TT;
@@ -978,7 +987,16 @@ __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, fl
     HRing<1, HRING_R> rg;
     hgemm_ring_start<1, H>(rg, nn0_w, H, col0);
     for (int r = tid; r < TT; r += NT) s_c[r] = r < nrows ? cutoff_weight(f.e.dist[e0 + r], f.conv_cutoff, f.smooth) : 0.0f;
-    const float b0 = nn0_b[col], b2 = nn2_b[col];
+    float b0 = 0.0f, b2 = 0.0f;
+    if constexpr (TR) {
+        for (int c = tid; c < H; c += NT) {
+            s_bias[c] = nn0_b[c];
+            s_bias[H + c] = nn2_b[c];
+        }
+    } else {
+        b0 = nn0_b[col];
+        b2 = nn2_b[col];
+    }
     {   // edge_attr tile -> LDS planes with every load of a thread in flight together (rows past the end clamped)
         constexpr int NIT = TT * C4 / NT;
         static_assert(TT * C4 % NT == 0, "tile / block mismatch");
@@ -1005,11 +1023,29 @@ __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, fl
 
     f32x16 accm[RB][1], accx[RB][1];
     hzero(accm, accx);
-    hgemm_ring_run<RB, 1, H>(rg, pl, LDH, accm, accx);
+    hgemm_ring_run<RB, 1, H, false, TR>(rg, pl, LDH, accm, accx);
     hgemm_ring_start<1, H>(rg, nn2_w, H, col0);
     TSD_TRACE_WAVE(8);
     TSD_TRACE_AT(2);
     __syncthreads();
+    if constexpr (TR) {
+        // (group-major: the next group's bias vector is requested before this group's stores -- a wave's LDS accesses stay in
+        // program order, and the role has no registers for all 16 biases at once: two workgroups per CU = 128 VGPRs)
+        const float* bb = s_bias + col0 + 4 * hi;
+        f32x4 bn = *reinterpret_cast<const f32x4*>(bb);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 bv = bn;
+            if (g4 < 3) bn = *reinterpret_cast<const f32x4*>(bb + 8 * (g4 + 1));
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                f32x4 y4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y4[r] = sspf(hval(accm[rb][0], accx[rb][0], 4 * g4 + r) + bv[r]);
+                planes_store4(pl, (rb * T + l31) * LDH + col0 + 8 * g4 + 4 * hi, y4, amax);
+            }
+        }
+    } else
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -1029,10 +1065,29 @@ __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, fl
     TSD_TRACE_AT(3);
 
     hzero(accm, accx);
-    hgemm_ring_run<RB, 1, H>(rg, pl, LDH, accm, accx);
+    hgemm_ring_run<RB, 1, H, false, TR>(rg, pl, LDH, accm, accx);
     TSD_TRACE_WAVE(16);
     TSD_TRACE_AT(4);
     __syncthreads();
+    if constexpr (TR) {
+        const float* bb = s_bias + H + col0 + 4 * hi;
+        float cw[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) cw[rb] = s_c[rb * T + l31];
+        f32x4 bn = *reinterpret_cast<const f32x4*>(bb);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 bv = bn;
+            if (g4 < 3) bn = *reinterpret_cast<const f32x4*>(bb + 8 * (g4 + 1));
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                f32x4 w4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w4[r] = (hval(accm[rb][0], accx[rb][0], 4 * g4 + r) + bv[r]) * cw[rb];
+                *reinterpret_cast<f32x4*>(buf + (rb * T + l31) * LDA + col0 + 8 * g4 + 4 * hi) = w4;
+            }
+        }
+    } else
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -1067,6 +1122,7 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
     const int col0 = wave * 32, col = col0 + l31;
     const int nrows = min(T, E - e0);
     float amax = 0.0f;
+    constexpr bool TR = !SAVE && TSD_FILTER_TRANS != 0;  // transposed accumulators (see filter_role_h): lane = tile row l31
     if (tid < T) {
         const int ee = e0 + min(tid, nrows - 1);
         s_src[tid] = q.e.src[ee];
@@ -1104,10 +1160,20 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
         hgemm_ring_start<1, H>(rg, q.w0b, H, col0);  // (behind the staging: its registers are free now)
         __syncthreads();
         hzero(accm, accx);
-        hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
-        const float b = q.b0[col];
+        hgemm_ring_run<1, 1, H, false, TR>(rg, pl, LDH, accm, accx);
+        if constexpr (TR) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pre_v[r] = acc_row(r, hi) < nrows ? hval(accm[0][0], accx[0][0], r) + b : 0.0f;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(q.b0 + col0 + 8 * g4 + 4 * hi);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    pre_v[4 * g4 + r] = l31 < nrows ? hval(accm[0][0], accx[0][0], 4 * g4 + r) + bv[r] : 0.0f;
+            }
+        } else {
+            const float b = q.b0[col];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pre_v[r] = acc_row(r, hi) < nrows ? hval(accm[0][0], accx[0][0], r) + b : 0.0f;
+        }
     };
     if (!defer_pre) pre_gemm();
     // wait for the node tiles that hold this tile's atoms (min .. max node id over both end points)
@@ -1174,8 +1240,17 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
     hgemm_ring_start<1, H>(rg, q.w0a, H, col0);  // (behind the staging: its registers are free now)
     __syncthreads();
     hzero(accm, accx);
-    hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
+    hgemm_ring_run<1, 1, H, false, TR>(rg, pl, LDH, accm, accx);
     __syncthreads();
+    if constexpr (TR) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 s4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s4[r] = swishf(pre_v[4 * g4 + r] + hval(accm[0][0], accx[0][0], 4 * g4 + r));
+            planes_store4(pl, l31 * LDH + col0 + 8 * g4 + 4 * hi, s4, amax);
+        }
+    } else
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float v = pre_v[r] + hval(accm[0][0], accx[0][0], r), sg = swishf(v);
@@ -1192,7 +1267,19 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
     if (wave < NW) {  // H -> H/2 and the final dot: the first H/64 waves
         const int c2 = wave * 32 + l31;
         hzero(accm, accx);
-        hgemm_tile<1, 1, H>(pl, LDH, q.w1, H / 2, wave * 32, accm, accx);
+        hgemm_tile<1, 1, H, false, HRING_R, TR>(pl, LDH, q.w1, H / 2, wave * 32, accm, accx);
+        if constexpr (TR) {   // the lane's 16 channels of row l31 summed in register order, then the other half-wave's 16
+            float v = 0.0f;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(q.b1 + wave * 32 + 8 * g4 + 4 * hi);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(q.w2 + wave * 32 + 8 * g4 + 4 * hi);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v += swishf(hval(accm[0][0], accx[0][0], 4 * g4 + r) + bv[r]) * wv[r];
+            }
+            v += __shfl_xor(v, 32);
+            if (hi == 0) s_red[wave * T + l31] = v;
+        } else {
         const float b = q.b1[c2], w2 = q.w2[c2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1211,6 +1298,7 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
             v += __shfl_xor(v, 2);
             v += __shfl_xor(v, 1);
             if (l31 == 0) s_red[wave * T + acc_row(r, hi)] = v;
+        }
         }
     }
     __syncthreads();
@@ -1860,7 +1948,7 @@ int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity,
 static inline size_t lds_combo(int H, int prec, int frb = 1) {
     const int ld = prec == PREC_H2 ? ldh_of(H) : H + 4;  // floats per tile row (two f16 planes of H + 8 = H + 8 floats)
     const size_t node = (size_t)TN * ld * 4;
-    const size_t filt = (size_t)(T * ld + T) * 4 * frb;
+    const size_t filt = (size_t)(T * ld + T) * 4 * frb + (prec == PREC_H2 ? (size_t)2 * H * 4 : 0);  // (+ the transposed form's biases)
     const size_t pair = (size_t)(T * ld + (H / 64) * T + 3 * T) * 4;  // pair role (H >= 64)
     return node > filt ? (node > pair ? node : pair) : (filt > pair ? filt : pair);
 }

@@ -57,9 +57,18 @@ struct UnitArgs {
     int32_t* status;           // TSD_STATUS_RANGE / TSD_STATUS_INTERNAL (a unit that breaks the size contract)
 };
 
+// TRANSPOSED ACCUMULATORS (round 5, split16.hpp hgemm_ring_run<..., TRANS>): the weight fragment is the MFMA's A operand, so
+// a lane ends up with runs of four consecutive CHANNELS of one tile row -- the ssp epilogue writes f16x4 (8 LDS stores per
+// lane, plane and 32-row block instead of 32), the filter tile goes to LDS as f32x4, the cutoff weight is one value per
+// lane, the node chain reads / writes h as 16-byte accesses.  Bit-identical (the same MFMA dot products).
+// -DTSD_UNIT_TRANS=0 builds the round-4 form (A/B timing: tools/build_variant.sh).
+#ifndef TSD_UNIT_TRANS
+#define TSD_UNIT_TRANS 1
+#endif
+
 // 16-row MFMA GEMM on RB16 row blocks sharing the weight ring (split16.hpp hgemm16_ring_run per row block: the same MFMA
 // sequence per output element)
-template <int RB16, int CB, int K>
+template <int RB16, int CB, int K, bool TRANS = false>
 __device__ __forceinline__ void hgemm16_ring_run_rb(HRing<CB, HRING16_R>& r, const Planes& A, int ldh, f32x4 (&accm)[RB16][CB],
                                                     f32x4 (&accx)[RB16][CB], int nrb /* row blocks that hold rows (uniform) */) {
     constexpr int R = HRING16_R, KS = K / 32;
@@ -82,9 +91,15 @@ __device__ __forceinline__ void hgemm16_ring_run_rb(HRing<CB, HRING16_R>& r, con
             if (rb < nrb) {
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb) {
-                    accx[rb][cb] = mfma_h16(ah[rb], r.b[slot][cb][1], accx[rb][cb]);
-                    accm[rb][cb] = mfma_h16(ah[rb], r.b[slot][cb][0], accm[rb][cb]);
-                    accx[rb][cb] = mfma_h16(al[rb], r.b[slot][cb][0], accx[rb][cb]);
+                    if constexpr (TRANS) {
+                        accx[rb][cb] = mfma_h16(r.b[slot][cb][1], ah[rb], accx[rb][cb]);
+                        accm[rb][cb] = mfma_h16(r.b[slot][cb][0], ah[rb], accm[rb][cb]);
+                        accx[rb][cb] = mfma_h16(r.b[slot][cb][0], al[rb], accx[rb][cb]);
+                    } else {
+                        accx[rb][cb] = mfma_h16(ah[rb], r.b[slot][cb][1], accx[rb][cb]);
+                        accm[rb][cb] = mfma_h16(ah[rb], r.b[slot][cb][0], accm[rb][cb]);
+                        accx[rb][cb] = mfma_h16(al[rb], r.b[slot][cb][0], accx[rb][cb]);
+                    }
                 }
             }
         if constexpr (ks + R < KS)
@@ -138,6 +153,8 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
     uint16_t* s_u = reinterpret_cast<uint16_t*>(s_c + U_ROWS);  // [U_ROWS] list mode: local (i | j << 8) of the pair;
                                                                 // block mode: local pair index of the tile row, 0xffff: none
     uint16_t* s_tile = s_u + U_ROWS;                 // [64] block mode: blocks (I * 16 + J) of tile t
+    float* s_bias = reinterpret_cast<float*>(s_tile + 64);  // [2][H] transposed form: nn.0 / nn.2 biases of the running block
+    constexpr bool UTR = TSD_UNIT_TRANS != 0;
     const Planes pl = planes_at(tile, UT, LDH);
     float* buf = tile;
 
@@ -236,8 +253,14 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
         f32x4 agg[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) agg[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float b0, b2;  // (loaded here, not in the tile loop: a global load there waits behind the prefetch in vmcnt order)
-        {
+        float b0 = 0.0f, b2 = 0.0f;  // (loaded here, not in the tile loop: a global load there waits behind the prefetch in vmcnt order)
+        if constexpr (UTR) {   // a lane needs 16 channels' biases: both vectors of the block in LDS (the barrier that ends the
+                               // first tile's conversion phase is between these stores and the first read)
+            if (tid < H) {
+                s_bias[tid] = Wl[A.o_nn0_b + tid];
+                s_bias[H + tid] = Wl[A.o_nn2_b + tid];
+            }
+        } else {
             TSD_UNIT_GEOM
             b0 = Wl[A.o_nn0_b + col];
             b2 = Wl[A.o_nn2_b + col];
@@ -303,7 +326,7 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
                 {   // (b) GEMM nn.0
                     TSD_UNIT_GEOM
                     hzero(am, ax);
-                    hgemm_ring_run<RB, 1, H>(rg, pl, LDH, am, ax);
+                    hgemm_ring_run<RB, 1, H, false, UTR>(rg, pl, LDH, am, ax);
                     hgemm_ring_start<1, H>(rg, nn2_w, H, col0);
 #ifdef TSD_UNIT_WFAKE
                     rg.step_bytes = 0;
@@ -317,6 +340,37 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
                 // (in-order return) would otherwise stall on an HBM round trip; the ring's first three k-steps were
                 // issued before them
                 if (t + 1 < ntile) fetch(t + 1);
+                if constexpr (UTR) {   // (c) shifted softplus -> planes, transposed accumulators: registers 4 g .. 4 g + 3 of a
+                    // lane are four consecutive channels of tile row l31: one 8-byte store per plane and group
+                    TSD_UNIT_GEOM
+                    const int pb = opaque(l31 * LDH + col0 + 4 * hi);
+                    const float* bb = s_bias + opaque(col0 + 4 * hi);
+                    f32x4 bv[4];  // (all bias reads ahead of the plane stores: LDS accesses of one wave stay in program order)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) bv[g4] = *reinterpret_cast<const f32x4*>(bb + 8 * g4);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            f32x4 y4;
+#pragma unroll
+                            for (int r = 0; r < 4; r += 2) {   // (pairs: packed fp32 adds / multiplies, as below)
+                                const int q0 = 4 * g4 + r;
+                                const f32x2 m2 = {am[rb][0][q0], am[rb][0][q0 + 1]}, x2 = {ax[rb][0][q0], ax[rb][0][q0 + 1]};
+                                const f32x2 b2v = {bv[g4][r], bv[g4][r + 1]};
+                                const f32x2 v = x2 * SPLIT_INV + m2 + b2v;
+                                const f32x2 t = {fast_exp(-fabsf(v[0])), fast_exp(-fabsf(v[1]))};
+                                const f32x2 t1 = t + 1.0f;
+                                const f32x2 lg = {__builtin_amdgcn_logf(t1[0]), __builtin_amdgcn_logf(t1[1])};
+                                const f32x2 mx = {fmaxf(v[0], 0.0f), fmaxf(v[1], 0.0f)};
+                                const f32x2 l2 = lg * 0.69314718055994530942f;
+                                const f32x2 y2 = (mx + l2) - 0.69314718055994530942f;
+                                y4[r] = y2[0];
+                                y4[r + 1] = y2[1];
+                            }
+                            planes_store4(pl, pb + rb * 32 * LDH + 8 * g4, y4, amax);
+                        }
+                } else
                 {   // (c) shifted softplus -> planes (one base per plane, the rows of a lane at constant offsets from it)
                     TSD_UNIT_GEOM
                     f16* hb = pl.hi + opaque(4 * hi * LDH + col);
@@ -350,10 +404,32 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
                 UTRACE(2);
                 {   // (d) GEMM nn.2
                     hzero(am, ax);
-                    hgemm_ring_run<RB, 1, H>(rg, pl, LDH, am, ax);
+                    hgemm_ring_run<RB, 1, H, false, UTR>(rg, pl, LDH, am, ax);
                 }
                 __syncthreads();
                 UTRACE(3);
+                if constexpr (UTR) {   // (f) W = (nn.2 + b) * C as fp32 rows over the planes, transposed accumulators: the cutoff
+                    // weight of the lane's row is ONE value, four consecutive channels are one 16-byte store
+                    TSD_UNIT_GEOM
+                    float* wb = buf + opaque(l31 * LDA + col0 + 4 * hi);
+                    const float* bb = s_bias + H + opaque(col0 + 4 * hi);
+                    f32x4 bv[4];
+                    float cw[RB];
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) bv[g4] = *reinterpret_cast<const f32x4*>(bb + 8 * g4);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb) cw[rb] = s_c[t * UT + rb * 32 + l31];
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            f32x4 w4;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                w4[r] = (hval(am[rb][0], ax[rb][0], 4 * g4 + r) + bv[g4][r]) * cw[rb];
+                            *reinterpret_cast<f32x4*>(wb + rb * 32 * LDA + 8 * g4) = w4;
+                        }
+                } else
                 {   // (f) W = (nn.2 + b) * C as fp32 rows over the planes (the cutoff weights of four consecutive rows by one
                     // 16-byte LDS read, all of a row block's up front: stores to `buf` and loads of `s_c` would otherwise be
                     // kept in program order, one LDS round trip per element)
@@ -504,10 +580,26 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
         {
             TSD_UNIT_GEOM
             zero_n();
-            hgemm16_ring_run_rb<RB16, CB16, H>(rn, pl, LDH, am, ax, nrb);
+            hgemm16_ring_run_rb<RB16, CB16, H, UTR>(rn, pl, LDH, am, ax, nrb);
             hgemm16_ring_start<CB16, H>(rn, Wl + A.o_lin_w, H, col0);
         }
         __syncthreads();
+        if constexpr (UTR) {   // transposed accumulators: lane = row l15 of the 16-row block, channels 4 q .. 4 q + 3 of the column block
+            TSD_UNIT_GEOM
+#pragma unroll
+            for (int cb = 0; cb < CB16; ++cb) {
+                const int c = col0 + cb * 16 + q * 4;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(Wl + A.o_lin2_b + c);
+#pragma unroll
+                for (int rb = 0; rb < RB16; ++rb)
+                    if (rb < nrb) {
+                        f32x4 y4;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y4[r] = sspf(hval4(am[rb][cb], ax[rb][cb], r) + b[r]);
+                        planes_store4(pl, (rb * 16 + l15) * LDH + c, y4, amax);
+                    }
+            }
+        } else
         {
             TSD_UNIT_GEOM
 #pragma unroll
@@ -527,10 +619,32 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
         {
             TSD_UNIT_GEOM
             zero_n();
-            hgemm16_ring_run_rb<RB16, CB16, H>(rn, pl, LDH, am, ax, nrb);
+            hgemm16_ring_run_rb<RB16, CB16, H, UTR>(rn, pl, LDH, am, ax, nrb);
             if (!last) hgemm16_ring_start<CB16, H>(rn, Wl + A.layer_stride + A.o_lin1, H, col0);
         }
         __syncthreads();
+        if constexpr (UTR) {
+            TSD_UNIT_GEOM
+            const float* h_in = (l == 0 ? A.z + m * A.nh_stride : hm) + (size_t)n0 * H;
+#pragma unroll
+            for (int cb = 0; cb < CB16; ++cb) {
+                const int c = col0 + cb * 16 + q * 4;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(Wl + A.o_lin_b + c);
+#pragma unroll
+                for (int rb = 0; rb < RB16; ++rb)
+                    if (rb < nrb) {
+                        const int row = rb * 16 + l15;
+                        f32x4 hn = {0.f, 0.f, 0.f, 0.f};
+                        if (row < na) {
+                            const f32x4 hi4 = *reinterpret_cast<const f32x4*>(h_in + (size_t)row * H + c);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) hn[r] = hi4[r] + (hval4(am[rb][cb], ax[rb][cb], r) + b[r]);
+                            *reinterpret_cast<f32x4*>(hm + (size_t)(n0 + row) * H + c) = hn;
+                        }
+                        if (!last) planes_store4(pl, row * LDH + c, hn, amax);
+                    }
+            }
+        } else
         {
             TSD_UNIT_GEOM
             const float* h_in = (l == 0 ? A.z + m * A.nh_stride : hm) + (size_t)n0 * H;
@@ -563,9 +677,22 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
         {
             TSD_UNIT_GEOM
             zero_n();
-            hgemm16_ring_run_rb<RB16, CB16, H>(rn, pl, LDH, am, ax, nrb);
+            hgemm16_ring_run_rb<RB16, CB16, H, UTR>(rn, pl, LDH, am, ax, nrb);
             // x1 of the next block: straight into the LDS copy (every wave is past its reads of the old x1: the
             // barriers of the node chain lie between); row blocks without atoms keep their zeros
+            if constexpr (UTR) {
+#pragma unroll
+                for (int rb = 0; rb < RB16; ++rb)
+                    if (rb < nrb) {
+#pragma unroll
+                        for (int cb = 0; cb < CB16; ++cb) {
+                            f32x4 x4;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) x4[r] = hval4(am[rb][cb], ax[rb][cb], r);
+                            *reinterpret_cast<f32x4*>(x1s + (rb * 16 + l15) * H + col0 + cb * 16 + q * 4) = x4;
+                        }
+                    }
+            } else {
 #pragma unroll
             for (int rb = 0; rb < RB16; ++rb)
                 if (rb < nrb) {
@@ -575,6 +702,7 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
                         for (int r = 0; r < 4; ++r)
                             x1s[(rb * 16 + q * 4 + r) * H + col0 + cb * 16 + l15] = hval4(am[rb][cb], ax[rb][cb], r);
                 }
+            }
         }
         __syncthreads();
         UTRACE(6);
@@ -1103,7 +1231,7 @@ __global__ __launch_bounds__(TEAMS * 2 * H, TEAMS == 1 ? 4 : 2) void unit_encode
 size_t unit_encoder_pp_lds(int H, int teams) { return ((size_t)teams * UT * ldh_of(H) + U_ROWS) * 4 + (size_t)U_ROWS * 2; }
 
 size_t unit_encoder_lds(int H) {
-    return ((size_t)UNA * H + (size_t)UT * ldh_of(H) + U_ROWS) * 4 + (size_t)U_ROWS * 2 + 64 * 2;
+    return ((size_t)UNA * H + (size_t)UT * ldh_of(H) + U_ROWS) * 4 + (size_t)U_ROWS * 2 + 64 * 2 + (size_t)2 * H * 4 /* s_bias */;
 }
 
 bool unit_encoder_supported(const tsd_model_cfg& c) { return c.hidden == 256; }

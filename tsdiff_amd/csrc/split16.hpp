@@ -226,7 +226,17 @@ __device__ __forceinline__ void hgemm_ring_start(HRing<CB, R>& r, const float* _
 // previous step's counted wait.  Left free, the compiler hoists the LDS reads of the last k-steps over the whole unrolled
 // loop into registers of their own (+30 VGPRs in the tail of a GEMM: the backward filter chain then loses the second
 // workgroup of its CU).
-template <int RB, int CB, int K, bool PIN = false, int R>
+//
+// TRANS (round 5): the SAME products with the operand roles swapped -- the weight fragment as the MFMA's A operand, the LDS
+// tile fragment as B (both are 8 f16 per lane in the same layout, so the swap is free) -- which leaves the transposed
+// result in the accumulators: lane l holds tile ROW l & 31 and the 16 output CHANNELS 8 (r >> 2) + 4 (l >> 5) + (r & 3),
+// i.e. four runs of FOUR CONSECUTIVE channels of one row, where the plain form holds 16 rows of one channel.  Epilogues
+// then write f16x4 / f32x4 (8 / 4 LDS stores per lane and 32-row block instead of 32 / 16) and per-row factors (cutoff
+// weight) are per-lane constants; per-channel biases become 4 x 4 values per lane (from LDS).  Every output element is
+// the same chain of MFMA dot products (a . b = b . a exactly; the k order inside the MFMA does not depend on which
+// operand is called A), so the transposed and the plain form are bit-identical (tests/test_gpu_round4.py: the fused
+// encoder vs the materialising forms, torch.equal).
+template <int RB, int CB, int K, bool PIN = false, bool TRANS = false, int R>
 __device__ __forceinline__ void hgemm_ring_run(HRing<CB, R>& r, const Planes& A, int ldh, f32x16 (&accm)[RB][CB],
                                                f32x16 (&accx)[RB][CB]) {
     constexpr int KS = K / 16;
@@ -249,22 +259,30 @@ __device__ __forceinline__ void hgemm_ring_run(HRing<CB, R>& r, const Planes& A,
         for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
-                accx[rb][cb] = mfma_h32(ah[rb], r.b[slot][cb][1], accx[rb][cb]);
-                accm[rb][cb] = mfma_h32(ah[rb], r.b[slot][cb][0], accm[rb][cb]);
-                accx[rb][cb] = mfma_h32(al[rb], r.b[slot][cb][0], accx[rb][cb]);
+                if constexpr (TRANS) {
+                    accx[rb][cb] = mfma_h32(r.b[slot][cb][1], ah[rb], accx[rb][cb]);
+                    accm[rb][cb] = mfma_h32(r.b[slot][cb][0], ah[rb], accm[rb][cb]);
+                    accx[rb][cb] = mfma_h32(r.b[slot][cb][0], al[rb], accx[rb][cb]);
+                } else {
+                    accx[rb][cb] = mfma_h32(ah[rb], r.b[slot][cb][1], accx[rb][cb]);
+                    accm[rb][cb] = mfma_h32(ah[rb], r.b[slot][cb][0], accm[rb][cb]);
+                    accx[rb][cb] = mfma_h32(al[rb], r.b[slot][cb][0], accx[rb][cb]);
+                }
             }
         if constexpr (ks + R < KS)
             hring_issue<CB>(r.b[slot], r.base + (size_t)(ks + R) * r.step_bytes, r.voff, r.plane_bytes, r.cb_bytes);
         if constexpr (PIN) asm volatile("" : "+v"(accx[RB - 1][CB - 1]));  // (... and the step's MFMAs ahead of the next step's reads)
     });
 }
-template <int RB, int CB, int K, bool PIN = false, int R = HRING_R>
+template <int RB, int CB, int K, bool PIN = false, int R = HRING_R, bool TRANS = false>
 __device__ __forceinline__ void hgemm_tile(const Planes& A, int ldh, const float* __restrict__ Bp16, int nout, int col0,
                                            f32x16 (&accm)[RB][CB], f32x16 (&accx)[RB][CB]) {
     HRing<CB, R> r;
     hgemm_ring_start<CB, K>(r, Bp16, nout, col0);
-    hgemm_ring_run<RB, CB, K, PIN>(r, A, ldh, accm, accx);
+    hgemm_ring_run<RB, CB, K, PIN, TRANS>(r, A, ldh, accm, accx);
 }
+// TRANS accumulators: channel offset (inside the wave's 32-column slice) of accumulator registers 4 g .. 4 g + 3
+__device__ __forceinline__ int tacc_col(int g, int hi) { return 8 * g + 4 * hi; }
 template <int RB, int CB>
 __device__ __forceinline__ void hzero(f32x16 (&accm)[RB][CB], f32x16 (&accx)[RB][CB]) {
     zero_acc(accm);
@@ -289,7 +307,8 @@ __device__ __forceinline__ void hgemm16_ring_start(HRing<CB, HRING16_R>& r, cons
         hring_issue<CB>(r.b[I], r.base + (size_t)I * r.step_bytes, r.voff, r.plane_bytes, r.cb_bytes);
     });
 }
-template <int CB, int K>
+// TRANS: as hgemm_ring_run -- lane l then holds tile row l & 15 and the four consecutive channels 4 (l >> 4) + r
+template <int CB, int K, bool TRANS = false>
 __device__ __forceinline__ void hgemm16_ring_run(HRing<CB, HRING16_R>& r, const Planes& A, int ldh, f32x4 (&accm)[CB],
                                                  f32x4 (&accx)[CB]) {
     constexpr int R = HRING16_R, KS = K / 32;
@@ -304,9 +323,15 @@ __device__ __forceinline__ void hgemm16_ring_run(HRing<CB, HRING16_R>& r, const 
         hring_wait<younger * CB * 2, CB>(r.b[slot]);
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
-            accx[cb] = mfma_h16(ah, r.b[slot][cb][1], accx[cb]);
-            accm[cb] = mfma_h16(ah, r.b[slot][cb][0], accm[cb]);
-            accx[cb] = mfma_h16(al, r.b[slot][cb][0], accx[cb]);
+            if constexpr (TRANS) {
+                accx[cb] = mfma_h16(r.b[slot][cb][1], ah, accx[cb]);
+                accm[cb] = mfma_h16(r.b[slot][cb][0], ah, accm[cb]);
+                accx[cb] = mfma_h16(r.b[slot][cb][0], al, accx[cb]);
+            } else {
+                accx[cb] = mfma_h16(ah, r.b[slot][cb][1], accx[cb]);
+                accm[cb] = mfma_h16(ah, r.b[slot][cb][0], accm[cb]);
+                accx[cb] = mfma_h16(al, r.b[slot][cb][0], accx[cb]);
+            }
         }
         if constexpr (ks + R < KS)
             hring_issue<CB>(r.b[slot], r.base + (size_t)(ks + R) * r.step_bytes, r.voff, r.plane_bytes, r.cb_bytes);

@@ -899,8 +899,10 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
     const tsd_geometry& g = batch->geo;
     const int N = x.N, H = x.H, L = x.L, F = x.F, PU = x.PU, Eu = x.Eu, Eo = x.Eo, Ed = x.Ed;
     const Work& w = x.w;
-    if (N == 0) {
+    if (N == 0) {   // an empty shard: all-zero gradient; the blocks' range is final behind the fill (the caller's side-stream
+                    // all-reduce waits for this event: it must not run beside the memset)
         TSD_HIP(hipMemsetAsync(grad, 0, x.R.total * sizeof(float), st));
+        if (blocks_done_event != nullptr) TSD_HIP(hipEventRecord((hipEvent_t)blocks_done_event, st));
         return TSD_OK;
     }
     const size_t NH = (size_t)N * H, EH = (size_t)PU * H;  // strides of the per-block node / edge arrays

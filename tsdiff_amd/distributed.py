@@ -90,13 +90,19 @@ def dp_backward(model, loss_nodes, group=None, reduce_fn=None, always_reduce=Fal
     stats = torch.stack([total.detach(), loss_nodes.new_full((), float(loss_nodes.shape[0]))])
     if distributed:
         reduce(stats)
-    model._dp_early_reduce = reduce if distributed else None
+    # The early (side-stream, in-place) all-reduce of the interaction blocks' range is only correct when the backward's
+    # flat gradient buffer BECOMES the parameters' .grad (AccumulateGrad steals the views when .grad is None).  With a
+    # .grad already present -- zero_grad(set_to_none=False), micro-batch accumulation, a preset .grad -- AccumulateGrad
+    # runs `p.grad += view` on the main stream while the side stream reduces the same memory, and the gather-scatter
+    # branch below would reduce p.grad a second time: arm it only when every trainable parameter's .grad is None.
+    params = [p for p in model.parameters() if p.requires_grad]
+    arm = distributed and all(p.grad is None for p in params)
+    model._dp_early_reduce = reduce if arm else None
     try:
         (total / stats[1]).backward()
     finally:
         model._dp_early_reduce = None
     if distributed:
-        params = [p for p in model.parameters() if p.requires_grad]
         flat = getattr(model, "_flat_grad", None)
         if flat is not None and all(p.grad is not None and p.grad.untyped_storage().data_ptr() ==
                                     flat.untyped_storage().data_ptr() for p in params) and \
@@ -116,6 +122,16 @@ def dp_backward(model, loss_nodes, group=None, reduce_fn=None, always_reduce=Fal
                 reduce(flat)
                 model._last_reduce = "flat-in-place"
         else:
+            early = getattr(model, "_dp_early_done", None)
+            if early is not None:
+                # (cannot happen when the early reduce is armed as above; if a caller armed it by hand the reduced range
+                # must not be reduced again: fail loudly rather than double-count 83 % of the gradient)
+                torch.cuda.current_stream(early[0].device).wait_stream(early[0])
+                model._dp_early_done = None
+                raise RuntimeError("tsdiff_amd.dp_backward: the interaction blocks' gradients were all-reduced early, but "
+                                   "the parameters' .grad are not views of the step's flat gradient (a .grad existed "
+                                   "before backward?): the gradients of this step are inconsistent -- zero_grad(set_to_none="
+                                   "True) before get_loss, or do not set model._dp_early_reduce by hand")
             for p in params:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)

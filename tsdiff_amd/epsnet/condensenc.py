@@ -125,26 +125,64 @@ class CondenseEncoderEpsNetwork(nn.Module):
     def parameters(self, recurse=True):
         """nn.Module.parameters, from a cached list: the reference's loop calls `clip_grad_norm_(model.parameters(), …)`
         every step (train.py:144) and the generic generator walks the module tree for it (~0.25 ms of a 2 ms step whose
-        length is its host side).  The module tree of this class is fixed after __init__; nn.Module._apply and
-        load_state_dict keep the Parameter objects."""
+        length is its host side).  The cache is VALIDATED on every use (each cached Parameter must still be the object
+        registered under its name in its module's `_parameters` dict: ~80 dictionary look-ups) and dropped by `_apply`,
+        `load_state_dict`, `register_parameter` / `register_module` and attribute assignment of a Parameter or Module on
+        this object -- load_state_dict(assign=True), parametrizations, torch.__future__'s overwrite-on-conversion and module
+        surgery replace Parameter objects, and an optimizer iterating a stale list would silently train nothing."""
         if not recurse:
             return super().parameters(recurse=False)
-        lst = self.__dict__.get("_param_list_cache")
-        if lst is None:
-            lst = list(super().parameters(recurse=True))
-            self.__dict__["_param_list_cache"] = lst
-        return iter(lst)
+        return iter(self._cached_params()[0])
+
+    def _cached_params(self):
+        c = self.__dict__.get("_param_cache")
+        if c is not None and all(d.get(k) is p for (d, k), p in zip(c[2], c[0])):
+            return c
+        refs, lst = [], []
+        seen = set()
+        for mod in self.modules():
+            for k, p in mod._parameters.items():
+                if p is not None and id(p) not in seen:  # (named_parameters' de-duplication: the alias ModuleLists)
+                    seen.add(id(p))
+                    refs.append((mod._parameters, k))
+                    lst.append(p)
+        P = dict(self.named_parameters())
+        raw = [P[n] for n in engine.raw_param_names(self._cfg.num_convs)]
+        assert [id(p) for p in lst] == [id(p) for p in super().parameters(recurse=True)]
+        c = (lst, raw, refs)
+        self.__dict__["_param_cache"] = c
+        return c
+
+    def _drop_param_cache(self):
+        self.__dict__.pop("_param_cache", None)
+
+    def _apply(self, fn, *a, **kw):
+        self._drop_param_cache()
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self._drop_param_cache()
+        r = super().load_state_dict(*a, **kw)
+        self._drop_param_cache()
+        return r
+
+    def register_parameter(self, name, param):
+        self._drop_param_cache()
+        return super().register_parameter(name, param)
+
+    def register_module(self, name, module):
+        self._drop_param_cache()
+        return super().register_module(name, module)
+
+    def __setattr__(self, name, value):
+        if isinstance(value, (nn.Parameter, nn.Module)):
+            self._drop_param_cache()
+        super().__setattr__(name, value)
 
     def raw_params(self):
-        """the trainable tensors in the order of the flat parameter vector (engine.raw_param_names); cached: walking
-        the module tree costs ~0.4 ms, once per training step otherwise.  nn.Module._apply (.to / .cuda / .float)
-        keeps the Parameter objects, so the list stays valid."""
-        lst = getattr(self, "_raw_param_list", None)
-        if lst is None:
-            P = dict(self.named_parameters())
-            lst = [P[n] for n in engine.raw_param_names(self._cfg.num_convs)]
-            self._raw_param_list = lst
-        return lst
+        """the trainable tensors in the order of the flat parameter vector (engine.raw_param_names); cached with
+        `parameters()` (same validation): walking the module tree costs ~0.4 ms, once per training step otherwise."""
+        return self._cached_params()[1]
 
     def packed_weights(self):
         """MFMA-packed fp32 arena in HBM, rebuilt when any parameter changed (version counters)."""

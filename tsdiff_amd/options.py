@@ -16,6 +16,7 @@ at import, by `TSDIFF_*` environment variables (read here and nowhere else); tes
 | pingpong           | TSDIFF_PINGPONG           | False   | form of the fused encoder on units that are single graphs of > 32 atoms: False = eight waves own a CU and walk one tile's phases together (unit_encoder_kernel); "solo" = block tiles with x1 / agg in memory at 128 VGPRs / 80 KB: two units per CU, interleaved by the hardware; "teams" = the same in lock step, two teams of eight waves in one workgroup, one on the matrix pipes while the other runs its VALU / LDS steps (unit_encoder_pp_kernel).  Bit-identical; measurements in DESIGN.md 4c |
 | train              | TSDIFF_TRAIN              | "fused" | training step: "fused" = forward + loss and the whole backward as two library calls (csrc/train_step.hip), "ops" = one autograd node per operation (same kernels; the cross-check) |
 | train_gemm         | TSDIFF_TRAIN_GEMM         | "h2"    | arithmetic of the fused training step's tile GEMMs: "f32" = fp32-input MFMA, "h2" = split-f16 operands (gradient operands scaled by a power of two per tensor).  A step whose activations leave the f16 range is recomputed in "f32" |
+| train_fallback_latch | TSDIFF_TRAIN_FALLBACK_LATCH | 16 | split-f16 training step: a step whose activations leave the f16 range is recomputed in fp32 and the NEXT step tries split-f16 again (`model._h2_range_trips` counts the trips); this many trips IN A ROW latch the model to fp32 (each trip costs a second forward) |
 | train_side_lane    | TSDIFF_TRAIN_SIDE_LANE    | True    | split-f16 training step: the backward's small latency-bound gradient launches (embedding tables, narrow layers) run on a stream of the library's own beside the batched weight gradients; False: everything on the caller's stream.  Bit-identical |
 """
 import os
@@ -38,6 +39,7 @@ class Options:
     pingpong: object = False
     train: str = "fused"
     train_gemm: str = "h2"
+    train_fallback_latch: int = 16
     train_side_lane: bool = True
 
     @classmethod
@@ -48,6 +50,7 @@ class Options:
                 pingpong={"0": False, "solo": "solo", "teams": "teams", "1": "teams"}.get(
                     os.environ.get("TSDIFF_PINGPONG", "0"), False),
                 train=os.environ.get("TSDIFF_TRAIN", "fused"), train_gemm=os.environ.get("TSDIFF_TRAIN_GEMM", "h2"),
+                train_fallback_latch=int(os.environ.get("TSDIFF_TRAIN_FALLBACK_LATCH", "16")),
                 train_side_lane=_flag("TSDIFF_TRAIN_SIDE_LANE"))
         o.validate()
         return o
@@ -57,6 +60,8 @@ class Options:
             raise ValueError(f"TSDIFF_GEMM={self.gemm!r}: expected 'h2' or 'f32'")
         if self.train_gemm not in ("h2", "f32"):
             raise ValueError(f"TSDIFF_TRAIN_GEMM={self.train_gemm!r}: expected 'h2' or 'f32'")
+        if self.train_fallback_latch < 1:
+            raise ValueError(f"TSDIFF_TRAIN_FALLBACK_LATCH={self.train_fallback_latch!r}: expected an integer >= 1")
         if self.train not in ("fused", "ops"):
             raise ValueError(f"TSDIFF_TRAIN={self.train!r}: expected 'fused' or 'ops'")
 

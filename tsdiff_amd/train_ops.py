@@ -581,18 +581,31 @@ class FusedTrainLoss(torch.autograd.Function):
         if code == _lib.TSD_ERR_RANGE:
             # an activation of the split-f16 forward left the f16 range (the library read the flag behind the forward's
             # last kernel and launched nothing): the forward is recomputed on the fp32-input MFMA kernels INTO THE SAME loss
-            # tensor (scalars the caller derived from it before backward() are stale for this one step), the backward runs
-            # in fp32, and the model trains in fp32 from here on
+            # tensor (scalars the caller derived from it before backward() are stale for this one step; the tensor itself
+            # now holds the fp32 step's values) and the backward runs in fp32.  The fallback is PER STEP: the next
+            # get_loss tries the split-f16 kernels again (one tiny aggregate at the cutoff edge must not change the
+            # arithmetic of a whole training run); `model._h2_range_trips` counts the trips, and only
+            # OPTIONS.train_fallback_latch CONSECUTIVE ones (a checkpoint whose activations really live beyond 65504)
+            # latch the model to fp32, because every trip costs a second forward.
             import warnings
+            m = ctx.model
+            m._h2_range_trips = getattr(m, "_h2_range_trips", 0) + 1
+            m._h2_range_run = getattr(m, "_h2_range_run", 0) + 1
+            latch = m._h2_range_run >= OPTIONS.train_fallback_latch
             warnings.warn("tsdiff_amd: an activation left the range the split-f16 training arithmetic covers; this step was "
-                          "recomputed and the model now trains on the fp32-input MFMA kernels", RuntimeWarning, stacklevel=2)
+                          "recomputed on the fp32-input MFMA kernels (trip %d%s)" % (
+                              m._h2_range_trips, "; %d in a row: the model now trains in fp32" % m._h2_range_run if latch else ""),
+                          RuntimeWarning, stacklevel=2)
+            if latch:
+                m._train_f32 = True
             db.status[:1].zero_()
-            ctx.model._train_f32 = True
             pos0, a_graph = ctx.fwd_in
             check(lib.tsd_train_forward(C.byref(cfg), C.byref(db.train_struct(False)), ptr(ctx.raw), ptr(db.atom_type),
                                         ptr(db.r_feat), ptr(db.p_feat), ptr(pos0), ptr(ctx.pos), ptr(a_graph), None,
                                         ptr(ctx.ws), ctx.ws.numel(), ptr(ctx.loss), ctx.counts, stream_ptr()))
             code = run(False)
+        elif ctx.h2:
+            ctx.model._h2_range_run = 0
         check(code)
         ctx.model._dp_early_done = None
         if early is not None:
