@@ -338,13 +338,8 @@ typedef struct tsd_batch {
                                                knowledge: graphs never interact, so any such partition is valid; the Python
                                                host balances it by pair count).  NULL: no fused encoder */
     int32_t num_units;
-    int32_t reserved2;                      /* bits 0-1: form of the fused encoder for batches whose EVERY unit is ONE graph (host
-                                               knowledge; true whenever every graph has more than TSD_UNIT_MAX_NODES / 2 atoms;
-                                               a unit that breaks the promise reports TSD_STATUS_INTERNAL).  0: the general
-                                               kernel (one workgroup owns a CU); 1: 8 x 8 atom-block tiles with x1 / agg of the
-                                               unit in memory, 128 VGPRs and 80 KB of LDS per workgroup: TWO units per CU;
-                                               2: the same in lock step, two teams of eight waves per workgroup (ping-pong).
-                                               All forms give the same bits */
+    int32_t reserved2;                      /* 0 (0.5 selected experimental two-team forms of the fused encoder here; they were
+                                               removed in 0.6: measured equal to the general kernel) */
 } tsd_batch;
 
 size_t tsd_forward_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs,

@@ -211,9 +211,9 @@ def test_options_object(monkeypatch):
     assert (o.gemm, o.train, o.train_gemm, o.train_side_lane, o.one_launch, o.fused_encoder) == ("h2", "fused", "h2", True, True, True)
     monkeypatch.setenv("TSDIFF_TRAIN_GEMM", "f32")
     monkeypatch.setenv("TSDIFF_TRAIN_SIDE_LANE", "0")
-    monkeypatch.setenv("TSDIFF_PINGPONG", "solo")
+    monkeypatch.setenv("TSDIFF_TRAIN_FALLBACK_LATCH", "4")
     e = options.Options.from_env()
-    assert e.train_gemm == "f32" and e.train_side_lane is False and e.pingpong == "solo" and e.gemm == "h2"
+    assert e.train_gemm == "f32" and e.train_side_lane is False and e.train_fallback_latch == 4 and e.gemm == "h2"
     monkeypatch.setenv("TSDIFF_TRAIN_GEMM", "bf16")
     with pytest.raises(ValueError):
         options.Options.from_env()

@@ -129,7 +129,6 @@ def _forms(monkeypatch):
         monkeypatch.setattr(engine.OPTIONS, "gemm", "h2")
         monkeypatch.setattr(engine.OPTIONS, "one_launch", form == "one_launch")
         monkeypatch.setattr(engine.OPTIONS, "fused_encoder", "force" if form.startswith("fused") else False)
-        monkeypatch.setattr(engine.OPTIONS, "pingpong", {"fused_pp": "teams", "fused_solo": "solo"}.get(form, False))
     return set_form
 
 
@@ -205,7 +204,7 @@ def test_fused_encoder_config_c5_shape_and_partial_runs(dev, monkeypatch):
                                t["p_feat"], t["pos"], t["bond_index"], t["bond_type"], b["num_nodes_per_graph"])
     set_form = _forms(monkeypatch)
     res = {}
-    for form in ("per_block", "fused", "fused_pp", "fused_solo"):   # (every unit is one 64-atom graph: all three forms apply)
+    for form in ("per_block", "fused"):
         set_form(form)
         model = make_model(cfg, 1, dev)
         inv, ei, _ = run_forward(model, g, dev)
@@ -214,7 +213,6 @@ def test_fused_encoder_config_c5_shape_and_partial_runs(dev, monkeypatch):
         res[form] = inv.clone()
         assert _db(model).units_single_graph
     assert torch.equal(res["fused"], res["per_block"])
-    assert torch.equal(res["fused_pp"], res["per_block"]) and torch.equal(res["fused_solo"], res["per_block"])
     # the encoder alone, whole and in two parts, on the state the forward left in the workspace
     lib = _lib.load()
     db = _db(model)
@@ -235,7 +233,7 @@ def test_fused_encoder_config_c5_shape_and_partial_runs(dev, monkeypatch):
 
 @pytest.mark.parametrize("n,graphs,cut", [(37, 5, 10.0), (50, 3, 10.0), (64, 2, 4.0), (33, 4, 3.0)])
 def test_fused_encoder_block_tiles_on_ragged_and_sparse_graphs(n, graphs, cut, dev, monkeypatch):
-    """the 8 x 8 atom-block tiles of the fused encoder (both forms) on graphs whose atom count is no multiple of 8 and,
+    """the 8 x 8 atom-block tiles of the fused encoder on graphs whose atom count is no multiple of 8 and,
     with a short radius cutoff, on graphs where most atom pairs are NOT edges (zero rows inside the tiles): bit-identical
     to the launch-per-block form, and against the oracle"""
     from oracle import tsdiff_oracle as O
@@ -250,7 +248,7 @@ def test_fused_encoder_block_tiles_on_ragged_and_sparse_graphs(n, graphs, cut, d
                                t["p_feat"], t["pos"], t["bond_index"], t["bond_type"], b["num_nodes_per_graph"])
     set_form = _forms(monkeypatch)
     res = {}
-    for form in ("per_block", "fused", "fused_pp", "fused_solo"):
+    for form in ("per_block", "fused"):
         set_form(form)
         model = make_model(cfg, 2, dev)
         inv, ei, _ = run_forward(model, g, dev)
@@ -259,8 +257,7 @@ def test_fused_encoder_block_tiles_on_ragged_and_sparse_graphs(n, graphs, cut, d
         res[form] = inv.clone()
     if cut < 10.0:
         assert ei.shape[1] < graphs * n * (n - 1), "the short cutoff was meant to drop pairs"
-    for form in ("fused", "fused_pp", "fused_solo"):
-        assert torch.equal(res[form], res["per_block"]), form
+    assert torch.equal(res["fused"], res["per_block"])
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -29,10 +29,6 @@ def child(workload, steps, lib, flags):
         engine.OPTIONS.gemm = "f32"  # fp32-input MFMA instead of the split-f16 forward
     if "fused0" in flags:
         engine.OPTIONS.fused_encoder = False  # materialised filters (one launch per block) where the fused encoder applies
-    if "pp1" in flags:
-        engine.OPTIONS.pingpong = "teams"  # the fused encoder in its ping-pong form (two teams of eight waves)
-    if "solo" in flags:
-        engine.OPTIONS.pingpong = "solo"  # ... as two independent 128-VGPR workgroups per CU
     if "fused1" in flags:
         engine.OPTIONS.fused_encoder = "force"  # the fused per-unit encoder also where the one-launch form applies
     from bench import SamplingRun, make_models, to_dev

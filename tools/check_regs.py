@@ -28,9 +28,6 @@ BUDGET = [
     (r"edge_embed_save_h_kernelILi256E", 128, 0),
     (r"unit_encoder_kernelILi256E", 256, 0),
     (r"wgrad_h2_batch_kernel", 256, 0),  # four waves per workgroup, two workgroups per CU
-    # sixteen waves per workgroup: 128 registers; a few loop-invariant values of the per-block prologue may sit in scratch
-    # (six scratch instructions per block, none inside the tile cycle)
-    (r"unit_encoder_pp_kernelILi256E", 128, 64),
 ]
 
 

@@ -3,10 +3,14 @@
     frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x average launch duration x 2.4 GHz)
 python tools/mfma_busy.py label=x_results.db ... > profiles/rNN_mfma_busy.json   (bench.py reads it)"""
 import json
+import os
 import sqlite3
 import sys
 
-out = {}
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_summary import stamp
+
+out = dict(stamp())
 for arg in sys.argv[1:]:
     label, db = arg.split("=", 1)
     try:

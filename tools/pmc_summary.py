@@ -11,8 +11,24 @@ exactly HALF of the bytes of a wide coalesced read, so the read side is doubled 
 Infinity-Cache hits are counted, so this is memory-side traffic, an upper bound on DRAM traffic.
 """
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def stamp():
+    """what the counters describe: hash of the kernel sources (bench.py refuses a file whose stamp is not the tree's) and
+    the commit they were taken at (.git_head, written by the caller before `gpurun`: the GPU box has no .git)"""
+    from bench import ROOT, kernel_source_sha
+    head = os.environ.get("TSDIFF_HEAD")
+    if not head:
+        try:
+            head = open(os.path.join(ROOT, ".git_head")).read().strip()
+        except OSError:
+            head = "unknown"
+    return {"kernel_source_sha": kernel_source_sha(), "head": head}
 
 
 def per_kernel(db, counter):
@@ -44,7 +60,7 @@ def main(fetch_db, write_db, out_prefix):
             "hbm_bytes_per_launch": fe["avg"] * 2048.0 + wr["avg"] * 1024.0,
         }
     with open(out_prefix + ".json", "w") as fh:
-        json.dump({"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of "
+        json.dump({**stamp(), "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of "
                              "`python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline`",
                    "correction": "FETCH_SIZE x2 (gfx950 wide-read under-count), KiB units", "kernels": out}, fh, indent=1)
     with open(out_prefix + ".md", "w") as fh:

@@ -290,10 +290,7 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     }
     if (fused) {
         // embedding launch (attribute rows) -> the whole encoder as one launch -> pair MLP launch
-        // (tsd_batch.reserved2 bit 0: every unit is ONE graph -- the ping-pong form of the kernel, whose x1 / agg rows live
-        // in the two x1 buffers of the workspace)
-        if ((r = launch_unit_encoder(c, b, W, w.ea, w.stride_ea, w.h, w.stride_nh, 0, L, w.x1, w.x1b, (b.reserved2 & 3),
-                                     prec.range_status, st)))
+        if ((r = launch_unit_encoder(c, b, W, w.ea, w.stride_ea, w.h, w.stride_nh, 0, L, w.x1, prec.range_status, st)))
             return r;
         return launch_pair_output(c, W, PU, g.out_u, w.h, w.ea, g.attr_row, b.edge_inv_u, M, w.stride_nh, w.stride_ea,
                                   (size_t)PU, st, nullptr, w.stride_pre, nullptr, kFold, prec);
@@ -737,8 +734,8 @@ int tsd_forward_encoder(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_
     TSD_REQUIRE(l_begin >= 0 && l_begin < l_end && l_end <= cfg->num_convs, "blocks [%d, %d) outside [0, %d)", l_begin,
                 l_end, cfg->num_convs);
     const Workspace w = carve(*cfg, b.num_nodes, b.num_pairs, b.num_models, b.workspace);
-    return launch_unit_encoder(*cfg, b, b.weights16, w.ea, w.stride_ea, w.h, w.stride_nh, l_begin, l_end, w.x1, w.x1b,
-                               (b.reserved2 & 3), b.status, (hipStream_t)stream);
+    return launch_unit_encoder(*cfg, b, b.weights16, w.ea, w.stride_ea, w.h, w.stride_nh, l_begin, l_end, w.x1, b.status,
+                               (hipStream_t)stream);
 }
 
 int tsd_ensemble_mean(int32_t num_models, int32_t num_pairs, tsd_edges out, const float* edge_inv_u,

@@ -279,8 +279,7 @@ int mega_slots(int H);  // resident workgroup slots of the one-launch kernel on 
 // the whole SchNet encoder as one launch of per-unit workgroups, filters never materialised (kernels_unit.hip)
 bool unit_encoder_supported(const tsd_model_cfg& c);
 int launch_unit_encoder(const tsd_model_cfg& c, const tsd_batch& b, const float* W16, const float* ea, size_t ea_stride,
-                        float* h, size_t nh_stride, int l_begin, int l_end, float* x1_io, float* agg_io, int pingpong,
-                        int32_t* status, hipStream_t st);
+                        float* h, size_t nh_stride, int l_begin, int l_end, float* x1_io, int32_t* status, hipStream_t st);
 int launch_bucket_weights16(const tsd_model_cfg& c, const float* bucket, int num_slots, float* out16, hipStream_t st);
 
 inline bool hidden_supported(int H) { return H == 64 || H == 128 || H == 256; }

@@ -839,11 +839,27 @@ __device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float*
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     float amax = 0.0f;
     HRing<CB16, HRING16_R> rg;
+    // transposed accumulators (split16.hpp hgemm16_ring_run<..., TRANS>; inference tiles): lane = tile row l15, the four
+    // consecutive channels 4 q .. 4 q + 3 of each 16-column block: 8-byte plane stores, 16-byte h / x1 accesses.  The two
+    // bias vectors go through LDS (behind the planes), written by the first H threads behind the gather.
+    constexpr bool TR = !SAVE && TSD_FILTER_TRANS != 0;
+    float* s_bias = smem + TN * LDH;  // [2][H] (TR)
 
     float b_lin2[CB16], b_lin[CB16], h_res[CB16][4];
+    f32x4 h4[CB16];  // (TR: the residual rows as 16-byte loads)
+    float bl2 = 0.0f, bl = 0.0f;
     TSD_TRACE_ID(1);
     TSD_TRACE_AT(0);
     if (a.mode == 0) {
+        if constexpr (TR) {
+            if (tid < H) {
+                bl2 = a.lin2_b[tid];
+                bl = a.lin_b[tid];
+            }
+#pragma unroll
+            for (int cb = 0; cb < CB16; ++cb)
+                h4[cb] = l15 < nrows ? *reinterpret_cast<const f32x4*>(a.h_in + (size_t)(n0 + l15) * H + col0 + cb * 16 + q * 4) : zero4;
+        } else {
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
             const int col = col0 + cb * 16 + l15;
@@ -855,19 +871,37 @@ __device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float*
                 h_res[cb][r] = row < nrows ? a.h_in[(size_t)(n0 + row) * H + col] : 0.0f;
             }
         }
+        }
         aggregate_tile<H, SAVE, 2 * H / 64, 8, true>(a.row_ptr, a.dst, a.umap, a.Wf, a.x1_in, a.N, n0, smem,
                                                       SAVE ? ns.agg : nullptr, &amax);
+        if constexpr (TR) {
+            if (tid < H) {
+                s_bias[tid] = bl2;
+                s_bias[H + tid] = bl;
+            }
+        }
         hgemm16_ring_start<CB16, H>(rg, a.lin2_w, H, col0);  // (after the gather: its registers are the gather's)
         TSD_TRACE_WAVE(16);
         __syncthreads();
         TSD_TRACE_AT(1);
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) accm[cb] = accx[cb] = zero4;
-        hgemm16_ring_run<CB16, H>(rg, pl, LDH, accm, accx);
+        hgemm16_ring_run<CB16, H, TR>(rg, pl, LDH, accm, accx);
         hgemm16_ring_start<CB16, H>(rg, a.lin_w, H, col0);
         TSD_TRACE_WAVE(8);
         TSD_TRACE_AT(2);
         __syncthreads();
+        if constexpr (TR) {
+#pragma unroll
+            for (int cb = 0; cb < CB16; ++cb) {
+                const int c = col0 + cb * 16 + q * 4;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(s_bias + c);
+                f32x4 y4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y4[r] = sspf(hval4(accm[cb], accx[cb], r) + b[r]);
+                planes_store4(pl, l15 * LDH + c, y4, amax);
+            }
+        } else
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
             const int col = col0 + cb * 16 + l15;
@@ -888,10 +922,28 @@ __device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float*
         TSD_TRACE_AT(3);
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) accm[cb] = accx[cb] = zero4;
-        hgemm16_ring_run<CB16, H>(rg, pl, LDH, accm, accx);
+        hgemm16_ring_run<CB16, H, TR>(rg, pl, LDH, accm, accx);
         if (a.lin1_next_w != nullptr) hgemm16_ring_start<CB16, H>(rg, a.lin1_next_w, H, col0);
         TSD_TRACE_AT(4);
         __syncthreads();
+        if constexpr (TR) {
+#pragma unroll
+            for (int cb = 0; cb < CB16; ++cb) {
+                const int c = col0 + cb * 16 + q * 4;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(s_bias + H + c);
+                f32x4 hn = zero4;
+                if (l15 < nrows) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hn[r] = h4[cb][r] + (hval4(accm[cb], accx[cb], r) + b[r]);
+                    float* hp = a.h + (size_t)(n0 + l15) * H + c;
+                    if (a.ready)  // write-through (sc1): the pair tiles of this launch read the row from other CUs
+                        store_stream16(hp, hn);
+                    else
+                        *reinterpret_cast<f32x4*>(hp) = hn;
+                }
+                planes_store4(pl, l15 * LDH + c, hn, amax);
+            }
+        } else
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
             const int col = col0 + cb * 16 + l15;
@@ -935,8 +987,19 @@ __device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float*
     TSD_TRACE_AT(5);
 #pragma unroll
     for (int cb = 0; cb < CB16; ++cb) accm[cb] = accx[cb] = zero4;
-    hgemm16_ring_run<CB16, H>(rg, pl, LDH, accm, accx);
+    hgemm16_ring_run<CB16, H, TR>(rg, pl, LDH, accm, accx);
     TSD_TRACE_AT(6);
+    if constexpr (TR) {
+        if (l15 < nrows) {
+#pragma unroll
+            for (int cb = 0; cb < CB16; ++cb) {
+                f32x4 x4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x4[r] = hval4(accm[cb], accx[cb], r);
+                *reinterpret_cast<f32x4*>(a.x1_out + (size_t)(n0 + l15) * H + col0 + cb * 16 + q * 4) = x4;
+            }
+        }
+    } else
 #pragma unroll
     for (int cb = 0; cb < CB16; ++cb) {
         const int col = col0 + cb * 16 + l15;
@@ -970,7 +1033,10 @@ __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, fl
     // consecutive channels of ONE tile row -- 8-byte plane stores, 16-byte filter-tile stores, one cutoff weight per lane;
     // the 16 channels' biases come from LDS.  The saving form keeps the plain layout (its side stores are row-contiguous
     // per wave that way).  Bit-identical either way.
-    constexpr bool TR = !SAVE && TSD_FILTER_TRANS != 0;
+#ifndef TSD_FROLE_TRANS
+#define TSD_FROLE_TRANS TSD_FILTER_TRANS
+#endif
+    constexpr bool TR = !SAVE && TSD_FROLE_TRANS != 0;
     float* s_bias = s_c + TT;      // [2][H] nn.0 / nn.2 biases (TR)
 
     const int E = *f.e.count;
@@ -1122,7 +1188,17 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
     const int col0 = wave * 32, col = col0 + l31;
     const int nrows = min(T, E - e0);
     float amax = 0.0f;
-    constexpr bool TR = !SAVE && TSD_FILTER_TRANS != 0;  // transposed accumulators (see filter_role_h): lane = tile row l31
+#ifndef TSD_PAIR_TRANS
+#define TSD_PAIR_TRANS TSD_FILTER_TRANS
+#endif
+    constexpr bool TR = !SAVE && TSD_PAIR_TRANS != 0;  // transposed accumulators (see filter_role_h): lane = tile row l31
+#ifndef TSD_PAIR_TR3
+#define TSD_PAIR_TR3 1
+#endif
+#ifndef TSD_PAIR_TR12
+#define TSD_PAIR_TR12 1
+#endif
+    constexpr bool TR3 = TR && TSD_PAIR_TR3 != 0, TR12 = TR && TSD_PAIR_TR12 != 0;
     if (tid < T) {
         const int ee = e0 + min(tid, nrows - 1);
         s_src[tid] = q.e.src[ee];
@@ -1160,8 +1236,8 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
         hgemm_ring_start<1, H>(rg, q.w0b, H, col0);  // (behind the staging: its registers are free now)
         __syncthreads();
         hzero(accm, accx);
-        hgemm_ring_run<1, 1, H, false, TR>(rg, pl, LDH, accm, accx);
-        if constexpr (TR) {
+        hgemm_ring_run<1, 1, H, false, TR12>(rg, pl, LDH, accm, accx);
+        if constexpr (TR12) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(q.b0 + col0 + 8 * g4 + 4 * hi);
@@ -1240,9 +1316,9 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
     hgemm_ring_start<1, H>(rg, q.w0a, H, col0);  // (behind the staging: its registers are free now)
     __syncthreads();
     hzero(accm, accx);
-    hgemm_ring_run<1, 1, H, false, TR>(rg, pl, LDH, accm, accx);
+    hgemm_ring_run<1, 1, H, false, TR12>(rg, pl, LDH, accm, accx);
     __syncthreads();
-    if constexpr (TR) {
+    if constexpr (TR12) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             f32x4 s4;
@@ -1267,8 +1343,8 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
     if (wave < NW) {  // H -> H/2 and the final dot: the first H/64 waves
         const int c2 = wave * 32 + l31;
         hzero(accm, accx);
-        hgemm_tile<1, 1, H, false, HRING_R, TR>(pl, LDH, q.w1, H / 2, wave * 32, accm, accx);
-        if constexpr (TR) {   // the lane's 16 channels of row l31 summed in register order, then the other half-wave's 16
+        hgemm_tile<1, 1, H, false, HRING_R, TR3>(pl, LDH, q.w1, H / 2, wave * 32, accm, accx);
+        if constexpr (TR3) {   // the lane's 16 channels of row l31 summed in register order, then the other half-wave's 16
             float v = 0.0f;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
@@ -1947,7 +2023,7 @@ int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity,
 
 static inline size_t lds_combo(int H, int prec, int frb = 1) {
     const int ld = prec == PREC_H2 ? ldh_of(H) : H + 4;  // floats per tile row (two f16 planes of H + 8 = H + 8 floats)
-    const size_t node = (size_t)TN * ld * 4;
+    const size_t node = (size_t)TN * ld * 4 + (prec == PREC_H2 ? (size_t)2 * H * 4 : 0);  // (+ the transposed form's biases)
     const size_t filt = (size_t)(T * ld + T) * 4 * frb + (prec == PREC_H2 ? (size_t)2 * H * 4 : 0);  // (+ the transposed form's biases)
     const size_t pair = (size_t)(T * ld + (H / 64) * T + 3 * T) * 4;  // pair role (H >= 64)
     return node > filt ? (node > pair ? node : pair) : (filt > pair ? filt : pair);
@@ -2125,6 +2201,17 @@ __device__ __forceinline__ void node_persist_h(const MegaArgs& A, int tile, int 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     float amax = 0.0f;
     int32_t* node_done = A.ctl + MegaCtl::NODE0;
+    // transposed accumulators (as node_role_h): lane = tile row l15, channels 4 q .. 4 q + 3 per 16-column block; the
+    // block's two bias vectors in LDS behind the planes and the x copy, x1 published straight from the registers
+#ifndef TSD_MEGA_NODE_TRANS
+#define TSD_MEGA_NODE_TRANS 1
+#endif
+#ifndef TSD_MEGA_DIRECT_X1
+#define TSD_MEGA_DIRECT_X1 1
+#endif
+    constexpr bool TRN = TSD_FILTER_TRANS != 0 && TSD_MEGA_NODE_TRANS != 0;
+    constexpr int XS_F = (H == 256 && TR == TN && TSD_MEGA_XLDS) ? XS_ROWS * 256 : 0;
+    float* s_bias = smem + TN * LDH + XS_F;  // [2][H]
     // the node tiles that hold atoms of the graphs this tile's atoms belong to
     const int g_first = A.node_graph[n0], g_last = A.node_graph[n0 + nrows - 1];
     // the atoms of those graphs (workgroup-uniform values the compiler would keep in vector registers)
@@ -2134,12 +2221,19 @@ __device__ __forceinline__ void node_persist_h(const MegaArgs& A, int tile, int 
     // residual input of block 0: the pos-independent node embedding z
     float h_res[CB16][4];
 #pragma unroll
-    for (int cb = 0; cb < CB16; ++cb)
+    for (int cb = 0; cb < CB16; ++cb) {
+        if constexpr (TRN) {
+            const f32x4 z4 = l15 < nrows ? *reinterpret_cast<const f32x4*>(A.z + (size_t)(n0 + l15) * H + col0 + cb * 16 + q * 4) : zero4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h_res[cb][r] = z4[r];
+        } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = q * 4 + r;
             h_res[cb][r] = row < nrows ? A.z[(size_t)(n0 + row) * H + col0 + cb * 16 + l15] : 0.0f;
         }
+        }
+    }
     // the filter tiles this tile's edges read rows of (geometry only: the same range in every block)
     int f_lo = 0x7fffffff, f_hi = -1;
     if (wave == 0) {
@@ -2212,19 +2306,44 @@ __device__ __forceinline__ void node_persist_h(const MegaArgs& A, int tile, int 
         }
         TSD_MEGA_P(tile, l, 2);
         float b_lin2[CB16], b_lin[CB16];  // (requested behind the gather: they arrive under the first GEMM)
+        float bl2 = 0.0f, bl = 0.0f;      // (TRN: one channel's two biases per thread, to LDS behind the first GEMM)
+        if constexpr (TRN) {
+            if (tid < H) {
+                bl2 = Wl[A.o_lin2_b + tid];
+                bl = Wl[A.o_lin_b + tid];
+            }
+        } else {
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
             b_lin2[cb] = Wl[A.o_lin2_b + col0 + cb * 16 + l15];
             b_lin[cb] = Wl[A.o_lin_b + col0 + cb * 16 + l15];
         }
+        }
         hgemm16_ring_start<CB16, H>(rg, Wl + A.o_lin2_w, H, col0);
         __syncthreads();
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) accm[cb] = accx[cb] = zero4;
-        hgemm16_ring_run<CB16, H>(rg, pl, LDH, accm, accx);
+        hgemm16_ring_run<CB16, H, TRN>(rg, pl, LDH, accm, accx);
+        if constexpr (TRN) {
+            if (tid < H) {  // (the previous block's readers are two barriers back)
+                s_bias[tid] = bl2;
+                s_bias[H + tid] = bl;
+            }
+        }
         hgemm16_ring_start<CB16, H>(rg, Wl + A.o_lin_w, H, col0);
         __syncthreads();
         TSD_MEGA_P(tile, l, 3);
+        if constexpr (TRN) {
+#pragma unroll
+            for (int cb = 0; cb < CB16; ++cb) {
+                const int c = col0 + cb * 16 + q * 4;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(s_bias + c);
+                f32x4 y4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y4[r] = sspf(hval4(accm[cb], accx[cb], r) + b[r]);
+                planes_store4(pl, l15 * LDH + c, y4, amax);
+            }
+        } else
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
             const int col = col0 + cb * 16 + l15;
@@ -2236,10 +2355,27 @@ __device__ __forceinline__ void node_persist_h(const MegaArgs& A, int tile, int 
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) accm[cb] = accx[cb] = zero4;
         TSD_MEGA_P(tile, l, 4);
-        hgemm16_ring_run<CB16, H>(rg, pl, LDH, accm, accx);
+        hgemm16_ring_run<CB16, H, TRN>(rg, pl, LDH, accm, accx);
         if (!last) hgemm16_ring_start<CB16, H>(rg, Wl + A.layer_stride + A.o_lin1, H, col0);
         __syncthreads();
         TSD_MEGA_P(tile, l, 5);
+        if constexpr (TRN) {
+#pragma unroll
+            for (int cb = 0; cb < CB16; ++cb) {
+                const int c = col0 + cb * 16 + q * 4;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(s_bias + H + c);
+                f32x4 hn = zero4;
+                if (l15 < nrows) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hn[r] = h_res[cb][r] + (hval4(accm[cb], accx[cb], r) + b[r]);
+                    if (last)  // the final node states: write-through, the pair tiles read them from other CUs
+                        store_stream16(A.h + (size_t)(n0 + l15) * H + c, hn);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h_res[cb][r] = hn[r];
+                if (!last) planes_store4(pl, l15 * LDH + c, hn, amax);
+            }
+        } else
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
             const int col = col0 + cb * 16 + l15;
@@ -2265,19 +2401,36 @@ __device__ __forceinline__ void node_persist_h(const MegaArgs& A, int tile, int 
         __syncthreads();
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) accm[cb] = accx[cb] = zero4;
-        hgemm16_ring_run<CB16, H>(rg, pl, LDH, accm, accx);
+        hgemm16_ring_run<CB16, H, TRN>(rg, pl, LDH, accm, accx);
+        if constexpr (TRN && TSD_MEGA_DIRECT_X1) {   // a lane holds 16 consecutive bytes of row l15: write-through stores straight from the
+                               // accumulators (no fp32 staging tile, one barrier less per block)
+            TSD_MEGA_P(tile, l, 6);
+            if (l15 < nrows) {
+#pragma unroll
+                for (int cb = 0; cb < CB16; ++cb) {
+                    f32x4 x4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x4[r] = hval4(accm[cb], accx[cb], r);
+                    store_stream16(x_out + (size_t)(n0 + l15) * H + col0 + cb * 16 + q * 4, x4);
+                }
+            }
+        } else {
         __syncthreads();  // every wave is done reading the planes: the x1 tile goes over them as fp32 rows
         TSD_MEGA_P(tile, l, 6);
 #pragma unroll
         for (int cb = 0; cb < CB16; ++cb) {
             const int col = col0 + cb * 16 + l15;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) xst[(q * 4 + r) * LDA + col] = hval4(accm[cb], accx[cb], r);
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (TRN) xst[l15 * LDA + col0 + cb * 16 + q * 4 + r] = hval4(accm[cb], accx[cb], r);
+                else xst[(q * 4 + r) * LDA + col] = hval4(accm[cb], accx[cb], r);
+            }
         }
         __syncthreads();
         for (int idx = tid; idx < nrows * C4; idx += NT) {  // whole 1-KiB rows, write-through
             const int r = idx / C4, c4 = idx % C4;
             store_stream16(x_out + (size_t)(n0 + r) * H + c4 * 4, *reinterpret_cast<const f32x4*>(xst + r * LDA + c4 * 4));
+        }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // (also: the staging rows are free for the next block's planes)
@@ -2356,7 +2509,7 @@ __global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A) {
 static size_t mega_lds_bytes(int H) {
     size_t lds = lds_combo(H, PREC_H2);
     if (H == 256 && MEGA_TR == TN && TSD_MEGA_XLDS)  // the node workgroups' LDS copy of x (xl_gather) behind their planes
-        lds = std::max(lds, (size_t)(TN * ldh_of(256) + XS_ROWS * 256) * 4);
+        lds = std::max(lds, (size_t)(TN * ldh_of(256) + XS_ROWS * 256 + 2 * 256 /* s_bias */) * 4);
     return lds;
 }
 int mega_slots(int H) {

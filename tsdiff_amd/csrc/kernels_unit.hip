@@ -52,8 +52,6 @@ struct UnitArgs {
     int smooth;
     int l_begin, l_end;        // blocks [l_begin, l_end) (the whole encoder: 0, L); l_begin > 0 reads h / x1 from memory
     float* x1_io;              // [M][N, H] x1 in (l_begin > 0) / out (l_end < L); may be NULL for the whole encoder
-                               // (the ping-pong form keeps x1 of every block >= 1 there: required)
-    float* agg_io;             // [M][N, H] ping-pong form: agg of the running block (scratch)
     int32_t* status;           // TSD_STATUS_RANGE / TSD_STATUS_INTERNAL (a unit that breaks the size contract)
 };
 
@@ -122,14 +120,11 @@ extern "C" int tsd_debug_unit_trace(void* host_buf) {
 #define UTRACE(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ut_acc[slot] += n_ - ut_t; ut_t = n_; } while (0)
 #define UTRACE_COUNT(slot) do { ut_acc[slot] += 1; } while (0)
 #define UTRACE_FLUSH do { ut_acc[9] = __builtin_amdgcn_s_memtime() - ut_t0; if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) { for (int i_ = 0; i_ < 10; ++i_) g_unit_trace[(size_t)blockIdx.x * 16 + i_] = ut_acc[i_]; } } while (0)
-// ping-pong form: team 0's wave 0 in row 2 b, team 1's wave 4 in row 2 b + 1 (b < 2048)
-#define UTRACE_FLUSH_PP do { ut_acc[9] = __builtin_amdgcn_s_memtime() - ut_t0; if ((threadIdx.x & 511) == 0 && blockIdx.y == 0 && blockIdx.x < 2048) { for (int i_ = 0; i_ < 10; ++i_) g_unit_trace[((size_t)blockIdx.x * 2 + (threadIdx.x >> 9)) * 16 + i_] = ut_acc[i_]; } } while (0)
 #else
 #define UTRACE_DECL
 #define UTRACE(slot)
 #define UTRACE_COUNT(slot)
 #define UTRACE_FLUSH
-#define UTRACE_FLUSH_PP
 #endif
 
 // A copy of a lane value the compiler must treat as new: the address arithmetic that hangs off it is recomputed where
@@ -717,518 +712,6 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
     UTRACE_FLUSH;
 }
 
-// =================================================================================================
-// PING-PONG FORM (units that are one graph of more than 32 atoms; BASELINE configs[4]).
-//
-// In the kernel above all eight waves walk the phases of one tile together: the MFMA pipes idle through the three
-// VALU / LDS phases (conversion, ssp, filter tile + accumulation: 47 % of a tile's cycles, tools/trace_unit.py) and the
-// VALU idles through the two GEMMs.  Here the workgroup is SIXTEEN waves (128 VGPRs each), two TEAMS of eight -- two waves of
-// each team on every SIMD -- with a tile buffer each; team 0 takes the even tiles, team 1 the odd ones,
-// one slot (a quarter of a tile's cycle) apart:
-//
-//      slot     team 0                     team 1
-//      4k       GEMM nn.0   (tile 2k)      filter tile -> LDS | accumulate | next planes   (tile 2k - 1)
-//      4k + 1   ssp epilogue               GEMM nn.0   (tile 2k + 1)
-//      4k + 2   GEMM nn.2                  ssp epilogue
-//      4k + 3   filter | accumulate | next GEMM nn.2
-//
-// so that exactly one team is on the matrix pipes at any time and the other team's VALU / LDS work runs beside it.  The
-// only barrier is the workgroup's: every slot is three steps, each ended by s_barrier -- the team in `filter |
-// accumulate | next planes` needs them between its steps, the team in a GEMM (or in the ssp epilogue) executes them
-// between thirds of its work (barriers do not drain the weight ring's loads).
-// Two tile buffers take 132 KB of LDS, so x1 and agg of the unit live in memory (workspace rows of the unit: 64 KB each,
-// L2 resident): a tile's accumulate step loads the 16 rows of x1 and read-modify-writes the 16 rows of agg it touches
-// (its two 8-atom blocks).  The accumulate steps of the two teams alternate in time, one slot apart, with barriers
-// between: the rows of agg still meet their partners in list order -- the result is BIT-IDENTICAL to the kernel above
-// and to the materialising forms.
-// =================================================================================================
-template <int RB, int CB, int K, int KS0, int KS1, int R>
-__device__ __forceinline__ void hgemm_ring_run_part(HRing<CB, R>& r, const Planes& A, int ldh, f32x16 (&accm)[RB][CB],
-                                                    f32x16 (&accx)[RB][CB]) {
-    constexpr int KS = K / 16;
-    const int lane = threadIdx.x & 63;
-    const int aoff = (lane & 31) * ldh + (lane >> 5) * 8;
-    static_for<KS0, KS1>([&](auto ksc) {
-        constexpr int ks = decltype(ksc)::value;
-        constexpr int slot = ks % R;
-        constexpr int younger = ((ks + R <= KS) ? R : KS - ks) - 1;
-        f32x4 ah[RB], al[RB];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-            ah[rb] = *reinterpret_cast<const f32x4*>(A.hi + aoff + rb * 32 * ldh + ks * 16);
-            al[rb] = *reinterpret_cast<const f32x4*>(A.lo + aoff + rb * 32 * ldh + ks * 16);
-        }
-        hring_wait<younger * CB * 2, CB>(r.b[slot]);
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) {
-                accx[rb][cb] = mfma_h32(ah[rb], r.b[slot][cb][1], accx[rb][cb]);
-                accm[rb][cb] = mfma_h32(ah[rb], r.b[slot][cb][0], accm[rb][cb]);
-                accx[rb][cb] = mfma_h32(al[rb], r.b[slot][cb][0], accx[rb][cb]);
-            }
-        if constexpr (ks + R < KS)
-            hring_issue<CB>(r.b[slot], r.base + (size_t)(ks + R) * r.step_bytes, r.voff, r.plane_bytes, r.cb_bytes);
-        // (k-steps stay apart: left alone the scheduler lifts the A-fragment reads of later k-steps above the MFMAs of this
-        // one, and with 128 accumulator registers per wave the kernel then spills its weight ring)
-        __builtin_amdgcn_sched_barrier(0);
-    });
-}
-
-
-// TEAMS = 2: the lock-step form described above (1024 threads).  TEAMS = 1: ONE team per workgroup (512 threads, 128 VGPRs,
-// 80 KB of LDS), so that TWO workgroups -- two units -- share a CU and the hardware interleaves their phases instruction by
-// instruction (a team that waits for its x / agg rows or its attribute fetch does not hold a barrier the other one needs).
-template <int H, int TEAMS>
-__global__ __launch_bounds__(TEAMS * 2 * H, TEAMS == 1 ? 4 : 2) void unit_encoder_pp_kernel(UnitArgs A) {
-    static_assert(H == 256 && (TEAMS == 1 || TEAMS == 2), "the unit encoder is built for hidden 256 (teams of eight waves)");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int LDH = ldh_of(H), LDA = H + 4, NT = TEAMS * 2 * H, C4 = H / 4, NW = NT / 64;
-    constexpr int RB16 = UNA / 16, CB16 = 1;  // (node chain: 16 columns per wave and pass)
-    constexpr int NPASS = H / (NW * 16);      // column passes of the node chain's GEMMs (16 waves: 1, 8 waves: 2)
-    constexpr int KS = H / 16;
-    float* tile0 = smem;                             // team 0: planes / fp32 filter tile
-    float* tile1 = tile0 + (TEAMS - 1) * UT * LDH;   // team 1 (TEAMS = 1: the same buffer)
-    float* s_c = tile0 + TEAMS * UT * LDH;                   // [U_ROWS] cutoff weight per tile row
-    uint16_t* s_u = reinterpret_cast<uint16_t*>(s_c + U_ROWS);  // [U_ROWS] local pair index of the tile row, 0xffff: none
-
-    const int u = blockIdx.x;
-    const size_t m = blockIdx.y;
-    const int tid = threadIdx.x;
-    const int n0 = A.unit_node[u], n1 = A.unit_node[u + 1], na = n1 - n0;
-    if (na <= 0) return;
-    const int e0 = A.eu.row_ptr[n0], e1 = A.eu.row_ptr[n1], ne = e1 - e0;
-    if (na > UNA || ne > UE_MAX || ne < 0 || A.node_graph[n0] != A.node_graph[n1 - 1]) {  // (host contract: one graph per unit)
-        if (tid == 0) atomicOr(A.status, TSD_STATUS_INTERNAL);
-        return;
-    }
-    const float* Wm = A.W + m * A.w_stride;
-    const float* ea = A.ea + m * A.ea_stride + (size_t)e0 * H;
-    float* hm = A.h + m * A.nh_stride;
-    float* X = A.x1_io + m * A.nh_stride + (size_t)n0 * H;   // x1 of the unit's atoms (blocks >= 1; written by the node chain)
-    float* G = A.agg_io + m * A.nh_stride + (size_t)n0 * H;  // agg of the unit's atoms
-    float amax = 0.0f;
-    UTRACE_DECL
-    const int nb = (na + 7) >> 3;
-    const int ntile = nb * (nb + 1) / 2;
-    const int nrb = (na + 15) >> 4;
-
-    // ---- per-unit staging: pair index and cutoff weight of every tile row ----
-    for (int idx = tid; idx < ntile * UT; idx += NT) {
-        int tt = idx >> 6, I = 0;
-        while (tt >= nb - I) {
-            tt -= nb - I;
-            ++I;
-        }
-        const int J = I + tt, pr = idx & 63;
-        const int i = I * 8 + (pr >> 3), j = J * 8 + (pr & 7);
-        int loc = -1;
-        if (i < j && j < na) {
-            const int uu = A.pair2u[A.pair_ptr[n0 + i] + j - 1];
-            if (uu >= e0 && uu < e1) loc = uu - e0;
-        }
-        s_u[idx] = (uint16_t)(loc < 0 ? 0xffff : loc);
-        s_c[idx] = loc < 0 ? 0.0f : cutoff_weight(A.eu.dist[e0 + loc], A.conv_cutoff, A.smooth);
-    }
-    __syncthreads();
-
-#define TSD_PP_GEOM                                                           \
-    const int tq = opaque(tid);                                               \
-    const int wave = tq >> 6, lane = tq & 63;                                 \
-    const int tw = wave & 7;                                                  \
-    const int hi = lane >> 5, l31 = lane & 31;                                \
-    const int col0 = tw * 32;                                                 \
-    (void)tw; (void)hi; (void)l31; (void)col0; (void)wave;
-
-    const int team = __builtin_amdgcn_readfirstlane(tid >> 9);  // 0: waves 0-7, 1: waves 8-15 (uniform per wave)
-    float* tile = team == 0 ? tile0 : tile1;
-    const Planes pl = planes_at(tile, UT, LDH);
-    float* buf = tile;
-    const int nt_team = (ntile - team + TEAMS - 1) / TEAMS;  // tiles of this team: t = TEAMS k + team
-
-    for (int l = A.l_begin; l < A.l_end; ++l) {
-        const float* Wl = Wm + A.layer0 + (size_t)l * A.layer_stride;
-        const float *nn0_w = Wl + A.o_nn0_w, *nn2_w = Wl + A.o_nn2_w;
-        const float* xin = l == 0 ? A.x1_0 + m * A.nh_stride + (size_t)n0 * H : X;
-        {   // agg of the block starts at zero
-            const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
-            for (int idx = tid; idx < na * C4; idx += NT) *reinterpret_cast<f32x4*>(G + idx * 4) = zz;
-        }
-        float b0, b2;
-        {
-            TSD_PP_GEOM
-            b0 = Wl[A.o_nn0_b + col0 + l31];
-            b2 = Wl[A.o_nn2_b + col0 + l31];
-        }
-        if (nt_team > 0) {   // the team's first tile: attribute rows -> planes, first k-steps of nn.0's weights
-            TSD_PP_GEOM
-            constexpr int NITP = UT / 8;
-            f32x4 v[NITP];
-            unsigned uu[NITP];
-            float site_m = 0.0f;
-#pragma unroll
-            for (int it = 0; it < NITP; ++it) uu[it] = s_u[team * UT + tw + it * 8];
-#pragma unroll
-            for (int it = 0; it < NITP; ++it)
-                v[it] = *reinterpret_cast<const f32x4*>(ea + (size_t)(uu[it] == 0xffffu ? 0u : uu[it]) * H + lane * 4);
-#pragma unroll
-            for (int it = 0; it < NITP; ++it) {
-                const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
-                planes_store4(pl, (tw + it * 8) * LDH + lane * 4, uu[it] != 0xffffu ? v[it] : zz, site_m);
-            }
-            site_close(amax, site_m);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();  // (also: the zeros of agg are in memory -- vmcnt(0) above -- before any accumulate step)
-
-        int tI = 0, tJ = 0;  // blocks of the team's current tile
-        if (team == 1) {
-            tJ = 1;
-            if (tJ == nb) { tI = 1; tJ = 1; }
-        }
-        auto next_tile = [&]() {  // TEAMS tiles on
-#pragma unroll
-            for (int s2 = 0; s2 < TEAMS; ++s2)
-                if (++tJ == nb) {
-                    ++tI;
-                    tJ = tI;
-                }
-        };
-        // Team 1 runs one slot behind team 0: it idles through one slot first, team 0 through one at the end; in between
-        // both walk whole tile cycles (GEMM nn.0 | ssp | GEMM nn.2 | filter, accumulate, next planes), three barriers per
-        // slot, the same number of barriers in every wave.
-        const int ncyc = (ntile + TEAMS - 1) / TEAMS;
-        if (TEAMS == 2 && team == 1) {
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_s_barrier();
-        }
-        // (the barriers INSIDE a GEMM / the ssp epilogue exist for the other team's steps: none with one team)
-        auto mid_barrier = [&]() {
-            if constexpr (TEAMS == 2) __builtin_amdgcn_s_barrier();
-        };
-        for (int k = 0; k < ncyc; ++k) {
-            const int t = TEAMS * k + team;
-            if (k >= nt_team) {   // (team 1 when the tile count is odd)
-#pragma unroll
-                for (int i = 0; i < 12; ++i) __builtin_amdgcn_s_barrier();
-                continue;
-            }
-            f32x16 accm[2][1], accx[2][1];
-            UTRACE(7);
-            // a GEMM's k-steps in three parts 4 | 5 | 7, cut roughly where the other team's steps end (`filter | accumulate |
-            // planes`, or the three parts of the ssp epilogue, sized to match).  ONE split for every GEMM: two code paths
-            // that both consume the weight ring make the compiler copy ring registers at the branch while their loads are
-            // in flight (tools/check_async_loads.py caught it).
-            auto gemm3 = [&](const float* wmat) {
-                // (the weight ring goes up HERE, not before the barrier that ends the previous slot: with 128 registers per
-                // wave a ring that is live across the loop edge is what the allocator spills -- while its loads are in flight)
-                HRing<1, HRING_R> rg;
-                {
-                    TSD_PP_GEOM
-                    hgemm_ring_start<1, H>(rg, wmat, H, col0);
-                }
-                hzero(accm, accx);
-                hgemm_ring_run_part<2, 1, H, 0, 4>(rg, pl, LDH, accm, accx);
-                mid_barrier();
-                hgemm_ring_run_part<2, 1, H, 4, 9>(rg, pl, LDH, accm, accx);
-                mid_barrier();
-                hgemm_ring_run_part<2, 1, H, 9, KS>(rg, pl, LDH, accm, accx);
-            };
-            {   // ---- slot 0: GEMM nn.0 in three parts
-                __builtin_amdgcn_s_setprio(0);
-                gemm3(nn0_w);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-            UTRACE(0);
-            {   // ---- slot 1: shifted softplus -> planes, in three parts
-                // (the VALU-side slots run at raised priority: a GEMM wave needs one issue slot per 32-cycle MFMA, the epilogue
-                // waves need them all -- at equal priority the older wave wins the SIMD's issue port)
-                __builtin_amdgcn_s_setprio(2);
-                TSD_PP_GEOM
-                f16* hb = pl.hi + opaque(4 * hi * LDH + col0 + l31);
-                f16* lb = pl.lo + opaque(4 * hi * LDH + col0 + l31);
-                auto elem = [&](auto ec) {   // element e of the lane's 32: row block e / 16, accumulator register e % 16
-                    constexpr int e = decltype(ec)::value, rb = e >> 4, r = e & 15;
-                    const float y = sspf(hval(accm[rb][0], accx[rb][0], r) + b0);
-                    f16 yh, yl;
-                    amax_upd(amax, y);
-                    split1(y, yh, yl);
-                    hb[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = yh;
-                    lb[(rb * 32 + (r & 3) + 8 * (r >> 2)) * LDH] = yl;
-                };
-                // (the planes are free: every wave of the team left GEMM nn.0 at the barrier that ended its slot)
-                static_for<0, 8>(elem);
-                mid_barrier();
-                static_for<8, 18>(elem);
-                mid_barrier();
-                static_for<18, 32>(elem);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-            UTRACE(1);
-            {   // ---- slot 2: GEMM nn.2 in three parts
-                __builtin_amdgcn_s_setprio(0);
-                gemm3(nn2_w);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-            UTRACE(2);
-            {   // ---- slot 3: filter tile -> LDS | accumulate | next tile's planes
-                __builtin_amdgcn_s_setprio(2);
-                const bool more = k + 1 < nt_team;  // (the team's next tile: t + TEAMS)
-                const bool diag = tI == tJ;
-                const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
-                // accumulate step, side 0 (the pair's j side: row tw of block J, partners = block I): its x rows are requested
-                // HERE, before the filter-tile step, and land under it
-                f32x4 xv0[8], a4;
-                {
-                    TSD_PP_GEOM
-#pragma unroll
-                    for (int p = 0; p < 8; ++p) {
-                        const int at = tI * 8 + p;
-                        xv0[p] = at < na ? *reinterpret_cast<const f32x4*>(xin + (size_t)at * H + lane * 4) : zz;
-                    }
-                }
-                {   // W = (nn.2 + b) * C as fp32 rows over the planes (four rows at a time, pinned: the attribute rows above
-                    // must stay in their registers -- a spilled one would wait for its load)
-                    TSD_PP_GEOM
-                    float* wb = buf + opaque(4 * hi * LDA + col0 + l31);
-#pragma unroll
-                    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            const f32x4 cw = *reinterpret_cast<const f32x4*>(s_c + t * UT + rb * 32 + 8 * g4 + 4 * hi);
-#pragma unroll
-                            for (int r3 = 0; r3 < 4; ++r3)
-                                wb[(rb * 32 + r3 + 8 * g4) * LDA] = (hval(accm[rb][0], accx[rb][0], g4 * 4 + r3) + b2) * cw[r3];
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                UTRACE(3);
-                // the attribute rows of the team's next tile (requested at the END of the accumulate step: with 128 registers per
-                // wave there is no room for them beside the accumulators of the filter-tile step or beside both sides' x rows
-                // -- tried: the compiler waits for the loads and spills them; their HBM latency shows in the planes step)
-                constexpr int NITP = UT / 8;
-                f32x4 v[NITP];
-                unsigned vlive = 0;
-                {   // accumulate: wave tw of the team adds the partners of row tw of block J (the pair's j side),
-                    // then of block I (its i side): read-modify-write of those rows' agg in memory.  Side 1's loads are
-                    // requested before side 0's arithmetic.  (Both sides' rows and the next tile's attribute rows in
-                    // registers at once do not fit 256 VGPRs: the allocator then spills the weight ring.)
-                    TSD_PP_GEOM
-                    const float* wrow = buf + lane * 4;
-                    f32x4 xv1[8], b4;
-                    {
-                        const int at = tJ * 8 + tw;
-                        a4 = at < na ? *reinterpret_cast<const f32x4*>(G + (size_t)at * H + lane * 4) : zz;
-                    }
-#pragma unroll
-                    for (int p = 0; p < 8; ++p) {
-                        const int at = tJ * 8 + p;
-                        xv1[p] = at < na ? *reinterpret_cast<const f32x4*>(xin + (size_t)at * H + lane * 4) : zz;
-                    }
-                    {
-                        const int at = tI * 8 + tw;
-                        b4 = (at < na && !diag) ? *reinterpret_cast<const f32x4*>(G + (size_t)at * H + lane * 4) : zz;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int p = 0; p < 8; ++p) {   // j side: tile row (p, tw) = p * 8 + tw
-                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + (p * 8 + tw) * LDA);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) a4[c] = __fadd_rn(a4[c], __fmul_rn(xv0[p][c], wv[c]));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (diag) {   // a diagonal tile: the same row takes its i side on top (partners below the row, then above)
-                        b4 = a4;
-                    } else {
-                        const int at = tJ * 8 + tw;
-                        if (at < na) *reinterpret_cast<f32x4*>(G + (size_t)at * H + lane * 4) = a4;
-                    }
-#pragma unroll
-                    for (int p = 0; p < 8; ++p) {   // i side: tile row (tw, p) = tw * 8 + p
-                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wrow + (tw * 8 + p) * LDA);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) b4[c] = __fadd_rn(b4[c], __fmul_rn(xv1[p][c], wv[c]));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    {
-                        const int at = tI * 8 + tw;
-                        if (at < na) *reinterpret_cast<f32x4*>(G + (size_t)at * H + lane * 4) = b4;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (more) {
-                        unsigned uu[NITP];
-#pragma unroll
-                        for (int it = 0; it < NITP; ++it) uu[it] = s_u[(t + TEAMS) * UT + tw + it * 8];
-#pragma unroll
-                        for (int it = 0; it < NITP; ++it) {
-                            vlive |= (uu[it] != 0xffffu ? 1u : 0u) << it;
-                            v[it] = *reinterpret_cast<const f32x4*>(ea + (size_t)(uu[it] == 0xffffu ? 0u : uu[it]) * H + lane * 4);
-                        }
-                    } else {
-#pragma unroll
-                        for (int it = 0; it < NITP; ++it) v[it] = zz;
-                    }
-                }
-                next_tile();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                UTRACE(4);
-                {   // v -> planes of the team's buffer; then, every older global access of the wave complete (the agg stores
-                    // above are what the other team's next accumulate step reads), the first k-steps of nn.0's weights
-                    TSD_PP_GEOM
-                    float site_m = 0.0f;
-#pragma unroll
-                    for (int it = 0; it < NITP; ++it) {
-                        const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
-                        planes_store4(pl, (tw + it * 8) * LDH + lane * 4, (vlive >> it & 1u) ? v[it] : zz, site_m);
-                    }
-                    site_close(amax, site_m);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                UTRACE(5);
-                UTRACE_COUNT(8);
-            }
-        }
-        if (TEAMS == 2 && team == 0) {
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_s_barrier();
-        }
-        // (every accumulate step has stored its rows and waited for them -- to_planes / the vmcnt(0) beside it -- before
-        // the barrier that ended its slot)
-        __syncthreads();
-
-        // ---- node chain of block l (all waves; the arithmetic of the kernel above) on team 0's buffer.  A wave owns 16 output
-        // columns per pass (16 waves: one pass; 8 waves: two -- with 32 columns per wave the accumulators of four row blocks
-        // do not fit 128 registers); a pass leaves its results as combined values (hval4) until every wave is done reading
-        // the planes the epilogue overwrites ----
-        {
-            const Planes pn = planes_at(tile0, UT, LDH);
-            const bool last = l + 1 == A.L;
-            float vals[NPASS][RB16][4];
-#define TSD_PPN_GEOM                                                      \
-    const int tq = opaque(tid);                                           \
-    const int wave = tq >> 6, lane = tq & 63;                             \
-    const int q = lane >> 4, l15 = lane & 15;                             \
-    (void)q; (void)l15; (void)wave;
-            auto gemm_n = [&](const float* wmat) {  // vals = planes x wmat^T, this wave's columns of every pass
-                TSD_PPN_GEOM
-#pragma unroll
-                for (int ps = 0; ps < NPASS; ++ps) {
-                    HRing<CB16, HRING16_R> rn;
-                    f32x4 am[RB16][CB16], ax[RB16][CB16];
-                    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-                    hgemm16_ring_start<CB16, H>(rn, wmat, H, (wave * NPASS + ps) * 16);
-#pragma unroll
-                    for (int rb = 0; rb < RB16; ++rb) am[rb][0] = ax[rb][0] = zero4;
-                    hgemm16_ring_run_rb<RB16, CB16, H>(rn, pn, LDH, am, ax, nrb);
-#pragma unroll
-                    for (int rb = 0; rb < RB16; ++rb)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) vals[ps][rb][r] = hval4(am[rb][0], ax[rb][0], r);
-                }
-            };
-            {
-                TSD_PPN_GEOM
-                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-                float site_m = 0.0f;
-#pragma unroll
-                for (int kk = 0; kk < UNA / NW; ++kk) {
-                    const int at = kk * NW + wave;
-                    const f32x4 a4 = at < na ? *reinterpret_cast<const f32x4*>(G + (size_t)at * H + lane * 4) : zero4;
-                    planes_store4(pn, at * LDH + lane * 4, a4, site_m);
-                }
-                site_close(amax, site_m);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();
-            gemm_n(Wl + A.o_lin2_w);
-            __syncthreads();
-            {
-                TSD_PPN_GEOM
-#pragma unroll
-                for (int ps = 0; ps < NPASS; ++ps) {
-                    const int c = (wave * NPASS + ps) * 16 + l15;
-                    const float b = Wl[A.o_lin2_b + c];
-#pragma unroll
-                    for (int rb = 0; rb < RB16; ++rb)
-                        if (rb < nrb) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r)
-                                planes_store1(pn, (rb * 16 + q * 4 + r) * LDH + c, sspf(vals[ps][rb][r] + b), amax);
-                        }
-                }
-            }
-            __syncthreads();
-            gemm_n(Wl + A.o_lin_w);
-            __syncthreads();
-            {
-                TSD_PPN_GEOM
-                const float* h_in = (l == 0 ? A.z + m * A.nh_stride : hm) + (size_t)n0 * H;
-#pragma unroll
-                for (int ps = 0; ps < NPASS; ++ps) {
-                    const int c = (wave * NPASS + ps) * 16 + l15;
-                    const float b = Wl[A.o_lin_b + c];
-#pragma unroll
-                    for (int rb = 0; rb < RB16; ++rb)
-                        if (rb < nrb) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = rb * 16 + q * 4 + r;
-                                float hn = 0.0f;
-                                if (row < na) {
-                                    hn = h_in[(size_t)row * H + c] + (vals[ps][rb][r] + b);
-                                    hm[(size_t)(n0 + row) * H + c] = hn;
-                                }
-                                if (!last) planes_store1(pn, row * LDH + c, hn, amax);
-                            }
-                        }
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            if (last) {
-                UTRACE(6);
-                break;
-            }
-            __syncthreads();
-            gemm_n(Wl + A.layer_stride + A.o_lin1);
-            {
-                TSD_PPN_GEOM
-                // x1 of the next block: to memory (the accumulate steps of the next block read it from there)
-#pragma unroll
-                for (int ps = 0; ps < NPASS; ++ps)
-#pragma unroll
-                    for (int rb = 0; rb < RB16; ++rb)
-                        if (rb < nrb) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int row = rb * 16 + q * 4 + r;
-                                if (row < na) X[(size_t)row * H + (wave * NPASS + ps) * 16 + l15] = vals[ps][rb][r];
-                            }
-                        }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();
-            UTRACE(6);
-#undef TSD_PPN_GEOM
-        }
-    }
-#undef TSD_PP_GEOM
-    range_report(amax, A.status);
-    UTRACE_FLUSH_PP;
-}
-
-size_t unit_encoder_pp_lds(int H, int teams) { return ((size_t)teams * UT * ldh_of(H) + U_ROWS) * 4 + (size_t)U_ROWS * 2; }
 
 size_t unit_encoder_lds(int H) {
     return ((size_t)UNA * H + (size_t)UT * ldh_of(H) + U_ROWS) * 4 + (size_t)U_ROWS * 2 + 64 * 2 + (size_t)2 * H * 4 /* s_bias */;
@@ -1237,8 +720,7 @@ size_t unit_encoder_lds(int H) {
 bool unit_encoder_supported(const tsd_model_cfg& c) { return c.hidden == 256; }
 
 int launch_unit_encoder(const tsd_model_cfg& c, const tsd_batch& b, const float* W16, const float* ea, size_t ea_stride,
-                        float* h, size_t nh_stride, int l_begin, int l_end, float* x1_io, float* agg_io, int pingpong,
-                        int32_t* status, hipStream_t st) {
+                        float* h, size_t nh_stride, int l_begin, int l_end, float* x1_io, int32_t* status, hipStream_t st) {
     if (!unit_encoder_supported(c) || b.unit_node == nullptr || b.num_units <= 0) {
         set_error("internal: the fused encoder needs hidden 256 and the batch's unit partition");
         return TSD_ERR_INVALID;
@@ -1277,28 +759,7 @@ int launch_unit_encoder(const tsd_model_cfg& c, const tsd_batch& b, const float*
     A.l_begin = l_begin;
     A.l_end = l_end;
     A.x1_io = x1_io;
-    A.agg_io = agg_io;
     A.status = status;
-    if (pingpong != 0) {  // (every unit ONE graph: the caller's knowledge)  1: two independent workgroups per CU; 2: lock-step teams
-        if (x1_io == nullptr || agg_io == nullptr) {
-            set_error("internal: this form of the encoder needs its x1 / agg rows");
-            return TSD_ERR_INVALID;
-        }
-        const size_t lds = unit_encoder_pp_lds(c.hidden, pingpong);
-        if (pingpong == 1) {
-            static DeviceOnce once;
-            int r = allow_lds(unit_encoder_pp_kernel<256, 1>, lds, once);
-            if (r) return r;
-            hipLaunchKernelGGL((unit_encoder_pp_kernel<256, 1>), dim3(b.num_units, b.num_models), dim3(512), lds, st, A);
-        } else {
-            static DeviceOnce once;
-            int r = allow_lds(unit_encoder_pp_kernel<256, 2>, lds, once);
-            if (r) return r;
-            hipLaunchKernelGGL((unit_encoder_pp_kernel<256, 2>), dim3(b.num_units, b.num_models), dim3(1024), lds, st, A);
-        }
-        TSD_LAUNCH_CHECK("unit_encoder_pp");
-        return TSD_OK;
-    }
     const size_t lds = unit_encoder_lds(c.hidden);
     static DeviceOnce once;
     int r = allow_lds(unit_encoder_kernel<256>, lds, once);

@@ -51,9 +51,16 @@ __device__ __forceinline__ void amax_upd(float& amax, float a) {
     asm("v_max_f32 %0, %0, |%1|" : "+v"(amax) : "v"(a));
 }
 __device__ __forceinline__ void amax_upd2(float& amax, float a, float b) {
-    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(a), "v"(b));
+    asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(a), "v"(b));
 }
+// `a` is made opaque first: with -ffp-contract=on the compiler may fuse a conversion with the multiply that produced its
+// input (v_fma_mixlo_f16: f16 of the EXACT product, one rounding) and, worse, does so for ONE of two uses of the same
+// conversion -- found in round 5 in the one-launch kernel's pair role: the high plane was stored as f16(fp32(x * s)) (packed
+// conversion) while the low plane was computed against f16(x * s) (mixed-precision fma); where the two roundings differ
+// (1 element in ~10^3) hi + lo 2^-11 misses the value by an f16 ulp -- 15 of 1791 pair outputs of a test batch were 6e-5 off.
+// Behind the empty asm statement both planes derive from the same fp32 register by plain round-to-nearest conversions.
 __device__ __forceinline__ void split1(float a, f16& h, f16& l) {
+    asm("" : "+v"(a));
     h = (f16)a;
     l = (f16)((a - (float)h) * SPLIT_SCALE);
 }

@@ -3,6 +3,10 @@
 #pragma once
 #include "train_internal.hpp"
 
+#ifndef TSD_TYPED_TRANS
+#define TSD_TYPED_TRANS 1  // transposed accumulators in the typed embedding tile (0: the round-4 layout; A/B builds)
+#endif
+
 namespace tsd {
 
 struct TypedList {
@@ -32,6 +36,10 @@ __device__ __forceinline__ void typed_embed_tile_h(const TypedEmbedW& w, const T
     float* s_d = stage + T * LDA;
     int* s_row = reinterpret_cast<int*>(s_d + T);
     float* s_cw = s_d + 2 * T;  // CFConv cutoff weight of the row (block-0 filters)
+    // transposed accumulators (split16.hpp hgemm_ring_run<..., TRANS>, as kernels_combo.hip::filter_role_h): lane = tile row
+    // l31, four runs of four consecutive channels; the three bias vectors of the tile's epilogues in LDS
+    constexpr bool TR = TSD_TYPED_TRANS != 0;
+    float* s_bias = s_cw + T;   // [3][H]: bucket bias, nn.0 bias, nn.2 bias (TR)
     const bool second = bx >= ta.n;
     const TypedList& tl = second ? tb : ta;
     const int t = second ? bx - ta.n : bx;
@@ -72,7 +80,16 @@ __device__ __forceinline__ void typed_embed_tile_h(const TypedEmbedW& w, const T
         if (!any) return;
     }
     HRing<1, HRING_R> rg;
-    const float bias_t = bt[col];
+    const float bias_t = TR ? 0.0f : bt[col];
+    if constexpr (TR) {
+        for (int c = tid; c < H; c += NT) {
+            s_bias[c] = bt[c];
+            if constexpr (FUSE0) {
+                s_bias[H + c] = (f0.nn0_b + m * w.wstride)[c];
+                s_bias[2 * H + c] = (f0.nn2_b + m * w.wstride)[c];
+            }
+        }
+    }
     {   // Linear(1,H) + swish: thread = (channel pair, quarter of the tile's rows)
         const int c = (tid % (H / 2)) * 2, r0 = (tid / (H / 2)) * (T / 4);
         const float wa = w0[c], wb = w0[c + 1], ba = b0[c], bb = b0[c + 1];
@@ -86,7 +103,7 @@ __device__ __forceinline__ void typed_embed_tile_h(const TypedEmbedW& w, const T
     __syncthreads();
     f32x16 accm[1][1], accx[1][1];
     hzero(accm, accx);
-    hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
+    hgemm_ring_run<1, 1, H, false, TR>(rg, pl, LDH, accm, accx);
     const bool fuse = FUSE0 && !second;
     const float *nn0_w = f0.nn0_w + m * w.wstride, *nn0_b = f0.nn0_b + m * w.wstride;
     const float *nn2_w = f0.nn2_w + m * w.wstride, *nn2_b = f0.nn2_b + m * w.wstride;
@@ -94,6 +111,22 @@ __device__ __forceinline__ void typed_embed_tile_h(const TypedEmbedW& w, const T
         if (fuse) hgemm_ring_start<1, H>(rg, nn0_w, H, col0);
     }
     __syncthreads();
+    if constexpr (TR) {
+        const float* bb = s_bias + col0 + 4 * hi;
+        f32x4 bn = *reinterpret_cast<const f32x4*>(bb);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 bv = bn;
+            if (g4 < 3) bn = *reinterpret_cast<const f32x4*>(bb + 8 * (g4 + 1));
+            f32x4 v4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v4[r] = swishf(hval(accm[0][0], accx[0][0], 4 * g4 + r) + bv[r]);
+            *reinterpret_cast<f32x4*>(stage + l31 * LDA + col0 + 8 * g4 + 4 * hi) = v4;
+            if constexpr (FUSE0) {
+                if (fuse) planes_store4(pl, l31 * LDH + col0 + 8 * g4 + 4 * hi, v4, amax);
+            }
+        }
+    } else
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = acc_row(r, hi);
@@ -118,19 +151,46 @@ __device__ __forceinline__ void typed_embed_tile_h(const TypedEmbedW& w, const T
         }
         // filter role of interaction block 0 on this tile (kernels_combo.hip::filter_role_h)
         float* wf = f0.wf + m * f0.wf_stride;
-        const float bb0 = nn0_b[col];
+        const float bb0 = TR ? 0.0f : nn0_b[col];
         hzero(accm, accx);
-        hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
+        hgemm_ring_run<1, 1, H, false, TR>(rg, pl, LDH, accm, accx);
         hgemm_ring_start<1, H>(rg, nn2_w, H, col0);
         __syncthreads();
+        if constexpr (TR) {
+            const float* bb = s_bias + H + col0 + 4 * hi;
+            f32x4 bn = *reinterpret_cast<const f32x4*>(bb);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 bv = bn;
+                if (g4 < 3) bn = *reinterpret_cast<const f32x4*>(bb + 8 * (g4 + 1));
+                f32x4 y4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y4[r] = sspf(hval(accm[0][0], accx[0][0], 4 * g4 + r) + bv[r]);
+                planes_store4(pl, l31 * LDH + col0 + 8 * g4 + 4 * hi, y4, amax);
+            }
+        } else
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             planes_store1(pl, acc_row(r, hi) * LDH + col, sspf(hval(accm[0][0], accx[0][0], r) + bb0), amax);
         __syncthreads();
-        const float bb2 = nn2_b[col];
+        const float bb2 = TR ? 0.0f : nn2_b[col];
         hzero(accm, accx);
-        hgemm_ring_run<1, 1, H>(rg, pl, LDH, accm, accx);
+        hgemm_ring_run<1, 1, H, false, TR>(rg, pl, LDH, accm, accx);
         // (every wave passed the barrier above after its row stores from `stage`: it may be overwritten)
+        if constexpr (TR) {
+            const float* bb = s_bias + 2 * H + col0 + 4 * hi;
+            const float cw = s_cw[l31];
+            f32x4 bn = *reinterpret_cast<const f32x4*>(bb);
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 bv = bn;
+                if (g4 < 3) bn = *reinterpret_cast<const f32x4*>(bb + 8 * (g4 + 1));
+                f32x4 w4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w4[r] = (hval(accm[0][0], accx[0][0], 4 * g4 + r) + bv[r]) * cw;
+                *reinterpret_cast<f32x4*>(stage + l31 * LDA + col0 + 8 * g4 + 4 * hi) = w4;
+            }
+        } else
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = acc_row(r, hi);

@@ -351,7 +351,7 @@ class DeviceBatch:
 
     def build_units(self, M):
         """the unit partition of the fused per-unit encoder for M bound checkpoints (host knowledge, pos independent)"""
-        key = (M, str(OPTIONS.fused_encoder), str(OPTIONS.pingpong))
+        key = (M, str(OPTIONS.fused_encoder))
         if self._units_for == key:
             return
         self._units_for = key
@@ -359,12 +359,6 @@ class DeviceBatch:
         if self.G == 0 or self.max_n > _lib.UNIT_MAX_NODES or self.P == 0:
             return
         cus = torch.cuda.get_device_properties(self.device).multi_processor_count
-        if OPTIONS.fused_encoder == "force" and OPTIONS.pingpong in ("solo", "teams", True):
-            # (A/B, tests: the block-tile forms of the kernel on ANY batch -- every graph a unit of its own)
-            bounds = np.concatenate([[0], np.cumsum(self.num_nodes_per_graph_host)])
-            self.unit_node = torch.from_numpy(bounds.astype(np.int32)).to(self.device)
-            self.units_single_graph = True
-            return
         bounds = partition_units(self.num_nodes_per_graph_host, M, cus)
         self.unit_node = torch.from_numpy(bounds.astype(np.int32)).to(self.device)
         # every unit one graph (certain when every graph has more than half a unit's atoms): the block-tile forms apply
@@ -401,8 +395,7 @@ class DeviceBatch:
             status=self.status.data_ptr(),
             unit_node=None if self.unit_node is None else self.unit_node.data_ptr(),
             num_units=0 if self.unit_node is None else int(self.unit_node.numel()) - 1,
-            reserved2=({"solo": 1, "teams": 2, True: 2}.get(OPTIONS.pingpong, 0)
-                       if (self.unit_node is not None and self.units_single_graph) else 0))
+            reserved2=0)
 
     def _tiles_struct(self, which):
         t = self.typed
@@ -547,7 +540,7 @@ class DeviceBatch:
         replayed by every later dynamic_sampling call on this batch (reference loop: models/sampler.py:187-254)"""
         key = (int(kind), float(clip), float(-1.0 if clip_pos is None else clip_pos),
                bool(OPTIONS.fused_step_tail and not self.per_block),
-               bool(OPTIONS.typed_tiles), self.gemm_mode(), self.reserved_flags(), str(OPTIONS.pingpong))
+               bool(OPTIONS.typed_tiles), self.gemm_mode(), self.reserved_flags())
         plan = self._plans.get(key)
         if plan is None:
             lib = _lib.load()

@@ -13,7 +13,6 @@ at import, by `TSDIFF_*` environment variables (read here and nowhere else); tes
 | wide_filter_tiles  | TSDIFF_WIDE_FILTER_TILES  | True    | 64-row filter tiles where a block launch is many chip-fulls deep; False: 32-row tiles everywhere |
 | fused_step_tail    | TSDIFF_FUSED_TAIL         | True    | sampling loop: update + next step's edge lists as one launch; False: three launches |
 | fused_encoder      | TSDIFF_FUSED_ENCODER      | True    | chip-full launches (big batches, ensembles): the whole SchNet encoder as ONE launch of per-unit workgroups that never write the CFConv filters to memory (kernels_unit.hip); False: one launch per block with materialised filters; "force": also where the one-launch form would apply.  Bit-identical (the messages are added in the directed list's order) |
-| pingpong           | TSDIFF_PINGPONG           | False   | form of the fused encoder on units that are single graphs of > 32 atoms: False = eight waves own a CU and walk one tile's phases together (unit_encoder_kernel); "solo" = block tiles with x1 / agg in memory at 128 VGPRs / 80 KB: two units per CU, interleaved by the hardware; "teams" = the same in lock step, two teams of eight waves in one workgroup, one on the matrix pipes while the other runs its VALU / LDS steps (unit_encoder_pp_kernel).  Bit-identical; measurements in DESIGN.md 4c |
 | train              | TSDIFF_TRAIN              | "fused" | training step: "fused" = forward + loss and the whole backward as two library calls (csrc/train_step.hip), "ops" = one autograd node per operation (same kernels; the cross-check) |
 | train_gemm         | TSDIFF_TRAIN_GEMM         | "h2"    | arithmetic of the fused training step's tile GEMMs: "f32" = fp32-input MFMA, "h2" = split-f16 operands (gradient operands scaled by a power of two per tensor).  A step whose activations leave the f16 range is recomputed in "f32" |
 | train_fallback_latch | TSDIFF_TRAIN_FALLBACK_LATCH | 16 | split-f16 training step: a step whose activations leave the f16 range is recomputed in fp32 and the NEXT step tries split-f16 again (`model._h2_range_trips` counts the trips); this many trips IN A ROW latch the model to fp32 (each trip costs a second forward) |
@@ -36,7 +35,6 @@ class Options:
     wide_filter_tiles: bool = True
     fused_step_tail: bool = True
     fused_encoder: bool = True
-    pingpong: object = False
     train: str = "fused"
     train_gemm: str = "h2"
     train_fallback_latch: int = 16
@@ -47,8 +45,6 @@ class Options:
         o = cls(gemm=os.environ.get("TSDIFF_GEMM", "h2"), typed_tiles=_flag("TSDIFF_TYPED_TILES"),
                 one_launch=_flag("TSDIFF_ONE_LAUNCH"), wide_filter_tiles=_flag("TSDIFF_WIDE_FILTER_TILES"),
                 fused_step_tail=_flag("TSDIFF_FUSED_TAIL"), fused_encoder=_flag("TSDIFF_FUSED_ENCODER"),
-                pingpong={"0": False, "solo": "solo", "teams": "teams", "1": "teams"}.get(
-                    os.environ.get("TSDIFF_PINGPONG", "0"), False),
                 train=os.environ.get("TSDIFF_TRAIN", "fused"), train_gemm=os.environ.get("TSDIFF_TRAIN_GEMM", "h2"),
                 train_fallback_latch=int(os.environ.get("TSDIFF_TRAIN_FALLBACK_LATCH", "16")),
                 train_side_lane=_flag("TSDIFF_TRAIN_SIDE_LANE"))
