@@ -72,20 +72,24 @@ def test_split_planes_reproduce_fp32_values_of_products(dev):
 
 
 def test_train_drift_h2_within_fp32_noise(dev):
-    """50 optimizer steps from one initialisation over the same batches / time steps / noise in three arithmetics
-    (tools/train_drift.py): the split-f16 training's parameter distance from the fp32 training stays within 2 x the distance
-    of a second fp32 training that differs by summation order only (op-by-op autograd form) -- plus a floor for the case
-    that the two fp32 trainings agree to the last bits"""
+    """50 optimizer steps at batch 200 from one initialisation over the same batches / time steps / noise in three
+    arithmetics (tools/train_drift.py; the 300-step table is profiles/r05_train_drift.md): after 50 steps the split-f16
+    training's parameter distance from the fp32 training is within 2 x the distance of a second fp32 training that differs
+    by summation order only (op-by-op autograd form; measured ratio 1.4-1.5) -- both five orders of magnitude below the
+    distance the parameters travel -- and the loss curves agree to 1e-4"""
     from tools.train_drift import drift
     from tsdiff_amd import synth
-    rows, trips, moved, res = drift(50, 48, 10, dev, synth.DEFAULT_MODEL_CONFIG)
+    rows, trips, moved, res = drift(50, 200, 25, dev, synth.DEFAULT_MODEL_CONFIG)
     assert trips == 0
-    assert moved > 1e-4, "the parameters did not move: the run proves nothing"
+    assert moved > 1e-3, "the parameters did not move: the run proves nothing"
     for s, lf, lh, lo, dh, do in rows:
+        print(f"step {s}: loss f32 {lf:.6g} h2 {lh:.6g} ops {lo:.6g}; h2 vs f32 {dh:.3e}, ops vs f32 {do:.3e}")
         if s == 0:
             assert dh == 0.0 and do == 0.0
             continue
         assert np.isfinite(lh) and np.isfinite(lf)
-        assert dh <= 2.0 * do + 1e-6 * moved, f"step {s}: h2 {dh:.3e} vs fp32 re-association {do:.3e}"
+        assert dh <= 1e-4 * moved and do <= 1e-4 * moved
+    s, lf, lh, lo, dh, do = rows[-1]
+    assert s == 50 and dh <= 2.0 * do + 1e-7, f"h2 {dh:.3e} vs fp32 re-association {do:.3e}"
     lf, lh = np.array(res["f32"][0]), np.array(res["h2"][0])
-    assert float(np.max(np.abs(lh - lf) / np.abs(lf))) < 1e-3
+    assert float(np.max(np.abs(lh - lf) / np.abs(lf))) < 1e-4

@@ -596,6 +596,13 @@ int tsd_interaction_block(const tsd_model_cfg* cfg, const float* w, int32_t laye
     return interaction_block_impl(0, nullptr, cfg, w, layer, num_nodes, enc, Wf_layer, x1_in, h, x1_out, filter_layer,
                                   capacity_u, enc_u, edge_attr, Wf_out, stream);
 }
+int tsd_attr_planes(int32_t hidden, int64_t rows, const float* edge_attr, float* edge_attr16, void* stream) {
+    TraceRange range("tsd:attr_planes");
+    TSD_REQUIRE(rows >= 0 && (rows == 0 || (edge_attr && edge_attr16)), "null pointer");
+    TSD_REQUIRE(edge_attr != edge_attr16, "in-place conversion is not supported");
+    return launch_attr_planes(hidden, rows, edge_attr, edge_attr16, (hipStream_t)stream);
+}
+
 int tsd_interaction_block16(const tsd_model_cfg* cfg, const float* w16, int32_t layer, int32_t num_nodes, tsd_edges enc,
                             const float* Wf_layer, const float* x1_in, float* h, float* x1_out, int32_t filter_layer,
                             int32_t capacity_u, tsd_edges enc_u, const float* edge_attr, float* Wf_out,

@@ -175,6 +175,15 @@ struct UmapRole {
 // points, fallback), PREC_H2 = split-f16 operands on the f16 MFMA pipes (split16.hpp; the inference forward's default).
 // A PREC_H2 launch takes the f16-plane weight arena (tsd_pack_weights16) where the fp32 one is documented, and a device
 // word that receives TSD_STATUS_RANGE when an operand left the f16 range.
+// ATTRIBUTE ROWS AS f16 PLANES (round 5).  The split-f16 embedding launch (kernels_typed.hip) writes a row of the edge
+// attribute matrix not as H floats but as the two f16 planes its consumers need -- bytes [0, 2H): the high plane,
+// [2H, 4H): the low plane scaled by 2^11 (split16.hpp), the same 4 H bytes -- so that the filter tiles of every block, the
+// fused encoder's tiles and the pair tiles copy 16-byte chunks straight into their LDS planes instead of converting the same
+// fp32 row L + 1 times per forward (the conversion was 10 % of a fused-encoder tile).  The planes hold exactly what the
+// consumers computed before: results are bit-identical.  The range / low-side checks of these rows moved to the producer.
+// Every INFERENCE role of the split-f16 arithmetic (filter_role_h, pair_role_h, the unit encoder) takes plane rows; the
+// saving (training) forms, the fp32 kernels and the fp32 piecewise entry points keep fp32 rows; tsd_attr_planes converts
+// an fp32 attribute matrix for the piecewise split-f16 entry point tsd_interaction_block16.
 enum : int { PREC_F32 = 0, PREC_H2 = 1 };
 struct Prec {
     int mode = PREC_F32;
@@ -268,6 +277,7 @@ int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity,
                          size_t ea_stride, size_t inv_stride, hipStream_t st, bool folded, int32_t* range_status,
                          const PairSave* save = nullptr);
 int launch_pack_weights16(const tsd_model_cfg& c, const float* packed, float* packed16, hipStream_t st);
+int launch_attr_planes(int H, int64_t rows, const float* src, float* dst, hipStream_t st);
 int launch_weights_preflight(const float* w, size_t n, float* out8, hipStream_t st);
 // the whole split-f16 forward of one checkpoint as ONE launch (kernels_combo.hip, small batches)
 int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float* pos, const float* W16, float* ea, float* wf,

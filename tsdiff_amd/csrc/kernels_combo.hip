@@ -129,14 +129,14 @@ struct VRow<1> {
 // TR: rows of the tile that are aggregated (default TN; the one-launch forward's node workgroups take 8: rows TR .. TN - 1
 // of the LDS tile are then not written here).
 template <int H, bool SAVE, int NW = 2 * H / 64 /* waves of the workgroup */, int U = 8 /* edges in flight per wave */,
-          bool SPLIT = false, bool SC1 = false, int TR = TN>
+          bool SPLIT = false, bool SC1 = false, int TR = TN, int PROWS = TN /* rows of the LDS tile (planes) */>
 __device__ __forceinline__ void aggregate_tile(const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ dst,
                                                const int32_t* __restrict__ umap, const float* __restrict__ Wf,
                                                const float* __restrict__ x, int N, int n0, float* buf,
                                                float* __restrict__ save, float* amax = nullptr) {
     constexpr int LDA = H + 4;
     constexpr int LDH = ldh_of(H);
-    const Planes pl = planes_at(buf, TN, LDH);
+    const Planes pl = planes_at(buf, PROWS, LDH);
     float amx = 0.0f;
     // (the asm loads below take these through "s" operands: wave-uniform as the compiler can see it, split16.hpp)
     dst = reinterpret_cast<const int32_t*>(uniform_ptr(dst));
@@ -145,7 +145,7 @@ __device__ __forceinline__ void aggregate_tile(const int32_t* __restrict__ row_p
     x = reinterpret_cast<const float*>(uniform_ptr(x));
     constexpr int RPW = TR / NW;  // rows aggregated per wave
     constexpr int V = H / 64;     // channels per lane during aggregation
-    static_assert(TR % NW == 0 && TR <= TN, "");
+    static_assert(TR % NW == 0 && TR <= PROWS, "");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // The RPW rows of this wave are consecutive, so their edges are ONE contiguous CSR range
     // [rp[first], rp[first + RPW]): one load of the RPW + 1 row offsets, one coalesced load of the indices per
@@ -1013,6 +1013,133 @@ __device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float*
     range_report(amax, range_status);
 }
 
+// The node role on WIDE tiles (NRB 16-row blocks per workgroup; round 5): in a launch that is many chip-fulls deep -- the
+// block launches of an 8-checkpoint ensemble carry 800 node tiles beside 1632 filter tiles -- a 16-row node tile streams
+// the three 256-KiB weight images of the chain through its CU for 16 rows of work and holds a workgroup slot for as long as
+// a 64-row filter tile does (profiles/r05_kernel_stats_ens8_base.md: the node tiles take as much slot time as the filter
+// tiles).  Here a weight fragment of the ring feeds NRB row blocks (the unit encoder's hgemm16_ring_run_rb) and a wave
+// gathers 2 NRB consecutive rows in one pass over its contiguous edge range.  Same arithmetic per row and element as
+// node_role_h (transposed accumulators): bit-identical; inference only.  The small-launch forms keep 16 rows: there the
+// chain's latency, not its slot time, is what counts.
+template <int H, int NRB>
+__device__ __forceinline__ void node_role_hw(const ComboNode& a, int tile, float* smem, int32_t* range_status) {
+    constexpr int LDH = ldh_of(H), TNR = TN * NRB;
+    constexpr int NT = 2 * H, CB16 = 2, C4 = H / 4;
+    const Planes pl = planes_at(smem, TNR, LDH);
+    float* s_bias = smem + TNR * LDH;  // [2][H]
+    const int n0 = tile * TNR;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, q = lane >> 4, l15 = lane & 15;
+    const int col0 = wave * 32;
+    const int nrows = min(TNR, a.N - n0);
+    const int nrb = (nrows + TN - 1) / TN;  // row blocks that hold atoms (uniform)
+    f32x4 accm[NRB][CB16], accx[NRB][CB16];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    float amax = 0.0f;
+    constexpr int RW = 2;  // ring depth (a throughput role beside other resident workgroups; 3 does not fit 128 VGPRs here)
+    HRing<CB16, RW> rg;
+    auto zero_acc4 = [&]() {
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < CB16; ++cb) accm[rb][cb] = accx[rb][cb] = zero4;
+    };
+    if (a.mode == 0) {
+        f32x4 h4[NRB][CB16];
+        float bl2 = 0.0f, bl = 0.0f;
+        if (tid < H) {
+            bl2 = a.lin2_b[tid];
+            bl = a.lin_b[tid];
+        }
+        aggregate_tile<H, false, 2 * H / 64, 8, true, false, TNR, TNR>(a.row_ptr, a.dst, a.umap, a.Wf, a.x1_in, a.N, n0, smem,
+                                                                      nullptr, &amax);
+        if (tid < H) {
+            s_bias[tid] = bl2;
+            s_bias[H + tid] = bl;
+        }
+        hgemm16_ring_start<CB16, H, RW>(rg, a.lin2_w, H, col0);
+        __syncthreads();
+        zero_acc4();
+        hgemm16_ring_run_rb<NRB, CB16, H, true, RW>(rg, pl, LDH, accm, accx, nrb);
+        hgemm16_ring_start<CB16, H, RW>(rg, a.lin_w, H, col0);
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) {
+            const int c = col0 + cb * 16 + q * 4;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(s_bias + c);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+                if (rb < nrb) {
+                    f32x4 y4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y4[r] = sspf(hval4(accm[rb][cb], accx[rb][cb], r) + b[r]);
+                    planes_store4(pl, (rb * TN + l15) * LDH + c, y4, amax);
+                }
+        }
+        __syncthreads();
+        // (the residual rows are requested here, not before the gather: they arrive under this GEMM, and the role has no
+        // registers to hold them across the first one)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < CB16; ++cb)
+                h4[rb][cb] = rb * TN + l15 < nrows
+                                 ? *reinterpret_cast<const f32x4*>(a.h_in + (size_t)(n0 + rb * TN + l15) * H + col0 + cb * 16 + q * 4)
+                                 : zero4;
+        zero_acc4();
+        hgemm16_ring_run_rb<NRB, CB16, H, true, RW>(rg, pl, LDH, accm, accx, nrb);
+        if (a.lin1_next_w != nullptr) hgemm16_ring_start<CB16, H, RW>(rg, a.lin1_next_w, H, col0);
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < CB16; ++cb) {
+            const int c = col0 + cb * 16 + q * 4;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(s_bias + H + c);
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+                if (rb < nrb) {
+                    const int row = rb * TN + l15;
+                    f32x4 hn = zero4;
+                    if (row < nrows) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) hn[r] = h4[rb][cb][r] + (hval4(accm[rb][cb], accx[rb][cb], r) + b[r]);
+                        *reinterpret_cast<f32x4*>(a.h + (size_t)(n0 + row) * H + c) = hn;
+                    }
+                    planes_store4(pl, row * LDH + c, hn, amax);
+                }
+        }
+        if (a.lin1_next_w == nullptr) {
+            range_report(amax, range_status);
+            return;
+        }
+        __syncthreads();
+    } else {
+        hgemm16_ring_start<CB16, H, RW>(rg, a.lin1_next_w, H, col0);
+        float site_m = 0.0f;
+        for (int idx = tid; idx < TNR * C4; idx += NT) {
+            const int r = idx / C4, c4 = idx % C4;
+            f32x4 v = zero4;
+            if (r < nrows) v = *reinterpret_cast<const f32x4*>(a.h_in + (size_t)(n0 + r) * H + c4 * 4);
+            planes_store4(pl, r * LDH + c4 * 4, v, site_m);
+        }
+        site_close(amax, site_m);
+        __syncthreads();
+    }
+    zero_acc4();
+    hgemm16_ring_run_rb<NRB, CB16, H, true, RW>(rg, pl, LDH, accm, accx, nrb);
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+        if (rb < nrb && rb * TN + l15 < nrows) {
+#pragma unroll
+            for (int cb = 0; cb < CB16; ++cb) {
+                f32x4 x4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x4[r] = hval4(accm[rb][cb], accx[rb][cb], r);
+                *reinterpret_cast<f32x4*>(a.x1_out + (size_t)(n0 + rb * TN + l15) * H + col0 + cb * 16 + q * 4) = x4;
+            }
+        }
+    range_report(amax, range_status);
+}
+
 // RB = 32-row blocks of one tile: 1 in the small launches (more, shorter tiles), 2 where a launch is many chip-fulls
 // of filter tiles (a weight fragment from the ring then feeds two row blocks: the tile is bound by the weight feed).
 template <int H, int RB, bool SAVE = false>
@@ -1076,6 +1203,14 @@ __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, fl
         }
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) ld16_wait4(v[rb]);
+        if constexpr (!SAVE) {   // the rows ARE the planes (common.hpp ATTRIBUTE ROWS AS f16 PLANES; checked where they were written): 16-byte copies
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                planes_put_chunk<H>(pl, r * LDH, c4, r < nrows ? v[it / 4][it % 4] : z);
+            }
+        } else {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
@@ -1083,6 +1218,7 @@ __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, fl
             planes_store4(pl, r * LDH + c4 * 4, r < nrows ? v[it / 4][it % 4] : z, site_m);
         }
         site_close(amax, site_m);
+        }
     }
     __syncthreads();
     TSD_TRACE_AT(1);
@@ -1224,6 +1360,13 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
             ld16_sc1(v[it], q.edge_attr + (size_t)s_row[r] * H + c4 * 4);
         }
         ld16_wait4(v);
+        if constexpr (!SAVE) {   // (rows stored as f16 planes: common.hpp ATTRIBUTE ROWS AS f16 PLANES)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+                planes_put_chunk<H>(pl, r * LDH, c4, v[it]);
+            }
+        } else {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
@@ -1233,6 +1376,7 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
             }
         }
         site_close(amax, site_m);
+        }
         hgemm_ring_start<1, H>(rg, q.w0b, H, col0);  // (behind the staging: its registers are free now)
         __syncthreads();
         hzero(accm, accx);
@@ -1878,7 +2022,8 @@ constexpr int NODE_RUN = 4;  // consecutive node tiles kept on one XCD (one 64-a
 // PREC: PREC_F32 = fp32-input MFMA roles; PREC_H2 = the split-f16 roles (SAVE form: the training step's block launches,
 // and no pre role: the piecewise pair output computes both halves itself).
 // FRB: 32-row blocks per filter tile of the split-f16 filter role (filter_role_h).
-template <int H, bool SAVE, bool TAIL, int PREC = PREC_F32, int FRB = 1>
+// NRB: 16-row blocks per node tile of the split-f16 node role (1: node_role_h; 2: node_role_hw, chip-full launches).
+template <int H, bool SAVE, bool TAIL, int PREC = PREC_F32, int FRB = 1, int NRB = 1>
 __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int node_tiles, ComboFilter f,
                                                             ComboStride sd, ComboPre q, FilterSave fsv,
                                                             NodeSave ns TSD_TRACE_ARG) {
@@ -1929,7 +2074,8 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
         // they share a SIMD with
         __builtin_amdgcn_s_setprio(3);
         TSD_TRACE_REAL(24);
-        if constexpr (PREC == PREC_H2) node_role_h<H, SAVE>(a, tile, smem, sd.range_status, ns TSD_TRACE_PASS);
+        if constexpr (PREC == PREC_H2 && NRB > 1) node_role_hw<H, NRB>(a, tile, smem, sd.range_status);
+        else if constexpr (PREC == PREC_H2) node_role_h<H, SAVE>(a, tile, smem, sd.range_status, ns TSD_TRACE_PASS);
         else node_role<H, SAVE>(a, tile, smem, ns TSD_TRACE_PASS);
         TSD_TRACE_REAL(25);
     } else {
@@ -2021,9 +2167,9 @@ int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity,
     return TSD_OK;
 }
 
-static inline size_t lds_combo(int H, int prec, int frb = 1) {
+static inline size_t lds_combo(int H, int prec, int frb = 1, int nrb = 1) {
     const int ld = prec == PREC_H2 ? ldh_of(H) : H + 4;  // floats per tile row (two f16 planes of H + 8 = H + 8 floats)
-    const size_t node = (size_t)TN * ld * 4 + (prec == PREC_H2 ? (size_t)2 * H * 4 : 0);  // (+ the transposed form's biases)
+    const size_t node = (size_t)TN * nrb * ld * 4 + (prec == PREC_H2 ? (size_t)2 * H * 4 : 0);  // (+ the transposed form's biases)
     const size_t filt = (size_t)(T * ld + T) * 4 * frb + (prec == PREC_H2 ? (size_t)2 * H * 4 : 0);  // (+ the transposed form's biases)
     const size_t pair = (size_t)(T * ld + (H / 64) * T + 3 * T) * 4;  // pair role (H >= 64)
     return node > filt ? (node > pair ? node : pair) : (filt > pair ? filt : pair);
@@ -2705,9 +2851,21 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
         f.wf_layer_stride = (size_t)capacity_u * c.hidden;
         f.wf_slots = wf_slots < 1 ? 1 : wf_slots;
     }
-    const int node_tiles = layer == -2 ? 0 : (N + TN - 1) / TN;
     ComboPre q{};
     if (pre && pre->tiles > 0) q = *pre;
+    // Wide node tiles (32 rows: node_role_hw) where the launch's node tiles alone are a chip-full of workgroup slots: their
+    // slot time, not the chain's latency, is what the launch pays for.  Inference form of the production width, ONE
+    // checkpoint: measured (tools/ab_step.py) 600 graphs 0.942 -> 0.920 ms/step, but an 8-checkpoint ensemble at batch 100
+    // 1.405 -> 1.454 -- eight weight sets do not stay in an XCD's L2 and the shallower weight ring of the wide role
+    // (two k-steps in flight: three do not fit 128 VGPRs) then shows.
+    int nrb = 1;
+#ifndef TSD_NODE_WIDE_MIN
+#define TSD_NODE_WIDE_MIN 512  // 16-row node tiles (x checkpoints) of a launch from which they are 32 rows; 0: never
+#endif
+    if (prec.mode == PREC_H2 && c.hidden == 256 && !fsave && !nsave && q.tiles == 0 && layer != -2 && TSD_NODE_WIDE_MIN > 0 &&
+        !prec.narrow_filter_tiles && M == 1 && (N + TN - 1) / TN >= TSD_NODE_WIDE_MIN)
+        nrb = 2;
+    const int node_tiles = layer == -2 ? 0 : (N + TN * nrb - 1) / (TN * nrb);
     if (q.pair) a.ready = q.ready;  // the node role of this launch publishes h to the pair tiles
     // Whole layers of filter tiles, many chip-fulls of them (big batches / ensembles): 64-row tiles.  A weight fragment
     // of the ring then feeds two row blocks, and the launch is bound by that feed.
@@ -2723,7 +2881,7 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     }
     const int grid = node_tiles + f.tiles + q.tiles;
     if (grid == 0) return TSD_OK;
-    const size_t lds = lds_combo(c.hidden, prec.mode, frb);
+    const size_t lds = lds_combo(c.hidden, prec.mode, frb, nrb);
     // interleave only when the launch is many chip-fulls deep (the node tiles alone over-subscribe the chip)
     int node_stride = 1;
     if (node_tiles >= 1024 && grid >= 3 * node_tiles) {
@@ -2740,18 +2898,20 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
 #else
 #define TSD_TRACE_HOST
 #endif
-#define TSD_COMBO_I(HH, SV, TL, PR, FR)                                                                     \
+#define TSD_COMBO_I(HH, SV, TL, PR, FR, ...)                                                                \
     {                                                                                                       \
         static DeviceOnce once;                                                                             \
-        int r = allow_lds(layer_combo_kernel<HH, SV, TL, PR, FR>, lds, once);                               \
+        int r = allow_lds(layer_combo_kernel<HH, SV, TL, PR, FR, ##__VA_ARGS__>, lds, once);                \
         if (r) return r;                                                                                    \
-        hipLaunchKernelGGL((layer_combo_kernel<HH, SV, TL, PR, FR>), dim3(grid, M), dim3(2 * HH), lds, st, a, node_tiles, f, \
-                           sd, q, fsv, nsv TSD_TRACE_HOST);                                                 \
+        hipLaunchKernelGGL((layer_combo_kernel<HH, SV, TL, PR, FR, ##__VA_ARGS__>), dim3(grid, M), dim3(2 * HH), lds, st, a, \
+                           node_tiles, f, sd, q, fsv, nsv TSD_TRACE_HOST);                                  \
     }
 #define TSD_COMBO(HH)                                                                                       \
     if (prec.mode == PREC_H2) {                                                                             \
         if (save) TSD_COMBO_I(HH, true, false, PREC_H2, 1)                                                  \
         else if (q.tiles > 0) TSD_COMBO_I(HH, false, true, PREC_H2, 1)                                      \
+        else if (nrb == 2 && HH == 256 && frb == 2) TSD_COMBO_I(256, false, false, PREC_H2, 2, 2)           \
+        else if (nrb == 2 && HH == 256) TSD_COMBO_I(256, false, false, PREC_H2, 1, 2)                       \
         else if (frb == 2) TSD_COMBO_I(HH, false, false, PREC_H2, 2)                                        \
         else TSD_COMBO_I(HH, false, false, PREC_H2, 1)                                                      \
     } else if (save) TSD_COMBO_I(HH, true, false, PREC_F32, 1)                                              \

@@ -64,47 +64,6 @@ struct UnitArgs {
 #define TSD_UNIT_TRANS 1
 #endif
 
-// 16-row MFMA GEMM on RB16 row blocks sharing the weight ring (split16.hpp hgemm16_ring_run per row block: the same MFMA
-// sequence per output element)
-template <int RB16, int CB, int K, bool TRANS = false>
-__device__ __forceinline__ void hgemm16_ring_run_rb(HRing<CB, HRING16_R>& r, const Planes& A, int ldh, f32x4 (&accm)[RB16][CB],
-                                                    f32x4 (&accx)[RB16][CB], int nrb /* row blocks that hold rows (uniform) */) {
-    constexpr int R = HRING16_R, KS = K / 32;
-    const int lane = threadIdx.x & 63;
-    const int aoff = (lane & 15) * ldh + (lane >> 4) * 8;
-    static_for<0, KS>([&](auto ksc) {
-        constexpr int ks = decltype(ksc)::value;
-        constexpr int slot = ks % R;
-        constexpr int younger = ((ks + R <= KS) ? R : KS - ks) - 1;
-        f32x4 ah[RB16], al[RB16];
-#pragma unroll
-        for (int rb = 0; rb < RB16; ++rb)
-            if (rb < nrb) {
-                ah[rb] = *reinterpret_cast<const f32x4*>(A.hi + aoff + rb * 16 * ldh + ks * 32);
-                al[rb] = *reinterpret_cast<const f32x4*>(A.lo + aoff + rb * 16 * ldh + ks * 32);
-            }
-        hring_wait<younger * CB * 2, CB>(r.b[slot]);
-#pragma unroll
-        for (int rb = 0; rb < RB16; ++rb)
-            if (rb < nrb) {
-#pragma unroll
-                for (int cb = 0; cb < CB; ++cb) {
-                    if constexpr (TRANS) {
-                        accx[rb][cb] = mfma_h16(r.b[slot][cb][1], ah[rb], accx[rb][cb]);
-                        accm[rb][cb] = mfma_h16(r.b[slot][cb][0], ah[rb], accm[rb][cb]);
-                        accx[rb][cb] = mfma_h16(r.b[slot][cb][0], al[rb], accx[rb][cb]);
-                    } else {
-                        accx[rb][cb] = mfma_h16(ah[rb], r.b[slot][cb][1], accx[rb][cb]);
-                        accm[rb][cb] = mfma_h16(ah[rb], r.b[slot][cb][0], accm[rb][cb]);
-                        accx[rb][cb] = mfma_h16(al[rb], r.b[slot][cb][0], accx[rb][cb]);
-                    }
-                }
-            }
-        if constexpr (ks + R < KS)
-            hring_issue<CB>(r.b[slot], r.base + (size_t)(ks + R) * r.step_bytes, r.voff, r.plane_bytes, r.cb_bytes);
-    });
-}
-
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Phase trace (variant builds only: tools/build_variant.sh utrace "-DTSD_UNIT_TRACE" kernels_unit.hip; tools/trace_unit.py):
@@ -299,16 +258,16 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
             auto phases = [&](auto rbc) {
                 constexpr int RB = decltype(rbc)::value;
                 HRing<1, HRING_R> rg;
-                {   // (a) attribute tile -> planes (rows that are no pair: zeros)
+                {   // (a) attribute tile -> planes (rows that are no pair: zeros).  The rows hold the two f16 planes already
+                    // (common.hpp ATTRIBUTE ROWS AS f16 PLANES; range / low-side checks where they were written): lane = 16-byte chunk
+                    // of the row, lanes 0-31 the high plane -- one LDS store per row, no conversion
                     TSD_UNIT_GEOM
-                    float site_m = 0.0f;  // (max |a| of this conversion site: split16.hpp site_close)
 #pragma unroll
                     for (int it = 0; it < NIT * RB / 2; ++it) {
                         const int r = wave + it * (NT / 64);
                         const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
-                        planes_store4(pl, r * LDH + lane * 4, (vlive >> it & 1u) ? v[it] : zz, site_m);
+                        planes_put_chunk<H>(pl, r * LDH, lane, (vlive >> it & 1u) ? v[it] : zz);
                     }
-                    site_close(amax, site_m);
                     hgemm_ring_start<1, H>(rg, nn0_w, H, col0);
 #ifdef TSD_UNIT_WFAKE  // (timing experiment, wrong results: every k-step reads the same 2 KB per wave -- weights from L1)
                     rg.step_bytes = 0;

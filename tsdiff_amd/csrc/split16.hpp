@@ -98,6 +98,14 @@ __device__ __forceinline__ void planes_store4(const Planes& p, int off, const f3
     *reinterpret_cast<f16x4*>(p.hi + off) = h;
     *reinterpret_cast<f16x4*>(p.lo + off) = l;
 }
+// A row of H values stored as planes in memory (common.hpp ATTRIBUTE ROWS AS f16 PLANES): chunk c (16 bytes, c < H / 4) of the row holds 8 f16 of
+// the high plane (c < H / 8: k = 8 c ..) or of the low plane (k = 8 (c - H / 8) ..).  Copy one chunk into the LDS planes.
+template <int H>
+__device__ __forceinline__ void planes_put_chunk(const Planes& p, int row_off /* r * ldh */, int c, const f32x4& v) {
+    // (one address: hi + row + chunk, the low plane `lo - hi` elements further)
+    f16* dst = p.hi + row_off + (c & (H / 8 - 1)) * 8 + (c >= H / 8 ? (int)(p.lo - p.hi) : 0);
+    *reinterpret_cast<f32x4*>(dst) = v;
+}
 // LOW side of the range.  An operand below 2^-14 has a subnormal high plane; its value is then carried by the scaled low
 // plane with an ABSOLUTE precision of 2^-36 = 1.5e-11 instead of 22 relative bits, i.e. worse than fp32's 2^-24 relative
 // below |a| = 2^-12 = 2.4e-4.  Single such elements do not matter (their absolute error drowns in the sum); a tensor whose
@@ -300,8 +308,8 @@ __device__ __forceinline__ float hval(const f32x16& m, const f32x16& x, int r) {
 // ---- 16-row blocks: v_mfma_f32_16x16x32_f16 (node tiles).  A lane l: row l & 15, k = 8 (l >> 4) .. + 7 of a 32-k step;
 // B lane l: column l & 15, the same k; C/D: col = l & 15, row = (l >> 4) * 4 + r.  One 32-k step = two 16-k steps of the
 // packed image: lane quarter q takes k-step 2 s + (q >> 1), half q & 1.  CB = 16-wide column blocks of this wave.
-template <int CB, int K>
-__device__ __forceinline__ void hgemm16_ring_start(HRing<CB, HRING16_R>& r, const float* __restrict__ Bp16, int nout, int col0) {
+template <int CB, int K, int R = HRING16_R>
+__device__ __forceinline__ void hgemm16_ring_start(HRing<CB, R>& r, const float* __restrict__ Bp16, int nout, int col0) {
     const int lane = threadIdx.x & 63, q = lane >> 4;
     r.base = uniform_ptr(Bp16);
     r.voff = (unsigned)((q >> 1) * 64 * nout + ((q & 1) * nout + col0 + (lane & 15)) * 16);
@@ -309,7 +317,7 @@ __device__ __forceinline__ void hgemm16_ring_start(HRing<CB, HRING16_R>& r, cons
     r.plane_bytes = 32 * nout;
     r.cb_bytes = 16 * 16;
     constexpr int KS = K / 32;
-    static_for<0, (HRING16_R < KS ? HRING16_R : KS)>([&](auto i) {
+    static_for<0, (R < KS ? R : KS)>([&](auto i) {
         constexpr int I = decltype(i)::value;
         hring_issue<CB>(r.b[I], r.base + (size_t)I * r.step_bytes, r.voff, r.plane_bytes, r.cb_bytes);
     });
@@ -344,6 +352,47 @@ __device__ __forceinline__ void hgemm16_ring_run(HRing<CB, HRING16_R>& r, const 
             hring_issue<CB>(r.b[slot], r.base + (size_t)(ks + R) * r.step_bytes, r.voff, r.plane_bytes, r.cb_bytes);
     });
 }
+// 16-row MFMA GEMM on RB16 row blocks sharing the weight ring (split16.hpp hgemm16_ring_run per row block: the same MFMA
+// sequence per output element)
+template <int RB16, int CB, int K, bool TRANS = false, int R = HRING16_R>
+__device__ __forceinline__ void hgemm16_ring_run_rb(HRing<CB, R>& r, const Planes& A, int ldh, f32x4 (&accm)[RB16][CB],
+                                                    f32x4 (&accx)[RB16][CB], int nrb /* row blocks that hold rows (uniform) */) {
+    constexpr int KS = K / 32;
+    const int lane = threadIdx.x & 63;
+    const int aoff = (lane & 15) * ldh + (lane >> 4) * 8;
+    static_for<0, KS>([&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value;
+        constexpr int slot = ks % R;
+        constexpr int younger = ((ks + R <= KS) ? R : KS - ks) - 1;
+        f32x4 ah[RB16], al[RB16];
+#pragma unroll
+        for (int rb = 0; rb < RB16; ++rb)
+            if (rb < nrb) {
+                ah[rb] = *reinterpret_cast<const f32x4*>(A.hi + aoff + rb * 16 * ldh + ks * 32);
+                al[rb] = *reinterpret_cast<const f32x4*>(A.lo + aoff + rb * 16 * ldh + ks * 32);
+            }
+        hring_wait<younger * CB * 2, CB>(r.b[slot]);
+#pragma unroll
+        for (int rb = 0; rb < RB16; ++rb)
+            if (rb < nrb) {
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    if constexpr (TRANS) {
+                        accx[rb][cb] = mfma_h16(r.b[slot][cb][1], ah[rb], accx[rb][cb]);
+                        accm[rb][cb] = mfma_h16(r.b[slot][cb][0], ah[rb], accm[rb][cb]);
+                        accx[rb][cb] = mfma_h16(r.b[slot][cb][0], al[rb], accx[rb][cb]);
+                    } else {
+                        accx[rb][cb] = mfma_h16(ah[rb], r.b[slot][cb][1], accx[rb][cb]);
+                        accm[rb][cb] = mfma_h16(ah[rb], r.b[slot][cb][0], accm[rb][cb]);
+                        accx[rb][cb] = mfma_h16(al[rb], r.b[slot][cb][0], accx[rb][cb]);
+                    }
+                }
+            }
+        if constexpr (ks + R < KS)
+            hring_issue<CB>(r.b[slot], r.base + (size_t)(ks + R) * r.step_bytes, r.voff, r.plane_bytes, r.cb_bytes);
+    });
+}
+
 template <int CB, int K>
 __device__ __forceinline__ void hgemm16_tile(const Planes& A, int ldh, const float* __restrict__ Bp16, int nout, int col0,
                                              f32x4 (&accm)[CB], f32x4 (&accx)[CB]) {

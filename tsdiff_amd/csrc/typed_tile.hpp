@@ -21,7 +21,7 @@ struct TypedEmbedW {
 
 // One tile of the embedding launch on the f16 MFMA pipes (PREC_H2, split16.hpp): `w.bucket` and the block-0 filter weights come from the
 // f16-plane arenas (tsd_bucket_weights16 / tsd_pack_weights16), the operand tiles live in LDS as two f16 planes, the
-// finished rows are staged as fp32 for the 1-KiB row stores.  Inputs and outputs in memory are the fp32 ones.
+// attribute rows leave as f16 planes (common.hpp ATTRIBUTE ROWS AS f16 PLANES), block 0's filter rows as fp32.
 template <int H, bool FUSE0>
 __device__ __forceinline__ void typed_embed_tile_h(const TypedEmbedW& w, const TypedList& ta, const TypedList& tb, int bx,
                                                    size_t m, const float* __restrict__ pos,
@@ -111,9 +111,13 @@ __device__ __forceinline__ void typed_embed_tile_h(const TypedEmbedW& w, const T
         if (fuse) hgemm_ring_start<1, H>(rg, nn0_w, H, col0);
     }
     __syncthreads();
+    // s1 goes to the LDS planes -- the operand of block 0's filter GEMM on this tile, and the FORM the attribute rows are
+    // stored in (common.hpp ATTRIBUTE ROWS AS f16 PLANES: every consumer wants the two f16 planes, so the row is converted once, here, with the
+    // range and low-side checks of split16.hpp: a lane holds 16 channels of one row = one conversion site)
     if constexpr (TR) {
         const float* bb = s_bias + col0 + 4 * hi;
         f32x4 bn = *reinterpret_cast<const f32x4*>(bb);
+        float site_m = 0.0f;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             const f32x4 bv = bn;
@@ -121,28 +125,25 @@ __device__ __forceinline__ void typed_embed_tile_h(const TypedEmbedW& w, const T
             f32x4 v4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v4[r] = swishf(hval(accm[0][0], accx[0][0], 4 * g4 + r) + bv[r]);
-            *reinterpret_cast<f32x4*>(stage + l31 * LDA + col0 + 8 * g4 + 4 * hi) = v4;
-            if constexpr (FUSE0) {
-                if (fuse) planes_store4(pl, l31 * LDH + col0 + 8 * g4 + 4 * hi, v4, amax);
-            }
+            planes_store4(pl, l31 * LDH + col0 + 8 * g4 + 4 * hi, v4, site_m);
         }
+        if (l31 < nrows && s_row[l31] >= 0) site_close(amax, site_m);  // (rows that are no edge now are dropped)
     } else
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = acc_row(r, hi);
-        const float v = swishf(hval(accm[0][0], accx[0][0], r) + bias_t);
-        stage[row * LDA + col] = v;
-        if constexpr (FUSE0) {
-            if (fuse) planes_store1(pl, row * LDH + col, v, amax);
-        }
+        planes_store1(pl, row * LDH + col, swishf(hval(accm[0][0], accx[0][0], r) + bias_t), amax);
     }
     __syncthreads();
-    // s1 is the attribute tile: whole 1-KiB rows to the rows of the edges the pairs are at this step
+    // the attribute tile: whole 1-KiB rows -- 512 bytes of the high plane, 512 of the low one -- to the rows of the edges the
+    // pairs are at this step
     for (int idx = tid; idx < nrows * C4; idx += NT) {
         const int r = idx / C4, c4 = idx % C4;
         const int row = s_row[r];
-        if (row >= 0)
-            store_stream16(edge_attr + (size_t)row * H + c4 * 4, *reinterpret_cast<const f32x4*>(stage + r * LDA + c4 * 4));
+        if (row >= 0) {
+            const f16* src = (c4 < C4 / 2 ? pl.hi : pl.lo) + r * LDH + (c4 & (C4 / 2 - 1)) * 8;
+            store_stream16(edge_attr + (size_t)row * H + c4 * 4, *reinterpret_cast<const f32x4*>(src));
+        }
     }
     if constexpr (FUSE0) {
         if (!fuse) {
