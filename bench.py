@@ -92,6 +92,9 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true",
                     help="train workload only: the next batch's topology is built inside its get_loss (the default "
                          "builds it on a side stream during the current step, model.prefetch_batch)")
+    ap.add_argument("--single-range-reduce", action="store_true",
+                    help="train workload only: ONE all-reduce of the flat gradient behind the backward pass instead of three "
+                         "ranges with the interaction blocks' 83 %% early on a side stream (A/B under torch.distributed.run)")
     ap.add_argument("--reuse-batch", action="store_true",
                     help="train workload only: ONE batch for every step with its topology cached (A/B; the default "
                          "rotates 8 batches and rebuilds the topology every step like a real data loader)")
@@ -515,7 +518,7 @@ def pmc_traffic(name_prefix, fname):
 # ---------------------------------------------------------------------------------------------------
 # training step (BASELINE configs[3])
 # ---------------------------------------------------------------------------------------------------
-def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist, prefetch=True):
+def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist, prefetch=True, overlap=True):
     """one training step of configs/train_config.yml per iteration: loss (get_loss), backward, RCCL gradient
     all-reduce, clip_grad_norm_, Adam.  Returns (seconds, last mean loss, atoms per batch, executed flops per step)."""
     from tsdiff_amd import synth
@@ -548,7 +551,7 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist, prefet
         loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
                               g["batch"], g["num_nodes_per_graph"], graphs)
         used[0] = model._batches[0][2]
-        mean = dp_backward(model, loss, always_reduce=dist is not None)  # (one rank under torch.distributed.run: RCCL still runs)
+        mean = dp_backward(model, loss, always_reduce=dist is not None, overlap=overlap)  # (one rank under torch.distributed.run: RCCL still runs)
         optim.clip_grad_norm_(model.parameters(), 3000.0)
         opt.step()
         if not reuse_batch:
@@ -584,7 +587,7 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist, prefet
 
 def bench_train_main(args, model, dev, rank, world, dist):
     dt, last, N, flops = run_train(model, args.graphs, args.steps, args.warmup, args.reuse_batch, dev, rank, dist,
-                                   prefetch=not args.no_prefetch)
+                                   prefetch=not args.no_prefetch, overlap=not args.single_range_reduce)
     tmax = torch.tensor([dt], device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -601,8 +604,10 @@ def bench_train_main(args, model, dev, rank, world, dist):
                        "batch_topology": "one batch reused" if args.reuse_batch else
                        ("rebuilt every step inside get_loss" if args.no_prefetch else
                         "rebuilt every step, on a side stream during the previous step (prefetch_batch)"),
-                       "parallelism": f"graph-batch data parallel over {world} GPU(s), one RCCL all-reduce of "
-                                      "the flat fp32 gradient per step"},
+                       "parallelism": f"graph-batch data parallel over {world} GPU(s), RCCL all-reduce of the flat fp32 "
+                                      "gradient per step: " + ("one range behind the backward pass" if args.single_range_reduce
+                                                               else "three ranges, the interaction blocks' 83 % early on a side stream"),
+                       "reduce_path": getattr(model, "_last_reduce", None)},
             "roofline": train_roofline(tf, flops),
             "final_loss": last}))
 

@@ -93,3 +93,31 @@ def test_train_drift_h2_within_fp32_noise(dev):
     assert s == 50 and dh <= 2.0 * do + 1e-7, f"h2 {dh:.3e} vs fp32 re-association {do:.3e}"
     lf, lh = np.array(res["f32"][0]), np.array(res["h2"][0])
     assert float(np.max(np.abs(lh - lf) / np.abs(lf))) < 1e-4
+
+
+def test_fused_encoder_refuses_a_broken_unit_partition(dev, monkeypatch):
+    """tsd_batch.unit_node is the caller's: a unit that cuts a graph (its local atom numbers would leave the unit's LDS rows)
+    makes the workgroup report TSD_STATUS_INTERNAL instead of computing -- `force` raises, the default policy reruns the
+    batch on the forms without units and returns the right answer"""
+    from tests.test_gpu_round4 import _db
+    from tsdiff_amd import _lib, engine, synth
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    b = synth.dense_stress_batch(4, n=40, seed=3)
+    t = {k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}
+    g = to_dev({**t, "num_graphs": 4}, dev)
+    monkeypatch.setattr(engine.OPTIONS, "fused_encoder", False)
+    ref, ref_ei, _ = run_forward(make_model(cfg, 2, dev), g, dev)
+    for mode in ("force", True):
+        monkeypatch.setattr(engine.OPTIONS, "fused_encoder", mode)
+        model = make_model(cfg, 2, dev)
+        inv, ei, _ = run_forward(model, g, dev)
+        assert torch.equal(inv, ref)
+        db = _db(model)
+        assert db.unit_node is not None and db.unit_node.numel() == 5
+        db.unit_node[1] += 3  # units 0 and 1 now cut graph 1
+        if mode == "force":
+            with pytest.raises(_lib.TsdError):
+                run_forward(model, g, dev)
+        else:
+            inv2, _, _ = run_forward(model, g, dev)
+            assert torch.equal(inv2, ref) and db.per_block

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of the whole sampling step (configs[1] by default) across library variants and host switches.
 
-    python tools/ab_step.py [--workload c2|c5|ens8|gNNN] [--steps 200] [--rounds 3] NAME=LIB[:tail0] ...
+    python tools/ab_step.py [--workload c2|c5|ensN|gNNN|gNNNmM] [--steps 200] [--rounds 3] NAME=LIB[:tail0] ...
 
 Every configuration runs in its own child process (one library per process), the configurations interleaved over
 `rounds` rounds; prints ms/step min / median per configuration.  LIB = path of a libtsdiff_hip.so variant
@@ -36,6 +36,9 @@ def child(workload, steps, lib, flags):
     dev = torch.device("cuda:0")
     cfg = synth.DEFAULT_MODEL_CONFIG
     M = int(workload[3:]) if workload.startswith("ens") else 1  # ensN: N checkpoints on the configs[1] batch
+    if workload[0] == "g" and "m" in workload:  # gNNNmM: NNN graphs, M checkpoints (g300m8: configs[2]'s per-GPU unit)
+        workload, mm = workload.split("m")
+        M = int(mm)
     models = make_models(cfg, range(M), dev)
     if workload == "c5":
         b = synth.dense_stress_batch(1024, n=64, seed=1000)

@@ -37,6 +37,9 @@ def main():
     if which == "c2":
         g = to_dev(synth.wb97xd3_like_batch(100, seed=1000), dev)
         g["pos"] = torch.randn(g["pos"].shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1234)) * 1.5
+    elif which[0] == "g":   # gNNN: NNN graphs of the configs[1] distribution (g800: the tile counts of an 8-checkpoint ensemble)
+        g = to_dev(synth.wb97xd3_like_batch(int(which[1:]), seed=1000), dev)
+        g["pos"] = torch.randn(g["pos"].shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1234)) * 1.5
     else:
         g = to_dev(synth.dense_stress_batch(64, n=64, seed=1000), dev)
     s = EnsembleSampler([model])
@@ -45,6 +48,10 @@ def main():
     db = s._bound_batch(g["atom_type"], g["r_feat"], g["p_feat"], g["bond_index"], g["bond_type"], g["batch"])
     N, PU = db.N, db.P // 2
     ea = torch.randn(max(PU, 1), H, device=dev)
+    if h2:  # (the split-f16 filter role takes plane rows)
+        ea16 = torch.empty_like(ea)
+        _lib.check(lib.tsd_attr_planes(H, ea.shape[0], _lib.ptr(ea), _lib.ptr(ea16), _lib.stream_ptr()))
+        ea = ea16
     wf = torch.randn(2, max(PU, 1), H, device=dev)
     xa, xb = torch.randn(N, H, device=dev), torch.empty(N, H, device=dev)
     hbuf = torch.randn(N, H, device=dev)

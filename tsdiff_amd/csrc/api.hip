@@ -234,7 +234,7 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     // unit partition (every graph <= TSD_UNIT_MAX_NODES atoms); tsd_batch.reserved bit 2 switches it off, bit 4 asks for
     // it also where the one-launch form would apply (tests, A/B).  Same bits as the materialising forms.
     const bool fused_ok = h2 && unit_encoder_supported(c) && b.unit_node != nullptr && b.num_units > 0 && P > 0 &&
-                          !(b.reserved & 4);
+                          prec.range_status != nullptr && !(b.reserved & 4);  // (a status word: the kernel validates its units)
     const bool mega_ok = h2 && mega_shape(c, N, P, M) && prec.range_status != nullptr && P > 0 && !(b.reserved & 1);
     const bool fused = fused_ok && (!mega_ok || (b.reserved & 16));
     const bool mega = mega_ok && !fused;

@@ -36,9 +36,9 @@ constexpr int UE_MAX = 2016;   // undirected pairs per unit: one complete 64-ato
 constexpr int U_ROWS = 36 * 64;  // tile rows of a unit: 31.5 list tiles, or 36 block tiles (8 blocks: 8 * 9 / 2)
 
 struct UnitArgs {
-    int L, N, num_units;
+    int L, N, num_units, M;
     const int32_t* unit_node;  // [num_units + 1] node offsets
-    const int32_t *node_graph, *pair_ptr, *pair2u;  // topology / geometry tables (block mode: tile row -> pair of the list)
+    const int32_t *node_graph, *graph_ptr, *pair_ptr, *pair2u;  // topology / geometry tables (block mode: tile row -> pair of the list)
     tsd_edges eu;              // undirected encoder list (row_ptr, src, dst, dist)
     const float* W;            // f16-plane weight arena of checkpoint 0 (checkpoint m at + m * w_stride)
     size_t w_stride;
@@ -78,7 +78,7 @@ extern "C" int tsd_debug_unit_trace(void* host_buf) {
 #define UTRACE_DECL unsigned long long ut_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ut_t = __builtin_amdgcn_s_memtime(); const unsigned long long ut_t0 = ut_t;
 #define UTRACE(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ut_acc[slot] += n_ - ut_t; ut_t = n_; } while (0)
 #define UTRACE_COUNT(slot) do { ut_acc[slot] += 1; } while (0)
-#define UTRACE_FLUSH do { ut_acc[9] = __builtin_amdgcn_s_memtime() - ut_t0; if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) { for (int i_ = 0; i_ < 10; ++i_) g_unit_trace[(size_t)blockIdx.x * 16 + i_] = ut_acc[i_]; } } while (0)
+#define UTRACE_FLUSH do { ut_acc[9] = __builtin_amdgcn_s_memtime() - ut_t0; if (threadIdx.x == 0 && blockIdx.x % (unsigned)A.M == 0 && blockIdx.x / (unsigned)A.M < 4096) { for (int i_ = 0; i_ < 10; ++i_) g_unit_trace[(size_t)(blockIdx.x / (unsigned)A.M) * 16 + i_] = ut_acc[i_]; } } while (0)
 #else
 #define UTRACE_DECL
 #define UTRACE(slot)
@@ -112,16 +112,35 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
     const Planes pl = planes_at(tile, UT, LDH);
     float* buf = tile;
 
-    const int u = blockIdx.x;
-    const size_t m = blockIdx.y;
+    // Workgroup -> (unit, checkpoint): checkpoint = id % M on a 1-D grid.  Workgroups are dealt to the 8 XCDs round robin
+    // (id % 8, MI355X_MICROARCH.md), so with the 8 checkpoints of a production ensemble every XCD only ever runs ONE
+    // checkpoint and its 4-MB L2 holds that checkpoint's weight images of the blocks its workgroups are in (1.3 MB per
+    // block); with checkpoint-major order an XCD saw three or four checkpoints at once and the tile GEMMs streamed their
+    // weights from the Infinity Cache (tools/trace_unit.py ens8: 7.1 / 6.7 k cycles per GEMM against 6.2 / 5.9 k with one
+    // checkpoint).  A speed assumption only (measured: the GEMM phases did not move; the change is neutral).
+    const int u = (int)(blockIdx.x / (unsigned)A.M);
+    const size_t m = blockIdx.x % (unsigned)A.M;
     const int tid = threadIdx.x;
     const int n0 = A.unit_node[u], n1 = A.unit_node[u + 1], na = n1 - n0;
-    if (na <= 0) return;
-    const int e0 = A.eu.row_ptr[n0], e1 = A.eu.row_ptr[n1], ne = e1 - e0;
-    if (na > UNA || ne > UE_MAX || ne < 0) {  // (the host built the units: never expected)
-        if (tid == 0) atomicOr(A.status, TSD_STATUS_INTERNAL);
+    // The unit partition is the CALLER's (tsd_batch.unit_node): every workgroup checks its own unit -- offsets inside
+    // [0, N] and ascending, the first unit starts at 0 and the last ends at N (so the units cover every atom exactly
+    // once), at most UNA atoms, whole graphs only (a unit that cuts a graph would index LDS rows outside [0, UNA) with its
+    // 8-bit local atom numbers) -- and reports TSD_STATUS_INTERNAL instead of computing on a broken one.
+    bool bad = n0 < 0 || n1 > A.N || n1 < n0 || (u == 0 && n0 != 0) || (u == A.num_units - 1 && n1 != A.N) || na > UNA;
+    if (!bad && na > 0)
+        bad = A.graph_ptr[A.node_graph[n0]] != n0 || A.graph_ptr[A.node_graph[n1 - 1] + 1] != n1;
+    int e0 = 0, e1 = 0;
+    if (!bad && na > 0) {
+        e0 = A.eu.row_ptr[n0];
+        e1 = A.eu.row_ptr[n1];
+        bad = e1 < e0 || e1 - e0 > UE_MAX;
+    }
+    if (bad) {
+        if (tid == 0 && A.status != nullptr) atomicOr(A.status, TSD_STATUS_INTERNAL);
         return;
     }
+    if (na <= 0) return;
+    const int ne = e1 - e0;
     const float* Wm = A.W + m * A.w_stride;
     const float* ea = A.ea + m * A.ea_stride + (size_t)e0 * H;
     float* hm = A.h + m * A.nh_stride;
@@ -462,47 +481,56 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
                 }
             } else {   // (g) list mode: wave w owns the rows r with r % 8 == w (agg[r / 8], 4 columns per lane).  A row's
                 // partners below it come from pairs (i, r) -- the row is the pair's j -- and precede, in list order, its
-                // partners above it, pairs (r, j): the wave walks its j-side pairs of the tile in ascending order, then
-                // its i-side pairs -- every row meets its partners in ascending order.  Four pairs per round: their
-                // eight 16-byte LDS reads are in flight together, the adds stay in order.
+                // partners above it, pairs (r, j).  ROW BY ROW (round 5): for each of its (up to eight) rows the wave takes
+                // the row's j-side pairs of the tile in ascending order, then its i-side pairs, into a LOCAL copy of the
+                // row's sums -- the loop over the rows is unrolled, so agg[] is indexed statically (the round-4 form walked
+                // the tile's pairs and indexed agg[] dynamically per message: s_set_gpr_idx moves around every add, 5.9 k
+                // cycles per tile of small molecules, tools/trace_unit.py ens8).  Four pairs per round: their eight 16-byte
+                // LDS reads are in flight together, the adds stay in order.  Same order per row: the same bits.
                 TSD_UNIT_GEOM
-                const unsigned ijv = lane < nrows ? (unsigned)s_u[t * UT + lane] : 0xffffu;
+                const unsigned ijv = lane < nrows ? (unsigned)s_u[t * UT + lane] : 0xffffu;  // (0xffff: matches no row)
                 const int iv = (int)(ijv & 255u), jv = (int)(ijv >> 8);
                 const float* wrow = buf + lane * 4;
                 const float* xrow = x1s + lane * 4;
                 const int wq = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
-                for (int side = 0; side < 2; ++side) {
-                    const int rowv = side == 0 ? jv : iv, othv = side == 0 ? iv : jv;
-                    unsigned long long msk = __ballot(lane < nrows && (rowv & 7) == wq);
-                    while (msk) {
-                        int p[4], row[4], oth[4];
-                        bool ok[4];
-                        p[0] = (int)__builtin_ctzll(msk);
-                        ok[0] = true;
-                        msk &= msk - 1ull;
+                for (int k = 0; k < 8; ++k) {
+                    const int r = wq + 8 * k;
+                    const unsigned long long mj = __ballot(jv == r), mi = __ballot(iv == r);
+                    if ((mj | mi) != 0ull) {
+                        f32x4 a4 = agg[k];
 #pragma unroll
-                        for (int s = 1; s < 4; ++s) {
-                            ok[s] = msk != 0ull;
-                            p[s] = ok[s] ? (int)__builtin_ctzll(msk) : p[s - 1];  // (a slot past the end re-reads the last pair)
-                            if (ok[s]) msk &= msk - 1ull;
-                        }
-                        f32x4 wv[4], xv[4];
+                        for (int side = 0; side < 2; ++side) {
+                            const int othv = side == 0 ? iv : jv;
+                            unsigned long long msk = side == 0 ? mj : mi;
+                            while (msk) {
+                                int p[4];
+                                bool ok[4];
+                                p[0] = (int)__builtin_ctzll(msk);
+                                ok[0] = true;
+                                msk &= msk - 1ull;
 #pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            row[s] = __builtin_amdgcn_readlane(rowv, p[s]);
-                            oth[s] = __builtin_amdgcn_readlane(othv, p[s]);
-                            wv[s] = *reinterpret_cast<const f32x4*>(wrow + p[s] * LDA);
-                            xv[s] = *reinterpret_cast<const f32x4*>(xrow + oth[s] * H);
-                        }
+                                for (int s4 = 1; s4 < 4; ++s4) {
+                                    ok[s4] = msk != 0ull;
+                                    p[s4] = ok[s4] ? (int)__builtin_ctzll(msk) : p[s4 - 1];  // (a slot past the end re-reads the last pair)
+                                    if (ok[s4]) msk &= msk - 1ull;
+                                }
+                                f32x4 wv[4], xv[4];
 #pragma unroll
-                        for (int s = 0; s < 4; ++s)
-                            if (ok[s]) {
-                                f32x4 a4 = agg[row[s] >> 3];
+                                for (int s4 = 0; s4 < 4; ++s4) {
+                                    const int oth = __builtin_amdgcn_readlane(othv, p[s4]);
+                                    wv[s4] = *reinterpret_cast<const f32x4*>(wrow + p[s4] * LDA);
+                                    xv[s4] = *reinterpret_cast<const f32x4*>(xrow + oth * H);
+                                }
 #pragma unroll
-                                for (int c = 0; c < 4; ++c) a4[c] = __fadd_rn(a4[c], __fmul_rn(xv[s][c], wv[s][c]));
-                                agg[row[s] >> 3] = a4;
+                                for (int s4 = 0; s4 < 4; ++s4)
+                                    if (ok[s4]) {
+#pragma unroll
+                                        for (int c = 0; c < 4; ++c) a4[c] = __fadd_rn(a4[c], __fmul_rn(xv[s4][c], wv[s4][c]));
+                                    }
                             }
+                        }
+                        agg[k] = a4;
                     }
                 }
             }
@@ -689,8 +717,10 @@ int launch_unit_encoder(const tsd_model_cfg& c, const tsd_batch& b, const float*
     A.L = c.num_convs;
     A.N = b.num_nodes;
     A.num_units = b.num_units;
+    A.M = b.num_models;
     A.unit_node = b.unit_node;
     A.node_graph = b.node_graph;
+    A.graph_ptr = b.graph_ptr;
     A.pair_ptr = b.pair_ptr;
     A.pair2u = b.geo.pair2u;
     A.eu = b.geo.enc_u;
@@ -723,7 +753,7 @@ int launch_unit_encoder(const tsd_model_cfg& c, const tsd_batch& b, const float*
     static DeviceOnce once;
     int r = allow_lds(unit_encoder_kernel<256>, lds, once);
     if (r) return r;
-    hipLaunchKernelGGL(unit_encoder_kernel<256>, dim3(b.num_units, b.num_models), dim3(512), lds, st, A);
+    hipLaunchKernelGGL(unit_encoder_kernel<256>, dim3(b.num_units * b.num_models), dim3(512), lds, st, A);
     TSD_LAUNCH_CHECK("unit_encoder");
     return TSD_OK;
 }

@@ -61,7 +61,7 @@ def _all_reduce_sum(t, group=None):
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
-def dp_backward(model, loss_nodes, group=None, reduce_fn=None, always_reduce=False):
+def dp_backward(model, loss_nodes, group=None, reduce_fn=None, always_reduce=False, overlap=True):
     """Backward of the reference's `loss.mean()` (train.py:140-143) over the GLOBAL batch.
 
     `loss_nodes` is this rank's (N_r, 1) per-node loss.  The reference averages over all nodes of the
@@ -81,7 +81,8 @@ def dp_backward(model, loss_nodes, group=None, reduce_fn=None, always_reduce=Fal
     the interaction blocks are final -- one contiguous range of the flat vector, 83 % of it; their all-reduce starts
     right there on a side stream and runs beside the rest of the backward pass (the embedding's backward chain, the
     node-embedding gradients); the two remaining ranges (head and tail of the vector) are reduced when the backward has
-    finished.  Three collectives per step in a fixed order on every rank."""
+    finished.  Three collectives per step in a fixed order on every rank.  `overlap=False`: ONE all-reduce of the whole
+    flat gradient behind the backward pass (the form of rounds 1-3; A/B: `bench.py --workload train --single-range-reduce`)."""
     distributed = reduce_fn is not None or (dist.is_initialized() and (always_reduce or dist.get_world_size(group) > 1))
     reduce = reduce_fn if reduce_fn is not None else (lambda t: _all_reduce_sum(t, group))
     # (new_full is a fill kernel: torch.tensor(x, device=cuda) would be a synchronous host-to-device copy, i.e.
@@ -96,7 +97,7 @@ def dp_backward(model, loss_nodes, group=None, reduce_fn=None, always_reduce=Fal
     # runs `p.grad += view` on the main stream while the side stream reduces the same memory, and the gather-scatter
     # branch below would reduce p.grad a second time: arm it only when every trainable parameter's .grad is None.
     params = [p for p in model.parameters() if p.requires_grad]
-    arm = distributed and all(p.grad is None for p in params)
+    arm = distributed and overlap and all(p.grad is None for p in params)
     model._dp_early_reduce = reduce if arm else None
     try:
         (total / stats[1]).backward()
