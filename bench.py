@@ -594,7 +594,7 @@ def bench_train_main(args, model, dev, rank, world, dist):
     dt = float(tmax.item())
     if rank == 0:
         tf = flops / (dt / args.steps) / 1e12
-        print(json.dumps({
+        emit(json.dumps({
             "metric": "training steps/s (configs[3]: get_loss + backward + grad all-reduce + clip + Adam)",
             "value": round(world * args.graphs * args.steps / dt, 1), "unit": "graphs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -666,8 +666,25 @@ def cpu_baseline(args, cfg, b, pos_init):
 
 
 # ---------------------------------------------------------------------------------------------------
+_REAL_STDOUT = None
+
+
+def emit(line):
+    """the ONE JSON line of the contract, on the process's original stdout"""
+    if _REAL_STDOUT is None:
+        print(line, flush=True)
+    else:
+        os.write(_REAL_STDOUT, (line + "\n").encode())
+
+
 def main():
+    global _REAL_STDOUT
     args = parse()
+    # Libraries write to fd 1 behind Python's back (RCCL prints a five-line version banner at init_process_group): everything
+    # but the result line goes to stderr.
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -896,7 +913,10 @@ def main():
         s8 = EnsembleSampler(m8)
         run8 = SamplingRun(s8, g, args.graphs, pos_init, not args.no_graph, 99)
         run8.run(3)
-        K8 = 20
+        t_r = time.perf_counter()
+        while time.perf_counter() - t_r < 0.15:  # (the same untimed clock ramp as the headline: the chip idled while the
+            run8.run(20)                          # eight checkpoints were built)
+        K8 = 50
         dt8, p8 = run8.timed(K8)
         assert torch.isfinite(p8).all()
         F8, _ = forward_flops(models[0]._cfg, E_enc, E_out, E_diff, N, 8)
@@ -964,7 +984,7 @@ def main():
             "reference_loop_ms_per_step": out.get("reference_loop_ms_per_step"),
             "dualenc_forward_ms": g(out, "dualenc", "forward_ms"), "kernel_source_sha": kernel_source_sha()}
     roofline.update({k: v for k, v in flat.items() if k not in roofline})
-    print(json.dumps(out))
+    emit(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -102,9 +102,10 @@ def test_fused_encoder_refuses_a_broken_unit_partition(dev, monkeypatch):
     from tests.test_gpu_round4 import _db
     from tsdiff_amd import _lib, engine, synth
     cfg = synth.DEFAULT_MODEL_CONFIG
-    b = synth.dense_stress_batch(4, n=40, seed=3)
+    G = 72  # (4320 atoms: past the one-launch form's size, so the default policy takes the fused encoder by itself)
+    b = synth.dense_stress_batch(G, n=60, seed=3)
     t = {k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}
-    g = to_dev({**t, "num_graphs": 4}, dev)
+    g = to_dev({**t, "num_graphs": G}, dev)
     monkeypatch.setattr(engine.OPTIONS, "fused_encoder", False)
     ref, ref_ei, _ = run_forward(make_model(cfg, 2, dev), g, dev)
     for mode in ("force", True):
@@ -113,7 +114,7 @@ def test_fused_encoder_refuses_a_broken_unit_partition(dev, monkeypatch):
         inv, ei, _ = run_forward(model, g, dev)
         assert torch.equal(inv, ref)
         db = _db(model)
-        assert db.unit_node is not None and db.unit_node.numel() == 5
+        assert db.unit_node is not None and db.unit_node.numel() == G + 1
         db.unit_node[1] += 3  # units 0 and 1 now cut graph 1
         if mode == "force":
             with pytest.raises(_lib.TsdError):

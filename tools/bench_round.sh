@@ -3,7 +3,7 @@
 # Writes gpurun_out/<tag>_bench_*.json (one JSON line each) and gpurun_out/<tag>_parity_report.md.  Copy what is to
 # be judged to profiles/.  Run tools/profile_round.sh first when the line's `traffic` / `mfma_busy` fields are to
 # come from this round's counter passes (bench.py reads profiles/<tag>_pmc_traffic*.json and <tag>_mfma_busy.json).
-TAG=${1:-r03}
+TAG=${1:-r05}
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
 python3 bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_driver_flags.json 2> $O/${TAG}_bench_driver_flags.err      # the driver's command
@@ -14,6 +14,8 @@ python3 bench.py --models 8 --steps 50 --warmup 5 --no-cpu-baseline --no-extras 
 python3 bench.py --models 8 --graphs 300 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/${TAG}_bench_c3_unit.json 2> /dev/null  # configs[2]: one GPU's share
 python3 bench.py --workload train --steps 20 --warmup 5 > $O/${TAG}_bench_train.json 2> /dev/null
 python3 bench.py --workload train --steps 20 --warmup 5 --no-prefetch > $O/${TAG}_bench_train_no_prefetch.json 2> /dev/null
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --workload train --steps 40 --warmup 8 > $O/${TAG}_bench_train_torchrun_3range.json 2> /dev/null
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --workload train --steps 40 --warmup 8 --single-range-reduce > $O/${TAG}_bench_train_torchrun_1range.json 2> /dev/null
 python3 tools/parity_report.py > $O/${TAG}_parity_report.md 2> $O/${TAG}_parity_report.err
 for f in $O/${TAG}_bench_*.json; do python3 - "$f" <<'PY'
 import json, sys

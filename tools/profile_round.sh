@@ -2,7 +2,7 @@
 # All profile artefacts of a round in one gpurun call:   gpurun -- 'bash tools/profile_round.sh r02'
 # Writes gpurun_out/<tag>_*: kernel-trace stats (c2, c5, train), HBM traffic PMC passes (c2, c5: FETCH_SIZE and
 # WRITE_SIZE in separate passes), SQ issue/stall/MFMA-busy counters (c2, c5; MFMA-busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x launch time x clock)).  Copy what is to be judged to profiles/.
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 db() { ls $1/*/*results.db $1/*results.db 2>/dev/null | head -1; }
 B="--no-cpu-baseline --no-extras --no-f32"
@@ -16,6 +16,10 @@ python3 tools/rocpd_stats.py $(db /tmp/p_c5) > gpurun_out/${TAG}_kernel_stats_c5
 rocprofv3 --kernel-trace --stats -d /tmp/p_tr -o tr -- python3 bench.py --workload train --steps 20 --warmup 5 > gpurun_out/${TAG}_prof_train.log 2>&1
 python3 tools/rocpd_stats.py $(db /tmp/p_tr) > gpurun_out/${TAG}_kernel_stats_train.md
 python3 tools/step_timeline.py $(db /tmp/p_tr) > gpurun_out/${TAG}_train_timeline.md
+# the 8-checkpoint ensemble at batch 100 (configs[2]'s per-GPU unit): kernel stats and one step's timeline
+rocprofv3 --kernel-trace --stats -d /tmp/p_e8 -o e8 -- python3 bench.py --models 8 --steps 50 --warmup 5 $B > gpurun_out/${TAG}_prof_ens8.log 2>&1
+python3 tools/rocpd_stats.py $(db /tmp/p_e8) > gpurun_out/${TAG}_kernel_stats_ens8.md
+python3 tools/step_timeline.py $(db /tmp/p_e8) step_tail > gpurun_out/${TAG}_step_timeline_ens8.md
 python3 tools/step_timeline.py $(db /tmp/p_c2) step_tail > gpurun_out/${TAG}_step_timeline.md
 # roctx ranges of the library's entry points (no counters in this pass)
 rocprofv3 --kernel-trace --marker-trace -d /tmp/p_mk -o mk -- python3 bench.py --steps 20 --warmup 5 --no-graph $B > gpurun_out/${TAG}_prof_markers.log 2>&1

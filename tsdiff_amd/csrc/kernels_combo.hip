@@ -2010,8 +2010,9 @@ int launch_row_gather(int H, int N, tsd_edges e, const float* W, const float* x,
     return TSD_OK;
 }
 
-struct ComboStride {  // per-checkpoint strides (blockIdx.y = checkpoint of the ensemble)
+struct ComboStride {  // per-checkpoint strides (checkpoint = blockIdx.x % M)
     size_t w, nh, ea, wf, pre;
+    int M;            // checkpoints of the launch
     int node_stride;  // 1: node tiles are the first workgroups; S > 1 (odd): node tile j is workgroup j * S
     int32_t* range_status;  // PREC_H2 launches: device word for TSD_STATUS_RANGE (or NULL)
 };
@@ -2033,8 +2034,14 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
                                                             ComboStride sd, ComboPre q, FilterSave fsv,
                                                             NodeSave ns TSD_TRACE_ARG) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // Workgroup -> (checkpoint, item): 1-D grid, checkpoint = id % M (round 5).  Workgroups go to the 8 XCDs round robin
+    // (id % 8), so the 8 checkpoints of a production ensemble are one per XCD and each 4-MB L2 holds ONE checkpoint's
+    // weight images of the block (1.3 MB) instead of whatever two or three checkpoints the checkpoint-major order had
+    // resident at a time.  A speed assumption only.
+    const unsigned ckpts = (unsigned)sd.M;
+    const int bx = (int)(blockIdx.x / ckpts);
     {
-        const size_t m = blockIdx.y;
+        const size_t m = blockIdx.x % ckpts;
         const size_t wo = m * sd.w, no = m * sd.nh;
         a.Wf += m * sd.wf; a.x1_in += no; a.h_in += no; a.h += no; a.x1_out += no;
         a.lin2_w += wo; a.lin2_b += wo; a.lin_w += wo; a.lin_b += wo;
@@ -2059,7 +2066,7 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
     // tile gathers 3x slower beside an fp32 MFMA stream, 6 -> 21 us, but the launch stays bound by the CUs that run
     // two filter tiles, 40.4 vs 39.5 us.)
     const int S = sd.node_stride;
-    const int b = blockIdx.x;
+    const int b = bx;
     const bool is_node = S > 1 ? (b % S == 0 && b / S < node_tiles) : b < node_tiles;
     const int node_id = S > 1 ? b / S : b;
     const int others_before = S > 1 ? b - min(node_tiles, b / S + 1) : b - node_tiles;
@@ -2112,13 +2119,13 @@ int filter_tiles_per_layer(int capacity_u);
 // launch) on the f16 MFMA pipes: pair_role_h without the wait.
 template <int H, bool SAVE = false>
 __global__ __launch_bounds__(2 * H) void pair_output_h_kernel(ComboPre q, size_t wstride, size_t h_stride, size_t ea_stride,
-                                                              int32_t* range_status, PairSave sv) {
+                                                              int32_t* range_status, PairSave sv, int M) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const size_t m = blockIdx.y, wo = m * wstride;
+    const size_t m = blockIdx.x % (unsigned)M, wo = m * wstride;  // (checkpoint = id % M: see layer_combo_kernel)
     q.edge_attr += m * ea_stride; q.w0b += wo; q.b0 += wo;
     q.w0a += wo; q.w1 += wo; q.b1 += wo; q.w2 += wo; q.b2 += wo;
     q.h += m * h_stride; q.edge_inv += m * q.inv_stride;
-    pair_role_h<H, SAVE>(q, blockIdx.x, 0, smem, false, range_status, sv);
+    pair_role_h<H, SAVE>(q, (int)(blockIdx.x / (unsigned)M), 0, smem, false, range_status, sv);
 }
 int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity, tsd_edges e, const float* h,
                          const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
@@ -2156,10 +2163,10 @@ int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity,
         static DeviceOnce once, once_s;                                                                          \
         int r = save ? allow_lds(pair_output_h_kernel<HH, true>, lds, once_s) : allow_lds(pair_output_h_kernel<HH>, lds, once); \
         if (r) return r;                                                                                         \
-        if (save) hipLaunchKernelGGL((pair_output_h_kernel<HH, true>), dim3(tiles, M), dim3(2 * HH), lds, st, q, L.total, h_stride, \
-                           ea_stride, range_status, *save);                                                      \
-        else hipLaunchKernelGGL(pair_output_h_kernel<HH>, dim3(tiles, M), dim3(2 * HH), lds, st, q, L.total, h_stride, \
-                           ea_stride, range_status, PairSave{});                                                 \
+        if (save) hipLaunchKernelGGL((pair_output_h_kernel<HH, true>), dim3(tiles * M), dim3(2 * HH), lds, st, q, L.total, h_stride, \
+                           ea_stride, range_status, *save, M);                                                   \
+        else hipLaunchKernelGGL(pair_output_h_kernel<HH>, dim3(tiles * M), dim3(2 * HH), lds, st, q, L.total, h_stride, \
+                           ea_stride, range_status, PairSave{}, M);                                              \
     }
     switch (c.hidden) {
         case 64: TSD_POH(64) break;
@@ -2860,12 +2867,13 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     if (pre && pre->tiles > 0) q = *pre;
     // Wide node tiles (32 rows: node_role_hw) where the launch's node tiles alone are a chip-full of workgroup slots: their
     // slot time, not the chain's latency, is what the launch pays for.  Inference form of the production width, ONE
-    // checkpoint: measured (tools/ab_step.py) 600 graphs 0.942 -> 0.920 ms/step, but an 8-checkpoint ensemble at batch 100
-    // 1.405 -> 1.454 -- eight weight sets do not stay in an XCD's L2 and the shallower weight ring of the wide role
-    // (two k-steps in flight: three do not fit 128 VGPRs) then shows.
+    // checkpoint, from the size at which the one-launch forward no longer applies (> 256 node tiles): measured
+    // (tools/ab_step.py) 300 graphs 0.514 -> 0.486 ms/step, 400: 0.636 -> 0.600, 500: 0.756 -> 0.742, 600: 0.942 -> 0.920;
+    // but an 8-checkpoint ensemble at batch 100 1.405 -> 1.454 -- eight weight sets do not stay in an XCD's L2 and the
+    // shallower weight ring of the wide role (two k-steps in flight: three do not fit 128 VGPRs) then shows.
     int nrb = 1;
 #ifndef TSD_NODE_WIDE_MIN
-#define TSD_NODE_WIDE_MIN 512  // 16-row node tiles (x checkpoints) of a launch from which they are 32 rows; 0: never
+#define TSD_NODE_WIDE_MIN 257  // 16-row node tiles of a (single-checkpoint) launch from which they are 32 rows; 0: never
 #endif
     if (prec.mode == PREC_H2 && c.hidden == 256 && !fsave && !nsave && q.tiles == 0 && layer != -2 && TSD_NODE_WIDE_MIN > 0 &&
         !prec.narrow_filter_tiles && M == 1 && (N + TN - 1) / TN >= TSD_NODE_WIDE_MIN)
@@ -2893,7 +2901,7 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
         node_stride = grid / node_tiles;
         if (node_stride % 2 == 0) --node_stride;
     }
-    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, pre_stride, node_stride, prec.range_status};
+    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, pre_stride, M, node_stride, prec.range_status};
     if (prec.mode == PREC_H2 && q.tiles > 0 && !q.pair) {
         set_error("internal: the split-f16 block launch has no pre role");
         return TSD_ERR_INVALID;
@@ -2908,7 +2916,7 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
         static DeviceOnce once;                                                                             \
         int r = allow_lds(layer_combo_kernel<HH, SV, TL, PR, FR, ##__VA_ARGS__>, lds, once);                \
         if (r) return r;                                                                                    \
-        hipLaunchKernelGGL((layer_combo_kernel<HH, SV, TL, PR, FR, ##__VA_ARGS__>), dim3(grid, M), dim3(2 * HH), lds, st, a, \
+        hipLaunchKernelGGL((layer_combo_kernel<HH, SV, TL, PR, FR, ##__VA_ARGS__>), dim3(grid * M), dim3(2 * HH), lds, st, a, \
                            node_tiles, f, sd, q, fsv, nsv TSD_TRACE_HOST);                                  \
     }
 #define TSD_COMBO(HH)                                                                                       \

@@ -345,19 +345,22 @@ __global__ __launch_bounds__(2 * H) void typed_embed_h_kernel(TypedEmbedW w, Typ
                                                               const int32_t* __restrict__ pair2u, int P,
                                                               const int32_t* __restrict__ attr_row,
                                                               float* __restrict__ edge_attr, size_t out_stride,
-                                                              UmapRole um, EmbedFuse0 f0, int32_t* range_status) {
+                                                              UmapRole um, EmbedFuse0 f0, int32_t* range_status, int M) {
     constexpr int NT = 2 * H;
     const int embed_tiles = ta.n + tb.n;
-    if ((int)blockIdx.x >= embed_tiles) {  // extra role: directed-edge -> undirected-pair map (checkpoint 0 only)
-        if (blockIdx.y == 0) {
-            const int t = ((int)blockIdx.x - embed_tiles) * NT + (int)threadIdx.x;
+    // (1-D grid, checkpoint = id % M: one checkpoint per XCD with ensembles of 8 -- kernels_combo.hip layer_combo_kernel)
+    const int bx = (int)(blockIdx.x / (unsigned)M);
+    const size_t m = blockIdx.x % (unsigned)M;
+    if (bx >= embed_tiles) {  // extra role: directed-edge -> undirected-pair map (checkpoint 0 only)
+        if (m == 0) {
+            const int t = (bx - embed_tiles) * NT + (int)threadIdx.x;
             edge_umap_body(um.g, um.graph_ptr, um.node_graph, um.pair_ptr, um.P, t);
             if (t < um.n_zero) um.zero_words[t] = 0;
         }
         return;
     }
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    typed_embed_tile_h<H, FUSE0>(w, ta, tb, (int)blockIdx.x, blockIdx.y, pos, pair2u, P, attr_row, edge_attr, out_stride, f0,
+    typed_embed_tile_h<H, FUSE0>(w, ta, tb, bx, m, pos, pair2u, P, attr_row, edge_attr, out_stride, f0,
                                  range_status, smem);
 }
 
@@ -393,9 +396,9 @@ int launch_typed_embed(const tsd_model_cfg& c, const float* W, const tsd_batch& 
         static DeviceOnce once;                                                                                \
         int r = allow_lds(typed_embed_h_kernel<HH, FU>, lds, once);                                            \
         if (r) return r;                                                                                       \
-        hipLaunchKernelGGL((typed_embed_h_kernel<HH, FU>), dim3(grid, M), dim3(2 * HH), lds, st, w, ta, tb, pos, \
+        hipLaunchKernelGGL((typed_embed_h_kernel<HH, FU>), dim3(grid * M), dim3(2 * HH), lds, st, w, ta, tb, pos, \
                            b.geo.pair2u, b.num_pairs, b.geo.attr_row, edge_attr, out_stride, um, FARG,         \
-                           prec.range_status);                                                                 \
+                           prec.range_status, M);                                                              \
     }
 #define TSD_TE(HH, FU, FARG)                                                                                   \
     {                                                                                                          \

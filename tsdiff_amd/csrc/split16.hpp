@@ -60,7 +60,9 @@ __device__ __forceinline__ void amax_upd2(float& amax, float a, float b) {
 // (1 element in ~10^3) hi + lo 2^-11 misses the value by an f16 ulp -- 15 of 1791 pair outputs of a test batch were 6e-5 off.
 // Behind the empty asm statement both planes derive from the same fp32 register by plain round-to-nearest conversions.
 __device__ __forceinline__ void split1(float a, f16& h, f16& l) {
+#ifndef TSD_SPLIT_NO_OPAQUE  // (timing experiments only: without the statement the planes can be inconsistent)
     asm("" : "+v"(a));
+#endif
     h = (f16)a;
     l = (f16)((a - (float)h) * SPLIT_SCALE);
 }
@@ -277,7 +279,9 @@ __device__ __forceinline__ void hgemm_ring_run(HRing<CB, R>& r, const Planes& A,
                 if constexpr (TRANS) {
                     accx[rb][cb] = mfma_h32(r.b[slot][cb][1], ah[rb], accx[rb][cb]);
                     accm[rb][cb] = mfma_h32(r.b[slot][cb][0], ah[rb], accm[rb][cb]);
+#ifndef TSD_MFMA2  // (timing experiment, wrong results: two of the three MFMAs of a product -- tools/energy_probe.sh)
                     accx[rb][cb] = mfma_h32(r.b[slot][cb][0], al[rb], accx[rb][cb]);
+#endif
                 } else {
                     accx[rb][cb] = mfma_h32(ah[rb], r.b[slot][cb][1], accx[rb][cb]);
                     accm[rb][cb] = mfma_h32(ah[rb], r.b[slot][cb][0], accm[rb][cb]);
