@@ -294,6 +294,31 @@ int launch_bucket_weights16(const tsd_model_cfg& c, const float* bucket, int num
 
 inline bool hidden_supported(int H) { return H == 64 || H == 128 || H == 256; }
 
+// Workgroup -> (item, checkpoint) on the 1-D grids of the ensemble launches (round 5).  M > 0: checkpoint = id % M --
+// workgroups go to the 8 XCDs round robin (id % 8, MI355X_MICROARCH.md), so the 8 checkpoints of a production ensemble run
+// one per XCD and each 4-MB L2 holds ONE checkpoint's weight images of the running block; M < 0: checkpoint-major (id /
+// items), the order of rounds 1-4.  The launchers interleave while a checkpoint's share of the grid is less than two
+// chip-fulls of workgroup slots (ckpt_grid_m): there the checkpoint-major order has three or four checkpoints resident at
+// a time and every XCD sees them all (measured, tools/ab_step.py: 8 checkpoints at batch 100 1.391 -> 1.326 ms/step,
+// 4 checkpoints 0.710 -> 0.702); with 300 graphs x 8 checkpoints a checkpoint's items are several chip-fulls, one or two
+// checkpoints are resident either way, and the interleaved order measured 1 % slower (3.621 vs 3.590).  A speed
+// assumption only.
+__device__ __forceinline__ void wg_item_ckpt(int M, int& item, size_t& m) {
+    const unsigned id = blockIdx.x;
+    if (M > 0) {
+        item = (int)(id / (unsigned)M);
+        m = id % (unsigned)M;
+    } else {
+        const unsigned items = gridDim.x / (unsigned)(-M);
+        item = (int)(id % items);
+        m = id / items;
+    }
+}
+#ifndef TSD_CKPT_INTERLEAVE_MAX
+#define TSD_CKPT_INTERLEAVE_MAX 1024  // items per checkpoint below which the grid is interleaved (0: never)
+#endif
+inline int ckpt_grid_m(int M, long items_per_ckpt) { return (M > 1 && items_per_ckpt < TSD_CKPT_INTERLEAVE_MAX) ? M : -M; }
+
 // ---------------------------------------------------------------------------------------------
 // device math (fp32, no fast-math)
 // ---------------------------------------------------------------------------------------------

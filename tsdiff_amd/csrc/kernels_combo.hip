@@ -1021,6 +1021,9 @@ __device__ __forceinline__ void node_role_h(const ComboNode& a, int tile, float*
 // gathers 2 NRB consecutive rows in one pass over its contiguous edge range.  Same arithmetic per row and element as
 // node_role_h (transposed accumulators): bit-identical; inference only.  The small-launch forms keep 16 rows: there the
 // chain's latency, not its slot time, is what counts.
+#ifndef TSD_NODE_WIDE_RING
+#define TSD_NODE_WIDE_RING 2
+#endif
 template <int H, int NRB>
 __device__ __forceinline__ void node_role_hw(const ComboNode& a, int tile, float* smem, int32_t* range_status) {
     constexpr int LDH = ldh_of(H), TNR = TN * NRB;
@@ -1036,7 +1039,7 @@ __device__ __forceinline__ void node_role_hw(const ComboNode& a, int tile, float
     f32x4 accm[NRB][CB16], accx[NRB][CB16];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     float amax = 0.0f;
-    constexpr int RW = 2;  // ring depth (a throughput role beside other resident workgroups; 3 does not fit 128 VGPRs here)
+    constexpr int RW = TSD_NODE_WIDE_RING;  // ring depth (k-steps of weights in flight)
     HRing<CB16, RW> rg;
     auto zero_acc4 = [&]() {
 #pragma unroll
@@ -2012,7 +2015,7 @@ int launch_row_gather(int H, int N, tsd_edges e, const float* W, const float* x,
 
 struct ComboStride {  // per-checkpoint strides (checkpoint = blockIdx.x % M)
     size_t w, nh, ea, wf, pre;
-    int M;            // checkpoints of the launch
+    int M;            // checkpoints of the launch, signed: common.hpp wg_item_ckpt / ckpt_grid_m
     int node_stride;  // 1: node tiles are the first workgroups; S > 1 (odd): node tile j is workgroup j * S
     int32_t* range_status;  // PREC_H2 launches: device word for TSD_STATUS_RANGE (or NULL)
 };
@@ -2034,14 +2037,11 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
                                                             ComboStride sd, ComboPre q, FilterSave fsv,
                                                             NodeSave ns TSD_TRACE_ARG) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // Workgroup -> (checkpoint, item): 1-D grid, checkpoint = id % M (round 5).  Workgroups go to the 8 XCDs round robin
-    // (id % 8), so the 8 checkpoints of a production ensemble are one per XCD and each 4-MB L2 holds ONE checkpoint's
-    // weight images of the block (1.3 MB) instead of whatever two or three checkpoints the checkpoint-major order had
-    // resident at a time.  A speed assumption only.
-    const unsigned ckpts = (unsigned)sd.M;
-    const int bx = (int)(blockIdx.x / ckpts);
+    int bx;      // (1-D grid, checkpoint = id % M: common.hpp wg_item_ckpt)
+    size_t m_;
+    wg_item_ckpt(sd.M, bx, m_);
     {
-        const size_t m = blockIdx.x % ckpts;
+        const size_t m = m_;
         const size_t wo = m * sd.w, no = m * sd.nh;
         a.Wf += m * sd.wf; a.x1_in += no; a.h_in += no; a.h += no; a.x1_out += no;
         a.lin2_w += wo; a.lin2_b += wo; a.lin_w += wo; a.lin_b += wo;
@@ -2121,11 +2121,14 @@ template <int H, bool SAVE = false>
 __global__ __launch_bounds__(2 * H) void pair_output_h_kernel(ComboPre q, size_t wstride, size_t h_stride, size_t ea_stride,
                                                               int32_t* range_status, PairSave sv, int M) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const size_t m = blockIdx.x % (unsigned)M, wo = m * wstride;  // (checkpoint = id % M: see layer_combo_kernel)
+    int tile;
+    size_t m;
+    wg_item_ckpt(M, tile, m);
+    const size_t wo = m * wstride;
     q.edge_attr += m * ea_stride; q.w0b += wo; q.b0 += wo;
     q.w0a += wo; q.w1 += wo; q.b1 += wo; q.w2 += wo; q.b2 += wo;
     q.h += m * h_stride; q.edge_inv += m * q.inv_stride;
-    pair_role_h<H, SAVE>(q, (int)(blockIdx.x / (unsigned)M), 0, smem, false, range_status, sv);
+    pair_role_h<H, SAVE>(q, tile, 0, smem, false, range_status, sv);
 }
 int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity, tsd_edges e, const float* h,
                          const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
@@ -2164,9 +2167,9 @@ int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity,
         int r = save ? allow_lds(pair_output_h_kernel<HH, true>, lds, once_s) : allow_lds(pair_output_h_kernel<HH>, lds, once); \
         if (r) return r;                                                                                         \
         if (save) hipLaunchKernelGGL((pair_output_h_kernel<HH, true>), dim3(tiles * M), dim3(2 * HH), lds, st, q, L.total, h_stride, \
-                           ea_stride, range_status, *save, M);                                                   \
+                           ea_stride, range_status, *save, ckpt_grid_m(M, tiles));                               \
         else hipLaunchKernelGGL(pair_output_h_kernel<HH>, dim3(tiles * M), dim3(2 * HH), lds, st, q, L.total, h_stride, \
-                           ea_stride, range_status, PairSave{}, M);                                              \
+                           ea_stride, range_status, PairSave{}, ckpt_grid_m(M, tiles));                          \
     }
     switch (c.hidden) {
         case 64: TSD_POH(64) break;
@@ -2869,14 +2872,19 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     // slot time, not the chain's latency, is what the launch pays for.  Inference form of the production width, ONE
     // checkpoint, from the size at which the one-launch forward no longer applies (> 256 node tiles): measured
     // (tools/ab_step.py) 300 graphs 0.514 -> 0.486 ms/step, 400: 0.636 -> 0.600, 500: 0.756 -> 0.742, 600: 0.942 -> 0.920;
-    // but an 8-checkpoint ensemble at batch 100 1.405 -> 1.454 -- eight weight sets do not stay in an XCD's L2 and the
-    // shallower weight ring of the wide role (two k-steps in flight: three do not fit 128 VGPRs) then shows.
+    // an 8-checkpoint ensemble at batch 100 LOST with the checkpoint-major grid (1.405 -> 1.454: eight weight sets do not
+    // stay in an XCD's L2 and the shallower weight ring of the wide role -- two k-steps in flight: three do not fit 128
+    // VGPRs -- then shows) and WINS since the checkpoints are interleaved over the XCDs (common.hpp wg_item_ckpt):
+    // 1.320 -> 1.285; 300 graphs x 8 checkpoints 3.633 -> 3.527.
     int nrb = 1;
+#ifndef TSD_NODE_WIDE_ANY_M
+#define TSD_NODE_WIDE_ANY_M 1  // wide node tiles for ensembles too (0: single-checkpoint launches only; A/B builds)
+#endif
 #ifndef TSD_NODE_WIDE_MIN
 #define TSD_NODE_WIDE_MIN 257  // 16-row node tiles of a (single-checkpoint) launch from which they are 32 rows; 0: never
 #endif
     if (prec.mode == PREC_H2 && c.hidden == 256 && !fsave && !nsave && q.tiles == 0 && layer != -2 && TSD_NODE_WIDE_MIN > 0 &&
-        !prec.narrow_filter_tiles && M == 1 && (N + TN - 1) / TN >= TSD_NODE_WIDE_MIN)
+        !prec.narrow_filter_tiles && (M == 1 || TSD_NODE_WIDE_ANY_M) && (long)((N + TN - 1) / TN) * M >= TSD_NODE_WIDE_MIN)
         nrb = 2;
     const int node_tiles = layer == -2 ? 0 : (N + TN * nrb - 1) / (TN * nrb);
     if (q.pair) a.ready = q.ready;  // the node role of this launch publishes h to the pair tiles
@@ -2901,7 +2909,7 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
         node_stride = grid / node_tiles;
         if (node_stride % 2 == 0) --node_stride;
     }
-    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, pre_stride, M, node_stride, prec.range_status};
+    const ComboStride sd{L.total, nh_stride, ea_stride, wf_stride, pre_stride, ckpt_grid_m(M, grid), node_stride, prec.range_status};
     if (prec.mode == PREC_H2 && q.tiles > 0 && !q.pair) {
         set_error("internal: the split-f16 block launch has no pre role");
         return TSD_ERR_INVALID;

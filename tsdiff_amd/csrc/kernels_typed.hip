@@ -348,9 +348,9 @@ __global__ __launch_bounds__(2 * H) void typed_embed_h_kernel(TypedEmbedW w, Typ
                                                               UmapRole um, EmbedFuse0 f0, int32_t* range_status, int M) {
     constexpr int NT = 2 * H;
     const int embed_tiles = ta.n + tb.n;
-    // (1-D grid, checkpoint = id % M: one checkpoint per XCD with ensembles of 8 -- kernels_combo.hip layer_combo_kernel)
-    const int bx = (int)(blockIdx.x / (unsigned)M);
-    const size_t m = blockIdx.x % (unsigned)M;
+    int bx;  // (1-D grid, checkpoint = id % M: common.hpp wg_item_ckpt)
+    size_t m;
+    wg_item_ckpt(M, bx, m);
     if (bx >= embed_tiles) {  // extra role: directed-edge -> undirected-pair map (checkpoint 0 only)
         if (m == 0) {
             const int t = (bx - embed_tiles) * NT + (int)threadIdx.x;
@@ -398,7 +398,7 @@ int launch_typed_embed(const tsd_model_cfg& c, const float* W, const tsd_batch& 
         if (r) return r;                                                                                       \
         hipLaunchKernelGGL((typed_embed_h_kernel<HH, FU>), dim3(grid * M), dim3(2 * HH), lds, st, w, ta, tb, pos, \
                            b.geo.pair2u, b.num_pairs, b.geo.attr_row, edge_attr, out_stride, um, FARG,         \
-                           prec.range_status, M);                                                              \
+                           prec.range_status, ckpt_grid_m(M, grid));                                           \
     }
 #define TSD_TE(HH, FU, FARG)                                                                                   \
     {                                                                                                          \

@@ -36,7 +36,7 @@ constexpr int UE_MAX = 2016;   // undirected pairs per unit: one complete 64-ato
 constexpr int U_ROWS = 36 * 64;  // tile rows of a unit: 31.5 list tiles, or 36 block tiles (8 blocks: 8 * 9 / 2)
 
 struct UnitArgs {
-    int L, N, num_units, M;
+    int L, N, num_units, M;  // M: checkpoints, signed (common.hpp wg_item_ckpt)
     const int32_t* unit_node;  // [num_units + 1] node offsets
     const int32_t *node_graph, *graph_ptr, *pair_ptr, *pair2u;  // topology / geometry tables (block mode: tile row -> pair of the list)
     tsd_edges eu;              // undirected encoder list (row_ptr, src, dst, dist)
@@ -78,7 +78,7 @@ extern "C" int tsd_debug_unit_trace(void* host_buf) {
 #define UTRACE_DECL unsigned long long ut_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long ut_t = __builtin_amdgcn_s_memtime(); const unsigned long long ut_t0 = ut_t;
 #define UTRACE(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ut_acc[slot] += n_ - ut_t; ut_t = n_; } while (0)
 #define UTRACE_COUNT(slot) do { ut_acc[slot] += 1; } while (0)
-#define UTRACE_FLUSH do { ut_acc[9] = __builtin_amdgcn_s_memtime() - ut_t0; if (threadIdx.x == 0 && blockIdx.x % (unsigned)A.M == 0 && blockIdx.x / (unsigned)A.M < 4096) { for (int i_ = 0; i_ < 10; ++i_) g_unit_trace[(size_t)(blockIdx.x / (unsigned)A.M) * 16 + i_] = ut_acc[i_]; } } while (0)
+#define UTRACE_FLUSH do { ut_acc[9] = __builtin_amdgcn_s_memtime() - ut_t0; if (threadIdx.x == 0 && m == 0 && u < 4096) { for (int i_ = 0; i_ < 10; ++i_) g_unit_trace[(size_t)u * 16 + i_] = ut_acc[i_]; } } while (0)
 #else
 #define UTRACE_DECL
 #define UTRACE(slot)
@@ -112,14 +112,9 @@ __global__ __launch_bounds__(2 * H) void unit_encoder_kernel(UnitArgs A) {
     const Planes pl = planes_at(tile, UT, LDH);
     float* buf = tile;
 
-    // Workgroup -> (unit, checkpoint): checkpoint = id % M on a 1-D grid.  Workgroups are dealt to the 8 XCDs round robin
-    // (id % 8, MI355X_MICROARCH.md), so with the 8 checkpoints of a production ensemble every XCD only ever runs ONE
-    // checkpoint and its 4-MB L2 holds that checkpoint's weight images of the blocks its workgroups are in (1.3 MB per
-    // block); with checkpoint-major order an XCD saw three or four checkpoints at once and the tile GEMMs streamed their
-    // weights from the Infinity Cache (tools/trace_unit.py ens8: 7.1 / 6.7 k cycles per GEMM against 6.2 / 5.9 k with one
-    // checkpoint).  A speed assumption only (measured: the GEMM phases did not move; the change is neutral).
-    const int u = (int)(blockIdx.x / (unsigned)A.M);
-    const size_t m = blockIdx.x % (unsigned)A.M;
+    int u;       // (1-D grid, checkpoint = id % M: common.hpp wg_item_ckpt; measured neutral for this kernel)
+    size_t m;
+    wg_item_ckpt(A.M, u, m);
     const int tid = threadIdx.x;
     const int n0 = A.unit_node[u], n1 = A.unit_node[u + 1], na = n1 - n0;
     // The unit partition is the CALLER's (tsd_batch.unit_node): every workgroup checks its own unit -- offsets inside
@@ -717,7 +712,7 @@ int launch_unit_encoder(const tsd_model_cfg& c, const tsd_batch& b, const float*
     A.L = c.num_convs;
     A.N = b.num_nodes;
     A.num_units = b.num_units;
-    A.M = b.num_models;
+    A.M = ckpt_grid_m(b.num_models, b.num_units);
     A.unit_node = b.unit_node;
     A.node_graph = b.node_graph;
     A.graph_ptr = b.graph_ptr;
