@@ -302,7 +302,7 @@ __device__ __forceinline__ void xl_gather(const int32_t* __restrict__ row_ptr, c
                                           const float* __restrict__ x, int xbase, int nloc, float* xs, int N, int n0,
                                           float* buf, float& amax, WaitFn&& wait_for_x) {
     static_assert(H == 256, "one 16-byte load per lane and row");
-    constexpr int V = 4, U = 8, LDH = ldh_of(H), RPW = TR / NW, C4 = H / 4;
+    constexpr int V = 4, U = 8, LDH = ldh_of(H), RPW = TR / NW;
     static_assert(TR % NW == 0 && TR <= TN, "");
     const Planes pl = planes_at(buf, TN, LDH);
     dst = reinterpret_cast<const int32_t*>(uniform_ptr(dst));
@@ -2638,7 +2638,6 @@ __global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A) {
     else if (b < A.n_filter + parked) filter_item = b - parked;
     else if (b < A.n_filter + A.n_pair) pair_item = b - A.n_filter;
     if (filter_item >= 0) {  // filter tiles of blocks 1 .. L-1
-        const int layer = 1 + filter_item / A.tiles_per_layer;
 #ifndef TSD_MEGA_SKIP_FILTER  // (timing experiments only: wrong results)
         filter_role_h<H, 1>(A.f, filter_item, smem, A.status, FilterSave{} TSD_TRACE_NULL);
 #endif
@@ -2650,7 +2649,7 @@ __global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A) {
                                __HIP_MEMORY_SCOPE_AGENT);  // (filter_item counts from block 1)
         TSD_MEGA_T(0, 3);
         TSD_MEGA_T(2, wall_clock64());
-        TSD_MEGA_T(3, (unsigned long long)layer);
+        TSD_MEGA_T(3, (unsigned long long)(1 + filter_item / A.tiles_per_layer));
         return;
     }
     if (pair_item >= 0) {
