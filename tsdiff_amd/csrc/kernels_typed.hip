@@ -390,7 +390,7 @@ int launch_typed_embed(const tsd_model_cfg& c, const float* W, const tsd_batch& 
     }
     const int grid = ta.n + tb.n + um.blocks;
     if (grid == 0) return TSD_OK;
-    const size_t lds = h2 ? (size_t)(T * ldh_of(H) + T * (H + 4) + 3 * T + 3 * H /* biases */) * 4 : (size_t)(T * (H + 4) + 2 * T) * 4;
+    const size_t lds = h2 ? (size_t)(T * ldh_of(H) + 3 * T + 3 * H /* biases */) * 4 : (size_t)(T * (H + 4) + 2 * T) * 4;
 #define TSD_TEH(HH, FU, FARG)                                                                                  \
     {                                                                                                          \
         static DeviceOnce once;                                                                                \

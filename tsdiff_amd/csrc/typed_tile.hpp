@@ -31,9 +31,15 @@ __device__ __forceinline__ void typed_embed_tile_h(const TypedEmbedW& w, const T
                                                    float* smem) {
     constexpr int T = TSD_EDGE_TILE;
     constexpr int LDA = H + 4, LDH = ldh_of(H), NT = 2 * H, C4 = H / 4;
+    // LDS: 37 KB -- the fp32 staging rows of block 0's filter tile lie OVER the planes (one more barrier per tile), so that
+    // THREE workgroups share a CU (<= 80 VGPRs: tools/check_regs.py): round 5 measured 8 checkpoints at batch 100 1.271 ->
+    // 1.255 ms/step, BASELINE configs[4] 18.29 -> 18.15, batch 100 unchanged (0.1947 / 0.1946); 64-row tiles (one pass over a
+    // bucket's matrix per 64 pairs, two workgroups per CU) measured WORSE at batch 100 (0.195 -> 0.200) and with 8
+    // checkpoints (1.271 -> 1.281), equal elsewhere: not kept (docs/NOTEBOOK.md)
+    static_assert(LDA <= LDH, "the staging rows lie over the planes");
     const Planes pl = planes_at(smem, T, LDH);
-    float* stage = smem + T * LDH;  // fp32 rows [T][LDA]
-    float* s_d = stage + T * LDA;
+    float* stage = smem;  // fp32 rows [T][LDA] (FUSE0; over the planes)
+    float* s_d = smem + T * LDH;
     int* s_row = reinterpret_cast<int*>(s_d + T);
     float* s_cw = s_d + 2 * T;  // CFConv cutoff weight of the row (block-0 filters)
     // transposed accumulators (split16.hpp hgemm_ring_run<..., TRANS>, as kernels_combo.hip::filter_role_h): lane = tile row
@@ -177,7 +183,7 @@ __device__ __forceinline__ void typed_embed_tile_h(const TypedEmbedW& w, const T
         const float bb2 = TR ? 0.0f : nn2_b[col];
         hzero(accm, accx);
         hgemm_ring_run<1, 1, H, false, TR>(rg, pl, LDH, accm, accx);
-        // (every wave passed the barrier above after its row stores from `stage`: it may be overwritten)
+        __syncthreads();  // (every wave has read its last operand fragment: the planes become the staging rows)
         if constexpr (TR) {
             const float* bb = s_bias + 2 * H + col0 + 4 * hi;
             const float cw = s_cw[l31];
