@@ -1311,7 +1311,10 @@ __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, fl
 }
 
 // SAVE (training step): the tile's inputs and pre-/post-activations also go to `sv` (as pair_output_kernel<H, true>).
-template <int H, bool SAVE = false>
+// HSPLIT (the stand-alone launch, whose budget is 80 VGPRs = three workgroups per CU): the h rows in two batches of two
+// chunks per thread (16 registers instead of 32 beside the live accumulators; the other workgroups of the CU hide the
+// second round trip).
+template <int H, bool SAVE = false, bool HSPLIT = false>
 __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int node_tiles, float* smem, bool defer_pre,
                                             int32_t* range_status, const PairSave& sv = PairSave{}) {
     constexpr int LDH = ldh_of(H), NT = 2 * H, C4 = H / 4, NW = H / 64;
@@ -1349,21 +1352,25 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
         s_row[tid] = row;
     }
     __syncthreads();
+    // ONE accumulation chain for Linear(2H, H) of the concatenation [h_src * h_dst, attr] (common.py:226-229): the attribute
+    // half first (it does not depend on h: the one-launch forward runs it while the node tiles finish), then the h half
+    // into the SAME accumulators -- no 16 registers of intermediate sums beside them (80 VGPRs: three workgroups per CU)
     f32x16 accm[1][1], accx[1][1];
-    float pre_v[16];
-    f32x4 hs[4], hd[4];  // the gathered h rows of the tile (NIT = 4 chunks per thread)
-    auto issue_h = [&]() {
+    constexpr int PR = HSPLIT ? 2 : HRING_R;  // weight k-steps in flight (HSPLIT: six waves per SIMD hide the rest)
+    constexpr int HB = HSPLIT ? 2 : 4;  // chunks of the gathered h rows per thread and batch (NIT = 4 in all)
+    f32x4 hs[HB], hd[HB];
+    auto issue_h = [&](int it0) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+        for (int k = 0; k < HB; ++k) {
+            const int idx = tid + (it0 + k) * NT, r = idx / C4, c4 = idx % C4;
             const float* ps = q.h + (size_t)s_src[r] * H + c4 * 4;
             const float* pd = q.h + (size_t)s_dst[r] * H + c4 * 4;
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(hs[it]) : "v"(ps) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(hd[it]) : "v"(pd) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(hs[k]) : "v"(ps) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(hd[k]) : "v"(pd) : "memory");
         }
     };
     auto pre_gemm = [&]() {
-        HRing<1, HRING_R> rg;
+        HRing<1, PR> rg;
         constexpr int NIT = T * C4 / NT;
         static_assert(NIT == 4, "ld16_wait4 names four registers");
         f32x4 v[NIT];  // (sc1: see filter_role_h)
@@ -1395,20 +1402,14 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
         __syncthreads();
         hzero(accm, accx);
         hgemm_ring_run<1, 1, H, false, TR12>(rg, pl, LDH, accm, accx);
-        if constexpr (TR12) {
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(q.b0 + col0 + 8 * g4 + 4 * hi);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    pre_v[4 * g4 + r] = l31 < nrows ? hval(accm[0][0], accx[0][0], 4 * g4 + r) + bv[r] : 0.0f;
-            }
-        } else {
-            const float b = q.b0[col];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) pre_v[r] = acc_row(r, hi) < nrows ? hval(accm[0][0], accx[0][0], r) + b : 0.0f;
-        }
     };
+    // the first layer's biases: the one-launch forward (whose pair tiles end its dependency chain) requests them here, ahead of
+    // the wait for the node tiles; the stand-alone launch (80 VGPRs) where it adds them
+    f32x4 b0v[4];
+    if constexpr (TR12 && !HSPLIT) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) b0v[g4] = *reinterpret_cast<const f32x4*>(q.b0 + col0 + 8 * g4 + 4 * hi);
+    }
     if (!defer_pre) pre_gemm();
     // wait for the node tiles that hold this tile's atoms (min .. max node id over both end points)
     if (wave == 0 && q.ready != nullptr) {  // (ready == NULL: the stand-alone pair output, h is complete)
@@ -1444,44 +1445,54 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
         pre_gemm();
         __syncthreads();
     }
-    HRing<1, HRING_R> rg;
+    HRing<1, PR> rg;
     {   // h_src * h_dst -> LDS planes.  The rows were written by other CUs during this launch: sc1 loads
         constexpr int NIT = T * C4 / NT;
         static_assert(T * C4 % NT == 0, "tile / block mismatch");
         static_assert(NIT == 4, "the wait statement names 2 x 4 registers");
         // (requesting these rows together with the attribute rows in the stand-alone launch -- one round trip instead of two,
         // 32 more registers across the first GEMM -- measured nothing: 1.372 vs 1.377 ms/step with 8 checkpoints, round 5)
-        issue_h();
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(hs[0]), "+v"(hs[1]), "+v"(hs[2]), "+v"(hs[3]), "+v"(hd[0]), "+v"(hd[1]), "+v"(hd[2]), "+v"(hd[3])
-                     :: "memory");
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            planes_store4(pl, r * LDH + c4 * 4, r < nrows ? hs[it] * hd[it] : z, amax);
-            if constexpr (SAVE) {
-                if (r < nrows) *reinterpret_cast<f32x4*>(sv.hp + (size_t)(e0 + r) * 2 * H + c4 * 4) = hs[it] * hd[it];
+        for (int it0 = 0; it0 < NIT; it0 += HB) {
+            issue_h(it0);
+            if constexpr (HSPLIT)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(hs[0]), "+v"(hs[1]), "+v"(hd[0]), "+v"(hd[1]) :: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(hs[0]), "+v"(hs[1]), "+v"(hs[HB - 2]), "+v"(hs[HB - 1]), "+v"(hd[0]), "+v"(hd[1]),
+                               "+v"(hd[HB - 2]), "+v"(hd[HB - 1])
+                             :: "memory");
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const int idx = tid + (it0 + k) * NT, r = idx / C4, c4 = idx % C4;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                planes_store4(pl, r * LDH + c4 * 4, r < nrows ? hs[k] * hd[k] : z, amax);
+                if constexpr (SAVE) {
+                    if (r < nrows) *reinterpret_cast<f32x4*>(sv.hp + (size_t)(e0 + r) * 2 * H + c4 * 4) = hs[k] * hd[k];
+                }
             }
         }
     }
     hgemm_ring_start<1, H>(rg, q.w0a, H, col0);  // (behind the staging: its registers are free now)
     __syncthreads();
-    hzero(accm, accx);
-    hgemm_ring_run<1, 1, H, false, TR12>(rg, pl, LDH, accm, accx);
+    hgemm_ring_run<1, 1, H, false, TR12>(rg, pl, LDH, accm, accx);  // (on top of the attribute half's sums)
     __syncthreads();
     if constexpr (TR12) {
+        const bool live = l31 < nrows;  // (rows past the end: zeros, as their h rows)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 bv;
+            if constexpr (HSPLIT) bv = *reinterpret_cast<const f32x4*>(q.b0 + col0 + 8 * g4 + 4 * hi);
+            else bv = b0v[g4];
             f32x4 s4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s4[r] = swishf(pre_v[4 * g4 + r] + hval(accm[0][0], accx[0][0], 4 * g4 + r));
+            for (int r = 0; r < 4; ++r) s4[r] = swishf(live ? hval(accm[0][0], accx[0][0], 4 * g4 + r) + bv[r] : 0.0f);
             planes_store4(pl, l31 * LDH + col0 + 8 * g4 + 4 * hi, s4, amax);
         }
     } else
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const float v = pre_v[r] + hval(accm[0][0], accx[0][0], r), sg = swishf(v);
+        const float v = acc_row(r, hi) < nrows ? hval(accm[0][0], accx[0][0], r) + q.b0[col] : 0.0f, sg = swishf(v);
         planes_store1(pl, acc_row(r, hi) * LDH + col, sg, amax);
         if constexpr (SAVE) {
             const int row = acc_row(r, hi);
@@ -1495,7 +1506,7 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
     if (wave < NW) {  // H -> H/2 and the final dot: the first H/64 waves
         const int c2 = wave * 32 + l31;
         hzero(accm, accx);
-        hgemm_tile<1, 1, H, false, HRING_R, TR3>(pl, LDH, q.w1, H / 2, wave * 32, accm, accx);
+        hgemm_tile<1, 1, H, false, PR, TR3>(pl, LDH, q.w1, H / 2, wave * 32, accm, accx);
         if constexpr (TR3) {   // the lane's 16 channels of row l31 summed in register order, then the other half-wave's 16
             float v = 0.0f;
 #pragma unroll
@@ -2117,8 +2128,10 @@ int filter_tiles_per_layer(int capacity_u);
 
 // The stand-alone pair output (tsd_pair_output's place in a forward that does not run it inside the last block
 // launch) on the f16 MFMA pipes: pair_role_h without the wait.
+// (inference form: three workgroups of 8 waves per CU = 6 waves per SIMD = 80 VGPRs; the compiler's free allocation is 84, the
+// cap costs no spill -- tools/check_regs.py holds it to 80 registers and no scratch)
 template <int H, bool SAVE = false>
-__global__ __launch_bounds__(2 * H) void pair_output_h_kernel(ComboPre q, size_t wstride, size_t h_stride, size_t ea_stride,
+__global__ __launch_bounds__(2 * H) __attribute__((amdgpu_waves_per_eu(SAVE || H != 256 ? 1 : 6))) void pair_output_h_kernel(ComboPre q, size_t wstride, size_t h_stride, size_t ea_stride,
                                                               int32_t* range_status, PairSave sv, int M) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int tile;
@@ -2128,7 +2141,7 @@ __global__ __launch_bounds__(2 * H) void pair_output_h_kernel(ComboPre q, size_t
     q.edge_attr += m * ea_stride; q.w0b += wo; q.b0 += wo;
     q.w0a += wo; q.w1 += wo; q.b1 += wo; q.w2 += wo; q.b2 += wo;
     q.h += m * h_stride; q.edge_inv += m * q.inv_stride;
-    pair_role_h<H, SAVE>(q, tile, 0, smem, false, range_status, sv);
+    pair_role_h<H, SAVE, !SAVE>(q, tile, 0, smem, false, range_status, sv);
 }
 int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity, tsd_edges e, const float* h,
                          const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
