@@ -247,8 +247,13 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     const Workspace w = carve(c, N, P, M, b.workspace);
     const int node_tiles_all = (N + TSD_NODE_TILE - 1) / TSD_NODE_TILE;
     // small forwards (the node chain of a block leaves most of the chip idle): the LAST block launch also runs the
-    // whole pair MLP behind per-node-tile readiness flags, which the embedding launch zeroes
-    const bool small_fwd = (long)node_tiles_all * M <= 256;
+    // whole pair MLP behind per-node-tile readiness flags, which the embedding launch zeroes.  The split-f16 forward does so
+    // up to 4096 node tiles x checkpoints (round 5: one launch boundary less is worth 300 graphs 0.463 -> 0.458 ms/step,
+    // 600: 0.871 -> 0.857, 8 checkpoints at batch 100 1.258 -> 1.251, 200 x 4: 1.214 -> 1.205; not measured beyond)
+#ifndef TSD_SMALL_FWD_MAX
+#define TSD_SMALL_FWD_MAX 4096
+#endif
+    const bool small_fwd = (long)node_tiles_all * M <= (h2 ? TSD_SMALL_FWD_MAX : 256);
     if (small_fwd) {
         um.zero_words = w.ready;
         um.n_zero = node_tiles_all * M;
@@ -266,12 +271,12 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     f0.smooth = c.smooth_conv;
     f0.wf = w.wf;
     f0.wf_stride = w.stride_wf;
-    // (batch-100 sizes only: measured 0.441 -> 0.435 ms/step at configs[1]; at configs[4] the longer embedding
-    // tiles lose more than the launch saves, 50.5 -> 52.8 ms/step)
-    // static type-sorted tiles (one GEMM per embedded edge instead of three) when the batch carries them
-    // ... and with the typed embedding's small LDS tile also at configs[4] sizes (42.90 -> 42.54 ms/step; the 8-checkpoint
-    // ensemble at batch 100 in between loses 0.4 %: not there)
-    const bool fuse_block0 = !fused && (small_fwd || mega || (typed && (long)node_tiles_all * M >= 2048));
+    // Block 0's filters ride with the embedding tiles (the attribute tile is in LDS already: two more GEMMs instead of a
+    // launch that reloads it).  With the typed embedding's small tile: everywhere (round 5, three workgroups per CU:
+    // 300 graphs 0.484 -> 0.454 ms/step, 600: 0.867 -> 0.865, 8 checkpoints at batch 100 1.251 -> 1.247, 200 graphs x 4
+    // checkpoints 1.206 -> 1.199; round 3 had it at batch-100 sizes and >= 2048 node tiles only); with the generic
+    // embedding kernel at batch-100 sizes only (configs[4]: 50.5 -> 52.8 ms/step with it, round 2)
+    const bool fuse_block0 = !fused && (small_fwd || mega || typed);
     if (typed) {
         if ((r = launch_typed_embed(c, W, b, pos, w.ea, M, w.stride_ea, st, &um, fuse_block0 ? &f0 : nullptr, prec))) return r;
     } else if ((r = launch_edge_embed2(c, W, PU, g.enc_u, w.ea, PU, g.diff_u, w.ea + (size_t)PU * H, M, w.stride_ea, st,
