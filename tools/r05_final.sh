@@ -4,6 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out
 ( time timeout 1500 python3 -m pytest tests -q -m gpu ) > $O/r05_gpu_tests.log 2>&1; tail -3 $O/r05_gpu_tests.log
 bash tools/profile_round.sh r05 > $O/r05_profile_round.log 2>&1
+cp $O/r05_pmc_traffic*.json $O/r05_mfma_busy.json profiles/ 2>/dev/null  # (bench.py reads the counter files of THIS campaign)
 bash tools/bench_round.sh r05 > $O/r05_bench_round.log 2>&1; tail -12 $O/r05_bench_round.log
 python3 tools/power_trace.py --hz 20 --seconds 6 --out $O/r05_c5_power_clock.md c5 d128 d256 ens8 c2 > $O/r05_power.log 2>&1; cat $O/r05_c5_power_clock.md
 bash tools/energy_probe.sh > $O/r05_energy_probe.log 2>&1; cat $O/r05_energy_probe.log | tail -6
