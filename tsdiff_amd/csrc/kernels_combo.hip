@@ -2276,6 +2276,7 @@ struct MegaCtl {  // int32 words in the forward workspace
 struct MegaArgs {
     // roles' grid ranges
     int n_node, n_filter, n_pair, tiles_per_layer;
+    int filter_rows;           // pairs per filter tile: 32, or 64 (hidden 256, a block's tiles fill the chip)
     int L, N;
     int half_slots;            // half of the device's resident-workgroup slots for this kernel (mega_slots() / 2: 256 on a whole MI355X)
     const int32_t* epoch_src;  // device word: epoch = *epoch_src + epoch_bias (>= 1, + 1 per launch since the block was zeroed)
@@ -2297,6 +2298,16 @@ struct MegaArgs {
     ComboPre q;
 };
 
+// Rows per filter tile of the one-launch forward (MegaArgs.filter_rows: 32 or 64, hidden 256).  At batch 100 the launch is
+// paced by its filter tiles -- 2448 of 32 rows on the ~312 slots the node workgroups and the parked pair tiles leave them
+// run until 132 us of a 157-us launch, and every block's node chain waits for the last tiles of its layer (tools/trace_mega.py)
+// -- and a weight fragment that feeds two row blocks is the cheaper tile per row, as in the chip-full launches: with 64-row
+// tiles the last filter tile ends at 111 us, the launch at 150 (traced builds); 0.1884 -> 0.1876 / 0.1889 -> 0.1869 ms/step
+// untraced.  Half-empty launches (50 graphs: +1.2 %) keep the shorter tiles: 64 rows from TSD_MEGA_WIDE_MIN 32-row tiles per
+// block on.
+#ifndef TSD_MEGA_WIDE_MIN
+#define TSD_MEGA_WIDE_MIN 384  // (0: never)
+#endif
 constexpr unsigned MEGA_SPIN_LIMIT = 4000000u;
 #ifndef TSD_MEGA_XLDS
 #define TSD_MEGA_XLDS 1  // the node workgroups gather x from an LDS copy of their graphs' rows (aggregate_tile_xl); 0: from L2
@@ -2424,8 +2435,8 @@ __device__ __forceinline__ void node_persist_h(const MegaArgs& A, int tile, int 
             hn = max(hn, __shfl_xor(hn, off));
         }
         if (hn >= 0) {
-            f_lo = lo / T;
-            f_hi = hn / T;
+            f_lo = lo / A.filter_rows;
+            f_hi = hn / A.filter_rows;
         }
     }
     bool use_xl = false;
@@ -2652,7 +2663,12 @@ __global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A) {
     else if (b < A.n_filter + A.n_pair) pair_item = b - A.n_filter;
     if (filter_item >= 0) {  // filter tiles of blocks 1 .. L-1
 #ifndef TSD_MEGA_SKIP_FILTER  // (timing experiments only: wrong results)
-        filter_role_h<H, 1>(A.f, filter_item, smem, A.status, FilterSave{} TSD_TRACE_NULL);
+        if constexpr (H == 256) {
+            if (A.filter_rows == 2 * T) filter_role_h<H, 2>(A.f, filter_item, smem, A.status, FilterSave{} TSD_TRACE_NULL);
+            else filter_role_h<H, 1>(A.f, filter_item, smem, A.status, FilterSave{} TSD_TRACE_NULL);
+        } else {
+            filter_role_h<H, 1>(A.f, filter_item, smem, A.status, FilterSave{} TSD_TRACE_NULL);
+        }
 #endif
         // every storing wave drains, the workgroup meets, ONE lane publishes the tile (Guideline 16 R1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2680,7 +2696,7 @@ __global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A) {
 // or smaller part the filter tiles they wait for always find a free slot.  (A second tenant on the same GPU can still
 // hold slots: that is what the bounded waits and the host's per-block rerun are for.)
 static size_t mega_lds_bytes(int H) {
-    size_t lds = lds_combo(H, PREC_H2);
+    size_t lds = lds_combo(H, PREC_H2, H == 256 && TSD_MEGA_WIDE_MIN > 0 ? 2 : 1);
     if (H == 256 && MEGA_TR == TN && TSD_MEGA_XLDS)  // the node workgroups' LDS copy of x (xl_gather) behind their planes
         lds = std::max(lds, (size_t)(TN * ldh_of(256) + XS_ROWS * 256 + 2 * 256 /* s_bias */) * 4);
     return lds;
@@ -2751,7 +2767,9 @@ int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float*
     A.wf = wf;
     A.wf_layer_stride = (size_t)PU * H;
     // filter role: the queue of kernels_combo's per-block launches from block 1 on, slot = block
-    A.tiles_per_layer = filter_tiles_per_layer(PU);
+    const int frb = (H == 256 && TSD_MEGA_WIDE_MIN > 0 && filter_tiles_per_layer(PU) >= TSD_MEGA_WIDE_MIN) ? 2 : 1;
+    A.filter_rows = T * frb;
+    A.tiles_per_layer = (PU + T * frb - 1) / (T * frb);
     A.f.tiles = (L - 1) * A.tiles_per_layer;
     A.f.g_begin = A.tiles_per_layer;
     A.f.tiles_per_layer = A.tiles_per_layer;
