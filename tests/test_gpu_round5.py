@@ -122,3 +122,39 @@ def test_fused_encoder_refuses_a_broken_unit_partition(dev, monkeypatch):
         else:
             inv2, _, _ = run_forward(model, g, dev)
             assert torch.equal(inv2, ref) and db.per_block
+
+
+@pytest.mark.parametrize("graphs,M", [(12, 4), (40, 2), (100, 2), (100, 4), (30, 3)])
+def test_ensemble_in_the_one_launch_form_matches_the_block_launches(graphs, M, dev, monkeypatch):
+    """An ensemble whose checkpoints make whole groups (as many per group as keep the node workgroups within half of the
+    chip's slots) runs in the one-launch kernel, group after group in one grid (api.hip mega_shape / mega_group): one group
+    (12 x 4, 40 x 2, 100 x 2), two groups of two (100 x 4); 30 x 3 fits one group as well.  Bit-identical to the
+    launch-per-block forms, per checkpoint (edge_inv of every checkpoint), and to each checkpoint run alone."""
+    from tests.test_gpu_round4 import _db
+    from tsdiff_amd import engine, synth
+    from tsdiff_amd.sampler import EnsembleSampler
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    b, t, g = _stretched_batch(graphs, 7 + graphs + M, dev)
+    args = (g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"], None)
+    out = {}
+    for form in (True, False):
+        monkeypatch.setattr(engine.OPTIONS, "gemm", "h2")
+        monkeypatch.setattr(engine.OPTIONS, "one_launch", form)
+        monkeypatch.setattr(engine.OPTIONS, "fused_encoder", False)
+        ens = EnsembleSampler([make_model(cfg, 10 + k, dev) for k in range(M)])
+        with torch.no_grad():
+            mean = ens(*args)[0].clone()
+        db = ens._bound_batch(*args[:3], *args[4:7])
+        assert not db.per_block
+        out[form] = (mean, db.edge_inv_u.clone())
+    assert torch.equal(out[True][1], out[False][1])   # every checkpoint's pair outputs
+    assert torch.equal(out[True][0], out[False][0])
+    # checkpoint k alone (the single-checkpoint one-launch form)
+    monkeypatch.setattr(engine.OPTIONS, "one_launch", True)
+    E = out[True][0].shape[0]
+    for k in (0, M - 1):
+        one = EnsembleSampler([make_model(cfg, 10 + k, dev)])
+        with torch.no_grad():
+            one(*args)
+        d1 = one._bound_batch(*args[:3], *args[4:7])
+        assert torch.equal(d1.edge_inv_u[0, :E // 2], out[True][1][k, :E // 2]), k   # (undirected out edges)

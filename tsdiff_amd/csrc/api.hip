@@ -135,7 +135,7 @@ struct Workspace {
     int32_t* ctl;    // control words of the one-launch forward (kernels_combo.hip MegaCtl), zeroed by the host per run
     size_t ctl_words;
     float* x1m;      // one-launch forward: [L - 1][N, H] x1 of every block (a buffer is written once per launch)
-    size_t stride_ea, stride_wf, stride_nh, stride_pre;
+    size_t stride_ea, stride_wf, stride_nh, stride_pre, stride_ctl /* int32 words */, stride_x1m;
     int wf_slots;
     size_t total;
 };
@@ -149,14 +149,29 @@ constexpr bool kFold = TSD_FOLD != 0;
 #ifndef TSD_MEGA
 #define TSD_MEGA 1  // 0 (A/B variant builds): the split-f16 forward as one launch per block
 #endif
-// Shapes the one-launch forward takes: one checkpoint, every node workgroup resident at once on at most HALF of the
+// Shapes the one-launch forward takes: every node workgroup of a checkpoint resident at once on at most HALF of the
 // device's slots for that kernel (occupancy x compute units, queried per device: 512 on a whole MI355X, less on a
 // partitioned or smaller part), and a filter arena of all L blocks (no ring) that stays small.
+// An ensemble (round 5) runs in the SAME launch as groups of G checkpoints -- as many as fit that half of the slots --
+// one group after the other in the grid, when it is whole groups: 2 checkpoints at batch 100 0.381 -> 0.312 ms/step, 8 at
+// batch 25 0.426 -> 0.345 (one group each), 8 at batch 100 1.236 -> 1.206 (four groups of two), 4 x 200 graphs 1.191 ->
+// 1.159 (four of one); a last group that is not full loses (3 checkpoints at batch 100 as 2 + 1: 0.475 -> 0.547), so
+// such ensembles stay on the launch-per-block forms.
+#ifndef TSD_MEGA_ENSEMBLE
+#define TSD_MEGA_ENSEMBLE 1  // 0 (A/B variant builds): ensembles on the launch-per-block forms, as before round 5
+#endif
+// checkpoints per group of the one-launch forward
+static int mega_group(const tsd_model_cfg& c, int N, int M) {
+    const int node_wgs = (N + mega_node_rows() - 1) / mega_node_rows();
+    const int fit = node_wgs > 0 ? mega_slots(c.hidden) / 2 / node_wgs : 1;
+    return fit < 1 ? 1 : (fit > M ? M : fit);
+}
 static bool mega_shape(const tsd_model_cfg& c, int N, int P, int M) {
-    if (TSD_MEGA == 0 || M != 1 || N <= 0 || c.num_convs > 60) return false;
+    if (TSD_MEGA == 0 || M < 1 || (M != 1 && !TSD_MEGA_ENSEMBLE) || N <= 0 || c.num_convs > 60) return false;
     const int node_wgs = (N + mega_node_rows() - 1) / mega_node_rows();
     if (2 * node_wgs > mega_slots(c.hidden)) return false;
-    return (size_t)(P / 2) * c.hidden * c.num_convs * sizeof(float) <= ((size_t)2 << 30);
+    if (M > 1 && M % mega_group(c, N, M) != 0) return false;
+    return (size_t)M * (P / 2) * c.hidden * c.num_convs * sizeof(float) <= ((size_t)2 << 30);
 }
 
 static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base) {
@@ -179,9 +194,12 @@ static Workspace carve(const tsd_model_cfg& c, int N, int P, int M, float* base)
     w.stride_pre = pad(PU * H);
     w.pre = take(w.stride_pre * M);
     w.ready = reinterpret_cast<int32_t*>(take(pad((size_t)M * ((N + TSD_NODE_TILE - 1) / TSD_NODE_TILE))));
-    w.ctl_words = pad(mega_shape(c, N, P, M) ? mega_ctl_words(filter_tiles_per_layer((int)PU), c.num_convs) : 64);
+    // (one control block and one x1m block per checkpoint)
+    w.stride_ctl = pad(mega_shape(c, N, P, M) ? mega_ctl_words(filter_tiles_per_layer((int)PU), c.num_convs) : 64);
+    w.ctl_words = w.stride_ctl * (mega_shape(c, N, P, M) ? (size_t)M : 1);
     w.ctl = reinterpret_cast<int32_t*>(take(w.ctl_words));
-    w.x1m = take(mega_shape(c, N, P, M) && c.num_convs > 1 ? w.stride_nh * (size_t)(c.num_convs - 1) : 0);
+    w.stride_x1m = mega_shape(c, N, P, M) && c.num_convs > 1 ? w.stride_nh * (size_t)(c.num_convs - 1) : 0;
+    w.x1m = take(w.stride_x1m * M);
     w.total = o;
     return w;
 }
@@ -290,8 +308,18 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
             epoch_src = w.ctl + 32;  // (MegaCtl::ZERO: a word nothing writes)
             epoch_bias = 1;
         }
+        // an ensemble: groups of as many checkpoints as keep the node workgroups within half of the slots, group after
+        // group in the same grid
+        MegaGroup mg;
+        mg.M = M;
+        mg.G = mega_group(c, N, M);
+        mg.s_nh = w.stride_nh;
+        mg.s_x1m = w.stride_x1m;
+        mg.s_wf = w.stride_wf;
+        mg.s_ea = w.stride_ea;
+        mg.s_ctl = (int)w.stride_ctl;
         return launch_forward_mega(c, b, pos, W, w.ea, w.wf, w.h, w.x1m, w.stride_nh, w.ctl, epoch_src, epoch_bias,
-                                   prec.range_status, st);
+                                   prec.range_status, st, mg);
     }
     if (fused) {
         // embedding launch (attribute rows) -> the whole encoder as one launch -> pair MLP launch
@@ -719,8 +747,8 @@ int tsd_forward_blocks(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t
     TSD_REQUIRE(epoch >= 1, "epoch=%d (1, 2, ... since the first call)", epoch);
     const tsd_batch& b = *batch;
     const bool typed = kFold && b.enc_tiles.num_tiles > 0 && b.bucket_weights != nullptr;
-    if (!(typed && b.weights16 && b.bucket_weights16 && b.status && mega_shape(*cfg, b.num_nodes, b.num_pairs, b.num_models) &&
-          b.num_pairs > 0)) {
+    if (!(typed && b.weights16 && b.bucket_weights16 && b.status && b.num_models == 1 &&
+          mega_shape(*cfg, b.num_nodes, b.num_pairs, b.num_models) && b.num_pairs > 0)) {
         set_error("tsd_forward_blocks: the batch does not take the one-launch split-f16 forward");
         return TSD_ERR_UNSUPPORTED;
     }

@@ -280,9 +280,14 @@ int launch_pack_weights16(const tsd_model_cfg& c, const float* packed, float* pa
 int launch_attr_planes(int H, int64_t rows, const float* src, float* dst, hipStream_t st);
 int launch_weights_preflight(const float* w, size_t n, float* out8, hipStream_t st);
 // the whole split-f16 forward of one checkpoint as ONE launch (kernels_combo.hip, small batches)
+struct MegaGroup {   // the M checkpoints of a batch in groups of G in one launch of the one-launch forward; strides in floats / int32 words
+    int M = 1, G = 1;
+    size_t s_nh = 0, s_x1m = 0, s_wf = 0, s_ea = 0;
+    int s_ctl = 0;
+};
 int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float* pos, const float* W16, float* ea, float* wf,
                         float* h, float* x1m, size_t x1_stride, int32_t* ctl, const int32_t* epoch_src, int epoch_bias,
-                        int32_t* status, hipStream_t st);
+                        int32_t* status, hipStream_t st, const MegaGroup& mg = MegaGroup{});
 size_t mega_ctl_words(int tiles_per_layer, int L);
 int mega_node_rows();
 int mega_slots(int H);  // resident workgroup slots of the one-launch kernel on the current device (0: unknown)

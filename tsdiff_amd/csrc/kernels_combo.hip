@@ -2277,6 +2277,11 @@ struct MegaArgs {
     // roles' grid ranges
     int n_node, n_filter, n_pair, tiles_per_layer;
     int filter_rows;           // pairs per filter tile: 32, or 64 (hidden 256, a block's tiles fill the chip)
+    // checkpoints of this launch (an ensemble's forwards in groups whose node workgroups fit the resident half of the chip):
+    // workgroup id = item * G + g, every pointer below is checkpoint 0's of the group and moves by g * its stride
+    int G, M, per_group;       // G checkpoints per group, M in all (the grid holds ceil(M / G) groups of per_group workgroups each, group-major)
+    size_t s_w, s_nh, s_x1m, s_wf, s_ea, s_inv;  // floats: weight arena, node arrays, x1m block, filter arena, attribute rows, edge_inv
+    int s_ctl;                 // int32 words of one checkpoint's control block
     int L, N;
     int half_slots;            // half of the device's resident-workgroup slots for this kernel (mega_slots() / 2: 256 on a whole MI355X)
     const int32_t* epoch_src;  // device word: epoch = *epoch_src + epoch_bias (>= 1, + 1 per launch since the block was zeroed)
@@ -2627,12 +2632,31 @@ __device__ __forceinline__ void node_persist_h(const MegaArgs& A, int tile, int 
 
 
 template <int H>
-__global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A) {
+__global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A_) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     TSD_MEGA_T(1, wall_clock64());
+    MegaArgs A = A_;
+    int b = blockIdx.x;
+    if (A.M > 1) {
+        // An ensemble: groups of G checkpoints one after the other in the grid (a group's node workgroups are dispatched when
+        // the group before has left them slots: they wait for workgroups of their own checkpoint only, so in-order dispatch
+        // is still enough for progress), a group's checkpoints interleaved -- one checkpoint's workgroups on the XCDs
+        // id % G (common.hpp wg_item_ckpt)
+        const unsigned grp = (unsigned)b / (unsigned)A.per_group;
+        b = (int)((unsigned)b % (unsigned)A.per_group);
+        const size_t g = (size_t)grp * A.G + (unsigned)b % (unsigned)A.G;
+        b = (int)((unsigned)b / (unsigned)A.G);
+        if (g >= (size_t)A.M) return;   // (the last group of an ensemble that is no multiple of G)
+        const size_t ow = g * A.s_w, on = g * A.s_nh, owf = g * A.s_wf, oea = g * A.s_ea;
+        A.ctl += g * (size_t)A.s_ctl;
+        A.W += ow; A.z += on; A.x1_0 += on; A.x1m += g * A.s_x1m; A.h += on; A.wf += owf;
+        A.f.Wl0 += ow; A.f.edge_attr += oea; A.f.wf += owf;
+        A.q.edge_attr += oea; A.q.w0b += ow; A.q.b0 += ow; A.q.w0a += ow; A.q.w1 += ow; A.q.b1 += ow; A.q.w2 += ow; A.q.b2 += ow;
+        A.q.h += on; A.q.edge_inv += g * A.s_inv; A.q.ready += g * (size_t)A.s_ctl;
+        A.half_slots /= A.G;   // (the parking arithmetic below is per checkpoint)
+    }
     const int epoch =  // (wave-uniform: kept in an SGPR)
         __builtin_amdgcn_readfirstlane(__hip_atomic_load(A.epoch_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + A.epoch_bias;
-    int b = blockIdx.x;
     if (b < A.n_node) {
         __builtin_amdgcn_s_setprio(3);
         node_persist_h<H>(A, b, epoch, smem);
@@ -2731,14 +2755,29 @@ int mega_slots(int H) {
     cache[hi][d].store(v);
     return v;
 }
+// The forwards of the batch's M checkpoints in ONE launch, in groups of G (MegaGroup: per-checkpoint strides of the arrays;
+// M = G = 1: the single-checkpoint form).  G * node workgroups must fit half of the device's slots (api.hip mega_group).
 int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float* pos, const float* W16, float* ea, float* wf,
                         float* h, float* x1m, size_t x1_stride, int32_t* ctl, const int32_t* epoch_src, int epoch_bias,
-                        int32_t* status, hipStream_t st) {
+                        int32_t* status, hipStream_t st, const MegaGroup& mg) {
     (void)pos;
     const WeightLayout WL = weight_layout(c);
     const int H = c.hidden, L = c.num_convs, N = b.num_nodes, P = b.num_pairs, PU = P / 2;
     const tsd_geometry& g = b.geo;
+    if (mg.G < 1 || mg.M < 1) {
+        set_error("internal: checkpoint groups (%d of %d)", mg.G, mg.M);
+        return TSD_ERR_INVALID;
+    }
     MegaArgs A{};
+    A.G = mg.G;
+    A.M = mg.M;
+    A.s_w = WL.total;
+    A.s_nh = mg.s_nh;
+    A.s_x1m = mg.s_x1m;
+    A.s_wf = mg.s_wf;
+    A.s_ea = mg.s_ea;
+    A.s_inv = (size_t)PU;
+    A.s_ctl = mg.s_ctl;
     A.L = L;
     A.N = N;
     A.epoch_src = epoch_src;
@@ -2767,7 +2806,8 @@ int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float*
     A.wf = wf;
     A.wf_layer_stride = (size_t)PU * H;
     // filter role: the queue of kernels_combo's per-block launches from block 1 on, slot = block
-    const int frb = (H == 256 && TSD_MEGA_WIDE_MIN > 0 && filter_tiles_per_layer(PU) >= TSD_MEGA_WIDE_MIN) ? 2 : 1;
+    // (64-row filter tiles by the GROUP's tiles per block: they share the slots)
+    const int frb = (H == 256 && TSD_MEGA_WIDE_MIN > 0 && (long)filter_tiles_per_layer(PU) * mg.G >= TSD_MEGA_WIDE_MIN) ? 2 : 1;
     A.filter_rows = T * frb;
     A.tiles_per_layer = (PU + T * frb - 1) / (T * frb);
     A.f.tiles = (L - 1) * A.tiles_per_layer;
@@ -2812,8 +2852,8 @@ int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float*
     A.n_filter = A.f.tiles;
     A.n_pair = A.q.tiles;
     A.half_slots = mega_slots(H) / 2;
-    if (A.n_node > A.half_slots) {
-        set_error("internal: %d node workgroups on a device with %d resident slots", A.n_node, 2 * A.half_slots);
+    if ((long)A.n_node * A.G > A.half_slots) {
+        set_error("internal: %d x %d node workgroups on a device with %d resident slots", A.G, A.n_node, 2 * A.half_slots);
         return TSD_ERR_INVALID;
     }
     // (tests, tsd_batch.reserved bit 3: the last filter tile of the last block is never run, so the node workgroup that
@@ -2822,12 +2862,14 @@ int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float*
     const int grid = A.n_node + A.n_filter + A.n_pair;
     if (grid == 0 || A.n_node == 0) return TSD_OK;
     const size_t lds = mega_lds_bytes(H);
+    A.per_group = grid * A.G;
+    const int groups = (A.M + A.G - 1) / A.G;
 #define TSD_MEGA(HH)                                                                                         \
     {                                                                                                        \
         static DeviceOnce once;                                                                              \
         int r = allow_lds(forward_mega_kernel<HH>, lds, once);                                               \
         if (r) return r;                                                                                     \
-        hipLaunchKernelGGL(forward_mega_kernel<HH>, dim3(grid), dim3(2 * HH), lds, st, A);                   \
+        hipLaunchKernelGGL(forward_mega_kernel<HH>, dim3(A.per_group * groups), dim3(2 * HH), lds, st, A);   \
     }
     switch (H) {
         case 64: TSD_MEGA(64) break;
