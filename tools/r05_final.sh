@@ -11,5 +11,5 @@ bash tools/energy_probe.sh > $O/r05_energy_probe.log 2>&1; cat $O/r05_energy_pro
 { for g in 400 800; do python3 tools/filter_probe.py $g; TSDIFF_LIB=tools/bin/lib_fw0.so python3 tools/filter_probe.py $g; done; } 2>/dev/null > $O/r05_filter_probe.log; cat $O/r05_filter_probe.log
 { echo "== tools/trace_unit.py c5"; TSDIFF_LIB=tools/bin/lib_utrace.so python3 tools/trace_unit.py c5; echo "== tools/trace_unit.py ens8"; TSDIFF_LIB=tools/bin/lib_utrace.so python3 tools/trace_unit.py ens8; } 2>/dev/null > $O/r05_trace_unit.log; cat $O/r05_trace_unit.log
 TSDIFF_LIB=$PWD/tools/bin/lib_trace.so python3 tools/trace_combo.py g800 3 h2 > $O/r05_trace_combo_g800.log 2>/dev/null; head -12 $O/r05_trace_combo_g800.log
-for w in c2 ens8 g300 c5 g300m8; do st=200; [ $w = c5 ] && st=8; [ $w = g300m8 ] && st=50; python3 tools/ab_step.py --workload $w --steps $st --rounds 2 r05=default r04=tools/bin/lib_r04.so; done 2>&1 | grep -v amdgpu > $O/r05_ab_vs_r04.log; cat $O/r05_ab_vs_r04.log
+for w in c2 g120 g200 ens2 ens8 g300 c5 g300m8; do st=200; [ $w = c5 ] && st=8; [ $w = g300m8 ] && st=50; python3 tools/ab_step.py --workload $w --steps $st --rounds 2 r05=default r04=tools/bin/lib_r04.so; done 2>&1 | grep -v amdgpu > $O/r05_ab_vs_r04.log; cat $O/r05_ab_vs_r04.log
 python3 tools/ab_step.py --workload ens8 --rounds 2 materialised=default fused=default:fused1 2>&1 | grep -v amdgpu > $O/r05_ab_fused_ens8.log; cat $O/r05_ab_fused_ens8.log
