@@ -153,7 +153,7 @@ constexpr bool kFold = TSD_FOLD != 0;
 // device's slots for that kernel (occupancy x compute units, queried per device: 512 on a whole MI355X, less on a
 // partitioned or smaller part), and a filter arena of all L blocks (no ring) that stays small.
 // An ensemble (round 5) runs in the SAME launch as groups of G checkpoints -- as many as fit that half of the slots --
-// one group after the other in the grid, when it is whole groups: 2 checkpoints at batch 100 0.381 -> 0.312 ms/step, 8 at
+// staggered in the grid (kernels_combo.hip forward_mega_kernel), when it is whole groups: 2 checkpoints at batch 100 0.381 -> 0.312 ms/step, 8 at
 // batch 25 0.426 -> 0.345 (one group each), 8 at batch 100 1.236 -> 1.206 (four groups of two), 4 x 200 graphs 1.191 ->
 // 1.159 (four of one); a last group that is not full loses (3 checkpoints at batch 100 as 2 + 1: 0.475 -> 0.547), so
 // such ensembles stay on the launch-per-block forms.
@@ -163,7 +163,10 @@ constexpr bool kFold = TSD_FOLD != 0;
 // checkpoints per group of the one-launch forward
 static int mega_group(const tsd_model_cfg& c, int N, int M) {
     const int node_wgs = (N + mega_node_rows() - 1) / mega_node_rows();
-    const int fit = node_wgs > 0 ? mega_slots(c.hidden) / 2 / node_wgs : 1;
+#ifndef TSD_MEGA_GROUP_DIV
+#define TSD_MEGA_GROUP_DIV 2  // a group's node workgroups on at most 1 / DIV of the slots (4: measured slower, kernels_combo.hip)
+#endif
+    const int fit = node_wgs > 0 ? mega_slots(c.hidden) / TSD_MEGA_GROUP_DIV / node_wgs : 1;
     return fit < 1 ? 1 : (fit > M ? M : fit);
 }
 static bool mega_shape(const tsd_model_cfg& c, int N, int P, int M) {

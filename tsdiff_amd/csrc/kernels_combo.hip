@@ -2638,14 +2638,45 @@ __global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A_) {
     MegaArgs A = A_;
     int b = blockIdx.x;
     if (A.M > 1) {
-        // An ensemble: groups of G checkpoints one after the other in the grid (a group's node workgroups are dispatched when
-        // the group before has left them slots: they wait for workgroups of their own checkpoint only, so in-order dispatch
-        // is still enough for progress), a group's checkpoints interleaved -- one checkpoint's workgroups on the XCDs
-        // id % G (common.hpp wg_item_ckpt)
-        const unsigned grp = (unsigned)b / (unsigned)A.per_group;
-        b = (int)((unsigned)b % (unsigned)A.per_group);
-        const size_t g = (size_t)grp * A.G + (unsigned)b % (unsigned)A.G;
-        b = (int)((unsigned)b / (unsigned)A.G);
+        // An ensemble: groups of G checkpoints, a group's checkpoints interleaved -- one checkpoint's workgroups on the XCDs
+        // id % G (common.hpp wg_item_ckpt).  The groups are STAGGERED in the grid,
+        //   [N0 F0] [N1 F1 P0] [N2 F2 P1] ... [N(K-1) F(K-1) P(K-2)] [P(K-1)]     (N node workgroups, F filter tiles, P pair tiles)
+        // so that group k + 1's node chain starts while group k's runs its last blocks and its pair tiles -- which sleep until
+        // that chain is done -- do not hold the slots of the next group's filter tiles.  A workgroup still waits only for
+        // workgroups of its own checkpoint, which precede it in the grid or never wait (F(k) follows N(k) directly, and N(k)
+        // needs nothing behind F(k)): in-order dispatch is enough for progress even when the node workgroups of two groups
+        // fill every slot -- N(k) then simply finishes first.  Round 5: 8 checkpoints at batch 100 1.218 -> 1.199 ms/step,
+        // 4: 0.628 -> 0.616, 4 x 200 graphs 1.163 -> 1.147 against group after group; groups of half the size (two node
+        // sets = half of the slots) lose: 1.237.
+        unsigned id = blockIdx.x, grp, j;
+        int base;
+        const unsigned sN = (unsigned)A.n_node * A.G, sF = (unsigned)A.n_filter * A.G, sP = (unsigned)A.n_pair * A.G;
+#ifndef TSD_MEGA_STAGGER
+#define TSD_MEGA_STAGGER 1  // 0 (A/B variant builds): group after group
+#endif
+        if (TSD_MEGA_STAGGER) {
+            const unsigned K = ((unsigned)A.M + A.G - 1) / (unsigned)A.G, blk = sN + sF + sP;
+            if (id < sN + sF) {
+                grp = 0;
+                if (id < sN) { j = id; base = 0; } else { j = id - sN; base = A.n_node; }
+            } else {
+                id -= sN + sF;
+                const unsigned k = id / blk + 1, r = id % blk;
+                if (k < K) {
+                    if (r < sN) { grp = k; j = r; base = 0; }
+                    else if (r < sN + sF) { grp = k; j = r - sN; base = A.n_node; }
+                    else { grp = k - 1; j = r - sN - sF; base = A.n_node + A.n_filter; }
+                } else {
+                    grp = K - 1; j = id - (K - 1) * blk; base = A.n_node + A.n_filter;
+                }
+            }
+        } else {
+            grp = id / (unsigned)A.per_group;
+            j = id % (unsigned)A.per_group;
+            base = 0;
+        }
+        const size_t g = (size_t)grp * A.G + j % (unsigned)A.G;
+        b = base + (int)(j / (unsigned)A.G);
         if (g >= (size_t)A.M) return;   // (the last group of an ensemble that is no multiple of G)
         const size_t ow = g * A.s_w, on = g * A.s_nh, owf = g * A.s_wf, oea = g * A.s_ea;
         A.ctl += g * (size_t)A.s_ctl;
@@ -2653,7 +2684,7 @@ __global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A_) {
         A.f.Wl0 += ow; A.f.edge_attr += oea; A.f.wf += owf;
         A.q.edge_attr += oea; A.q.w0b += ow; A.q.b0 += ow; A.q.w0a += ow; A.q.w1 += ow; A.q.b1 += ow; A.q.w2 += ow; A.q.b2 += ow;
         A.q.h += on; A.q.edge_inv += g * A.s_inv; A.q.ready += g * (size_t)A.s_ctl;
-        A.half_slots /= A.G;   // (the parking arithmetic below is per checkpoint)
+        A.half_slots = 0;      // (no parked pair tiles: positions in the grid say nothing about CUs here)
     }
     const int epoch =  // (wave-uniform: kept in an SGPR)
         __builtin_amdgcn_readfirstlane(__hip_atomic_load(A.epoch_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + A.epoch_bias;
