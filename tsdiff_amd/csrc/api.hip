@@ -173,7 +173,11 @@ static bool mega_shape(const tsd_model_cfg& c, int N, int P, int M) {
     if (TSD_MEGA == 0 || M < 1 || (M != 1 && !TSD_MEGA_ENSEMBLE) || N <= 0 || c.num_convs > 60) return false;
     const int node_wgs = (N + mega_node_rows() - 1) / mega_node_rows();
     if (2 * node_wgs > mega_slots(c.hidden)) return false;
-    if (M > 1 && M % mega_group(c, N, M) != 0) return false;
+#ifndef TSD_MEGA_WHOLE_GROUPS
+#define TSD_MEGA_WHOLE_GROUPS 1  // (0, A/B builds: also with a last group that is not full -- 3 checkpoints at batch 100 0.485 ->
+                                 // 0.570 ms/step, 5: 0.826 -> 0.859, 4 x 80 graphs 0.513 -> 0.588, 7: 1.195 -> 1.149)
+#endif
+    if (TSD_MEGA_WHOLE_GROUPS && M > 1 && M % mega_group(c, N, M) != 0) return false;
     return (size_t)M * (P / 2) * c.hidden * c.num_convs * sizeof(float) <= ((size_t)2 << 30);
 }
 
