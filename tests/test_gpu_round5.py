@@ -158,3 +158,33 @@ def test_ensemble_in_the_one_launch_form_matches_the_block_launches(graphs, M, d
             one(*args)
         d1 = one._bound_batch(*args[:3], *args[4:7])
         assert torch.equal(d1.edge_inv_u[0, :E // 2], out[True][1][k, :E // 2]), k   # (undirected out edges)
+
+
+def test_ensemble_one_launch_wait_that_gives_up_reruns_per_block(dev, monkeypatch):
+    """the bounded waits of the one-launch kernel with an ENSEMBLE in it (two groups of two checkpoints at batch 100): fault
+    injection (tsd_batch.reserved bit 3: the last filter tile of every checkpoint is never run) -> TSD_STATUS_INTERNAL, the
+    forward is rerun on the block launches and returns their bits without raising"""
+    from tests.test_gpu_round4 import _batch
+    from tsdiff_amd import _lib, engine, synth
+    from tsdiff_amd.sampler import EnsembleSampler
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    _, _, g = _batch(100, 1000, dev)
+    args = (g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"], None)
+    monkeypatch.setattr(engine.OPTIONS, "gemm", "h2")
+    monkeypatch.setattr(engine.OPTIONS, "fused_encoder", False)
+    monkeypatch.setattr(engine.OPTIONS, "one_launch", False)
+    models = [make_model(cfg, 20 + k, dev) for k in range(4)]
+    with torch.no_grad():
+        ref = EnsembleSampler(models)(*args)[0].clone()
+    monkeypatch.setattr(engine.OPTIONS, "one_launch", True)
+    ens = EnsembleSampler([make_model(cfg, 20 + k, dev) for k in range(4)])
+    with torch.no_grad():
+        ok = ens(*args)[0].clone()
+    db = ens._bound_batch(*args[:3], *args[4:7])
+    assert torch.equal(ok, ref) and not db.per_block
+    db.test_flags = 8
+    with torch.no_grad():
+        out = ens(*args)[0].clone()
+    assert db.per_block, "the fault was not noticed"
+    assert int(db.status[0].item()) & (_lib.STATUS_INTERNAL | _lib.STATUS_RANGE) == 0
+    assert torch.equal(out, ref)
