@@ -274,7 +274,7 @@ def test_split_f16_sweep_vs_fp64(case, dev):
     """weight scale, weight distribution, hidden size, geometry scale: per tensor the split-f16 forward is as close to an
     fp64 evaluation as the fp32-MFMA forward (e_h2 <= max(1.5 e_f32, 1e-6)), also on the 1 % smallest entries (absolute
     error over the tensor scale); a case that leaves the f16 range is rerun in fp32 by itself (then both are that path)"""
-    from tools.split_f16_sweep import config_for, run_case, scaled_state_dict
+    from tests.tools.split_f16_sweep import config_for, run_case, scaled_state_dict
     name, H, L, ws, heavy, (lo, hi) = case
     cfg = config_for(H, L)
     r = run_case(cfg, scaled_state_dict(cfg, 3, ws, heavy), 40, 1000, lo, hi, dev)

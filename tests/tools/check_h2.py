@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Split-f16 forward (TSDIFF_GEMM=h2, csrc/split16.hpp) against the fp32-MFMA forward and the CPU oracle in fp32 and
-fp64: the same batches as tools/parity_report.py, both arithmetic modes of the same library in one process.
-    python tools/check_h2.py [n_seeds]"""
+fp64: the same batches as tests/tools/parity_report.py, both arithmetic modes of the same library in one process.
+    python tests/tools/check_h2.py [n_seeds]"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import tsdiff_oracle as O  # noqa: E402  (checker only)
 from tsdiff_amd import engine, synth  # noqa: E402

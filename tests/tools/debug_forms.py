@@ -3,7 +3,7 @@
 library variant (TSDIFF_LIB) against the oracle; prints where the error is"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from tsdiff_amd import _lib, engine, synth
 if os.environ.get("TSDIFF_LIB"):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Error statistics of the HIP forward against the CPU oracle (fp32) and against an fp64 evaluation of the
 oracle, over seeded random batches (full H=256 / 7-block model).  Run on the GPU box:
-    python tools/parity_report.py > profiles/r01_parity_report.md
+    python tests/tools/parity_report.py > profiles/r01_parity_report.md
 """
 import os
 import sys
@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import tsdiff_oracle as O  # noqa: E402  (checker only)
 from tsdiff_amd import synth  # noqa: E402

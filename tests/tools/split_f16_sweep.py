@@ -3,7 +3,7 @@
 fp32-input-MFMA forward, over weight scale, weight distribution, hidden size and geometry scale -- the table of
 profiles/r04_split_f16_sweep.md:
 
-    python tools/split_f16_sweep.py [--graphs 100] > profiles/r04_split_f16_sweep.md
+    python tests/tools/split_f16_sweep.py [--graphs 100] > profiles/r04_split_f16_sweep.md
 
 Per case: e = max|x - ref64| / max|ref64| of edge_inv for both arithmetic forms; the same on the 1 % of entries with
 the smallest |ref64| (absolute error over the tensor's scale: what a small entry loses); and whether the split-f16 call left the f16 range and was rerun in fp32 (TSD_STATUS_RANGE -> `fallback`).
@@ -14,7 +14,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -99,7 +99,7 @@ def config_for(hidden, convs):
 def main():
     graphs = int(sys.argv[sys.argv.index("--graphs") + 1]) if "--graphs" in sys.argv else 100
     dev = torch.device("cuda:0")
-    print("# Split-f16 forward against an fp64 evaluation, next to the fp32-input-MFMA forward (tools/split_f16_sweep.py)\n")
+    print("# Split-f16 forward against an fp64 evaluation, next to the fp32-input-MFMA forward (tests/tools/split_f16_sweep.py)\n")
     print(f"`edge_inv` of a {graphs}-graph wb97xd3-like batch; e = max|x - ref64| / max|ref64|; `small 1 %` = the same maximum over "
           "the 1 % of entries with the smallest |ref64| (absolute error over the tensor scale); `fallback` = the split-f16 call "
           "left the f16 range (TSD_STATUS_RANGE) and was rerun on the fp32-MFMA kernels, so both columns are that path; "

@@ -16,7 +16,7 @@ python3 bench.py --workload train --steps 20 --warmup 5 > $O/${TAG}_bench_train.
 python3 bench.py --workload train --steps 20 --warmup 5 --no-prefetch > $O/${TAG}_bench_train_no_prefetch.json 2> /dev/null
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --workload train --steps 40 --warmup 8 > $O/${TAG}_bench_train_torchrun_3range.json 2> /dev/null
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 1 --workload train --steps 40 --warmup 8 --single-range-reduce > $O/${TAG}_bench_train_torchrun_1range.json 2> /dev/null
-python3 tools/parity_report.py > $O/${TAG}_parity_report.md 2> $O/${TAG}_parity_report.err
+python3 tests/tools/parity_report.py > $O/${TAG}_parity_report.md 2> $O/${TAG}_parity_report.err
 for f in $O/${TAG}_bench_*.json; do python3 - "$f" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
