@@ -1314,21 +1314,23 @@ __device__ __forceinline__ void filter_role_h(const ComboFilter& f, int item, fl
 // HSPLIT (the stand-alone launch, whose budget is 80 VGPRs = three workgroups per CU): the h rows in two batches of two
 // chunks per thread (16 registers instead of 32 beside the live accumulators; the other workgroups of the CU hide the
 // second round trip).
-template <int H, bool SAVE = false, bool HSPLIT = false>
+// RB: 32-row blocks per pair tile (2: the one-launch forward's pair tiles where they fill the chip -- when the node chain ends
+// every pair tile of the launch streams the MLP's 384 KB of weights at once; a fragment that feeds two row blocks halves that).
+template <int H, bool SAVE = false, bool HSPLIT = false, int RB = 1>
 __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int node_tiles, float* smem, bool defer_pre,
                                             int32_t* range_status, const PairSave& sv = PairSave{}) {
-    constexpr int LDH = ldh_of(H), NT = 2 * H, C4 = H / 4, NW = H / 64;
-    const Planes pl = planes_at(smem, T, LDH);
-    float* s_red = smem + T * LDH;  // [NW][T]
-    int* s_src = reinterpret_cast<int*>(s_red + NW * T);
-    int* s_dst = s_src + T;
-    int* s_row = s_dst + T;
+    constexpr int LDH = ldh_of(H), NT = 2 * H, C4 = H / 4, NW = H / 64, TT = T * RB;
+    const Planes pl = planes_at(smem, TT, LDH);
+    float* s_red = smem + TT * LDH;  // [NW][TT]
+    int* s_src = reinterpret_cast<int*>(s_red + NW * TT);
+    int* s_dst = s_src + TT;
+    int* s_row = s_dst + TT;
     const int E = *q.e.count;
-    const int e0 = tile * T;
+    const int e0 = tile * TT;
     if (e0 >= E) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int col0 = wave * 32, col = col0 + l31;
-    const int nrows = min(T, E - e0);
+    const int nrows = min(TT, E - e0);
     float amax = 0.0f;
 #ifndef TSD_PAIR_TRANS
 #define TSD_PAIR_TRANS TSD_FILTER_TRANS
@@ -1341,7 +1343,8 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
 #define TSD_PAIR_TR12 1
 #endif
     constexpr bool TR3 = TR && TSD_PAIR_TR3 != 0, TR12 = TR && TSD_PAIR_TR12 != 0;
-    if (tid < T) {
+    static_assert(RB == 1 || (TR3 && TR12 && !HSPLIT), "64-row pair tiles: the transposed inference form");
+    if (tid < TT) {
         const int ee = e0 + min(tid, nrows - 1);
         s_src[tid] = q.e.src[ee];
         s_dst[tid] = q.e.dst[ee];
@@ -1355,7 +1358,7 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
     // ONE accumulation chain for Linear(2H, H) of the concatenation [h_src * h_dst, attr] (common.py:226-229): the attribute
     // half first (it does not depend on h: the one-launch forward runs it while the node tiles finish), then the h half
     // into the SAME accumulators -- no 16 registers of intermediate sums beside them (80 VGPRs: three workgroups per CU)
-    f32x16 accm[1][1], accx[1][1];
+    f32x16 accm[RB][1], accx[RB][1];
     constexpr int PR = HSPLIT ? 2 : HRING_R;  // weight k-steps in flight (HSPLIT: six waves per SIMD hide the rest)
     constexpr int HB = HSPLIT ? 2 : 4;  // chunks of the gathered h rows per thread and batch (NIT = 4 in all)
     f32x4 hs[HB], hd[HB];
@@ -1371,50 +1374,54 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
     };
     auto pre_gemm = [&]() {
         HRing<1, PR> rg;
-        constexpr int NIT = T * C4 / NT;
-        static_assert(NIT == 4, "ld16_wait4 names four registers");
-        f32x4 v[NIT];  // (sc1: see filter_role_h)
+        constexpr int NIT = TT * C4 / NT;
+        static_assert(NIT == 4 * RB, "ld16_wait4 names four registers");
         float site_m = 0.0f;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+        for (int ib = 0; ib < NIT; ib += 4) {   // (four chunks per thread = 32 tile rows per round trip)
+        f32x4 v[4];  // (sc1: see filter_role_h)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + (ib + it) * NT, r = idx / C4, c4 = idx % C4;
             ld16_sc1(v[it], q.edge_attr + (size_t)s_row[r] * H + c4 * 4);
         }
         ld16_wait4(v);
         if constexpr (!SAVE) {   // (rows stored as f16 planes: common.hpp ATTRIBUTE ROWS AS f16 PLANES)
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+            for (int it = 0; it < 4; ++it) {
+                const int idx = tid + (ib + it) * NT, r = idx / C4, c4 = idx % C4;
                 planes_put_chunk<H>(pl, r * LDH, c4, v[it]);
             }
         } else {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * NT, r = idx / C4, c4 = idx % C4;
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + (ib + it) * NT, r = idx / C4, c4 = idx % C4;
             planes_store4(pl, r * LDH + c4 * 4, v[it], site_m);
             if constexpr (SAVE) {
                 if (r < nrows) *reinterpret_cast<f32x4*>(sv.hp + (size_t)(e0 + r) * 2 * H + H + c4 * 4) = v[it];
             }
         }
-        site_close(amax, site_m);
         }
+        }
+        if constexpr (SAVE) site_close(amax, site_m);
         hgemm_ring_start<1, H>(rg, q.w0b, H, col0);  // (behind the staging: its registers are free now)
         __syncthreads();
         hzero(accm, accx);
-        hgemm_ring_run<1, 1, H, false, TR12>(rg, pl, LDH, accm, accx);
+        hgemm_ring_run<RB, 1, H, false, TR12>(rg, pl, LDH, accm, accx);
     };
     // the first layer's biases: the one-launch forward (whose pair tiles end its dependency chain) requests them here, ahead of
     // the wait for the node tiles; the stand-alone launch (80 VGPRs) where it adds them
     f32x4 b0v[4];
-    if constexpr (TR12 && !HSPLIT) {
+    constexpr bool B0_EARLY = TR12 && !HSPLIT && RB == 1;  // (the 64-row form has no registers for them across the GEMMs)
+    if constexpr (B0_EARLY) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) b0v[g4] = *reinterpret_cast<const f32x4*>(q.b0 + col0 + 8 * g4 + 4 * hi);
     }
     if (!defer_pre) pre_gemm();
     // wait for the node tiles that hold this tile's atoms (min .. max node id over both end points)
     if (wave == 0 && q.ready != nullptr) {  // (ready == NULL: the stand-alone pair output, h is complete)
-        int lo = lane < T ? min(s_src[lane], s_dst[lane]) : 0x7fffffff;
-        int hn = lane < T ? max(s_src[lane], s_dst[lane]) : -1;
+        int lo = lane < TT ? min(s_src[lane], s_dst[lane]) : 0x7fffffff;
+        int hn = lane < TT ? max(s_src[lane], s_dst[lane]) : -1;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             lo = min(lo, __shfl_xor(lo, off));
@@ -1447,9 +1454,9 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
     }
     HRing<1, PR> rg;
     {   // h_src * h_dst -> LDS planes.  The rows were written by other CUs during this launch: sc1 loads
-        constexpr int NIT = T * C4 / NT;
-        static_assert(T * C4 % NT == 0, "tile / block mismatch");
-        static_assert(NIT == 4, "the wait statement names 2 x 4 registers");
+        constexpr int NIT = TT * C4 / NT;
+        static_assert(TT * C4 % NT == 0, "tile / block mismatch");
+        static_assert(NIT == 4 * RB, "the wait statement names 2 x 4 registers");
         // (requesting these rows together with the attribute rows in the stand-alone launch -- one round trip instead of two,
         // 32 more registers across the first GEMM -- measured nothing: 1.372 vs 1.377 ms/step with 8 checkpoints, round 5)
 #pragma unroll
@@ -1475,19 +1482,22 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
     }
     hgemm_ring_start<1, H>(rg, q.w0a, H, col0);  // (behind the staging: its registers are free now)
     __syncthreads();
-    hgemm_ring_run<1, 1, H, false, TR12>(rg, pl, LDH, accm, accx);  // (on top of the attribute half's sums)
+    hgemm_ring_run<RB, 1, H, false, TR12>(rg, pl, LDH, accm, accx);  // (on top of the attribute half's sums)
     __syncthreads();
     if constexpr (TR12) {
-        const bool live = l31 < nrows;  // (rows past the end: zeros, as their h rows)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             f32x4 bv;
-            if constexpr (HSPLIT) bv = *reinterpret_cast<const f32x4*>(q.b0 + col0 + 8 * g4 + 4 * hi);
+            if constexpr (!B0_EARLY) bv = *reinterpret_cast<const f32x4*>(q.b0 + col0 + 8 * g4 + 4 * hi);
             else bv = b0v[g4];
-            f32x4 s4;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) s4[r] = swishf(live ? hval(accm[0][0], accx[0][0], 4 * g4 + r) + bv[r] : 0.0f);
-            planes_store4(pl, l31 * LDH + col0 + 8 * g4 + 4 * hi, s4, amax);
+            for (int rb = 0; rb < RB; ++rb) {
+                const bool live = rb * T + l31 < nrows;  // (rows past the end: zeros, as their h rows)
+                f32x4 s4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s4[r] = swishf(live ? hval(accm[rb][0], accx[rb][0], 4 * g4 + r) + bv[r] : 0.0f);
+                planes_store4(pl, (rb * T + l31) * LDH + col0 + 8 * g4 + 4 * hi, s4, amax);
+            }
         }
     } else
 #pragma unroll
@@ -1506,18 +1516,25 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
     if (wave < NW) {  // H -> H/2 and the final dot: the first H/64 waves
         const int c2 = wave * 32 + l31;
         hzero(accm, accx);
-        hgemm_tile<1, 1, H, false, PR, TR3>(pl, LDH, q.w1, H / 2, wave * 32, accm, accx);
+        hgemm_tile<RB, 1, H, false, PR, TR3>(pl, LDH, q.w1, H / 2, wave * 32, accm, accx);
         if constexpr (TR3) {   // the lane's 16 channels of row l31 summed in register order, then the other half-wave's 16
-            float v = 0.0f;
+            float v[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) v[rb] = 0.0f;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(q.b1 + wave * 32 + 8 * g4 + 4 * hi);
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(q.w2 + wave * 32 + 8 * g4 + 4 * hi);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v += swishf(hval(accm[0][0], accx[0][0], 4 * g4 + r) + bv[r]) * wv[r];
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[rb] += swishf(hval(accm[rb][0], accx[rb][0], 4 * g4 + r) + bv[r]) * wv[r];
             }
-            v += __shfl_xor(v, 32);
-            if (hi == 0) s_red[wave * T + l31] = v;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                v[rb] += __shfl_xor(v[rb], 32);
+                if (hi == 0) s_red[wave * TT + rb * T + l31] = v[rb];
+            }
         } else {
         const float b = q.b1[c2], w2 = q.w2[c2];
 #pragma unroll
@@ -1536,7 +1553,7 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
             v += __shfl_xor(v, 4);
             v += __shfl_xor(v, 2);
             v += __shfl_xor(v, 1);
-            if (l31 == 0) s_red[wave * T + acc_row(r, hi)] = v;
+            if (l31 == 0) s_red[wave * TT + acc_row(r, hi)] = v;
         }
         }
     }
@@ -1544,7 +1561,7 @@ __device__ __forceinline__ void pair_role_h(const ComboPre& q, int tile, int nod
     if (tid < nrows) {
         float v = s_red[tid];
 #pragma unroll
-        for (int k = 1; k < NW; ++k) v += s_red[k * T + tid];
+        for (int k = 1; k < NW; ++k) v += s_red[k * TT + tid];
         q.edge_inv[e0 + tid] = v + q.b2[0];
     }
     range_report(amax, range_status);
@@ -2199,7 +2216,7 @@ static inline size_t lds_combo(int H, int prec, int frb = 1, int nrb = 1) {
     const int ld = prec == PREC_H2 ? ldh_of(H) : H + 4;  // floats per tile row (two f16 planes of H + 8 = H + 8 floats)
     const size_t node = (size_t)TN * nrb * ld * 4 + (prec == PREC_H2 ? (size_t)2 * H * 4 : 0);  // (+ the transposed form's biases)
     const size_t filt = (size_t)(T * ld + T) * 4 * frb + (prec == PREC_H2 ? (size_t)2 * H * 4 : 0);  // (+ the transposed form's biases)
-    const size_t pair = (size_t)(T * ld + (H / 64) * T + 3 * T) * 4;  // pair role (H >= 64)
+    const size_t pair = (size_t)(T * ld + (H / 64) * T + 3 * T) * 4 * (prec == PREC_H2 ? frb : 1);  // pair role (H >= 64; 64-row tiles with the filter role's)
     return node > filt ? (node > pair ? node : pair) : (filt > pair ? filt : pair);
 }
 
@@ -2277,6 +2294,7 @@ struct MegaArgs {
     // roles' grid ranges
     int n_node, n_filter, n_pair, tiles_per_layer;
     int filter_rows;           // pairs per filter tile: 32, or 64 (hidden 256, a block's tiles fill the chip)
+    int pair_rows;             // pairs per pair tile: likewise
     // checkpoints of this launch (an ensemble's forwards in groups whose node workgroups fit the resident half of the chip):
     // workgroup id = item * G + g, every pointer below is checkpoint 0's of the group and moves by g * its stride
     int G, M, per_group;       // G checkpoints per group, M in all (the grid holds ceil(M / G) groups of per_group workgroups each, group-major)
@@ -2739,7 +2757,12 @@ __global__ __launch_bounds__(2 * H) void forward_mega_kernel(MegaArgs A_) {
     if (pair_item >= 0) {
         ComboPre q = A.q;
         q.ready_target = epoch * 64 + A.L;
-        pair_role_h<H>(q, pair_item, A.n_node, smem, /* defer_pre */ pair_item < parked, A.status);
+        if constexpr (H == 256) {
+            if (A.pair_rows == 2 * T) pair_role_h<H, false, false, 2>(q, pair_item, A.n_node, smem, /* defer_pre */ pair_item < parked, A.status);
+            else pair_role_h<H>(q, pair_item, A.n_node, smem, /* defer_pre */ pair_item < parked, A.status);
+        } else {
+            pair_role_h<H>(q, pair_item, A.n_node, smem, /* defer_pre */ pair_item < parked, A.status);
+        }
         TSD_MEGA_T(0, 4);
         TSD_MEGA_T(2, wall_clock64());
     }
@@ -2859,7 +2882,14 @@ int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float*
     A.f.wf_layer_stride = (size_t)PU * H;
     A.f.wf_slots = L;
     // pair role
-    A.q.tiles = (PU + T - 1) / T;
+    // 64-row pair tiles where a group's pair tiles are more than a round of the chip (8 checkpoints at batch 100: 1.199 ->
+    // 1.182 ms/step; 200 graphs, 2 checkpoints: equal); a single batch-100 forward ends with ONE partial round of pair tiles,
+    // which the longer tile only stretches (0.2007 -> 0.2046)
+#ifndef TSD_MEGA_PAIR_WIDE_MIN
+#define TSD_MEGA_PAIR_WIDE_MIN 768  // 32-row pair tiles of a group from which they are 64 rows (0: never)
+#endif
+    A.pair_rows = (H == 256 && TSD_MEGA_PAIR_WIDE_MIN > 0 && (long)((PU + T - 1) / T) * mg.G >= TSD_MEGA_PAIR_WIDE_MIN) ? 2 * T : T;
+    A.q.tiles = (PU + A.pair_rows - 1) / A.pair_rows;
     A.q.e = g.out_u;
     A.q.edge_attr = ea;
     A.q.attr_row = g.attr_row;
