@@ -188,3 +188,29 @@ def test_ensemble_one_launch_wait_that_gives_up_reruns_per_block(dev, monkeypatc
     assert db.per_block, "the fault was not noticed"
     assert int(db.status[0].item()) & (_lib.STATUS_INTERNAL | _lib.STATUS_RANGE) == 0
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("graphs,M", [(100, 1), (100, 2), (200, 1)])
+def test_one_launch_kernel_with_32_and_64_row_tiles_gives_the_same_bits(graphs, M, dev, monkeypatch):
+    """OPTIONS.wide_filter_tiles (tsd_batch.reserved bit 1) in the one-launch kernel: 64-row filter tiles from 384 32-row tiles
+    per block (x checkpoints of a group) on, 64-row pair tiles from 768 -- against 32-row tiles everywhere: every row is the
+    same MFMA sequence, bit-identical"""
+    from tests.test_gpu_round4 import _batch
+    from tsdiff_amd import engine, synth
+    from tsdiff_amd.sampler import EnsembleSampler
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    _, _, g = _batch(graphs, 1000, dev)
+    args = (g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"], None)
+    out = {}
+    for wide in (True, False):
+        monkeypatch.setattr(engine.OPTIONS, "gemm", "h2")
+        monkeypatch.setattr(engine.OPTIONS, "one_launch", True)
+        monkeypatch.setattr(engine.OPTIONS, "fused_encoder", False)
+        monkeypatch.setattr(engine.OPTIONS, "wide_filter_tiles", wide)
+        ens = EnsembleSampler([make_model(cfg, 30 + k, dev) for k in range(M)])
+        with torch.no_grad():
+            ens(*args)
+        db = ens._bound_batch(*args[:3], *args[4:7])
+        assert not db.per_block
+        out[wide] = db.edge_inv_u.clone()
+    assert torch.equal(out[True], out[False])

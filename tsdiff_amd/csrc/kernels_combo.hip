@@ -2861,7 +2861,8 @@ int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float*
     A.wf_layer_stride = (size_t)PU * H;
     // filter role: the queue of kernels_combo's per-block launches from block 1 on, slot = block
     // (64-row filter tiles by the GROUP's tiles per block: they share the slots)
-    const int frb = (H == 256 && TSD_MEGA_WIDE_MIN > 0 && (long)filter_tiles_per_layer(PU) * mg.G >= TSD_MEGA_WIDE_MIN) ? 2 : 1;
+    const bool narrow = (b.reserved & 2) != 0;   // (tsd_batch.reserved bit 1: 32-row tiles everywhere; bit-identical -- tests, A/B)
+    const int frb = (H == 256 && !narrow && TSD_MEGA_WIDE_MIN > 0 && (long)filter_tiles_per_layer(PU) * mg.G >= TSD_MEGA_WIDE_MIN) ? 2 : 1;
     A.filter_rows = T * frb;
     A.tiles_per_layer = (PU + T * frb - 1) / (T * frb);
     A.f.tiles = (L - 1) * A.tiles_per_layer;
@@ -2888,7 +2889,7 @@ int launch_forward_mega(const tsd_model_cfg& c, const tsd_batch& b, const float*
 #ifndef TSD_MEGA_PAIR_WIDE_MIN
 #define TSD_MEGA_PAIR_WIDE_MIN 768  // 32-row pair tiles of a group from which they are 64 rows (0: never)
 #endif
-    A.pair_rows = (H == 256 && TSD_MEGA_PAIR_WIDE_MIN > 0 && (long)((PU + T - 1) / T) * mg.G >= TSD_MEGA_PAIR_WIDE_MIN) ? 2 * T : T;
+    A.pair_rows = (H == 256 && !narrow && TSD_MEGA_PAIR_WIDE_MIN > 0 && (long)((PU + T - 1) / T) * mg.G >= TSD_MEGA_PAIR_WIDE_MIN) ? 2 * T : T;
     A.q.tiles = (PU + A.pair_rows - 1) / A.pair_rows;
     A.q.e = g.out_u;
     A.q.edge_attr = ea;
