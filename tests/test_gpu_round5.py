@@ -214,3 +214,22 @@ def test_one_launch_kernel_with_32_and_64_row_tiles_gives_the_same_bits(graphs, 
         assert not db.per_block
         out[wide] = db.edge_inv_u.clone()
     assert torch.equal(out[True], out[False])
+
+
+def test_stand_alone_pair_launch_with_64_row_tiles_gives_the_same_bits(dev, monkeypatch):
+    """the pair MLP as its own launch (behind the fused per-unit encoder) takes 64-row tiles from 4096 32-row tiles on:
+    80 graphs of 62 atoms = 151 280 out pairs = 4728 tiles; OPTIONS.wide_filter_tiles = False keeps 32 rows -- bit-identical"""
+    from tsdiff_amd import engine, synth
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    G = 80
+    b = synth.dense_stress_batch(G, n=62, seed=4)
+    g = to_dev({**{k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}, "num_graphs": G}, dev)
+    out = {}
+    for wide in (True, False):
+        monkeypatch.setattr(engine.OPTIONS, "gemm", "h2")
+        monkeypatch.setattr(engine.OPTIONS, "fused_encoder", "force")
+        monkeypatch.setattr(engine.OPTIONS, "wide_filter_tiles", wide)
+        inv, ei, _ = run_forward(make_model(cfg, 5, dev), g, dev)
+        out[wide] = inv.clone()
+    assert out[True].shape[0] >= 2 * 4096 * 32 - 64
+    assert torch.isfinite(out[True]).all() and torch.equal(out[True], out[False])

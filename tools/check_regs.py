@@ -20,8 +20,9 @@ BUDGET = [
     (r"forward_mega_kernelILi256E", 128, 0),
     (r"typed_embed_h_kernelILi256E", 80, 0),   # THREE workgroups of 8 waves per CU (37 KB of LDS each)
     (r"layer_combo_kernelILi256ELb0ELb[01]ELi1E", 128, 0),  # split-f16 block launches (all filter-tile widths)
-    (r"pair_output_h_kernelILi256ELb0E", 80, 0),  # inference form: THREE workgroups per CU
-    (r"pair_output_h_kernelILi256ELb1E", 128, 0),  # saving form of the training step
+    (r"pair_output_h_kernelILi256ELb0ELi1E", 80, 0),  # inference form: THREE workgroups per CU
+    (r"pair_output_h_kernelILi256ELb0ELi2E", 128, 0),  # ... its 64-row tiles (launches many rounds deep): two
+    (r"pair_output_h_kernelILi256ELb1ELi1E", 128, 0),  # saving form of the training step
     (r"layer_combo_kernelILi256ELb1ELb0ELi1ELi1E", 128, 0),  # split-f16 block launch of the training step (saving form)
     (r"block_bwd_kernelILi256E", 128, 0),                    # backward block launch, fp32 and split-f16 filter chains
     (r"pair_bwd_h_kernelILi256E", 128, 0),                   # split-f16 training step: the other tile kernels

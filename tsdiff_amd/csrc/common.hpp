@@ -275,7 +275,7 @@ int launch_edge_embed_save_h(const tsd_model_cfg& c, const float* W16, int cap_a
 int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity, tsd_edges e, const float* h,
                          const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
                          size_t ea_stride, size_t inv_stride, hipStream_t st, bool folded, int32_t* range_status,
-                         const PairSave* save = nullptr);
+                         const PairSave* save = nullptr, bool narrow = false);
 int launch_pack_weights16(const tsd_model_cfg& c, const float* packed, float* packed16, hipStream_t st);
 int launch_attr_planes(int H, int64_t rows, const float* src, float* dst, hipStream_t st);
 int launch_weights_preflight(const float* w, size_t n, float* out8, hipStream_t st);

@@ -2147,8 +2147,10 @@ int filter_tiles_per_layer(int capacity_u);
 // launch) on the f16 MFMA pipes: pair_role_h without the wait.
 // (inference form: three workgroups of 8 waves per CU = 6 waves per SIMD = 80 VGPRs; the compiler's free allocation is 84, the
 // cap costs no spill -- tools/check_regs.py holds it to 80 registers and no scratch)
-template <int H, bool SAVE = false>
-__global__ __launch_bounds__(2 * H) __attribute__((amdgpu_waves_per_eu(SAVE || H != 256 ? 1 : 6))) void pair_output_h_kernel(ComboPre q, size_t wstride, size_t h_stride, size_t ea_stride,
+// RB = 2: 64-row tiles for launches many rounds deep (configs[4]: 64 k tiles) -- 128 VGPRs under the cap (132 free), two
+// workgroups per CU, half the weight stream per row: configs[4] 18.64 -> 18.30 ms/step.
+template <int H, bool SAVE = false, int RB = 1>
+__global__ __launch_bounds__(2 * H) __attribute__((amdgpu_waves_per_eu(SAVE || H != 256 ? 1 : (RB > 1 ? 4 : 6)))) void pair_output_h_kernel(ComboPre q, size_t wstride, size_t h_stride, size_t ea_stride,
                                                               int32_t* range_status, PairSave sv, int M) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int tile;
@@ -2158,16 +2160,20 @@ __global__ __launch_bounds__(2 * H) __attribute__((amdgpu_waves_per_eu(SAVE || H
     q.edge_attr += m * ea_stride; q.w0b += wo; q.b0 += wo;
     q.w0a += wo; q.w1 += wo; q.b1 += wo; q.w2 += wo; q.b2 += wo;
     q.h += m * h_stride; q.edge_inv += m * q.inv_stride;
-    pair_role_h<H, SAVE, !SAVE>(q, tile, 0, smem, false, range_status, sv);
+    pair_role_h<H, SAVE, (!SAVE && RB == 1), RB>(q, tile, 0, smem, false, range_status, sv);
 }
 int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity, tsd_edges e, const float* h,
                          const float* edge_attr, const int32_t* attr_row, float* edge_inv, int M, size_t h_stride,
                          size_t ea_stride, size_t inv_stride, hipStream_t st, bool folded, int32_t* range_status,
-                         const PairSave* save) {
+                         const PairSave* save, bool narrow) {
     const WeightLayout L = weight_layout(c);
     const size_t H = c.hidden;
     const int tiles = (capacity + T - 1) / T;
     if (tiles == 0) return TSD_OK;
+#ifndef TSD_PAIR_OUT_WIDE_MIN
+#define TSD_PAIR_OUT_WIDE_MIN 4096  // 32-row pair tiles (x checkpoints) of the stand-alone launch from which they are 64 rows; 0: never
+#endif
+    const bool wide = !save && !narrow && c.hidden == 256 && TSD_PAIR_OUT_WIDE_MIN > 0 && (long)tiles * M >= TSD_PAIR_OUT_WIDE_MIN;
     ComboPre q{};
     q.tiles = tiles;
     q.e = e;
@@ -2190,6 +2196,18 @@ int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity,
     if (save && (folded || M != 1)) {
         set_error("internal: the saving pair output takes the unfolded first layer of one checkpoint");
         return TSD_ERR_INVALID;
+    }
+    if (wide) {
+        static DeviceOnce once_w;
+        const int tiles2 = (capacity + 2 * T - 1) / (2 * T);
+        q.tiles = tiles2;
+        const size_t lds2 = (size_t)(2 * T * ldh_of(256) + (256 / 64) * 2 * T + 3 * 2 * T) * 4;
+        int r = allow_lds(pair_output_h_kernel<256, false, 2>, lds2, once_w);
+        if (r) return r;
+        hipLaunchKernelGGL((pair_output_h_kernel<256, false, 2>), dim3(tiles2 * M), dim3(512), lds2, st, q, L.total, h_stride,
+                           ea_stride, range_status, PairSave{}, ckpt_grid_m(M, tiles2));
+        TSD_LAUNCH_CHECK("pair_output_h (64-row tiles)");
+        return TSD_OK;
     }
 #define TSD_POH(HH)                                                                                              \
     {                                                                                                            \

@@ -1546,7 +1546,7 @@ int launch_pair_output(const tsd_model_cfg& c, const float* W, int capacity, tsd
             return TSD_ERR_INVALID;
         }
         return launch_pair_output_h(c, W, capacity, e, h, edge_attr, attr_row, edge_inv, M, h_stride, ea_stride, inv_stride,
-                                    st, folded, prec.range_status, save);
+                                    st, folded, prec.range_status, save, prec.narrow_filter_tiles);
     }
     const WeightLayout L = weight_layout(c);
     PairW w{W + L.out_w0, W + L.out_b0, W + L.out_w1, W + L.out_b1, W + L.out_w2, W + L.out_b2,

@@ -10,7 +10,7 @@ at import, by `TSDIFF_*` environment variables (read here and nowhere else); tes
 | gemm               | TSDIFF_GEMM               | "h2"    | arithmetic of the inference forward's tile GEMMs: "h2" = split-f16 operands on the f16 MFMA pipes (22-bit operands, fp32 accumulation; csrc/split16.hpp), "f32" = fp32-input MFMA.  NOT bit-identical (1e-6 of the tensor scale apart).  A call that leaves the f16 range reruns in "f32" by itself |
 | typed_tiles        | TSDIFF_TYPED_TILES        | True    | edge embedding on static type-sorted tiles with per-type folded matrices (kernels_typed.hip); False: the generic embedding kernel (and, since the split-f16 forward needs the typed tiles, fp32 arithmetic) |
 | one_launch         | TSDIFF_ONE_LAUNCH         | True    | small batches: the L interaction blocks + pair MLP as ONE launch (forward_mega_kernel); False: one launch per block |
-| wide_filter_tiles  | TSDIFF_WIDE_FILTER_TILES  | True    | 64-row filter tiles where a block launch is many chip-fulls deep, 64-row filter and pair tiles in the one-launch kernel where they fill the chip; False: 32-row tiles everywhere.  Bit-identical |
+| wide_filter_tiles  | TSDIFF_WIDE_FILTER_TILES  | True    | 64-row filter tiles where a block launch is many chip-fulls deep, 64-row filter and pair tiles in the one-launch kernel where they fill the chip, 64-row tiles in a stand-alone pair launch of >= 4096 tiles; False: 32-row tiles everywhere.  Bit-identical |
 | fused_step_tail    | TSDIFF_FUSED_TAIL         | True    | sampling loop: update + next step's edge lists as one launch; False: three launches |
 | fused_encoder      | TSDIFF_FUSED_ENCODER      | True    | chip-full launches (big batches, ensembles): the whole SchNet encoder as ONE launch of per-unit workgroups that never write the CFConv filters to memory (kernels_unit.hip); False: one launch per block with materialised filters; "force": also where the one-launch form would apply.  Bit-identical (the messages are added in the directed list's order) |
 | train              | TSDIFF_TRAIN              | "fused" | training step: "fused" = forward + loss and the whole backward as two library calls (csrc/train_step.hip), "ops" = one autograd node per operation (same kernels; the cross-check) |
