@@ -233,3 +233,21 @@ def test_stand_alone_pair_launch_with_64_row_tiles_gives_the_same_bits(dev, monk
         out[wide] = inv.clone()
     assert out[True].shape[0] >= 2 * 4096 * 32 - 64
     assert torch.isfinite(out[True]).all() and torch.equal(out[True], out[False])
+
+
+def test_pair_role_of_the_last_block_launch_with_64_row_tiles_gives_the_same_bits(dev, monkeypatch):
+    """1300 graphs, one checkpoint (1300 node tiles: block launches, the pair MLP inside the last one): > 4096 pair tiles of
+    32 rows -> 64-row tiles; OPTIONS.wide_filter_tiles = False keeps every tile at 32 rows -- bit-identical"""
+    from tests.test_gpu_round4 import _batch
+    from tsdiff_amd import engine, synth
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    _, _, g = _batch(1300, 77, dev)
+    out = {}
+    for wide in (True, False):
+        monkeypatch.setattr(engine.OPTIONS, "gemm", "h2")
+        monkeypatch.setattr(engine.OPTIONS, "fused_encoder", False)
+        monkeypatch.setattr(engine.OPTIONS, "wide_filter_tiles", wide)
+        inv, _, _ = run_forward(make_model(cfg, 6, dev), g, dev)
+        out[wide] = inv.clone()
+    assert out[True].shape[0] // 2 >= 4096 * 32, out[True].shape   # (undirected out pairs: at least 4096 32-row tiles)
+    assert torch.isfinite(out[True]).all() and torch.equal(out[True], out[False])

@@ -369,6 +369,12 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
     const bool pair_role = small_fwd && TSD_PAIR_ROLE != 0 && status != nullptr;
     const bool use_pre = small_fwd && (pair_role || !h2);
     if (pair_role) {
+        // 64-row pair tiles where the role is many rounds deep (as the stand-alone pair launch: kernels_combo.hip
+        // TSD_PAIR_OUT_WIDE_MIN; round 5: 1000 graphs, 8 x 300 graphs)
+        if (h2 && H == 256 && !prec.narrow_filter_tiles && (long)pre.tiles * M >= 4096) {
+            pre.rows = 2 * TSD_EDGE_TILE;
+            pre.tiles = (PU + pre.rows - 1) / pre.rows;
+        }
         pre.pair = 1;
         pre.w0a = W + WL.out_w0;
         pre.w1 = W + WL.out_w1;

@@ -194,6 +194,7 @@ struct Prec {
 // optional third role of the per-block launch (kernels_combo.hip), filled by the forward in api.hip
 struct ComboPre {
     int tiles;  // 0: no pre role
+    int rows = TSD_EDGE_TILE;  // pairs per tile of the pair role: 32, or 64 (split-f16, hidden 256, launches many rounds deep)
     tsd_edges e;
     const float* edge_attr;
     const int32_t* attr_row;  // edge_attr row of out edge e (NULL: e)

@@ -2126,7 +2126,14 @@ __global__ __launch_bounds__(2 * H) void layer_combo_kernel(ComboNode a, int nod
                 // workgroups b and b + 256 of a launch share a CU (measured; a speed assumption only): these pair tiles
                 // sit beside the node tiles
                 const bool defer = TSD_PAIR_DEFER && b >= 256 && b - 256 < node_tiles;
-                if constexpr (PREC == PREC_H2) pair_role_h<H>(q, item - f.tiles, node_tiles, smem, defer, sd.range_status);
+                if constexpr (PREC == PREC_H2) {
+                    if constexpr (H == 256) {
+                        if (q.rows == 2 * T) pair_role_h<H, false, false, 2>(q, item - f.tiles, node_tiles, smem, defer, sd.range_status);
+                        else pair_role_h<H>(q, item - f.tiles, node_tiles, smem, defer, sd.range_status);
+                    } else {
+                        pair_role_h<H>(q, item - f.tiles, node_tiles, smem, defer, sd.range_status);
+                    }
+                }
                 else pair_role<H>(q, item - f.tiles, node_tiles, smem, defer);
             } else if constexpr (PREC == PREC_F32) {
                 pre_role<H>(q, item - f.tiles, smem);
@@ -3054,7 +3061,8 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     }
     const int grid = node_tiles + f.tiles + q.tiles;
     if (grid == 0) return TSD_OK;
-    const size_t lds = lds_combo(c.hidden, prec.mode, frb, nrb);
+    size_t lds = lds_combo(c.hidden, prec.mode, frb, nrb);
+    if (q.tiles > 0 && q.pair && q.rows == 2 * T) lds = std::max(lds, lds_combo(c.hidden, prec.mode, 2, 1));  // (64-row pair tiles)
     // interleave only when the launch is many chip-fulls deep (the node tiles alone over-subscribe the chip)
     int node_stride = 1;
     if (node_tiles >= 1024 && grid >= 3 * node_tiles) {
