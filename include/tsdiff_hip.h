@@ -312,8 +312,9 @@ typedef struct tsd_batch {
                                    runs its step tail as three launches instead of the fused one (<= 64-atom graphs) */
     int32_t reserved;           /* flags; bit 0: run the forward as one launch per block even where the one-launch form
                                    applies (also what a caller sets after a TSD_STATUS_INTERNAL report: that form has no
-                                   in-kernel waits); bit 1: 32-row filter tiles also where a split-f16 block launch would
-                                   take 64-row ones (A/B and cross-check switches; results are bit-identical); bit 2: no
+                                   in-kernel waits); bit 1: 32-row filter and pair tiles also where a split-f16 launch
+                                   (block launch, one-launch forward, pair output) would take 64-row ones (A/B and
+                                   cross-check switches; results are bit-identical); bit 2: no
                                    fused per-unit encoder (kernels_unit.hip) where it would apply: one launch per block
                                    with materialised filters instead (bit-identical results); bit 4: the fused
                                    encoder also where the one-launch form would apply (tests, A/B);
@@ -362,8 +363,8 @@ int tsd_score_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
  * forward -- the L interaction blocks (models/encoder/schnet.py:203-225) and the pair MLP (models/common.py:226-229) --
  * on the state the last tsd_score_forward of this batch left in the workspace (edge attributes, block-0 filters, edge
  * lists).  `epoch` numbers the calls 1, 2, 3, ... (the hand-off words of the launch are monotonic; call 1 zeroes them).
- * TSD_ERR_UNSUPPORTED when the batch does not take that path (no weights16 / status, several checkpoints, > 256 node
- * tiles). */
+ * TSD_ERR_UNSUPPORTED when the batch does not take that path (no weights16 / status, several checkpoints -- an ensemble's
+ * one-launch forward, groups of checkpoints in one grid, runs inside tsd_score_forward only --, > 256 node tiles). */
 int tsd_forward_blocks(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t epoch, void* stream);
 
 /* Measurement / cross-check entry of the fused per-unit encoder (csrc/kernels_unit.hip; models/encoder/schnet.py:74-128,
