@@ -183,7 +183,7 @@ def combo_roofline(lib, db, cfg, dev, reps=40, h2=False):
     ea = torch.randn(max(PU, 1), H, device=dev)
     if h2:  # (the split-f16 filter role takes the attribute rows as f16 planes, as the embedding launch leaves them)
         ea16 = torch.empty_like(ea)
-        _lib.check(lib.tsd_attr_planes(H, ea.shape[0], _lib.ptr(ea), _lib.ptr(ea16), _lib.stream_ptr()))
+        _lib.check(lib.tsd_attr_planes(H, ea.shape[0], _lib.ptr(ea), _lib.ptr(ea16), None, _lib.stream_ptr()))
         ea = ea16
     wf = torch.randn(2, max(PU, 1), H, device=dev)
     xa, xb = torch.randn(N, H, device=dev), torch.empty(N, H, device=dev)

@@ -230,9 +230,11 @@ int tsd_interaction_block(const tsd_model_cfg* cfg, const float* w, int32_t laye
  * then takes edge_attr = s1 and the FOLDED nn.0 of tsd_pack_weights, as the forward does); range_status: device word
  * for TSD_STATUS_RANGE or NULL.  Node-side inputs and all outputs are the fp32 ones; `edge_attr` is in the form the
  * split-f16 embedding launch leaves it in (0.6): every row = its two f16 planes, bytes [0, 2H) the high plane, [2H, 4H)
- * the low plane x 2^11 -- tsd_attr_planes converts an fp32 matrix. */
+ * the low plane x 2^11 -- tsd_attr_planes converts an fp32 matrix and, as the embedding launch does for its rows, raises
+ * TSD_STATUS_RANGE in *range_status (device word or NULL) for a value beyond the f16 range or a run of 8 channels that is
+ * tiny throughout (csrc/split16.hpp); tsd_interaction_block16 does not re-check rows it receives as planes (0.7). */
 int tsd_attr_planes(int32_t hidden, int64_t rows, const float* edge_attr /* [rows, H] fp32 */,
-                    float* edge_attr16 /* [rows, H] floats: plane rows */, void* stream);
+                    float* edge_attr16 /* [rows, H] floats: plane rows */, int32_t* range_status, void* stream);
 int tsd_interaction_block16(const tsd_model_cfg* cfg, const float* w16, int32_t layer, int32_t num_nodes,
                             tsd_edges enc, const float* Wf_layer, const float* x1_in, float* h, float* x1_out,
                             int32_t filter_layer, int32_t capacity_u, tsd_edges enc_u, const float* edge_attr,

@@ -1,0 +1,205 @@
+"""Round-6 GPU tests (through the C ABI, `-m gpu`): the waiting pair role behind spread node tiles, the
+piecewise split-f16 entry with plane rows, parity on weights the package trained itself, the per-graph aggregation."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from tests.test_gpu_parity import dev, make_model, run_forward, to_dev  # noqa: E402,F401
+from tests.test_gpu_round4 import _db  # noqa: E402
+from tests.util import assert_close  # noqa: E402
+
+RTOL = 1e-5  # north_star: eps within 1e-5 rel-fp32 of the reference
+
+pytestmark = pytest.mark.gpu
+
+
+def _sparse_big_batch(graphs, n, box, seed, dev):
+    from tsdiff_amd import synth
+    b = synth.dense_stress_batch(graphs, n=n, seed=seed, box=box)
+    t = {k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}
+    return b, t, to_dev({**t, "num_graphs": graphs}, dev)
+
+
+@pytest.mark.parametrize("graphs,n,box", [(600, 44, 16.0), (450, 44, 19.0)])
+def test_pair_role_behind_many_node_tiles_with_half_the_pairs_cut_off(graphs, n, box, dev, monkeypatch):
+    """>= 1024 node tiles (1650 / 1238) with the pair MLP inside the last block launch and a COMPACTED
+    out list (about half / a third of the pairs inside the 10 A cutoff): the node tiles must all be dispatched ahead of the
+    waiting pair tiles (node_stride 1 whenever the pair role rides along) -- no TSD_STATUS_INTERNAL, and the same bits as
+    the form without any in-kernel wait (tsd_batch.reserved bit 0: stand-alone pair launch)"""
+    from tsdiff_amd import engine, synth
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    b, t, g = _sparse_big_batch(graphs, n, box, 7, dev)
+    monkeypatch.setattr(engine.OPTIONS, "gemm", "h2")
+    monkeypatch.setattr(engine.OPTIONS, "fused_encoder", False)
+    model = make_model(cfg, 3, dev)
+    inv, ei, _ = run_forward(model, g, dev)
+    db = _db(model)
+    assert not db.per_block, "a bounded in-kernel wait gave up (TSD_STATUS_INTERNAL) in the default form"
+    assert db.gemm_mode() == "h2"
+    frac = ei.shape[1] / float(graphs * n * (n - 1))
+    assert 0.2 < frac < 0.8, f"the batch does not exercise a compacted out list ({frac:.2f} of the pairs kept)"
+    monkeypatch.setattr(engine.OPTIONS, "one_launch", False)
+    ref_model = make_model(cfg, 3, dev)
+    ref, ref_ei, _ = run_forward(ref_model, g, dev)
+    assert _db(ref_model).reserved_flags() & 1  # (the form without in-kernel waits)
+    assert torch.equal(ei, ref_ei)
+    assert torch.equal(inv, ref)
+    assert bool(torch.isfinite(inv).all())
+
+
+def test_internal_status_fallback_form_has_no_waiting_pair_role(dev, monkeypatch):
+    """the form the host falls back to after TSD_STATUS_INTERNAL (tsd_batch.reserved bit 0) must not
+    contain the waiting pair role either.  Fault injection on a block-launch batch (reserved bit 3 would only hit the
+    one-launch kernel), so: run the fallback form directly on a batch past the one-launch size and check that the stand-alone
+    pair kernel ran (roctx-free check: the ready words of the workspace stay zero -- no node tile published to a pair role)"""
+    from tsdiff_amd import engine, synth
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    b, t, g = _sparse_big_batch(120, 44, 14.0, 3, dev)
+    monkeypatch.setattr(engine.OPTIONS, "gemm", "h2")
+    monkeypatch.setattr(engine.OPTIONS, "fused_encoder", False)
+    model = make_model(cfg, 3, dev)
+    inv, ei, _ = run_forward(model, g, dev)
+    db = _db(model)
+    assert not db.per_block
+    db.per_block = True  # what status_fallback does after TSD_STATUS_INTERNAL
+    db.drop_plans()
+    inv2, ei2, _ = run_forward(model, g, dev)
+    assert torch.equal(inv2, inv) and torch.equal(ei2, ei)
+    assert db.reserved_flags() & 1
+
+
+def test_attr_planes_and_the_piecewise_split_f16_block_vs_the_fp32_entry(dev):
+    """tsd_attr_planes + tsd_interaction_block16 (plane rows in, 0.6) against tsd_interaction_block on the
+    same fp32 rows: filters of a layer and one node chain within 1e-5; tsd_attr_planes raises TSD_STATUS_RANGE for a value
+    beyond the f16 range and for a run of channels that is tiny throughout, and leaves the word alone otherwise"""
+    from tsdiff_amd import _lib, synth
+    lib = _lib.load()
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    H, L = cfg["hidden_dim"], cfg["encoder"]["num_convs"]
+    b = synth.wb97xd3_like_batch(40, seed=4)
+    t = {k: torch.from_numpy(v) for k, v in b.items() if isinstance(v, np.ndarray)}
+    g = to_dev({**t, "num_graphs": 40}, dev)
+    model = make_model(cfg, 3, dev)
+    run_forward(model, g, dev)
+    db = _db(model)
+    N, PU = db.N, db.P // 2
+    gen = torch.Generator(device=dev).manual_seed(5)
+    ea = torch.randn(PU, H, device=dev, generator=gen) * 0.5
+    ea16 = torch.empty_like(ea)
+    status = torch.zeros(4, dtype=torch.int32, device=dev)
+    _lib.check(lib.tsd_attr_planes(H, PU, _lib.ptr(ea), _lib.ptr(ea16), _lib.ptr(status), _lib.stream_ptr()))
+    assert int(status[0]) == 0
+    # the planes reproduce the rows to 22 bits
+    pl = ea16.view(torch.float16).view(PU, 2, H).float()
+    back = pl[:, 0] + pl[:, 1] / 2048.0
+    assert float((back - ea).abs().max()) <= 2.0 ** -21 * float(ea.abs().max())
+    x = torch.randn(N, H, device=dev, generator=gen) * 0.3
+    h0 = torch.randn(N, H, device=dev, generator=gen) * 0.3
+    out = {}
+    for h2 in (False, True):
+        wf = torch.zeros(2, PU, H, device=dev)
+        hbuf, xo = h0.clone(), torch.empty(N, H, device=dev)
+
+        def blk(layer, fl, xi, xo_):
+            args = (C.byref(db.cfg), _lib.ptr(db.weights16[0] if h2 else db.weights[0]), layer, N, db.enc.struct(),
+                    _lib.ptr(wf[layer % 2]) if layer >= 0 else None, _lib.ptr(xi), _lib.ptr(hbuf), _lib.ptr(xo_), fl, PU,
+                    db.enc_u.struct(), _lib.ptr(ea16 if h2 else ea), _lib.ptr(wf[fl % 2]) if fl >= 0 else None)
+            if h2:
+                _lib.check(lib.tsd_interaction_block16(*args, _lib.ptr(status), _lib.stream_ptr()))
+            else:
+                _lib.check(lib.tsd_interaction_block(*args, _lib.stream_ptr()))
+        blk(-2, 0, x, xo)
+        blk(0, 1, x, xo)
+        torch.cuda.synchronize()
+        Eu = db.enc_u.num_edges()
+        out[h2] = (wf[0, :Eu].clone(), wf[1, :Eu].clone(), hbuf.clone(), xo.clone())
+    assert int(status[0]) == 0
+    for a, r, what in zip(out[True], out[False], ("filters of block 0", "filters of block 1", "h", "x1")):
+        assert_close(a.cpu().numpy(), r.cpu().numpy(), RTOL, what)
+    # range reports of the producer
+    big = ea.clone()
+    big[3, 7] = 1.0e6
+    _lib.check(lib.tsd_attr_planes(H, PU, _lib.ptr(big), _lib.ptr(ea16), _lib.ptr(status), _lib.stream_ptr()))
+    assert int(status[0]) & _lib.STATUS_RANGE
+    status.zero_()
+    tiny = ea.clone()
+    tiny[5, 16:24] = 1.0e-6  # one conversion site (8 consecutive channels of a row) below 2^-12 throughout
+    _lib.check(lib.tsd_attr_planes(H, PU, _lib.ptr(tiny), _lib.ptr(ea16), _lib.ptr(status), _lib.stream_ptr()))
+    assert int(status[0]) & _lib.STATUS_RANGE
+    status.zero_()
+    _lib.check(lib.tsd_attr_planes(H, PU, _lib.ptr(ea), _lib.ptr(ea16), None, _lib.stream_ptr()))  # NULL word: no report
+    assert int(status[0]) == 0
+
+
+def _ragged_csr(sizes, keep, rng):
+    """CSR of a batch of graphs (contiguous node ranges): every node lists the other nodes of its graph, each kept with
+    probability `keep`, ascending -- rows of 0 .. n - 1 edges, empty rows included"""
+    row_ptr, dst = [0], []
+    base = 0
+    for n in sizes:
+        for i in range(n):
+            others = np.concatenate([np.arange(0, i), np.arange(i + 1, n)]) + base
+            sel = others[rng.random(n - 1) < keep] if n > 1 else others
+            dst.append(sel)
+            row_ptr.append(row_ptr[-1] + len(sel))
+        base += n
+    return np.asarray(row_ptr, np.int32), (np.concatenate(dst) if dst else np.zeros(0)).astype(np.int32), base
+
+
+def _sequential_rows(row_ptr, dst, widx, W, x1):
+    """out[i] = sum over the row's edges IN LIST ORDER of round(x1[dst] * W[widx]), from 0: vectorised over rows, sequential
+    along a row (what a sequential fp32 scatter_add does; reference schnet.py:100-107)"""
+    N = row_ptr.numel() - 1
+    deg = (row_ptr[1:] - row_ptr[:-1]).long()
+    out = torch.zeros(N, W.shape[1], device=W.device)
+    for k in range(int(deg.max()) if N else 0):
+        rows = (deg > k).nonzero().view(-1)
+        e = row_ptr[rows].long() + k
+        out[rows] = out[rows] + x1[dst[e].long()] * W[widx[e].long()]
+    return out
+
+
+@pytest.mark.parametrize("H", [256, 64])
+def test_windowed_aggregation_is_bitwise_the_sequential_scatter_on_ragged_graphs(H, dev):
+    """cfconv_aggregate_win_kernel (round 6: a workgroup owns 32 destination rows and stages the x1 window of its edges in
+    LDS once; launches of >= 16384 rows) on a batch that exercises every branch: graphs of 1 .. 130 atoms (windows that fit,
+    windows that straddle graphs, graphs of more than 64 atoms -> the global-gather fallback), empty rows, rows that end
+    inside / at the end of a 64-edge index chunk, a last partial workgroup, with and without the directed -> undirected
+    filter map -- bit-identical to the sequential scatter in list order, and to the one-wave-per-row kernel on a slice
+    small enough to take it"""
+    from tsdiff_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    sizes = []
+    while sum(sizes) < 17000:
+        sizes.append(int(rng.choice([1, 2, 3, 7, 16, 23, 33, 40, 64, 64, 64, 65, 90, 130])))
+    rp, ds, N = _ragged_csr(sizes, 0.8, rng)
+    assert N >= 16384 and N % 32 != 0
+    E = int(rp[-1])
+    row_ptr, dst = torch.from_numpy(rp).to(dev), torch.from_numpy(ds).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(3)
+    W = torch.randn(E, H, device=dev, generator=gen)
+    x1 = torch.randn(N, H, device=dev, generator=gen)
+    ident = torch.arange(E, dtype=torch.int32, device=dev)
+    umap = torch.randperm(E, device=dev, generator=gen).to(torch.int32)
+    for um in (None, umap):
+        out = torch.full((N, H), float("nan"), device=dev)
+        _lib.check(lib.tsd_cfconv_aggregate(H, N, _lib.ptr(row_ptr), _lib.ptr(dst), _lib.ptr(um) if um is not None else None,
+                                            _lib.ptr(W), _lib.ptr(x1), _lib.ptr(out), _lib.stream_ptr()))
+        ref = _sequential_rows(row_ptr, dst, ident if um is None else um, W, x1)
+        assert torch.equal(out, ref), f"windowed aggregation differs from the sequential order (umap: {um is not None})"
+    # the first 4000 rows alone (one wave per row: below the windowed form's launch size) give the same bits
+    n0 = 4000
+    out0 = torch.full((n0, H), float("nan"), device=dev)
+    _lib.check(lib.tsd_cfconv_aggregate(H, n0, _lib.ptr(row_ptr), _lib.ptr(dst), None, _lib.ptr(W), _lib.ptr(x1),
+                                        _lib.ptr(out0), _lib.stream_ptr()))
+    # (rows of a graph cut by the slice still name nodes beyond it: x1 has them)
+    assert torch.equal(out0, _sequential_rows(row_ptr[: n0 + 1], dst, ident, W, x1))

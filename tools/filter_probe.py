@@ -24,7 +24,7 @@ N, PU, H = db.N, db.P // 2, 256
 Eu = db.enc_u.num_edges()
 ea = torch.randn(max(PU, 1), H, device=dev)
 ea16 = torch.empty_like(ea)
-_lib.check(lib.tsd_attr_planes(H, ea.shape[0], _lib.ptr(ea), _lib.ptr(ea16), _lib.stream_ptr()))
+_lib.check(lib.tsd_attr_planes(H, ea.shape[0], _lib.ptr(ea), _lib.ptr(ea16), None, _lib.stream_ptr()))
 wf = torch.empty(max(PU, 1), H, device=dev)
 x = torch.randn(N, H, device=dev)
 def launch():

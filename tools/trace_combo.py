@@ -50,7 +50,7 @@ def main():
     ea = torch.randn(max(PU, 1), H, device=dev)
     if h2:  # (the split-f16 filter role takes plane rows)
         ea16 = torch.empty_like(ea)
-        _lib.check(lib.tsd_attr_planes(H, ea.shape[0], _lib.ptr(ea), _lib.ptr(ea16), _lib.stream_ptr()))
+        _lib.check(lib.tsd_attr_planes(H, ea.shape[0], _lib.ptr(ea), _lib.ptr(ea16), None, _lib.stream_ptr()))
         ea = ea16
     wf = torch.randn(2, max(PU, 1), H, device=dev)
     xa, xb = torch.randn(N, H, device=dev), torch.empty(N, H, device=dev)

@@ -155,7 +155,7 @@ SIGNATURES = {
     "tsd_filter_gen": (C.c_int, [_CFG, _P, C.c_int32, Edges, _P, _P, _P]),
     "tsd_interaction_block": (C.c_int, [_CFG, _P, C.c_int32, C.c_int32, Edges, _P, _P, _P, _P, C.c_int32, C.c_int32,
                                         Edges, _P, _P, _P]),
-    "tsd_attr_planes": (C.c_int, [C.c_int32, C.c_int64, _P, _P, _P]),
+    "tsd_attr_planes": (C.c_int, [C.c_int32, C.c_int64, _P, _P, _P, _P]),
     "tsd_interaction_block16": (C.c_int, [_CFG, _P, C.c_int32, C.c_int32, Edges, _P, _P, _P, _P, C.c_int32, C.c_int32,
                                           Edges, _P, _P, _P, _P]),
     "tsd_cfconv_aggregate": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),

@@ -366,7 +366,9 @@ static int forward_impl(const tsd_model_cfg& c, const tsd_batch& b, const float*
 #ifndef TSD_PAIR_ROLE
 #define TSD_PAIR_ROLE 1  // 0 (A/B variant builds): pre role + separate pair_output launch, as in round 2
 #endif
-    const bool pair_role = small_fwd && TSD_PAIR_ROLE != 0 && status != nullptr;
+    // (tsd_batch.reserved bit 0 -- the form the host falls back to after TSD_STATUS_INTERNAL -- has NO in-kernel wait:
+    // its pair MLP is the stand-alone launch)
+    const bool pair_role = small_fwd && TSD_PAIR_ROLE != 0 && status != nullptr && !(b.reserved & 1);
     const bool use_pre = small_fwd && (pair_role || !h2);
     if (pair_role) {
         // 64-row pair tiles where the role is many rounds deep (as the stand-alone pair launch: kernels_combo.hip
@@ -642,11 +644,12 @@ int tsd_interaction_block(const tsd_model_cfg* cfg, const float* w, int32_t laye
     return interaction_block_impl(0, nullptr, cfg, w, layer, num_nodes, enc, Wf_layer, x1_in, h, x1_out, filter_layer,
                                   capacity_u, enc_u, edge_attr, Wf_out, stream);
 }
-int tsd_attr_planes(int32_t hidden, int64_t rows, const float* edge_attr, float* edge_attr16, void* stream) {
+int tsd_attr_planes(int32_t hidden, int64_t rows, const float* edge_attr, float* edge_attr16, int32_t* range_status,
+                    void* stream) {
     TraceRange range("tsd:attr_planes");
     TSD_REQUIRE(rows >= 0 && (rows == 0 || (edge_attr && edge_attr16)), "null pointer");
     TSD_REQUIRE(edge_attr != edge_attr16, "in-place conversion is not supported");
-    return launch_attr_planes(hidden, rows, edge_attr, edge_attr16, (hipStream_t)stream);
+    return launch_attr_planes(hidden, rows, edge_attr, edge_attr16, range_status, (hipStream_t)stream);
 }
 
 int tsd_interaction_block16(const tsd_model_cfg* cfg, const float* w16, int32_t layer, int32_t num_nodes, tsd_edges enc,

@@ -278,7 +278,7 @@ int launch_pair_output_h(const tsd_model_cfg& c, const float* W16, int capacity,
                          size_t ea_stride, size_t inv_stride, hipStream_t st, bool folded, int32_t* range_status,
                          const PairSave* save = nullptr, bool narrow = false);
 int launch_pack_weights16(const tsd_model_cfg& c, const float* packed, float* packed16, hipStream_t st);
-int launch_attr_planes(int H, int64_t rows, const float* src, float* dst, hipStream_t st);
+int launch_attr_planes(int H, int64_t rows, const float* src, float* dst, int32_t* range_status, hipStream_t st);
 int launch_weights_preflight(const float* w, size_t n, float* out8, hipStream_t st);
 // the whole split-f16 forward of one checkpoint as ONE launch (kernels_combo.hip, small batches)
 struct MegaGroup {   // the M checkpoints of a batch in groups of G in one launch of the one-launch forward; strides in floats / int32 words

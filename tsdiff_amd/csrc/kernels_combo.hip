@@ -3064,8 +3064,11 @@ int launch_layer_combo(const tsd_model_cfg& c, const float* W, int layer, int N,
     size_t lds = lds_combo(c.hidden, prec.mode, frb, nrb);
     if (q.tiles > 0 && q.pair && q.rows == 2 * T) lds = std::max(lds, lds_combo(c.hidden, prec.mode, 2, 1));  // (64-row pair tiles)
     // interleave only when the launch is many chip-fulls deep (the node tiles alone over-subscribe the chip)
+    // (never with the waiting pair role: its tiles spin on the node tiles' ready flags, so every node tile has to be
+    // DISPATCHED before any of them -- node tiles first, S = 1; a spread node tile behind a slot-filling crowd of
+    // waiting pair tiles would never start: ADVICE r05, tests/test_gpu_round6.py)
     int node_stride = 1;
-    if (node_tiles >= 1024 && grid >= 3 * node_tiles) {
+    if (!q.pair && node_tiles >= 1024 && grid >= 3 * node_tiles) {
         node_stride = grid / node_tiles;
         if (node_stride % 2 == 0) --node_stride;
     }

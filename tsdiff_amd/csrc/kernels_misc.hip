@@ -136,15 +136,195 @@ __global__ __launch_bounds__(256) void cfconv_aggregate_kernel(int N, const int3
     for (int v = 0; v < V; ++v) out[(size_t)i * H + lane * V + v] = acc[v];
 }
 
+// ---------------------------------------------------------------------------------------------
+// T5, windowed form (round 6): the same sums for launches that are many chip-fulls of rows (BASELINE configs[4]: 65 536
+// rows, 4.2 GB of filters).  A workgroup owns AGW_ROWS consecutive destination rows.  Graphs are contiguous node ranges, so
+// the source rows its edges name lie in a short window [lo, hi] of x1: the workgroup finds the window (min / max over its
+// slice of `dst`, 16 KB), copies it into LDS ONCE (<= AGW_WIN rows = 64 KB at H = 256: a 64-atom graph) and every edge then
+// costs one streamed filter row from HBM and one ds_read from LDS -- in the one-wave-per-row form above each edge's x1 row
+// is a second 1-KB vector load served by L2, and every XCD's L2 fetches every graph's x1 rows (PMC: 4.86 GB per launch for
+// 4.38 GB algorithmic, profiles/r05_pmc_traffic_c5.md).  A window that does not fit (a graph of more than AGW_WIN atoms, or
+// rows that straddle several graphs) takes the global gather for that workgroup.  A wave walks the CONTIGUOUS edge range of
+// its AGW_ROWS / AGW_WAVES consecutive rows in batches of U edges and closes a row where the CSR says so (wave-uniform
+// control flow): no clamped tail batch per row.  Per row the edges are added in list order, product rounded, then added,
+// from 0: bit-identical to the form above and to a sequential scatter_add.
+// ---------------------------------------------------------------------------------------------
+#ifndef TSD_AGW_ROWS
+#define TSD_AGW_ROWS 32
+#endif
+#ifndef TSD_AGW_WAVES
+#define TSD_AGW_WAVES 8
+#endif
+#ifndef TSD_AGW_U
+#define TSD_AGW_U 16
+#endif
+#ifndef TSD_AGW_MIN_ROWS
+#define TSD_AGW_MIN_ROWS 16384  // rows of a launch from which the windowed form runs (0: never); below, one wave per row
+#endif
+constexpr int AGW_ROWS = TSD_AGW_ROWS, AGW_WAVES = TSD_AGW_WAVES, AGW_WIN = 64, AGW_RW = AGW_ROWS / AGW_WAVES;
+static_assert(AGW_ROWS % AGW_WAVES == 0, "rows per wave");
+constexpr size_t agw_lds_bytes(int H) { return (size_t)AGW_WIN * H * 4 + (AGW_ROWS + 1 + 2 * AGW_WAVES + 3) / 4 * 16; }
+
+template <int H, bool XL>
+__device__ __forceinline__ void agw_wave(const int* __restrict__ rp /* LDS: row_ptr[r0 ..] */, int ra, int rb, int r0, int lo,
+                                         const float* __restrict__ xs, const int32_t* __restrict__ dst,
+                                         const int32_t* __restrict__ umap, const float* __restrict__ W,
+                                         const float* __restrict__ x1, float* __restrict__ out) {
+    constexpr int V = H / 64, U = XL ? TSD_AGW_U : TSD_AGW_U / 2;  // (the global-gather fallback holds two rows per edge)
+    typedef typename VecOf<V>::type vrow;
+    const int lane = threadIdx.x & 63;
+    const int ea = __builtin_amdgcn_readfirstlane(rp[ra - r0]), ez = __builtin_amdgcn_readfirstlane(rp[rb - r0]);
+    int cur = ra, ce = __builtin_amdgcn_readfirstlane(rp[ra + 1 - r0]);
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.0f;
+    // rows that end at edge `enext` (the row just summed, and empty rows behind it) are stored and closed
+    auto flush = [&](int enext) {
+        while (cur < rb && ce == enext) {
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                out[(size_t)cur * H + lane * V + v] = acc[v];
+                acc[v] = 0.0f;
+            }
+            ++cur;
+            if (cur < rb) ce = __builtin_amdgcn_readfirstlane(rp[cur + 1 - r0]);
+        }
+    };
+    flush(ea);
+    for (int eb = ea; eb < ez; eb += 64) {
+        const int cnt = min(64, ez - eb);
+        const int ee = eb + min(lane, cnt - 1);
+        const int jv = dst[ee] - (XL ? lo : 0);
+        const int wv = umap ? umap[ee] : ee;
+        for (int k = 0; k < cnt; k += U) {
+            vrow w[U], x[XL ? 1 : U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kk = min(k + u, cnt - 1);
+                const int we = __builtin_amdgcn_readlane(wv, kk);
+                w[u] = __builtin_nontemporal_load(reinterpret_cast<const vrow*>(W + (size_t)we * H + lane * V));
+                if constexpr (!XL) {
+                    const int j = __builtin_amdgcn_readlane(jv, kk);
+                    x[u] = *reinterpret_cast<const vrow*>(x1 + (size_t)j * H + lane * V);
+                }
+            }
+            // (the x rows of four edges are read from LDS together, ahead of their use: a ds_read per edge right before its
+            // multiply would expose the LDS latency once per edge -- the row-closing branches keep the compiler from hoisting)
+#pragma unroll
+            for (int u0 = 0; u0 < U; u0 += 4) {
+                vrow xg[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if constexpr (XL) {
+                        const int j = __builtin_amdgcn_readlane(jv, min(k + u0 + g, cnt - 1));
+                        xg[g] = *reinterpret_cast<const vrow*>(xs + j * H + lane * V);
+                    } else {
+                        xg[g] = x[u0 + g];
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int u = u0 + g;
+                    if (k + u < cnt) {
+#pragma unroll
+                        for (int v = 0; v < V; ++v)
+                            acc[v] = __fadd_rn(acc[v], __fmul_rn(VecOf<V>::get(xg[g], v), VecOf<V>::get(w[u], v)));
+                        flush(eb + k + u + 1);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(64 * AGW_WAVES) void cfconv_aggregate_win_kernel(int N, const int32_t* __restrict__ row_ptr,
+                                                                              const int32_t* __restrict__ dst,
+                                                                              const int32_t* __restrict__ umap,
+                                                                              const float* __restrict__ W,
+                                                                              const float* __restrict__ x1,
+                                                                              float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float agw_smem[];
+    constexpr int T = 64 * AGW_WAVES;
+    float* xs = agw_smem;
+    int* rp = reinterpret_cast<int*>(agw_smem + (size_t)AGW_WIN * H);
+    int* red = rp + AGW_ROWS + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r0 = blockIdx.x * AGW_ROWS, r1 = min(N, r0 + AGW_ROWS);
+    if (tid <= r1 - r0) rp[tid] = row_ptr[r0 + tid];
+    __syncthreads();
+    const int e_lo = rp[0], e_hi = rp[r1 - r0];
+    int lo = 0x7fffffff, hi = -1;
+    for (int e = e_lo + tid; e < e_hi; e += T) {
+        const int j = dst[e];
+        lo = min(lo, j);
+        hi = max(hi, j);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off));
+        hi = max(hi, __shfl_xor(hi, off));
+    }
+    if (lane == 0) {
+        red[wave] = lo;
+        red[AGW_WAVES + wave] = hi;
+    }
+    __syncthreads();
+    lo = red[0];
+    hi = red[AGW_WAVES];
+#pragma unroll
+    for (int w = 1; w < AGW_WAVES; ++w) {
+        lo = min(lo, red[w]);
+        hi = max(hi, red[AGW_WAVES + w]);
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    const bool xl = hi >= lo && hi - lo < AGW_WIN;  // (workgroup-uniform)
+    if (xl) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(x1 + (size_t)lo * H);
+        f32x4* d = reinterpret_cast<f32x4*>(xs);
+        const int chunks = (hi - lo + 1) * (H / 4);
+        for (int c = tid; c < chunks; c += T) d[c] = src[c];
+        __syncthreads();
+    }
+    const int ra = r0 + wave * AGW_RW, rb = min(r1, ra + AGW_RW);
+    if (ra >= rb) return;  // (no barrier below)
+    if (xl) agw_wave<H, true>(rp, ra, rb, r0, lo, xs, dst, umap, W, x1, out);
+    else agw_wave<H, false>(rp, ra, rb, r0, 0, xs, dst, umap, W, x1, out);
+}
+
 int launch_cfconv_aggregate(int H, int N, const int32_t* row_ptr, const int32_t* dst, const int32_t* umap,
                             const float* W, const float* x1, float* out, hipStream_t st) {
     if (N == 0) return TSD_OK;
+    if (!hidden_supported(H)) {
+        set_error("hidden=%d unsupported (64/128/256)", H);
+        return TSD_ERR_INVALID;
+    }
+    if (TSD_AGW_MIN_ROWS > 0 && N >= TSD_AGW_MIN_ROWS) {
+        const int blocks = (N + AGW_ROWS - 1) / AGW_ROWS;
+        const size_t lds = agw_lds_bytes(H);
+#define TSD_AGW(HH)                                                                                              \
+    {                                                                                                            \
+        static DeviceOnce once;                                                                                  \
+        int r = allow_lds(cfconv_aggregate_win_kernel<HH>, lds, once);                                           \
+        if (r) return r;                                                                                         \
+        hipLaunchKernelGGL(cfconv_aggregate_win_kernel<HH>, dim3(blocks), dim3(64 * AGW_WAVES), lds, st, N, row_ptr, dst, \
+                           umap, W, x1, out);                                                                    \
+    }
+        switch (H) {
+            case 64: TSD_AGW(64) break;
+            case 128: TSD_AGW(128) break;
+            default: TSD_AGW(256) break;
+        }
+#undef TSD_AGW
+        TSD_LAUNCH_CHECK("cfconv_aggregate_win");
+        return TSD_OK;
+    }
     const int blocks = (N + 3) / 4;
     switch (H) {
         case 64: hipLaunchKernelGGL(cfconv_aggregate_kernel<64>, dim3(blocks), dim3(256), 0, st, N, row_ptr, dst, umap, W, x1, out); break;
         case 128: hipLaunchKernelGGL(cfconv_aggregate_kernel<128>, dim3(blocks), dim3(256), 0, st, N, row_ptr, dst, umap, W, x1, out); break;
-        case 256: hipLaunchKernelGGL(cfconv_aggregate_kernel<256>, dim3(blocks), dim3(256), 0, st, N, row_ptr, dst, umap, W, x1, out); break;
-        default: set_error("hidden=%d unsupported (64/128/256)", H); return TSD_ERR_INVALID;
+        default: hipLaunchKernelGGL(cfconv_aggregate_kernel<256>, dim3(blocks), dim3(256), 0, st, N, row_ptr, dst, umap, W, x1, out); break;
     }
     TSD_LAUNCH_CHECK("cfconv_aggregate");
     return TSD_OK;

@@ -1609,7 +1609,8 @@ __global__ void split16_kernel(const float* __restrict__ src, float* __restrict_
     d[((((size_t)ks * 2 + 1) * 2 + half) * nout + col) * 8 + e] = l;
 }
 // fp32 attribute rows [rows, H] -> plane rows (common.hpp ATTRIBUTE ROWS AS f16 PLANES): one thread per 8 channels
-__global__ void attr_planes_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, long rows) {
+__global__ void attr_planes_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, long rows,
+                                   int32_t* __restrict__ range_status) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int c8 = H / 8;
     if (idx >= rows * c8) return;
@@ -1617,25 +1618,33 @@ __global__ void attr_planes_kernel(const float* __restrict__ src, float* __restr
     const int c = (int)(idx % c8);
     const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + r * H + c * 8), a1 = *reinterpret_cast<const f32x4*>(src + r * H + c * 8 + 4);
     f16x8 h, l;
+    // range check as in the producers of the fused forward (split16.hpp): |a| > 65504 and a conversion site -- here the 8
+    // consecutive channels of one row that a thread converts -- whose non-zero values all lie below 2^-12
+    float amax = 0.0f, m = 0.0f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         f16 hh, ll;
-        split1(i < 4 ? a0[i] : a1[i - 4], hh, ll);
+        const float a = i < 4 ? a0[i] : a1[i - 4];
+        amax_upd(m, a);
+        split1(a, hh, ll);
         h[i] = hh;
         l[i] = ll;
     }
+    site_close(amax, m);
+    range_report(amax, range_status);
     f16* d = reinterpret_cast<f16*>(dst + r * H);
     *reinterpret_cast<f16x8*>(d + c * 8) = h;
     *reinterpret_cast<f16x8*>(d + H + c * 8) = l;
 }
-int launch_attr_planes(int H, int64_t rows, const float* src, float* dst, hipStream_t st) {
+int launch_attr_planes(int H, int64_t rows, const float* src, float* dst, int32_t* range_status, hipStream_t st) {
     if (rows <= 0) return TSD_OK;
     if (!hidden_supported(H)) {
         set_error("hidden=%d unsupported (64/128/256)", H);
         return TSD_ERR_INVALID;
     }
     const long n = rows * (H / 8);
-    hipLaunchKernelGGL(attr_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, H, (long)rows);
+    hipLaunchKernelGGL(attr_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, H, (long)rows,
+                       range_status);
     TSD_LAUNCH_CHECK("attr_planes");
     return TSD_OK;
 }

@@ -707,6 +707,10 @@ int launch_unit_encoder(const tsd_model_cfg& c, const tsd_batch& b, const float*
         set_error("internal: the fused encoder needs hidden 256 and the batch's unit partition");
         return TSD_ERR_INVALID;
     }
+    if (status == nullptr) {  // (the kernel reports a broken unit partition through it: without the word it would return early, silently)
+        set_error("internal: the fused encoder needs a status word");
+        return TSD_ERR_INVALID;
+    }
     const WeightLayout WL = weight_layout(c);
     UnitArgs A{};
     A.L = c.num_convs;
