@@ -148,15 +148,26 @@ __global__ __launch_bounds__(256) void cfconv_aggregate_kernel(int N, const int3
 // its AGW_ROWS / AGW_WAVES consecutive rows in batches of U edges and closes a row where the CSR says so (wave-uniform
 // control flow): no clamped tail batch per row.  Per row the edges are added in list order, product rounded, then added,
 // from 0: bit-identical to the form above and to a sequential scatter_add.
+// Measured at configs[4] size (tools/ab_agg.py, interleaved child processes, three boxes of the pool, round 6): the
+// one-wave-per-row form 749 / 800 / 769 us per launch (0.73 / 0.68 / 0.71 of 8 TB/s), this form 677-713 us (0.77-0.81) --
+// 6.4 TB/s, the rate a plain copy reaches on this chip (MI355X_MICROARCH.md).  Shape of the workgroup: 16 rows x 16 waves
+// (one row per wave) 677 us, 16 x 8: 686, 32 x 8: 707, 64 x 16: 710; 8 edges in flight per wave 691 against 16: 707;
+// a second batch in flight (TSD_AGW_DB) and XCD-aware group orders (TSD_AGW_SWZ): no gain (716 vs 713, 701 vs 686).
 // ---------------------------------------------------------------------------------------------
 #ifndef TSD_AGW_ROWS
-#define TSD_AGW_ROWS 32
+#define TSD_AGW_ROWS 16
 #endif
 #ifndef TSD_AGW_WAVES
-#define TSD_AGW_WAVES 8
+#define TSD_AGW_WAVES 16
 #endif
 #ifndef TSD_AGW_U
-#define TSD_AGW_U 16
+#define TSD_AGW_U 8
+#endif
+#ifndef TSD_AGW_SWZ
+#define TSD_AGW_SWZ 0
+#endif
+#ifndef TSD_AGW_DB
+#define TSD_AGW_DB 0  // 1: two batches of U filter rows in flight per wave (double buffer)
 #endif
 #ifndef TSD_AGW_MIN_ROWS
 #define TSD_AGW_MIN_ROWS 16384  // rows of a launch from which the windowed form runs (0: never); below, one wave per row
@@ -196,8 +207,7 @@ __device__ __forceinline__ void agw_wave(const int* __restrict__ rp /* LDS: row_
         const int ee = eb + min(lane, cnt - 1);
         const int jv = dst[ee] - (XL ? lo : 0);
         const int wv = umap ? umap[ee] : ee;
-        for (int k = 0; k < cnt; k += U) {
-            vrow w[U], x[XL ? 1 : U];
+        auto issue = [&](vrow (&w)[U], vrow (&x)[XL ? 1 : U], int k) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int kk = min(k + u, cnt - 1);
@@ -208,8 +218,10 @@ __device__ __forceinline__ void agw_wave(const int* __restrict__ rp /* LDS: row_
                     x[u] = *reinterpret_cast<const vrow*>(x1 + (size_t)j * H + lane * V);
                 }
             }
-            // (the x rows of four edges are read from LDS together, ahead of their use: a ds_read per edge right before its
-            // multiply would expose the LDS latency once per edge -- the row-closing branches keep the compiler from hoisting)
+        };
+        // (the x rows of four edges are read from LDS together, ahead of their use: a ds_read per edge right before its
+        // multiply would expose the LDS latency once per edge -- the row-closing branches keep the compiler from hoisting)
+        auto consume = [&](vrow (&w)[U], vrow (&x)[XL ? 1 : U], int k) {
 #pragma unroll
             for (int u0 = 0; u0 < U; u0 += 4) {
                 vrow xg[4];
@@ -233,6 +245,24 @@ __device__ __forceinline__ void agw_wave(const int* __restrict__ rp /* LDS: row_
                     }
                 }
             }
+        };
+        if constexpr (XL && TSD_AGW_DB) {
+            // two batches in flight: batch k + U is requested before batch k is summed (the stream never drains inside a
+            // 64-edge chunk)
+            vrow wa[U], wb[U], xd[1];
+            issue(wa, xd, 0);
+            for (int k = 0; k < cnt; k += 2 * U) {
+                if (k + U < cnt) issue(wb, xd, k + U);
+                consume(wa, xd, k);
+                if (k + 2 * U < cnt) issue(wa, xd, k + 2 * U);
+                if (k + U < cnt) consume(wb, xd, k + U);
+            }
+        } else {
+            for (int k = 0; k < cnt; k += U) {
+                vrow w[U], x[XL ? 1 : U];
+                issue(w, x, k);
+                consume(w, x, k);
+            }
         }
     }
 }
@@ -250,7 +280,18 @@ __global__ __launch_bounds__(64 * AGW_WAVES) void cfconv_aggregate_win_kernel(in
     int* rp = reinterpret_cast<int*>(agw_smem + (size_t)AGW_WIN * H);
     int* red = rp + AGW_ROWS + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r0 = blockIdx.x * AGW_ROWS, r1 = min(N, r0 + AGW_ROWS);
+    // Workgroup -> row group.  Workgroups are dealt round-robin to the 8 XCDs; TSD_AGW_SWZ = 1 (variant builds) sends runs of
+    // AGW_WIN / AGW_ROWS consecutive groups (the destination rows of one 64-atom graph: the same x1 window) to ONE XCD.
+    int grp = blockIdx.x;
+    if (TSD_AGW_SWZ) {
+        constexpr int RUN = AGW_WIN / AGW_ROWS;
+        const int full = (int)gridDim.x / (8 * RUN) * (8 * RUN);
+        if (grp < full) {
+            const int x = grp & 7, r = grp >> 3;
+            grp = ((r / RUN) * 8 + x) * RUN + r % RUN;
+        }
+    }
+    const int r0 = grp * AGW_ROWS, r1 = min(N, r0 + AGW_ROWS);
     if (tid <= r1 - r0) rp[tid] = row_ptr[r0 + tid];
     __syncthreads();
     const int e_lo = rp[0], e_hi = rp[r1 - r0];
