@@ -34,9 +34,16 @@ def train_run(mode, steps, graphs, every, dev, cfg=None, lr=5e-4, n_batches=8, s
     from tsdiff_amd.options import OPTIONS
     cfg = cfg or synth.DEFAULT_MODEL_CONFIG
     old = (OPTIONS.train, OPTIONS.train_gemm)
-    OPTIONS.train, OPTIONS.train_gemm = ("ops", "f32") if mode == "ops" else ("fused", mode)
+    pert = int(mode[4:]) if mode.startswith("f32p") else 0  # f32p<k>: the fp32 step from a 1-ulp-perturbed initialisation
+    OPTIONS.train, OPTIONS.train_gemm = ("ops", "f32") if mode == "ops" else ("fused", "f32" if pert else mode)
     try:
         model = bench.make_models(cfg, [0], dev)[0]
+        if pert:
+            gp = torch.Generator(device="cpu").manual_seed(900 + pert)
+            with torch.no_grad():
+                for _, p in sorted(model.named_parameters()):
+                    if p.requires_grad:
+                        p.mul_((1.0 + 1e-7 * torch.randn(p.shape, generator=gp)).to(p.device))
         model.train()
         batches = []
         for k in range(n_batches):
@@ -71,9 +78,11 @@ def train_run(mode, steps, graphs, every, dev, cfg=None, lr=5e-4, n_batches=8, s
         OPTIONS.train, OPTIONS.train_gemm = old
 
 
-def drift(steps, graphs, every, dev, cfg=None):
-    """rows [(step, loss_f32, loss_h2, loss_ops, d_h2, d_ops)], trips"""
-    res = {m: train_run(m, steps, graphs, every, dev, cfg) for m in ("f32", "h2", "ops")}
+def drift(steps, graphs, every, dev, cfg=None, perturbed=0):
+    """rows [(step, loss_f32, loss_h2, loss_ops, d_h2, d_ops)], trips, relative distance travelled, per-mode results.
+    `perturbed` > 0: that many extra fp32 trainings from initialisations perturbed by one ulp (modes f32p1 ..): how far the
+    TRAINING DYNAMICS carry a 1e-7 difference, whatever its source -- res[\"f32pK\"] and `perturbed_rows(res)`"""
+    res = {m: train_run(m, steps, graphs, every, dev, cfg) for m in ("f32", "h2", "ops") + tuple(f"f32p{k + 1}" for k in range(perturbed))}
     rows = []
     for s in sorted(res["f32"][1]):
         ref = res["f32"][1][s]
@@ -85,15 +94,27 @@ def drift(steps, graphs, every, dev, cfg=None):
     return rows, res["h2"][2], moved, res
 
 
+def perturbed_rows(res):
+    """{step: [|| theta_f32pK - theta_f32 || / || theta_f32 || for K = 1 ..]}"""
+    ks = sorted(m for m in res if m.startswith("f32p"))
+    out = {}
+    for s in sorted(res["f32"][1]):
+        ref = res["f32"][1][s]
+        out[s] = [float((res[m][1][s] - ref).norm()) / float(ref.norm()) for m in ks]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--graphs", type=int, default=200)
     ap.add_argument("--every", type=int, default=50)
-    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r05_train_drift.md"))
+    ap.add_argument("--perturbed", type=int, default=3)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r06_train_drift.md"))
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    rows, trips, moved, res = drift(a.steps, a.graphs, a.every, dev)
+    rows, trips, moved, res = drift(a.steps, a.graphs, a.every, dev, perturbed=a.perturbed)
+    pr = perturbed_rows(res)
     L = ["# Training drift of the split-f16 step against fp32 (tools/train_drift.py)", "",
          f"{a.steps} optimizer steps at batch {a.graphs} (Adam lr 5e-4, betas 0.95 / 0.999, clip 3000: configs/train_config.yml), "
          "8 synthetic batches rotating, the SAME batches / time steps / noise draws in every run, one initialisation "
@@ -101,9 +122,14 @@ def main():
          "op-by-op autograd form (other kernels, other summation order: the re-association noise floor).  Distances are "
          "|| theta_x - theta_f32 || / || theta_f32 || over all trainable parameters; the parameters themselves moved "
          f"{moved:.3e} (relative) from the initialisation over the run.  Split-f16 range trips: {trips}.", "",
-         "| step | loss f32 | loss h2 | loss ops | h2 vs f32 | ops vs f32 (noise floor) | ratio |", "|---:|---:|---:|---:|---:|---:|---:|"]
+         f"`f32p1..{a.perturbed}`: the SAME fp32 step from initialisations perturbed by one ulp (theta (1 + 1e-7 xi)): what the "
+         "training dynamics make of a 1e-7 difference.", "",
+         "| step | loss f32 | loss h2 | loss ops | h2 vs f32 | ops vs f32 (noise floor) | ratio | 1-ulp-perturbed fp32 runs vs f32 | h2 / largest perturbed |",
+         "|---:|---:|---:|---:|---:|---:|---:|---|---:|"]
     for s, lf, lh, lo, dh, do in rows:
-        L.append(f"| {s} | {lf:.6g} | {lh:.6g} | {lo:.6g} | {dh:.3e} | {do:.3e} | {dh / max(do, 1e-300):.2f} |")
+        pp = pr.get(s, [])
+        L.append(f"| {s} | {lf:.6g} | {lh:.6g} | {lo:.6g} | {dh:.3e} | {do:.3e} | {dh / max(do, 1e-300):.2f} | "
+                 + " ".join(f"{x:.3e}" for x in pp) + f" | {dh / max(max(pp), 1e-300) if pp and max(pp) > 0 else 0:.2f} |")
     lf, lh, lo = res["f32"][0], res["h2"][0], res["ops"][0]
     import numpy as np
     rel = lambda x, y: float(np.max(np.abs(np.array(x) - np.array(y)) / np.maximum(np.abs(np.array(y)), 1e-30)))
