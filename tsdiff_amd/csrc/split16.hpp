@@ -231,6 +231,9 @@ __device__ __forceinline__ void hgemm_ring_start(HRing<CB, R>& r, const float* _
     r.base = uniform_ptr(Bp16);
     r.voff = (unsigned)(((lane >> 5) * nout + col0 + (lane & 31)) * 16);
     r.step_bytes = 64 * nout;   // 2 planes x 2 halves x nout x 16 B
+#ifdef TSD_RING_WFAKE  // (timing experiment, WRONG results: every k-step re-reads the first one -- the weights come from L1.
+    r.step_bytes = 0;      //  The bound on what ANY weight-stationary scheme could buy; profiles/r06_weight_stationary_bound.md)
+#endif
     r.plane_bytes = 32 * nout;
     r.cb_bytes = 32 * 16;
     constexpr int KS = K / 16;
@@ -318,6 +321,9 @@ __device__ __forceinline__ void hgemm16_ring_start(HRing<CB, R>& r, const float*
     r.base = uniform_ptr(Bp16);
     r.voff = (unsigned)((q >> 1) * 64 * nout + ((q & 1) * nout + col0 + (lane & 15)) * 16);
     r.step_bytes = 128 * nout;  // two 16-k steps
+#ifdef TSD_RING_WFAKE
+    r.step_bytes = 0;
+#endif
     r.plane_bytes = 32 * nout;
     r.cb_bytes = 16 * 16;
     constexpr int KS = K / 32;
