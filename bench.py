@@ -93,8 +93,11 @@ def parse():
                     help="train workload only: the next batch's topology is built inside its get_loss (the default "
                          "builds it on a side stream during the current step, model.prefetch_batch)")
     ap.add_argument("--single-range-reduce", action="store_true",
-                    help="train workload only: ONE all-reduce of the flat gradient behind the backward pass instead of three "
-                         "ranges with the interaction blocks' 83 %% early on a side stream (A/B under torch.distributed.run)")
+                    help="train workload only: ONE all-reduce of the flat gradient behind the backward pass (the default since "
+                         "round 6: tsdiff_amd.options dp_overlap)")
+    ap.add_argument("--three-range-reduce", action="store_true",
+                    help="train workload only: three ranges with the interaction blocks' 83 %% all-reduced early on a side "
+                         "stream (A/B under torch.distributed.run; OPTIONS.dp_overlap)")
     ap.add_argument("--reuse-batch", action="store_true",
                     help="train workload only: ONE batch for every step with its topology cached (A/B; the default "
                          "rotates 8 batches and rebuilds the topology every step like a real data loader)")
@@ -518,7 +521,7 @@ def pmc_traffic(name_prefix, fname):
 # ---------------------------------------------------------------------------------------------------
 # training step (BASELINE configs[3])
 # ---------------------------------------------------------------------------------------------------
-def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist, prefetch=True, overlap=True):
+def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist, prefetch=True, overlap=None):
     """one training step of configs/train_config.yml per iteration: loss (get_loss), backward, RCCL gradient
     all-reduce, clip_grad_norm_, Adam.  Returns (seconds, last mean loss, atoms per batch, executed flops per step)."""
     from tsdiff_amd import synth
@@ -587,7 +590,8 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist, prefet
 
 def bench_train_main(args, model, dev, rank, world, dist):
     dt, last, N, flops = run_train(model, args.graphs, args.steps, args.warmup, args.reuse_batch, dev, rank, dist,
-                                   prefetch=not args.no_prefetch, overlap=not args.single_range_reduce)
+                                   prefetch=not args.no_prefetch,
+                                   overlap=True if args.three_range_reduce else (False if args.single_range_reduce else None))
     tmax = torch.tensor([dt], device=dev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -605,8 +609,8 @@ def bench_train_main(args, model, dev, rank, world, dist):
                        ("rebuilt every step inside get_loss" if args.no_prefetch else
                         "rebuilt every step, on a side stream during the previous step (prefetch_batch)"),
                        "parallelism": f"graph-batch data parallel over {world} GPU(s), RCCL all-reduce of the flat fp32 "
-                                      "gradient per step: " + ("one range behind the backward pass" if args.single_range_reduce
-                                                               else "three ranges, the interaction blocks' 83 % early on a side stream"),
+                                      "gradient per step: " + ("three ranges, the interaction blocks' 83 % early on a side stream"
+                                                               if args.three_range_reduce else "one range behind the backward pass"),
                        "reduce_path": getattr(model, "_last_reduce", None)},
             "roofline": train_roofline(tf, flops),
             "final_loss": last}))

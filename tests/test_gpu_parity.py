@@ -1169,7 +1169,8 @@ def test_fused_training_context_is_single_use_and_detects_overwrites(dev):
         l3.mean().backward()
 
 
-def test_dp_backward_flat_gradient_path_on_the_real_model(dev):
+@pytest.mark.parametrize("overlap", [None, True])
+def test_dp_backward_flat_gradient_path_on_the_real_model(overlap, dev):
     """BASELINE configs[3] data parallelism without a second GPU: dp_backward on the REAL model with a reducer that
     emulates a second rank holding the same shard (x2).  The fused step's gradients are views of one flat buffer,
     which is reduced in place: every p.grad doubles, the loss normaliser counts both shards, clip_grad_norm_ sees
@@ -1194,12 +1195,16 @@ def test_dp_backward_flat_gradient_path_on_the_real_model(dev):
         calls.append(t.numel())
         t.mul_(2.0)
     loss = model.get_loss(*args, **kw)
-    mean = dp_backward(model, loss, reduce_fn=twice)
+    mean = dp_backward(model, loss, reduce_fn=twice, overlap=overlap)
     n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
-    # 2 scalars, then the ONE flat buffer in three ranges: the interaction blocks' gradients early (beside the rest of the
-    # backward pass, on a side stream), then head and tail
-    assert model._last_reduce == "flat-in-place, blocks early" and calls[0] == 2 and len(calls) == 4
-    assert sum(calls[1:]) == n_params and calls[1] == max(calls[1:])
+    if overlap:
+        # 2 scalars, then the ONE flat buffer in three ranges: the interaction blocks' gradients early (beside the rest of
+        # the backward pass, on a side stream), then head and tail
+        assert model._last_reduce == "flat-in-place, blocks early" and calls[0] == 2 and len(calls) == 4
+        assert sum(calls[1:]) == n_params and calls[1] == max(calls[1:])
+    else:
+        # the default since round 6 (OPTIONS.dp_overlap off): 2 scalars, then ONE all-reduce of the flat buffer
+        assert model._last_reduce == "flat-in-place" and calls == [2, n_params]
     assert abs(float(mean) - float(loss.mean())) < 1e-6 * abs(float(loss.mean()))
     # sum over "two ranks" of d(sum loss_r / 2N)/dp = d(mean loss)/dp: identical to the single-process gradient
     for k, p in model.named_parameters():

@@ -61,7 +61,7 @@ def _all_reduce_sum(t, group=None):
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
-def dp_backward(model, loss_nodes, group=None, reduce_fn=None, always_reduce=False, overlap=True):
+def dp_backward(model, loss_nodes, group=None, reduce_fn=None, always_reduce=False, overlap=None):
     """Backward of the reference's `loss.mean()` (train.py:140-143) over the GLOBAL batch.
 
     `loss_nodes` is this rank's (N_r, 1) per-node loss.  The reference averages over all nodes of the
@@ -82,7 +82,17 @@ def dp_backward(model, loss_nodes, group=None, reduce_fn=None, always_reduce=Fal
     right there on a side stream and runs beside the rest of the backward pass (the embedding's backward chain, the
     node-embedding gradients); the two remaining ranges (head and tail of the vector) are reduced when the backward has
     finished.  Three collectives per step in a fixed order on every rank.  `overlap=False`: ONE all-reduce of the whole
-    flat gradient behind the backward pass (the form of rounds 1-3; A/B: `bench.py --workload train --single-range-reduce`)."""
+    flat gradient behind the backward pass (the form of rounds 1-3; A/B: `bench.py --workload train --single-range-reduce`).
+    `overlap=None` (default): OPTIONS.dp_overlap, which is OFF -- the three-range form costs ~0.14 ms of HOST time per
+    step (an event, a side stream, three collective calls: profiles/r05_bench_train_torchrun_*.json, 2.28 vs 2.13 ms on
+    one rank) and hides at most the blocks' 83 % of an 11-MB ring all-reduce (~0.11 of ~0.13 ms on 8 ranks over xGMI,
+    DESIGN.md section 6); while the step is as long as its host side (2.0 ms of launches for 2.0 ms of kernels) that is
+    a net loss on any world size.  It pays once the host runs ahead of the GPU by more than those 0.14 ms per step, or
+    on fabrics where the all-reduce is several times slower than xGMI (multi-node): opt in with OPTIONS.dp_overlap /
+    TSDIFF_DP_OVERLAP=1 / overlap=True.  No measured multi-rank number exists yet (no N > 1 box has run this code)."""
+    if overlap is None:
+        from .options import OPTIONS
+        overlap = bool(OPTIONS.dp_overlap)
     distributed = reduce_fn is not None or (dist.is_initialized() and (always_reduce or dist.get_world_size(group) > 1))
     reduce = reduce_fn if reduce_fn is not None else (lambda t: _all_reduce_sum(t, group))
     # (new_full is a fill kernel: torch.tensor(x, device=cuda) would be a synchronous host-to-device copy, i.e.
