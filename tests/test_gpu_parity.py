@@ -18,6 +18,7 @@ from tests.util import assert_close, batch_inputs, load_golden
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-5
+ELEM_TOL = 1e-4  # per-element relative error of every entry above 1 % of the tensor's scale (against the fp32 reference)
 
 
 @pytest.fixture(scope="module")
@@ -73,7 +74,7 @@ def test_forward_vs_reference_golden(name, dev):
     assert edge_inv.shape == (d["edge_index"].shape[1], 1) and el.shape == edge_inv.shape
     assert np.array_equal(ei.cpu().numpy(), d["edge_index"])            # index work: bit exact
     assert_close(el.cpu().numpy(), d["edge_length"], 1e-6, "edge_length")
-    assert_close(edge_inv.cpu().numpy(), d["edge_inv"], RTOL, "edge_inv")
+    assert_close(edge_inv.cpu().numpy(), d["edge_inv"], RTOL, "edge_inv", elem_tol=ELEM_TOL)
     # graph extension of both orders, with types
     db = model.device_batch(g["atom_type"], g["r_feat"], g["p_feat"], g["bond_index"], g["bond_type"], g["batch"])
     eie, _, tre, tpe = db.edges_to_torch("enc")
@@ -209,7 +210,7 @@ def test_forward_vs_oracle_seeded_batch(dev):
     model = make_model(cfg, 3, dev)
     edge_inv, ei, el = run_forward(model, g, dev)
     assert torch.equal(ei.cpu(), o_ei)
-    assert_close(edge_inv.cpu().numpy(), o_inv.numpy(), RTOL, "edge_inv")
+    assert_close(edge_inv.cpu().numpy(), o_inv.numpy(), RTOL, "edge_inv", elem_tol=ELEM_TOL)
     # determinism: a second evaluation is bit-identical (no atomics on the network path)
     edge_inv2, _, _ = run_forward(model, g, dev)
     assert torch.equal(edge_inv, edge_inv2)
@@ -564,7 +565,7 @@ def test_full_size_properties(dev):
                                   t["p_feat"], t["pos"] * 3.0, t["bond_index"], t["bond_type"],
                                   b["num_nodes_per_graph"])
     assert torch.equal(ei.cpu(), o_ei)
-    assert_close(edge_inv.cpu().numpy(), o_inv.numpy(), RTOL, "edge_inv at batch 100")
+    assert_close(edge_inv.cpu().numpy(), o_inv.numpy(), RTOL, "edge_inv at batch 100", elem_tol=ELEM_TOL)
     N = g["pos"].shape[0]
     assert torch.isfinite(edge_inv).all()
     # sorted row-major, no self loops, intra-graph only
@@ -1013,7 +1014,7 @@ def test_config_c5_shape_vs_oracle(dev):
                                   t["p_feat"], t["pos"], t["bond_index"], t["bond_type"], b["num_nodes_per_graph"])
     assert torch.equal(ei.cpu(), o_ei)
     assert_close(el.cpu().numpy(), o_el.numpy(), 1e-6, "edge_length (C5 shape)")
-    assert_close(edge_inv.cpu().numpy(), o_inv.numpy(), RTOL, "edge_inv (C5 shape)")
+    assert_close(edge_inv.cpu().numpy(), o_inv.numpy(), RTOL, "edge_inv (C5 shape)", elem_tol=ELEM_TOL)
     db = model.device_batch(g["atom_type"], g["r_feat"], g["p_feat"], g["bond_index"], g["bond_type"], g["batch"])
     _, _, tr, tp = db.edges_to_torch("enc")
     o_ei4, o_tr, o_tp = O.extend_graph(t["pos"], t["bond_index"], t["bond_type"], b["num_nodes_per_graph"],
@@ -1106,7 +1107,7 @@ def test_ensemble_of_8_full_model_batch100_vs_oracle(dev):
     o_inv, o_ei, _ = O.ensemble_forward(sds, cfg, t["atom_type"], t["r_feat"], t["p_feat"], t["pos"], t["bond_index"],
                                         t["bond_type"], b["num_nodes_per_graph"])
     assert torch.equal(ei.cpu(), o_ei)
-    assert_close(edge_inv.cpu().numpy(), o_inv.numpy(), RTOL, "ensemble-of-8 mean edge_inv")
+    assert_close(edge_inv.cpu().numpy(), o_inv.numpy(), RTOL, "ensemble-of-8 mean edge_inv", elem_tol=ELEM_TOL)
     # each member alone equals its slice of the batched evaluation, bit for bit
     db = ens._bound_batch(g["atom_type"], g["r_feat"], g["p_feat"], g["bond_index"], g["bond_type"], g["batch"])
     per_u = db.edge_inv_u.clone()
