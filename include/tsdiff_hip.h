@@ -328,7 +328,11 @@ typedef struct tsd_batch {
                                    `status` when an activation left the f16 range, tsd_train_backward2 then returns
                                    TSD_ERR_RANGE.  Pass the same bit to both calls of a step; bit 6 (with bit 5): the
                                    backward keeps its small gradient launches (embedding tables, narrow layers) on the
-                                   caller's stream instead of the library's side stream (A/B switch, same results) */
+                                   caller's stream instead of the library's side stream (A/B switch, same results);
+                                   bit 7 (tsd_train_forward, 0.7): the edge lists of `geo` are current for the call's `pos`
+                                   (tsd_geometry_build ran on them, e.g. ahead on a side stream) and counts_host[0, 1, 3]
+                                   (+ [2]: topology status) hold their counts: the call neither rebuilds them nor waits for
+                                   the device */
     tsd_typed_tiles enc_tiles, diff_tiles;  /* static type-sorted embedding tiles, or num_tiles = 0: generic embedding */
     const float* bucket_weights;            /* [M][(enc + diff buckets) * (H*H + H)] (tsd_bucket_weights_build) or NULL */
     /* ---- appended in 0.4: the split-f16 inference forward (see tsd_pack_weights16) ---- */

@@ -258,3 +258,71 @@ def test_split_f16_forward_on_weights_the_package_trained_itself(dev, monkeypatc
     assert torch.equal(ei.cpu(), o_ei)
     assert_close(inv.cpu().numpy(), o32.numpy(), RTOL, "edge_inv on trained weights vs the fp32 oracle")
     assert _db(model).gemm_mode() == "h2"
+
+
+def test_batch_prefetched_with_its_positions_trains_bit_identically(dev):
+    """prefetch_batch(pos=...) (round 6): the next step's random draws, forward diffusion and perturbed-geometry edge lists
+    are built ahead on the side stream and the training step's forward starts without its host wait for the edge counts
+    (tsd_batch.reserved bit 7).  The draws are the same torch calls in the same order, so a loop that prefetches batch
+    k + 1 behind step k is BIT-IDENTICAL -- loss and every parameter after four optimizer steps -- to the loop that does not
+    prefetch at all and to the one that prefetches the topology only; a get_loss with another `pos` tensor ignores the stash"""
+    from types import SimpleNamespace
+    from tsdiff_amd import optim, synth
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    G = 24
+    batches = [to_dev({k2: torch.from_numpy(v) for k2, v in synth.wb97xd3_like_batch(G, seed=950 + k).items()
+                       if isinstance(v, np.ndarray)}, dev) for k in range(3)]
+
+    def topo(g):
+        return (g["atom_type"], g["r_feat"], g["p_feat"], g["bond_index"], g["bond_type"], g["batch"], g["num_nodes_per_graph"])
+
+    def run(mode):
+        model = make_model(cfg, 0, dev)
+        model.train()
+        opt = optim.get_optimizer(SimpleNamespace(type="adam", lr=5e-4, weight_decay=0.0, beta1=0.95, beta2=0.999), model)
+        torch.manual_seed(123)
+        torch.cuda.manual_seed_all(123)
+        losses, used = [], 0
+        for k in range(4):
+            g = batches[k % 3]
+            opt.zero_grad()
+            hit = model._batches and getattr(model._batches[0][2], "train_stash", None) is not None
+            loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
+                                  g["batch"], g["num_nodes_per_graph"], G)
+            used += int(bool(hit) and model._batches[0][2].train_stash is None)  # (consumed by the fused step's forward)
+            loss.mean().backward()
+            optim.clip_grad_norm_(model.parameters(), 3000.0)
+            opt.step()
+            losses.append(loss.detach().clone())
+            model._batches.clear()
+            nxt = batches[(k + 1) % 3]
+            if mode == "topology":
+                model.prefetch_batch(*topo(nxt))
+            elif mode == "pos":
+                db = model.prefetch_batch(*topo(nxt), pos=nxt["pos"], num_graphs=G)
+                assert db.train_stash is not None
+        torch.cuda.synchronize()
+        flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        return losses, flat, used
+    ref_l, ref_p, _ = run("none")
+    for mode in ("topology", "pos"):
+        l, p, used = run(mode)
+        for a, b in zip(l, ref_l):
+            assert torch.equal(a, b), mode
+        assert torch.equal(p, ref_p), mode
+        assert used == (3 if mode == "pos" else 0), f"{mode}: the stash was consumed {used} times"
+    # another positions tensor than the one the batch was prefetched with: the stash is ignored (and dropped), the result is
+    # what a fresh get_loss gives
+    model = make_model(cfg, 0, dev)
+    model.train()
+    g = batches[0]
+    model.prefetch_batch(*topo(g), pos=g["pos"], num_graphs=G)
+    other = (g["pos"] * 1.01).contiguous()
+    torch.manual_seed(5); torch.cuda.manual_seed_all(5)
+    la = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], other, g["bond_index"], g["bond_type"], g["batch"],
+                        g["num_nodes_per_graph"], G)
+    model._batches.clear()
+    torch.manual_seed(5); torch.cuda.manual_seed_all(5)
+    lb = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], other, g["bond_index"], g["bond_type"], g["batch"],
+                        g["num_nodes_per_graph"], G)
+    assert torch.equal(la, lb)

@@ -778,6 +778,11 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
     TSD_REQUIRE(cfg && batch && raw && atom_type && r_feat && p_feat && pos0 && pos && a_graph && workspace && loss &&
                     counts_host, "null pointer");
     const tsd_geometry& g = batch->geo;
+    // tsd_batch.reserved bit 7 (round 6): the caller built the edge lists of `pos` ahead (tsd_geometry_build on these
+    // buffers, e.g. on a side stream beside the previous step -- CondenseEncoderEpsNetwork.prefetch_batch(pos=...)) and
+    // hands the counts over in counts_host[0, 1, 3] (+ the topology status word in [2]): no build, and no host wait in
+    // this call -- the forward's launches queue up behind the previous step's backward pass
+    if (!(batch->reserved & 128)) {
     TSD_TRY(launch_geometry(*cfg, batch->num_nodes, batch->num_graphs, batch->num_pairs, pos, batch->graph_ptr,
                             batch->node_graph, batch->pair_ptr, batch->pair_code, g, st));
     // the edge counts size the launches of the backward pass: the one host sync of the step.  They land in a pinned
@@ -792,6 +797,7 @@ int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const fl
     if (topo_status) TSD_HIP(hipMemcpyAsync(&pinned[2], topo_status, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     TSD_HIP(hipStreamSynchronize(st));
     for (int k = 0; k < 4; ++k) counts_host[k] = pinned[k];
+    }
     if (counts_host[2] & (TSD_STATUS_BAD_BOND | TSD_STATUS_ASYMMETRIC)) return TSD_OK;  // the caller raises
     Ctx x;
     TSD_TRY(make_ctx(x, cfg, batch, raw, workspace, workspace_floats, counts_host, st));

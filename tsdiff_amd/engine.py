@@ -429,6 +429,25 @@ class DeviceBatch:
                                      ptr(self.node_graph), ptr(self.pair_ptr), ptr(self.pair_code),
                                      self.geo_struct(), stream_ptr()))
 
+    def build_geometry_async(self, pos):
+        """the edge lists of `pos` on the current stream WITHOUT the host read of the topology status that geometry()
+        makes first (prefetch_batch: the status word travels with the counts, counts_to_host_async)"""
+        lib = _lib.load()
+        self.geo_gen += 1
+        check(lib.tsd_geometry_build(C.byref(self.cfg), self.N, self.G, self.P, ptr(pos), ptr(self.graph_ptr),
+                                     ptr(self.node_graph), ptr(self.pair_ptr), ptr(self.pair_code),
+                                     self.geo_struct(), stream_ptr()))
+
+    def counts_to_host_async(self):
+        """[enc_u count, out_u count, topology status, diff_u count] -> a pinned host tensor, copied on the current stream
+        (no host wait here; the caller records an event behind it) -- the layout of tsd_train_forward's counts_host"""
+        dev4 = torch.stack([self.enc_u.count[0], self.out_u.count[0], self.status[0].to(self.enc_u.count.dtype),
+                            self.diff_u.count[0]])
+        host = torch.empty(4, dtype=dev4.dtype, pin_memory=True)
+        host.copy_(dev4, non_blocking=True)
+        self._counts_dev = dev4  # (kept until the copy has run)
+        return host
+
     def forward(self, pos):
         """geometry + M forwards; results stay on the device (self.edge_inv_u[m, :E_out/2])."""
         lib = _lib.load()

@@ -224,8 +224,42 @@ class CondenseEncoderEpsNetwork(nn.Module):
         self._batches = [(key, ts, db)] + self._batches[:1]
         return db
 
+    def _draw_diffusion(self, pos, node2graph, num_graphs, _time_step=None, _pos_noise=None):
+        """the random draws of get_loss (condensenc.py:275-289): symmetric time steps, Gaussian noise -- in this order"""
+        dev = pos.device
+        t0 = engine.cfg_get(self.config, "t0", 0)
+        t1 = engine.cfg_get(self.config, "t1", self.num_timesteps)
+        if _time_step is None:
+            sz = num_graphs // 2 + 1
+            half_1 = torch.randint(t0, t1, size=(sz,), device=dev)
+            half_2 = t0 + t1 - 1 - half_1
+            time_step = torch.cat([half_1, half_2], dim=0)[:num_graphs]
+        else:
+            time_step = _time_step
+        pos_noise = torch.randn(size=pos.size(), device=dev) if _pos_noise is None else _pos_noise
+        return time_step, pos_noise
+
+    def _diffuse_fused(self, pos, pos_noise, time_step, node2graph, num_graphs):
+        """the forward diffusion as one launch (tsd_diffuse_positions: the same operations in the same order)
+        -> (pos, pos_perturbed, a per graph), contiguous fp32"""
+        from .. import _lib
+        from .._lib import check, ptr, stream_ptr
+        dev = pos.device
+        alphas = self.alphas.detach()
+        pos_c, noise_c = pos.detach().contiguous(), pos_noise.to(dev).contiguous()
+        ts = time_step.to(device=dev, dtype=torch.int64).contiguous()
+        n2g = node2graph.to(device=dev, dtype=torch.int64).contiguous()
+        if ts.shape[0] != num_graphs or n2g.shape[0] != pos_c.shape[0] or noise_c.shape != pos_c.shape:
+            raise ValueError("get_loss: time_step / batch / pos_noise do not match num_graphs / pos")
+        pos_perturbed = torch.empty_like(pos_c)
+        a = torch.empty(ts.shape[0], dtype=torch.float32, device=dev)
+        check(_lib.load().tsd_diffuse_positions(pos_c.shape[0], ts.shape[0], alphas.shape[0], ptr(alphas), ptr(ts),
+                                                ptr(n2g), ptr(pos_c), ptr(noise_c), ptr(pos_perturbed), ptr(a),
+                                                stream_ptr()))
+        return pos_perturbed, a
+
     def prefetch_batch(self, atom_type, r_feat, p_feat, bond_index, bond_type, batch, num_nodes_per_graph=None,
-                       wait_for=None):
+                       wait_for=None, pos=None, num_graphs=None):
         """Build the position-independent state of the NEXT training batch (graph offsets, k-hop pair codes, buffers:
         what get_loss would build first) on a side stream, while the GPU is still busy with the current step -- the
         role of the reference's DataLoader workers (train.py:92-101), for the part of the batch that lives on the
@@ -235,7 +269,14 @@ class CondenseEncoderEpsNetwork(nn.Module):
         batch in the cache and orders its stream behind the build (an event wait on the device, no host sync).
         Optional: get_loss builds the batch itself when this was not called.
         The input tensors must be complete when this is called (a loader's finished copies); if they are still being
-        produced on some stream, pass that stream or an event recorded behind their producers as `wait_for`."""
+        produced on some stream, pass that stream or an event recorded behind their producers as `wait_for`.
+        `pos` (+ `num_graphs`; round 6): the batch's ground-truth positions.  The build then also makes get_loss's random
+        draws for this batch (the same torch calls in the same order: time steps, then noise -- so a loop that prefetches
+        batch k + 1 behind step k consumes the generator exactly as one that does not), diffuses the positions and builds
+        the perturbed geometry's edge lists, whose COUNTS travel to pinned host memory behind an event: get_loss(pos) on
+        this batch finds them there and the training step's forward starts without its host wait for the edge counts
+        (csrc/train_step.hip, tsd_batch.reserved bit 7).  get_loss with injected draws, another `pos` tensor, or under
+        no_grad ignores the stash and draws for itself."""
         dev = atom_type.device
         if dev.type != "cuda":
             return None
@@ -256,10 +297,25 @@ class CondenseEncoderEpsNetwork(nn.Module):
         with torch.cuda.stream(side):
             db = engine.DeviceBatch(self._cfg, atom_type, r_feat, p_feat, bond_index, bond_type, batch,
                                     num_nodes_per_graph, defer_status=True)
+            stash = None
+            if pos is not None and pos.is_cuda and pos.dtype == torch.float32 and OPTIONS.train != "ops" and \
+                    any(p.requires_grad for p in self.raw_params()):
+                G = int(num_graphs) if num_graphs is not None else db.G
+                time_step, pos_noise = self._draw_diffusion(pos, batch, G)
+                pos_perturbed, a = self._diffuse_fused(pos, pos_noise, time_step, batch, G)
+                db.build_geometry_async(pos_perturbed)
+                counts = db.counts_to_host_async()
+                stash = {"pos": (pos._cdata, pos._version), "pos_perturbed": pos_perturbed, "a": a, "counts": counts,
+                         "keep": (time_step, pos_noise)}
             ev = torch.cuda.Event()
             ev.record(side)
         for t in db.owned_tensors():  # allocated under the side stream, used (and eventually freed) under `main`
             t.record_stream(main)
+        if stash is not None:
+            for t in (stash["pos_perturbed"], stash["a"]) + stash["keep"]:
+                t.record_stream(main)
+            stash["event"] = ev
+        db.train_stash = stash
         db.ready_event = ev
         self._batches = [(key, ts, db)] + self._batches[:1]
         return db
@@ -300,37 +356,27 @@ class CondenseEncoderEpsNetwork(nn.Module):
         `_time_step` / `_pos_noise` inject the random draws (parity tests)."""
         node2graph = batch
         dev = pos.device
-        t0 = engine.cfg_get(self.config, "t0", 0)
-        t1 = engine.cfg_get(self.config, "t1", self.num_timesteps)
-        if _time_step is None:
-            sz = num_graphs // 2 + 1
-            half_1 = torch.randint(t0, t1, size=(sz,), device=dev)
-            half_2 = t0 + t1 - 1 - half_1
-            time_step = torch.cat([half_1, half_2], dim=0)[:num_graphs]
-        else:
-            time_step = _time_step
-        pos_noise = torch.randn(size=pos.size(), device=dev) if _pos_noise is None else _pos_noise
         training = torch.is_grad_enabled() and any(p.requires_grad for p in self.raw_params())
         fused = training and OPTIONS.train != "ops"
-        if fused and pos.is_cuda and pos.dtype == torch.float32 and pos_noise.dtype == torch.float32:
-            # the forward diffusion as one launch (tsd_diffuse_positions: the same operations in the same order)
-            from .. import _lib
-            from .._lib import check, ptr, stream_ptr
-            alphas = self.alphas.detach()
-            pos_c, noise_c = pos.detach().contiguous(), pos_noise.to(dev).contiguous()
-            ts = time_step.to(device=dev, dtype=torch.int64).contiguous()
-            n2g = node2graph.to(device=dev, dtype=torch.int64).contiguous()
-            if ts.shape[0] != num_graphs or n2g.shape[0] != pos_c.shape[0] or noise_c.shape != pos_c.shape:
-                raise ValueError("get_loss: time_step / batch / pos_noise do not match num_graphs / pos")
-            pos_perturbed = torch.empty_like(pos_c)
-            a = torch.empty(ts.shape[0], dtype=torch.float32, device=dev)
-            check(_lib.load().tsd_diffuse_positions(pos_c.shape[0], ts.shape[0], alphas.shape[0], ptr(alphas), ptr(ts),
-                                                    ptr(n2g), ptr(pos_c), ptr(noise_c), ptr(pos_perturbed), ptr(a),
-                                                    stream_ptr()))
+        # a batch prefetched WITH its positions (prefetch_batch(pos=...)) carries the draws, the diffused positions and the
+        # perturbed geometry's edge lists already: nothing to draw, nothing to wait for
+        stash = None
+        if fused and _time_step is None and _pos_noise is None and pos.is_cuda:
+            key = tuple((t._cdata, t._version) for t in (atom_type, r_feat, p_feat, bond_index, bond_type, batch))
+            for k, _, cand in self._batches:
+                if k == key and getattr(cand, "train_stash", None) is not None and \
+                        cand.train_stash["pos"] == (pos._cdata, pos._version):
+                    stash = cand.train_stash
+        if stash is not None:
+            pos_perturbed, a = stash["pos_perturbed"], stash["a"]
         else:
-            a = self.alphas.detach().index_select(0, time_step)
-            a_pos = a.index_select(0, node2graph).unsqueeze(-1)
-            pos_perturbed = (pos + pos_noise * (1.0 - a_pos).sqrt() / a_pos.sqrt()).contiguous()
+            time_step, pos_noise = self._draw_diffusion(pos, node2graph, num_graphs, _time_step, _pos_noise)
+            if fused and pos.is_cuda and pos.dtype == torch.float32 and pos_noise.dtype == torch.float32:
+                pos_perturbed, a = self._diffuse_fused(pos, pos_noise, time_step, node2graph, num_graphs)
+            else:
+                a = self.alphas.detach().index_select(0, time_step)
+                a_pos = a.index_select(0, node2graph).unsqueeze(-1)
+                pos_perturbed = (pos + pos_noise * (1.0 - a_pos).sqrt() / a_pos.sqrt()).contiguous()
         # (the fused step reads the topology status together with its edge counts: one host sync less per batch)
         db = self.device_batch(atom_type, r_feat, p_feat, bond_index, bond_type, batch, num_nodes_per_graph,
                                defer_status=fused)

@@ -518,6 +518,16 @@ class FusedTrainLoss(torch.autograd.Function):
         counts = (C.c_int32 * 4)()  # undirected edge counts of the two lists, topology status word, separately embedded out edges
         loss = torch.empty(db.N, 1, dtype=torch.float32, device=dev)
         pos0, pos_perturbed, a_graph = _c(pos0.float()), _c(pos_perturbed.float()), _c(a_graph.float())
+        # a batch prefetched with its positions (CondenseEncoderEpsNetwork.prefetch_batch(pos=...)): the perturbed geometry's
+        # edge lists were built ahead on the side stream and their counts are in pinned memory behind an event that fired
+        # long ago -- the library neither rebuilds them nor waits for the device (tsd_batch.reserved bit 7)
+        stash = getattr(db, "train_stash", None)
+        db.train_stash = None  # (one-shot: any other geometry build on this batch overwrites the lists)
+        if stash is not None and stash["pos_perturbed"] is pos_perturbed:
+            stash["event"].synchronize()
+            for k in range(4):
+                counts[k] = int(stash["counts"][k])
+            b.reserved |= 128
         check(lib.tsd_train_forward(C.byref(cfg), C.byref(b), ptr(raw), ptr(db.atom_type), ptr(db.r_feat),
                                     ptr(db.p_feat), ptr(pos0), ptr(pos_perturbed), ptr(a_graph), ptr(db.status),
                                     ptr(ws), ws.numel(), ptr(loss), counts, stream_ptr()))
