@@ -92,9 +92,9 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true",
                     help="train workload only: the next batch's topology is built inside its get_loss (the default "
                          "builds it on a side stream during the current step, model.prefetch_batch)")
-    ap.add_argument("--prefetch-topology-only", action="store_true",
-                    help="train workload only: prefetch the next batch's topology but not its draws / diffusion / edge lists "
-                         "(the form of rounds 3-5: the step's forward then waits on the host for the edge counts)")
+    ap.add_argument("--prefetch-pos", action="store_true",
+                    help="train workload only: prefetch the next batch WITH its positions (draws, diffusion and edge lists "
+                         "built ahead on the side stream: the step's forward does not wait on the host for the edge counts)")
     ap.add_argument("--single-range-reduce", action="store_true",
                     help="train workload only: ONE all-reduce of the flat gradient behind the backward pass (the default since "
                          "round 6: tsdiff_amd.options dp_overlap)")
@@ -566,10 +566,11 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist, prefet
             model._batches.clear()
             if prefetch:
                 nxt = batches[counter[0] % len(batches)]
-                # (with the positions: the next step's draws, diffusion and edge lists are built ahead too, and its
-                # forward starts without the host wait for the edge counts -- same generator consumption, same results)
-                model.prefetch_batch(*topo_args(nxt), pos=nxt["pos"] if prefetch == "pos" or prefetch is True else None,
-                                     num_graphs=graphs)
+                # (prefetch == "pos": the next step's draws, diffusion and edge lists are built ahead too and its forward
+                # starts without the host wait for the edge counts -- same generator consumption, same results; measured
+                # in-process against the topology-only form, tools/ab_train_prefetch.py: 1.95 vs 1.89 ms/step median,
+                # 1.90 vs 1.89 minimum -- the loop is as long as its host side, which the form does not shorten: opt-in)
+                model.prefetch_batch(*topo_args(nxt), pos=nxt["pos"] if prefetch == "pos" else None, num_graphs=graphs)
         return mean
     if not reuse_batch:
         model._batches.clear()
@@ -597,7 +598,7 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist, prefet
 
 def bench_train_main(args, model, dev, rank, world, dist):
     dt, last, N, flops = run_train(model, args.graphs, args.steps, args.warmup, args.reuse_batch, dev, rank, dist,
-                                   prefetch=False if args.no_prefetch else ("topology" if args.prefetch_topology_only else True),
+                                   prefetch=False if args.no_prefetch else ("pos" if args.prefetch_pos else True),
                                    overlap=True if args.three_range_reduce else (False if args.single_range_reduce else None))
     tmax = torch.tensor([dt], device=dev)
     if dist is not None:
@@ -614,9 +615,9 @@ def bench_train_main(args, model, dev, rank, world, dist):
             "config": {"workload": "configs[3] training step", "graphs_per_gpu": args.graphs, "atoms_per_gpu": N,
                        "batch_topology": "one batch reused" if args.reuse_batch else
                        ("rebuilt every step inside get_loss" if args.no_prefetch else
-                        ("rebuilt every step, on a side stream during the previous step (prefetch_batch)" if args.prefetch_topology_only
-                         else "topology, draws, diffusion and edge lists of the next step built on a side stream during the "
-                              "previous step (prefetch_batch(pos=...)): no host wait for the edge counts")),
+                        ("topology, draws, diffusion and edge lists of the next step built on a side stream during the "
+                         "previous step (prefetch_batch(pos=...)): no host wait for the edge counts" if args.prefetch_pos
+                         else "rebuilt every step, on a side stream during the previous step (prefetch_batch)")),
                        "parallelism": f"graph-batch data parallel over {world} GPU(s), RCCL all-reduce of the flat fp32 "
                                       "gradient per step: " + ("three ranges, the interaction blocks' 83 % early on a side stream"
                                                                if args.three_range_reduce else "one range behind the backward pass"),

@@ -539,6 +539,12 @@ int tsd_gine_aggregate(int32_t num_nodes, int64_t num_edges, int32_t H, int32_t 
 int tsd_diffuse_positions(int32_t num_nodes, int32_t num_graphs, int32_t num_timesteps, const float* alphas,
                           const int64_t* time_step, const int64_t* node_graph, const float* pos, const float* noise,
                           float* pos_perturbed /* [N,3] */, float* a_graph /* [G] */, void* stream);
+/* The four host words of tsd_train_forward's `counts_host` for edge lists built ahead (tsd_geometry_build on `geo`, e.g. on a
+ * side stream beside the previous step): [enc_u count, out_u count, *topo_status (or 0), diff_u count] written by one small
+ * kernel into PINNED, device-visible host memory `counts_pinned` [4] on `stream`.  Record an event behind the call and read
+ * the words when it has fired; hand them to tsd_train_forward with tsd_batch.reserved bit 7 (0.7). */
+int tsd_geometry_counts_async(tsd_geometry geo, const int32_t* topo_status, int32_t* counts_pinned /* [4], pinned host */,
+                              void* stream);
 size_t tsd_train_raw_floats(const tsd_model_cfg* cfg);
 size_t tsd_train_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs);
 int tsd_train_forward(const tsd_model_cfg* cfg, const tsd_batch* batch, const float* raw, const int64_t* atom_type,

@@ -189,6 +189,7 @@ SIGNATURES = {
     "tsd_gine_aggregate": (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_float, _P, _P, _P, _P, _P]),
     "tsd_gaussian_edge_encode": (C.c_int, [C.c_int64, C.c_int32, C.c_float, _P, _P, _P, _P, _P, _P]),
     "tsd_diffuse_positions": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "tsd_geometry_counts_async": (C.c_int, [Geometry, _P, _P, _P]),
     "tsd_train_raw_floats": (C.c_size_t, [_CFG]),
     "tsd_train_workspace_floats": (C.c_size_t, [_CFG, C.c_int32, C.c_int32]),
     "tsd_train_forward": (C.c_int, [_CFG, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P]),

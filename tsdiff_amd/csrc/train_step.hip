@@ -414,6 +414,19 @@ __global__ void diffuse_kernel(int N, int G, int T, const float* __restrict__ al
     for (int k = 0; k < 3; ++k) out[3 * i + k] = pos[3 * i + k] + (noise[3 * i + k] * s1) / s2;
 }
 
+// the four words tsd_train_forward needs on the host -- [enc_u count, out_u count, topology status, diff_u count] -- written
+// straight into pinned (device-visible) host memory: no staging copy, one launch
+__global__ void counts_to_host_kernel(const int32_t* __restrict__ a, const int32_t* __restrict__ b, const int32_t* __restrict__ st,
+                                      const int32_t* __restrict__ d, int32_t* __restrict__ host4) {
+    if (threadIdx.x == 0) {
+        host4[0] = *a;
+        host4[1] = *b;
+        host4[2] = st ? *st : 0;
+        host4[3] = *d;
+        __threadfence_system();
+    }
+}
+
 // ---- optimizer on the flat parameter / gradient vectors (reference train.py:144-145, utils/common.py:58-68) ----
 // |g|: fixed-order two-stage sum of squares (NORM_WG workgroups, then one), no atomics
 constexpr int NORM_WG = 1024;
@@ -766,6 +779,14 @@ int tsd_diffuse_positions(int32_t num_nodes, int32_t num_graphs, int32_t num_tim
     hipLaunchKernelGGL(diffuse_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, num_nodes, num_graphs,
                        num_timesteps, alphas, time_step, node_graph, pos, noise, pos_perturbed, a_graph);
     TSD_LAUNCH_CHECK("diffuse_positions");
+    return TSD_OK;
+}
+
+int tsd_geometry_counts_async(tsd_geometry geo, const int32_t* topo_status, int32_t* counts_pinned, void* stream) {
+    TSD_REQUIRE(geo.enc_u.count && geo.out_u.count && geo.diff_u.count && counts_pinned, "null pointer");
+    hipLaunchKernelGGL(counts_to_host_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, geo.enc_u.count, geo.out_u.count,
+                       topo_status, geo.diff_u.count, counts_pinned);
+    TSD_LAUNCH_CHECK("geometry_counts_async");
     return TSD_OK;
 }
 

@@ -438,14 +438,11 @@ class DeviceBatch:
                                      ptr(self.node_graph), ptr(self.pair_ptr), ptr(self.pair_code),
                                      self.geo_struct(), stream_ptr()))
 
-    def counts_to_host_async(self):
-        """[enc_u count, out_u count, topology status, diff_u count] -> a pinned host tensor, copied on the current stream
-        (no host wait here; the caller records an event behind it) -- the layout of tsd_train_forward's counts_host"""
-        dev4 = torch.stack([self.enc_u.count[0], self.out_u.count[0], self.status[0].to(self.enc_u.count.dtype),
-                            self.diff_u.count[0]])
-        host = torch.empty(4, dtype=dev4.dtype, pin_memory=True)
-        host.copy_(dev4, non_blocking=True)
-        self._counts_dev = dev4  # (kept until the copy has run)
+    def counts_to_host_async(self, host):
+        """[enc_u count, out_u count, topology status, diff_u count] -> the pinned host tensor `host` (int32 [4]), written by
+        one small kernel on the current stream (no host wait here; the caller records an event behind it) -- the layout of
+        tsd_train_forward's counts_host"""
+        check(_lib.load().tsd_geometry_counts_async(self.geo_struct(), ptr(self.status), ptr(host), stream_ptr()))
         return host
 
     def forward(self, pos):

@@ -304,7 +304,13 @@ class CondenseEncoderEpsNetwork(nn.Module):
                 time_step, pos_noise = self._draw_diffusion(pos, batch, G)
                 pos_perturbed, a = self._diffuse_fused(pos, pos_noise, time_step, batch, G)
                 db.build_geometry_async(pos_perturbed)
-                counts = db.counts_to_host_async()
+                # (pinned words: a ring of four on the model -- a pinned allocation per step would cost more than the wait it saves)
+                ring = getattr(self, "_counts_ring", None)
+                if ring is None:
+                    ring = self._counts_ring = [torch.empty(4, dtype=torch.int32).pin_memory() for _ in range(4)]
+                    self._counts_next = 0
+                counts = db.counts_to_host_async(ring[self._counts_next % 4])
+                self._counts_next += 1
                 stash = {"pos": (pos._cdata, pos._version), "pos_perturbed": pos_perturbed, "a": a, "counts": counts,
                          "keep": (time_step, pos_noise)}
             ev = torch.cuda.Event()
