@@ -463,7 +463,7 @@ using namespace tsd;
 
 extern "C" {
 
-const char* tsd_version(void) { return "tsdiff_hip 0.6 (gfx950; fp32 MFMA, split-f16 MFMA inference forward and training step, fused per-unit encoder, transposed-accumulator tile GEMMs, ensembles in the one-launch forward)"; }
+const char* tsd_version(void) { return "tsdiff_hip 0.7 (gfx950; fp32 MFMA, split-f16 MFMA inference forward and training step, fused per-unit encoder, transposed-accumulator tile GEMMs, ensembles in the one-launch forward, windowed CFConv aggregation)"; }
 const char* tsd_last_error(void) { return g_err; }
 
 size_t tsd_raw_weight_floats(const tsd_model_cfg* cfg) {
