@@ -242,7 +242,10 @@ def load():
             f"{LIB_PATH} not found: the HIP extension is not built (run `python __graft_entry__.py` "
             "or `make -C tsdiff_amd/csrc`). There is no CPU fallback for the product path.")
     lib = C.CDLL(LIB_PATH)
+    variant = os.path.abspath(LIB_PATH) != os.path.join(_HERE, "libtsdiff_hip.so")
     for name, (res, args) in SIGNATURES.items():
+        if variant and not hasattr(lib, name):
+            continue  # (tools/ab_*.py with an OLDER library, e.g. last round's for a same-box A/B: entries it lacks stay unbound)
         fn = getattr(lib, name)  # AttributeError if the .so is stale -> loud
         fn.restype = res
         fn.argtypes = args
