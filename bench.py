@@ -92,6 +92,9 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true",
                     help="train workload only: the next batch's topology is built inside its get_loss (the default "
                          "builds it on a side stream during the current step, model.prefetch_batch)")
+    ap.add_argument("--prefetch-late", action="store_true",
+                    help="train workload only: build the next batch's topology behind opt.step() (rounds 3-5) instead of "
+                         "right behind get_loss")
     ap.add_argument("--prefetch-pos", action="store_true",
                     help="train workload only: prefetch the next batch WITH its positions (draws, diffusion and edge lists "
                          "built ahead on the side stream: the step's forward does not wait on the host for the edge counts)")
@@ -557,14 +560,25 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist, prefet
         loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
                               g["batch"], g["num_nodes_per_graph"], graphs)
         used[0] = model._batches[0][2]
+        early = prefetch and prefetch != "late" and not reuse_batch
+        if early:
+            # The next batch's topology is built on a side stream (a loader's prefetch) RIGHT BEHIND get_loss: the host side
+            # of the build (0.3-0.5 ms of Python and a dozen launches) then runs while the GPU is in this step's forward,
+            # i.e. inside the time the backward call would otherwise spend waiting for the forward's range flag (round 6;
+            # behind opt.step(), as in rounds 3-5, the same host work lies on the loop's critical path: `--prefetch-late`)
+            nxt = batches[counter[0] % len(batches)]
+            model.prefetch_batch(*topo_args(nxt), pos=nxt["pos"] if prefetch == "pos" else None, num_graphs=graphs)
         mean = dp_backward(model, loss, always_reduce=dist is not None, overlap=overlap)  # (one rank under torch.distributed.run: RCCL still runs)
         optim.clip_grad_norm_(model.parameters(), 3000.0)
         opt.step()
         if not reuse_batch:
             # the batch's cached topology is dropped: the next step's is built from scratch, either inside its get_loss
-            # or -- `prefetch` -- right here on a side stream while the GPU works on this step (a loader's prefetch)
-            model._batches.clear()
-            if prefetch:
+            # or -- `prefetch` -- on a side stream while the GPU works on this step
+            if early:
+                model._batches = [e for e in model._batches if e[2] is not used[0]]
+            else:
+                model._batches.clear()
+            if prefetch and not early:
                 nxt = batches[counter[0] % len(batches)]
                 # (prefetch == "pos": the next step's draws, diffusion and edge lists are built ahead too and its forward
                 # starts without the host wait for the edge counts -- same generator consumption, same results; measured
@@ -598,7 +612,7 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist, prefet
 
 def bench_train_main(args, model, dev, rank, world, dist):
     dt, last, N, flops = run_train(model, args.graphs, args.steps, args.warmup, args.reuse_batch, dev, rank, dist,
-                                   prefetch=False if args.no_prefetch else ("pos" if args.prefetch_pos else True),
+                                   prefetch=False if args.no_prefetch else ("pos" if args.prefetch_pos else ("late" if args.prefetch_late else True)),
                                    overlap=True if args.three_range_reduce else (False if args.single_range_reduce else None))
     tmax = torch.tensor([dt], device=dev)
     if dist is not None:
