@@ -350,7 +350,7 @@ typedef struct tsd_batch {
                                                host balances it by pair count).  NULL: no fused encoder */
     int32_t num_units;
     int32_t reserved2;                      /* 0 (0.5 selected experimental two-team forms of the fused encoder here; they were
-                                               removed in 0.6: measured equal to the general kernel) */
+                                               removed in 0.6: measured equal to the general kernel, docs/NOTEBOOK.md) */
 } tsd_batch;
 
 size_t tsd_forward_workspace_floats(const tsd_model_cfg* cfg, int32_t num_nodes, int32_t num_pairs,

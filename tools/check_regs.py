@@ -3,7 +3,7 @@
 
 Several kernels are built to a residency, not just to correctness: the one-launch forward and the block launches
 must keep TWO workgroups of 8 waves per CU (<= 128 VGPRs, AGPRs included: gfx950 has one unified file), the typed embedding
-tile THREE (<= 80), WITHOUT an occupancy cap, because under a cap the compiler spills beside the asm-issued load rings; the fused
+tile THREE (<= 80), WITHOUT an occupancy cap, because under a cap the compiler spills beside the asm-issued load rings (docs/NOTEBOOK.md, "what went wrong on the way to the one-launch kernel"); the fused
 per-unit encoder owns a CU (<= 256).  None of them may touch scratch memory.  A compiler bump that moves one of them
 over its line halves the occupancy silently -- this check reads the `.amdhsa` metadata of the `.verify.s` files that
 `make verify` already writes and fails the build instead.

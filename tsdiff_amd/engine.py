@@ -460,7 +460,7 @@ class DeviceBatch:
         fused encoder; test bits"""
         # the fused per-unit encoder: on by itself where it wins -- every unit one graph of more than 32 atoms (8 x 8
         # atom-block tiles; BASELINE configs[4]: -12 % step time) -- and off for small-molecule batches, where the
-        # materialised forms keep two workgroups per CU busy and measure faster (DESIGN.md 4c); "force": everywhere
+        # materialised forms keep two workgroups per CU busy and measure faster (DESIGN.md 4.3); "force": everywhere
         fe = OPTIONS.fused_encoder
         fused_on = fe == "force" or (bool(fe) and self.units_single_graph and not self.per_block)
         return ((0 if (OPTIONS.one_launch and not self.per_block) else 1) | (0 if OPTIONS.wide_filter_tiles else 2) |
