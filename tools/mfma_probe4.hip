@@ -164,6 +164,122 @@ __global__ __launch_bounds__(512) void probe(const float* __restrict__ A, const 
     }
 }
 
+
+// Register-blocked form (round 6): a wave owns RB row blocks x CB column blocks (RB x CB accumulators) and loads RB A fragments
+// (LDS) + CB B fragments (ring) per k-step for RB x CB products: with 2 x 2 the operand bytes per MFMA halve against the
+// product's 2 x 1.  NW waves per workgroup (NW x CB x 32 = 256 columns), tile of RB x 32 rows, f16 x 2 planes only.
+template <int RB, int CB, int NW, int R>
+__global__ __launch_bounds__(NW * 64) void probe_blk(const float* __restrict__ A, const uint16_t* __restrict__ Bp, int nrep,
+                                                      float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    constexpr int NP = 2, ROWS = RB * 32, PLANE = ROWS * LDA16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    for (int idx = tid; idx < ROWS * H; idx += NW * 64) {
+        const int row = idx / H, k = idx % H;
+        float r = A[(size_t)(blockIdx.x % 4) * 32 * H + idx % (128 * H)];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const uint16_t u = to16<false>(r);
+            r -= from16<false>(u);
+            smem[p * PLANE + row * LDA16 + k] = u;
+        }
+    }
+    __syncthreads();
+    const int col0 = wave * CB * 32;
+    constexpr int nout = H;
+    f32x16 acc[RB][CB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+    const uint16_t* aptr = smem + l31 * LDA16 + hi * 8;
+    unsigned voff = (unsigned)((hi * nout + col0 + l31) * 16);
+    constexpr int KSB = NP * 2 * nout * 16, PB = 2 * nout * 16;
+    for (int rep = 0; rep < nrep; ++rep) {
+        const char* base = reinterpret_cast<const char*>(Bp) + (size_t)(rep & 1) * KS * KSB;
+        f32x4 b[R][CB][NP];
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const char* sb = base + (size_t)i * KSB + p * PB + cb * 512;
+                    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[i][cb][p]) : "v"(voff), "s"(sb) : "memory");
+                }
+        static_for<0, KS>([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            constexpr int slot = ks % R;
+            const unsigned vo = voff;
+            const char* bs = base;
+            f32x4 a[RB][NP];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    a[rb][p] = *reinterpret_cast<const f32x4*>(aptr + p * PLANE + rb * 32 * LDA16 + ks * 16);
+            constexpr int younger = ((ks + R <= KS) ? R : KS - ks) - 1;
+            if constexpr (CB == 2)
+                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(b[slot][0][0]), "+v"(b[slot][0][1]), "+v"(b[slot][1][0]), "+v"(b[slot][1][1]) : "n"(younger * NP * CB) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(b[slot][0][0]), "+v"(b[slot][0][1]) : "n"(younger * NP * CB) : "memory");
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) {
+                    acc[rb][cb] = mfma16<false>(a[rb][0], b[slot][cb][1], acc[rb][cb]);
+                    acc[rb][cb] = mfma16<false>(a[rb][1], b[slot][cb][0], acc[rb][cb]);
+                    acc[rb][cb] = mfma16<false>(a[rb][0], b[slot][cb][0], acc[rb][cb]);
+                }
+            if constexpr (ks + R < KS) {
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        const char* sb = bs + (size_t)(ks + R) * KSB + p * PB + cb * 512;
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(b[slot][cb][p]) : "v"(vo), "s"(sb) : "memory");
+                    }
+            }
+        });
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[rb][cb][r];
+    out[(size_t)blockIdx.x * NW * 64 + tid] = s;
+}
+
+template <int RB, int CB, int NW, int R>
+static void run_blk(const char* name, int grid, int nrep, const float* A, const uint16_t* Bp, float* out, int wg_per_cu) {
+    constexpr int ROWS = RB * 32;
+    size_t lds = (size_t)2 * ROWS * LDA16 * 2;
+    const size_t want = (size_t)160 * 1024 / wg_per_cu - 512;
+    if (lds < want) lds = want;
+    if (lds > 160 * 1024) { printf("%-30s skipped (LDS)\n", name); return; }
+    auto kern = probe_blk<RB, CB, NW, R>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, 0, A, Bp, nrep, out);
+    hipEventRecord(e0, 0);
+    const int it = 10;
+    for (int w = 0; w < it; ++w) hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds, 0, A, Bp, nrep, out);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= it;
+    const double flop = (double)grid * nrep * ROWS * H * H * 2.0;
+    printf("%-22s rows %3d = %d x 32, %d col blocks per wave, %d waves, R %d, wg/cu %d, grid %5d: %8.2f us  %7.1f TFLOP/s(fp32-eq)\n", name,
+           ROWS, RB, CB, NW, R, wg_per_cu, grid, ms * 1e3, flop / (ms * 1e-3) / 1e12);
+}
+
 static std::vector<float> hA, hW;
 
 template <bool BF, int NP, int RB, int R, bool REGS>
@@ -241,6 +357,16 @@ static void suite(const char* tag, const float* A, const float* W, float* out, f
     run<BF, NP, 2, 4, false>(name, 256, 2, A, Bp, out, 1);
     run<BF, NP, 1, 4, false>(name, 256, 2, A, Bp, out, 1);
     run<BF, NP, 1, 4, false>(name, 256, 6, A, Bp, out, 1);
+    if (NP == 2 && !BF) {
+        // register-blocked forms: operand bytes per MFMA against the product's 2 x 1 (RB x CB)
+        for (int wpc : {1, 2}) {
+            run_blk<2, 1, 8, 3>("f16x2 blk 2x1 (product)", 2048, 16, A, Bp, out, wpc);
+            run_blk<2, 2, 4, 3>("f16x2 blk 2x2", 2048, 16, A, Bp, out, wpc);
+            run_blk<2, 2, 4, 2>("f16x2 blk 2x2", 2048, 16, A, Bp, out, wpc);
+            run_blk<4, 2, 4, 2>("f16x2 blk 4x2", 1024, 16, A, Bp, out, wpc);
+            run_blk<4, 1, 8, 3>("f16x2 blk 4x1", 1024, 16, A, Bp, out, wpc);
+        }
+    }
     printf("\n");
     hipFree(Bp);
 }
