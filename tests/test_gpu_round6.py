@@ -326,3 +326,70 @@ def test_batch_prefetched_with_its_positions_trains_bit_identically(dev):
     lb = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], other, g["bond_index"], g["bond_type"], g["batch"],
                         g["num_nodes_per_graph"], G)
     assert torch.equal(la, lb)
+
+
+def test_flat_gradient_form_of_the_training_step_is_bit_identical_and_falls_back(dev, monkeypatch):
+    """The flat form of the fused step's autograd node (round 6; tsdiff_amd/train_ops.py fused_train_loss): with parameters
+    that are views of one flat buffer and no .grad, autograd sees ONE leaf and the backward hands cached views of a
+    persistent flat gradient to the Parameters.  Three optimizer steps give bit-identical losses, gradients and parameters
+    to the per-parameter form (OPTIONS.train_flat_grad = False); an existing .grad (zero_grad(set_to_none=False),
+    accumulation) selects the per-parameter form with torch's accumulate semantics; a re-homed Parameter is noticed"""
+    from types import SimpleNamespace
+    from tsdiff_amd import optim, synth
+    from tsdiff_amd.options import OPTIONS
+    cfg = synth.DEFAULT_MODEL_CONFIG
+    G = 16
+    batches = [to_dev({k2: torch.from_numpy(v) for k2, v in synth.wb97xd3_like_batch(G, seed=970 + k).items()
+                       if isinstance(v, np.ndarray)}, dev) for k in range(2)]
+
+    def run(flat_form):
+        monkeypatch.setattr(OPTIONS, "train_flat_grad", flat_form)
+        model = make_model(cfg, 0, dev)
+        model.train()
+        opt = optim.get_optimizer(SimpleNamespace(type="adam", lr=5e-4, weight_decay=0.0, beta1=0.95, beta2=0.999), model)
+        torch.manual_seed(77)
+        torch.cuda.manual_seed_all(77)
+        out = []
+        for k in range(3):
+            g = batches[k % 2]
+            opt.zero_grad()
+            loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
+                                  g["batch"], g["num_nodes_per_graph"], G)
+            assert (loss.grad_fn is not None)
+            loss.mean().backward()
+            grads = torch.cat([p.grad.reshape(-1) for p in model.raw_params()]).clone()
+            optim.clip_grad_norm_(model.parameters(), 3000.0)
+            opt.step()
+            out.append((loss.detach().clone(), grads))
+        torch.cuda.synchronize()
+        used_flat = getattr(model, "_flat_grad_buf", None) is not None
+        return out, torch.cat([p.detach().reshape(-1) for p in model.raw_params()]).clone(), used_flat, model, opt
+    a, pa, fa, model, opt = run(True)
+    b, pb, fb, _, _ = run(False)
+    assert fa and not fb, "the flat form did not run where it should (or ran where it should not)"
+    for (la, ga), (lb, gb) in zip(a, b):
+        assert torch.equal(la, lb) and torch.equal(ga, gb)
+    assert torch.equal(pa, pb)
+    # an existing .grad: the per-parameter form, torch's accumulation (g + g)
+    monkeypatch.setattr(OPTIONS, "train_flat_grad", True)
+    g = batches[0]
+    args = (g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"],
+            g["num_nodes_per_graph"], G)
+    kw = dict(_time_step=torch.arange(G, device=dev) * 37 % 5000, _pos_noise=torch.randn(g["pos"].shape, device=dev))
+    opt.zero_grad()
+    model.get_loss(*args, **kw).mean().backward()
+    g1 = [p.grad.clone() for p in model.raw_params()]
+    model.get_loss(*args, **kw).mean().backward()   # .grad exists: accumulate
+    for p, x in zip(model.raw_params(), g1):
+        assert torch.allclose(p.grad, 2.0 * x, rtol=1e-6, atol=0.0)
+    # a Parameter re-homed outside the flat buffer is noticed: the step falls back to the per-parameter form (which copies
+    # the parameters into a fresh flat vector) instead of training on the stale copy
+    opt.zero_grad()
+    p0 = model.raw_params()[3]
+    p0.data = p0.data.clone() * 1.5
+    l_moved = model.get_loss(*args, **kw)
+    ref = make_model(cfg, 0, dev)
+    ref.load_state_dict(model.state_dict())
+    ref.train()
+    l_ref = ref.get_loss(*args, **kw)
+    assert torch.equal(l_moved, l_ref)

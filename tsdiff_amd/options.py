@@ -16,6 +16,7 @@ at import, by `TSDIFF_*` environment variables (read here and nowhere else); tes
 | train              | TSDIFF_TRAIN              | "fused" | training step: "fused" = forward + loss and the whole backward as two library calls (csrc/train_step.hip), "ops" = one autograd node per operation (same kernels; the cross-check) |
 | train_gemm         | TSDIFF_TRAIN_GEMM         | "h2"    | arithmetic of the fused training step's tile GEMMs: "f32" = fp32-input MFMA, "h2" = split-f16 operands (gradient operands scaled by a power of two per tensor).  A step whose activations leave the f16 range is recomputed in "f32" |
 | train_fallback_latch | TSDIFF_TRAIN_FALLBACK_LATCH | 16 | split-f16 training step: a step whose activations leave the f16 range is recomputed in fp32 and the NEXT step tries split-f16 again (`model._h2_range_trips` counts the trips); this many trips IN A ROW latch the model to fp32 (each trip costs a second forward) |
+| train_flat_grad    | TSDIFF_TRAIN_FLAT_GRAD    | True    | fused training step with parameters that are views of one flat buffer (optim.get_optimizer) and carry no .grad: autograd sees ONE flat leaf instead of ~80 parameters, and the backward hands out cached views of a persistent flat gradient as the Parameters' .grad (−0.5 ms of host time per step).  Same gradients, bit for bit; the .grad tensors of consecutive steps share memory (as with zero_grad(set_to_none=False)) and torch.autograd.grad(loss, parameters) does not see the parameters; False: one autograd input per parameter |
 | dp_overlap         | TSDIFF_DP_OVERLAP         | False   | data-parallel training step (distributed.dp_backward): all-reduce the interaction blocks' gradient range (83 % of the flat vector) early on a side stream beside the rest of the backward pass, head and tail behind it (three collectives); False: ONE all-reduce of the flat gradient behind the backward pass.  Off by default since round 6: +0.14 ms of host time per step against <= 0.11 ms of hidden communication on 8 ranks over xGMI while the step is host-bound.  Same gradients either way |
 | train_side_lane    | TSDIFF_TRAIN_SIDE_LANE    | True    | split-f16 training step: the backward's small latency-bound gradient launches (embedding tables, narrow layers) run on a stream of the library's own beside the batched weight gradients; False: everything on the caller's stream.  Bit-identical |
 """
@@ -41,6 +42,7 @@ class Options:
     train_fallback_latch: int = 16
     train_side_lane: bool = True
     dp_overlap: bool = False
+    train_flat_grad: bool = True
 
     @classmethod
     def from_env(cls):
@@ -49,7 +51,8 @@ class Options:
                 fused_step_tail=_flag("TSDIFF_FUSED_TAIL"), fused_encoder=_flag("TSDIFF_FUSED_ENCODER"),
                 train=os.environ.get("TSDIFF_TRAIN", "fused"), train_gemm=os.environ.get("TSDIFF_TRAIN_GEMM", "h2"),
                 train_fallback_latch=int(os.environ.get("TSDIFF_TRAIN_FALLBACK_LATCH", "16")),
-                train_side_lane=_flag("TSDIFF_TRAIN_SIDE_LANE"), dp_overlap=_flag("TSDIFF_DP_OVERLAP", False))
+                train_side_lane=_flag("TSDIFF_TRAIN_SIDE_LANE"), dp_overlap=_flag("TSDIFF_DP_OVERLAP", False),
+                train_flat_grad=_flag("TSDIFF_TRAIN_FLAT_GRAD"))
         o.validate()
         return o
 

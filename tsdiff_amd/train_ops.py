@@ -539,8 +539,12 @@ class FusedTrainLoss(torch.autograd.Function):
         ctx.stamp = (db.geo_gen, model._train_ws_gen)
         # the live flat buffer is read again by backward (weights of the dgrads): an optimizer step or any other
         # in-place update of a parameter in between would differentiate against other weights than the forward used
-        ctx.param_versions = (flat._version + sum(p._version for p in params)) if live else None
-        ctx.params = params if live else None
+        # (flat form: `params` is the one flat leaf; the versions that move are the real Parameters')
+        real = getattr(model, "_flat_real_params", None) if (len(params) == 1 and params[0] is getattr(model, "_flat_leaf", None)) else None
+        ctx.flat_form = real is not None
+        vparams = real if real is not None else params
+        ctx.param_versions = (flat._version + sum(p._version for p in vparams)) if live else None
+        ctx.params = vparams if live else None
         ctx.used = False
         ctx.model, ctx.db, ctx.raw, ctx.ws, ctx.counts, ctx.pos = model, db, raw, ws, counts, pos_perturbed
         ctx.sizes = [p.numel() for p in params]
@@ -571,7 +575,15 @@ class FusedTrainLoss(torch.autograd.Function):
                 "another loss?): the fused training step differentiates against the live flat parameter buffer.  "
                 "Call backward before stepping, or set TSDIFF_TRAIN=ops.")
         ctx.used = True
-        grad = torch.empty_like(ctx.raw)
+        if ctx.flat_form:
+            # ONE persistent flat gradient per model: its per-parameter views are made once and handed out again every step
+            # (80 views + 80 AccumulateGrad nodes per step were ~0.5 ms of a 2-ms loop that is as long as its host side)
+            grad = getattr(ctx.model, "_flat_grad_buf", None)
+            if grad is None or grad.shape != ctx.raw.shape or grad.device != ctx.raw.device:
+                grad = ctx.model._flat_grad_buf = torch.empty_like(ctx.raw)
+                ctx.model._flat_grad_views = None
+        else:
+            grad = torch.empty_like(ctx.raw)
         dloss = _c(dloss.float()).view(-1)
         # data-parallel step (distributed.dp_backward set `_dp_early_reduce`): the interaction blocks' gradients -- one
         # contiguous range, 83 % of the vector -- are final long before the call's last kernel; the library records an
@@ -629,10 +641,53 @@ class FusedTrainLoss(torch.autograd.Function):
                 early(grad[off:off + cnt])
             grad.record_stream(side)
             ctx.model._dp_early_done = (side, off, cnt)
-        views = [g.view(s) for g, s in zip(grad.split(ctx.sizes), ctx.shapes)]  # views of ONE flat buffer
         ctx.model._flat_grad = grad  # (distributed.dp_backward all-reduces it in place)
+        if ctx.flat_form:
+            real = ctx.params
+            views = ctx.model._flat_grad_views
+            if views is None:
+                views = ctx.model._flat_grad_views = [g.view(p.shape) for g, p in zip(grad.split([p.numel() for p in real]), real)]
+            if all(p.grad is None for p in real):
+                for p, v in zip(real, views):
+                    p.grad = v
+            else:  # a .grad appeared between get_loss and backward: torch's accumulate semantics
+                for p, v in zip(real, views):
+                    p.grad = v.clone() if p.grad is None else p.grad + v
+            return (None, None, None, None, None, None)
+        views = [g.view(s) for g, s in zip(grad.split(ctx.sizes), ctx.shapes)]  # views of ONE flat buffer
         return (None, None, None, None, None) + tuple(views)
 
 
 def fused_train_loss(model, db, pos0, pos_perturbed, a_graph):
-    return FusedTrainLoss.apply(model, db, pos0, pos_perturbed, a_graph, *model.raw_params())
+    """The flat form (round 6): when the parameters are views of ONE flat buffer (optim.flatten_parameters: what
+    optim.get_optimizer sets up) and none of them carries a .grad, autograd sees ONE leaf -- a tensor that shares the flat
+    buffer's storage -- instead of ~80 parameters; the backward writes a persistent flat gradient and assigns its cached
+    per-parameter views to the Parameters' .grad itself.  Same gradients, bit for bit; what differs from torch's default:
+    the .grad tensors of consecutive steps are views of the SAME memory (as with zero_grad(set_to_none=False)), and
+    torch.autograd.grad(loss, parameters) does not see the parameters (OPTIONS.train_flat_grad = False, or any existing
+    .grad, selects the per-parameter form)."""
+    params = model.raw_params()
+    flat = getattr(model, "_flat_param", None)
+    if OPTIONS.train_flat_grad and flat is not None and flat.is_cuda and all(p.grad is None for p in params):
+        from . import optim
+        cache = getattr(model, "_flat_leaf_key", None)
+        key = (flat._cdata, tuple(id(p) for p in params))
+        if cache != key:
+            ok = optim._views_of(params, flat)
+            model._flat_leaf_key = key
+            model._flat_leaf = flat.detach().requires_grad_(True) if ok else None
+            model._flat_real_params = list(params) if ok else None
+            model._flat_grad_views = None
+            offs, o = [], 0
+            for p in params:
+                offs.append(o * flat.element_size())
+                o += p.numel()
+            model._flat_offsets = offs
+        if model._flat_leaf is not None:
+            # every step: the Parameters must still be the views they were made (a re-homed one -- p.data = ..., weight
+            # tying, a partial .to() -- would otherwise train on the stale copy in the flat buffer): one data_ptr() each
+            base = flat.data_ptr()
+            if all(p.data_ptr() == base + off for p, off in zip(params, model._flat_offsets)):
+                return FusedTrainLoss.apply(model, db, pos0, pos_perturbed, a_graph, model._flat_leaf)
+            model._flat_leaf_key = None  # (re-validated, or abandoned, at the next call)
+    return FusedTrainLoss.apply(model, db, pos0, pos_perturbed, a_graph, *params)
