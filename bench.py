@@ -92,12 +92,11 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true",
                     help="train workload only: the next batch's topology is built inside its get_loss (the default "
                          "builds it on a side stream during the current step, model.prefetch_batch)")
-    ap.add_argument("--prefetch-late", action="store_true",
-                    help="train workload only: build the next batch's topology behind opt.step() (rounds 3-5) instead of "
-                         "right behind get_loss")
-    ap.add_argument("--prefetch-pos", action="store_true",
-                    help="train workload only: prefetch the next batch WITH its positions (draws, diffusion and edge lists "
-                         "built ahead on the side stream: the step's forward does not wait on the host for the edge counts)")
+    ap.add_argument("--prefetch-mode", default="pos", choices=["pos", "pos-late", "early", "late"],
+                    help="train workload only: how the next batch is prefetched on the side stream.  pos (default since round "
+                         "6): right behind get_loss, WITH its positions -- the next step's draws, diffusion and edge lists are "
+                         "built ahead and its forward does not wait on the host for the edge counts; pos-late: the same behind "
+                         "opt.step(); early / late: the topology only (late = rounds 3-5)")
     ap.add_argument("--single-range-reduce", action="store_true",
                     help="train workload only: ONE all-reduce of the flat gradient behind the backward pass (the default since "
                          "round 6: tsdiff_amd.options dp_overlap)")
@@ -560,14 +559,17 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist, prefet
         loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
                               g["batch"], g["num_nodes_per_graph"], graphs)
         used[0] = model._batches[0][2]
-        early = prefetch and prefetch != "late" and not reuse_batch
+        mode = "pos" if prefetch is True else prefetch  # False | "late" | "early" | "pos" (early, with positions) | "pos-late"
+        early = bool(mode) and mode in ("early", "pos") and not reuse_batch
+        with_pos = bool(mode) and mode.startswith("pos")
         if early:
-            # The next batch's topology is built on a side stream (a loader's prefetch) RIGHT BEHIND get_loss: the host side
-            # of the build (0.3-0.5 ms of Python and a dozen launches) then runs while the GPU is in this step's forward,
-            # i.e. inside the time the backward call would otherwise spend waiting for the forward's range flag (round 6;
-            # behind opt.step(), as in rounds 3-5, the same host work lies on the loop's critical path: `--prefetch-late`)
+            # The next batch is built on a side stream (a loader's prefetch) RIGHT BEHIND get_loss, with its positions: the
+            # next step's draws, diffusion and edge lists too, so that its forward starts without the host wait for the edge
+            # counts.  Measured in one process, interleaved blocks, with the flat form of the autograd node (round 6,
+            # profiles/r06_ab_train_prefetch.md): pos 1.849 ms/step median, pos-late 1.870, late (rounds 3-5) 1.915,
+            # early 1.993; none 2.2
             nxt = batches[counter[0] % len(batches)]
-            model.prefetch_batch(*topo_args(nxt), pos=nxt["pos"] if prefetch == "pos" else None, num_graphs=graphs)
+            model.prefetch_batch(*topo_args(nxt), pos=nxt["pos"] if with_pos else None, num_graphs=graphs)
         mean = dp_backward(model, loss, always_reduce=dist is not None, overlap=overlap)  # (one rank under torch.distributed.run: RCCL still runs)
         optim.clip_grad_norm_(model.parameters(), 3000.0)
         opt.step()
@@ -580,11 +582,7 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist, prefet
                 model._batches.clear()
             if prefetch and not early:
                 nxt = batches[counter[0] % len(batches)]
-                # (prefetch == "pos": the next step's draws, diffusion and edge lists are built ahead too and its forward
-                # starts without the host wait for the edge counts -- same generator consumption, same results; measured
-                # in-process against the topology-only form, tools/ab_train_prefetch.py: 1.95 vs 1.89 ms/step median,
-                # 1.90 vs 1.89 minimum -- the loop is as long as its host side, which the form does not shorten: opt-in)
-                model.prefetch_batch(*topo_args(nxt), pos=nxt["pos"] if prefetch == "pos" else None, num_graphs=graphs)
+                model.prefetch_batch(*topo_args(nxt), pos=nxt["pos"] if with_pos else None, num_graphs=graphs)
         return mean
     if not reuse_batch:
         model._batches.clear()
@@ -612,7 +610,7 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist, prefet
 
 def bench_train_main(args, model, dev, rank, world, dist):
     dt, last, N, flops = run_train(model, args.graphs, args.steps, args.warmup, args.reuse_batch, dev, rank, dist,
-                                   prefetch=False if args.no_prefetch else ("pos" if args.prefetch_pos else ("late" if args.prefetch_late else True)),
+                                   prefetch=False if args.no_prefetch else args.prefetch_mode,
                                    overlap=True if args.three_range_reduce else (False if args.single_range_reduce else None))
     tmax = torch.tensor([dt], device=dev)
     if dist is not None:
@@ -629,9 +627,11 @@ def bench_train_main(args, model, dev, rank, world, dist):
             "config": {"workload": "configs[3] training step", "graphs_per_gpu": args.graphs, "atoms_per_gpu": N,
                        "batch_topology": "one batch reused" if args.reuse_batch else
                        ("rebuilt every step inside get_loss" if args.no_prefetch else
-                        ("topology, draws, diffusion and edge lists of the next step built on a side stream during the "
-                         "previous step (prefetch_batch(pos=...)): no host wait for the edge counts" if args.prefetch_pos
-                         else "rebuilt every step, on a side stream during the previous step (prefetch_batch)")),
+                        {"pos": "topology, draws, diffusion and edge lists of the next step built on a side stream right behind "
+                                "get_loss (prefetch_batch(pos=...)): no host wait for the edge counts",
+                         "pos-late": "the same behind opt.step()",
+                         "early": "topology rebuilt every step on a side stream right behind get_loss (prefetch_batch)",
+                         "late": "topology rebuilt every step on a side stream behind opt.step() (prefetch_batch)"}[args.prefetch_mode]),
                        "parallelism": f"graph-batch data parallel over {world} GPU(s), RCCL all-reduce of the flat fp32 "
                                       "gradient per step: " + ("three ranges, the interaction blocks' 83 % early on a side stream"
                                                                if args.three_range_reduce else "one range behind the backward pass"),
