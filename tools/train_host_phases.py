@@ -34,14 +34,19 @@ def step(i, rec):
     opt.zero_grad(); t = lap("zero_grad", t) if rec else t
     loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"], g["batch"], g["num_nodes_per_graph"], G)
     t = lap("get_loss (forward)", t) if rec else t
+    if mode == "pos":
+        nxt = batches[(i + 1) % 8]
+        model.prefetch_batch(*topo(nxt), pos=nxt["pos"], num_graphs=G)
+        t = lap("prefetch", t) if rec else t
     dp_backward(model, loss); t = lap("dp_backward", t) if rec else t
     optim.clip_grad_norm_(model.parameters(), 3000.0); t = lap("clip", t) if rec else t
     opt.step(); t = lap("adam", t) if rec else t
+    if mode == "pos":
+        model._batches = model._batches[:1]
+        return
     model._batches.clear()
     nxt = batches[(i + 1) % 8]
-    if mode == "pos":
-        model.prefetch_batch(*topo(nxt), pos=nxt["pos"], num_graphs=G)
-    elif mode == "topology":
+    if mode == "topology":
         model.prefetch_batch(*topo(nxt))
     t = lap("prefetch", t) if rec else t
 gc.collect(); gc.freeze()

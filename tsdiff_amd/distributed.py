@@ -95,6 +95,14 @@ def dp_backward(model, loss_nodes, group=None, reduce_fn=None, always_reduce=Fal
         overlap = bool(OPTIONS.dp_overlap)
     distributed = reduce_fn is not None or (dist.is_initialized() and (always_reduce or dist.get_world_size(group) > 1))
     reduce = reduce_fn if reduce_fn is not None else (lambda t: _all_reduce_sum(t, group))
+    if not distributed:
+        # one process: the global node count is this rank's -- d(mean)/d(loss_i) = 1/N as ONE fill launch instead of the
+        # sum / stack / divide graph below and its three backward launches (same value: both are the correctly rounded
+        # fp32 quotient 1/N)
+        n = float(loss_nodes.shape[0])
+        model._dp_early_reduce = None
+        loss_nodes.backward(gradient=loss_nodes.new_full(loss_nodes.shape, 1.0 / n) if n > 0 else torch.zeros_like(loss_nodes))
+        return loss_nodes.detach().sum() / max(n, 1.0)
     # (new_full is a fill kernel: torch.tensor(x, device=cuda) would be a synchronous host-to-device copy, i.e.
     # a hidden stream sync between the forward and the backward pass)
     total = loss_nodes.sum()
