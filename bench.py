@@ -92,11 +92,12 @@ def parse():
     ap.add_argument("--no-prefetch", action="store_true",
                     help="train workload only: the next batch's topology is built inside its get_loss (the default "
                          "builds it on a side stream during the current step, model.prefetch_batch)")
-    ap.add_argument("--prefetch-mode", default="pos", choices=["pos", "pos-late", "early", "late"],
-                    help="train workload only: how the next batch is prefetched on the side stream.  pos (default since round "
-                         "6): right behind get_loss, WITH its positions -- the next step's draws, diffusion and edge lists are "
-                         "built ahead and its forward does not wait on the host for the edge counts; pos-late: the same behind "
-                         "opt.step(); early / late: the topology only (late = rounds 3-5)")
+    ap.add_argument("--prefetch-mode", default="auto", choices=["auto", "pos", "pos-late", "early", "late"],
+                    help="train workload only: how the next batch is prefetched on the side stream.  pos: right behind get_loss, "
+                         "WITH its positions -- the next step's draws, diffusion and edge lists are built ahead and its forward "
+                         "does not wait on the host for the edge counts; pos-late: the same behind opt.step(); early / late: "
+                         "the topology only (late = rounds 3-5); auto (default since round 6): pos in one process, pos-late "
+                         "under torch.distributed")
     ap.add_argument("--single-range-reduce", action="store_true",
                     help="train workload only: ONE all-reduce of the flat gradient behind the backward pass (the default since "
                          "round 6: tsdiff_amd.options dp_overlap)")
@@ -559,7 +560,10 @@ def run_train(model, graphs, steps, warmup, reuse_batch, dev, rank, dist, prefet
         loss = model.get_loss(g["atom_type"], g["r_feat"], g["p_feat"], g["pos"], g["bond_index"], g["bond_type"],
                               g["batch"], g["num_nodes_per_graph"], graphs)
         used[0] = model._batches[0][2]
-        mode = "pos" if prefetch is True else prefetch  # False | "late" | "early" | "pos" (early, with positions) | "pos-late"
+        # False | "late" | "early" | "pos" (early, with positions) | "pos-late"; True / "auto": pos in one process, pos-late under
+        # torch.distributed (an early prefetch in front of dp_backward's collectives measured 2.5-2.7 ms/step under a one-rank
+        # RCCL group against 2.0 for the late placements: the side-stream build and the collective's stream hand-overs collide)
+        mode = ("pos" if dist is None else "pos-late") if prefetch in (True, "auto") else prefetch
         early = bool(mode) and mode in ("early", "pos") and not reuse_batch
         with_pos = bool(mode) and mode.startswith("pos")
         if early:
@@ -627,7 +631,10 @@ def bench_train_main(args, model, dev, rank, world, dist):
             "config": {"workload": "configs[3] training step", "graphs_per_gpu": args.graphs, "atoms_per_gpu": N,
                        "batch_topology": "one batch reused" if args.reuse_batch else
                        ("rebuilt every step inside get_loss" if args.no_prefetch else
-                        {"pos": "topology, draws, diffusion and edge lists of the next step built on a side stream right behind "
+                        {"auto": "topology, draws, diffusion and edge lists of the next step built on a side stream "
+                                 "(prefetch_batch(pos=...): no host wait for the edge counts) " +
+                                 ("right behind get_loss" if dist is None else "behind opt.step()"),
+                         "pos": "topology, draws, diffusion and edge lists of the next step built on a side stream right behind "
                                 "get_loss (prefetch_batch(pos=...)): no host wait for the edge counts",
                          "pos-late": "the same behind opt.step()",
                          "early": "topology rebuilt every step on a side stream right behind get_loss (prefetch_batch)",
