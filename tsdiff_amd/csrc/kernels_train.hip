@@ -460,6 +460,63 @@ __device__ __forceinline__ void wgrad_reduce_body(int64_t nW, int nB, int S, con
 // threads of a reduce launch: 16 wave groups when the split list is long
 static inline int reduce_threads(int S) { return S >= 64 ? 1024 : 256; }
 
+// The batched reduce with FOUR consecutive outputs per lane (round 6): 16-byte loads and stores, a quarter of the workgroups.
+// Work items [0, nW / 4) are weight quads, [nW / 4, nW / 4 + nB) single bias sums; per element the same additions in the same
+// order as wgrad_reduce_body (splits of a wave group in order, the groups by the same fixed tree): bit-identical.
+__global__ __launch_bounds__(1024) void wgrad_reduce_batch4_kernel(int64_t nW, int nB, int S, const float* __restrict__ part,
+                                                                  const float* __restrict__ bias_part, WgradOutBatch o,
+                                                                  int accumulate) {
+    __shared__ f32x4 sm[16][64];
+    const int k = blockIdx.y;
+    part += (size_t)k * S * nW;
+    bias_part += (size_t)k * S * nB;
+    float* __restrict__ dW = o.it[k].dW;
+    float* __restrict__ db = o.it[k].db;
+    if (db == nullptr) nB = 0;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6, Q = blockDim.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane, nQ = nW / 4;
+    const int per = (S + Q - 1) / Q;
+    const int k0 = min(S, q * per), k1 = min(S, (q + 1) * per);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < nQ) {
+        for (int kk = k0; kk < k1; ++kk) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(part + (size_t)kk * nW + 4 * i);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[c] += v[c];
+        }
+    } else if (i < nQ + nB) {
+        for (int kk = k0; kk < k1; ++kk) s[0] += bias_part[(size_t)kk * nB + (i - nQ)];
+    }
+    sm[q][lane] = s;
+    __syncthreads();
+    if (q == 0) {
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (Q == 16) {
+                float t[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    t[g] = (sm[4 * g][lane][c] + sm[4 * g + 1][lane][c]) + (sm[4 * g + 2][lane][c] + sm[4 * g + 3][lane][c]);
+                v[c] = (t[0] + t[1]) + (t[2] + t[3]);
+            } else {
+                v[c] = (sm[0][lane][c] + sm[1][lane][c]) + (sm[2][lane][c] + sm[3][lane][c]);
+            }
+        }
+        if (i < nQ) {
+            f32x4* d = reinterpret_cast<f32x4*>(dW + 4 * i);
+            if (accumulate) {
+                const f32x4 old = *d;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = old[c] + v[c];
+            }
+            *d = v;
+        } else if (i < nQ + nB) {
+            db[i - nQ] = accumulate ? db[i - nQ] + v[0] : v[0];
+        }
+    }
+}
+
 // wgrad of the narrow layers (Linear(1,H), Linear(25,H/2), Linear(H/2,1)): dW[o,i] = sum_r dY[r,o] X[r,i], in <= 32.
 // Same two-stage column reduction as the bias gradient with `in` accumulators per thread:
 // stage 1: grid (out/64, CS_CHUNKS) -> part[chunk][o*in + i]; stage 2: sums the chunks in order.
@@ -514,7 +571,7 @@ __global__ __launch_bounds__(256) void wgrad_small_kernel(int rows, int in, int 
 // ---------------------------------------------------------------------------------------------
 // All dense weights of a training step packed by ONE launch (forward layout and transposed dgrad layout):
 // the optimizer changes every weight every step, so per-call packing cost 86 launches (0.4 ms) per step.
-#define TSD_PACK_MAX 48
+#define TSD_PACK_MAX 128  // (3.5 KB of kernel arguments per launch; 48 until round 6: a training step packs ~230 items)
 struct PackBatch {
     const float* W[TSD_PACK_MAX];
     float* dst[TSD_PACK_MAX];
@@ -1109,6 +1166,17 @@ int launch_wgrad_batch(int n, int rows, int in, int out, const float* const* dY,
         } else
         hipLaunchKernelGGL(wgrad_batch_kernel, dim3(in / 128, out / 128, m * S), dim3(WG_NT), 0, st, rows, in, out, per,
                            S, b, part, bpart);
+        // (dW of a 128 x 128-blocked layer is 16-byte aligned in every caller: the flat gradient's matrices start at multiples
+        // of 4 floats -- checked, the scalar form otherwise)
+#ifndef TSD_REDUCE4
+#define TSD_REDUCE4 1  // 0 (A/B builds): the one-output-per-lane reduce of rounds 1-5
+#endif
+        bool quad = TSD_REDUCE4 != 0 && nW % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
+        for (int k = 0; k < m && quad; ++k) quad = (reinterpret_cast<uintptr_t>(o.it[k].dW) & 15) == 0;
+        if (quad)
+            hipLaunchKernelGGL(wgrad_reduce_batch4_kernel, dim3((unsigned)((nW / 4 + out + 63) / 64), m), dim3(reduce_threads(S)),
+                               0, st, nW, out, S, part, bpart, o, accumulate);
+        else
         hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)((nW + out + 63) / 64), m), dim3(reduce_threads(S)),
                            0, st, nW, out, S, part, bpart, o, accumulate);
     }

@@ -939,7 +939,11 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
         // accumulates), the attribute gradient of every embedded pair (rows [0, Eu) enc_u edges, rows [Eu, Eu + Ed)
         // the out edges' own), dh when there is no pair to write it
         const int edge_blocks = (int)nblk(Eo);
-        const ZeroRange z0{grad, x.R.total}, z1{w.d_ea, (size_t)(Eu + Ed) * H}, z2{w.dh, Eo > 0 ? (size_t)0 : NH};
+        // (third range: dh when there is no pair to write it -- else, split-f16 step, the running-max words of the backward's
+        // dY tensors, which were a memset launch of their own until round 6)
+        const bool z_amax = h2 && Eo > 0 && H == 256;
+        const ZeroRange z0{grad, x.R.total}, z1{w.d_ea, (size_t)(Eu + Ed) * H},
+            z2{z_amax ? w.amax : w.dh, z_amax ? 5 * (size_t)L + 6 : (Eo > 0 ? (size_t)0 : NH)};
         const size_t zfloats = z0.n + z1.n + z2.n;
         const int zero_blocks = (int)std::min<size_t>(2048, (zfloats / 4 + 255) / 256 + 1);
         hipLaunchKernelGGL(bwd_head_kernel, dim3(edge_blocks + zero_blocks), dim3(256), 0, st, g.out_u, edge_blocks, pos,
@@ -954,7 +958,6 @@ int tsd_train_backward2(const tsd_model_cfg* cfg, const tsd_batch* batch, const 
             // (split-f16 step: the chain on f16 MFMA, the weight gradients with dY scaled by the maxima it kept; their X --
             // gs0, hp -- passed the range check of the split-f16 forward's pair tiles)
             float* pamax = w.amax + 2 * L;
-            if (h2) TSD_HIP(hipMemsetAsync(w.amax, 0, (5 * (size_t)L + 6) * sizeof(float), st));
             TSD_TRY(launch_pair_bwd(H, Eo, g.out_u, g.attr_row, ds, raw + x.R.out_w2, w.g1, w.g0,
                                     (h2 ? w.pack_t16 : w.pack_t) + x.R.out_w1, (h2 ? w.pack_t16 : w.pack_t) + x.R.out_w0, dg1,
                                     dg0, dp, w.d_ea, PU, PU - Eu, st, h2 ? pamax : nullptr));
