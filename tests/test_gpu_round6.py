@@ -382,6 +382,16 @@ def test_flat_gradient_form_of_the_training_step_is_bit_identical_and_falls_back
     model.get_loss(*args, **kw).mean().backward()   # .grad exists: accumulate
     for p, x in zip(model.raw_params(), g1):
         assert torch.allclose(p.grad, 2.0 * x, rtol=1e-6, atol=0.0)
+    # a frozen parameter, or a tensor hook on one: the per-parameter form (a frozen parameter gets no .grad, the hook fires)
+    opt.zero_grad()
+    frozen = model.raw_params()[5]
+    frozen.requires_grad_(False)
+    fired = []
+    hk = model.raw_params()[7].register_hook(lambda gr: fired.append(1) or gr)
+    model.get_loss(*args, **kw).mean().backward()
+    assert frozen.grad is None and fired == [1] and model.raw_params()[6].grad is not None
+    frozen.requires_grad_(True)
+    hk.remove()
     # a Parameter re-homed outside the flat buffer is noticed: the step falls back to the per-parameter form (which copies
     # the parameters into a fresh flat vector) instead of training on the stale copy
     opt.zero_grad()

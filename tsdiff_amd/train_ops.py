@@ -668,7 +668,11 @@ def fused_train_loss(model, db, pos0, pos_perturbed, a_graph):
     .grad, selects the per-parameter form)."""
     params = model.raw_params()
     flat = getattr(model, "_flat_param", None)
-    if OPTIONS.train_flat_grad and flat is not None and flat.is_cuda and all(p.grad is None for p in params):
+    # (every parameter trainable and hook-free: a frozen parameter must not receive a .grad, tensor hooks and
+    # post-accumulate-grad hooks only fire on the per-parameter path)
+    if OPTIONS.train_flat_grad and flat is not None and flat.is_cuda and \
+            all(p.grad is None and p.requires_grad and not p._backward_hooks and
+                not getattr(p, "_post_accumulate_grad_hooks", None) for p in params):
         from . import optim
         cache = getattr(model, "_flat_leaf_key", None)
         key = (flat._cdata, tuple(id(p) for p in params))
