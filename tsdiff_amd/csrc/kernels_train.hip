@@ -504,13 +504,18 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_batch4_kernel(int64_t nW, i
             }
         }
         if (i < nQ) {
-            f32x4* d = reinterpret_cast<f32x4*>(dW + 4 * i);
-            if (accumulate) {
-                const f32x4 old = *d;
+            if ((reinterpret_cast<uintptr_t>(dW) & 15) == 0) {
+                f32x4* d = reinterpret_cast<f32x4*>(dW + 4 * i);
+                if (accumulate) {
+                    const f32x4 old = *d;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) v[c] = old[c] + v[c];
+                    for (int c = 0; c < 4; ++c) v[c] = old[c] + v[c];
+                }
+                *d = v;
+            } else {  // (a matrix that starts off a 16-byte boundary in the flat gradient: edge_cat.*, behind the 1-float out_b2)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dW[4 * i + c] = accumulate ? dW[4 * i + c] + v[c] : v[c];
             }
-            *d = v;
         } else if (i < nQ + nB) {
             db[i - nQ] = accumulate ? db[i - nQ] + v[0] : v[0];
         }
@@ -1166,13 +1171,11 @@ int launch_wgrad_batch(int n, int rows, int in, int out, const float* const* dY,
         } else
         hipLaunchKernelGGL(wgrad_batch_kernel, dim3(in / 128, out / 128, m * S), dim3(WG_NT), 0, st, rows, in, out, per,
                            S, b, part, bpart);
-        // (dW of a 128 x 128-blocked layer is 16-byte aligned in every caller: the flat gradient's matrices start at multiples
-        // of 4 floats -- checked, the scalar form otherwise)
+        // (the partials are 16-byte aligned; a dW that is not -- checked per problem in the kernel -- is written by scalar stores)
 #ifndef TSD_REDUCE4
 #define TSD_REDUCE4 1  // 0 (A/B builds): the one-output-per-lane reduce of rounds 1-5
 #endif
-        bool quad = TSD_REDUCE4 != 0 && nW % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
-        for (int k = 0; k < m && quad; ++k) quad = (reinterpret_cast<uintptr_t>(o.it[k].dW) & 15) == 0;
+        const bool quad = TSD_REDUCE4 != 0 && nW % 4 == 0 && (reinterpret_cast<uintptr_t>(part) & 15) == 0;
         if (quad)
             hipLaunchKernelGGL(wgrad_reduce_batch4_kernel, dim3((unsigned)((nW / 4 + out + 63) / 64), m), dim3(reduce_threads(S)),
                                0, st, nW, out, S, part, bpart, o, accumulate);
