@@ -229,7 +229,10 @@ def test_split_f16_forward_on_weights_the_package_trained_itself(dev, monkeypatc
     against the fp32 oracle"""
     from oracle import tsdiff_oracle as O
     from tests.tools.split_f16_sweep import rel_elementwise, run_case, trained_state_dict
-    from tsdiff_amd import synth
+    from tsdiff_amd import engine, synth
+    from tsdiff_amd.options import OPTIONS
+    monkeypatch.setattr(engine.OPTIONS, "gemm", "h2")       # (the defaults, whatever TSDIFF_* the environment carries)
+    monkeypatch.setattr(OPTIONS, "train_gemm", "h2")
     cfg = synth.DEFAULT_MODEL_CONFIG
     sd, trips, losses = trained_state_dict(cfg, 300, dev)
     assert trips == 0, f"{trips} split-f16 range trips while training"
