@@ -190,7 +190,15 @@ class EnsembleSampler(nn.Module):
                     pos_traj += list(host.clone().unbind(0))  # (plain pageable tensors, as the reference returns)
                 elif return_traj:
                     pos_traj += list(traj.cpu().unbind(0))
-            status = int(status_host[0]) if status_host is not None else int(db.status[0].item())  # the host sync of the loop
+            if status_host is None:
+                # (the status word through pinned memory as well: a pageable .item() is a staged blocking copy, ~30 us of the
+                # ~0.17 ms a call costs beside its steps)
+                status_host = getattr(db, "_status_pin", None)
+                if status_host is None:
+                    status_host = db._status_pin = torch.empty(1, dtype=torch.int32).pin_memory()
+                status_host.copy_(db.status[:1], non_blocking=True)
+                torch.cuda.current_stream(dev).synchronize()
+            status = int(status_host[0])  # the host sync of the loop
             if db.status_fallback(status):
                 # the whole call again, same draws (injected, or the same Philox seed), in the form that cannot fail
                 # that way: an activation left the f16 range -> fp32-MFMA kernels; a bounded in-kernel wait of the
