@@ -429,7 +429,9 @@ typedef struct tsd_sampler_state {
 } tsd_sampler_state;
 typedef struct tsd_sampler_plan tsd_sampler_plan;
 
-/* Captures one step on `stream` (must not be the legacy default stream) into a graph; nothing executes.
+/* Captures the step on `stream` (must not be the legacy default stream) into graphs of 8, 4, 2 and 1 consecutive steps
+ * (0.7: all of them here, so that no later call pays for a capture; a run of n steps is n / 8 launches of the longest and at
+ * most one each of the others); nothing executes.
  * `batch`'s arrays, `pos` [N,3] (updated in place by every step) and `state` must stay alive and unmoved
  * for the life of the plan.  kind 0 = LD, 1 = DDPM; clip_pos < 0: no clamp. */
 int tsd_sampler_plan_create(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t kind, float clip,
@@ -442,8 +444,8 @@ int tsd_sampler_plan_run(tsd_sampler_plan* plan, int32_t n_steps, const tsd_run_
 /* The caller must have synchronised with every stream the plan was run on. */
 void tsd_sampler_plan_destroy(tsd_sampler_plan* plan);
 
-/* One-shot form: plan_create + plan_run + stream synchronise + plan_destroy (use the plan calls to keep the
- * graph across calls).  noises NULL: device Philox with (seed, offset). */
+/* One-shot form: a plan that captures only the graphs this call's n_steps needs + plan_run + stream synchronise +
+ * plan_destroy (use the plan calls to keep the graphs across calls).  noises NULL: device Philox with (seed, offset). */
 int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t kind, int32_t n_steps,
                     const float* coefs, const float* noises, uint64_t seed, uint64_t offset, float clip,
                     float clip_pos, float* pos, float* traj, tsd_sampler_state* state, int32_t use_graph,

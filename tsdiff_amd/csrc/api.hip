@@ -434,7 +434,12 @@ static int step_impl(const tsd_model_cfg& c, const tsd_batch& b, int kind, float
 // (round 3: a second graph of TSD_PLAN_MULTI consecutive steps -- consecutive graph launches are ~9 us apart on the
 // device, kernels inside a graph are back to back -- captured on the first call that runs that many steps; every
 // per-step value comes from the device-side step counter / ticket, so a step is the same wherever it is replayed from)
+// (round 6: graphs of 8, 4, 2 and 1 steps -- a call of n steps is n / 8 launches of the longest and at most three more, where
+// the 8 + 1 form of rounds 3-5 ran the remainder step by step (the driver's 20-step call: 3 launches instead of 6) -- and
+// tsd_sampler_plan_create captures them ALL, so that the first long call of a plan no longer pays for a capture.)
 constexpr int TSD_PLAN_MULTI = 8;
+constexpr int TSD_PLAN_SIZES = 4;                                  // graphs of 8, 4, 2, 1 steps
+constexpr int TSD_PLAN_STEPS[TSD_PLAN_SIZES] = {TSD_PLAN_MULTI, 4, 2, 1};
 struct tsd_sampler_plan {
     tsd_model_cfg cfg;
     tsd_batch batch;
@@ -442,10 +447,8 @@ struct tsd_sampler_plan {
     float clip, clip_pos;
     float* pos;
     tsd_sampler_state* state;
-    hipGraph_t graph;
-    hipGraphExec_t exec;
-    hipGraph_t graph_multi;
-    hipGraphExec_t exec_multi;
+    hipGraph_t graph[TSD_PLAN_SIZES];
+    hipGraphExec_t exec[TSD_PLAN_SIZES];
 };
 
 namespace tsd {
@@ -820,6 +823,20 @@ int tsd_philox_normal(uint64_t seed, uint64_t offset, int64_t n_atoms, float* ou
     return launch_philox_normal(seed, offset, n_atoms, out, (hipStream_t)stream);
 }
 
+// capture + instantiate the graph of TSD_PLAN_STEPS[i] consecutive steps (nothing executes)
+static int plan_capture(tsd_sampler_plan* p, int i, hipStream_t st) {
+    if (p->exec[i] != nullptr) return TSD_OK;
+    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) return check_hip(e, "hipStreamBeginCapture");
+    int r = TSD_OK;
+    for (int q = 0; q < TSD_PLAN_STEPS[i] && r == TSD_OK; ++q)
+        r = step_impl(p->cfg, p->batch, p->kind, p->clip, p->clip_pos, p->pos, p->state, st);
+    e = hipStreamEndCapture(st, &p->graph[i]);
+    if (r == TSD_OK) r = check_hip(e, "hipStreamEndCapture");
+    if (r == TSD_OK) r = check_hip(hipGraphInstantiate(&p->exec[i], p->graph[i], nullptr, nullptr, 0), "hipGraphInstantiate");
+    return r;
+}
+
 int tsd_sampler_plan_create(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t kind, float clip,
                             float clip_pos, float* pos, tsd_sampler_state* state, void* stream,
                             tsd_sampler_plan** plan_out) {
@@ -831,19 +848,10 @@ int tsd_sampler_plan_create(const tsd_model_cfg* cfg, const tsd_batch* batch, in
     TSD_REQUIRE(kind == 0 || kind == 1, "kind=%d (0 = ld, 1 = ddpm)", kind);
     TSD_REQUIRE(stream != nullptr, "stream capture is illegal on the legacy default stream: pass a created stream");
     hipStream_t st = (hipStream_t)stream;
-    tsd_sampler_plan* p = new tsd_sampler_plan{*cfg, *batch, kind, clip, clip_pos, pos, state, nullptr, nullptr, nullptr, nullptr};
-    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) {
-        delete p;
-        return check_hip(e, "hipStreamBeginCapture");
-    }
-    r = step_impl(p->cfg, p->batch, kind, clip, clip_pos, pos, state, st);
-    e = hipStreamEndCapture(st, &p->graph);
-    if (r == TSD_OK) r = check_hip(e, "hipStreamEndCapture");
-    if (r == TSD_OK) r = check_hip(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0), "hipGraphInstantiate");
+    tsd_sampler_plan* p = new tsd_sampler_plan{*cfg, *batch, kind, clip, clip_pos, pos, state, {}, {}};
+    for (int i = TSD_PLAN_SIZES - 1; i >= 0 && r == TSD_OK; --i) r = plan_capture(p, i, st);  // (1 step first: errors surface early)
     if (r != TSD_OK) {
-        if (p->graph) (void)hipGraphDestroy(p->graph);
-        delete p;
+        tsd_sampler_plan_destroy(p);
         return r;
     }
     *plan_out = p;
@@ -880,37 +888,26 @@ int tsd_sampler_plan_run(tsd_sampler_plan* plan, int32_t n_steps, const tsd_run_
         return r;
     }
     int k = 0;
-    if (use_graph && n_steps >= TSD_PLAN_MULTI) {
-        if (!plan->exec_multi) {  // first long call on this plan: capture TSD_PLAN_MULTI steps (nothing executes)
-            hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-            if (e != hipSuccess) return check_hip(e, "hipStreamBeginCapture");
-            for (int q = 0; q < TSD_PLAN_MULTI && r == TSD_OK; ++q)
-                r = step_impl(plan->cfg, b, plan->kind, plan->clip, plan->clip_pos, plan->pos, plan->state, st);
-            e = hipStreamEndCapture(st, &plan->graph_multi);
-            if (r == TSD_OK) r = check_hip(e, "hipStreamEndCapture");
-            if (r == TSD_OK)
-                r = check_hip(hipGraphInstantiate(&plan->exec_multi, plan->graph_multi, nullptr, nullptr, 0),
-                              "hipGraphInstantiate");
-            if (r != TSD_OK) return r;
-        }
-        for (; k + TSD_PLAN_MULTI <= n_steps; k += TSD_PLAN_MULTI) TSD_HIP(hipGraphLaunch(plan->exec_multi, st));
-    }
-    for (; k < n_steps; ++k) {
-        if (use_graph) {
-            TSD_HIP(hipGraphLaunch(plan->exec, st));
-        } else if ((r = step_impl(plan->cfg, b, plan->kind, plan->clip, plan->clip_pos, plan->pos, plan->state, st))) {
-            return r;
+    if (use_graph) {
+        // longest graphs first: n / 8 launches of the 8-step graph, then at most one each of 4, 2, 1
+        for (int i = 0; i < TSD_PLAN_SIZES; ++i) {
+            const int sz = TSD_PLAN_STEPS[i];
+            if (k + sz > n_steps) continue;
+            if ((r = plan_capture(plan, i, st))) return r;  // (a plan from tsd_sampler_plan_create holds them all already)
+            for (; k + sz <= n_steps; k += sz) TSD_HIP(hipGraphLaunch(plan->exec[i], st));
         }
     }
+    for (; k < n_steps; ++k)
+        if ((r = step_impl(plan->cfg, b, plan->kind, plan->clip, plan->clip_pos, plan->pos, plan->state, st))) return r;
     return TSD_OK;
 }
 
 void tsd_sampler_plan_destroy(tsd_sampler_plan* plan) {
     if (!plan) return;
-    if (plan->exec) (void)hipGraphExecDestroy(plan->exec);
-    if (plan->graph) (void)hipGraphDestroy(plan->graph);
-    if (plan->exec_multi) (void)hipGraphExecDestroy(plan->exec_multi);
-    if (plan->graph_multi) (void)hipGraphDestroy(plan->graph_multi);
+    for (int i = 0; i < TSD_PLAN_SIZES; ++i) {
+        if (plan->exec[i]) (void)hipGraphExecDestroy(plan->exec[i]);
+        if (plan->graph[i]) (void)hipGraphDestroy(plan->graph[i]);
+    }
     delete plan;
 }
 
@@ -921,15 +918,14 @@ int tsd_sampler_run(const tsd_model_cfg* cfg, const tsd_batch* batch, int32_t ki
     TraceRange range("tsd:sampler_run");
     tsd_sampler_plan* plan = nullptr;
     int r;
-    if (use_graph) {
-        if ((r = tsd_sampler_plan_create(cfg, batch, kind, clip, clip_pos, pos, state, stream, &plan))) return r;
-    } else {  // eager: no capture, the same kernels launched one by one
-        if ((r = check_cfg(cfg))) return r;
-        if ((r = check_batch(*cfg, batch))) return r;
-        TSD_REQUIRE(pos && state, "null pointer");
-        TSD_REQUIRE(kind == 0 || kind == 1, "kind=%d (0 = ld, 1 = ddpm)", kind);
-        plan = new tsd_sampler_plan{*cfg, *batch, kind, clip, clip_pos, pos, state, nullptr, nullptr, nullptr, nullptr};
-    }
+    // a bare plan: the one-shot form captures only the graphs its own n_steps needs (tsd_sampler_plan_run does, lazily);
+    // use_graph == 0: no capture at all, the same kernels launched one by one
+    if ((r = check_cfg(cfg))) return r;
+    if ((r = check_batch(*cfg, batch))) return r;
+    TSD_REQUIRE(pos && state, "null pointer");
+    TSD_REQUIRE(kind == 0 || kind == 1, "kind=%d (0 = ld, 1 = ddpm)", kind);
+    TSD_REQUIRE(!use_graph || stream != nullptr, "stream capture is illegal on the legacy default stream: pass a created stream");
+    plan = new tsd_sampler_plan{*cfg, *batch, kind, clip, clip_pos, pos, state, {}, {}};
     const tsd_run_args args{coefs, noises, traj, seed, offset};
     r = tsd_sampler_plan_run(plan, n_steps, &args, use_graph, stream);
     // the exec object must outlive its launches: wait for the stream before destroying it
