@@ -1,5 +1,8 @@
 #!/bin/bash
 # round 6: every measurement of the round at one HEAD in one gpurun call (tools/gpu.sh --timeout 3300 -- 'bash tools/r06_final.sh')
+# Variant libraries it compares against (git-ignored, built here before the call):
+#   tools/build_variant.sh agg_old "-DTSD_AGW_MIN_ROWS=0" kernels_misc.hip      (the one-wave-per-row aggregation)
+#   tools/bin/lib_r05.so: `make -C tsdiff_amd/csrc ../libtsdiff_hip.so` in a worktree of commit 1c4256b (round 5), copied
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out; R=r06
 python3 -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' 2>&1 | tail -2
