@@ -834,6 +834,8 @@ static int plan_capture(tsd_sampler_plan* p, int i, hipStream_t st) {
     e = hipStreamEndCapture(st, &p->graph[i]);
     if (r == TSD_OK) r = check_hip(e, "hipStreamEndCapture");
     if (r == TSD_OK) r = check_hip(hipGraphInstantiate(&p->exec[i], p->graph[i], nullptr, nullptr, 0), "hipGraphInstantiate");
+    // (the executable graph's one-time upload now, not inside its first launch; best effort)
+    if (r == TSD_OK) (void)hipGraphUpload(p->exec[i], st);
     return r;
 }
 
