@@ -57,9 +57,9 @@ def test_pair_role_behind_many_node_tiles_with_half_the_pairs_cut_off(graphs, n,
 
 def test_internal_status_fallback_form_has_no_waiting_pair_role(dev, monkeypatch):
     """the form the host falls back to after TSD_STATUS_INTERNAL (tsd_batch.reserved bit 0) must not
-    contain the waiting pair role either.  Fault injection on a block-launch batch (reserved bit 3 would only hit the
-    one-launch kernel), so: run the fallback form directly on a batch past the one-launch size and check that the stand-alone
-    pair kernel ran (roctx-free check: the ready words of the workspace stay zero -- no node tile published to a pair role)"""
+    contain the waiting pair role either (api.hip forward_impl: bit 0 selects the stand-alone pair launch).  The fault
+    injection bit only reaches the one-launch kernel, so the fallback form is selected directly -- what status_fallback does --
+    on a batch past the one-launch size: it carries reserved bit 0 and gives the default form's result bit for bit"""
     from tsdiff_amd import engine, synth
     cfg = synth.DEFAULT_MODEL_CONFIG
     b, t, g = _sparse_big_batch(120, 44, 14.0, 3, dev)
